@@ -1,0 +1,315 @@
+/*
+ * oracle/ref_build/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A thin C-ABI shim around the *reference's own* literal-matcher hot path,
+ * compiled in place from /root/reference/src (never copied into this repo):
+ *
+ *   hwlmBuildProto / hwlmBuild   src/hwlm/hwlm_build.cpp:121-215
+ *   hwlmExec                     src/hwlm/hwlm.c:172-199
+ *   fdrBuildProtoHinted          src/fdr/fdr_compile.cpp:900-911  (engine forcing, as unit/internal/fdr.cpp:140-150)
+ *   fdrExec                      src/fdr/fdr.c:827-851
+ *   shuftiBuildMasks/shuftiExec  src/nfa/shufticompile.cpp:54, src/nfa/shufti.c:150
+ *   truffleBuildMasks/truffleExec src/nfa/trufflecompile.cpp:59, src/nfa/truffle.c:118
+ *   vermicelliExec & friends     src/nfa/vermicelli.h:42-518
+ *
+ * Built into oracle/_ref/libhsref.so by oracle/ref_build/Makefile.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only
+ * as the checker / the timed CPU baseline -- never from the product path.
+ */
+#include "config.h"
+
+#include "hs_compile.h"
+#include "grey.h"
+#include "hwlm/hwlm.h"
+#include "hwlm/hwlm_build.h"
+#include "hwlm/hwlm_internal.h"
+#include "hwlm/hwlm_literal.h"
+#include "fdr/fdr.h"
+#include "fdr/fdr_compile.h"
+#include "fdr/fdr_compile_internal.h"
+#include "fdr/fdr_engine_description.h"
+#include "fdr/teddy_engine_description.h"
+#include "fdr/fdr_internal.h"
+#include "nfa/shufticompile.h"
+#include "nfa/trufflecompile.h"
+#include "util/bytecode_ptr.h"
+#include "util/charreach.h"
+#include "util/compile_context.h"
+#include "util/target_info.h"
+#include "scratch.h"
+
+extern "C" {
+#include "nfa/shufti.h"
+#include "nfa/truffle.h"
+#include "nfa/vermicelli.h"
+}
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace ue2;
+
+extern "C" {
+
+typedef struct hsref_lit {
+    const uint8_t *s;
+    uint32_t len;
+    uint32_t id;
+    uint8_t nocase;
+    uint8_t noruns;
+    uint8_t pad[2];
+    uint32_t msk_len;
+    uint64_t groups;
+    const uint8_t *msk;
+    const uint8_t *cmp;
+} hsref_lit_t;
+
+typedef uint64_t (*hsref_cb_t)(size_t end, uint32_t id, void *ctx);
+
+} // extern "C"
+
+namespace {
+
+struct RefTable {
+    bytecode_ptr<HWLM> hwlm; // normal path (hwlmExec)
+    bytecode_ptr<FDR> fdr;   // hinted path (fdrExec directly)
+    std::string info;
+};
+
+struct CallCtx {
+    hsref_cb_t cb;
+    void *user;
+    uint64_t count;
+};
+
+// The reference callback receives only (end, id, scratch); route the caller's
+// context through a thread-local exactly as a unit test would through a global.
+static thread_local CallCtx *tl_ctx = nullptr;
+
+extern "C" hwlmcb_rv_t trampoline(size_t end, u32 id, struct hs_scratch *) {
+    return (hwlmcb_rv_t)tl_ctx->cb(end, id, tl_ctx->user);
+}
+
+extern "C" hwlmcb_rv_t counting_cb(size_t, u32, struct hs_scratch *) {
+    tl_ctx->count++;
+    return HWLM_CONTINUE_MATCHING;
+}
+
+target_t make_target(int isa) {
+    if (isa == 0) {
+        return get_current_target();
+    }
+    hs_platform_info pi;
+    memset(&pi, 0, sizeof(pi));
+    pi.tune = HS_TUNE_FAMILY_GENERIC;
+    pi.cpu_features = (isa >= 2) ? HS_CPU_FEATURES_AVX2 : 0;
+    return target_t(pi);
+}
+
+std::vector<hwlmLiteral> to_lits(const hsref_lit_t *lits, size_t n) {
+    std::vector<hwlmLiteral> v;
+    v.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        const hsref_lit_t &l = lits[i];
+        std::vector<u8> msk, cmp;
+        if (l.msk_len) {
+            msk.assign(l.msk, l.msk + l.msk_len);
+            cmp.assign(l.cmp, l.cmp + l.msk_len);
+        }
+        v.emplace_back(std::string((const char *)l.s, l.len), l.nocase != 0,
+                       l.noruns != 0, l.id, (hwlm_group_t)l.groups, msk, cmp);
+    }
+    return v;
+}
+
+CharReach to_cr(const uint8_t bitmap[32]) {
+    CharReach cr;
+    for (unsigned c = 0; c < 256; c++) {
+        if (bitmap[c / 8] & (1u << (c % 8))) {
+            cr.set(c);
+        }
+    }
+    return cr;
+}
+
+} // namespace
+
+extern "C" {
+
+/* isa: 0 = this host's ISA (get_current_target), 1 = force no-AVX2 target,
+ * 2 = force AVX2 target.  hint: engine id as in unit/internal/fdr.cpp, or
+ * 0xffffffff for the reference's own choice via hwlmBuildProto. */
+void *hsref_hwlm_build(const hsref_lit_t *lits, size_t n, int make_small,
+                       uint32_t hint, int isa) {
+    try {
+        std::vector<hwlmLiteral> v = to_lits(lits, n);
+        target_t target = make_target(isa);
+        Grey grey;
+        std::unique_ptr<RefTable> t(new RefTable);
+        char buf[160];
+        if (hint != 0xffffffffu) {
+            auto proto = fdrBuildProtoHinted(HWLM_ENGINE_FDR, v, make_small != 0,
+                                             hint, target, grey);
+            if (!proto) {
+                return nullptr;
+            }
+            t->fdr = fdrBuildTable(*proto, grey);
+            if (!t->fdr) {
+                return nullptr;
+            }
+            snprintf(buf, sizeof(buf), "fdrExec engineID=%u size=%zu (hinted %u)",
+                     t->fdr->engineID, fdrSize(t->fdr.get()), hint);
+        } else {
+            CompileContext cc(false, false, target, grey);
+            auto proto = hwlmBuildProto(v, make_small != 0, cc);
+            if (!proto) {
+                return nullptr;
+            }
+            t->hwlm = hwlmBuild(*proto, cc);
+            if (!t->hwlm) {
+                return nullptr;
+            }
+            const HWLM *h = t->hwlm.get();
+            if (h->type == HWLM_ENGINE_NOOD) {
+                snprintf(buf, sizeof(buf), "hwlmExec type=noodle size=%zu",
+                         hwlmSize(h));
+            } else {
+                const FDR *f = (const FDR *)HWLM_C_DATA(h);
+                snprintf(buf, sizeof(buf),
+                         "hwlmExec type=fdr engineID=%u domain=%u stride=%u size=%zu",
+                         f->engineID, (unsigned)f->domain, (unsigned)f->stride,
+                         hwlmSize(h));
+            }
+        }
+        t->info = buf;
+        return t.release();
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+void hsref_hwlm_free(void *h) { delete (RefTable *)h; }
+
+const char *hsref_hwlm_info(void *h) { return ((RefTable *)h)->info.c_str(); }
+
+static int run_one(RefTable *t, const uint8_t *buf, size_t len, size_t start,
+                   HWLMCallback cb, uint64_t groups) {
+    struct hs_scratch scratch; // as unit/internal/fdr.cpp:180-183
+    scratch.fdr_conf = NULL;
+    if (t->fdr) {
+        return (int)fdrExec(t->fdr.get(), buf, len, start, cb, &scratch,
+                            (hwlm_group_t)groups);
+    }
+    return (int)hwlmExec(t->hwlm.get(), buf, len, start, cb, &scratch,
+                         (hwlm_group_t)groups);
+}
+
+/* Mirror of hwlmExec (src/hwlm/hwlm.h:116-118) with a user context. */
+int hsref_hwlm_exec(void *h, const uint8_t *buf, size_t len, size_t start,
+                    hsref_cb_t cb, void *ctx, uint64_t groups) {
+    CallCtx c{cb, ctx, 0};
+    CallCtx *prev = tl_ctx;
+    tl_ctx = &c;
+    int rv = run_one((RefTable *)h, buf, len, start, trampoline, groups);
+    tl_ctx = prev;
+    return rv;
+}
+
+/* hsbench-style block loop (tools/hsbench/main.cpp:502-528 with the counting
+ * callback of engine_hyperscan.cpp:89-97): scan blocks [off[i], off[i+1]) of
+ * base, return total number of matches. Used as the timed CPU baseline. */
+uint64_t hsref_hwlm_count_blocks(void *h, const uint8_t *base,
+                                 const uint64_t *off, size_t nblocks,
+                                 size_t start, uint64_t groups) {
+    CallCtx c{nullptr, nullptr, 0};
+    CallCtx *prev = tl_ctx;
+    tl_ctx = &c;
+    for (size_t i = 0; i < nblocks; i++) {
+        run_one((RefTable *)h, base + off[i], (size_t)(off[i + 1] - off[i]),
+                start, counting_cb, groups);
+    }
+    tl_ctx = prev;
+    return c.count;
+}
+
+/* ---- character-class accelerators ---- */
+
+/* returns number of shufti buckets used, or -1 if the class is not
+ * representable (src/nfa/shufticompile.cpp:54-109). */
+int hsref_shufti_build(const uint8_t bitmap[32], uint8_t lo[16], uint8_t hi[16]) {
+    return shuftiBuildMasks(to_cr(bitmap), lo, hi);
+}
+
+void hsref_truffle_build(const uint8_t bitmap[32], uint8_t m1[16], uint8_t m2[16]) {
+    truffleBuildMasks(to_cr(bitmap), m1, m2);
+}
+
+void hsref_truffle2cr(const uint8_t m1[16], const uint8_t m2[16], uint8_t bitmap[32]) {
+    CharReach cr = truffle2cr(m1, m2);
+    memset(bitmap, 0, 32);
+    for (size_t c = cr.find_first(); c != cr.npos; c = cr.find_next(c)) {
+        bitmap[c / 8] |= 1u << (c % 8);
+    }
+}
+
+static m128 ld128(const uint8_t *p) {
+    m128 v;
+    memcpy(&v, p, 16);
+    return v;
+}
+
+/* All exec wrappers return an offset relative to buf (len = "not found" for
+ * forward scans; -1 for reverse scans), see src/nfa/shufti.h:40-52. */
+int64_t hsref_shufti_exec(const uint8_t lo[16], const uint8_t hi[16],
+                          const uint8_t *buf, size_t len) {
+    return shuftiExec(ld128(lo), ld128(hi), buf, buf + len) - buf;
+}
+int64_t hsref_rshufti_exec(const uint8_t lo[16], const uint8_t hi[16],
+                           const uint8_t *buf, size_t len) {
+    return rshuftiExec(ld128(lo), ld128(hi), buf, buf + len) - buf;
+}
+int64_t hsref_truffle_exec(const uint8_t m1[16], const uint8_t m2[16],
+                           const uint8_t *buf, size_t len) {
+    return truffleExec(ld128(m1), ld128(m2), buf, buf + len) - buf;
+}
+int64_t hsref_rtruffle_exec(const uint8_t m1[16], const uint8_t m2[16],
+                            const uint8_t *buf, size_t len) {
+    return rtruffleExec(ld128(m1), ld128(m2), buf, buf + len) - buf;
+}
+int64_t hsref_verm_exec(uint8_t c, int nocase, const uint8_t *buf, size_t len) {
+    return vermicelliExec((char)c, (char)nocase, buf, buf + len) - buf;
+}
+int64_t hsref_nverm_exec(uint8_t c, int nocase, const uint8_t *buf, size_t len) {
+    return nvermicelliExec((char)c, (char)nocase, buf, buf + len) - buf;
+}
+int64_t hsref_dverm_exec(uint8_t c1, uint8_t c2, int nocase, const uint8_t *buf,
+                         size_t len) {
+    return vermicelliDoubleExec((char)c1, (char)c2, (char)nocase, buf, buf + len) - buf;
+}
+int64_t hsref_rverm_exec(uint8_t c, int nocase, const uint8_t *buf, size_t len) {
+    return rvermicelliExec((char)c, (char)nocase, buf, buf + len) - buf;
+}
+
+/* which engine ids are valid for hints on this host (unit/internal/fdr.cpp:114-137) */
+size_t hsref_valid_engines(uint32_t *out, size_t cap, int isa) {
+    target_t target = make_target(isa);
+    std::vector<uint32_t> ret;
+    std::vector<FDREngineDescription> fd;
+    getFdrDescriptions(&fd);
+    for (const auto &d : fd) {
+        if (d.isValidOnTarget(target)) ret.push_back(d.getID());
+    }
+    std::vector<TeddyEngineDescription> td;
+    getTeddyDescriptions(&td);
+    for (const auto &d : td) {
+        if (d.isValidOnTarget(target)) ret.push_back(d.getID());
+    }
+    for (size_t i = 0; i < ret.size() && i < cap; i++) out[i] = ret[i];
+    return ret.size();
+}
+
+} // extern "C"
