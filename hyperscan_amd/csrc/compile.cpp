@@ -1,0 +1,388 @@
+/*
+ * compile.cpp -- host-side literal compiler for the GPU scan engine.
+ *
+ * Plays the role of the reference's hwlmBuildProto/hwlmBuild
+ * (src/hwlm/hwlm_build.cpp:121-215) and of the FDR/Teddy table and confirm
+ * compilers behind it (src/fdr/fdr_compile.cpp:589-632 setupTab,
+ * src/fdr/teddy_compile.cpp:439-509 fillNibbleMasks,
+ * src/fdr/fdr_confirm_compile.cpp:73-290), but produces this engine's own
+ * tables (table.h) -- the reference's bucket/domain/stride machinery is an x86
+ * cache-and-PSHUFB design and is deliberately not reproduced.
+ *
+ * What IS reproduced exactly is the match predicate: each literal becomes the
+ * (v, msk, size) triple of the reference's LitInfo (fillLitInfo,
+ * fdr_confirm_compile.cpp:73-127), so that "(conf_key & msk) == v" on the eight
+ * bytes ending at `end` decides a match in both implementations.
+ *
+ * Filter design: every literal is keyed on its last 4 (class A), 3 (class B) or
+ * <= 2 (class C) bytes, whichever keeps the number of concrete key variants
+ * (case bits / mask wildcards enumerated) small. Each variant sets one bit in
+ * the hashed LDS filter and owns an entry in an exact hash table that lists the
+ * literals to confirm.
+ */
+#include "internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <unordered_map>
+
+static thread_local std::string g_last_error;
+
+void hsgpu_set_error(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char *hsgpu_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *hsgpu_version(void) { return "hsgpu 0.1 (gfx950)"; }
+
+namespace {
+
+bool is_alpha(uint8_t c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+uint64_t right_aligned_u64(const uint8_t *p, uint32_t len) {
+    uint64_t m = 0;
+    uint32_t n = std::min<uint32_t>(len, 8);
+    memcpy((uint8_t *)&m + 8 - n, p + len - n, n);
+    return m;
+}
+
+/* hwlmLiteral constructor checks (hwlm_literal.cpp:57-115) + LitInfo fill. */
+int normalise(const hsgpu_lit_t &l, size_t index, HsgpuDevLit &o) {
+    if (l.len > HSGPU_LITERAL_MAX_LEN || l.msk_len > HSGPU_MASKLEN) {
+        hsgpu_set_error("literal %zu: length %u / mask length %u exceeds 8", index, l.len, l.msk_len);
+        return HSGPU_COMPILER_ERROR;
+    }
+    if ((l.len && !l.s) || (l.msk_len && (!l.msk || !l.cmp))) {
+        hsgpu_set_error("literal %zu: null pointer", index);
+        return HSGPU_COMPILER_ERROR;
+    }
+    if (l.id == 0xffffffffu) { /* reserved, hwlm_build.cpp:190 */
+        hsgpu_set_error("literal %zu: id 0xffffffff is reserved", index);
+        return HSGPU_COMPILER_ERROR;
+    }
+    uint32_t mlen = l.msk_len;
+    bool all_zero = true;
+    for (uint32_t j = 0; j < mlen; j++) all_zero &= (l.msk[j] == 0);
+    if (all_zero) mlen = 0;
+    if (l.len == 0 && mlen == 0) {
+        hsgpu_set_error("literal %zu: empty literal", index);
+        return HSGPU_COMPILER_ERROR;
+    }
+    uint64_t msk = ~0ULL, val = 0;
+    for (uint32_t j = 0; j < 8; j++) {
+        uint32_t sh = (7 - j) * 8;
+        if (j >= l.len) {
+            msk &= ~(0xffULL << sh);
+        } else {
+            uint8_t c = l.s[l.len - j - 1];
+            if (l.nocase && is_alpha(c)) {
+                msk &= ~(0x20ULL << sh);
+                val |= (uint64_t)(c & 0xdf) << sh;
+            } else {
+                val |= (uint64_t)c << sh;
+            }
+        }
+    }
+    if (mlen) {
+        uint64_t lm = right_aligned_u64(l.msk, mlen), lc = right_aligned_u64(l.cmp, mlen);
+        /* maskIsConsistent (hwlm_literal.cpp:57-79): where both constrain a bit
+         * they must agree; cmp may not set bits outside msk. */
+        uint64_t both = lm & msk;
+        if ((val & both) != (lc & both) || (lc & ~lm)) {
+            hsgpu_set_error("literal %zu: msk/cmp inconsistent with the literal", index);
+            return HSGPU_COMPILER_ERROR;
+        }
+        msk |= lm;
+        val |= lc;
+    }
+    o.v = val;
+    o.msk = msk;
+    o.groups = l.groups;
+    o.id = l.id;
+    o.size = (uint8_t)std::max(mlen, l.len);
+    o.flags = l.noruns ? HSGPU_LIT_NORUNS : 0;
+    o.pad = 0;
+    return HSGPU_SUCCESS;
+}
+
+struct KeyChoice {
+    int cls; /* 0 = A (4 bytes), 1 = B (3 bytes), 2 = C (2 bytes) */
+};
+
+inline uint32_t popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+
+KeyChoice choose_class(const HsgpuDevLit &l) {
+    uint32_t m4 = (uint32_t)(l.msk >> 32), m3 = m4 >> 8, m2 = m4 >> 16;
+    uint32_t wa = popc(~m4), wb = popc(~m3 & 0xffffffu), wc = popc(~m2 & 0xffffu);
+    (void)wc;
+    if (wa <= 4) return {0};
+    if (wb <= 4) return {1};
+    if (wa <= 8) return {0};
+    if (wb <= 8) return {1};
+    return {2};
+}
+
+/* call f(key) for every value of (v | sub) over all submasks sub of wild */
+template <class F> void for_each_variant(uint32_t v, uint32_t wild, F f) {
+    uint32_t sub = 0;
+    do {
+        f(v | sub);
+        sub = (sub - wild) & wild;
+    } while (sub != 0);
+}
+
+uint32_t ceil_log2(uint64_t x) {
+    uint32_t k = 0;
+    while ((1ULL << k) < x) k++;
+    return k;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+} // namespace
+
+uint32_t hsgpu_blob_checksum(const uint8_t *blob, size_t len) {
+    uint32_t a = 1, b = 0;
+    for (size_t i = sizeof(HsgpuTableHeader); i < len; i++) {
+        a = (a + blob[i]) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    return (b << 16) | a;
+}
+
+int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::vector<uint8_t> &blob) {
+    (void)flags;
+    if (!lits || n == 0) {
+        hsgpu_set_error("no literals");
+        return HSGPU_COMPILER_ERROR;
+    }
+    if (n > (1u << 24)) {
+        hsgpu_set_error("too many literals (%zu)", n);
+        return HSGPU_COMPILER_ERROR;
+    }
+    std::vector<HsgpuDevLit> dl(n);
+    for (size_t i = 0; i < n; i++) {
+        int rv = normalise(lits[i], i, dl[i]);
+        if (rv != HSGPU_SUCCESS) return rv;
+    }
+
+    /* key -> literal indices, per class (literal order preserved inside a list) */
+    std::unordered_map<uint32_t, std::vector<uint32_t>> keys[3];
+    uint32_t n_cls[3] = {0, 0, 0}, max_size = 0;
+    for (size_t i = 0; i < n; i++) {
+        const HsgpuDevLit &l = dl[i];
+        max_size = std::max<uint32_t>(max_size, l.size);
+        int cls = choose_class(l).cls;
+        n_cls[cls]++;
+        uint32_t m4 = (uint32_t)(l.msk >> 32), v4 = (uint32_t)(l.v >> 32);
+        uint32_t v, wild;
+        if (cls == 0) {
+            v = v4;
+            wild = ~m4;
+        } else if (cls == 1) {
+            v = v4 >> 8;
+            wild = ~(m4 >> 8) & 0xffffffu;
+        } else {
+            v = v4 >> 16;
+            wild = ~(m4 >> 16) & 0xffffu;
+        }
+        for_each_variant(v, wild, [&](uint32_t key) { keys[cls][key].push_back((uint32_t)i); });
+    }
+
+    const uint32_t entries = (uint32_t)(keys[0].size() + keys[1].size());
+    /* one bit per entry; aim at <= ~1.5% of bits set, within 16 KB .. 128 KB */
+    uint32_t k = std::min<uint32_t>(15, std::max<uint32_t>(12, ceil_log2((uint64_t)entries * 2)));
+    uint32_t ht_log2[2];
+    for (int c = 0; c < 2; c++) ht_log2[c] = std::max<uint32_t>(4, ceil_log2((uint64_t)keys[c].size() * 2 + 1));
+
+    uint32_t tflags = (n_cls[0] ? HSGPU_F_HAS_A : 0) | (n_cls[1] ? HSGPU_F_HAS_B : 0) | (n_cls[2] ? HSGPU_F_HAS_C : 0);
+
+    /* lists */
+    std::vector<uint32_t> lists;
+    auto add_list = [&](const std::vector<uint32_t> &v) -> uint32_t {
+        uint32_t ref = (uint32_t)lists.size() + 1;
+        for (size_t j = 0; j < v.size(); j++) lists.push_back(v[j] | (j + 1 == v.size() ? HSGPU_LIST_END : 0));
+        return ref;
+    };
+
+    /* layout */
+    size_t off = sizeof(HsgpuTableHeader);
+    HsgpuTableHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = HSGPU_TABLE_MAGIC;
+    h.version = HSGPU_TABLE_VERSION;
+    h.flags = tflags;
+    h.n_lits = (uint32_t)n;
+    h.max_size = max_size;
+    h.filter_log2_words = k;
+    h.filter_entries = entries;
+    h.ht_a_log2 = ht_log2[0];
+    h.ht_b_log2 = ht_log2[1];
+    h.n_a = n_cls[0];
+    h.n_b = n_cls[1];
+    h.n_c = n_cls[2];
+    h.off_filter = (uint32_t)off;
+    off += (size_t)4 << k;
+    h.off_c2bits = (uint32_t)off;
+    off += 2048 * 4;
+    h.off_ht_a = (uint32_t)off;
+    off += sizeof(HsgpuHtSlot) << ht_log2[0];
+    h.off_ht_b = (uint32_t)off;
+    off += sizeof(HsgpuHtSlot) << ht_log2[1];
+    h.off_c2ref = (uint32_t)off;
+    off += (tflags & HSGPU_F_HAS_C) ? 65536 * 4 : 16;
+
+    std::vector<uint32_t> filter((size_t)1 << k, 0), c2bits(2048, 0);
+    std::vector<HsgpuHtSlot> ht[2];
+    for (int c = 0; c < 2; c++) ht[c].assign((size_t)1 << ht_log2[c], HsgpuHtSlot{0, 0});
+    std::vector<uint32_t> c2ref((tflags & HSGPU_F_HAS_C) ? 65536 : 4, 0);
+
+    for (int c = 0; c < 2; c++) {
+        /* deterministic order: sort keys */
+        std::vector<uint32_t> ks;
+        ks.reserve(keys[c].size());
+        for (auto &kv : keys[c]) ks.push_back(kv.first);
+        std::sort(ks.begin(), ks.end());
+        for (uint32_t key : ks) {
+            uint32_t x24 = (c == 0) ? (key >> 8) : key; /* 3-byte suffix */
+            uint32_t prod = hsgpu_filter_prod(x24);
+            uint32_t a = hsgpu_filter_a(prod, k);
+            uint32_t bit = (c == 0) ? hsgpu_filter_bit_a(key & 0xff, a) : hsgpu_filter_bit_b(prod);
+            filter[a >> 2] |= 1u << bit;
+            uint32_t mask = ((uint32_t)1 << ht_log2[c]) - 1;
+            uint32_t s = hsgpu_ht_slot(key, ht_log2[c]);
+            while (ht[c][s].ref) s = (s + 1) & mask;
+            ht[c][s].key = key;
+            ht[c][s].ref = add_list(keys[c][key]);
+        }
+    }
+    {
+        std::vector<uint32_t> ks;
+        for (auto &kv : keys[2]) ks.push_back(kv.first);
+        std::sort(ks.begin(), ks.end());
+        for (uint32_t key : ks) {
+            c2bits[key >> 5] |= 1u << (key & 31);
+            c2ref[key] = add_list(keys[2][key]);
+        }
+    }
+    if (lists.empty()) lists.push_back(HSGPU_LIST_END);
+
+    h.off_lists = (uint32_t)off;
+    h.n_lists = (uint32_t)lists.size();
+    off += align_up(lists.size() * 4, 16);
+    h.off_lits = (uint32_t)off;
+    off += n * sizeof(HsgpuDevLit);
+    off = align_up(off, 16);
+    if (off > 0xfffffff0ull) {
+        hsgpu_set_error("compiled table too large");
+        return HSGPU_COMPILER_ERROR;
+    }
+    h.blob_bytes = (uint32_t)off;
+
+    blob.assign(off, 0);
+    memcpy(blob.data() + h.off_filter, filter.data(), filter.size() * 4);
+    memcpy(blob.data() + h.off_c2bits, c2bits.data(), c2bits.size() * 4);
+    memcpy(blob.data() + h.off_ht_a, ht[0].data(), ht[0].size() * sizeof(HsgpuHtSlot));
+    memcpy(blob.data() + h.off_ht_b, ht[1].data(), ht[1].size() * sizeof(HsgpuHtSlot));
+    memcpy(blob.data() + h.off_c2ref, c2ref.data(), c2ref.size() * 4);
+    memcpy(blob.data() + h.off_lists, lists.data(), lists.size() * 4);
+    memcpy(blob.data() + h.off_lits, dl.data(), n * sizeof(HsgpuDevLit));
+    h.checksum = hsgpu_blob_checksum(blob.data(), blob.size());
+    memcpy(blob.data(), &h, sizeof(h));
+    return HSGPU_SUCCESS;
+}
+
+int hsgpu_validate_blob(const void *buf, size_t len) {
+    if (!buf || len < sizeof(HsgpuTableHeader)) return HSGPU_INVALID;
+    HsgpuTableHeader h;
+    memcpy(&h, buf, sizeof(h));
+    if (h.magic != HSGPU_TABLE_MAGIC) return HSGPU_INVALID;
+    if (h.version != HSGPU_TABLE_VERSION) return HSGPU_DB_VERSION_ERROR;
+    if (h.blob_bytes != len) return HSGPU_INVALID;
+    if (h.filter_log2_words < 4 || h.filter_log2_words > 15 || h.ht_a_log2 < 4 || h.ht_a_log2 > 28 ||
+        h.ht_b_log2 < 4 || h.ht_b_log2 > 28)
+        return HSGPU_INVALID;
+    auto in = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(h) && off + bytes <= len; };
+    if (!in(h.off_filter, 4ull << h.filter_log2_words) || !in(h.off_c2bits, 8192) ||
+        !in(h.off_ht_a, 8ull << h.ht_a_log2) || !in(h.off_ht_b, 8ull << h.ht_b_log2) ||
+        !in(h.off_c2ref, (h.flags & HSGPU_F_HAS_C) ? 262144 : 16) || !in(h.off_lists, 4ull * h.n_lists) ||
+        !in(h.off_lits, 32ull * h.n_lits))
+        return HSGPU_INVALID;
+    if (hsgpu_blob_checksum((const uint8_t *)buf, len) != h.checksum) return HSGPU_INVALID;
+    return HSGPU_SUCCESS;
+}
+
+/* ---- C ABI: build side --------------------------------------------------- */
+
+extern "C" int hsgpu_hwlm_build(const hsgpu_lit_t *lits, size_t n, unsigned flags, hsgpu_hwlm_t **out) {
+    if (!out) return HSGPU_INVALID;
+    *out = nullptr;
+    try {
+        std::vector<uint8_t> blob;
+        int rv = hsgpu_compile_table(lits, n, flags, blob);
+        if (rv != HSGPU_SUCCESS) return rv;
+        hsgpu_hwlm *t = new hsgpu_hwlm;
+        t->blob.swap(blob);
+        *out = t;
+        return HSGPU_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return HSGPU_NOMEM;
+    } catch (...) {
+        return HSGPU_UNKNOWN_ERROR;
+    }
+}
+
+extern "C" void hsgpu_hwlm_free(hsgpu_hwlm_t *t) {
+    if (!t) return;
+    hsgpu_release_device_copies(t);
+    delete t;
+}
+
+extern "C" size_t hsgpu_hwlm_size(const hsgpu_hwlm_t *t) { return t ? t->blob.size() : 0; }
+
+extern "C" int hsgpu_hwlm_get_info(const hsgpu_hwlm_t *t, hsgpu_hwlm_info_t *info) {
+    if (!t || !info) return HSGPU_INVALID;
+    const HsgpuTableHeader *h = t->hdr();
+    info->n_lits = h->n_lits;
+    info->n_class_a = h->n_a;
+    info->n_class_b = h->n_b;
+    info->n_class_c = h->n_c;
+    info->filter_words = 1u << h->filter_log2_words;
+    info->filter_entries = h->filter_entries;
+    info->ht_a_slots = 1u << h->ht_a_log2;
+    info->ht_b_slots = 1u << h->ht_b_log2;
+    info->max_size = h->max_size;
+    info->blob_bytes = h->blob_bytes;
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_hwlm_serialize(const hsgpu_hwlm_t *t, void *buf, size_t cap, size_t *len) {
+    if (!t || !len) return HSGPU_INVALID;
+    *len = t->blob.size();
+    if (!buf) return HSGPU_SUCCESS;
+    if (cap < t->blob.size()) return HSGPU_INSUFFICIENT_SPACE;
+    memcpy(buf, t->blob.data(), t->blob.size());
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_hwlm_deserialize(const void *buf, size_t len, hsgpu_hwlm_t **out) {
+    if (!out) return HSGPU_INVALID;
+    *out = nullptr;
+    int rv = hsgpu_validate_blob(buf, len);
+    if (rv != HSGPU_SUCCESS) return rv;
+    try {
+        hsgpu_hwlm *t = new hsgpu_hwlm;
+        t->blob.assign((const uint8_t *)buf, (const uint8_t *)buf + len);
+        *out = t;
+        return HSGPU_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return HSGPU_NOMEM;
+    }
+}

@@ -1,0 +1,103 @@
+/*
+ * table.h -- layout of the compiled literal table ("blob") shared by the host
+ * compiler (compile.cpp), the runtime (runtime.hip) and the scan kernels.
+ *
+ * The blob is position independent (offsets from its first byte), so it can be
+ * serialised as-is (the reference's bytecode has the same property, tested by
+ * unit/internal/fdr.cpp:408-445) and uploaded to HBM with one copy.
+ *
+ * Roles (reference analogue in brackets):
+ *   filter   u32[2^k]  hashed suffix bit-filter, staged in LDS by every workgroup
+ *                      [FDR table fdr.c:157-244 / Teddy nibble masks teddy.c:918-969]
+ *   c2bits   u32[2048] exact 2-byte-suffix bit table, staged in LDS (only when
+ *                      some literal is keyed on <= 2 bytes)
+ *   ht_a/b   open-addressed {key, list} tables keyed by the exact 4-/3-byte
+ *                      suffix variant [litIndex hash, fdr_confirm_runtime.h:51-56]
+ *   c2ref    u32[65536] list reference per 2-byte suffix
+ *   lists    u32[]     literal indices, bit 31 marks the last entry of a list
+ *   lits     DevLit[]  per literal (v, msk, groups, id, size, flags)
+ *                      [struct LitInfo, fdr_confirm.h:57-83]
+ */
+#ifndef HSGPU_TABLE_H
+#define HSGPU_TABLE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HSGPU_HD __host__ __device__ __forceinline__
+#else
+#define HSGPU_HD static inline
+#endif
+
+#define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
+#define HSGPU_TABLE_VERSION 1u
+
+#define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
+#define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
+#define HSGPU_F_HAS_C 4u /* literals keyed on their last <= 2 bytes */
+
+#define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
+#define HSGPU_HT_MUL 0x9E3779B1u
+#define HSGPU_LIST_END 0x80000000u
+
+#define HSGPU_LIT_NORUNS 1u
+
+struct HsgpuTableHeader {
+    uint32_t magic;
+    uint32_t version;
+    uint32_t blob_bytes;
+    uint32_t flags;
+    uint32_t n_lits;
+    uint32_t max_size;
+    uint32_t filter_log2_words;
+    uint32_t filter_entries;
+    uint32_t ht_a_log2;
+    uint32_t ht_b_log2;
+    uint32_t n_a, n_b, n_c;
+    uint32_t off_filter;
+    uint32_t off_c2bits;
+    uint32_t off_ht_a;
+    uint32_t off_ht_b;
+    uint32_t off_c2ref;
+    uint32_t off_lists;
+    uint32_t n_lists;
+    uint32_t off_lits;
+    uint32_t checksum; /* adler-style sum over everything after the header */
+    uint32_t reserved[10];
+};
+static_assert(sizeof(HsgpuTableHeader) == 128, "header is 128 bytes");
+
+struct HsgpuHtSlot {
+    uint32_t key;
+    uint32_t ref; /* 0 = empty, else 1 + index of the list's first entry */
+};
+
+struct HsgpuDevLit {
+    uint64_t v;      /* literal bytes, last byte in the most significant byte */
+    uint64_t msk;    /* compare mask, same alignment */
+    uint64_t groups; /* hwlm_group_t */
+    uint32_t id;
+    uint8_t size; /* max(len(s), len(msk)) */
+    uint8_t flags;
+    uint16_t pad;
+};
+static_assert(sizeof(HsgpuDevLit) == 32, "DevLit is 32 bytes");
+
+/* ---- the filter hash, identical on host (insert) and device (probe) --------
+ * For the byte position p (its byte b0 = buf[p], b1 = buf[p-1], ...):
+ *   x    = b2 | b1 << 8 | b0 << 16                 (the 3-byte suffix)
+ *   prod = (x * HSGPU_FILTER_MUL) mod 2^32          (one v_mul_u32_u24)
+ *   a    = prod >> (30 - k)                         (k = log2 filter words)
+ *   word = a >> 2
+ *   bitA = (b3 + a) & 31     for a literal keyed on 4 bytes
+ *   bitB = (prod >> 8) & 31  for a literal keyed on 3 bytes
+ */
+HSGPU_HD uint32_t hsgpu_filter_prod(uint32_t x24) { return (x24 & 0xffffffu) * HSGPU_FILTER_MUL; }
+HSGPU_HD uint32_t hsgpu_filter_a(uint32_t prod, uint32_t k) { return prod >> (30u - k); }
+HSGPU_HD uint32_t hsgpu_filter_bit_a(uint32_t b3, uint32_t a) { return (b3 + a) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t prod) { return (prod >> 8) & 31u; }
+
+HSGPU_HD uint32_t hsgpu_ht_slot(uint32_t key, uint32_t log2) { return (key * HSGPU_HT_MUL) >> (32u - log2); }
+
+#endif

@@ -1,0 +1,211 @@
+"""Python mirror of the reference's HWLM interface.
+
+  reference (C++ / C)                                      here
+  hwlmLiteral(s, nocase, noruns, id, groups, msk, cmp)      HwlmLiteral(...)
+      src/hwlm/hwlm_literal.h:51-129
+  hwlmBuildProto + hwlmBuild -> bytecode_ptr<HWLM>          hwlm_build(lits) -> HwlmTable
+      src/hwlm/hwlm_build.h:112-120
+  hwlmSize(HWLM*)                                           hwlm_size(table)
+  hwlmExec(tab, buf, len, start, cb, scratch, groups)       hwlm_exec(table, buf, start, cb, scratch, groups)
+      src/hwlm/hwlm.h:116-118
+Argument meaning, return values (HWLM_SUCCESS / HWLM_TERMINATED) and callback
+protocol (return value = live group mask, 0 terminates) are the reference's.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import HWLM_CB, HsgpuInfo, HsgpuLit, HsgpuMatch
+
+HWLM_ALL_GROUPS = 0xFFFFFFFFFFFFFFFF
+HWLM_CONTINUE_MATCHING = HWLM_ALL_GROUPS
+HWLM_TERMINATE_MATCHING = 0
+HWLM_SUCCESS = 0
+HWLM_TERMINATED = 1
+HWLM_ERROR_UNKNOWN = 2
+
+MATCH_DTYPE = np.dtype([("block", "<u4"), ("end", "<u4"), ("id", "<u4"), ("lit", "<u4")])
+
+
+class HsgpuError(RuntimeError):
+    def __init__(self, code, what):
+        lib = _native.load_library()
+        msg = lib.hsgpu_last_error().decode(errors="replace")
+        super().__init__(f"{what} failed with {code}: {msg}")
+        self.code = code
+
+
+class HwlmLiteral:
+    """One literal; same fields as the reference's hwlmLiteral."""
+
+    __slots__ = ("s", "nocase", "noruns", "id", "groups", "msk", "cmp")
+
+    def __init__(self, s, nocase=False, id=0, noruns=False, groups=HWLM_ALL_GROUPS, msk=b"", cmp=b""):
+        self.s = s.encode("latin-1") if isinstance(s, str) else bytes(s)
+        self.nocase = bool(nocase)
+        self.noruns = bool(noruns)
+        self.id = int(id)
+        self.groups = int(groups)
+        self.msk = bytes(msk)
+        self.cmp = bytes(cmp)
+
+    def __repr__(self):
+        return f"HwlmLiteral({self.s!r}, nocase={self.nocase}, id={self.id})"
+
+
+def pack_literals(lits, struct=HsgpuLit):
+    """-> (ctypes array, keepalive list) in the C ABI's hsgpu_lit_t layout."""
+    arr = (struct * len(lits))()
+    keep = []
+    for i, l in enumerate(lits):
+        sb = C.create_string_buffer(l.s, len(l.s)) if l.s else None
+        mb = C.create_string_buffer(l.msk, len(l.msk)) if l.msk else None
+        cb = C.create_string_buffer(l.cmp, len(l.cmp)) if l.cmp else None
+        keep += [sb, mb, cb]
+        arr[i].s = C.cast(sb, C.c_void_p) if sb else None
+        arr[i].len = len(l.s)
+        arr[i].id = l.id
+        arr[i].nocase = 1 if l.nocase else 0
+        arr[i].noruns = 1 if l.noruns else 0
+        arr[i].msk_len = len(l.msk)
+        arr[i].groups = l.groups
+        arr[i].msk = C.cast(mb, C.c_void_p) if mb else None
+        arr[i].cmp = C.cast(cb, C.c_void_p) if cb else None
+    return arr, keep
+
+
+class HwlmTable:
+    """Compiled literal table (immutable; shareable between scratches)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._lib = _native.load_library()
+
+    @classmethod
+    def build(cls, lits, flags=0):
+        lib = _native.load_library()
+        arr, _keep = pack_literals(list(lits))
+        h = C.c_void_p()
+        rv = lib.hsgpu_hwlm_build(arr, len(arr), flags, C.byref(h))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_hwlm_build")
+        return cls(h)
+
+    @classmethod
+    def deserialize(cls, blob):
+        lib = _native.load_library()
+        h = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        rv = lib.hsgpu_hwlm_deserialize(buf, len(blob), C.byref(h))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_hwlm_deserialize")
+        return cls(h)
+
+    def serialize(self):
+        n = C.c_size_t()
+        self._lib.hsgpu_hwlm_serialize(self._h, None, 0, C.byref(n))
+        buf = (C.c_char * n.value)()
+        rv = self._lib.hsgpu_hwlm_serialize(self._h, buf, n.value, C.byref(n))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_hwlm_serialize")
+        return bytes(buf)
+
+    @property
+    def size(self):
+        return self._lib.hsgpu_hwlm_size(self._h)
+
+    def info(self):
+        i = HsgpuInfo()
+        self._lib.hsgpu_hwlm_get_info(self._h, C.byref(i))
+        return {n: getattr(i, n) for n, _ in HsgpuInfo._fields_}
+
+    def close(self):
+        if self._h:
+            self._lib.hsgpu_hwlm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scratch:
+    """Per-caller device state (stream + buffers); the role of hs_scratch."""
+
+    def __init__(self, device=-1):
+        self._lib = _native.load_library()
+        h = C.c_void_p()
+        rv = self._lib.hsgpu_scratch_alloc(C.byref(h), device)
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_alloc")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.hsgpu_scratch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def hwlm_build(lits, flags=0):
+    return HwlmTable.build(lits, flags)
+
+
+def hwlm_size(table):
+    return table.size
+
+
+def _as_u8(buf):
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    if a.dtype != np.uint8 or not a.flags["C_CONTIGUOUS"]:
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+def hwlm_exec(table, buf, start, cb, scratch, groups=HWLM_ALL_GROUPS, ctx=None):
+    """Mirror of hwlmExec. cb(end, id, ctx) -> live group mask (0 terminates)."""
+    a = _as_u8(buf)
+
+    def tramp(end, lit_id, _):
+        return int(cb(end, lit_id, ctx)) & HWLM_ALL_GROUPS
+
+    ccb = HWLM_CB(tramp)
+    return table._lib.hsgpu_hwlm_exec(table._h, scratch._h, a.ctypes.data, a.size, start, ccb, None, groups)
+
+
+def hwlm_exec_batch(table, scratch, base, off, start=0, cap=None):
+    """Batched host form: returns a structured array of (block, end, id, lit)
+    sorted by (block, end, lit)."""
+    a = _as_u8(base)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    nblocks = off.size - 1
+    cap = int(cap) if cap is not None else max(4096, a.size // 64)
+    lib = table._lib
+    while True:
+        out = np.zeros(cap, dtype=MATCH_DTYPE)
+        n = C.c_size_t()
+        rv = lib.hsgpu_hwlm_exec_batch(table._h, scratch._h, a.ctypes.data, off.ctypes.data, nblocks, start,
+                                       out.ctypes.data, cap, C.byref(n))
+        if rv == -12:  # HSGPU_INSUFFICIENT_SPACE
+            cap = n.value
+            continue
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_hwlm_exec_batch")
+        return out[: n.value]
+
+
+def hwlm_scan_dev(table, scratch, corpus_ptr, total_bytes, off_ptr, nblocks, out_ptr, cap, count_ptr,
+                  start=0, stream=None):
+    """Device-resident hot path: raw device pointers in, asynchronous."""
+    rv = table._lib.hsgpu_hwlm_scan_dev(table._h, scratch._h, corpus_ptr, total_bytes, off_ptr, nblocks, start,
+                                        out_ptr, cap, count_ptr, stream)
+    if rv != 0:
+        raise HsgpuError(rv, "hsgpu_hwlm_scan_dev")

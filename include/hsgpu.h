@@ -1,0 +1,154 @@
+/*
+ * hsgpu.h -- C ABI of the MI355X-native block-mode literal scan engine.
+ *
+ * This is the drop-in boundary for Hyperscan's literal-matcher layer ("HWLM"):
+ * every entry point names the reference interface it replaces.  Plain pointers
+ * and sizes only; no C++ or torch types cross this boundary.
+ *
+ *   reference interface                          replaced by
+ *   -------------------------------------------  ---------------------------------
+ *   struct hwlmLiteral   src/hwlm/hwlm_literal.h:51-129   hsgpu_lit_t
+ *   hwlmBuildProto+hwlmBuild src/hwlm/hwlm_build.h:112-120 hsgpu_hwlm_build
+ *   hwlmSize             src/hwlm/hwlm_build.h:127         hsgpu_hwlm_size
+ *   HWLMCallback         src/hwlm/hwlm.h:98-99             hsgpu_hwlm_cb
+ *   hwlmExec             src/hwlm/hwlm.h:116-118           hsgpu_hwlm_exec
+ *   (no equivalent: one hs_scan per block,                 hsgpu_hwlm_exec_batch,
+ *    tools/hsbench/main.cpp:502-528)                       hsgpu_hwlm_scan_dev
+ *   struct hs_scratch    src/scratch.h (per-thread state)  hsgpu_scratch_t
+ *   hs_serialize_database src/hs_common.h:108-169          hsgpu_hwlm_serialize/_deserialize
+ *   shuftiExec/truffleExec/vermicelliExec                  hsgpu_class_* (hsgpu_class.h section below)
+ *     src/nfa/shufti.h:46, truffle.h:45, vermicelli.h:42
+ *
+ * Error convention: the hs_error_t values of src/hs_common.h:478-588.
+ * hsgpu_hwlm_exec additionally returns the hwlm_error_t values of
+ * src/hwlm/hwlm.h:62-72 (0 success, 1 terminated by callback, 2 error).
+ */
+#ifndef HSGPU_H
+#define HSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hs_error_t mirror (src/hs_common.h:478-588) */
+#define HSGPU_SUCCESS 0
+#define HSGPU_INVALID (-1)
+#define HSGPU_NOMEM (-2)
+#define HSGPU_SCAN_TERMINATED (-3)
+#define HSGPU_COMPILER_ERROR (-4)
+#define HSGPU_DB_VERSION_ERROR (-5)
+#define HSGPU_SCRATCH_IN_USE (-10)
+#define HSGPU_INSUFFICIENT_SPACE (-12)
+#define HSGPU_UNKNOWN_ERROR (-13)
+
+/* hwlm_error_t mirror (src/hwlm/hwlm.h:62-72) */
+#define HSGPU_HWLM_SUCCESS 0
+#define HSGPU_HWLM_TERMINATED 1
+#define HSGPU_HWLM_ERROR_UNKNOWN 2
+
+#define HSGPU_ALL_GROUPS 0xffffffffffffffffULL /* HWLM_ALL_GROUPS */
+#define HSGPU_LITERAL_MAX_LEN 8                /* HWLM_LITERAL_MAX_LEN, hwlm.h:75 */
+#define HSGPU_MASKLEN 8                        /* HWLM_MASKLEN, hwlm_literal.h:46 */
+
+/* One literal, field for field the reference's hwlmLiteral:
+ * s/len (<= 8 bytes), id passed to the callback, nocase, noruns, groups and
+ * the supplementary msk/cmp pair ((v & msk) == cmp over the final msk_len <= 8
+ * bytes, memory order, last byte of msk aligned with last byte of s). */
+typedef struct hsgpu_lit {
+    const uint8_t *s;
+    uint32_t len;
+    uint32_t id;
+    uint8_t nocase;
+    uint8_t noruns;
+    uint8_t pad[2];
+    uint32_t msk_len;
+    uint64_t groups;
+    const uint8_t *msk;
+    const uint8_t *cmp;
+} hsgpu_lit_t;
+
+/* One match record as written by the GPU: `end` is the offset of the literal's
+ * last byte inside block `block` (hwlm.h:101-105); `lit` is the index of the
+ * literal in the array given to hsgpu_hwlm_build. 16 bytes, 16-byte aligned. */
+typedef struct hsgpu_match {
+    uint32_t block;
+    uint32_t end;
+    uint32_t id;
+    uint32_t lit;
+} hsgpu_match_t;
+
+typedef struct hsgpu_hwlm hsgpu_hwlm_t;       /* compiled literal table (immutable, shareable) */
+typedef struct hsgpu_scratch hsgpu_scratch_t; /* per-caller device state: stream + buffers */
+
+/* Callback: as HWLMCallback. Return value = the live group mask; 0 terminates. */
+typedef uint64_t (*hsgpu_hwlm_cb)(size_t end, uint32_t id, void *ctx);
+
+typedef struct hsgpu_hwlm_info {
+    uint32_t n_lits;
+    uint32_t n_class_a, n_class_b, n_class_c; /* literals keyed on 4-, 3-, <=2-byte suffix */
+    uint32_t filter_words;                    /* LDS filter size in 32-bit words */
+    uint32_t filter_entries;                  /* enumerated key variants inserted */
+    uint32_t ht_a_slots, ht_b_slots;
+    uint32_t max_size;                        /* longest literal/mask */
+    uint32_t blob_bytes;
+} hsgpu_hwlm_info_t;
+
+/* ---- build side ---------------------------------------------------------- */
+
+/* Compile n literals. Fails with HSGPU_COMPILER_ERROR on an invalid literal
+ * (len > 8, msk_len > 8, empty literal, inconsistent msk/cmp, id 0xffffffff). */
+int hsgpu_hwlm_build(const hsgpu_lit_t *lits, size_t n, unsigned flags, hsgpu_hwlm_t **out);
+void hsgpu_hwlm_free(hsgpu_hwlm_t *t);
+size_t hsgpu_hwlm_size(const hsgpu_hwlm_t *t);
+int hsgpu_hwlm_get_info(const hsgpu_hwlm_t *t, hsgpu_hwlm_info_t *info);
+/* Position-independent blob; two-call pattern: buf == NULL returns the size. */
+int hsgpu_hwlm_serialize(const hsgpu_hwlm_t *t, void *buf, size_t cap, size_t *len);
+int hsgpu_hwlm_deserialize(const void *buf, size_t len, hsgpu_hwlm_t **out);
+
+/* ---- run side ------------------------------------------------------------ */
+
+/* device < 0: the calling thread's current HIP device. */
+int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device);
+void hsgpu_scratch_free(hsgpu_scratch_t *s);
+
+/* Mirror of hwlmExec: scan one host block, deliver callbacks in non-decreasing
+ * `end` on the calling thread, honouring the group mask returned by the callback,
+ * noruns and termination. Returns HSGPU_HWLM_*. */
+int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *buf, size_t len,
+                    size_t start, hsgpu_hwlm_cb cb, void *ctx, uint64_t groups);
+
+/* Batched host form: nblocks independent blocks, block i = base[off[i], off[i+1]).
+ * Writes up to cap records sorted by (block, end, lit) and the total in *nout
+ * (HSGPU_INSUFFICIENT_SPACE if *nout > cap; the first cap are valid). */
+int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *base,
+                          const uint64_t *off, size_t nblocks, size_t start,
+                          hsgpu_match_t *out, size_t cap, size_t *nout);
+
+/* Device-resident form (the hot path): corpus, offsets, records and counter all
+ * live in HBM; asynchronous on `stream` (a hipStream_t passed as void*, NULL =
+ * the scratch's own stream); no host synchronisation. d_off holds nblocks+1
+ * ascending uint64 offsets with d_off[nblocks] == total_bytes. *d_count must be
+ * zero on entry and receives the TOTAL number of matches (records beyond cap are
+ * dropped, unsorted). d_corpus must be 16-byte aligned. */
+int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus,
+                        uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t start,
+                        void *d_out, uint64_t cap, void *d_count, void *stream);
+
+/* Sort cap' = min(count, cap) device records in place by (block, end, lit). */
+int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n, void *stream);
+
+/* Replay sorted records of ONE block through a callback with the reference's
+ * sequential semantics (groups gate, noruns, terminate). Host only. */
+int hsgpu_hwlm_replay(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n,
+                      hsgpu_hwlm_cb cb, void *ctx, uint64_t groups);
+
+const char *hsgpu_last_error(void);
+const char *hsgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSGPU_H */

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Everything native is built once per session (cheap when up to date)."""
+    import __graft_entry__ as ge
+
+    lib = os.path.join(ROOT, "hyperscan_amd", "lib", "libhsgpu.so")
+    if not os.path.exists(lib) or os.path.isdir("/root/reference/src"):
+        ge.build()
+    else:
+        ge.build_oracle()
+    yield
+
+
+@pytest.fixture(scope="session")
+def scratch():
+    import hyperscan_amd as H
+
+    s = H.Scratch(0)
+    yield s
+    s.close()
