@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""bench.py -- hsbench-style block-mode throughput of the GPU literal scan engine.
+
+Metric (BASELINE.json): GB/s scanned in block mode (+ matches/s), whole job over
+N GPUs, inputs resident in HBM when the timed region starts.
+
+A "step" is one pass of the hot path over one batch: every rank scans its own
+shard (all blocks of the corpus, one kernel launch) and, for N > 1, the match
+records are all-gathered over RCCL. hsbench protocol (tools/hsbench/main.cpp:
+502-528, 720-724, 823-839): corpus pre-loaded, barrier, K repeats, bytes*K/secs.
+
+Workloads:
+  teddy64   config 2: 64 literals len 4-8, 1 GiB synthetic packet corpus per GPU
+  fdr10k    config 3: 10 000 snort-like literals, 1 GiB packet shard per GPU
+The default is teddy64 (configs[1]); the fdr10k line is measured in the same run
+and attached as "also".
+
+One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+REC_BYTES = 16
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(name, total_bytes, seed_shift):
+    from hyperscan_amd import corpus as cp
+
+    if name == "teddy64":
+        lits = cp.teddy_literals(64, seed=2)
+        corpus, off = cp.packet_corpus(total_bytes, lits, seed=3 + seed_shift)
+    elif name == "fdr10k":
+        lits, _full = cp.snort_like_literals(10000, seed=4)
+        corpus, off = cp.packet_corpus(total_bytes, lits, seed=10 + seed_shift)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return lits, corpus, off
+
+
+class GpuJob:
+    """One rank's resident state: table, corpus/offsets/records in HBM."""
+
+    def __init__(self, lits, corpus, off, device):
+        import torch
+
+        import hyperscan_amd as H
+
+        self.torch = torch
+        self.H = H
+        self.dev = torch.device("cuda", device)
+        self.table = H.hwlm_build(lits)
+        self.scratch = H.Scratch(device)
+        self.total = int(corpus.size)
+        self.nblocks = int(off.size - 1)
+        self.d_corpus = torch.from_numpy(corpus).to(self.dev)
+        self.d_off = torch.from_numpy(off.view(np.int64)).to(self.dev)
+        self.cap = max(1 << 16, self.total // 1024)
+        self.d_out = torch.zeros(self.cap * 4, dtype=torch.int32, device=self.dev)
+        self.d_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        assert self.d_corpus.data_ptr() % 16 == 0
+
+    def launch(self):
+        """memset(count) + ONE scan kernel on torch's current stream."""
+        from hyperscan_amd import hwlm as hw
+
+        self.d_count.zero_()
+        stream = self.torch.cuda.current_stream().cuda_stream
+        hw.hwlm_scan_dev(self.table, self.scratch, self.d_corpus.data_ptr(), self.total, self.d_off.data_ptr(),
+                         self.nblocks, self.d_out.data_ptr(), self.cap, self.d_count.data_ptr(), 0, stream)
+
+    def count(self):
+        return int(self.d_count.item())
+
+    def records(self):
+        n = min(self.count(), self.cap)
+        return self.d_out[: n * 4].view(n, 4).cpu().numpy().astype(np.uint32)
+
+
+def cpu_baseline(lits, corpus, off, want_seconds=6.0, sample_bytes=64 << 20):
+    """The reference's own hwlmExec (oracle/_ref, compiled from /root/reference) -- or
+    the C restatement when that library is absent -- timed on this box's host cores
+    over a bounded sample of the same workload, hsbench style: T threads, each
+    scanning its own slice of the sample, repeated until ~want_seconds elapsed."""
+    from tests import oracle_binding as ob
+
+    k = int(np.searchsorted(off, min(sample_bytes, int(off[-1])), side="right")) - 1
+    k = max(k, 1)
+    s_off = off[: k + 1].copy()
+    s_bytes = int(s_off[-1])
+    sample = corpus[:s_bytes]
+    kind = "reference" if ob.ref_available() else "port"
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    eng = [ob.Reference(lits) if kind == "reference" else ob.Oracle(lits) for _ in range(threads)]
+    info = eng[0].info() if kind == "reference" else "oracle/hwlm_oracle.c"
+    # slice the sample's blocks evenly (by block count) over the threads
+    bounds = np.linspace(0, k, threads + 1).astype(np.int64)
+    counts = [0] * threads
+    passes = [0] * threads
+
+    def work(i, deadline):
+        lo, hi = int(bounds[i]), int(bounds[i + 1])
+        if hi <= lo:
+            return
+        o = s_off[lo:hi + 1]
+        while True:
+            counts[i] = eng[i].count_blocks(sample, o)
+            passes[i] += 1
+            if time.perf_counter() >= deadline:
+                break
+
+    # single-thread number first (T=1 over the whole sample), then all cores
+    t0 = time.perf_counter()
+    n1 = eng[0].count_blocks(sample, s_off)
+    t1 = time.perf_counter() - t0
+    reps1 = 1
+    while t1 < want_seconds / 3:
+        eng[0].count_blocks(sample, s_off)
+        reps1 += 1
+        t1 = time.perf_counter() - t0
+    single = s_bytes * reps1 / t1 / 1e9
+
+    t0 = time.perf_counter()
+    deadline = t0 + want_seconds * 2 / 3
+    ths = [threading.Thread(target=work, args=(i, deadline)) for i in range(threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    scanned = sum(int(s_off[int(bounds[i + 1])] - s_off[int(bounds[i])]) * passes[i] for i in range(threads))
+    multi = scanned / dt / 1e9
+    assert sum(counts) == n1, "CPU baseline: per-thread counts do not add up"
+    return {
+        "value": round(multi, 4), "unit": "GB/s", "cores": threads, "kind": kind,
+        "sample": f"first {s_bytes} bytes / {k} blocks of the same corpus, {threads} threads x own slice, "
+                  f"~{want_seconds * 2 / 3:.0f}s; engine: {info}",
+        "single_thread_GBps": round(single, 4), "matches_in_sample": int(n1),
+    }, (k, int(n1))
+
+
+def run_workload(name, args, rank, world, dist, do_cpu):
+    import torch
+
+    total = int(args.gib * (1 << 30))
+    t0 = time.perf_counter()
+    lits, corpus, off = build_workload(name, total, seed_shift=rank)
+    log(f"[rank {rank}] {name}: generated {corpus.size} bytes / {off.size - 1} blocks in {time.perf_counter() - t0:.1f}s")
+    job = GpuJob(lits, corpus, off, torch.cuda.current_device())
+    info = job.table.info()
+
+    def gather():
+        """RCCL all-gather of match records over xGMI: counts, then padded records."""
+        cnt = job.d_count.clone()
+        allc = torch.empty(world, dtype=torch.int64, device=job.dev)
+        dist.all_gather_into_tensor(allc, cnt)
+        mx = int(min(allc.max().item(), job.cap))
+        if mx == 0:
+            return allc, None
+        buf = torch.empty(world * mx * 4, dtype=torch.int32, device=job.dev)
+        dist.all_gather_into_tensor(buf, job.d_out[: mx * 4].contiguous())
+        return allc, buf
+
+    def step():
+        job.launch()
+        if world > 1:
+            gather()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    n_matches = job.count()
+    assert n_matches <= job.cap, "record buffer too small"
+
+    # parity gate on a sample (bounded CPU time): GPU count over the first k blocks == CPU count
+    cpu = None
+    if do_cpu:
+        cpu, (k, n_cpu) = cpu_baseline(lits, corpus, off)
+        recs = job.records()
+        n_gpu = int((recs[:, 0] < k).sum())
+        assert n_gpu == n_cpu, f"PARITY FAILURE on the sample: GPU {n_gpu} vs CPU {n_cpu}"
+        cpu["parity"] = f"GPU == CPU match count on the sample ({n_cpu})"
+
+    # timed region: barrier + sync on both sides, exactly K steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        job.d_count.zero_()
+        ev[i][0].record()
+        from hyperscan_amd import hwlm as hw
+        hw.hwlm_scan_dev(job.table, job.scratch, job.d_corpus.data_ptr(), job.total, job.d_off.data_ptr(),
+                         job.nblocks, job.d_out.data_ptr(), job.cap, job.d_count.data_ptr(), 0,
+                         torch.cuda.current_stream().cuda_stream)
+        ev[i][1].record()
+        if world > 1:
+            gather()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert job.count() == n_matches, "match count changed between repeats"  # hsbench main.cpp:778-787
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_s = float(np.mean(kern_ms)) / 1e3
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=job.dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tot = torch.tensor([job.total, n_matches], dtype=torch.int64, device=job.dev)
+        dist.all_reduce(tot)
+        all_bytes, all_matches = int(tot[0].item()), int(tot[1].item())
+    else:
+        all_bytes, all_matches = job.total, n_matches
+
+    alg_bytes = job.total + REC_BYTES * n_matches
+    achieved = alg_bytes / kern_avg_s / 1e9
+    res = {
+        "value": round(all_bytes * args.steps / dt / 1e9, 3),
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "matches_per_s": round(all_matches * args.steps / dt, 1),
+        "matches_per_step": all_matches,
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "hwlm_scan_kernel", "kernel_ms_avg": round(kern_avg_s * 1e3, 4),
+            "kernel_ms_best": round(float(np.min(kern_ms)), 4),
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+        "table": info,
+    }
+    if cpu:
+        res["cpu_baseline"] = cpu
+    del job
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gib", type=float, default=1.0, help="corpus GiB per GPU")
+    ap.add_argument("--workload", default="teddy64", choices=["teddy64", "fdr10k"])
+    ap.add_argument("--no-also", action="store_true", help="skip the second workload line")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    do_cpu = (rank == 0 and world == 1 and not args.no_cpu)
+    main_res = run_workload(args.workload, args, rank, world, dist, do_cpu)
+    also = None
+    if not args.no_also:
+        other = "fdr10k" if args.workload == "teddy64" else "teddy64"
+        also = run_workload(other, args, rank, world, dist, do_cpu)
+
+    if rank == 0:
+        blocks_desc = "synthetic packets {64,128,256,576,1024,1460} B, 70% HTTP-like text / 30% random"
+        out = {
+            "metric": "GB/s scanned (hsbench block mode)", "value": main_res["value"], "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: " + (
+                "64 literals len 4-8" if args.workload == "teddy64" else "10000 snort-like literals (8-byte suffixes)")
+                + f", {args.gib:g} GiB per GPU, block mode, {blocks_desc}",
+                "records": "16 B (block,end,id,lit)", "sharding": f"{world} x independent shards"
+                + (", RCCL all-gather of records per step" if world > 1 else "")},
+            "matches_per_s": main_res["matches_per_s"], "matches_per_step": main_res["matches_per_step"],
+            "roofline": main_res["roofline"], "table": main_res["table"],
+        }
+        if "cpu_baseline" in main_res:
+            out["cpu_baseline"] = main_res["cpu_baseline"]
+        if also:
+            other = "fdr10k" if args.workload == "teddy64" else "teddy64"
+            out["also"] = {other: {k: also[k] for k in also}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
