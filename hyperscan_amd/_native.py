@@ -25,7 +25,7 @@ class HsgpuMatch(C.Structure):
 class HsgpuInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "n_lits", "n_class_a", "n_class_b", "n_class_c", "filter_words", "filter_entries",
-        "ht_a_slots", "ht_b_slots", "max_size", "blob_bytes")]
+        "ht_a_slots", "ht_b_slots", "max_size", "blob_bytes", "flags")]
 
 
 HWLM_CB = C.CFUNCTYPE(C.c_uint64, C.c_size_t, C.c_uint32, C.c_void_p)

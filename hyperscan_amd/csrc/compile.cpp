@@ -119,13 +119,15 @@ struct KeyChoice {
 inline uint32_t popc(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
 
 KeyChoice choose_class(const HsgpuDevLit &l) {
+    /* the longest key that needs at most 16 concrete variants (4 wildcard bits);
+     * failing that, the key with the fewest variants */
     uint32_t m4 = (uint32_t)(l.msk >> 32), m3 = m4 >> 8, m2 = m4 >> 16;
     uint32_t wa = popc(~m4), wb = popc(~m3 & 0xffffffu), wc = popc(~m2 & 0xffffu);
-    (void)wc;
     if (wa <= 4) return {0};
     if (wb <= 4) return {1};
-    if (wa <= 8) return {0};
-    if (wb <= 8) return {1};
+    if (wc <= 4) return {2};
+    if (wa <= wb && wa <= wc) return {0};
+    if (wb <= wc) return {1};
     return {2};
 }
 
@@ -158,7 +160,6 @@ uint32_t hsgpu_blob_checksum(const uint8_t *blob, size_t len) {
 }
 
 int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::vector<uint8_t> &blob) {
-    (void)flags;
     if (!lits || n == 0) {
         hsgpu_set_error("no literals");
         return HSGPU_COMPILER_ERROR;
@@ -173,40 +174,87 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
         if (rv != HSGPU_SUCCESS) return rv;
     }
 
-    /* key -> literal indices, per class (literal order preserved inside a list) */
+    /* Stride. With stride 2 the kernel looks up every second byte position q only
+     * (FDR has the same idea, fdr.c:246-327): a lookup at q must then catch
+     * literals ending at q (delta 0, keyed on their last bytes) AND at q + 1
+     * (delta 1, keyed on the bytes before their last one). Needs every literal to
+     * have at least one byte left at delta 1. */
+    uint32_t min_size = 8;
+    for (size_t i = 0; i < n; i++) min_size = std::min<uint32_t>(min_size, dl[i].size);
+    /* below 4 bytes the delta-1 key would be a bare 2-gram: too many candidates */
+    const bool stride2 = !(flags & HSGPU_BUILD_FORCE_STRIDE1) && (min_size >= 4 || ((flags & HSGPU_BUILD_FORCE_STRIDE2) && min_size >= 2));
+    const uint32_t n_delta = stride2 ? 2 : 1;
+
+    /* Case-blind keys: when any literal is caseless, hash and exact-table keys drop
+     * bit 5 of every byte (one v_and per lookup), so a caseless literal needs ONE
+     * key instead of one per case variant; the exact compare still decides. */
+    bool blind = (flags & HSGPU_BUILD_FORCE_BLIND) != 0;
+    for (size_t i = 0; i < n && !blind; i++) blind = lits[i].nocase != 0;
+    const uint32_t blind4 = blind ? 0x20202020u : 0u;
+
+    /* key -> (literal index | delta << 30), per class (literal order preserved) */
     std::unordered_map<uint32_t, std::vector<uint32_t>> keys[3];
     uint32_t n_cls[3] = {0, 0, 0}, max_size = 0;
     for (size_t i = 0; i < n; i++) {
-        const HsgpuDevLit &l = dl[i];
-        max_size = std::max<uint32_t>(max_size, l.size);
-        int cls = choose_class(l).cls;
-        n_cls[cls]++;
-        uint32_t m4 = (uint32_t)(l.msk >> 32), v4 = (uint32_t)(l.v >> 32);
-        uint32_t v, wild;
-        if (cls == 0) {
-            v = v4;
-            wild = ~m4;
-        } else if (cls == 1) {
-            v = v4 >> 8;
-            wild = ~(m4 >> 8) & 0xffffffu;
-        } else {
-            v = v4 >> 16;
-            wild = ~(m4 >> 16) & 0xffffu;
+        max_size = std::max<uint32_t>(max_size, dl[i].size);
+        for (uint32_t delta = 0; delta < n_delta; delta++) {
+            HsgpuDevLit l = dl[i];
+            l.v <<= 8 * delta;
+            l.msk <<= 8 * delta;
+            /* blind: bit 5 is neither a constraint nor a wildcard to enumerate */
+            l.msk |= (uint64_t)blind4 << 32;
+            l.v &= ~((uint64_t)blind4 << 32);
+            int cls = choose_class(l).cls;
+            if (delta == 0) n_cls[cls]++;
+            uint32_t m4 = (uint32_t)(l.msk >> 32), v4 = (uint32_t)(l.v >> 32);
+            uint32_t v, wild;
+            if (cls == 0) {
+                v = v4;
+                wild = ~m4;
+            } else if (cls == 1) {
+                v = v4 >> 8;
+                wild = ~(m4 >> 8) & 0xffffffu;
+            } else {
+                v = v4 >> 16;
+                wild = ~(m4 >> 16) & 0xffffu;
+            }
+            const uint32_t ent = (uint32_t)i | delta << HSGPU_LIST_DELTA_SHIFT;
+            for_each_variant(v, wild, [&](uint32_t key) { keys[cls][key].push_back(ent); });
         }
-        for_each_variant(v, wild, [&](uint32_t key) { keys[cls][key].push_back((uint32_t)i); });
     }
 
     const uint32_t entries = (uint32_t)(keys[0].size() + keys[1].size());
-    /* one bit per entry; aim at <= ~1.5% of bits set, within 16 KB .. 128 KB */
-    uint32_t k = std::min<uint32_t>(15, std::max<uint32_t>(12, ceil_log2((uint64_t)entries * 2)));
+    uint32_t tflags = (keys[0].size() ? HSGPU_F_HAS_A : 0) | (keys[1].size() ? HSGPU_F_HAS_B : 0) |
+                      (keys[2].size() ? HSGPU_F_HAS_C : 0) | (stride2 ? HSGPU_F_STRIDE2 : 0) |
+                      (blind ? HSGPU_F_BLIND : 0);
+    /* Filter layout.
+     *  - small sets ("Teddy class", <= 1024 key variants): bank-replicated rows; every
+     *    lane reads its own LDS bank, so lookups are conflict-free. 128 bits per
+     *    entry per copy, between 256 rows (32 KiB) and 1024 rows (128 KiB).
+     *  - large sets ("FDR class"): one hashed 2^k-word filter, k <= 15 (128 KiB),
+     *    two bits per class-A key once the filter is more than ~0.4% full. */
+    uint32_t k;
+    if (!(flags & HSGPU_BUILD_FORCE_HASHED) && (entries <= 1024 || (flags & HSGPU_BUILD_FORCE_REPL))) {
+        tflags |= HSGPU_F_REPL;
+        /* 160 KiB of LDS = 128 KiB filter + 8 KiB 2-byte table + 24 KiB per-wavefront areas (fused kernel) */
+        k = 10;
+        if ((uint64_t)entries * 128 > ((uint64_t)32 << k)) tflags |= HSGPU_F_K2; /* > 0.8% of bits set */
+    } else {
+        k = 15;
+        if ((uint64_t)entries * 128 > ((uint64_t)32 << k)) tflags |= HSGPU_F_K2;
+    }
+    if (flags & HSGPU_BUILD_FORCE_K2) tflags |= HSGPU_F_K2;
+    if (flags & HSGPU_BUILD_FORCE_K1) tflags &= ~HSGPU_F_K2;
+    const uint32_t fwords = hsgpu_filter_words(tflags, k);
+    const uint32_t fshift = hsgpu_filter_shift(tflags, k);
     uint32_t ht_log2[2];
-    for (int c = 0; c < 2; c++) ht_log2[c] = std::max<uint32_t>(4, ceil_log2((uint64_t)keys[c].size() * 2 + 1));
-
-    uint32_t tflags = (n_cls[0] ? HSGPU_F_HAS_A : 0) | (n_cls[1] ? HSGPU_F_HAS_B : 0) | (n_cls[2] ? HSGPU_F_HAS_C : 0);
+    for (int c = 0; c < 2; c++)
+        ht_log2[c] = std::max<uint32_t>(2, ceil_log2((uint64_t)keys[c].size() / 2 + 1)); /* <= 2 of 4 slots used */
 
     /* lists */
     std::vector<uint32_t> lists;
     auto add_list = [&](const std::vector<uint32_t> &v) -> uint32_t {
+        if (v.size() == 1) return v[0] | HSGPU_REF_DIRECT;
         uint32_t ref = (uint32_t)lists.size() + 1;
         for (size_t j = 0; j < v.size(); j++) lists.push_back(v[j] | (j + 1 == v.size() ? HSGPU_LIST_END : 0));
         return ref;
@@ -221,7 +269,7 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     h.flags = tflags;
     h.n_lits = (uint32_t)n;
     h.max_size = max_size;
-    h.filter_log2_words = k;
+    h.filter_log2 = k;
     h.filter_entries = entries;
     h.ht_a_log2 = ht_log2[0];
     h.ht_b_log2 = ht_log2[1];
@@ -229,20 +277,28 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     h.n_b = n_cls[1];
     h.n_c = n_cls[2];
     h.off_filter = (uint32_t)off;
-    off += (size_t)4 << k;
+    off += (size_t)4 * fwords;
     h.off_c2bits = (uint32_t)off;
     off += 2048 * 4;
     h.off_ht_a = (uint32_t)off;
-    off += sizeof(HsgpuHtSlot) << ht_log2[0];
+    off += (sizeof(HsgpuHtSlot) * HSGPU_BUCKET_SLOTS) << ht_log2[0];
     h.off_ht_b = (uint32_t)off;
-    off += sizeof(HsgpuHtSlot) << ht_log2[1];
+    off += (sizeof(HsgpuHtSlot) * HSGPU_BUCKET_SLOTS) << ht_log2[1];
     h.off_c2ref = (uint32_t)off;
     off += (tflags & HSGPU_F_HAS_C) ? 65536 * 4 : 16;
 
-    std::vector<uint32_t> filter((size_t)1 << k, 0), c2bits(2048, 0);
+    std::vector<uint32_t> filter(fwords, 0), c2bits(2048, 0);
     std::vector<HsgpuHtSlot> ht[2];
-    for (int c = 0; c < 2; c++) ht[c].assign((size_t)1 << ht_log2[c], HsgpuHtSlot{0, 0});
+    for (int c = 0; c < 2; c++) ht[c].assign((size_t)HSGPU_BUCKET_SLOTS << ht_log2[c], HsgpuHtSlot{0, 0});
     std::vector<uint32_t> c2ref((tflags & HSGPU_F_HAS_C) ? 65536 : 4, 0);
+
+    auto set_bit = [&](uint32_t a, uint32_t bit) {
+        if (tflags & HSGPU_F_REPL) {
+            for (uint32_t col = 0; col < 32; col++) filter[a * 32 + col] |= 1u << bit;
+        } else {
+            filter[a >> 2] |= 1u << bit;
+        }
+    };
 
     for (int c = 0; c < 2; c++) {
         /* deterministic order: sort keys */
@@ -251,16 +307,29 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
         for (auto &kv : keys[c]) ks.push_back(kv.first);
         std::sort(ks.begin(), ks.end());
         for (uint32_t key : ks) {
-            uint32_t x24 = (c == 0) ? (key >> 8) : key; /* 3-byte suffix */
-            uint32_t prod = hsgpu_filter_prod(x24);
-            uint32_t a = hsgpu_filter_a(prod, k);
-            uint32_t bit = (c == 0) ? hsgpu_filter_bit_a(key & 0xff, a) : hsgpu_filter_bit_b(prod);
-            filter[a >> 2] |= 1u << bit;
-            uint32_t mask = ((uint32_t)1 << ht_log2[c]) - 1;
-            uint32_t s = hsgpu_ht_slot(key, ht_log2[c]);
-            while (ht[c][s].ref) s = (s + 1) & mask;
-            ht[c][s].key = key;
-            ht[c][s].ref = add_list(keys[c][key]);
+            uint32_t x1 = (c == 0) ? (key >> 8) : key; /* 3-byte suffix */
+            uint32_t prod1 = hsgpu_filter_prod(x1);
+            uint32_t a1 = prod1 >> fshift;
+            if (c == 0) {
+                set_bit(a1, hsgpu_filter_bit_a(key & 0xff, a1));
+                if (tflags & HSGPU_F_K2) set_bit(a1, hsgpu_filter_bit_a2(key & 0xff, prod1));
+            } else {
+                set_bit(a1, hsgpu_filter_bit_b(prod1));
+                if (tflags & HSGPU_F_K2) set_bit(a1, hsgpu_filter_bit_b2(prod1));
+            }
+            uint32_t bmask = ((uint32_t)1 << ht_log2[c]) - 1;
+            uint32_t bkt = hsgpu_ht_bucket(key, ht_log2[c]);
+            for (;;) {
+                HsgpuHtSlot *sl = &ht[c][(size_t)bkt * HSGPU_BUCKET_SLOTS];
+                uint32_t j = 0;
+                while (j < HSGPU_BUCKET_SLOTS && sl[j].ref) j++;
+                if (j < HSGPU_BUCKET_SLOTS) {
+                    sl[j].key = key;
+                    sl[j].ref = add_list(keys[c][key]);
+                    break;
+                }
+                bkt = (bkt + 1) & bmask;
+            }
         }
     }
     {
@@ -306,12 +375,12 @@ int hsgpu_validate_blob(const void *buf, size_t len) {
     if (h.magic != HSGPU_TABLE_MAGIC) return HSGPU_INVALID;
     if (h.version != HSGPU_TABLE_VERSION) return HSGPU_DB_VERSION_ERROR;
     if (h.blob_bytes != len) return HSGPU_INVALID;
-    if (h.filter_log2_words < 4 || h.filter_log2_words > 15 || h.ht_a_log2 < 4 || h.ht_a_log2 > 28 ||
-        h.ht_b_log2 < 4 || h.ht_b_log2 > 28)
+    if (h.filter_log2 < 4 || h.filter_log2 > 15 || ((h.flags & HSGPU_F_REPL) && h.filter_log2 > 10) ||
+        h.ht_a_log2 < 2 || h.ht_a_log2 > 26 || h.ht_b_log2 < 2 || h.ht_b_log2 > 26)
         return HSGPU_INVALID;
     auto in = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(h) && off + bytes <= len; };
-    if (!in(h.off_filter, 4ull << h.filter_log2_words) || !in(h.off_c2bits, 8192) ||
-        !in(h.off_ht_a, 8ull << h.ht_a_log2) || !in(h.off_ht_b, 8ull << h.ht_b_log2) ||
+    if (!in(h.off_filter, 4ull * hsgpu_filter_words(h.flags, h.filter_log2)) || !in(h.off_c2bits, 8192) ||
+        !in(h.off_ht_a, 32ull << h.ht_a_log2) || !in(h.off_ht_b, 32ull << h.ht_b_log2) ||
         !in(h.off_c2ref, (h.flags & HSGPU_F_HAS_C) ? 262144 : 16) || !in(h.off_lists, 4ull * h.n_lists) ||
         !in(h.off_lits, 32ull * h.n_lits))
         return HSGPU_INVALID;
@@ -354,10 +423,11 @@ extern "C" int hsgpu_hwlm_get_info(const hsgpu_hwlm_t *t, hsgpu_hwlm_info_t *inf
     info->n_class_a = h->n_a;
     info->n_class_b = h->n_b;
     info->n_class_c = h->n_c;
-    info->filter_words = 1u << h->filter_log2_words;
+    info->filter_words = hsgpu_filter_words(h->flags, h->filter_log2);
+    info->flags = h->flags;
     info->filter_entries = h->filter_entries;
-    info->ht_a_slots = 1u << h->ht_a_log2;
-    info->ht_b_slots = 1u << h->ht_b_log2;
+    info->ht_a_slots = HSGPU_BUCKET_SLOTS << h->ht_a_log2;
+    info->ht_b_slots = HSGPU_BUCKET_SLOTS << h->ht_b_log2;
     info->max_size = h->max_size;
     info->blob_bytes = h->blob_bytes;
     return HSGPU_SUCCESS;

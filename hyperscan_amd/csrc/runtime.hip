@@ -16,6 +16,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -57,7 +60,7 @@ struct DevBuf {
 struct hsgpu_scratch {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf corpus, off, out, count, sort_tmp;
+    DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets;
     unsigned long long *h_count = nullptr; /* pinned */
     int n_cu = 0;
     size_t lds_per_cu = 0;
@@ -140,6 +143,11 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->out.release();
     s->count.release();
     s->sort_tmp.release();
+    s->hint.release();
+    s->cand.release();
+    s->ctl.release();
+    s->rec_stage.release();
+    s->rec_offsets.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -147,27 +155,111 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
 
 /* ---- the launch --------------------------------------------------------------- */
 
+static int set_dyn_lds(const void *fn, size_t lds) {
+    /* once per (function, size): raising the dynamic-LDS limit past 64 KiB */
+    static std::mutex mu;
+    static std::map<const void *, size_t> done;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = done.find(fn);
+    if (it != done.end() && it->second >= lds) return HSGPU_SUCCESS;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done[fn] = lds;
+    return HSGPU_SUCCESS;
+}
+
+static int scan_mode() { /* 0 = two-phase (default), 1 = fused only; tuning/testing knob */
+    static const char *m = getenv("HSGPU_MODE");
+    return (m && !strcmp(m, "fused")) ? 1 : 0;
+}
+
 static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArgs &a, hipStream_t stream) {
     const HsgpuTableHeader *h = t->hdr();
-    const void *fn = hsgpu_scan_kernel_for(h->flags);
-    if (!fn) {
+    const void *f_two = hsgpu_filter_kernel_for(h->flags, false);
+    const void *f_fused = hsgpu_filter_kernel_for(h->flags, true);
+    const void *f_conf = hsgpu_confirm_kernel_for(h->flags);
+    if (!f_two || !f_fused || !f_conf) {
         hsgpu_set_error("no kernel for table flags %u", h->flags);
         return HSGPU_UNKNOWN_ERROR;
     }
-    size_t lds = hsgpu_scan_lds_bytes(h->flags, h->filter_log2_words);
+    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true);      /* fused */
+    const size_t lds_two = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false); /* two-phase filter */
     if (lds > s->lds_per_cu) {
         hsgpu_set_error("filter needs %zu bytes of LDS, device has %zu", lds, s->lds_per_cu);
         return HSGPU_UNKNOWN_ERROR;
     }
-    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tile = hsgpu_scan_super_tile();
-    uint64_t n_tiles = (a.total + tile - 1) / tile;
+    const uint64_t n_tiles = (a.total + tile - 1) / tile;
     if (n_tiles == 0) return HSGPU_SUCCESS;
-    unsigned wg_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(2048 / HSGPU_WG_THREADS, s->lds_per_cu / lds));
-    unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)s->n_cu * wg_per_cu);
+    const unsigned wg_per_cu =
+        (unsigned)std::max<size_t>(1, std::min<size_t>(2048 / HSGPU_WG_THREADS, s->lds_per_cu / lds));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)s->n_cu * wg_per_cu);
+
     HsgpuScanArgs args = a;
+    args.t_flags = h->flags;
+    args.t_filter_log2 = h->filter_log2;
+    args.t_ht_a_log2 = h->ht_a_log2;
+    args.t_ht_b_log2 = h->ht_b_log2;
+    args.t_off_filter = h->off_filter;
+    args.t_off_c2bits = h->off_c2bits;
+    args.t_off_ht_a = h->off_ht_a;
+    args.t_off_ht_b = h->off_ht_b;
+    args.t_off_c2ref = h->off_c2ref;
+    args.t_off_lists = h->off_lists;
+    args.t_off_lits = h->off_lits;
+    int rv;
+    /* phase 0: per-KiB block hints */
+    args.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
+    if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    args.hint = (const uint32_t *)s->hint.p;
+    {
+        const uint64_t *off = a.off;
+        uint64_t nblocks = a.nblocks, total = a.total, n_hint = args.n_hint;
+        uint32_t *hint = (uint32_t *)s->hint.p;
+        void *kargs[] = {&off, &nblocks, &total, &hint, &n_hint};
+        HIP_TRY(hipLaunchKernel(hsgpu_hint_kernel(), dim3((unsigned)((n_hint + 255) / 256)), dim3(256), kargs, 0,
+                                stream));
+    }
+    /* staged match records: one region per producing wavefront, packed into the
+     * caller's buffer by the last two kernels. 2x headroom over an even split. */
+    const uint32_t n_waves = grid * (HSGPU_WG_THREADS / 64);
+    args.rec_regions = n_waves;
+    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_waves + 1)));
+    if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_waves * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
+    /* one zeroed control block: rec_counts[2n] | cand_counts[n + 1]; rec_offsets apart */
+    const size_t ctl_words = (size_t)3 * n_waves + 1;
+    if ((rv = s->ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->rec_offsets.ensure((size_t)n_waves * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
+    args.rec_stage = (uint4 *)s->rec_stage.p;
+    args.rec_counts = (uint32_t *)s->ctl.p;
+    args.rec_offsets = (unsigned long long *)s->rec_offsets.p;
+    HIP_TRY(hipMemsetAsync(s->ctl.p, 0, ctl_words * sizeof(uint32_t), stream));
+
     void *kargs[] = {&args};
-    HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
+    if (scan_mode() == 1) {
+        args.cand = nullptr;
+        args.cand_cap = 0;
+        args.cand_waves = 0;
+        args.cand_counts = nullptr;
+        if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
+        HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
+    } else {
+        /* phase 1 + 2, then the fused kernel as overflow fallback (returns at once
+         * unless some wavefront ran out of candidate space). Every filter wavefront
+         * owns a private region of the candidate buffer: one 32-byte entry per 64
+         * corpus bytes on average, i.e. room for candidates in a quarter of all chunks. */
+        args.cand_waves = n_waves;
+        args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / 64 + n_waves - 1) / n_waves);
+        if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32)) != HSGPU_SUCCESS) return rv;
+        args.cand = (uint4 *)s->cand.p;
+        args.cand_counts = (uint32_t *)s->ctl.p + 2 * (size_t)n_waves;
+        if ((rv = set_dyn_lds(f_two, lds_two)) != HSGPU_SUCCESS) return rv;
+        if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
+        HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds_two, stream));
+        HIP_TRY(hipLaunchKernel(f_conf, dim3((n_waves + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
+        HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
+    }
+    HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
+    HIP_TRY(hipLaunchKernel(hsgpu_record_pack_kernel(), dim3((n_waves + 3) / 4), dim3(256), kargs, 0, stream));
     return HSGPU_SUCCESS;
 }
 

@@ -4,10 +4,13 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 #include "../../include/hsgpu.h"
 
 #define HSGPU_WG_THREADS 1024
+#define HSGPU_CONFIRM_THREADS 256
+#define HSGPU_HINT_SHIFT 10 /* one block hint per KiB of corpus */
 
 struct HsgpuScanArgs {
     const uint8_t *corpus;      /* all blocks, concatenated; 16-byte aligned */
@@ -16,13 +19,32 @@ struct HsgpuScanArgs {
     uint64_t nblocks;
     uint64_t start;             /* hwlmExec's `start`, applied inside every block */
     const uint8_t *blob;        /* compiled table in HBM */
+    /* table header fields the kernels need, copied here by the host so that no
+     * kernel starts with a dependent read of the header */
+    uint32_t t_flags, t_filter_log2, t_ht_a_log2, t_ht_b_log2;
+    uint32_t t_off_filter, t_off_c2bits, t_off_ht_a, t_off_ht_b, t_off_c2ref, t_off_lists, t_off_lits;
     hsgpu_match_t *out;         /* match records */
     uint64_t cap;               /* capacity of out */
     unsigned long long *count;  /* total matches (may exceed cap) */
+    const uint32_t *hint;       /* hint[t] = block containing byte t << HSGPU_HINT_SHIFT */
+    uint64_t n_hint;
+    uint4 *cand;                /* two-phase: 32-byte candidate entries (2 x uint4), one region per filter wavefront */
+    uint32_t cand_cap;          /* entries per region */
+    uint32_t cand_waves;        /* number of regions = filter grid x 16 */
+    uint32_t *cand_counts;      /* [cand_waves] entries written per region, [cand_waves] = overflow flag */
+    uint4 *rec_stage;           /* staged match records, one region of rec_cap per producing wavefront */
+    uint32_t rec_cap;
+    uint32_t rec_regions;       /* number of record regions */
+    uint32_t *rec_counts;       /* [rec_regions][2]: records at the front / at the back of each region */
+    unsigned long long *rec_offsets; /* [rec_regions]: exclusive scan of the region fills */
 };
 
-const void *hsgpu_scan_kernel_for(uint32_t table_flags);
-size_t hsgpu_scan_lds_bytes(uint32_t table_flags, uint32_t filter_log2_words);
+const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
+const void *hsgpu_confirm_kernel_for(uint32_t table_flags);
+const void *hsgpu_hint_kernel(void);
+const void *hsgpu_record_scan_kernel(void);
+const void *hsgpu_record_pack_kernel(void);
+size_t hsgpu_filter_lds_bytes(uint32_t table_flags, uint32_t filter_log2, bool fused);
 uint32_t hsgpu_scan_super_tile(void);
 
 #endif

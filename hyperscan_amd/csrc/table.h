@@ -31,15 +31,23 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 1u
+#define HSGPU_TABLE_VERSION 3u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
 #define HSGPU_F_HAS_C 4u /* literals keyed on their last <= 2 bytes */
+#define HSGPU_F_REPL 8u  /* filter is bank-replicated (small sets): conflict-free LDS reads */
+#define HSGPU_F_K2 16u   /* keys set/test two bits of their filter word */
+#define HSGPU_F_STRIDE2 32u /* lookups at even positions only; keys for delta 0 and 1 */
+#define HSGPU_F_BLIND 64u   /* hash and exact-table keys ignore bit 5 (the ASCII case bit) of every byte */
 
 #define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
 #define HSGPU_HT_MUL 0x9E3779B1u
 #define HSGPU_LIST_END 0x80000000u
+#define HSGPU_REF_DIRECT 0x80000000u /* slot.ref: ONE list entry (literal | delta), no list */
+#define HSGPU_LIST_DELTA_SHIFT 30     /* list entry bit 30: the literal ends at q + 1, not at q */
+#define HSGPU_LIST_LIT_MASK 0x00ffffffu
+#define HSGPU_BUCKET_SLOTS 4u
 
 #define HSGPU_LIT_NORUNS 1u
 
@@ -50,9 +58,9 @@ struct HsgpuTableHeader {
     uint32_t flags;
     uint32_t n_lits;
     uint32_t max_size;
-    uint32_t filter_log2_words;
+    uint32_t filter_log2; /* hashed: log2(words); replicated: log2(rows), 32 words per row */
     uint32_t filter_entries;
-    uint32_t ht_a_log2;
+    uint32_t ht_a_log2; /* log2(buckets), HSGPU_BUCKET_SLOTS slots each */
     uint32_t ht_b_log2;
     uint32_t n_a, n_b, n_c;
     uint32_t off_filter;
@@ -85,19 +93,31 @@ struct HsgpuDevLit {
 static_assert(sizeof(HsgpuDevLit) == 32, "DevLit is 32 bytes");
 
 /* ---- the filter hash, identical on host (insert) and device (probe) --------
- * For the byte position p (its byte b0 = buf[p], b1 = buf[p-1], ...):
- *   x    = b2 | b1 << 8 | b0 << 16                 (the 3-byte suffix)
+ * For a lookup at byte position q (b0 = buf[q], b1 = buf[q-1], b2 = buf[q-2], b3 = buf[q-3]):
+ *   x    = b2 | b1 << 8 | b0 << 16                  (the 3 bytes ending at q; & 0xdfdfdf if BLIND)
  *   prod = (x * HSGPU_FILTER_MUL) mod 2^32          (one v_mul_u32_u24)
- *   a    = prod >> (30 - k)                         (k = log2 filter words)
- *   word = a >> 2
- *   bitA = (b3 + a) & 31     for a literal keyed on 4 bytes
- *   bitB = (prod >> 8) & 31  for a literal keyed on 3 bytes
+ * hashed filter of 2^k words:
+ *   a    = prod >> (30 - k);  word = a >> 2         (a keeps two sub-word hash bits)
+ * replicated filter of 2^r rows x 32 identical columns (lane l reads column l & 31):
+ *   a    = prod >> (32 - r);  word = a * 32 + column
+ * bits tested in that word:
+ *   bitA  = (a + b3) & 31              4-byte key, first bit   (v_add_u32_sdwa + v_bfe)
+ *   bitA2 = ((prod >> 11) + b3) & 31   4-byte key, second bit  (only with HSGPU_F_K2)
+ *   bitB  = (prod >> 8) & 31           3-byte key, first bit
+ *   bitB2 = (prod >> 13) & 31          3-byte key, second bit  (only with HSGPU_F_K2)
  */
 HSGPU_HD uint32_t hsgpu_filter_prod(uint32_t x24) { return (x24 & 0xffffffu) * HSGPU_FILTER_MUL; }
-HSGPU_HD uint32_t hsgpu_filter_a(uint32_t prod, uint32_t k) { return prod >> (30u - k); }
+HSGPU_HD uint32_t hsgpu_filter_shift(uint32_t flags, uint32_t log2) {
+    return (flags & HSGPU_F_REPL) ? 32u - log2 : 30u - log2;
+}
 HSGPU_HD uint32_t hsgpu_filter_bit_a(uint32_t b3, uint32_t a) { return (b3 + a) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { return (b3 + (prod >> 11)) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t prod) { return (prod >> 8) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_b2(uint32_t prod) { return (prod >> 13) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_words(uint32_t flags, uint32_t log2) {
+    return (flags & HSGPU_F_REPL) ? (32u << log2) : (1u << log2);
+}
 
-HSGPU_HD uint32_t hsgpu_ht_slot(uint32_t key, uint32_t log2) { return (key * HSGPU_HT_MUL) >> (32u - log2); }
+HSGPU_HD uint32_t hsgpu_ht_bucket(uint32_t key, uint32_t log2) { return (key * HSGPU_HT_MUL) >> (32u - log2); }
 
 #endif

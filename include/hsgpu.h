@@ -94,7 +94,18 @@ typedef struct hsgpu_hwlm_info {
     uint32_t ht_a_slots, ht_b_slots;
     uint32_t max_size;                        /* longest literal/mask */
     uint32_t blob_bytes;
+    uint32_t flags;                           /* HSGPU_F_* of csrc/table.h (classes, filter layout) */
 } hsgpu_hwlm_info_t;
+
+/* hsgpu_hwlm_build flags: engine forcing for tests, like the reference's
+ * fdrBuildProtoHinted hook (src/fdr/fdr_compile.cpp:900-911). 0 = automatic. */
+#define HSGPU_BUILD_FORCE_REPL 1u   /* bank-replicated ("Teddy class") filter */
+#define HSGPU_BUILD_FORCE_HASHED 2u /* hashed ("FDR class") filter */
+#define HSGPU_BUILD_FORCE_K2 4u     /* two filter bits per key */
+#define HSGPU_BUILD_FORCE_K1 8u     /* one filter bit per key */
+#define HSGPU_BUILD_FORCE_STRIDE1 16u /* look up every byte position (no stride-2 keys) */
+#define HSGPU_BUILD_FORCE_STRIDE2 64u /* stride 2 even with 2- and 3-byte literals */
+#define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
 
 /* ---- build side ---------------------------------------------------------- */
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""tools/kbench.py -- kernel-only timing loop for profiling / tuning (GPU box).
+Usage: python tools/kbench.py [teddy64|fdr10k] [--gib 1] [--iters 20]
+Prints kernel ms (avg/best), GB/s and the match count. No CPU baseline."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", nargs="?", default="teddy64")
+    ap.add_argument("--gib", type=float, default=1.0)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    import torch
+
+    import bench
+
+    lits, corpus, off = bench.build_workload(a.workload, int(a.gib * (1 << 30)), 0)
+    job = bench.GpuJob(lits, corpus, off, 0)
+    for _ in range(3):
+        job.launch()
+    torch.cuda.synchronize()
+    n = job.count()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+    for i in range(a.iters):
+        job.d_count.zero_()
+        ev[i][0].record()
+        from hyperscan_amd import hwlm as hw
+        hw.hwlm_scan_dev(job.table, job.scratch, job.d_corpus.data_ptr(), job.total, job.d_off.data_ptr(),
+                         job.nblocks, job.d_out.data_ptr(), job.cap, job.d_count.data_ptr(), 0,
+                         torch.cuda.current_stream().cuda_stream)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    ms = np.array([x.elapsed_time(y) for x, y in ev])
+    gb = (job.total + 16 * n) / 1e9
+    print(f"{a.workload}: kernel avg {ms.mean():.4f} ms best {ms.min():.4f} ms -> {gb / ms.mean() * 1e3:.1f} GB/s avg, "
+          f"{gb / ms.min() * 1e3:.1f} best; matches {n}; table {job.table.info()}")
+
+
+if __name__ == "__main__":
+    main()
