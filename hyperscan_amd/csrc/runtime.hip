@@ -60,6 +60,8 @@ struct DevBuf {
 struct hsgpu_scratch {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;           /* block hints are computed beside the filter kernel */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets;
     unsigned long long *h_count = nullptr; /* pinned */
     int n_cu = 0;
@@ -120,6 +122,9 @@ extern "C" int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device) {
     s->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&s->h_count, sizeof(unsigned long long)) != hipSuccess) {
         hsgpu_set_error("scratch setup failed");
         hsgpu_scratch_free(s);
@@ -149,6 +154,9 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->rec_stage.release();
     s->rec_offsets.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->side) (void)hipStreamDestroy(s->side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -211,31 +219,41 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
     if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
     args.hint = (const uint32_t *)s->hint.p;
+    const bool two_phase = scan_mode() == 0;
     {
+        /* two-phase: the hints are only needed by the confirm kernel, so they are
+         * computed on a side stream while the filter kernel streams the corpus */
         const uint64_t *off = a.off;
         uint64_t nblocks = a.nblocks, total = a.total, n_hint = args.n_hint;
         uint32_t *hint = (uint32_t *)s->hint.p;
-        void *kargs[] = {&off, &nblocks, &total, &hint, &n_hint};
-        HIP_TRY(hipLaunchKernel(hsgpu_hint_kernel(), dim3((unsigned)((n_hint + 255) / 256)), dim3(256), kargs, 0,
-                                stream));
+        void *hargs[] = {&off, &nblocks, &total, &hint, &n_hint};
+        hipStream_t hs = stream;
+        if (two_phase) {
+            HIP_TRY(hipEventRecord(s->ev_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+            hs = s->side;
+        }
+        HIP_TRY(hipLaunchKernel(hsgpu_hint_kernel(), dim3((unsigned)((n_hint + 255) / 256)), dim3(256), hargs, 0, hs));
+        if (two_phase) HIP_TRY(hipEventRecord(s->ev_join, s->side));
     }
     /* staged match records: one region per producing wavefront, packed into the
      * caller's buffer by the last two kernels. 2x headroom over an even split. */
     const uint32_t n_waves = grid * (HSGPU_WG_THREADS / 64);
-    args.rec_regions = n_waves;
-    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_waves + 1)));
-    if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_waves * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
-    /* one zeroed control block: rec_counts[2n] | cand_counts[n + 1]; rec_offsets apart */
-    const size_t ctl_words = (size_t)3 * n_waves + 1;
+    const uint32_t n_rec = n_waves * HSGPU_CONFIRM_SPLIT; /* the fused kernel uses the first n_waves of them */
+    args.rec_regions = n_rec;
+    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
+    if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
+    /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1]; rec_offsets apart */
+    const size_t ctl_words = (size_t)2 * n_rec + n_waves + 1;
     if ((rv = s->ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
-    if ((rv = s->rec_offsets.ensure((size_t)n_waves * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->rec_offsets.ensure((size_t)n_rec * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
     args.rec_stage = (uint4 *)s->rec_stage.p;
     args.rec_counts = (uint32_t *)s->ctl.p;
     args.rec_offsets = (unsigned long long *)s->rec_offsets.p;
     HIP_TRY(hipMemsetAsync(s->ctl.p, 0, ctl_words * sizeof(uint32_t), stream));
 
     void *kargs[] = {&args};
-    if (scan_mode() == 1) {
+    if (!two_phase) {
         args.cand = nullptr;
         args.cand_cap = 0;
         args.cand_waves = 0;
@@ -251,15 +269,16 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / 64 + n_waves - 1) / n_waves);
         if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32)) != HSGPU_SUCCESS) return rv;
         args.cand = (uint4 *)s->cand.p;
-        args.cand_counts = (uint32_t *)s->ctl.p + 2 * (size_t)n_waves;
+        args.cand_counts = (uint32_t *)s->ctl.p + 2 * (size_t)n_rec;
         if ((rv = set_dyn_lds(f_two, lds_two)) != HSGPU_SUCCESS) return rv;
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds_two, stream));
-        HIP_TRY(hipLaunchKernel(f_conf, dim3((n_waves + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
+        HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
+        HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
     }
     HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
-    HIP_TRY(hipLaunchKernel(hsgpu_record_pack_kernel(), dim3((n_waves + 3) / 4), dim3(256), kargs, 0, stream));
+    HIP_TRY(hipLaunchKernel(hsgpu_record_pack_kernel(), dim3((n_rec + 3) / 4), dim3(256), kargs, 0, stream));
     return HSGPU_SUCCESS;
 }
 
@@ -337,7 +356,7 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
     HIP_TRY(hipMemcpyAsync(s->corpus.p, base + lo, total, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->off.p, rel.data(), rel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
     uint64_t cap = std::max<uint64_t>(4096, total / 256);
-    for (int attempt = 0; attempt < 3; attempt++) {
+    for (int attempt = 0; attempt < 8; attempt++) {
         if ((rv = s->out.ensure(cap * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipMemsetAsync(s->count.p, 0, sizeof(unsigned long long), s->stream));
         rv = hsgpu_hwlm_scan_dev(t, s, s->corpus.p, total, s->off.p, nblocks, start, s->out.p, cap, s->count.p,
@@ -352,7 +371,10 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
             std::sort(recs.begin(), recs.end(), rec_less);
             return HSGPU_SUCCESS;
         }
-        cap = n; /* overflow: the count is exact, rerun with room for all of them */
+        /* overflow: the count is exact; rerun with room for all of them, and since the
+         * records are staged in per-wavefront regions sized from cap, leave headroom
+         * for skew (doubling per attempt) */
+        cap = std::max<uint64_t>(n + n / 4, cap * 2);
     }
     hsgpu_set_error("match buffer overflow persisted");
     return HSGPU_UNKNOWN_ERROR;

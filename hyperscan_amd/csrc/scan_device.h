@@ -1,0 +1,678 @@
+/*
+ * scan_device.h -- the block-mode multi-literal scan kernel for gfx950.
+ *
+ * Replaces, on the GPU, the reference's FDR / Teddy / Noodle main loops and
+ * their confirm step:
+ *   FDR_MAIN_LOOP + get_conf_stride_N     src/fdr/fdr.c:157-327,694-723
+ *   prep_conf_teddy_m1..m4, CONFIRM_TEDDY src/fdr/teddy.c:893-1064
+ *   noodle scan/final                     src/hwlm/noodle_engine.c:113-138
+ *   do_confirm_fdr / confWithBit          src/fdr/fdr.c:330-364,
+ *                                         src/fdr/fdr_confirm_runtime.h:43-102
+ * It is a new design, not a translation: there are no buckets, no shift-or
+ * state and no zones. See DESIGN.md "Kernel".
+ *
+ * Mapping. The corpus is the concatenation of all blocks (CSR offsets). A
+ * workgroup of 16 wavefronts owns a 16 KiB super-tile per iteration; each
+ * wavefront owns 1 KiB of it, each lane one 16-byte chunk, loaded with one
+ * coalesced global_load_dwordx4 two iterations ahead of its use (register
+ * double-buffering; nothing in the steady-state loop waits for HBM).
+ *
+ * Filter (per lookup position, all lanes): hash the 3 bytes ending there with
+ * one v_mul_u32_u24, read ONE 32-bit word of the LDS-resident filter, test one
+ * bit chosen by the 4th byte (optionally a second bit). With stride 2 only every
+ * second byte is a lookup position: the table then also holds every literal
+ * keyed one byte early, so a lookup at q catches literals ending at q and q + 1
+ * (the kernel is VALU-bound at ~7 instructions per lookup, so this doubles its
+ * rate). Two filter layouts:
+ *   REPL   small literal sets ("Teddy class"): 32 identical columns, lane l reads
+ *          column l & 31 -> every lane of a 32-lane LDS group hits its own bank,
+ *          conflict-free by construction;
+ *   hashed large sets ("FDR class"): one 2^k-word table, up to 128 KiB.
+ * Candidates are collected as one 16-bit mask per lane and class.
+ *
+ * Confirm. Candidates are rare (a fraction of a percent of positions) but each
+ * one needs a chain of dependent HBM/L2 reads (window -> hash bucket -> literal
+ * -> block offsets). Inside the streaming kernel every link of that chain queues
+ * behind the wavefront's own prefetches, so the default pipeline is two-phase:
+ *   hwlm_filter_kernel  streams the corpus, compacts {chunk, masks} candidate
+ *                       entries through a per-wavefront LDS queue and writes
+ *                       them to HBM 64 at a time (one reservation per 512 B);
+ *   hwlm_confirm_kernel one lane per candidate entry, all of them in flight at
+ *                       once: exact hash-table bucket (32 B), (window & msk) ==
+ *                       v per listed literal, block lookup through a per-KiB
+ *                       hint table, bound checks, records staged per wavefront
+ *                       in LDS and stored with one reservation per flush.
+ * A fused variant (confirm inside the streaming kernel) is kept as the
+ * always-correct fallback for inputs so dense that the candidate buffer
+ * overflows (the role of the reference's flood path, flood_runtime.h:86-335);
+ * it is launched after the other two and returns at once unless they overflowed.
+ *
+ * Block boundaries are invisible to the filter; the confirm step resolves the
+ * block of a candidate and rejects matches that would start before their block
+ * (or before `start` within it).
+ */
+#ifndef HSGPU_SCAN_DEVICE_H
+#define HSGPU_SCAN_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scan_kernels.h"
+#include "table.h"
+
+namespace {
+
+
+constexpr int WG_THREADS = HSGPU_WG_THREADS;
+constexpr int WAVES = WG_THREADS / 64;
+constexpr int CHUNK = 16;                     /* bytes per lane per iteration */
+constexpr int WAVE_TILE = 64 * CHUNK;         /* 1 KiB */
+constexpr int SUPER_TILE = WAVES * WAVE_TILE; /* 16 KiB */
+constexpr int QCAP = 128;                     /* fused: candidate-queue entries per wavefront */
+constexpr int OCAP = 28;                      /* staged match records per wavefront */
+constexpr int CONFIRM_THREADS = HSGPU_CONFIRM_THREADS;
+constexpr int OFLUSH = 12;                    /* flush the staged records at this fill */
+
+/* per-wavefront LDS area: candidate queue (fused kernel) + staged output records */
+struct WaveLds {
+    uint2 cand[QCAP];
+    uint4 rec[OCAP];
+    uint32_t nrec;   /* records staged in rec[] */
+    uint32_t nfront; /* records already appended to the front of this wavefront's HBM region */
+    uint32_t nback;  /* records spilled to the back of the region (staging full mid-drain) */
+    uint32_t pad[13];
+};
+static_assert(sizeof(WaveLds) == 1536, "per-wave LDS area is 1.5 KiB: 128 KiB filter + 8 KiB + 16 x 1.5 KiB = 160 KiB");
+
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+__device__ __forceinline__ uint32_t bfe1(uint32_t v, uint32_t bit) { return __builtin_amdgcn_ubfe(v, bit, 1); }
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {
+    return __builtin_amdgcn_alignbyte(hi, lo, n);
+}
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+    return (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32 |
+           __builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+/* 32-bit read at an absolute LDS byte address. The filter kernels have no static
+ * __shared__ data, so their dynamic LDS segment starts at LDS address 0 (checked
+ * once at kernel entry); addressing it absolutely saves the per-lookup
+ * "v_add base" the compiler otherwise emits. */
+typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
+__device__ __forceinline__ uint32_t lds_word(uint32_t byte_addr) { return *(lds_u32_t *)(uintptr_t)byte_addr; }
+
+struct Tables {
+    const uint8_t *corpus;
+    const uint64_t *off;
+    uint64_t nblocks, start, total;
+    const HsgpuHtSlot *ht_a, *ht_b;
+    const uint32_t *c2ref, *lists;
+    const HsgpuDevLit *lits;
+    uint32_t ht_a_log2, ht_b_log2;
+    uint32_t key_mask;    /* 0xdfdfdfdf when the exact-table keys are case-blind, else all ones */
+    const uint32_t *hint; /* block containing byte t << HSGPU_HINT_SHIFT, t < n_hint */
+    uint64_t n_hint;
+    WaveLds *wl;       /* this wavefront's LDS area */
+    uint4 *rec_region; /* this wavefront's private region of the staged-record buffer */
+    uint32_t rec_cap;  /* its capacity in records */
+};
+
+/* the 8 bytes ending at g, little-endian, bytes before the corpus read as 0
+ * (conf_key of fdr.c:360 in block mode). Aligned dword loads + funnel shift. */
+__device__ __forceinline__ uint64_t window8(const uint8_t *corpus, uint64_t g) {
+    if (g < 7) {
+        uint64_t w = 0;
+        for (uint64_t i = 0; i <= g; i++) w |= (uint64_t)corpus[i] << (8 * (7 - g + i));
+        return w;
+    }
+    uint64_t first = g - 7;
+    const uint32_t *p = (const uint32_t *)(corpus + (first & ~3ull));
+    uint32_t sh = (uint32_t)(first & 3);
+    uint32_t d0 = p[0], d1 = p[1];
+    if (sh == 0) return (uint64_t)d1 << 32 | d0;
+    uint32_t d2 = p[2];
+    uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh * 8);
+    uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh * 8);
+    return (uint64_t)hi << 32 | lo;
+}
+
+/* index of the block containing corpus offset g: last b with off[b] <= g,
+ * searched in [lo, hi] (inclusive bounds known to bracket it) */
+__device__ __forceinline__ uint64_t find_block(const uint64_t *off, uint64_t lo, uint64_t hi, uint64_t g) {
+    hi += 1; /* invariant: off[lo] <= g < off[hi] */
+    while (hi - lo > 1) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+/* Block of corpus offset g and that block's start. Two dependent reads in the
+ * common case: the hint pair, then the next three offsets after off[lo] all at
+ * once; only tiles cut into more than three blocks fall back to bisection. */
+__device__ __forceinline__ uint64_t block_of(const Tables &t, uint64_t g, uint64_t &block_start) {
+    const uint64_t tile = g >> HSGPU_HINT_SHIFT;
+    const uint64_t lo = t.hint[tile];
+    const uint64_t hi = (tile + 1 < t.n_hint) ? t.hint[tile + 1] : t.nblocks - 1;
+    const uint64_t o0 = t.off[lo];
+    const uint64_t o1 = t.off[min(lo + 1, t.nblocks)], o2 = t.off[min(lo + 2, t.nblocks)],
+                   o3 = t.off[min(lo + 3, t.nblocks)];
+    if (g < o1 || lo + 1 > hi) { block_start = o0; return lo; }
+    if (g < o2 || lo + 2 > hi) { block_start = o1; return lo + 1; }
+    if (g < o3 || lo + 3 > hi) { block_start = o2; return lo + 2; }
+    const uint64_t b = find_block(t.off, lo + 3, hi, g);
+    block_start = t.off[b];
+    return b;
+}
+
+/* One list entry = literal index | delta << 30: does that literal end at g + delta?
+ * w0 / w1 are the 8-byte windows ending at g and g + 1. */
+__device__ __forceinline__ void check_lit(const Tables &t, uint32_t ent, uint64_t w0, uint64_t w1, uint64_t g) {
+    const uint32_t li = ent & HSGPU_LIST_LIT_MASK;
+    const uint32_t delta = (ent >> HSGPU_LIST_DELTA_SHIFT) & 1u;
+    const uint64_t w = delta ? w1 : w0;
+    const uint4 *lp = (const uint4 *)(t.lits + li);
+    const uint4 l0 = lp[0], l1 = lp[1]; /* {v, msk}, {groups, id, size|flags}: one 32-byte line */
+    const uint64_t v = (uint64_t)l0.y << 32 | l0.x, msk = (uint64_t)l0.w << 32 | l0.z;
+    if ((w & msk) != v) return;
+    const uint64_t ge = g + delta;
+    if (ge >= t.total) return; /* q + 1 can be one past the corpus */
+    const uint32_t id = l1.z, size = l1.w & 0xff;
+    uint64_t bstart;
+    const uint64_t b = block_of(t, ge, bstart);
+    const uint64_t end = ge - bstart;
+    /* left bound (fdr_confirm_runtime.h:77-88) and `start` (hwlm.h:108-111) */
+    if (end + 1 < size || end + 1 - size < t.start) return;
+    /* Stage the record in this wavefront's LDS area. No global atomics anywhere:
+     * a single counter word sustains only ~90 returning atomics per microsecond,
+     * which would cap the whole scan at a few tens of thousands of matches per ms.
+     * Staged records are appended to the wavefront's private HBM region at
+     * convergent points (flush_records); a compaction pass packs the regions. */
+    const uint4 rec = make_uint4((uint32_t)b, (uint32_t)end, id, li);
+    const uint32_t s = __hip_atomic_fetch_add(&t.wl->nrec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (s < OCAP) {
+        t.wl->rec[s] = rec;
+    } else { /* staging full inside one drain: spill to the back of the region */
+        const uint32_t k = __hip_atomic_fetch_add(&t.wl->nback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (k < t.rec_cap) t.rec_region[t.rec_cap - 1 - k] = rec;
+    }
+}
+
+/* Convergent: append the staged records to the front of the wavefront's region. */
+__device__ __forceinline__ void flush_records(const Tables &t, uint32_t lane, uint32_t threshold) {
+    uint32_t n = __hip_atomic_load(&t.wl->nrec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n < threshold) return;
+    if (n > OCAP) n = OCAP;
+    const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
+    if (lane < n && f + lane < t.rec_cap) t.rec_region[f + lane] = t.wl->rec[lane];
+    if (lane == 0) {
+        t.wl->nfront = f + n; /* keeps counting past the capacity: the total stays exact */
+        __hip_atomic_store(&t.wl->nrec, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+
+/* End of a wavefront's work: publish how much of its region is in use. */
+__device__ __forceinline__ void publish_records(const Tables &t, const HsgpuScanArgs &args, uint32_t lane,
+                                                uint32_t region) {
+    flush_records(t, lane, 1);
+    if (lane == 0) {
+        args.rec_counts[2 * region] = t.wl->nfront;
+        args.rec_counts[2 * region + 1] =
+            __hip_atomic_load(&t.wl->nback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+
+__device__ __forceinline__ void walk_ref(const Tables &t, uint32_t ref, uint64_t w0, uint64_t w1, uint64_t g) {
+    if (ref & HSGPU_REF_DIRECT) {
+        check_lit(t, ref, w0, w1, g);
+        return;
+    }
+    uint32_t i = ref - 1, e;
+    do {
+        e = t.lists[i++];
+        check_lit(t, e, w0, w1, g);
+    } while (!(e & HSGPU_LIST_END));
+}
+
+/* one 32-byte bucket (4 slots) per probe; continue to the next bucket only when
+ * this one is full (the host inserts with the same rule). */
+__device__ __forceinline__ void probe(const Tables &t, const HsgpuHtSlot *ht, uint32_t log2, uint32_t key,
+                                      uint64_t w0, uint64_t w1, uint64_t g) {
+    const uint32_t mask = (1u << log2) - 1;
+    uint32_t b = hsgpu_ht_bucket(key, log2);
+    for (;;) {
+        const uint4 *bp = (const uint4 *)(ht + (size_t)b * HSGPU_BUCKET_SLOTS);
+        const uint4 s01 = bp[0], s23 = bp[1];
+        if (s01.y && s01.x == key) return walk_ref(t, s01.y, w0, w1, g);
+        if (s01.w && s01.z == key) return walk_ref(t, s01.w, w0, w1, g);
+        if (s23.y && s23.x == key) return walk_ref(t, s23.y, w0, w1, g);
+        if (s23.w && s23.z == key) return walk_ref(t, s23.w, w0, w1, g);
+        if (!s23.w) return; /* slots fill in order: last slot empty => bucket not full */
+        b = (b + 1) & mask;
+    }
+}
+
+/* confirm one lookup position g given the windows ending at g (w0) and g + 1 (w1) */
+template <bool HAS_A, bool HAS_B, bool HAS_C>
+__device__ __forceinline__ void confirm_pos(const Tables &t, bool hit_a, bool hit_o, uint64_t w0, uint64_t w1,
+                                            uint64_t g) {
+    const uint32_t w4 = (uint32_t)(w0 >> 32) & t.key_mask;
+    if (HAS_A && hit_a) probe(t, t.ht_a, t.ht_a_log2, w4, w0, w1, g);
+    if ((HAS_B || HAS_C) && hit_o) {
+        if (HAS_B) probe(t, t.ht_b, t.ht_b_log2, w4 >> 8, w0, w1, g);
+        if (HAS_C) {
+            const uint32_t ref = t.c2ref[w4 >> 16];
+            if (ref) walk_ref(t, ref, w0, w1, g);
+        }
+    }
+}
+
+/* fused kernel: {chunk, masks} entry, windows re-read from the corpus (L2 hits) */
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+__device__ __forceinline__ void drain_entry(const Tables &t, uint2 e) {
+    const uint32_t m = e.y;
+    uint32_t any = (m | m >> 16) & 0xffffu;
+    while (any) {
+        const uint32_t j = __builtin_ctz(any);
+        any &= any - 1;
+        const uint64_t g = (uint64_t)e.x * CHUNK + j;
+        const uint64_t w0 = window8(t.corpus, g);
+        const uint64_t w1 = (S2 && g + 1 < t.total) ? window8(t.corpus, g + 1) : 0;
+        confirm_pos<HAS_A, HAS_B, HAS_C>(t, m >> j & 1, m >> (16 + j) & 1, w0, w1, g);
+    }
+}
+
+/* two-phase: a 32-byte candidate entry carries the lane's chunk and the 8 bytes
+ * in front of it, so confirming never touches the corpus again */
+__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t nbytes) { /* nbytes 1..8 */
+    return nbytes == 8 ? hi : (lo >> (8 * nbytes)) | (hi << (64 - 8 * nbytes));
+}
+
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+__device__ __forceinline__ void drain_fat_entry(const Tables &t, uint4 e0, uint4 e1) {
+    const uint32_t m = e0.y;
+    const uint64_t A = (uint64_t)e0.w << 32 | e0.z; /* c[-8..-1] */
+    const uint64_t B = (uint64_t)e1.y << 32 | e1.x; /* c[0..7]   */
+    const uint64_t C = (uint64_t)e1.w << 32 | e1.z; /* c[8..15]  */
+    uint32_t any = (m | m >> 16) & 0xffffu;
+    while (any) {
+        const uint32_t j = __builtin_ctz(any);
+        any &= any - 1;
+        const uint64_t g = (uint64_t)e0.x * CHUNK + j;
+        /* window ending at c[e]: e <= 7 -> (A,B) shifted by e+1 bytes, else (B,C) by e-7 */
+        const uint64_t w0 = j < 8 ? funnel64(A, B, j + 1) : funnel64(B, C, j - 7);
+        uint64_t w1 = 0;
+        if (S2) w1 = (j + 1) < 8 ? funnel64(A, B, j + 2) : funnel64(B, C, j - 6); /* j even: j + 1 <= 15 */
+        confirm_pos<HAS_A, HAS_B, HAS_C>(t, m >> j & 1, m >> (16 + j) & 1, w0, w1, g);
+    }
+}
+
+struct Chunk {
+    uint4 d;  /* this lane's 16 bytes */
+    uint2 h;  /* the 8 bytes in front of them (h.y = c[-4..-1]) */
+};
+
+struct FilterCfg {
+    uint32_t shift;  /* prod >> shift = a */
+    uint32_t amask;  /* hashed: byte-address mask for a */
+    uint32_t lane4;  /* replicated: (lane & 31) * 4 */
+    uint32_t c2base; /* LDS byte address of the 2-byte table */
+};
+
+/* The filter over one 16-byte chunk: candidate masks, bit q = lookup position q;
+ * low half = 4-byte-key hits, high half = 3-/2-byte-key hits. Fully unrolled:
+ * every window is a compile-time byte offset into {h.y, d.x, d.y, d.z, d.w}. */
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND>
+__device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg &f) {
+    const uint32_t arr[6] = {c.h.y, c.d.x, c.d.y, c.d.z, c.d.w, 0u};
+    uint32_t acc_a = 0, acc_o = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q += (S2 ? 2 : 1)) {
+        /* 3 bytes ending at c[q]: byte offset q + 2 into arr */
+        const int o = q + 2;
+        uint32_t x = (o & 3) ? alignbyte(arr[(o >> 2) + 1], arr[o >> 2], o & 3) : arr[o >> 2];
+        if (BLIND) x &= 0xdfdfdfdfu; /* b3's bit 5 never reaches the 5-bit index either */
+        /* the byte before them, c[q-3]: byte offset q + 1 (an SDWA operand select) */
+        const uint32_t b3 = (arr[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xffu;
+        const uint32_t prod = mul_u24(x, HSGPU_FILTER_MUL);
+        const uint32_t a = prod >> f.shift;
+        const uint32_t addr = REPL ? ((a << 7) | f.lane4) : (a & f.amask);
+        const uint32_t word = lds_word(addr);
+        if (HAS_A) {
+            uint32_t hit = bfe1(word, a + b3);
+            if (K2) hit &= bfe1(word, (prod >> 11) + b3);
+            acc_a |= hit << q;
+        }
+        if (HAS_B || HAS_C) {
+            uint32_t hit = 0;
+            if (HAS_B) {
+                hit = bfe1(word, prod >> 8);
+                if (K2) hit &= bfe1(word, prod >> 13);
+            }
+            if (HAS_C) {
+                const uint32_t kc = __builtin_amdgcn_ubfe(x, 8, 16);
+                hit |= bfe1(lds_word(f.c2base + ((kc >> 5) << 2)), kc);
+            }
+            acc_o |= hit << q;
+        }
+    }
+    return acc_a | acc_o << 16;
+}
+
+struct SpillState {
+    uint4 *region;     /* this wavefront's region of the candidate buffer (32-byte entries) */
+    uint32_t written;  /* entries appended so far */
+    uint32_t overflow; /* region exhausted: the scan falls back to the fused kernel */
+};
+
+/* two-phase: lanes with candidates append {chunk index, masks, 8-byte halo, chunk}
+ * straight to this wavefront's private HBM region (ranked by ballot; no atomics,
+ * no LDS staging) */
+__device__ __forceinline__ void spill(const HsgpuScanArgs &args, SpillState &sp, uint64_t coff, uint32_t acc,
+                                      const Chunk &c) {
+    const bool has = acc != 0;
+    const unsigned long long bal = __ballot(has);
+    if (!bal) return;
+    const uint32_t n = __popcll(bal);
+    if (sp.written + n > args.cand_cap) {
+        sp.overflow = 1;
+        return;
+    }
+    if (has) {
+        const uint32_t rank =
+            __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+        uint4 *e = sp.region + 2ull * (sp.written + rank);
+        e[0] = make_uint4((uint32_t)(coff >> 4), acc, c.h.x, c.h.y);
+        e[1] = c.d;
+    }
+    sp.written += n;
+}
+
+/* fused: push into the wavefront's LDS queue; confirm 64 at a time */
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+__device__ __forceinline__ void enqueue_fused(const Tables &t, uint32_t &qcount, uint32_t lane, uint64_t coff,
+                                              uint32_t acc) {
+    uint2 *queue = t.wl->cand;
+    const bool has = acc != 0;
+    const unsigned long long bal = __ballot(has);
+    if (bal) {
+        if (has) {
+            uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+            queue[idx] = make_uint2((uint32_t)(coff >> 4), acc);
+        }
+        qcount += __popcll(bal);
+        if (qcount >= 64) {
+            qcount -= 64;
+            drain_entry<HAS_A, HAS_B, HAS_C, S2>(t, queue[qcount + lane]);
+            flush_records(t, lane, OFLUSH);
+        }
+    }
+}
+
+__device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args) {
+    t.corpus = args.corpus;
+    t.off = args.off;
+    t.nblocks = args.nblocks;
+    t.start = args.start;
+    t.total = args.total;
+    t.ht_a = (const HsgpuHtSlot *)(args.blob + args.t_off_ht_a);
+    t.ht_b = (const HsgpuHtSlot *)(args.blob + args.t_off_ht_b);
+    t.c2ref = (const uint32_t *)(args.blob + args.t_off_c2ref);
+    t.lists = (const uint32_t *)(args.blob + args.t_off_lists);
+    t.lits = (const HsgpuDevLit *)(args.blob + args.t_off_lits);
+    t.ht_a_log2 = args.t_ht_a_log2;
+    t.ht_b_log2 = args.t_ht_b_log2;
+    t.key_mask = (args.t_flags & HSGPU_F_BLIND) ? 0xdfdfdfdfu : 0xffffffffu;
+    t.hint = args.hint;
+    t.n_hint = args.n_hint;
+    t.wl = nullptr;
+    t.rec_region = nullptr;
+    t.rec_cap = 0;
+}
+
+__device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t lane) {
+    t.wl = wl;
+    if (lane == 0) {
+        wl->nrec = 0;
+        wl->nfront = 0;
+        wl->nback = 0;
+    }
+}
+
+/* ---- phase 1: the streaming filter (FUSED: + in-kernel confirm) ----------- */
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED>
+__global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs args) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
+    /* the fused kernel doubles as the overflow fallback: nothing to do unless the
+     * two-phase pipeline ran out of candidate space */
+    if (FUSED && args.cand_counts && !args.cand_counts[args.cand_waves]) return;
+
+    const uint32_t flog2 = args.t_filter_log2;
+    const uint32_t nw = REPL ? (32u << flog2) : (1u << flog2);
+    uint32_t *filter = lds;
+    uint32_t *c2bits = lds + nw;
+
+    /* stage the filter(s) in LDS: once per workgroup, 16 B per lane per step */
+    {
+        const uint4 *src = (const uint4 *)(args.blob + args.t_off_filter);
+        for (uint32_t i = threadIdx.x; i < nw / 4; i += WG_THREADS) ((uint4 *)filter)[i] = src[i];
+        if (HAS_C) {
+            const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
+            for (uint32_t i = threadIdx.x; i < 512; i += WG_THREADS) ((uint4 *)c2bits)[i] = src2[i];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * WAVES;
+    const uint32_t wave_global = blockIdx.x * WAVES + wave;
+
+    Tables t;
+    uint32_t qcount = 0;
+    SpillState sp;
+    sp.region = nullptr;
+    sp.written = 0;
+    sp.overflow = 0;
+    if (FUSED) {
+        init_tables(t, args);
+        init_wave_lds(t, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)) + wave, lane);
+        t.rec_region = args.rec_stage + (uint64_t)wave_global * args.rec_cap;
+        t.rec_cap = args.rec_cap;
+    } else {
+        sp.region = args.cand + 2ull * wave_global * args.cand_cap;
+    }
+
+    FilterCfg f;
+    f.shift = REPL ? 32u - flog2 : 30u - flog2;
+    f.amask = (nw - 1u) << 2;
+    f.lane4 = (lane & 31u) << 2;
+    f.c2base = nw * 4;
+
+    const uint8_t *corpus = args.corpus;
+    const uint64_t total = args.total;
+    const uint64_t n_full = total / SUPER_TILE; /* super-tiles with every load in bounds */
+    const uint32_t G = gridDim.x;
+    const uint32_t lane_off = wave * WAVE_TILE + lane * CHUNK;
+
+    /* unconditional loads of a (clamped) full tile: no branches, so the compiler
+     * keeps them in flight across iterations with counted s_waitcnt */
+    auto issue = [&](uint64_t tile) -> Chunk {
+        const uint64_t tl = tile < n_full ? tile : n_full - 1;
+        const uint64_t off = tl * SUPER_TILE + lane_off;
+        Chunk c;
+        c.d = *(const uint4 *)(corpus + off);
+        c.h = *(const uint2 *)(corpus + (off ? off - 8 : 0));
+        return c;
+    };
+
+#define HSGPU_HANDLE(CUR, COFF)                                                                   \
+    {                                                                                             \
+        if ((COFF) == 0) CUR.h = make_uint2(0, 0); /* nothing in front of the corpus */           \
+        const uint32_t acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f);             \
+        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2>(t, qcount, lane, (COFF), acc);          \
+        else spill(args, sp, (COFF), acc, CUR);                                                   \
+    }
+
+    if (n_full && blockIdx.x < n_full) {
+        uint64_t tile = blockIdx.x;
+        /* three register stages rotate by name (loop unrolled x3), so a stage is
+         * never copied and the only wait is for the stage about to be filtered */
+        Chunk c0 = issue(tile), c1 = issue(tile + G), c2;
+#define HSGPU_STAGE(CUR, NEW)                                   \
+    {                                                           \
+        NEW = issue(tile + 2ull * G);                           \
+        const uint64_t coff = tile * SUPER_TILE + lane_off;     \
+        HSGPU_HANDLE(CUR, coff)                                 \
+        tile += G;                                              \
+        if (tile >= n_full) break;                              \
+    }
+        for (;;) {
+            HSGPU_STAGE(c0, c2)
+            HSGPU_STAGE(c1, c0)
+            HSGPU_STAGE(c2, c1)
+        }
+#undef HSGPU_STAGE
+    }
+
+    /* the partial last super-tile: guarded, byte-wise where needed; one workgroup.
+     * Bytes at/after the end of the corpus read as zero and their lookup
+     * positions are masked off. */
+    if (total % SUPER_TILE && blockIdx.x == n_full % G) {
+        const uint64_t coff = n_full * SUPER_TILE + lane_off;
+        Chunk c;
+        c.d = make_uint4(0, 0, 0, 0);
+        c.h = make_uint2(0, 0);
+        if (coff < total) {
+            if (coff + CHUNK <= total) {
+                c.d = *(const uint4 *)(corpus + coff);
+            } else {
+                uint32_t tmp[4] = {0, 0, 0, 0};
+                const uint32_t n = (uint32_t)(total - coff);
+                for (uint32_t i = 0; i < n; i++) tmp[i >> 2] |= (uint32_t)corpus[coff + i] << (8 * (i & 3));
+                c.d = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+            }
+            if (coff) c.h = *(const uint2 *)(corpus + coff - 8);
+        }
+        uint32_t acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(c, f);
+        uint32_t valid = 0;
+        if (coff < total) valid = (coff + CHUNK <= total) ? 0xffffu : ((1u << (uint32_t)(total - coff)) - 1u);
+        acc &= valid | valid << 16;
+        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2>(t, qcount, lane, coff, acc);
+        else spill(args, sp, coff, acc, c);
+    }
+#undef HSGPU_HANDLE
+
+    if (FUSED) {
+        if (lane < qcount) drain_entry<HAS_A, HAS_B, HAS_C, S2>(t, t.wl->cand[lane]);
+        publish_records(t, args, lane, wave_global);
+    } else if (lane == 0) {
+        args.cand_counts[wave_global] = sp.written;
+        if (sp.overflow) args.cand_counts[n_waves] = 1;
+    }
+}
+
+/* ---- phase 2: confirm. HSGPU_CONFIRM_SPLIT wavefronts share one filter
+ * wavefront's candidate region (batch b of 64 entries goes to wavefront
+ * b % SPLIT), so that even a few thousand entries per region are confirmed by
+ * many short dependent-read chains in parallel rather than one long one. ---- */
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+__global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScanArgs args) {
+    __shared__ WaveLds wave_lds[CONFIRM_THREADS / 64];
+    if (args.cand_counts[args.cand_waves]) return; /* overflow: the fused fallback redoes the scan */
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t cw = blockIdx.x * (CONFIRM_THREADS / 64) + wave; /* confirm wavefront = record region */
+    if (cw >= args.rec_regions) return;
+    const uint32_t r = cw / HSGPU_CONFIRM_SPLIT, part = cw % HSGPU_CONFIRM_SPLIT;
+    const uint32_t n = args.cand_counts[r];
+    if (part * 64 >= n) return; /* nothing for this wavefront (its record counts stay zero) */
+    Tables t;
+    init_tables(t, args);
+    init_wave_lds(t, wave_lds + wave, lane);
+    t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
+    t.rec_cap = args.rec_cap;
+    const uint4 *region = args.cand + 2ull * r * args.cand_cap;
+    for (uint32_t base = part * 64; base < n; base += 64 * HSGPU_CONFIRM_SPLIT) {
+        const uint32_t i = base + lane;
+        if (i < n) drain_fat_entry<HAS_A, HAS_B, HAS_C, S2>(t, region[2 * i], region[2 * i + 1]);
+        flush_records(t, lane, OFLUSH);
+    }
+    publish_records(t, args, lane, cw);
+}
+
+/* ---- phase 3: pack the per-wavefront record regions into the caller's buffer ---- */
+/* one workgroup: exclusive scan of the region fills, total into *count. Thread t
+ * owns regions t, t + 1024, ... (coalesced, independent loads); the order in
+ * which regions land in the output is immaterial. */
+__global__ __launch_bounds__(1024) void record_scan_kernel(HsgpuScanArgs args) {
+    __shared__ unsigned long long part[1024];
+    __shared__ uint32_t any_overflow;
+    const uint32_t n = args.rec_regions, tid = threadIdx.x;
+    const uint2 *counts = (const uint2 *)args.rec_counts;
+    if (tid == 0) any_overflow = 0;
+    __syncthreads();
+    unsigned long long sum = 0;
+    bool ovf = false;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint2 c = counts[i];
+        ovf |= (unsigned long long)c.x + c.y > args.rec_cap;
+        sum += (unsigned long long)c.x + c.y;
+    }
+    part[tid] = sum;
+    if (ovf) any_overflow = 1;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) { /* Hillis-Steele inclusive scan of 1024 partial sums */
+        unsigned long long v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = tid ? part[tid - 1] : 0;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint2 c = counts[i];
+        args.rec_offsets[i] = run;
+        run += (unsigned long long)c.x + c.y;
+    }
+    if (tid == 1023) {
+        const unsigned long long total = part[1023];
+        /* a region that ran out of space lost records; its fill counters kept
+         * counting, so the total is still exact: report it, but never a value
+         * <= cap (that would claim the output is complete) */
+        *args.count = (any_overflow && total <= args.cap) ? args.cap + 1 : total;
+    }
+}
+
+/* wavefront w copies region w to out[rec_offsets[w] ...) */
+__global__ __launch_bounds__(256) void record_pack_kernel(HsgpuScanArgs args) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= args.rec_regions) return;
+    const uint32_t f = args.rec_counts[2 * w], b = args.rec_counts[2 * w + 1];
+    if ((unsigned long long)f + b > args.rec_cap) return;
+    const unsigned long long o = args.rec_offsets[w];
+    const uint4 *region = args.rec_stage + (uint64_t)w * args.rec_cap;
+    uint4 *out = (uint4 *)args.out;
+    for (uint32_t i = lane; i < f; i += 64)
+        if (o + i < args.cap) out[o + i] = region[i];
+    for (uint32_t i = lane; i < b; i += 64)
+        if (o + f + i < args.cap) out[o + f + i] = region[args.rec_cap - 1 - i];
+}
+
+/* ---- phase 0: hint[t] = block containing corpus byte t * 1024 ------------------- */
+__global__ void block_hint_kernel(const uint64_t *off, uint64_t nblocks, uint64_t total, uint32_t *hint,
+                                  uint64_t n_hint) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hint) return;
+    const uint64_t g = i << HSGPU_HINT_SHIFT;
+    hint[i] = (uint32_t)(g < total ? find_block(off, 0, nblocks - 1, g) : nblocks - 1);
+}
+
+
+} // namespace
+
+#endif
