@@ -45,6 +45,9 @@ _SIGS = {
                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsgpu_hwlm_scan_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                       C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "hsgpu_scratch_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "hsgpu_scratch_get_timing": (C.c_int, [C.c_void_p, C.c_uint, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float)]),
     "hsgpu_match_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "hsgpu_hwlm_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, HWLM_CB, C.c_void_p, C.c_uint64]),
     "hsgpu_last_error": (C.c_char_p, []),

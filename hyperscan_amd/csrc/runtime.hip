@@ -62,6 +62,12 @@ struct hsgpu_scratch {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;           /* block hints are computed beside the filter kernel */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool timing = false;                   /* hsgpu_scratch_enable_timing */
+    /* ring of event sets {start, filter done, confirm done, packed}: one per scan */
+    static const int kRing = 32;
+    hipEvent_t ev_ring[kRing][4] = {};
+    hipEvent_t *ev_t = nullptr; /* the set of the scan being launched */
+    uint64_t n_timed = 0;       /* scans launched with timing on */
     DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets;
     unsigned long long *h_count = nullptr; /* pinned */
     int n_cu = 0;
@@ -154,11 +160,41 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->rec_stage.release();
     s->rec_offsets.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
+    for (int r = 0; r < hsgpu_scratch::kRing; r++)
+        for (int i = 0; i < 4; i++)
+            if (s->ev_ring[r][i]) (void)hipEventDestroy(s->ev_ring[r][i]);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->side) (void)hipStreamDestroy(s->side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+}
+
+extern "C" int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable) {
+    if (!s) return HSGPU_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    if (enable && !s->ev_ring[0][0]) {
+        for (int r = 0; r < hsgpu_scratch::kRing; r++)
+            for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&s->ev_ring[r][i]));
+    }
+    s->timing = enable != 0;
+    s->n_timed = 0;
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float *filter_ms, float *confirm_ms,
+                                        float *total_ms) {
+    if (!s || back >= hsgpu_scratch::kRing || back >= s->n_timed) return HSGPU_INVALID;
+    hipEvent_t *ev = s->ev_ring[(s->n_timed - 1 - back) % hsgpu_scratch::kRing];
+    HIP_TRY(hipEventSynchronize(ev[3]));
+    float f = 0, c = 0, t = 0;
+    HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&c, ev[1], ev[2]));
+    HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[3]));
+    if (filter_ms) *filter_ms = f;
+    if (confirm_ms) *confirm_ms = c;
+    if (total_ms) *total_ms = t;
+    return HSGPU_SUCCESS;
 }
 
 /* ---- the launch --------------------------------------------------------------- */
@@ -253,6 +289,10 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     HIP_TRY(hipMemsetAsync(s->ctl.p, 0, ctl_words * sizeof(uint32_t), stream));
 
     void *kargs[] = {&args};
+    if (s->timing) {
+        s->ev_t = s->ev_ring[s->n_timed % hsgpu_scratch::kRing];
+        HIP_TRY(hipEventRecord(s->ev_t[0], stream));
+    }
     if (!two_phase) {
         args.cand = nullptr;
         args.cand_cap = 0;
@@ -260,6 +300,10 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.cand_counts = nullptr;
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
+        if (s->timing) {
+            HIP_TRY(hipEventRecord(s->ev_t[1], stream));
+            HIP_TRY(hipEventRecord(s->ev_t[2], stream));
+        }
     } else {
         /* phase 1 + 2, then the fused kernel as overflow fallback (returns at once
          * unless some wavefront ran out of candidate space). Every filter wavefront
@@ -273,12 +317,18 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if ((rv = set_dyn_lds(f_two, lds_two)) != HSGPU_SUCCESS) return rv;
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds_two, stream));
+        if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
         HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
+        if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[2], stream));
     }
     HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
     HIP_TRY(hipLaunchKernel(hsgpu_record_pack_kernel(), dim3((n_rec + 3) / 4), dim3(256), kargs, 0, stream));
+    if (s->timing) {
+        HIP_TRY(hipEventRecord(s->ev_t[3], stream));
+        s->n_timed++;
+    }
     return HSGPU_SUCCESS;
 }
 

@@ -143,6 +143,20 @@ class Scratch:
             raise HsgpuError(rv, "hsgpu_scratch_alloc")
         self._h = h
 
+    def enable_timing(self, on=True):
+        rv = self._lib.hsgpu_scratch_enable_timing(self._h, 1 if on else 0)
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_enable_timing")
+
+    def timing(self, back=0):
+        """(filter_ms, confirm_ms, total_ms) of the hwlm_scan_dev `back` launches ago
+        on this scratch (0 = the last one; a ring of 32 is kept)."""
+        f, c, t = C.c_float(), C.c_float(), C.c_float()
+        rv = self._lib.hsgpu_scratch_get_timing(self._h, back, C.byref(f), C.byref(c), C.byref(t))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_get_timing")
+        return f.value, c.value, t.value
+
     def close(self):
         if self._h:
             self._lib.hsgpu_scratch_free(self._h)

@@ -1,0 +1,237 @@
+"""Host-side logic without a GPU: the C-ABI library loads and exports every symbol
+include/hsgpu.h declares, literal validation mirrors the reference's, compiled
+tables satisfy their invariants (every key variant of every literal is present
+in the LDS filter and reachable through the exact hash table), serialisation
+round-trips and rejects corruption, and the sequential replay applies the
+reference's group / noruns / termination rules."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import hyperscan_amd as H
+from hyperscan_amd import _native
+from hyperscan_amd import hwlm as hw
+from tests.util import random_literals
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+F_A, F_B, F_C, F_REPL, F_K2, F_S2, F_BLIND = 1, 2, 4, 8, 16, 32, 64
+FORCE_REPL, FORCE_HASHED, FORCE_K2, FORCE_K1, FORCE_S1, FORCE_BLIND, FORCE_S2 = 1, 2, 4, 8, 16, 32, 64
+MUL, HT_MUL = 0x9E3779, 0x9E3779B1
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load_library()
+    hdr = open(os.path.join(ROOT, "include", "hsgpu.h")).read()
+    declared = set(re.findall(r"\b(hsgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"hsgpu_hwlm_cb"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/hsgpu.h but not exported"
+    assert set(_native.exported_symbols()) <= declared | {"hsgpu_last_error", "hsgpu_version"}
+    assert b"gfx950" in lib.hsgpu_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(H.HsgpuError):
+        H.Scratch(0)
+
+
+@pytest.mark.parametrize("bad", [
+    dict(s=b"123456789"),                      # > HWLM_LITERAL_MAX_LEN (hwlm.h:75)
+    dict(s=b""),                               # empty
+    dict(s=b"ab", id=0xFFFFFFFF),              # reserved id (hwlm_build.cpp:190)
+    dict(s=b"ab", msk=b"\xff" * 9, cmp=b"a" * 9),  # > HWLM_MASKLEN
+    dict(s=b"ab", msk=b"\xff\xff", cmp=b"xb"),     # msk/cmp contradict the literal (maskIsConsistent)
+])
+def test_build_rejects_invalid_literals(bad):
+    with pytest.raises(H.HsgpuError) as e:
+        H.hwlm_build([H.HwlmLiteral(**bad)])
+    assert e.value.code == -4  # HS_COMPILER_ERROR
+
+
+def parse(blob):
+    f = struct.unpack_from("<32I", blob, 0)
+    names = ["magic", "version", "blob_bytes", "flags", "n_lits", "max_size", "filter_log2", "filter_entries",
+             "ht_a_log2", "ht_b_log2", "n_a", "n_b", "n_c", "off_filter", "off_c2bits", "off_ht_a", "off_ht_b",
+             "off_c2ref", "off_lists", "n_lists", "off_lits", "checksum"]
+    h = dict(zip(names, f))
+    fl = h["flags"]
+    nw = (32 << h["filter_log2"]) if fl & F_REPL else (1 << h["filter_log2"])
+    h["filter"] = np.frombuffer(blob, "<u4", nw, h["off_filter"])
+    h["c2bits"] = np.frombuffer(blob, "<u4", 2048, h["off_c2bits"])
+    h["ht_a"] = np.frombuffer(blob, "<u4", 8 << h["ht_a_log2"], h["off_ht_a"]).reshape(-1, 4, 2)
+    h["ht_b"] = np.frombuffer(blob, "<u4", 8 << h["ht_b_log2"], h["off_ht_b"]).reshape(-1, 4, 2)
+    h["c2ref"] = np.frombuffer(blob, "<u4", 65536 if fl & F_C else 4, h["off_c2ref"])
+    h["lists"] = np.frombuffer(blob, "<u4", h["n_lists"], h["off_lists"])
+    h["lits"] = np.frombuffer(blob, np.dtype([("v", "<u8"), ("msk", "<u8"), ("groups", "<u8"), ("id", "<u4"),
+                                              ("size", "u1"), ("flags", "u1"), ("pad", "<u2")]), h["n_lits"],
+                              h["off_lits"])
+    return h
+
+
+def list_entries(h, ref):
+    if ref & 0x80000000:
+        return [ref & 0x7FFFFFFF]
+    out, i = [], ref - 1
+    while True:
+        e = int(h["lists"][i])
+        out.append(e & 0x7FFFFFFF)
+        i += 1
+        if e & 0x80000000:
+            return out
+
+
+def ht_lookup(h, tab, log2, key):
+    b = ((key * HT_MUL) & 0xFFFFFFFF) >> (32 - log2)
+    while True:
+        for k, ref in tab[b]:
+            if ref and k == key:
+                return list_entries(h, int(ref))
+        if not tab[b][3][1]:
+            return None
+        b = (b + 1) & ((1 << log2) - 1)
+
+
+def filter_word_and_bits(h, x24, b3):
+    fl, k = h["flags"], h["filter_log2"]
+    prod = (x24 * MUL) & 0xFFFFFFFF
+    if fl & F_REPL:
+        a = prod >> (32 - k)
+        words = [int(h["filter"][a * 32 + c]) for c in range(32)]
+    else:
+        a = prod >> (30 - k)
+        words = [int(h["filter"][a >> 2])]
+    bit_a = [(a + b3) & 31] + ([((prod >> 11) + b3) & 31] if fl & F_K2 else [])
+    bit_b = [(prod >> 8) & 31] + ([(prod >> 13) & 31] if fl & F_K2 else [])
+    return words, bit_a, bit_b
+
+
+def check_table_covers(lits, flags):
+    """Every text window a literal can match must pass the filter and reach the
+    literal through the exact tables: checked on concrete windows built from each
+    literal (both case variants, both stride-2 alignments)."""
+    t = H.hwlm_build(lits, flags)
+    h = parse(t.serialize())
+    fl = h["flags"]
+    assert h["magic"] == 0x54475348 and h["n_lits"] == len(lits)
+    key_mask = 0xDFDFDFDF if fl & F_BLIND else 0xFFFFFFFF
+    rng = np.random.default_rng(5)
+    deltas = (0, 1) if fl & F_S2 else (0,)
+    for li, lit in enumerate(lits):
+        for variant in range(4):
+            s = bytearray(lit.s)
+            if lit.nocase:
+                for i, c in enumerate(s):
+                    if chr(c).isalpha() and c < 128 and (variant >> (i & 1)) & 1:
+                        s[i] = c ^ 0x20
+            ctx = bytes(rng.integers(0, 256, 8, dtype=np.uint8)) + bytes(s)  # random bytes in front
+            for d in deltas:
+                if len(s) - d < 1:
+                    continue
+                # lookup position q = end - d; window bytes b3 b2 b1 b0 end at q
+                w = ctx[: len(ctx) - d][-4:]
+                b3, x24 = w[0], w[1] | w[2] << 8 | w[3] << 16
+                xh = x24 & (0xDFDFDF if fl & F_BLIND else 0xFFFFFF)
+                words, bit_a, bit_b = filter_word_and_bits(h, xh, b3)
+                w4 = (w[0] | w[1] << 8 | w[2] << 16 | w[3] << 24) & key_mask
+                want = li | d << 30
+                found = False
+                if fl & F_A and all(all(wd >> b & 1 for b in bit_a) for wd in words):
+                    ents = ht_lookup(h, h["ht_a"], h["ht_a_log2"], w4)
+                    found |= ents is not None and want in ents
+                if not found and fl & F_B and all(all(wd >> b & 1 for b in bit_b) for wd in words):
+                    ents = ht_lookup(h, h["ht_b"], h["ht_b_log2"], w4 >> 8)
+                    found |= ents is not None and want in ents
+                if not found and fl & F_C:
+                    kc = w4 >> 16
+                    if h["c2bits"][kc >> 5] >> (kc & 31) & 1 and h["c2ref"][kc]:
+                        found |= want in list_entries(h, int(h["c2ref"][kc]))
+                assert found, (lit, d, variant, flags)
+    return h
+
+
+@pytest.mark.parametrize("flags", [0, FORCE_REPL, FORCE_HASHED, FORCE_HASHED | FORCE_K2, FORCE_REPL | FORCE_K2,
+                                   FORCE_S1, FORCE_S1 | FORCE_HASHED | FORCE_K1, FORCE_BLIND, FORCE_S2,
+                                   FORCE_S2 | FORCE_HASHED | FORCE_BLIND | FORCE_K2])
+def test_table_covers_every_literal(flags):
+    rng = np.random.default_rng(flags + 1)
+    lits = random_literals(rng, 150, 1, 8, nocase_frac=0.4)
+    h = check_table_covers(lits, flags)
+    if flags & FORCE_REPL:
+        assert h["flags"] & F_REPL
+    if flags & FORCE_HASHED:
+        assert not h["flags"] & F_REPL
+    if flags & FORCE_S1:
+        assert not h["flags"] & F_S2
+
+
+def test_table_modes_auto():
+    rng = np.random.default_rng(3)
+    small = H.hwlm_build(random_literals(rng, 64, 4, 8, nocase_frac=0)).info()
+    assert small["flags"] & F_REPL and small["flags"] & F_S2 and not small["flags"] & F_BLIND
+    big = H.hwlm_build(random_literals(rng, 5000, 3, 8, nocase_frac=0.3)).info()
+    assert not big["flags"] & F_REPL and not big["flags"] & F_S2 and big["flags"] & F_BLIND
+    # case-blind keys: a caseless literal costs one filter entry, not one per case variant
+    assert big["filter_entries"] <= 5000
+
+
+def test_msk_cmp_literals_in_table():
+    lits = [H.HwlmLiteral("bc", False, 7, msk=b"\xf0\xff\xff", cmp=b"\x30bc"),
+            H.HwlmLiteral("xyz", True, 8, msk=b"\xff\x00\x00\x00", cmp=b"Q\x00\x00\x00")]
+    t = H.hwlm_build(lits)
+    h = parse(t.serialize())
+    assert h["lits"]["size"].tolist() == [3, 4]
+    assert h["max_size"] == 4
+
+
+def test_serialize_roundtrip_and_corruption():
+    rng = np.random.default_rng(9)
+    t = H.hwlm_build(random_literals(rng, 300, 2, 8))
+    blob = t.serialize()
+    assert len(blob) == t.size == H.hwlm_size(t)
+    t2 = H.HwlmTable.deserialize(blob)
+    assert t2.serialize() == blob and t2.info() == t.info()
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x40
+    with pytest.raises(H.HsgpuError):
+        H.HwlmTable.deserialize(bytes(bad))
+    with pytest.raises(H.HsgpuError):
+        H.HwlmTable.deserialize(blob[:-16])
+    with pytest.raises(H.HsgpuError):
+        H.HwlmTable.deserialize(b"\0" * 64)
+
+
+def replay(table, recs, groups, cb):
+    arr = np.zeros(len(recs), dtype=hw.MATCH_DTYPE)
+    for i, (e, lit) in enumerate(recs):
+        arr[i] = (0, e, 0, lit)
+    ccb = _native.HWLM_CB(lambda e, i, _c: cb(e, i))
+    return table._lib.hsgpu_hwlm_replay(table._h, arr.ctypes.data, len(recs), ccb, None, groups)
+
+
+def test_replay_rules():
+    """hsgpu_hwlm_replay = what the reference does inside confWithBit
+    (fdr_confirm_runtime.h:69-96): noruns vs last delivered id, group gate against
+    the callback's last return value, stop on 0."""
+    lits = [H.HwlmLiteral("m", False, 0, noruns=True), H.HwlmLiteral("A", False, 42),
+            H.HwlmLiteral("q", False, 5, groups=4)]
+    t = H.hwlm_build(lits)
+    out = []
+    recs = [(0, 0), (18, 0), (32, 1), (78, 0), (80, 0)]
+    assert replay(t, recs, H.HWLM_ALL_GROUPS, lambda e, i: (out.append((e, i)), H.HWLM_ALL_GROUPS)[1]) == 0
+    assert out == [(0, 0), (32, 42), (78, 0)]          # NoRepeat2, unit/internal/fdr.cpp:268-292
+    out = []
+    assert replay(t, recs, H.HWLM_ALL_GROUPS, lambda e, i: (out.append((e, i)), 0)[1]) == 1
+    assert out == [(0, 0)]                             # HWLM_TERMINATED after exactly one match
+    out = []
+    assert replay(t, [(1, 2), (2, 1), (3, 2)], 3, lambda e, i: (out.append((e, i)), 4)[1]) == 0
+    assert out == [(2, 42), (3, 5)]                    # group 4 only live after the first callback
