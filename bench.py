@@ -164,16 +164,12 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     info = job.table.info()
 
     def gather():
-        """RCCL all-gather of match records over xGMI: counts, then padded records."""
-        cnt = job.d_count.clone()
-        allc = torch.empty(world, dtype=torch.int64, device=job.dev)
-        dist.all_gather_into_tensor(allc, cnt)
-        mx = int(min(allc.max().item(), job.cap))
-        if mx == 0:
-            return allc, None
-        buf = torch.empty(world * mx * 4, dtype=torch.int32, device=job.dev)
-        dist.all_gather_into_tensor(buf, job.d_out[: mx * 4].contiguous())
-        return allc, buf
+        """The path's one exchange step: RCCL all-gather of match records over xGMI
+        (counts, then records padded to the largest count) -- hyperscan_amd/dist.py."""
+        from hyperscan_amd import dist as hd
+
+        n = min(int(job.d_count.item()), job.cap)
+        return hd.all_gather_records(job.d_out.view(-1, 4), n, rank * job.nblocks, dist, world, job.dev)
 
     def step():
         job.launch()

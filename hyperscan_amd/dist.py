@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of a block corpus and the one exchange step of the path.
+
+Blocks are independent scans (the reference shares nothing between hs_scan calls:
+the database is immutable, all mutable state lives in the caller's scratch), so
+the corpus shards by contiguous block ranges balanced by bytes, every rank scans
+its shard with no data-path collective, and afterwards the match records are
+all-gathered (RCCL over xGMI with backend "nccl"; gloo in the CPU tests):
+counts first, then records padded to the largest count.
+"""
+import numpy as np
+
+
+def shard_blocks_by_bytes(off, world):
+    """off: nblocks+1 ascending offsets. -> [(b_lo, b_hi)] per rank, contiguous,
+    covering all blocks, balanced by bytes (not by block count)."""
+    off = np.asarray(off, dtype=np.uint64)
+    nblocks = off.size - 1
+    total = int(off[-1] - off[0])
+    cuts = [0]
+    for r in range(1, world):
+        target = int(off[0]) + total * r // world
+        b = int(np.searchsorted(off, target, side="left"))
+        b = min(max(b, cuts[-1]), nblocks)
+        cuts.append(b)
+    cuts.append(nblocks)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def local_shard(corpus, off, rank, world):
+    """-> (corpus slice, rebased offsets, first global block index) of this rank."""
+    lo, hi = shard_blocks_by_bytes(off, world)[rank]
+    o = np.asarray(off[lo:hi + 1], dtype=np.uint64)
+    base = int(o[0]) if o.size else 0
+    return corpus[base:int(o[-1]) if o.size else base], (o - np.uint64(base)).astype(np.uint64), lo
+
+
+def all_gather_records(records, count, block_base, dist, world, device=None):
+    """records: int32 tensor [cap, 4] (block, end, id, lit) with `count` valid rows and
+    rank-local block indices; block_base: this rank's first global block index.
+    Returns (int32 tensor [total, 4] with GLOBAL block indices, ordered by rank, counts list).
+    Two collectives: all_gather(counts), all_gather(records padded to max count)."""
+    import torch
+
+    device = device if device is not None else records.device
+    cnt = torch.tensor([int(count), int(block_base)], dtype=torch.int64, device=device)
+    allc = torch.empty(world * 2, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allc, cnt)
+    allc = allc.view(world, 2).cpu()
+    counts = allc[:, 0].tolist()
+    bases = allc[:, 1].tolist()
+    mx = max(counts)
+    if mx == 0:
+        return torch.zeros((0, 4), dtype=torch.int32, device=device), counts
+    pad = torch.zeros((mx, 4), dtype=torch.int32, device=device)
+    n = int(count)
+    pad[:n] = records[:n]
+    buf = torch.empty((world * mx, 4), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(buf, pad)
+    parts = []
+    for r in range(world):
+        p = buf[r * mx:r * mx + counts[r]].clone()
+        p[:, 0] += int(bases[r])
+        parts.append(p)
+    return torch.cat(parts, dim=0), counts

@@ -1,0 +1,76 @@
+"""The N > 1 path on CPU: world_size-2 gloo. Each rank takes its shard
+(hyperscan_amd.dist), produces its match records (here with the CPU oracle --
+tests may use it; the scan itself is covered by the -m gpu tests), and the
+records are all-gathered exactly as bench.py does over RCCL. The union must equal
+a single-process scan of the whole corpus."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hyperscan_amd import corpus as cp
+from hyperscan_amd import dist as hd
+from tests import oracle_binding as ob
+
+
+def test_shards_cover_and_balance():
+    rng = np.random.default_rng(1)
+    lens = rng.integers(0, 3000, 5000)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        sh = hd.shard_blocks_by_bytes(off, world)
+        assert sh[0][0] == 0 and sh[-1][1] == off.size - 1
+        assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+        sizes = [int(off[hi] - off[lo]) for lo, hi in sh]
+        assert max(sizes) - min(sizes) <= 2 * 3000
+    # degenerate: fewer blocks than ranks, empty corpus
+    assert hd.shard_blocks_by_bytes(np.array([0, 10], dtype=np.uint64), 4)[-1][1] == 1
+    assert hd.shard_blocks_by_bytes(np.array([0], dtype=np.uint64), 2) == [(0, 0), (0, 0)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lits = cp.teddy_literals(32, seed=5)
+    corpus, off = cp.packet_corpus(1 << 20, lits, seed=9, match_every=1024)
+    my_corpus, my_off, base = hd.local_shard(corpus, off, rank, world)
+    recs = ob.Oracle(lits).collect_blocks(my_corpus, my_off)
+    t = torch.zeros((max(1, recs.size), 4), dtype=torch.int32)
+    t[: recs.size, 0] = torch.from_numpy(recs["block"].astype(np.int32))
+    t[: recs.size, 1] = torch.from_numpy(recs["end"].astype(np.int32))
+    t[: recs.size, 2] = torch.from_numpy(recs["id"].astype(np.int32))
+    allr, counts = hd.all_gather_records(t, recs.size, base, dist, world)
+    if rank == 0:
+        np.save(out_path, allr.numpy())
+    assert sum(counts) == allr.shape[0]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_gather_equals_single_scan(tmp_path):
+    out = str(tmp_path / "gathered.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    lits = cp.teddy_literals(32, seed=5)
+    corpus, off = cp.packet_corpus(1 << 20, lits, seed=9, match_every=1024)
+    want = ob.Oracle(lits).collect_blocks(corpus, off)
+    g = sorted(zip(got[:, 0].tolist(), got[:, 1].tolist(), got[:, 2].tolist()))
+    w = sorted(zip(want["block"].tolist(), want["end"].tolist(), want["id"].tolist()))
+    assert len(w) > 100 and g == w
+    # shards are contiguous block ranges, so rank order == global block order
+    assert np.all(np.diff(got[:, 0]) >= 0)
