@@ -1,0 +1,125 @@
+"""Python mirror of the reference's character-class accelerators, batched on the GPU.
+
+  reference (C)                                              here
+  shuftiExec(mask_lo, mask_hi, buf, buf_end)                  CharClass.from_shufti(lo, hi)  + class_scan(...)
+      src/nfa/shufti.h:46-52                                      -> first[c][block]
+  rshuftiExec / rtruffleExec / rvermicelliExec                -> last[c][block]
+  truffleExec(mask1, mask2, buf, buf_end)                     CharClass.from_truffle(m1, m2)
+      src/nfa/truffle.h:45-50
+  vermicelliExec(c, nocase, buf, buf_end) / nvermicelliExec   CharClass.from_verm(c, nocase, negate)
+      src/nfa/vermicelli.h:42-104
+  truffleBuildMasks(CharReach) src/nfa/trufflecompile.cpp:59  CharClass(...).to_truffle()
+
+Return convention as in the reference: offset of the first member in the block, the
+block length when there is none; for the reverse scans the last member, -1 when none.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from .hwlm import HsgpuError
+
+CLASS_MAX = 8
+WORK_BYTES = 4160
+
+
+class _Class(C.Structure):
+    _fields_ = [("bitmap", C.c_uint8 * 32)]
+
+
+def _lib():
+    lib = _native.load_library()
+    if not getattr(lib, "_class_sigs", False):
+        lib.hsgpu_class_from_shufti.restype = C.c_int
+        lib.hsgpu_class_from_shufti.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Class)]
+        lib.hsgpu_class_from_truffle.restype = C.c_int
+        lib.hsgpu_class_from_truffle.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Class)]
+        lib.hsgpu_class_from_verm.restype = C.c_int
+        lib.hsgpu_class_from_verm.argtypes = [C.c_uint8, C.c_int, C.c_int, C.POINTER(_Class)]
+        lib.hsgpu_class_to_truffle.restype = C.c_int
+        lib.hsgpu_class_to_truffle.argtypes = [C.POINTER(_Class), C.c_void_p, C.c_void_p]
+        lib.hsgpu_class_scan_dev.restype = C.c_int
+        lib.hsgpu_class_scan_dev.argtypes = [C.POINTER(_Class), C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p,
+                                             C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
+        lib._class_sigs = True
+    return lib
+
+
+class CharClass:
+    """A 256-bit character class (the reference's CharReach)."""
+
+    def __init__(self, members=()):
+        self.bitmap = np.zeros(32, dtype=np.uint8)
+        for v in members:
+            v = v if isinstance(v, int) else ord(v)
+            self.bitmap[v >> 3] |= 1 << (v & 7)
+
+    @classmethod
+    def _from_c(cls, c):
+        o = cls()
+        o.bitmap = np.frombuffer(bytes(c.bitmap), dtype=np.uint8).copy()
+        return o
+
+    def _to_c(self):
+        c = _Class()
+        C.memmove(c.bitmap, self.bitmap.ctypes.data, 32)
+        return c
+
+    @classmethod
+    def from_shufti(cls, lo, hi):
+        c = _Class()
+        lo, hi = bytes(lo), bytes(hi)
+        if _lib().hsgpu_class_from_shufti(lo, hi, C.byref(c)) != 0:
+            raise HsgpuError(-1, "hsgpu_class_from_shufti")
+        return cls._from_c(c)
+
+    @classmethod
+    def from_truffle(cls, m1, m2):
+        c = _Class()
+        if _lib().hsgpu_class_from_truffle(bytes(m1), bytes(m2), C.byref(c)) != 0:
+            raise HsgpuError(-1, "hsgpu_class_from_truffle")
+        return cls._from_c(c)
+
+    @classmethod
+    def from_verm(cls, ch, nocase=False, negate=False):
+        c = _Class()
+        ch = ch if isinstance(ch, int) else ord(ch)
+        _lib().hsgpu_class_from_verm(ch, int(nocase), int(negate), C.byref(c))
+        return cls._from_c(c)
+
+    def to_truffle(self):
+        m1, m2 = (C.c_uint8 * 16)(), (C.c_uint8 * 16)()
+        c = self._to_c()
+        _lib().hsgpu_class_to_truffle(C.byref(c), m1, m2)
+        return bytes(m1), bytes(m2)
+
+    def members(self):
+        return [v for v in range(256) if self.bitmap[v >> 3] >> (v & 7) & 1]
+
+
+def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True, want_last=False, stream=None):
+    """Evaluate <= 8 classes over a device-resident block batch (torch tensors).
+    -> (bitmaps uint8 [n][ceil(total/16)*2], first int64-view uint32 [n][nblocks] | None, last | None)"""
+    import torch
+
+    lib = _lib()
+    n = len(classes)
+    assert 1 <= n <= CLASS_MAX
+    dev = d_corpus.device
+    arr = (_Class * n)(*[c._to_c() for c in classes])
+    words = (total + 15) // 16
+    bitmaps = torch.zeros((n, max(1, words) * 2), dtype=torch.uint8, device=dev)
+    ptrs = (C.c_void_p * n)(*[bitmaps[i].data_ptr() for i in range(n)])
+    work = torch.zeros(WORK_BYTES, dtype=torch.uint8, device=dev)
+    first = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_first and nblocks) else None
+    last = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_last and nblocks) else None
+    st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    rv = lib.hsgpu_class_scan_dev(arr, n, d_corpus.data_ptr(), total, d_off.data_ptr() if d_off is not None else None,
+                                  nblocks, ptrs, first.data_ptr() if first is not None else None,
+                                  last.data_ptr() if last is not None else None, work.data_ptr(), st)
+    if rv != 0:
+        raise HsgpuError(rv, "hsgpu_class_scan_dev")
+    torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
+    return bitmaps, first, last

@@ -147,11 +147,12 @@ def line_corpus(total_bytes, seed=5, lo=40, hi=200):
     """Config 4 corpus: newline-terminated text lines of 40-200 bytes, one block
     per line (tools/hsbench/scripts/linebasedCorpus.py:29-35)."""
     rng = np.random.default_rng(seed)
-    n = int(total_bytes / ((lo + hi) / 2)) + 8
+    n = int(total_bytes / ((lo + hi) / 2) * 1.1) + 64
     lens = rng.integers(lo, hi + 1, n).astype(np.int64)
     csum = np.cumsum(lens)
+    assert int(csum[-1]) >= total_bytes
     k = int(np.searchsorted(csum, total_bytes))
-    lens = lens[: k + 1]
+    lens = lens[: k + 1].copy()
     lens[k] -= int(csum[k]) - total_bytes
     if lens[k] == 0:
         lens = lens[:k]

@@ -165,6 +165,34 @@ int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n, void *stre
 int hsgpu_hwlm_replay(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n,
                       hsgpu_hwlm_cb cb, void *ctx, uint64_t groups);
 
+/* ---- character-class scanning ------------------------------------------------------
+ * The GPU form of the reference's class accelerators: shuftiExec/rshuftiExec
+ * (src/nfa/shufti.h:46-52), truffleExec/rtruffleExec (src/nfa/truffle.h:45-50),
+ * vermicelliExec/nvermicelliExec/rvermicelliExec (src/nfa/vermicelli.h:42-518), dispatched
+ * by run_accel (src/nfa/accel.c:35-146). Every scheme decodes to a 256-bit class. */
+#define HSGPU_CLASS_MAX 8
+#define HSGPU_CLASS_WORK_BYTES 4160 /* device work area for hsgpu_class_scan_dev */
+
+typedef struct hsgpu_class {
+    uint8_t bitmap[32]; /* bit v (LSB first) set <=> byte value v is a member */
+} hsgpu_class_t;
+
+int hsgpu_class_from_shufti(const uint8_t lo[16], const uint8_t hi[16], hsgpu_class_t *out);
+int hsgpu_class_from_truffle(const uint8_t mask1[16], const uint8_t mask2[16], hsgpu_class_t *out);
+int hsgpu_class_from_verm(uint8_t c, int nocase, int negate, hsgpu_class_t *out);
+int hsgpu_class_to_truffle(const hsgpu_class_t *cls, uint8_t mask1[16], uint8_t mask2[16]);
+
+/* Evaluate n_classes <= 8 classes over a block batch resident in HBM, asynchronously
+ * on `stream`. d_bitmaps[c]: device buffer of (total_bytes + 15) / 16 * 2 bytes that
+ * receives membership bitmap c (bit i, LSB first <=> corpus[i] in class c).
+ * d_first / d_last (optional, uint32 [n_classes][nblocks]): per block the offset of the
+ * first / last member -- the accelerators' return value relative to the block start --
+ * or the block length / 0xffffffff when there is none (shufti.h:40-52). d_work:
+ * HSGPU_CLASS_WORK_BYTES of 16-byte aligned device memory. */
+int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_classes, const void *d_corpus,
+                         uint64_t total_bytes, const void *d_off, uint64_t nblocks, void *const *d_bitmaps,
+                         void *d_first, void *d_last, void *d_work, void *stream);
+
 const char *hsgpu_last_error(void);
 const char *hsgpu_version(void);
 

@@ -1,0 +1,128 @@
+"""Character-class scanning on the GPU against the oracle's scalar restatements
+(oracle/hwlm_oracle.c: hso_class_*, hso_shufti_*, hso_truffle_*, hso_verm_*) and,
+when shipped, against the reference's own shuftiExec / truffleExec / vermicelliExec."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hyperscan_amd import accel
+from hyperscan_amd import corpus as cp
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = {
+    "lower": [c for c in range(ord("a"), ord("z") + 1)],
+    "upper": [c for c in range(ord("A"), ord("Z") + 1)],
+    "digit": [c for c in range(ord("0"), ord("9") + 1)],
+    "hex": list(b"0123456789abcdef"),
+    "space": list(b" \t\r\n\x0b\x0c"),
+    "high": list(range(128, 256)),
+    "vowel": list(b"aeiouAEIOU"),
+    "nl": [10],
+}
+
+
+def oracle_bitmap(cls, buf):
+    L = ob.hso()
+    out = np.zeros((buf.size + 7) // 8, dtype=np.uint8)
+    L.hso_class_bitmap(cls.bitmap.ctypes.data, buf.ctypes.data, buf.size, out.ctypes.data)
+    return out
+
+
+def test_bitmaps_and_first_last_match_oracle():
+    import torch
+
+    corpus, off = cp.line_corpus(3 << 20, seed=5)
+    # sprinkle high bytes
+    rng = np.random.default_rng(2)
+    pos = rng.integers(0, corpus.size, 5000)
+    corpus[pos] = rng.integers(128, 256, pos.size)
+    classes = [accel.CharClass(m) for m in CLASSES.values()]
+    dev = torch.device("cuda", 0)
+    d_corpus = torch.from_numpy(corpus).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    nb = off.size - 1
+    bitmaps, first, last = accel.class_scan(classes, d_corpus, corpus.size, d_off, nb, True, True)
+    bm = bitmaps.cpu().numpy()
+    fi = first.cpu().numpy().view(np.uint32)
+    la = last.cpu().numpy().view(np.uint32)
+    L = ob.hso()
+    for ci, cls in enumerate(classes):
+        want = oracle_bitmap(cls, corpus)
+        assert np.array_equal(bm[ci][: want.size], want), list(CLASSES)[ci]
+        for b in rng.integers(0, nb, 300).tolist() + [0, nb - 1]:
+            blk = corpus[int(off[b]):int(off[b + 1])]
+            f = L.hso_class_fwd(cls.bitmap.ctypes.data, blk.ctypes.data, blk.size)
+            r = L.hso_class_rev(cls.bitmap.ctypes.data, blk.ctypes.data, blk.size)
+            assert fi[ci, b] == f
+            assert la[ci, b] == (r & 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("total", [1, 15, 16, 17, 16383, 16384, 16385, 100_003])
+def test_ragged_sizes(total):
+    import torch
+
+    rng = np.random.default_rng(total)
+    buf = rng.integers(0, 256, total, dtype=np.uint8)
+    cls = accel.CharClass(rng.integers(0, 256, 40).tolist())
+    d = torch.from_numpy(buf).to("cuda:0")
+    off = np.array([0, total // 2, total // 2, total], dtype=np.uint64)  # includes an empty block
+    d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+    bitmaps, first, last = accel.class_scan([cls], d, total, d_off, 3, True, True)
+    want = oracle_bitmap(cls, buf)
+    assert np.array_equal(bitmaps.cpu().numpy()[0][: want.size], want)
+    L = ob.hso()
+    for b in range(3):
+        blk = np.ascontiguousarray(buf[int(off[b]):int(off[b + 1])])
+        f = L.hso_class_fwd(cls.bitmap.ctypes.data, blk.ctypes.data, blk.size)
+        r = L.hso_class_rev(cls.bitmap.ctypes.data, blk.ctypes.data, blk.size)
+        assert first.cpu().numpy().view(np.uint32)[0, b] == f
+        assert last.cpu().numpy().view(np.uint32)[0, b] == (r & 0xFFFFFFFF)
+
+
+def test_decoders_match_reference_masks():
+    """shufti / truffle masks built by the REFERENCE decode (on our side) to the class
+    they were built from, and the GPU first-hit equals shuftiExec / truffleExec."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not shipped")
+    import torch
+
+    R = ob.href()
+    rng = np.random.default_rng(8)
+    buf = np.frombuffer(bytes(rng.integers(32, 127, 5000, dtype=np.uint8)), dtype=np.uint8)
+    d = torch.from_numpy(buf.copy()).to("cuda:0")
+    d_off = torch.from_numpy(np.array([0, buf.size], dtype=np.int64)).to("cuda:0")
+    for name, members in CLASSES.items():
+        cls = accel.CharClass(members)
+        lo, hi = (C.c_uint8 * 16)(), (C.c_uint8 * 16)()
+        nb = R.hsref_shufti_build(cls.bitmap.ctypes.data, lo, hi)
+        m1, m2 = (C.c_uint8 * 16)(), (C.c_uint8 * 16)()
+        R.hsref_truffle_build(cls.bitmap.ctypes.data, m1, m2)
+        assert accel.CharClass.from_truffle(bytes(m1), bytes(m2)).members() == sorted(set(members))
+        assert cls.to_truffle() == (bytes(m1), bytes(m2))  # trufflecompile.cpp:59-72
+        want_t = R.hsref_truffle_exec(m1, m2, buf.ctypes.data, buf.size)
+        _bm, first, last = accel.class_scan([cls], d, buf.size, d_off, 1, True, True)
+        assert int(first.cpu().numpy().view(np.uint32)[0, 0]) == want_t
+        assert int(last.cpu().numpy()[0, 0]) == R.hsref_rtruffle_exec(m1, m2, buf.ctypes.data, buf.size)
+        if nb > 0:
+            assert accel.CharClass.from_shufti(bytes(lo), bytes(hi)).members() == sorted(set(members))
+            assert want_t == R.hsref_shufti_exec(lo, hi, buf.ctypes.data, buf.size)
+
+
+def test_vermicelli_semantics():
+    import torch
+
+    buf = np.frombuffer(b"xxxxxxxxxxxxxxxxxxxxxxxxxxxQxxxxxqxxxxxxxxxxxxxxxxxxxxxx", dtype=np.uint8)
+    d = torch.from_numpy(buf.copy()).to("cuda:0")
+    d_off = torch.from_numpy(np.array([0, buf.size], dtype=np.int64)).to("cuda:0")
+    L = ob.hso()
+    for ch, nocase, negate in ((ord("q"), 0, 0), (ord("Q"), 1, 0), (ord("x"), 0, 1), (ord("z"), 0, 0)):
+        cls = accel.CharClass.from_verm(ch, nocase, negate)
+        _bm, first, last = accel.class_scan([cls], d, buf.size, d_off, 1, True, True)
+        assert int(first.cpu().numpy()[0, 0]) == L.hso_verm_fwd(ch, nocase, negate, buf.ctypes.data, buf.size)
+        assert int(last.cpu().numpy()[0, 0]) == L.hso_verm_rev(ch, nocase, negate, buf.ctypes.data, buf.size)
+        if ob.ref_available() and not negate:
+            R = ob.href()
+            assert int(first.cpu().numpy()[0, 0]) == R.hsref_verm_exec(ch, nocase, buf.ctypes.data, buf.size)
