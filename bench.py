@@ -62,7 +62,7 @@ class GpuJob:
         self.torch = torch
         self.H = H
         self.dev = torch.device("cuda", device)
-        self.table = H.hwlm_build(lits)
+        self.table = H.hwlm_build(lits, int(os.environ.get("HSGPU_BUILD_FLAGS", "0")))  # tuning knob
         self.scratch = H.Scratch(device)
         self.total = int(corpus.size)
         self.nblocks = int(off.size - 1)
@@ -75,10 +75,9 @@ class GpuJob:
         assert self.d_corpus.data_ptr() % 16 == 0
 
     def launch(self):
-        """memset(count) + ONE scan kernel on torch's current stream."""
+        """One batch scan (the library's kernel pipeline) on torch's current stream."""
         from hyperscan_amd import hwlm as hw
 
-        self.d_count.zero_()
         stream = self.torch.cuda.current_stream().cuda_stream
         hw.hwlm_scan_dev(self.table, self.scratch, self.d_corpus.data_ptr(), self.total, self.d_off.data_ptr(),
                          self.nblocks, self.d_out.data_ptr(), self.cap, self.d_count.data_ptr(), 0, stream)

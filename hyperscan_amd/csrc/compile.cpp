@@ -234,7 +234,9 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
      *  - large sets ("FDR class"): one hashed 2^k-word filter, k <= 15 (128 KiB),
      *    two bits per class-A key once the filter is more than ~0.4% full. */
     uint32_t k;
-    if (!(flags & HSGPU_BUILD_FORCE_HASHED) && (entries <= 1024 || (flags & HSGPU_BUILD_FORCE_REPL))) {
+    /* replicated only pays at stride 1, where the lookup rate is high enough for LDS
+     * bank conflicts to matter; at stride 2 the hashed table's 32x more bits win */
+    if (!(flags & HSGPU_BUILD_FORCE_HASHED) && ((entries <= 1024 && !stride2) || (flags & HSGPU_BUILD_FORCE_REPL))) {
         tflags |= HSGPU_F_REPL;
         /* 160 KiB of LDS = 128 KiB filter + 8 KiB 2-byte table + 24 KiB per-wavefront areas (fused kernel) */
         k = 10;

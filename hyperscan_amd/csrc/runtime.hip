@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
@@ -68,7 +69,9 @@ struct hsgpu_scratch {
     hipEvent_t ev_ring[kRing][4] = {};
     hipEvent_t *ev_t = nullptr; /* the set of the scan being launched */
     uint64_t n_timed = 0;       /* scans launched with timing on */
-    DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets;
+    DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets, stats;
+    bool ctl_clean = false;                /* every control word is zero (left so by control_reset_kernel) */
+    unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
     int n_cu = 0;
     size_t lds_per_cu = 0;
@@ -138,7 +141,9 @@ extern "C" int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device) {
     }
     s->n_cu = prop.multiProcessorCount;
     s->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
-    if (s->count.ensure(sizeof(unsigned long long)) != HSGPU_SUCCESS) {
+    if (s->count.ensure(sizeof(unsigned long long)) != HSGPU_SUCCESS ||
+        s->stats.ensure(2 * sizeof(unsigned long long)) != HSGPU_SUCCESS ||
+        hipMemset(s->stats.p, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
         hsgpu_scratch_free(s);
         return HSGPU_NOMEM;
     }
@@ -157,6 +162,7 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->hint.release();
     s->cand.release();
     s->ctl.release();
+    s->stats.release();
     s->rec_stage.release();
     s->rec_offsets.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
@@ -194,6 +200,22 @@ extern "C" int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float
     if (filter_ms) *filter_ms = f;
     if (confirm_ms) *confirm_ms = c;
     if (total_ms) *total_ms = t;
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_scratch_get_stats(hsgpu_scratch_t *s, uint64_t *cand_entries, int *overflowed) {
+    /* synchronous; for tuning and tests: 32-byte candidate entries spilled by the
+     * two-phase scans since the previous call, and how many of those scans overflowed
+     * a candidate region (and were redone by the fused fallback kernel) */
+    if (!s) return HSGPU_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long cur[2] = {0, 0};
+    HIP_TRY(hipMemcpy(cur, s->stats.p, sizeof(cur), hipMemcpyDeviceToHost));
+    if (cand_entries) *cand_entries = cur[0] - s->stats_seen[0];
+    if (overflowed) *overflowed = (int)(cur[1] - s->stats_seen[1]);
+    s->stats_seen[0] = cur[0];
+    s->stats_seen[1] = cur[1];
     return HSGPU_SUCCESS;
 }
 
@@ -281,12 +303,18 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
     /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1]; rec_offsets apart */
     const size_t ctl_words = (size_t)2 * n_rec + n_waves + 1;
+    const void *ctl_before = s->ctl.p;
     if ((rv = s->ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    if (s->ctl.p != ctl_before) s->ctl_clean = false;
     if ((rv = s->rec_offsets.ensure((size_t)n_rec * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
     args.rec_stage = (uint4 *)s->rec_stage.p;
     args.rec_counts = (uint32_t *)s->ctl.p;
     args.rec_offsets = (unsigned long long *)s->rec_offsets.p;
-    HIP_TRY(hipMemsetAsync(s->ctl.p, 0, ctl_words * sizeof(uint32_t), stream));
+    args.stats = (unsigned long long *)s->stats.p;
+    /* the control words are left zeroed by the previous scan's last kernel; only a
+     * fresh (or possibly dirty) buffer needs a memset */
+    if (!s->ctl_clean) HIP_TRY(hipMemsetAsync(s->ctl.p, 0, s->ctl.cap, stream));
+    s->ctl_clean = false; /* until this scan's control_reset_kernel has been queued */
 
     void *kargs[] = {&args};
     if (s->timing) {
@@ -329,6 +357,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipEventRecord(s->ev_t[3], stream));
         s->n_timed++;
     }
+    {
+        const uint32_t words = std::max<uint32_t>(2 * n_rec, n_waves + 1);
+        HIP_TRY(hipLaunchKernel(hsgpu_control_reset_kernel(), dim3((words + 255) / 256), dim3(256), kargs, 0, stream));
+        s->ctl_clean = true;
+    }
     return HSGPU_SUCCESS;
 }
 
@@ -344,8 +377,11 @@ extern "C" int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, co
         hsgpu_set_error("corpus larger than 64 GiB per launch");
         return HSGPU_INVALID;
     }
-    if (nblocks == 0 || total_bytes == 0) return HSGPU_SUCCESS;
     HIP_TRY(hipSetDevice(s->device));
+    if (nblocks == 0 || total_bytes == 0) {
+        HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream ? (hipStream_t)stream : s->stream));
+        return HSGPU_SUCCESS;
+    }
     const uint8_t *d_blob = nullptr;
     int rv = table_on_device(t, s->device, &d_blob);
     if (rv != HSGPU_SUCCESS) return rv;
@@ -359,6 +395,10 @@ extern "C" int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, co
     a.out = (hsgpu_match_t *)d_out;
     a.cap = cap;
     a.count = (unsigned long long *)d_count;
+    {
+        static const char *dbg = getenv("HSGPU_DEBUG");
+        a.debug = dbg ? (uint32_t)atoi(dbg) : 0;
+    }
     return launch_scan(t, s, a, stream ? (hipStream_t)stream : s->stream);
 }
 

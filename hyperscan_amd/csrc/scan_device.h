@@ -513,28 +513,37 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
 #define HSGPU_HANDLE(CUR, COFF)                                                                   \
     {                                                                                             \
         if ((COFF) == 0) CUR.h = make_uint2(0, 0); /* nothing in front of the corpus */           \
-        const uint32_t acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f);             \
+        uint32_t acc;                                                                             \
+        if (args.debug & 2) {                                                                     \
+            acc = 0;                                                                              \
+            asm volatile("" ::"v"(CUR.d.x), "v"(CUR.d.y), "v"(CUR.d.z), "v"(CUR.d.w), "v"(CUR.h.x), "v"(CUR.h.y)); \
+        } else {                                                                                  \
+            acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f);                 \
+        }                                                                                         \
+        if (args.debug & 1) acc = 0;                                                              \
         if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2>(t, qcount, lane, (COFF), acc);          \
         else spill(args, sp, (COFF), acc, CUR);                                                   \
     }
 
     if (n_full && blockIdx.x < n_full) {
         uint64_t tile = blockIdx.x;
-        /* three register stages rotate by name (loop unrolled x3), so a stage is
-         * never copied and the only wait is for the stage about to be filtered */
-        Chunk c0 = issue(tile), c1 = issue(tile + G), c2;
+        /* four register stages rotate by name (loop unrolled x4): three tiles are in
+         * flight while one is filtered, a stage is never copied, and the only wait is
+         * for the stage about to be filtered */
+        Chunk c0 = issue(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3;
 #define HSGPU_STAGE(CUR, NEW)                                   \
     {                                                           \
-        NEW = issue(tile + 2ull * G);                           \
+        NEW = issue(tile + 3ull * G);                           \
         const uint64_t coff = tile * SUPER_TILE + lane_off;     \
         HSGPU_HANDLE(CUR, coff)                                 \
         tile += G;                                              \
         if (tile >= n_full) break;                              \
     }
         for (;;) {
-            HSGPU_STAGE(c0, c2)
+            HSGPU_STAGE(c0, c3)
             HSGPU_STAGE(c1, c0)
             HSGPU_STAGE(c2, c1)
+            HSGPU_STAGE(c3, c2)
         }
 #undef HSGPU_STAGE
     }
@@ -618,28 +627,59 @@ __global__ __launch_bounds__(1024) void record_scan_kernel(HsgpuScanArgs args) {
     __syncthreads();
     unsigned long long sum = 0;
     bool ovf = false;
-    for (uint32_t i = tid; i < n; i += 1024) {
-        const uint2 c = counts[i];
-        ovf |= (unsigned long long)c.x + c.y > args.rec_cap;
-        sum += (unsigned long long)c.x + c.y;
+    for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) { /* 8 independent loads in flight per thread */
+        uint2 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t i = i0 + u * 1024;
+            c[u] = i < n ? counts[i] : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            ovf |= (unsigned long long)c[u].x + c[u].y > args.rec_cap;
+            sum += (unsigned long long)c[u].x + c[u].y;
+        }
     }
-    part[tid] = sum;
     if (ovf) any_overflow = 1;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) { /* Hillis-Steele inclusive scan of 1024 partial sums */
-        unsigned long long v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    /* inclusive scan of the 1024 per-thread sums: shuffles inside each wavefront,
+     * then the 16 wavefront totals, two barriers in all */
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long v = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += v;
     }
-    unsigned long long run = tid ? part[tid - 1] : 0;
-    for (uint32_t i = tid; i < n; i += 1024) {
-        const uint2 c = counts[i];
-        args.rec_offsets[i] = run;
-        run += (unsigned long long)c.x + c.y;
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        unsigned long long w = lane < 16 ? part[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const unsigned long long v = __shfl_up(w, d);
+            if (lane >= (uint32_t)d) w += v;
+        }
+        if (lane < 16) part[16 + lane] = w; /* inclusive totals of wavefronts 0..lane */
+    }
+    __syncthreads();
+    const unsigned long long before_wave = wv ? part[16 + wv - 1] : 0;
+    unsigned long long run = before_wave + incl - sum; /* exclusive prefix of this thread */
+    for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {
+        uint2 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t i = i0 + u * 1024;
+            c[u] = i < n ? counts[i] : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t i = i0 + u * 1024;
+            if (i < n) args.rec_offsets[i] = run;
+            run += (unsigned long long)c[u].x + c[u].y;
+        }
     }
     if (tid == 1023) {
-        const unsigned long long total = part[1023];
+        const unsigned long long total = before_wave + incl;
         /* a region that ran out of space lost records; its fill counters kept
          * counting, so the total is still exact: report it, but never a value
          * <= cap (that would claim the output is complete) */
@@ -661,6 +701,30 @@ __global__ __launch_bounds__(256) void record_pack_kernel(HsgpuScanArgs args) {
         if (o + i < args.cap) out[o + i] = region[i];
     for (uint32_t i = lane; i < b; i += 64)
         if (o + f + i < args.cap) out[o + f + i] = region[args.rec_cap - 1 - i];
+}
+
+/* last kernel of a scan: every control word this scan used goes back to zero, so the
+ * next scan on this scratch needs no memset in front of it */
+__global__ __launch_bounds__(256) void control_reset_kernel(HsgpuScanArgs args) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2 * args.rec_regions) args.rec_counts[i] = 0;
+
+    /* cumulative statistics for hsgpu_scratch_get_stats: one atomic per wavefront */
+    uint32_t v = 0, o = 0;
+    if (args.cand_counts && i <= args.cand_waves) {
+        const uint32_t c = args.cand_counts[i];
+        args.cand_counts[i] = 0;
+        if (i == args.cand_waves) o = c;
+        else v = c;
+    }
+    unsigned long long vs = v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vs += __shfl_xor(vs, d);
+    const unsigned long long any_o = __ballot(o != 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (vs) atomicAdd(&args.stats[0], vs);
+        if (any_o) atomicAdd(&args.stats[1], 1ull);
+    }
 }
 
 /* ---- phase 0: hint[t] = block containing corpus byte t * 1024 ------------------- */

@@ -27,6 +27,7 @@ struct HsgpuScanArgs {
     hsgpu_match_t *out;         /* match records */
     uint64_t cap;               /* capacity of out */
     unsigned long long *count;  /* total matches (may exceed cap) */
+    uint32_t debug;             /* ablation knob (env HSGPU_DEBUG): 1 = no candidate spill, 2 = no filter math */
     const uint32_t *hint;       /* hint[t] = block containing byte t << HSGPU_HINT_SHIFT */
     uint64_t n_hint;
     uint4 *cand;                /* two-phase: 32-byte candidate entries (2 x uint4), one region per filter wavefront */
@@ -38,6 +39,7 @@ struct HsgpuScanArgs {
     uint32_t rec_regions;       /* number of record regions */
     uint32_t *rec_counts;       /* [rec_regions][2]: records at the front / at the back of each region */
     unsigned long long *rec_offsets; /* [rec_regions]: exclusive scan of the region fills */
+    unsigned long long *stats;  /* [2] cumulative: candidate entries spilled, overflowed scans */
 };
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
@@ -45,6 +47,7 @@ const void *hsgpu_confirm_kernel_for(uint32_t table_flags);
 const void *hsgpu_hint_kernel(void);
 const void *hsgpu_record_scan_kernel(void);
 const void *hsgpu_record_pack_kernel(void);
+const void *hsgpu_control_reset_kernel(void);
 size_t hsgpu_filter_lds_bytes(uint32_t table_flags, uint32_t filter_log2, bool fused);
 uint32_t hsgpu_scan_super_tile(void);
 

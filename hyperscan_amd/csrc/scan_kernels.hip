@@ -83,6 +83,7 @@ const void *hsgpu_confirm_kernel_for(uint32_t flags) {
 const void *hsgpu_hint_kernel(void) { return (const void *)block_hint_kernel; }
 const void *hsgpu_record_scan_kernel(void) { return (const void *)record_scan_kernel; }
 const void *hsgpu_record_pack_kernel(void) { return (const void *)record_pack_kernel; }
+const void *hsgpu_control_reset_kernel(void) { return (const void *)control_reset_kernel; }
 
 size_t hsgpu_filter_lds_bytes(uint32_t flags, uint32_t filter_log2, bool fused) {
     size_t words = (size_t)hsgpu_filter_words(flags, filter_log2) + ((flags & HSGPU_F_HAS_C) ? 2048 : 0);

@@ -157,6 +157,14 @@ class Scratch:
             raise HsgpuError(rv, "hsgpu_scratch_get_timing")
         return f.value, c.value, t.value
 
+    def stats(self):
+        """(candidate entries spilled, scans that overflowed) since the previous call -- synchronises."""
+        n, o = C.c_uint64(), C.c_int()
+        rv = self._lib.hsgpu_scratch_get_stats(self._h, C.byref(n), C.byref(o))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_get_stats")
+        return n.value, o.value
+
     def close(self):
         if self._h:
             self._lib.hsgpu_scratch_free(self._h)

@@ -141,8 +141,8 @@ int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8
 /* Device-resident form (the hot path): corpus, offsets, records and counter all
  * live in HBM; asynchronous on `stream` (a hipStream_t passed as void*, NULL =
  * the scratch's own stream); no host synchronisation. d_off holds nblocks+1
- * ascending uint64 offsets with d_off[nblocks] == total_bytes. *d_count must be
- * zero on entry and receives the TOTAL number of matches (records beyond cap are
+ * ascending uint64 offsets with d_off[nblocks] == total_bytes. *d_count receives
+ * the TOTAL number of matches (records beyond cap are
  * dropped, unsorted). d_corpus must be 16-byte aligned. */
 int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus,
                         uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t start,
@@ -156,6 +156,11 @@ int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d
 int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable);
 int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float *filter_ms, float *confirm_ms,
                              float *total_ms);
+
+/* Tuning / test aid (synchronises the device): 32-byte candidate entries spilled by the
+ * filter kernel since the previous call, and how many scans since then overflowed a
+ * candidate region (and were redone by the fused fallback kernel). */
+int hsgpu_scratch_get_stats(hsgpu_scratch_t *s, uint64_t *cand_entries, int *overflowed);
 
 /* Sort cap' = min(count, cap) device records in place by (block, end, lit). */
 int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n, void *stream);

@@ -39,7 +39,7 @@ def main():
     gb = (job.total + 16 * n) / 1e9
     print(f"{a.workload}: kernel avg {ms.mean():.4f} ms best {ms.min():.4f} ms -> {gb / ms.mean() * 1e3:.1f} GB/s avg, "
           f"{gb / ms.min() * 1e3:.1f} best; filter {np.mean(fm):.4f} ms confirm {np.mean(cm):.4f} ms; matches {n}; "
-          f"table {job.table.info()}")
+          f"candidates {job.scratch.stats()}; table {job.table.info()}")
 
 
 if __name__ == "__main__":
