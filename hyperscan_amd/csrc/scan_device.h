@@ -166,6 +166,21 @@ __device__ __forceinline__ uint64_t block_of(const Tables &t, uint64_t g, uint64
     return b;
 }
 
+/* Stage a match record in this wavefront's LDS area. No global atomics anywhere:
+ * a single counter word sustains only ~90 returning atomics per microsecond,
+ * which would cap the whole scan at a few tens of thousands of matches per ms.
+ * Staged records are appended to the wavefront's private HBM region at
+ * convergent points (flush_records); a compaction pass packs the regions. */
+__device__ __forceinline__ void stage_record(const Tables &t, const uint4 rec) {
+    const uint32_t s = __hip_atomic_fetch_add(&t.wl->nrec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (s < OCAP) {
+        t.wl->rec[s] = rec;
+    } else { /* staging full inside one drain: spill to the back of the region */
+        const uint32_t k = __hip_atomic_fetch_add(&t.wl->nback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (k < t.rec_cap) t.rec_region[t.rec_cap - 1 - k] = rec;
+    }
+}
+
 /* One list entry = literal index | delta << 30: does that literal end at g + delta?
  * w0 / w1 are the 8-byte windows ending at g and g + 1. */
 __device__ __forceinline__ void check_lit(const Tables &t, uint32_t ent, uint64_t w0, uint64_t w1, uint64_t g) {
@@ -184,19 +199,7 @@ __device__ __forceinline__ void check_lit(const Tables &t, uint32_t ent, uint64_
     const uint64_t end = ge - bstart;
     /* left bound (fdr_confirm_runtime.h:77-88) and `start` (hwlm.h:108-111) */
     if (end + 1 < size || end + 1 - size < t.start) return;
-    /* Stage the record in this wavefront's LDS area. No global atomics anywhere:
-     * a single counter word sustains only ~90 returning atomics per microsecond,
-     * which would cap the whole scan at a few tens of thousands of matches per ms.
-     * Staged records are appended to the wavefront's private HBM region at
-     * convergent points (flush_records); a compaction pass packs the regions. */
-    const uint4 rec = make_uint4((uint32_t)b, (uint32_t)end, id, li);
-    const uint32_t s = __hip_atomic_fetch_add(&t.wl->nrec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (s < OCAP) {
-        t.wl->rec[s] = rec;
-    } else { /* staging full inside one drain: spill to the back of the region */
-        const uint32_t k = __hip_atomic_fetch_add(&t.wl->nback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (k < t.rec_cap) t.rec_region[t.rec_cap - 1 - k] = rec;
-    }
+    stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, li));
 }
 
 /* Convergent: append the staged records to the front of the wavefront's region. */
@@ -269,6 +272,89 @@ __device__ __forceinline__ void confirm_pos(const Tables &t, bool hit_a, bool hi
     }
 }
 
+/* The confirm kernel's version of confirm_pos: the same decisions, but the dependent
+ * reads of all its paths are issued together and waited for once per level --
+ * level 1: the class-A and class-B hash buckets (+ the 2-byte reference),
+ * level 2: the literals those buckets name directly (the common one-literal case),
+ * level 3 (matches only): block hints and offsets inside check_lit.
+ * Full buckets, literal lists and other rarities take the general (serial) path. */
+__device__ __forceinline__ uint32_t bucket_find(const uint4 s01, const uint4 s23, uint32_t key, bool &full) {
+    full = s23.w != 0;
+    if (s01.y && s01.x == key) return s01.y;
+    if (s01.w && s01.z == key) return s01.w;
+    if (s23.y && s23.x == key) return s23.y;
+    if (s23.w && s23.z == key) return s23.w;
+    return 0;
+}
+
+/* a list entry whose literal record is already in registers */
+__device__ __forceinline__ void check_lit_loaded(const Tables &t, uint32_t ent, const uint4 l0, const uint4 l1,
+                                                 uint64_t w0, uint64_t w1, uint64_t g) {
+    const uint32_t delta = (ent >> HSGPU_LIST_DELTA_SHIFT) & 1u;
+    const uint64_t w = delta ? w1 : w0;
+    const uint64_t v = (uint64_t)l0.y << 32 | l0.x, msk = (uint64_t)l0.w << 32 | l0.z;
+    if ((w & msk) != v) return;
+    const uint64_t ge = g + delta;
+    if (ge >= t.total) return;
+    const uint32_t id = l1.z, size = l1.w & 0xff;
+    uint64_t bstart;
+    const uint64_t b = block_of(t, ge, bstart);
+    const uint64_t end = ge - bstart;
+    if (end + 1 < size || end + 1 - size < t.start) return;
+    stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, ent & HSGPU_LIST_LIT_MASK));
+}
+
+template <bool HAS_A, bool HAS_B, bool HAS_C>
+__device__ __forceinline__ void confirm_pos_batched(const Tables &t, bool hit_a, bool hit_o, uint64_t w0, uint64_t w1,
+                                                    uint64_t g) {
+    const uint32_t w4 = (uint32_t)(w0 >> 32) & t.key_mask;
+    const bool do_a = HAS_A && hit_a, do_b = HAS_B && hit_o, do_c = HAS_C && hit_o;
+    /* level 1: issue every table read, then look at them */
+    uint4 a01 = make_uint4(0, 0, 0, 0), a23 = a01, b01 = a01, b23 = a01;
+    uint32_t ref_c = 0;
+    if (do_a) {
+        const uint4 *bp = (const uint4 *)(t.ht_a + (size_t)hsgpu_ht_bucket(w4, t.ht_a_log2) * HSGPU_BUCKET_SLOTS);
+        a01 = bp[0];
+        a23 = bp[1];
+    }
+    if (do_b) {
+        const uint4 *bp = (const uint4 *)(t.ht_b + (size_t)hsgpu_ht_bucket(w4 >> 8, t.ht_b_log2) * HSGPU_BUCKET_SLOTS);
+        b01 = bp[0];
+        b23 = bp[1];
+    }
+    if (do_c) ref_c = t.c2ref[w4 >> 16];
+    bool full_a = false, full_b = false;
+    const uint32_t ref_a = do_a ? bucket_find(a01, a23, w4, full_a) : 0;
+    const uint32_t ref_b = do_b ? bucket_find(b01, b23, w4 >> 8, full_b) : 0;
+    /* level 2: literals named directly by a slot */
+    const bool dir_a = ref_a & HSGPU_REF_DIRECT, dir_b = ref_b & HSGPU_REF_DIRECT, dir_c = ref_c & HSGPU_REF_DIRECT;
+    uint4 la0 = make_uint4(0, 0, 0, 0), la1 = la0, lb0 = la0, lb1 = la0, lc0 = la0, lc1 = la0;
+    if (dir_a) {
+        const uint4 *lp = (const uint4 *)(t.lits + (ref_a & HSGPU_LIST_LIT_MASK));
+        la0 = lp[0];
+        la1 = lp[1];
+    }
+    if (dir_b) {
+        const uint4 *lp = (const uint4 *)(t.lits + (ref_b & HSGPU_LIST_LIT_MASK));
+        lb0 = lp[0];
+        lb1 = lp[1];
+    }
+    if (dir_c) {
+        const uint4 *lp = (const uint4 *)(t.lits + (ref_c & HSGPU_LIST_LIT_MASK));
+        lc0 = lp[0];
+        lc1 = lp[1];
+    }
+    if (dir_a) check_lit_loaded(t, ref_a, la0, la1, w0, w1, g);
+    if (dir_b) check_lit_loaded(t, ref_b, lb0, lb1, w0, w1, g);
+    if (dir_c) check_lit_loaded(t, ref_c, lc0, lc1, w0, w1, g);
+    /* the rest: literal lists, and keys that may live in a later bucket */
+    if (ref_a && !dir_a) walk_ref(t, ref_a, w0, w1, g);
+    if (ref_b && !dir_b) walk_ref(t, ref_b, w0, w1, g);
+    if (ref_c && !dir_c) walk_ref(t, ref_c, w0, w1, g);
+    if (do_a && !ref_a && full_a) probe(t, t.ht_a, t.ht_a_log2, w4, w0, w1, g);
+    if (do_b && !ref_b && full_b) probe(t, t.ht_b, t.ht_b_log2, w4 >> 8, w0, w1, g);
+}
+
 /* fused kernel: {chunk, masks} entry, windows re-read from the corpus (L2 hits) */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
 __device__ __forceinline__ void drain_entry(const Tables &t, uint2 e) {
@@ -305,7 +391,7 @@ __device__ __forceinline__ void drain_fat_entry(const Tables &t, uint4 e0, uint4
         const uint64_t w0 = j < 8 ? funnel64(A, B, j + 1) : funnel64(B, C, j - 7);
         uint64_t w1 = 0;
         if (S2) w1 = (j + 1) < 8 ? funnel64(A, B, j + 2) : funnel64(B, C, j - 6); /* j even: j + 1 <= 15 */
-        confirm_pos<HAS_A, HAS_B, HAS_C>(t, m >> j & 1, m >> (16 + j) & 1, w0, w1, g);
+        confirm_pos_batched<HAS_A, HAS_B, HAS_C>(t, m >> j & 1, m >> (16 + j) & 1, w0, w1, g);
     }
 }
 
