@@ -242,7 +242,9 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
         k = 10;
         if ((uint64_t)entries * 128 > ((uint64_t)32 << k)) tflags |= HSGPU_F_K2; /* > 0.8% of bits set */
     } else {
-        k = 15;
+        /* the full 128 KiB that one 16-wavefront workgroup per CU can hold: a smaller
+         * table with three 8-wavefront workgroups per CU measured slower */
+        k = (flags & HSGPU_BUILD_FORCE_SMALL) ? 13 : 15;
         if ((uint64_t)entries * 128 > ((uint64_t)32 << k)) tflags |= HSGPU_F_K2;
     }
     if (flags & HSGPU_BUILD_FORCE_K2) tflags |= HSGPU_F_K2;

@@ -247,20 +247,24 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         hsgpu_set_error("no kernel for table flags %u", h->flags);
         return HSGPU_UNKNOWN_ERROR;
     }
-    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true);      /* fused */
-    const size_t lds_two = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false); /* two-phase filter */
+    /* Geometry: big tables (up to 128 KiB of filter) run one 16-wavefront workgroup per
+     * CU; tables of <= 40 KiB run three 8-wavefront workgroups per CU (24 wavefronts
+     * hide more latency; the SGPR budget admits no second 16-wavefront workgroup). */
+    const bool small = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, 512) * 3 <= s->lds_per_cu;
+    const unsigned wg_threads = small ? 512 : HSGPU_WG_THREADS, wg_per_cu = small ? 3 : 1;
+    const uint32_t super_shift = small ? 13 : 14;
+    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads);      /* fused */
+    const size_t lds_two = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false, wg_threads); /* two-phase filter */
     if (lds > s->lds_per_cu) {
         hsgpu_set_error("filter needs %zu bytes of LDS, device has %zu", lds, s->lds_per_cu);
         return HSGPU_UNKNOWN_ERROR;
     }
-    const uint64_t tile = hsgpu_scan_super_tile();
-    const uint64_t n_tiles = (a.total + tile - 1) / tile;
+    const uint64_t n_tiles = (a.total + (1ull << super_shift) - 1) >> super_shift;
     if (n_tiles == 0) return HSGPU_SUCCESS;
-    const unsigned wg_per_cu =
-        (unsigned)std::max<size_t>(1, std::min<size_t>(2048 / HSGPU_WG_THREADS, s->lds_per_cu / lds));
     const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)s->n_cu * wg_per_cu);
 
     HsgpuScanArgs args = a;
+    args.super_shift = super_shift;
     args.t_flags = h->flags;
     args.t_filter_log2 = h->filter_log2;
     args.t_ht_a_log2 = h->ht_a_log2;
@@ -296,7 +300,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     }
     /* staged match records: one region per producing wavefront, packed into the
      * caller's buffer by the last two kernels. 2x headroom over an even split. */
-    const uint32_t n_waves = grid * (HSGPU_WG_THREADS / 64);
+    const uint32_t n_waves = grid * (wg_threads / 64);
     const uint32_t n_rec = n_waves * HSGPU_CONFIRM_SPLIT; /* the fused kernel uses the first n_waves of them */
     args.rec_regions = n_rec;
     args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
@@ -327,7 +331,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.cand_waves = 0;
         args.cand_counts = nullptr;
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
-        HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
+        HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
         if (s->timing) {
             HIP_TRY(hipEventRecord(s->ev_t[1], stream));
             HIP_TRY(hipEventRecord(s->ev_t[2], stream));
@@ -344,11 +348,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.cand_counts = (uint32_t *)s->ctl.p + 2 * (size_t)n_rec;
         if ((rv = set_dyn_lds(f_two, lds_two)) != HSGPU_SUCCESS) return rv;
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
-        HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds_two, stream));
+        HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
         HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
-        HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(HSGPU_WG_THREADS), kargs, lds, stream));
+        HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[2], stream));
     }
     HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));

@@ -63,11 +63,10 @@
 namespace {
 
 
-constexpr int WG_THREADS = HSGPU_WG_THREADS;
-constexpr int WAVES = WG_THREADS / 64;
+constexpr int WG_THREADS = HSGPU_WG_THREADS; /* largest workgroup: 16 wavefronts; small tables run 8 */
 constexpr int CHUNK = 16;                     /* bytes per lane per iteration */
 constexpr int WAVE_TILE = 64 * CHUNK;         /* 1 KiB */
-constexpr int SUPER_TILE = WAVES * WAVE_TILE; /* 16 KiB */
+/* a workgroup of W wavefronts owns a W KiB super-tile per iteration (16 or 8 KiB) */
 constexpr int QCAP = 128;                     /* fused: candidate-queue entries per wavefront */
 constexpr int OCAP = 28;                      /* staged match records per wavefront */
 constexpr int CONFIRM_THREADS = HSGPU_CONFIRM_THREADS;
@@ -545,16 +544,18 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     /* stage the filter(s) in LDS: once per workgroup, 16 B per lane per step */
     {
         const uint4 *src = (const uint4 *)(args.blob + args.t_off_filter);
-        for (uint32_t i = threadIdx.x; i < nw / 4; i += WG_THREADS) ((uint4 *)filter)[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < nw / 4; i += blockDim.x) ((uint4 *)filter)[i] = src[i];
         if (HAS_C) {
             const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
-            for (uint32_t i = threadIdx.x; i < 512; i += WG_THREADS) ((uint4 *)c2bits)[i] = src2[i];
+            for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
         }
     }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t WAVES = blockDim.x >> 6;           /* 16 or 8 */
+    const uint32_t super_shift = args.super_shift;   /* log2(WAVES * 1 KiB): 14 or 13 */
     const uint32_t n_waves = gridDim.x * WAVES;
     const uint32_t wave_global = blockIdx.x * WAVES + wave;
 
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
 
     const uint8_t *corpus = args.corpus;
     const uint64_t total = args.total;
-    const uint64_t n_full = total / SUPER_TILE; /* super-tiles with every load in bounds */
+    const uint64_t n_full = total >> super_shift; /* super-tiles with every load in bounds */
     const uint32_t G = gridDim.x;
     const uint32_t lane_off = wave * WAVE_TILE + lane * CHUNK;
 
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
      * keeps them in flight across iterations with counted s_waitcnt */
     auto issue = [&](uint64_t tile) -> Chunk {
         const uint64_t tl = tile < n_full ? tile : n_full - 1;
-        const uint64_t off = tl * SUPER_TILE + lane_off;
+        const uint64_t off = (tl << super_shift) + lane_off;
         Chunk c;
         c.d = *(const uint4 *)(corpus + off);
         c.h = *(const uint2 *)(corpus + (off ? off - 8 : 0));
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
 #define HSGPU_STAGE(CUR, NEW)                                   \
     {                                                           \
         NEW = issue(tile + 3ull * G);                           \
-        const uint64_t coff = tile * SUPER_TILE + lane_off;     \
+        const uint64_t coff = (tile << super_shift) + lane_off;  \
         HSGPU_HANDLE(CUR, coff)                                 \
         tile += G;                                              \
         if (tile >= n_full) break;                              \
@@ -637,8 +638,8 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     /* the partial last super-tile: guarded, byte-wise where needed; one workgroup.
      * Bytes at/after the end of the corpus read as zero and their lookup
      * positions are masked off. */
-    if (total % SUPER_TILE && blockIdx.x == n_full % G) {
-        const uint64_t coff = n_full * SUPER_TILE + lane_off;
+    if ((total & ((1ull << super_shift) - 1)) && blockIdx.x == n_full % G) {
+        const uint64_t coff = (n_full << super_shift) + lane_off;
         Chunk c;
         c.d = make_uint4(0, 0, 0, 0);
         c.h = make_uint2(0, 0);

@@ -19,6 +19,7 @@ struct HsgpuScanArgs {
     const uint64_t *off;        /* nblocks + 1 ascending offsets, off[nblocks] == total */
     uint64_t nblocks;
     uint64_t start;             /* hwlmExec's `start`, applied inside every block */
+    uint32_t super_shift;       /* log2 of the bytes a filter workgroup owns per iteration (wavefronts x 1 KiB) */
     const uint8_t *blob;        /* compiled table in HBM */
     /* table header fields the kernels need, copied here by the host so that no
      * kernel starts with a dependent read of the header */
@@ -48,7 +49,6 @@ const void *hsgpu_hint_kernel(void);
 const void *hsgpu_record_scan_kernel(void);
 const void *hsgpu_record_pack_kernel(void);
 const void *hsgpu_control_reset_kernel(void);
-size_t hsgpu_filter_lds_bytes(uint32_t table_flags, uint32_t filter_log2, bool fused);
-uint32_t hsgpu_scan_super_tile(void);
+size_t hsgpu_filter_lds_bytes(uint32_t table_flags, uint32_t filter_log2, bool fused, uint32_t wg_threads);
 
 #endif

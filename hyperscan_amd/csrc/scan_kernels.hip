@@ -85,9 +85,7 @@ const void *hsgpu_record_scan_kernel(void) { return (const void *)record_scan_ke
 const void *hsgpu_record_pack_kernel(void) { return (const void *)record_pack_kernel; }
 const void *hsgpu_control_reset_kernel(void) { return (const void *)control_reset_kernel; }
 
-size_t hsgpu_filter_lds_bytes(uint32_t flags, uint32_t filter_log2, bool fused) {
+size_t hsgpu_filter_lds_bytes(uint32_t flags, uint32_t filter_log2, bool fused, uint32_t wg_threads) {
     size_t words = (size_t)hsgpu_filter_words(flags, filter_log2) + ((flags & HSGPU_F_HAS_C) ? 2048 : 0);
-    return words * 4 + (fused ? (size_t)WAVES * sizeof(WaveLds) : 0);
+    return words * 4 + (fused ? (size_t)(wg_threads / 64) * sizeof(WaveLds) : 0);
 }
-
-uint32_t hsgpu_scan_super_tile(void) { return SUPER_TILE; }
