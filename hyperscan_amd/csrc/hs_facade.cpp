@@ -1,0 +1,729 @@
+/*
+ * hs_facade.cpp -- the public hs_* block-mode API (include/hs_gpu.h) on top of the
+ * GPU literal engine, with a host-side "Rose-lite" confirm.
+ *
+ * What each piece stands in for in the reference:
+ *   parse_pattern        the subset of src/parser/ needed for "literal prefix + simple
+ *                        tail" patterns (the full Ragel parser is out of scope)
+ *   build_database       rose_build_matchers.cpp:701-744: one HWLM literal per pattern =
+ *                        the last <= 8 bytes of its literal prefix, id = pattern index
+ *   on_literal           roseCallback -> roseRunProgram (src/rose/match.c:479-523,
+ *                        program_runtime.c): CHECK_MED/LONG_LIT = full-literal compare,
+ *                        then the tail engine; REPORT -> the user's match_event_handler;
+ *                        SINGLEMATCH = the exhaustion vector (src/report.h)
+ *   TailNfa::run         the NFA engines Rose triggers after a literal (nfaQueueExec);
+ *                        here a bit-parallel position NFA over <= 256 states
+ * Matches are reported as the reference does: `to` = offset after the last byte,
+ * `from` = 0 unless HS_FLAG_SOM_LEFTMOST, every distinct (id, to) once, in
+ * non-decreasing `to`.
+ */
+#include "../../include/hs_gpu.h"
+#include "internal.h"
+
+#include <algorithm>
+#include <bitset>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef std::bitset<256> ByteSet;
+constexpr unsigned kMaxStates = 256;
+constexpr unsigned kInf = ~0u;
+
+struct Unit { /* one character class; `star` = may repeat, `optional` = may be skipped */
+    ByteSet cls;
+    bool optional = false, star = false;
+};
+
+struct Pattern {
+    std::string lit;          /* literal prefix, as written (upper-cased compare if nocase) */
+    bool nocase = false, single = false, som = false;
+    unsigned id = 0;
+    std::vector<Unit> tail;   /* empty: pure literal */
+    bool tail_nullable = true;
+};
+
+struct ParseError {
+    std::string msg;
+};
+
+bool is_alpha(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+void add_range(ByteSet &s, unsigned lo, unsigned hi) {
+    for (unsigned c = lo; c <= hi && c < 256; c++) s.set(c);
+}
+
+ByteSet class_escape(char e, bool &ok) {
+    ByteSet s;
+    ok = true;
+    switch (e) {
+    case 'd': add_range(s, '0', '9'); break;
+    case 'w': add_range(s, '0', '9'); add_range(s, 'a', 'z'); add_range(s, 'A', 'Z'); s.set('_'); break;
+    case 's': s.set(' '); s.set('\t'); s.set('\n'); s.set('\r'); s.set('\f'); s.set('\v'); break;
+    case 'D': s = ~class_escape('d', ok); break;
+    case 'W': s = ~class_escape('w', ok); break;
+    case 'S': s = ~class_escape('s', ok); break;
+    default: ok = false;
+    }
+    return s;
+}
+
+/* a single escaped literal character: \n \t \r \f \v \a \e \0 \xHH \\ \. etc. */
+bool char_escape(const std::string &p, size_t &i, unsigned char &out) {
+    char e = p[i];
+    switch (e) {
+    case 'n': out = '\n'; i++; return true;
+    case 't': out = '\t'; i++; return true;
+    case 'r': out = '\r'; i++; return true;
+    case 'f': out = '\f'; i++; return true;
+    case 'v': out = '\v'; i++; return true;
+    case 'a': out = 7; i++; return true;
+    case 'e': out = 27; i++; return true;
+    case '0': out = 0; i++; return true;
+    case 'x': {
+        unsigned v = 0;
+        for (int k = 1; k <= 2; k++) {
+            if (i + k >= p.size()) return false;
+            char h = p[i + k];
+            unsigned d = (h >= '0' && h <= '9') ? h - '0' : (h >= 'a' && h <= 'f') ? h - 'a' + 10
+                         : (h >= 'A' && h <= 'F') ? h - 'A' + 10 : 99;
+            if (d == 99) return false;
+            v = v * 16 + d;
+        }
+        out = (unsigned char)v;
+        i += 3;
+        return true;
+    }
+    default:
+        if ((e >= 'a' && e <= 'z') || (e >= 'A' && e <= 'Z') || (e >= '1' && e <= '9')) return false;
+        out = (unsigned char)e;
+        i++;
+        return true;
+    }
+}
+
+ByteSet fold_case(const ByteSet &s) {
+    ByteSet o = s;
+    for (unsigned c = 'a'; c <= 'z'; c++)
+        if (s[c] || s[c - 32]) {
+            o.set(c);
+            o.set(c - 32);
+        }
+    return o;
+}
+
+/* pattern := literal-prefix tail ; tail := (atom quantifier?)* */
+Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
+    const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_PREFILTER | HS_FLAG_COMBINATION |
+                                 HS_FLAG_QUIET | HS_FLAG_ALLOWEMPTY;
+    if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};
+    Pattern pat;
+    pat.nocase = flags & HS_FLAG_CASELESS;
+    pat.single = flags & HS_FLAG_SINGLEMATCH;
+    pat.som = flags & HS_FLAG_SOM_LEFTMOST;
+    pat.id = id;
+    const bool dotall = flags & HS_FLAG_DOTALL;
+    size_t i = 0;
+    auto peek_quant = [&](size_t k) { return k < p.size() && (p[k] == '?' || p[k] == '*' || p[k] == '+' || p[k] == '{'); };
+    /* literal prefix: plain or escaped characters not followed by a quantifier */
+    while (i < p.size()) {
+        unsigned char c = (unsigned char)p[i];
+        size_t j = i;
+        unsigned char lit;
+        if (c == '\\') {
+            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            class_escape(p[i + 1], ok);
+            if (ok) break; /* \d etc: tail */
+            j = i + 1;
+            if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+        } else if (strchr(".[]()|^$*+?{}", c)) {
+            if (c == '.' || c == '[') break;
+            throw ParseError{std::string("Unsupported regex construct '") + (char)c +
+                             "': only a literal prefix followed by classes and quantifiers is supported."};
+        } else {
+            lit = c;
+            j = i + 1;
+        }
+        if (peek_quant(j)) break; /* this character belongs to the tail */
+        pat.lit.push_back((char)lit);
+        i = j;
+    }
+    if (pat.lit.empty()) throw ParseError{"Pattern must start with a literal (no literal prefix found)."};
+    /* tail */
+    while (i < p.size()) {
+        ByteSet cls;
+        unsigned char c = (unsigned char)p[i];
+        if (c == '\\') {
+            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            cls = class_escape(p[i + 1], ok);
+            if (ok) {
+                i += 2;
+            } else {
+                size_t j = i + 1;
+                unsigned char lit;
+                if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+                cls.set(lit);
+                i = j;
+            }
+        } else if (c == '.') {
+            cls.set();
+            if (!dotall) cls.reset('\n');
+            i++;
+        } else if (c == '[') {
+            size_t j = i + 1;
+            bool neg = false;
+            if (j < p.size() && p[j] == '^') {
+                neg = true;
+                j++;
+            }
+            bool first = true;
+            for (;;) {
+                if (j >= p.size()) throw ParseError{"Unterminated character class."};
+                if (p[j] == ']' && !first) break;
+                first = false;
+                ByteSet item;
+                unsigned lo;
+                bool is_class = false;
+                if (p[j] == '\\') {
+                    if (j + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+                    bool ok;
+                    item = class_escape(p[j + 1], ok);
+                    if (ok) {
+                        is_class = true;
+                        j += 2;
+                    } else {
+                        size_t k = j + 1;
+                        unsigned char lit;
+                        if (!char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                        lo = lit;
+                        j = k;
+                    }
+                } else {
+                    lo = (unsigned char)p[j++];
+                }
+                if (is_class) {
+                    cls |= item;
+                    continue;
+                }
+                unsigned hi = lo;
+                if (j + 1 < p.size() && p[j] == '-' && p[j + 1] != ']') {
+                    j++;
+                    if (p[j] == '\\') {
+                        size_t k = j + 1;
+                        unsigned char lit;
+                        if (k >= p.size() || !char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                        hi = lit;
+                        j = k;
+                    } else {
+                        hi = (unsigned char)p[j++];
+                    }
+                    if (hi < lo) throw ParseError{"Range out of order in character class."};
+                }
+                add_range(cls, lo, hi);
+            }
+            i = j + 1;
+            if (neg) cls = ~cls;
+        } else if (strchr("()|^$*+?{}]", c)) {
+            throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
+        } else {
+            cls.set(c);
+            i++;
+        }
+        if (pat.nocase) cls = fold_case(cls);
+        /* quantifier */
+        unsigned lo = 1, hi = 1;
+        if (i < p.size()) {
+            char q = p[i];
+            if (q == '?') { lo = 0; hi = 1; i++; }
+            else if (q == '*') { lo = 0; hi = kInf; i++; }
+            else if (q == '+') { lo = 1; hi = kInf; i++; }
+            else if (q == '{') {
+                size_t j = i + 1;
+                auto num = [&](unsigned &v) {
+                    if (j >= p.size() || p[j] < '0' || p[j] > '9') return false;
+                    v = 0;
+                    while (j < p.size() && p[j] >= '0' && p[j] <= '9') v = v * 10 + (p[j++] - '0');
+                    return v <= 1000;
+                };
+                if (!num(lo)) throw ParseError{"Malformed repeat."};
+                hi = lo;
+                if (j < p.size() && p[j] == ',') {
+                    j++;
+                    if (j < p.size() && p[j] == '}') hi = kInf;
+                    else if (!num(hi) || hi < lo) throw ParseError{"Malformed repeat."};
+                }
+                if (j >= p.size() || p[j] != '}') throw ParseError{"Malformed repeat."};
+                i = j + 1;
+            }
+            if (i < p.size() && (p[i] == '?' || p[i] == '+')) throw ParseError{"Lazy/possessive quantifiers are not supported."};
+        }
+        for (unsigned k = 0; k < lo; k++) pat.tail.push_back(Unit{cls, false, false});
+        if (hi == kInf) {
+            if (lo == 0) pat.tail.push_back(Unit{cls, true, true});
+            else pat.tail.back().star = true;
+        } else {
+            for (unsigned k = lo; k < hi; k++) pat.tail.push_back(Unit{cls, true, false});
+        }
+        if (pat.tail.size() > kMaxStates - 1) throw ParseError{"Pattern too large."};
+    }
+    pat.tail_nullable = true;
+    for (const Unit &u : pat.tail) pat.tail_nullable &= u.optional;
+    return pat;
+}
+
+/* bit-parallel simulation of the linear NFA: state i = "units 0..i-1 consumed" */
+struct TailNfa {
+    typedef std::bitset<kMaxStates> States;
+    static States closure(const std::vector<Unit> &u, States s) {
+        for (size_t i = 0; i < u.size(); i++)
+            if (s[i] && u[i].optional) s.set(i + 1);
+        return s;
+    }
+    /* calls report(to) for every offset after which the tail has matched */
+    template <class F> static void run(const std::vector<Unit> &u, const unsigned char *buf, size_t len, size_t pos, F report) {
+        States cur;
+        cur.set(0);
+        cur = closure(u, cur);
+        const size_t S = u.size();
+        if (cur[S]) { if (!report(pos)) return; }
+        while (pos < len && cur.any()) {
+            const unsigned char c = buf[pos++];
+            States nxt;
+            for (size_t i = 0; i < S; i++)
+                if (cur[i] && u[i].cls[c]) {
+                    nxt.set(i + 1);
+                    if (u[i].star) nxt.set(i);
+                }
+            cur = closure(u, nxt);
+            if (cur[S]) { if (!report(pos)) return; }
+        }
+    }
+};
+
+} // namespace
+
+struct hs_database {
+    unsigned magic = 0x48534744; /* "HSGD" */
+    unsigned mode = HS_MODE_BLOCK;
+    std::vector<Pattern> pats;
+    hsgpu_hwlm_t *hwlm = nullptr;
+    size_t min_width = 0;
+    std::vector<std::string> sources; /* for serialisation: original expressions + flags */
+    std::vector<unsigned> src_flags, src_ids;
+    std::vector<unsigned char> src_is_lit;
+};
+
+struct hs_scratch {
+    unsigned magic = 0x48534753; /* "HSGS" */
+    hsgpu_scratch_t *gpu = nullptr;
+    bool in_use = false;
+    std::vector<hsgpu_match_t> recs;
+};
+
+namespace {
+
+hs_compile_error_t *make_error(const std::string &msg, int expr) {
+    hs_compile_error_t *e = (hs_compile_error_t *)malloc(sizeof(*e));
+    if (!e) return nullptr;
+    e->message = strdup(msg.c_str());
+    e->expression = expr;
+    return e;
+}
+
+hs_error_t build_database(const std::vector<std::string> &exprs, const std::vector<unsigned char> &is_lit,
+                          const unsigned *flags, const unsigned *ids, unsigned mode, hs_database_t **db,
+                          hs_compile_error_t **error) {
+    if (mode != HS_MODE_BLOCK) {
+        *error = make_error((mode & (HS_MODE_STREAM | HS_MODE_VECTORED))
+                                ? "Only HS_MODE_BLOCK is supported by the GPU literal engine."
+                                : "Invalid parameter: unrecognised mode flags.", -1);
+        return HS_COMPILER_ERROR;
+    }
+    hs_database *d = new hs_database;
+    std::vector<std::string> hw_s;
+    try {
+        for (size_t i = 0; i < exprs.size(); i++) {
+            const unsigned f = flags ? flags[i] : 0, id = ids ? ids[i] : 0;
+            try {
+                if (is_lit[i]) {
+                    /* src/compiler/compiler.cpp:405-419: flags the pure-literal API refuses */
+                    const unsigned bad = HS_FLAG_DOTALL | HS_FLAG_ALLOWEMPTY | HS_FLAG_UTF8 | HS_FLAG_UCP |
+                                         HS_FLAG_PREFILTER | HS_FLAG_COMBINATION | HS_FLAG_QUIET | HS_FLAG_MULTILINE;
+                    if (f & bad)
+                        throw ParseError{"Only HS_FLAG_CASELESS, HS_FLAG_SINGLEMATCH and HS_FLAG_SOM_LEFTMOST are "
+                                         "supported in literal API."};
+                    if (exprs[i].empty()) throw ParseError{"Pure literal API doesn't support empty string."};
+                    Pattern p;
+                    p.lit = exprs[i];
+                    p.nocase = f & HS_FLAG_CASELESS;
+                    p.single = f & HS_FLAG_SINGLEMATCH;
+                    p.som = f & HS_FLAG_SOM_LEFTMOST;
+                    p.id = id;
+                    d->pats.push_back(p);
+                } else {
+                    d->pats.push_back(parse_pattern(exprs[i], f, id));
+                }
+            } catch (const ParseError &pe) {
+                *error = make_error(pe.msg, (int)i);
+                delete d;
+                return HS_COMPILER_ERROR;
+            }
+        }
+        /* one HWLM literal per pattern: the last <= 8 bytes of the literal prefix */
+        std::vector<hsgpu_lit_t> lits(d->pats.size());
+        hw_s.resize(d->pats.size());
+        d->min_width = ~(size_t)0;
+        for (size_t i = 0; i < d->pats.size(); i++) {
+            const Pattern &p = d->pats[i];
+            hw_s[i] = p.lit.size() > 8 ? p.lit.substr(p.lit.size() - 8) : p.lit;
+            memset(&lits[i], 0, sizeof(lits[i]));
+            lits[i].s = (const uint8_t *)hw_s[i].data();
+            lits[i].len = (uint32_t)hw_s[i].size();
+            lits[i].id = (uint32_t)i; /* the "Rose program" of this literal = the pattern index */
+            lits[i].nocase = p.nocase;
+            lits[i].groups = HSGPU_ALL_GROUPS;
+            size_t w = p.lit.size();
+            for (const Unit &u : p.tail) w += u.optional ? 0 : 1;
+            d->min_width = std::min(d->min_width, w);
+        }
+        int rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
+        if (rv != HSGPU_SUCCESS) {
+            *error = make_error(hsgpu_last_error(), -1);
+            delete d;
+            return HS_COMPILER_ERROR;
+        }
+    } catch (const std::bad_alloc &) {
+        delete d;
+        *error = make_error("Unable to allocate memory.", -1);
+        return HS_COMPILER_ERROR;
+    }
+    d->sources = exprs;
+    d->src_is_lit = is_lit;
+    for (size_t i = 0; i < exprs.size(); i++) {
+        d->src_flags.push_back(flags ? flags[i] : 0);
+        d->src_ids.push_back(ids ? ids[i] : 0);
+    }
+    *db = d;
+    *error = nullptr;
+    return HS_SUCCESS;
+}
+
+bool lit_matches_at(const Pattern &p, const unsigned char *buf, size_t end /* offset after the literal */) {
+    const size_t n = p.lit.size();
+    if (end < n) return false;
+    const unsigned char *b = buf + end - n;
+    if (!p.nocase) return memcmp(b, p.lit.data(), n) == 0;
+    for (size_t i = 0; i < n; i++) {
+        unsigned char x = b[i], y = (unsigned char)p.lit[i];
+        if (is_alpha(x)) x &= 0xdf;
+        if (is_alpha(y)) y &= 0xdf;
+        if (x != y) return false;
+    }
+    return true;
+}
+
+struct Event {
+    unsigned long long to, from;
+    unsigned id;
+    bool operator<(const Event &o) const { return to != o.to ? to < o.to : (id != o.id ? id < o.id : from < o.from); }
+    bool operator==(const Event &o) const { return to == o.to && id == o.id; }
+};
+
+/* turn the HWLM hits of ONE block into user events; returns true if terminated */
+template <class Emit>
+bool confirm_block(const hs_database *db, const unsigned char *buf, size_t len, const hsgpu_match_t *recs, size_t n,
+                   Emit emit) {
+    std::vector<Event> ev;
+    for (size_t k = 0; k < n; k++) {
+        const Pattern &p = db->pats[recs[k].id];
+        const size_t lit_end = (size_t)recs[k].end + 1;
+        if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
+        const unsigned long long from = p.som ? lit_end - p.lit.size() : 0;
+        if (p.tail.empty()) {
+            ev.push_back(Event{lit_end, from, p.id});
+        } else {
+            TailNfa::run(p.tail, buf, len, lit_end, [&](size_t to) {
+                ev.push_back(Event{to, from, p.id});
+                return true;
+            });
+        }
+    }
+    std::sort(ev.begin(), ev.end());
+    ev.erase(std::unique(ev.begin(), ev.end()), ev.end()); /* one report per (id, to) */
+    std::set<unsigned> exhausted;                            /* SINGLEMATCH ids already reported */
+    std::set<unsigned> single_ids;
+    for (const Pattern &p : db->pats)
+        if (p.single) single_ids.insert(p.id);
+    for (const Event &e : ev) {
+        if (single_ids.count(e.id)) {
+            if (exhausted.count(e.id)) continue;
+            exhausted.insert(e.id);
+        }
+        if (emit(e)) return true;
+    }
+    return false;
+}
+
+} // namespace
+
+extern "C" {
+
+hs_error_t hs_compile_multi(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
+                            unsigned int elements, unsigned int mode, const hs_platform_info_t *platform,
+                            hs_database_t **db, hs_compile_error_t **error) {
+    (void)platform;
+    if (!error) {
+        if (db) *db = nullptr;
+        return HS_COMPILER_ERROR;
+    }
+    if (!db) { *error = make_error("Invalid parameter: db is NULL", -1); return HS_COMPILER_ERROR; }
+    *db = nullptr;
+    if (!expressions) { *error = make_error("Invalid parameter: expressions is NULL", -1); return HS_COMPILER_ERROR; }
+    if (elements == 0) { *error = make_error("Invalid parameter: elements is zero", -1); return HS_COMPILER_ERROR; }
+    std::vector<std::string> ex;
+    for (unsigned i = 0; i < elements; i++) {
+        if (!expressions[i]) { *error = make_error("Invalid parameter: expression is NULL", (int)i); return HS_COMPILER_ERROR; }
+        ex.push_back(expressions[i]);
+    }
+    return build_database(ex, std::vector<unsigned char>(elements, 0), flags, ids, mode, db, error);
+}
+
+hs_error_t hs_compile(const char *expression, unsigned int flags, unsigned int mode, const hs_platform_info_t *platform,
+                      hs_database_t **db, hs_compile_error_t **error) {
+    if (!expression) {
+        if (db) *db = nullptr;
+        if (error) *error = make_error("Invalid parameter: expression is NULL", -1);
+        return HS_COMPILER_ERROR;
+    }
+    unsigned id = 0;
+    return hs_compile_multi(&expression, &flags, &id, 1, mode, platform, db, error);
+}
+
+hs_error_t hs_compile_lit_multi(const char *const *expressions, const unsigned *flags, const unsigned *ids,
+                                const size_t *lens, unsigned elements, unsigned mode,
+                                const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error) {
+    (void)platform;
+    if (!error) {
+        if (db) *db = nullptr;
+        return HS_COMPILER_ERROR;
+    }
+    if (!db) { *error = make_error("Invalid parameter: db is NULL", -1); return HS_COMPILER_ERROR; }
+    *db = nullptr;
+    if (!expressions) { *error = make_error("Invalid parameter: expressions is NULL", -1); return HS_COMPILER_ERROR; }
+    if (!lens) { *error = make_error("Invalid parameter: len is NULL", -1); return HS_COMPILER_ERROR; }
+    if (elements == 0) { *error = make_error("Invalid parameter: elements is zero", -1); return HS_COMPILER_ERROR; }
+    std::vector<std::string> ex;
+    for (unsigned i = 0; i < elements; i++) ex.emplace_back(expressions[i] ? expressions[i] : "", expressions[i] ? lens[i] : 0);
+    return build_database(ex, std::vector<unsigned char>(elements, 1), flags, ids, mode, db, error);
+}
+
+hs_error_t hs_compile_lit(const char *expression, unsigned flags, const size_t len, unsigned mode,
+                          const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error) {
+    if (!expression) {
+        if (db) *db = nullptr;
+        if (error) *error = make_error("Invalid parameter: expression is NULL", -1);
+        return HS_COMPILER_ERROR;
+    }
+    unsigned id = 0;
+    return hs_compile_lit_multi(&expression, &flags, &id, &len, 1, mode, platform, db, error);
+}
+
+hs_error_t hs_free_compile_error(hs_compile_error_t *error) {
+    if (!error) return HS_SUCCESS;
+    free(error->message);
+    free(error);
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_free_database(hs_database_t *db) {
+    if (!db) return HS_SUCCESS;
+    if (db->magic != 0x48534744) return HS_INVALID;
+    hsgpu_hwlm_free(db->hwlm);
+    delete db;
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
+    if (!db || !size || db->magic != 0x48534744) return HS_INVALID;
+    size_t s = sizeof(*db) + hsgpu_hwlm_size(db->hwlm);
+    for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit);
+    *size = s;
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_database_info(const hs_database_t *db, char **info) {
+    if (!db || !info || db->magic != 0x48534744) return HS_INVALID;
+    char buf[160];
+    snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: BLOCK", hs_version());
+    *info = strdup(buf);
+    return *info ? HS_SUCCESS : HS_NOMEM;
+}
+
+/* serialised form: magic, count, then per pattern {is_lit, flags, id, len, bytes} -- the
+ * database is rebuilt from its sources on load (compilation is cheap for this engine) */
+hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length) {
+    if (!db || !bytes || !length || db->magic != 0x48534744) return HS_INVALID;
+    std::string out;
+    auto put32 = [&](unsigned v) { out.append((const char *)&v, 4); };
+    put32(0x48534744);
+    put32((unsigned)db->sources.size());
+    for (size_t i = 0; i < db->sources.size(); i++) {
+        put32(db->src_is_lit[i]);
+        put32(db->src_flags[i]);
+        put32(db->src_ids[i]);
+        put32((unsigned)db->sources[i].size());
+        out += db->sources[i];
+    }
+    *bytes = (char *)malloc(out.size());
+    if (!*bytes) return HS_NOMEM;
+    memcpy(*bytes, out.data(), out.size());
+    *length = out.size();
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_database_t **db) {
+    if (!bytes || !db) return HS_INVALID;
+    *db = nullptr;
+    size_t off = 0;
+    auto get32 = [&](unsigned &v) {
+        if (off + 4 > length) return false;
+        memcpy(&v, bytes + off, 4);
+        off += 4;
+        return true;
+    };
+    unsigned magic, n;
+    if (!get32(magic) || magic != 0x48534744 || !get32(n) || n == 0) return HS_INVALID;
+    std::vector<std::string> ex;
+    std::vector<unsigned char> is_lit;
+    std::vector<unsigned> flags, ids;
+    for (unsigned i = 0; i < n; i++) {
+        unsigned l, f, id, len;
+        if (!get32(l) || !get32(f) || !get32(id) || !get32(len) || off + len > length) return HS_INVALID;
+        ex.emplace_back(bytes + off, len);
+        off += len;
+        is_lit.push_back((unsigned char)l);
+        flags.push_back(f);
+        ids.push_back(id);
+    }
+    hs_compile_error_t *err = nullptr;
+    hs_error_t rv = build_database(ex, is_lit, flags.data(), ids.data(), HS_MODE_BLOCK, db, &err);
+    hs_free_compile_error(err);
+    return rv == HS_SUCCESS ? HS_SUCCESS : HS_INVALID;
+}
+
+hs_error_t hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch) {
+    if (!db || !scratch || db->magic != 0x48534744) return HS_INVALID;
+    if (*scratch) return (*scratch)->magic == 0x48534753 ? ((*scratch)->in_use ? HS_SCRATCH_IN_USE : HS_SUCCESS) : HS_INVALID;
+    hs_scratch *s = new (std::nothrow) hs_scratch;
+    if (!s) return HS_NOMEM;
+    int rv = hsgpu_scratch_alloc(&s->gpu, -1);
+    if (rv != HSGPU_SUCCESS) {
+        delete s;
+        return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
+    }
+    *scratch = s;
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_clone_scratch(const hs_scratch_t *src, hs_scratch_t **dest) {
+    if (!src || !dest || src->magic != 0x48534753) return HS_INVALID;
+    *dest = nullptr;
+    hs_scratch *s = new (std::nothrow) hs_scratch;
+    if (!s) return HS_NOMEM;
+    if (hsgpu_scratch_alloc(&s->gpu, -1) != HSGPU_SUCCESS) {
+        delete s;
+        return HS_UNKNOWN_ERROR;
+    }
+    *dest = s;
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_scratch_size(const hs_scratch_t *scratch, size_t *size) {
+    if (!scratch || !size || scratch->magic != 0x48534753) return HS_INVALID;
+    *size = sizeof(*scratch);
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
+    if (!scratch) return HS_SUCCESS;
+    if (scratch->magic != 0x48534753) return HS_INVALID;
+    if (scratch->in_use) return HS_SCRATCH_IN_USE;
+    hsgpu_scratch_free(scratch->gpu);
+    delete scratch;
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
+                         unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
+                         hs_batch_event_handler onEvent, void *context) {
+    (void)flags;
+    if (!scratch || !data || !off) return HS_INVALID;
+    if (!db || db->magic != 0x48534744) return HS_INVALID;
+    if (db->mode != HS_MODE_BLOCK) return HS_DB_MODE_ERROR;
+    if (scratch->magic != 0x48534753) return HS_INVALID;
+    if (scratch->in_use) return HS_SCRATCH_IN_USE;
+    scratch->in_use = true;
+    struct Guard { hs_scratch *s; ~Guard() { s->in_use = false; } } guard{scratch};
+    if (nblocks == 0) return HS_SUCCESS;
+    size_t cap = std::max<size_t>(4096, (size_t)(off[nblocks] - off[0]) / 64), n = 0;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        scratch->recs.resize(cap);
+        int rv = hsgpu_hwlm_exec_batch(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off,
+                                       (size_t)nblocks, 0, scratch->recs.data(), cap, &n);
+        if (rv == HSGPU_SUCCESS) break;
+        if (rv != HSGPU_INSUFFICIENT_SPACE) return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
+        cap = n + n / 4;
+        if (attempt == 7) return HS_UNKNOWN_ERROR;
+    }
+    bool any_terminated = false;
+    size_t k = 0;
+    while (k < n) { /* records are sorted by (block, end): one run per block */
+        const unsigned long long b = scratch->recs[k].block;
+        size_t e = k;
+        while (e < n && scratch->recs[e].block == b) e++;
+        const unsigned char *buf = (const unsigned char *)data + off[b];
+        const size_t len = (size_t)(off[b + 1] - off[b]);
+        if (len >= db->min_width && onEvent) {
+            any_terminated |= confirm_block(db, buf, len, scratch->recs.data() + k, e - k, [&](const Event &ev) {
+                return onEvent(b, ev.id, ev.from, ev.to, 0, context) != 0;
+            });
+        }
+        k = e;
+    }
+    return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
+}
+
+hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsigned int flags,
+                   hs_scratch_t *scratch, match_event_handler onEvent, void *context) {
+    if (!scratch || !data) return HS_INVALID; /* src/runtime.c:320-322 */
+    if (!db || db->magic != 0x48534744) return HS_INVALID;
+    struct Ctx { match_event_handler cb; void *user; } c{onEvent, context};
+    const unsigned long long off[2] = {0, length};
+    if (length < db->min_width) { /* src/runtime.c:346-350 */
+        if (scratch->magic != 0x48534753) return HS_INVALID;
+        return scratch->in_use ? HS_SCRATCH_IN_USE : HS_SUCCESS;
+    }
+    return hs_scan_batch(db, data, off, 1, flags, scratch,
+                         onEvent ? +[](unsigned long long, unsigned id, unsigned long long from, unsigned long long to,
+                                       unsigned fl, void *cc) { return ((Ctx *)cc)->cb(id, from, to, fl, ((Ctx *)cc)->user); }
+                                 : (hs_batch_event_handler) nullptr,
+                         &c);
+}
+
+const char *hs_version(void) { return "5.4.2-hsgpu-gfx950"; }
+
+hs_error_t hs_valid_platform(void) {
+    hsgpu_scratch_t *s = nullptr;
+    if (hsgpu_scratch_alloc(&s, -1) != HSGPU_SUCCESS) return HS_ARCH_ERROR;
+    hsgpu_scratch_free(s);
+    return HS_SUCCESS;
+}
+
+} // extern "C"

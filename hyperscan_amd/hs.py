@@ -1,0 +1,154 @@
+"""ctypes mirror of the public hs_* block-mode API served by libhsgpu.so (include/hs_gpu.h).
+Same names, argument meaning and error codes as the reference's src/hs.h."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+HS_SUCCESS, HS_INVALID, HS_NOMEM, HS_SCAN_TERMINATED, HS_COMPILER_ERROR = 0, -1, -2, -3, -4
+HS_DB_MODE_ERROR, HS_SCRATCH_IN_USE, HS_UNKNOWN_ERROR = -7, -10, -13
+HS_FLAG_CASELESS, HS_FLAG_DOTALL, HS_FLAG_MULTILINE, HS_FLAG_SINGLEMATCH = 1, 2, 4, 8
+HS_FLAG_UTF8, HS_FLAG_SOM_LEFTMOST = 32, 256
+HS_MODE_BLOCK, HS_MODE_STREAM, HS_MODE_VECTORED = 1, 2, 4
+
+
+class CompileErrorStruct(C.Structure):
+    _fields_ = [("message", C.c_char_p), ("expression", C.c_int)]
+
+
+MATCH_CB = C.CFUNCTYPE(C.c_int, C.c_uint, C.c_ulonglong, C.c_ulonglong, C.c_uint, C.c_void_p)
+BATCH_CB = C.CFUNCTYPE(C.c_int, C.c_ulonglong, C.c_uint, C.c_ulonglong, C.c_ulonglong, C.c_uint, C.c_void_p)
+
+
+class HsError(RuntimeError):
+    def __init__(self, code, message="", expression=-1):
+        super().__init__(f"hs error {code}: {message} (expression {expression})")
+        self.code, self.message, self.expression = code, message, expression
+
+
+def _lib():
+    lib = _native.load_library()
+    if not getattr(lib, "_hs_sigs", False):
+        P, E = C.POINTER, C.POINTER(C.POINTER(CompileErrorStruct))
+        lib.hs_compile_multi.argtypes = [P(C.c_char_p), P(C.c_uint), P(C.c_uint), C.c_uint, C.c_uint, C.c_void_p,
+                                         P(C.c_void_p), E]
+        lib.hs_compile_lit_multi.argtypes = [P(C.c_char_p), P(C.c_uint), P(C.c_uint), P(C.c_size_t), C.c_uint,
+                                             C.c_uint, C.c_void_p, P(C.c_void_p), E]
+        lib.hs_free_compile_error.argtypes = [P(CompileErrorStruct)]
+        lib.hs_free_database.argtypes = [C.c_void_p]
+        lib.hs_alloc_scratch.argtypes = [C.c_void_p, P(C.c_void_p)]
+        lib.hs_free_scratch.argtypes = [C.c_void_p]
+        lib.hs_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, MATCH_CB, C.c_void_p]
+        lib.hs_scan_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_uint, C.c_void_p,
+                                      BATCH_CB, C.c_void_p]
+        lib.hs_serialize_database.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_size_t)]
+        lib.hs_deserialize_database.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p)]
+        lib.hs_database_size.argtypes = [C.c_void_p, P(C.c_size_t)]
+        lib.hs_version.restype = C.c_char_p
+        lib._hs_sigs = True
+    return lib
+
+
+class Database:
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def _compile(cls, fn_name, exprs, flags, ids, mode, lens=None):
+        lib = _lib()
+        n = len(exprs)
+        bufs = [e if isinstance(e, bytes) else e.encode("latin-1") for e in exprs]
+        arr = (C.c_char_p * n)(*bufs)
+        fl = (C.c_uint * n)(*(flags if flags is not None else [0] * n))
+        idv = (C.c_uint * n)(*(ids if ids is not None else list(range(n))))
+        db = C.c_void_p()
+        err = C.POINTER(CompileErrorStruct)()
+        if fn_name == "hs_compile_lit_multi":
+            ln = (C.c_size_t * n)(*(lens if lens is not None else [len(b) for b in bufs]))
+            rv = lib.hs_compile_lit_multi(arr, fl, idv, ln, n, mode, None, C.byref(db), C.byref(err))
+        else:
+            rv = lib.hs_compile_multi(arr, fl, idv, n, mode, None, C.byref(db), C.byref(err))
+        if rv != HS_SUCCESS:
+            msg, ex = "", -1
+            if err:
+                msg, ex = err.contents.message.decode(errors="replace"), err.contents.expression
+                lib.hs_free_compile_error(err)
+            raise HsError(rv, msg, ex)
+        return cls(db)
+
+    @classmethod
+    def compile(cls, exprs, flags=None, ids=None, mode=HS_MODE_BLOCK):
+        return cls._compile("hs_compile_multi", exprs, flags, ids, mode)
+
+    @classmethod
+    def compile_lit(cls, exprs, flags=None, ids=None, mode=HS_MODE_BLOCK):
+        return cls._compile("hs_compile_lit_multi", exprs, flags, ids, mode)
+
+    def serialize(self):
+        lib = _lib()
+        p, n = C.c_void_p(), C.c_size_t()
+        rv = lib.hs_serialize_database(self._h, C.byref(p), C.byref(n))
+        if rv != 0:
+            raise HsError(rv)
+        out = C.string_at(p, n.value)
+        C.CDLL(None).free(p)
+        return out
+
+    @classmethod
+    def deserialize(cls, blob):
+        db = C.c_void_p()
+        rv = _lib().hs_deserialize_database(blob, len(blob), C.byref(db))
+        if rv != 0:
+            raise HsError(rv)
+        return cls(db)
+
+    def size(self):
+        n = C.c_size_t()
+        _lib().hs_database_size(self._h, C.byref(n))
+        return n.value
+
+    def close(self):
+        if self._h:
+            _lib().hs_free_database(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HsScratch:
+    def __init__(self, db):
+        h = C.c_void_p()
+        rv = _lib().hs_alloc_scratch(db._h, C.byref(h))
+        if rv != 0:
+            raise HsError(rv, "hs_alloc_scratch")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            _lib().hs_free_scratch(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def scan(db, data, scratch, on_event=None):
+    """hs_scan: on_event(id, from, to) -> truthy stops. Returns the hs_error_t."""
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    cb = MATCH_CB(lambda i, f, t, _fl, _c: 1 if (on_event and on_event(i, f, t)) else 0)
+    return _lib().hs_scan(db._h, buf.ctypes.data if buf.size else b"", buf.size, 0, scratch._h, cb, None)
+
+
+def scan_batch(db, data, off, scratch, on_event=None):
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    cb = BATCH_CB(lambda b, i, f, t, _fl, _c: 1 if (on_event and on_event(b, i, f, t)) else 0)
+    return _lib().hs_scan_batch(db._h, buf.ctypes.data, off.ctypes.data, off.size - 1, 0, scratch._h, cb, None)

@@ -1,0 +1,133 @@
+/*
+ * hs_gpu.h -- the public Hyperscan block-mode API surface, served by the GPU literal
+ * engine (libhsgpu.so) plus a small host-side confirm ("Rose-lite").
+ *
+ * Names, argument meaning, error codes and callback protocol are the reference's:
+ *   hs_compile / hs_compile_multi            src/hs_compile.h:360,443
+ *   hs_compile_lit / hs_compile_lit_multi    src/hs_compile.h:608,690
+ *   hs_free_compile_error                    src/hs_compile.h:710
+ *   hs_alloc_scratch / hs_clone_scratch /
+ *   hs_scratch_size / hs_free_scratch        src/hs_runtime.h:555-609
+ *   hs_scan                                  src/hs_runtime.h:479-482
+ *   match_event_handler                      src/hs_runtime.h:125-129
+ *   hs_free_database / hs_database_size /
+ *   hs_database_info / hs_serialize_database /
+ *   hs_deserialize_database                  src/hs_common.h:84-271
+ *   hs_version / hs_valid_platform           src/hs_common.h:450,467
+ *
+ * What is behind it: every pattern must start with a literal (>= 1 byte). The literal
+ * prefixes (their last <= 8 bytes, as Rose truncates them: rose_build_matchers.cpp:717-724)
+ * are matched on the GPU through hsgpu_hwlm_exec; the host then checks the full literal
+ * (the job of CHECK_MED_LIT / CHECK_LONG_LIT, src/rose/program_runtime.c:2896-2942) and,
+ * for patterns with a tail, runs a bit-parallel NFA over the bytes that follow
+ * (the job of the NFA engines Rose would trigger). Supported tail syntax: literal
+ * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes, and the quantifiers
+ * ? * + {m} {m,} {m,n}. Anything else (alternation, groups, anchors, leading
+ * non-literals, streaming / vectored modes) is rejected with HS_COMPILER_ERROR:
+ * the regex compiler proper is out of scope.
+ */
+#ifndef HS_GPU_H
+#define HS_GPU_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int hs_error_t;
+struct hs_database;
+typedef struct hs_database hs_database_t;
+struct hs_scratch;
+typedef struct hs_scratch hs_scratch_t;
+
+#define HS_SUCCESS 0
+#define HS_INVALID (-1)
+#define HS_NOMEM (-2)
+#define HS_SCAN_TERMINATED (-3)
+#define HS_COMPILER_ERROR (-4)
+#define HS_DB_VERSION_ERROR (-5)
+#define HS_DB_PLATFORM_ERROR (-6)
+#define HS_DB_MODE_ERROR (-7)
+#define HS_BAD_ALIGN (-8)
+#define HS_BAD_ALLOC (-9)
+#define HS_SCRATCH_IN_USE (-10)
+#define HS_ARCH_ERROR (-11)
+#define HS_INSUFFICIENT_SPACE (-12)
+#define HS_UNKNOWN_ERROR (-13)
+
+#define HS_FLAG_CASELESS 1
+#define HS_FLAG_DOTALL 2
+#define HS_FLAG_MULTILINE 4
+#define HS_FLAG_SINGLEMATCH 8
+#define HS_FLAG_ALLOWEMPTY 16
+#define HS_FLAG_UTF8 32
+#define HS_FLAG_UCP 64
+#define HS_FLAG_PREFILTER 128
+#define HS_FLAG_SOM_LEFTMOST 256
+#define HS_FLAG_COMBINATION 512
+#define HS_FLAG_QUIET 1024
+
+#define HS_MODE_BLOCK 1
+#define HS_MODE_NOSTREAM 1
+#define HS_MODE_STREAM 2
+#define HS_MODE_VECTORED 4
+
+typedef struct hs_compile_error {
+    char *message;
+    int expression;
+} hs_compile_error_t;
+
+typedef struct hs_platform_info {
+    unsigned int tune;
+    unsigned long long cpu_features;
+    unsigned long long reserved1;
+    unsigned long long reserved2;
+} hs_platform_info_t;
+
+typedef int (*match_event_handler)(unsigned int id, unsigned long long from, unsigned long long to,
+                                   unsigned int flags, void *context);
+
+hs_error_t hs_compile(const char *expression, unsigned int flags, unsigned int mode,
+                      const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error);
+hs_error_t hs_compile_multi(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
+                            unsigned int elements, unsigned int mode, const hs_platform_info_t *platform,
+                            hs_database_t **db, hs_compile_error_t **error);
+hs_error_t hs_compile_lit(const char *expression, unsigned flags, const size_t len, unsigned mode,
+                          const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error);
+hs_error_t hs_compile_lit_multi(const char *const *expressions, const unsigned *flags, const unsigned *ids,
+                                const size_t *lens, unsigned elements, unsigned mode,
+                                const hs_platform_info_t *platform, hs_database_t **db,
+                                hs_compile_error_t **error);
+hs_error_t hs_free_compile_error(hs_compile_error_t *error);
+
+hs_error_t hs_free_database(hs_database_t *db);
+hs_error_t hs_database_size(const hs_database_t *database, size_t *database_size);
+hs_error_t hs_database_info(const hs_database_t *database, char **info);
+hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length);
+hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_database_t **db);
+
+hs_error_t hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch);
+hs_error_t hs_clone_scratch(const hs_scratch_t *src, hs_scratch_t **dest);
+hs_error_t hs_scratch_size(const hs_scratch_t *scratch, size_t *scratch_size);
+hs_error_t hs_free_scratch(hs_scratch_t *scratch);
+
+hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsigned int flags,
+                   hs_scratch_t *scratch, match_event_handler onEvent, void *context);
+
+/* Extension (no reference equivalent): scan nblocks independent blocks
+ * data[off[i] .. off[i+1]) in one GPU batch; events carry the block index. A non-zero
+ * return from the handler stops matching in THAT block only. */
+typedef int (*hs_batch_event_handler)(unsigned long long block, unsigned int id, unsigned long long from,
+                                      unsigned long long to, unsigned int flags, void *context);
+hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
+                         unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
+                         hs_batch_event_handler onEvent, void *context);
+
+const char *hs_version(void);
+hs_error_t hs_valid_platform(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,183 @@
+"""The public hs_* surface (include/hs_gpu.h) on the GPU engine, in the manner of the
+reference's API-level tests: unit/hyperscan/literals.cpp (seeded random literal sets,
+every planted corpus must match), single.cpp / multi.cpp, order.cpp (offsets
+non-decreasing), arg_checks.cpp (error codes), serialize.cpp; plus the Rose-lite
+confirm (literal prefix + regex tail) against a brute-force oracle built on Python's re."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from hyperscan_amd import hs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def collect(db, data, scratch):
+    out = []
+    rv = hs.scan(db, data, scratch, lambda i, f, t: out.append((i, f, t)) and False)
+    assert rv == hs.HS_SUCCESS
+    return out
+
+
+def brute_literal(data, lits, flags, ids):
+    want = set()
+    for s, fl, i in zip(lits, flags, ids):
+        hay, needle = (data.upper(), s.upper()) if fl & hs.HS_FLAG_CASELESS else (data, s)
+        k = hay.find(needle)
+        first = True
+        while k >= 0:
+            if not (fl & hs.HS_FLAG_SINGLEMATCH) or first:
+                want.add((i, k if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, k + len(s)))
+            first = False
+            k = hay.find(needle, k + 1)
+    return sorted(want, key=lambda e: (e[2], e[0]))
+
+
+@pytest.mark.parametrize("count,lo,hi", [(1, 3, 10), (10, 3, 10), (100, 3, 10), (500, 10, 100), (2000, 3, 10)])
+def test_random_literal_sets(count, lo, hi):
+    # unit/hyperscan/literals.cpp:160-245 (rng.seed(29785643), sets of {1,10,100,500,10000} x len ranges)
+    rng = np.random.default_rng(29785643 + count)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    lits = list({bytes(rng.choice(alpha, int(rng.integers(lo, hi + 1)))) for _ in range(count)})
+    flags = [int(rng.choice([0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_SINGLEMATCH, hs.HS_FLAG_SOM_LEFTMOST])) for _ in lits]
+    ids = list(range(len(lits)))
+    db = hs.Database.compile_lit(lits, flags, ids)
+    scratch = hs.HsScratch(db)
+    data = bytearray(rng.choice(alpha, 20000).tobytes())
+    for s in lits[:: max(1, len(lits) // 60)]:
+        p = int(rng.integers(0, len(data) - len(s)))
+        data[p:p + len(s)] = s
+    data = bytes(data)
+    got = collect(db, data, scratch)
+    want = brute_literal(data, lits, flags, ids)
+    assert sorted(got, key=lambda e: (e[2], e[0])) == want
+    tos = [t for _i, _f, t in got]
+    assert tos == sorted(tos)  # unit/hyperscan/order.cpp:43-53
+    assert len(got) >= min(20, len(lits))  # planted literals may overwrite each other
+
+
+def test_single_pattern_and_termination():
+    db = hs.Database.compile(["hyperscan"], [hs.HS_FLAG_DOTALL])
+    scratch = hs.HsScratch(db)
+    data = b"xx hyperscan yy hyperscan zz"
+    assert collect(db, data, scratch) == [(0, 0, 12), (0, 0, 25)]
+    seen = []
+    rv = hs.scan(db, data, scratch, lambda i, f, t: seen.append(t) or True)
+    assert rv == hs.HS_SCAN_TERMINATED and seen == [12]
+    # block shorter than the pattern: nothing to do (src/runtime.c:346)
+    assert collect(db, b"hyper", scratch) == []
+
+
+def test_arg_checks():
+    # unit/hyperscan/arg_checks.cpp
+    with pytest.raises(hs.HsError) as e:
+        hs.Database.compile(["foo"], mode=hs.HS_MODE_STREAM)
+    assert e.value.code == hs.HS_COMPILER_ERROR
+    with pytest.raises(hs.HsError) as e:
+        hs.Database.compile(["(a|b)c"])
+    assert e.value.code == hs.HS_COMPILER_ERROR and e.value.expression == 0
+    with pytest.raises(hs.HsError) as e:
+        hs.Database.compile(["good", "[a-z]+tail"])
+    assert e.value.expression == 1
+    with pytest.raises(hs.HsError) as e:
+        hs.Database.compile_lit([b""])
+    assert "empty" in e.value.message
+    with pytest.raises(hs.HsError):
+        hs.Database.compile_lit([b"abc"], [hs.HS_FLAG_DOTALL])  # compiler.cpp:405-419
+    db = hs.Database.compile_lit([b"abc"])
+    scratch = hs.HsScratch(db)
+    lib = hs._lib()
+    cb = hs.MATCH_CB(lambda *a: 0)
+    assert lib.hs_scan(db._h, None, 3, 0, scratch._h, cb, None) == hs.HS_INVALID
+    assert lib.hs_scan(db._h, b"abc", 3, 0, None, cb, None) == hs.HS_INVALID
+    assert lib.hs_scan(None, b"abc", 3, 0, scratch._h, cb, None) == hs.HS_INVALID
+    assert b"hsgpu" in lib.hs_version()
+
+
+def test_serialize_roundtrip():
+    db = hs.Database.compile(["needle\\d+", "hay"], [0, hs.HS_FLAG_CASELESS], [7, 9])
+    blob = db.serialize()
+    db2 = hs.Database.deserialize(blob)
+    s1, s2 = hs.HsScratch(db), hs.HsScratch(db2)
+    data = b"HAY needle123 hay needle9"
+    assert collect(db, data, s1) == collect(db2, data, s2)
+    assert db.size() > 0
+    with pytest.raises(hs.HsError):
+        hs.Database.deserialize(b"garbage!")
+
+
+def brute_tail(data, lit, tail, flags, pid):
+    """All (id, 0, to): `to` such that data[k:to] fullmatches lit + tail for an occurrence k of lit."""
+    rf = (re.I if flags & hs.HS_FLAG_CASELESS else 0) | (re.S if flags & hs.HS_FLAG_DOTALL else 0)
+    tre = re.compile(tail.encode("latin-1"), rf)
+    hay, needle = (data.upper(), lit.upper()) if flags & hs.HS_FLAG_CASELESS else (data, lit)
+    out = set()
+    k = hay.find(needle)
+    while k >= 0:
+        s = k + len(lit)
+        for to in range(s, len(data) + 1):
+            if tre.fullmatch(data, s, to):
+                out.add((pid, 0, to))
+        k = hay.find(needle, k + 1)
+    return out
+
+
+TAILS = [r"[a-z]+\d", r"\s+\w{2,8}=", r".{0,16}END", r"x?y*z", r"[^\n]{3}", r"\d{2,}", r"[A-F0-9]{4}:", r"\.\w+"]
+
+
+def test_literal_prefix_plus_tail_patterns():
+    # config 5 shape: LIT_k<tail>, GPU literal hits feeding the host confirm
+    rng = np.random.default_rng(77)
+    lits = [b"GET /", b"user=", b"Content-Length", b"abcdefghijkl", b"Zq"]
+    pats, flags, ids, parts = [], [], [], []
+    for n, tail in enumerate(TAILS):
+        lit = lits[n % len(lits)]
+        fl = [0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL][n % 3]
+        pats.append(re.escape(lit.decode()).replace("\\ ", " ").replace("\\-", "-").replace("\\=", "=") + tail)
+        flags.append(fl)
+        ids.append(100 + n)
+        parts.append((lit, tail, fl, 100 + n))
+    db = hs.Database.compile(pats, flags, ids)
+    scratch = hs.HsScratch(db)
+    words = [b"GET /", b"get /", b"user=", b"USER=", b"Content-Length", b"abcdefghijkl", b"Zq", b"abc12", b"  key=",
+             b" END", b"xyyz", b"z", b"\n", b"0042", b"BEEF:", b".html", b"   ", b"q9", b"END"]
+    data = b"".join(words[int(i)] for i in rng.integers(0, len(words), 900))
+    want = set()
+    for lit, tail, fl, pid in parts:
+        want |= brute_tail(data, lit, tail, fl, pid)
+    got = collect(db, data, scratch)
+    assert set(got) == want and len(got) == len(want) and len(want) > 50
+    # batched form agrees with per-block hs_scan
+    off = np.array([0, 500, 500, 1800, len(data)], dtype=np.uint64)
+    ev = []
+    assert hs.scan_batch(db, data, off, scratch, lambda b, i, f, t: ev.append((b, i, f, t)) and False) == 0
+    for b in range(4):
+        blk = data[int(off[b]):int(off[b + 1])]
+        assert sorted(e[1:] for e in ev if e[0] == b) == sorted(collect(db, blk, scratch))
+
+
+def test_simplegrep_example(tmp_path):
+    """Config 1 plumbing: the simplegrep use case (examples/simplegrep.c of the reference)
+    through the public API, on a 64 MiB printable-ASCII buffer with 64 planted literals."""
+    exe = tmp_path / "simplegrep"
+    lib_dir = os.path.join(ROOT, "hyperscan_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-o", str(exe), os.path.join(ROOT, "examples", "simplegrep.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lhsgpu",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(1)
+    data = rng.integers(0x20, 0x7F, 64 << 20, dtype=np.uint8)
+    lit = np.frombuffer(b"hyperscan", dtype=np.uint8)
+    pos = np.sort(rng.choice((64 << 20) - 64, 64, replace=False))
+    for p in pos:
+        data[p:p + lit.size] = lit
+    f = tmp_path / "corpus.bin"
+    data.tofile(f)
+    out = subprocess.run([str(exe), "hyperscan", str(f)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    offs = [int(l.rsplit(" ", 1)[1]) for l in out.stdout.splitlines() if l.startswith("Match for pattern")]
+    want = sorted(set((pos + lit.size).tolist()) | {m.end() for m in re.finditer(b"hyperscan", data.tobytes())})
+    assert offs == want

@@ -34,6 +34,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/hsgpu.h but not exported"
     assert set(_native.exported_symbols()) <= declared | {"hsgpu_last_error", "hsgpu_version"}
     assert b"gfx950" in lib.hsgpu_version()
+    # the public hs_* facade (include/hs_gpu.h)
+    hdr2 = open(os.path.join(ROOT, "include", "hs_gpu.h")).read()
+    declared2 = set(re.findall(r"\b(hs_[a-z_]+)\s*\(", hdr2)) - {"hs_batch_event_handler"}
+    assert {"hs_compile", "hs_compile_lit_multi", "hs_scan", "hs_alloc_scratch", "hs_free_database"} <= declared2
+    for name in sorted(declared2):
+        assert hasattr(lib, name), f"{name} declared in include/hs_gpu.h but not exported"
+
+
+def test_hs_compile_errors_without_gpu():
+    """Compile-side argument and syntax checks of the hs_* facade need no GPU."""
+    from hyperscan_amd import hs
+
+    with pytest.raises(hs.HsError) as e:
+        hs.Database.compile(["foo"], mode=hs.HS_MODE_STREAM)
+    assert e.value.code == hs.HS_COMPILER_ERROR
+    with pytest.raises(hs.HsError) as e:
+        hs.Database.compile(["ok", "a(b|c)"])
+    assert e.value.expression == 1
+    with pytest.raises(hs.HsError):
+        hs.Database.compile(["\\d+abc"])  # no literal prefix
+    db = hs.Database.compile(["needle[a-z]{2,5}\\d", "x\\.y"], [hs.HS_FLAG_CASELESS, 0], [3, 4])
+    assert hs.Database.deserialize(db.serialize()).size() == db.size()
 
 
 def test_no_cpu_fallback_without_gpu():
