@@ -199,7 +199,9 @@ def test_table_covers_every_literal(flags):
 def test_table_modes_auto():
     rng = np.random.default_rng(3)
     small = H.hwlm_build(random_literals(rng, 64, 4, 8, nocase_frac=0)).info()
-    assert small["flags"] & F_REPL and small["flags"] & F_S2 and not small["flags"] & F_BLIND
+    assert small["flags"] & F_S2 and not small["flags"] & F_REPL and not small["flags"] & F_BLIND
+    short = H.hwlm_build(random_literals(rng, 64, 1, 3, nocase_frac=0)).info()
+    assert short["flags"] & F_REPL and not short["flags"] & F_S2  # stride 1: bank-replicated filter
     big = H.hwlm_build(random_literals(rng, 5000, 3, 8, nocase_frac=0.3)).info()
     assert not big["flags"] & F_REPL and not big["flags"] & F_S2 and big["flags"] & F_BLIND
     # case-blind keys: a caseless literal costs one filter entry, not one per case variant
