@@ -99,7 +99,8 @@ class CharClass:
         return [v for v in range(256) if self.bitmap[v >> 3] >> (v & 7) & 1]
 
 
-def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True, want_last=False, stream=None):
+def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True, want_last=False, stream=None,
+               buffers=None):
     """Evaluate <= 8 classes over a device-resident block batch (torch tensors).
     -> (bitmaps uint8 [n][ceil(total/16)*2], first int64-view uint32 [n][nblocks] | None, last | None)"""
     import torch
@@ -110,16 +111,21 @@ def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True,
     dev = d_corpus.device
     arr = (_Class * n)(*[c._to_c() for c in classes])
     words = (total + 15) // 16
-    bitmaps = torch.zeros((n, max(1, words) * 2), dtype=torch.uint8, device=dev)
+    if buffers is not None:  # reuse (bitmaps, first, last, work) from an earlier call: no allocation, no sync
+        bitmaps, first, last, work = buffers
+    else:
+        bitmaps = torch.empty((n, max(1, words) * 2), dtype=torch.uint8, device=dev)
+        work = torch.zeros(WORK_BYTES, dtype=torch.uint8, device=dev)
+        first = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_first and nblocks) else None
+        last = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_last and nblocks) else None
     ptrs = (C.c_void_p * n)(*[bitmaps[i].data_ptr() for i in range(n)])
-    work = torch.zeros(WORK_BYTES, dtype=torch.uint8, device=dev)
-    first = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_first and nblocks) else None
-    last = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_last and nblocks) else None
     st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
     rv = lib.hsgpu_class_scan_dev(arr, n, d_corpus.data_ptr(), total, d_off.data_ptr() if d_off is not None else None,
                                   nblocks, ptrs, first.data_ptr() if first is not None else None,
                                   last.data_ptr() if last is not None else None, work.data_ptr(), st)
     if rv != 0:
         raise HsgpuError(rv, "hsgpu_class_scan_dev")
-    torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
-    return bitmaps, first, last
+    if buffers is None:
+        torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
+        return bitmaps, first, last
+    return bitmaps, first, last, work
