@@ -69,6 +69,8 @@ struct hsgpu_scratch {
     hipEvent_t ev_ring[kRing][4] = {};
     hipEvent_t *ev_t = nullptr; /* the set of the scan being launched */
     uint64_t n_timed = 0;       /* scans launched with timing on */
+    DevBuf tstamp;              /* [kRing][2] device wall-clock min(start) / max(end) of the filter kernel */
+    double wall_clock_khz = 100000.0;
     DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets, stats;
     bool ctl_clean = false;                /* every control word is zero (left so by control_reset_kernel) */
     unsigned long long stats_seen[2] = {0, 0};
@@ -163,6 +165,7 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->cand.release();
     s->ctl.release();
     s->stats.release();
+    s->tstamp.release();
     s->rec_stage.release();
     s->rec_offsets.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
@@ -183,8 +186,32 @@ extern "C" int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable) {
         for (int r = 0; r < hsgpu_scratch::kRing; r++)
             for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&s->ev_ring[r][i]));
     }
+    if (enable) {
+        int rv = s->tstamp.ensure(hsgpu_scratch::kRing * 2 * sizeof(unsigned long long));
+        if (rv != HSGPU_SUCCESS) return rv;
+        std::vector<unsigned long long> init(hsgpu_scratch::kRing * 2);
+        for (int r = 0; r < hsgpu_scratch::kRing; r++) init[2 * r] = ~0ull, init[2 * r + 1] = 0;
+        HIP_TRY(hipMemcpy(s->tstamp.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device) == hipSuccess && khz > 0)
+            s->wall_clock_khz = khz;
+    }
     s->timing = enable != 0;
     s->n_timed = 0;
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_scratch_get_kernel_span(hsgpu_scratch_t *s, unsigned back, float *filter_ms) {
+    /* the filter kernel's own execution span (first workgroup start to last workgroup
+     * end) from the device wall clock -- what a kernel trace reports as its duration */
+    if (!s || !filter_ms || back >= hsgpu_scratch::kRing || back >= s->n_timed) return HSGPU_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_ring[(s->n_timed - 1 - back) % hsgpu_scratch::kRing][3]));
+    unsigned long long t[2] = {0, 0};
+    const size_t slot = (s->n_timed - 1 - back) % hsgpu_scratch::kRing;
+    HIP_TRY(hipMemcpy(t, (const unsigned long long *)s->tstamp.p + 2 * slot, sizeof(t), hipMemcpyDeviceToHost));
+    if (t[1] < t[0]) return HSGPU_INVALID;
+    *filter_ms = (float)((double)(t[1] - t[0]) / s->wall_clock_khz);
     return HSGPU_SUCCESS;
 }
 
@@ -282,22 +309,20 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
     args.hint = (const uint32_t *)s->hint.p;
     const bool two_phase = scan_mode() == 0;
-    {
-        /* two-phase: the hints are only needed by the confirm kernel, so they are
-         * computed on a side stream while the filter kernel streams the corpus */
+    /* Block hints are only needed by the confirm kernel. Two-phase: they are computed on a
+     * side stream, launched AFTER the filter kernel so that the filter's workgroups take
+     * their CUs first and the hint kernel fills the idle wavefront slots beside them.
+     * Fused: the filter itself needs them, so they run first on the same stream. */
+    auto launch_hints = [&](hipStream_t hs) -> int {
         const uint64_t *off = a.off;
         uint64_t nblocks = a.nblocks, total = a.total, n_hint = args.n_hint;
         uint32_t *hint = (uint32_t *)s->hint.p;
         void *hargs[] = {&off, &nblocks, &total, &hint, &n_hint};
-        hipStream_t hs = stream;
-        if (two_phase) {
-            HIP_TRY(hipEventRecord(s->ev_fork, stream));
-            HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-            hs = s->side;
-        }
         HIP_TRY(hipLaunchKernel(hsgpu_hint_kernel(), dim3((unsigned)((n_hint + 255) / 256)), dim3(256), hargs, 0, hs));
-        if (two_phase) HIP_TRY(hipEventRecord(s->ev_join, s->side));
-    }
+        return HSGPU_SUCCESS;
+    };
+    if (two_phase) HIP_TRY(hipEventRecord(s->ev_fork, stream)); /* everything the hints read is ready here */
+    else if ((rv = launch_hints(stream)) != HSGPU_SUCCESS) return rv;
     /* staged match records: one region per producing wavefront, packed into the
      * caller's buffer by the last two kernels. 2x headroom over an even split. */
     const uint32_t n_waves = grid * (wg_threads / 64);
@@ -321,8 +346,13 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     s->ctl_clean = false; /* until this scan's control_reset_kernel has been queued */
 
     void *kargs[] = {&args};
+    args.tstamp = nullptr;
+    args.tstamp_next = nullptr;
     if (s->timing) {
-        s->ev_t = s->ev_ring[s->n_timed % hsgpu_scratch::kRing];
+        const size_t slot = s->n_timed % hsgpu_scratch::kRing;
+        s->ev_t = s->ev_ring[slot];
+        args.tstamp = (unsigned long long *)s->tstamp.p + 2 * slot;
+        args.tstamp_next = (unsigned long long *)s->tstamp.p + 2 * ((slot + 1) % hsgpu_scratch::kRing);
         HIP_TRY(hipEventRecord(s->ev_t[0], stream));
     }
     if (!two_phase) {
@@ -350,6 +380,9 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
+        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        if ((rv = launch_hints(s->side)) != HSGPU_SUCCESS) return rv;
+        HIP_TRY(hipEventRecord(s->ev_join, s->side));
         HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));

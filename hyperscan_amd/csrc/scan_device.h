@@ -535,6 +535,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     /* the fused kernel doubles as the overflow fallback: nothing to do unless the
      * two-phase pipeline ran out of candidate space */
     if (FUSED && args.cand_counts && !args.cand_counts[args.cand_waves]) return;
+    if (!FUSED && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
 
     const uint32_t flog2 = args.t_filter_log2;
     const uint32_t nw = REPL ? (32u << flog2) : (1u << flog2);
@@ -670,6 +671,10 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         args.cand_counts[wave_global] = sp.written;
         if (sp.overflow) args.cand_counts[n_waves] = 1;
     }
+    if (!FUSED && args.tstamp) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&args.tstamp[1], (unsigned long long)wall_clock64());
+    }
 }
 
 /* ---- phase 2: confirm. HSGPU_CONFIRM_SPLIT wavefronts share one filter
@@ -795,6 +800,10 @@ __global__ __launch_bounds__(256) void record_pack_kernel(HsgpuScanArgs args) {
 __global__ __launch_bounds__(256) void control_reset_kernel(HsgpuScanArgs args) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < 2 * args.rec_regions) args.rec_counts[i] = 0;
+    if (i == 0 && args.tstamp_next) {
+        args.tstamp_next[0] = ~0ull;
+        args.tstamp_next[1] = 0;
+    }
 
     /* cumulative statistics for hsgpu_scratch_get_stats: one atomic per wavefront */
     uint32_t v = 0, o = 0;

@@ -41,6 +41,8 @@ struct HsgpuScanArgs {
     uint32_t *rec_counts;       /* [rec_regions][2]: records at the front / at the back of each region */
     unsigned long long *rec_offsets; /* [rec_regions]: exclusive scan of the region fills */
     unsigned long long *stats;  /* [2] cumulative: candidate entries spilled, overflowed scans */
+    unsigned long long *tstamp; /* timing only: [2] min start / max end of the filter kernel (device wall clock) */
+    unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by control_reset_kernel */
 };
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);

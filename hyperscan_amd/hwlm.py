@@ -157,6 +157,14 @@ class Scratch:
             raise HsgpuError(rv, "hsgpu_scratch_get_timing")
         return f.value, c.value, t.value
 
+    def kernel_span(self, back=0):
+        """Filter-kernel execution span in ms from the device wall clock (no dispatch gaps)."""
+        f = C.c_float()
+        rv = self._lib.hsgpu_scratch_get_kernel_span(self._h, back, C.byref(f))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_get_kernel_span")
+        return f.value
+
     def stats(self):
         """(candidate entries spilled, scans that overflowed) since the previous call -- synchronises."""
         n, o = C.c_uint64(), C.c_int()

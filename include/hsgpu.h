@@ -157,6 +157,9 @@ int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d
 int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable);
 int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float *filter_ms, float *confirm_ms,
                              float *total_ms);
+/* The filter kernel's own execution span (first workgroup start .. last workgroup end, device
+ * wall clock), i.e. what a kernel trace reports; HIP events additionally contain dispatch gaps. */
+int hsgpu_scratch_get_kernel_span(hsgpu_scratch_t *s, unsigned back, float *filter_ms);
 
 /* Tuning / test aid (synchronises the device): 32-byte candidate entries spilled by the
  * filter kernel since the previous call, and how many scans since then overflowed a

@@ -28,17 +28,17 @@ def main():
         job.launch()
     torch.cuda.synchronize()
     n = job.count()
-    fm, cm, tm = [], [], []
+    fm, cm, tm, sm = [], [], [], []
     for i in range(a.iters):
         job.launch()
     torch.cuda.synchronize()
     for back in range(min(a.iters, 32)):
         f, c, t = job.scratch.timing(back)
-        fm.append(f); cm.append(c); tm.append(t)
+        fm.append(f); cm.append(c); tm.append(t); sm.append(job.scratch.kernel_span(back))
     ms = np.array(tm)
     gb = (job.total + 16 * n) / 1e9
     print(f"{a.workload}: kernel avg {ms.mean():.4f} ms best {ms.min():.4f} ms -> {gb / ms.mean() * 1e3:.1f} GB/s avg, "
-          f"{gb / ms.min() * 1e3:.1f} best; filter {np.mean(fm):.4f} ms confirm {np.mean(cm):.4f} ms; matches {n}; "
+          f"{gb / ms.min() * 1e3:.1f} best; filter {np.mean(fm):.4f} ms (device clock {np.mean(sm):.4f}) confirm {np.mean(cm):.4f} ms; matches {n}; "
           f"candidates {job.scratch.stats()}; table {job.table.info()}")
 
 
