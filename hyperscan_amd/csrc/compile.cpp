@@ -244,7 +244,7 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     } else {
         /* the full 128 KiB that one 16-wavefront workgroup per CU can hold: a smaller
          * table with three 8-wavefront workgroups per CU measured slower */
-        k = (flags & HSGPU_BUILD_FORCE_SMALL) ? 13 : 15;
+        k = (flags & HSGPU_BUILD_FORCE_SMALL) ? 13 : (flags & HSGPU_BUILD_FORCE_MEDIUM) ? 14 : 15;
         if ((uint64_t)entries * 128 > ((uint64_t)32 << k)) tflags |= HSGPU_F_K2;
     }
     if (flags & HSGPU_BUILD_FORCE_K2) tflags |= HSGPU_F_K2;
@@ -318,7 +318,7 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
                 set_bit(a1, hsgpu_filter_bit_a(key & 0xff, a1));
                 if (tflags & HSGPU_F_K2) set_bit(a1, hsgpu_filter_bit_a2(key & 0xff, prod1));
             } else {
-                set_bit(a1, hsgpu_filter_bit_b(prod1));
+                set_bit(a1, hsgpu_filter_bit_b(a1));
                 if (tflags & HSGPU_F_K2) set_bit(a1, hsgpu_filter_bit_b2(prod1));
             }
             uint32_t bmask = ((uint32_t)1 << ht_log2[c]) - 1;

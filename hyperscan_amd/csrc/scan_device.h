@@ -433,7 +433,7 @@ __device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg
         if (HAS_B || HAS_C) {
             uint32_t hit = 0;
             if (HAS_B) {
-                hit = bfe1(word, prod >> 8);
+                hit = bfe1(word, a); /* bit a & 31: no extra shift */
                 if (K2) hit &= bfe1(word, prod >> 13);
             }
             if (HAS_C) {
@@ -587,28 +587,40 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     const uint32_t G = gridDim.x;
     const uint32_t lane_off = wave * WAVE_TILE + lane * CHUNK;
 
-    /* unconditional loads of a (clamped) full tile: no branches, so the compiler
-     * keeps them in flight across iterations with counted s_waitcnt */
+    /* Loads of one tile through a buffer descriptor built from wave-uniform values only
+     * (scalar registers): the lane offset is a 32-bit voffset, so a stage costs no vector
+     * address arithmetic at all, nothing branches, and the compiler keeps the loads in
+     * flight across iterations with counted s_waitcnt. The descriptor starts 8 bytes in
+     * front of the tile (halo at voffset, chunk at voffset + 8 via soffset); a tile past
+     * the last full one gets an empty descriptor: its loads return zeros and touch no
+     * memory, which replaces every bounds check. */
     auto issue = [&](uint64_t tile) -> Chunk {
-        const uint64_t tl = tile < n_full ? tile : n_full - 1;
-        const uint64_t off = (tl << super_shift) + lane_off;
+        const uint8_t *base = corpus + (tile << super_shift) - 8;
+        const int records = tile < n_full ? (int)0x7ffffff0 : 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, records, 0x00020000);
         Chunk c;
-        c.d = *(const uint4 *)(corpus + off);
-        c.h = *(const uint2 *)(corpus + (off ? off - 8 : 0));
+        const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 8, 0);
+        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, 0, 0);
+        c.d = make_uint4(d[0], d[1], d[2], d[3]);
+        c.h = make_uint2(h[0], h[1]);
+        return c;
+    };
+    /* tile 0 has nothing in front of it: descriptor at the corpus itself, and the
+     * first lane's halo offset wraps out of range, which reads as the zeros it needs */
+    auto issue_first = [&](uint64_t tile) -> Chunk {
+        if (tile) return issue(tile);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)corpus, 0, (int)0x7ffffff0, 0x00020000);
+        Chunk c;
+        const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 0, 0);
+        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off - 8u, 0, 0);
+        c.d = make_uint4(d[0], d[1], d[2], d[3]);
+        c.h = make_uint2(h[0], h[1]);
         return c;
     };
 
 #define HSGPU_HANDLE(CUR, COFF)                                                                   \
     {                                                                                             \
-        if ((COFF) == 0) CUR.h = make_uint2(0, 0); /* nothing in front of the corpus */           \
-        uint32_t acc;                                                                             \
-        if (args.debug & 2) {                                                                     \
-            acc = 0;                                                                              \
-            asm volatile("" ::"v"(CUR.d.x), "v"(CUR.d.y), "v"(CUR.d.z), "v"(CUR.d.w), "v"(CUR.h.x), "v"(CUR.h.y)); \
-        } else {                                                                                  \
-            acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f);                 \
-        }                                                                                         \
-        if (args.debug & 1) acc = 0;                                                              \
+        const uint32_t acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f);      \
         if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2>(t, qcount, lane, (COFF), acc);          \
         else spill(args, sp, (COFF), acc, CUR);                                                   \
     }
@@ -618,7 +630,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         /* four register stages rotate by name (loop unrolled x4): three tiles are in
          * flight while one is filtered, a stage is never copied, and the only wait is
          * for the stage about to be filtered */
-        Chunk c0 = issue(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3;
+        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3;
 #define HSGPU_STAGE(CUR, NEW)                                   \
     {                                                           \
         NEW = issue(tile + 3ull * G);                           \

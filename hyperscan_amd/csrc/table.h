@@ -103,7 +103,7 @@ static_assert(sizeof(HsgpuDevLit) == 32, "DevLit is 32 bytes");
  * bits tested in that word:
  *   bitA  = (a + b3) & 31              4-byte key, first bit   (v_add_u32_sdwa + v_bfe)
  *   bitA2 = ((prod >> 11) + b3) & 31   4-byte key, second bit  (only with HSGPU_F_K2)
- *   bitB  = (prod >> 8) & 31           3-byte key, first bit
+ *   bitB  = a & 31                     3-byte key, first bit
  *   bitB2 = (prod >> 13) & 31          3-byte key, second bit  (only with HSGPU_F_K2)
  */
 HSGPU_HD uint32_t hsgpu_filter_prod(uint32_t x24) { return (x24 & 0xffffffu) * HSGPU_FILTER_MUL; }
@@ -112,7 +112,7 @@ HSGPU_HD uint32_t hsgpu_filter_shift(uint32_t flags, uint32_t log2) {
 }
 HSGPU_HD uint32_t hsgpu_filter_bit_a(uint32_t b3, uint32_t a) { return (b3 + a) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { return (b3 + (prod >> 11)) & 31u; }
-HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t prod) { return (prod >> 8) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t a) { return a & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b2(uint32_t prod) { return (prod >> 13) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_words(uint32_t flags, uint32_t log2) {
     return (flags & HSGPU_F_REPL) ? (32u << log2) : (1u << log2);

@@ -106,6 +106,7 @@ typedef struct hsgpu_hwlm_info {
 #define HSGPU_BUILD_FORCE_STRIDE1 16u /* look up every byte position (no stride-2 keys) */
 #define HSGPU_BUILD_FORCE_STRIDE2 64u /* stride 2 even with 2- and 3-byte literals */
 #define HSGPU_BUILD_FORCE_SMALL 128u /* 32 KiB hashed filter, run as three 8-wavefront workgroups per CU */
+#define HSGPU_BUILD_FORCE_MEDIUM 256u /* 64 KiB hashed filter: two 16-wavefront workgroups per CU where registers allow */
 #define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
 
 /* ---- build side ---------------------------------------------------------- */

@@ -133,7 +133,7 @@ def filter_word_and_bits(h, x24, b3):
         a = prod >> (30 - k)
         words = [int(h["filter"][a >> 2])]
     bit_a = [(a + b3) & 31] + ([((prod >> 11) + b3) & 31] if fl & F_K2 else [])
-    bit_b = [(prod >> 8) & 31] + ([(prod >> 13) & 31] if fl & F_K2 else [])
+    bit_b = [a & 31] + ([(prod >> 13) & 31] if fl & F_K2 else [])
     return words, bit_a, bit_b
 
 
