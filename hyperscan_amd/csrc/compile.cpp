@@ -253,13 +253,14 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     const uint32_t fshift = hsgpu_filter_shift(tflags, k);
     uint32_t ht_log2[2];
     for (int c = 0; c < 2; c++)
-        ht_log2[c] = std::max<uint32_t>(2, ceil_log2((uint64_t)keys[c].size() / 2 + 1)); /* <= 2 of 4 slots used */
+        ht_log2[c] = std::min<uint32_t>(24, std::max<uint32_t>(2, ceil_log2((uint64_t)keys[c].size() * 2 + 1))); /* <= 0.5 keys per 4-slot bucket: a full bucket (probe continues) is a < 0.2% event */
 
     /* lists */
     std::vector<uint32_t> lists;
     auto add_list = [&](const std::vector<uint32_t> &v) -> uint32_t {
-        if (v.size() == 1) return v[0] | HSGPU_REF_DIRECT;
+        if (v.size() == 1) return v[0] | HSGPU_REF_DIRECT; /* literal | delta << 30 */
         uint32_t ref = (uint32_t)lists.size() + 1;
+        if (ref + v.size() > HSGPU_LIST_LIT_MASK) throw std::bad_alloc();
         for (size_t j = 0; j < v.size(); j++) lists.push_back(v[j] | (j + 1 == v.size() ? HSGPU_LIST_END : 0));
         return ref;
     };
@@ -293,7 +294,7 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
 
     std::vector<uint32_t> filter(fwords, 0), c2bits(2048, 0);
     std::vector<HsgpuHtSlot> ht[2];
-    for (int c = 0; c < 2; c++) ht[c].assign((size_t)HSGPU_BUCKET_SLOTS << ht_log2[c], HsgpuHtSlot{0, 0});
+    for (int c = 0; c < 2; c++) ht[c].assign((size_t)HSGPU_BUCKET_SLOTS << ht_log2[c], 0u);
     std::vector<uint32_t> c2ref((tflags & HSGPU_F_HAS_C) ? 65536 : 4, 0);
 
     auto set_bit = [&](uint32_t a, uint32_t bit) {
@@ -326,10 +327,9 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
             for (;;) {
                 HsgpuHtSlot *sl = &ht[c][(size_t)bkt * HSGPU_BUCKET_SLOTS];
                 uint32_t j = 0;
-                while (j < HSGPU_BUCKET_SLOTS && sl[j].ref) j++;
+                while (j < HSGPU_BUCKET_SLOTS && sl[j]) j++;
                 if (j < HSGPU_BUCKET_SLOTS) {
-                    sl[j].key = key;
-                    sl[j].ref = add_list(keys[c][key]);
+                    sl[j] = add_list(keys[c][key]) | hsgpu_ht_tag(key, ht_log2[c]) << HSGPU_SLOT_TAG_SHIFT;
                     break;
                 }
                 bkt = (bkt + 1) & bmask;
@@ -384,7 +384,7 @@ int hsgpu_validate_blob(const void *buf, size_t len) {
         return HSGPU_INVALID;
     auto in = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(h) && off + bytes <= len; };
     if (!in(h.off_filter, 4ull * hsgpu_filter_words(h.flags, h.filter_log2)) || !in(h.off_c2bits, 8192) ||
-        !in(h.off_ht_a, 32ull << h.ht_a_log2) || !in(h.off_ht_b, 32ull << h.ht_b_log2) ||
+        !in(h.off_ht_a, 16ull << h.ht_a_log2) || !in(h.off_ht_b, 16ull << h.ht_b_log2) ||
         !in(h.off_c2ref, (h.flags & HSGPU_F_HAS_C) ? 262144 : 16) || !in(h.off_lists, 4ull * h.n_lists) ||
         !in(h.off_lits, 32ull * h.n_lits))
         return HSGPU_INVALID;

@@ -37,11 +37,11 @@
  *   hwlm_filter_kernel  streams the corpus, compacts {chunk, masks} candidate
  *                       entries through a per-wavefront LDS queue and writes
  *                       them to HBM 64 at a time (one reservation per 512 B);
- *   hwlm_confirm_kernel one lane per candidate entry, all of them in flight at
- *                       once: exact hash-table bucket (32 B), (window & msk) ==
- *                       v per listed literal, block lookup through a per-KiB
- *                       hint table, bound checks, records staged per wavefront
- *                       in LDS and stored with one reservation per flush.
+ *   hwlm_confirm_kernel two candidate entries per lane: exact hash-table bucket
+ *                       (16 B: 4 tagged slots), (window & msk) == v of the literal
+ *                       the slot names; hits are queued in LDS and resolved 64 at
+ *                       a time (id/size, block lookup through a per-KiB hint table,
+ *                       bound checks), records stored into the wavefront's region.
  * A fused variant (confirm inside the streaming kernel) is kept as the
  * always-correct fallback for inputs so dense that the candidate buffer
  * overflows (the role of the reference's flood path, flood_runtime.h:86-335);
@@ -79,7 +79,9 @@ struct WaveLds {
     uint32_t nrec;   /* records staged in rec[] */
     uint32_t nfront; /* records already appended to the front of this wavefront's HBM region */
     uint32_t nback;  /* records spilled to the back of the region (staging full mid-drain) */
-    uint32_t pad[13];
+    uint32_t nmq;    /* confirm kernel: queued matches (in cand[]) */
+    uint32_t nrq;    /* confirm kernel: queued entries with candidate bits left */
+    uint32_t pad[11];
 };
 static_assert(sizeof(WaveLds) == 1536, "per-wave LDS area is 1.5 KiB: 128 KiB filter + 8 KiB + 16 x 1.5 KiB = 160 KiB");
 
@@ -104,13 +106,16 @@ struct Tables {
     const uint8_t *corpus;
     const uint64_t *off;
     uint64_t nblocks, start, total;
-    const HsgpuHtSlot *ht_a, *ht_b;
+    const uint4 *ht_a, *ht_b; /* 16-byte buckets of 4 tagged slots */
     const uint32_t *c2ref, *lists;
     const HsgpuDevLit *lits;
     uint32_t ht_a_log2, ht_b_log2;
     uint32_t key_mask;    /* 0xdfdfdfdf when the exact-table keys are case-blind, else all ones */
     const uint32_t *hint; /* block containing byte t << HSGPU_HINT_SHIFT, t < n_hint */
     uint64_t n_hint;
+#ifdef HSGPU_ABLATE
+    uint32_t ablate; /* tuning builds only: stop the confirm path early (HSGPU_DEBUG bits 8..11) */
+#endif
     WaveLds *wl;       /* this wavefront's LDS area */
     uint4 *rec_region; /* this wavefront's private region of the staged-record buffer */
     uint32_t rec_cap;  /* its capacity in records */
@@ -180,25 +185,43 @@ __device__ __forceinline__ void stage_record(const Tables &t, const uint4 rec) {
     }
 }
 
-/* One list entry = literal index | delta << 30: does that literal end at g + delta?
- * w0 / w1 are the 8-byte windows ending at g and g + 1. */
-__device__ __forceinline__ void check_lit(const Tables &t, uint32_t ent, uint64_t w0, uint64_t w1, uint64_t g) {
-    const uint32_t li = ent & HSGPU_LIST_LIT_MASK;
-    const uint32_t delta = (ent >> HSGPU_LIST_DELTA_SHIFT) & 1u;
-    const uint64_t w = delta ? w1 : w0;
-    const uint4 *lp = (const uint4 *)(t.lits + li);
-    const uint4 l0 = lp[0], l1 = lp[1]; /* {v, msk}, {groups, id, size|flags}: one 32-byte line */
-    const uint64_t v = (uint64_t)l0.y << 32 | l0.x, msk = (uint64_t)l0.w << 32 | l0.z;
-    if ((w & msk) != v) return;
-    const uint64_t ge = g + delta;
-    if (ge >= t.total) return; /* q + 1 can be one past the corpus */
+/* A literal whose (v, msk) matched the window ending at corpus offset ge: resolve the
+ * block, apply the left bound (fdr_confirm_runtime.h:77-88) and `start`
+ * (hwlm.h:108-111), stage the record. Three dependent reads (id/size, hints, offsets). */
+__device__ __forceinline__ void resolve_match(const Tables &t, uint64_t ge, uint32_t li) {
+    const uint4 l1 = ((const uint4 *)(t.lits + li))[1]; /* {groups, id, size|flags} */
     const uint32_t id = l1.z, size = l1.w & 0xff;
     uint64_t bstart;
     const uint64_t b = block_of(t, ge, bstart);
     const uint64_t end = ge - bstart;
-    /* left bound (fdr_confirm_runtime.h:77-88) and `start` (hwlm.h:108-111) */
     if (end + 1 < size || end + 1 - size < t.start) return;
     stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, li));
+}
+
+/* Confirm kernel: queue the match in the wavefront's LDS match queue (wl->cand,
+ * unused otherwise in that kernel) so that resolving runs with full lanes later;
+ * a full queue falls back to resolving in place. */
+constexpr uint32_t MQ_CAP = QCAP;
+__device__ __forceinline__ void push_match(const Tables &t, uint64_t ge, uint32_t li) {
+    const uint32_t s = __hip_atomic_fetch_add(&t.wl->nmq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (s < MQ_CAP) t.wl->cand[s] = make_uint2((uint32_t)ge, li | (uint32_t)(ge >> 32) << 24);
+    else resolve_match(t, ge, li);
+}
+
+/* One list entry = literal index | delta << 30: does that literal end at g + delta?
+ * w0 / w1 are the 8-byte windows ending at g and g + 1. */
+template <bool DEFER = false>
+__device__ __forceinline__ void check_lit(const Tables &t, uint32_t ent, uint64_t w0, uint64_t w1, uint64_t g) {
+    const uint32_t li = ent & HSGPU_LIST_LIT_MASK;
+    const uint32_t delta = (ent >> HSGPU_LIST_DELTA_SHIFT) & 1u;
+    const uint64_t w = delta ? w1 : w0;
+    const uint4 l0 = *(const uint4 *)(t.lits + li); /* {v, msk} */
+    const uint64_t v = (uint64_t)l0.y << 32 | l0.x, msk = (uint64_t)l0.w << 32 | l0.z;
+    if ((w & msk) != v) return;
+    const uint64_t ge = g + delta;
+    if (ge >= t.total) return; /* q + 1 can be one past the corpus */
+    if (DEFER) push_match(t, ge, li);
+    else resolve_match(t, ge, li);
 }
 
 /* Convergent: append the staged records to the front of the wavefront's region. */
@@ -226,32 +249,41 @@ __device__ __forceinline__ void publish_records(const Tables &t, const HsgpuScan
     }
 }
 
+template <bool DEFER = false>
 __device__ __forceinline__ void walk_ref(const Tables &t, uint32_t ref, uint64_t w0, uint64_t w1, uint64_t g) {
     if (ref & HSGPU_REF_DIRECT) {
-        check_lit(t, ref, w0, w1, g);
+        check_lit<DEFER>(t, ref, w0, w1, g); /* check_lit masks the literal index and the delta bit itself */
         return;
     }
-    uint32_t i = ref - 1, e;
+    uint32_t i = (ref & HSGPU_LIST_LIT_MASK) - 1, e;
     do {
         e = t.lists[i++];
-        check_lit(t, e, w0, w1, g);
+        check_lit<DEFER>(t, e, w0, w1, g);
     } while (!(e & HSGPU_LIST_END));
 }
 
-/* one 32-byte bucket (4 slots) per probe; continue to the next bucket only when
- * this one is full (the host inserts with the same rule). */
-__device__ __forceinline__ void probe(const Tables &t, const HsgpuHtSlot *ht, uint32_t log2, uint32_t key,
-                                      uint64_t w0, uint64_t w1, uint64_t g) {
-    const uint32_t mask = (1u << log2) - 1;
+/* which of a bucket's 4 slots carry this tag (bit i = slot i) */
+__device__ __forceinline__ uint32_t bucket_match(const uint4 s, uint32_t tag) {
+    auto hit = [&](uint32_t slot) { return slot && ((slot >> HSGPU_SLOT_TAG_SHIFT) & HSGPU_SLOT_TAG_MASK) == tag; };
+    return (hit(s.x) ? 1u : 0u) | (hit(s.y) ? 2u : 0u) | (hit(s.z) ? 4u : 0u) | (hit(s.w) ? 8u : 0u);
+}
+
+/* one 16-byte bucket (4 tagged slots) per probe; continue to the next bucket only
+ * when this one is full (the host inserts with the same rule). A tag match is a hint:
+ * the literal compare in check_lit is exact. */
+template <bool DEFER = false>
+__device__ __forceinline__ void probe(const Tables &t, const uint4 *ht, uint32_t log2, uint32_t key, uint64_t w0,
+                                      uint64_t w1, uint64_t g) {
+    const uint32_t mask = (1u << log2) - 1, tag = hsgpu_ht_tag(key, log2);
     uint32_t b = hsgpu_ht_bucket(key, log2);
     for (;;) {
-        const uint4 *bp = (const uint4 *)(ht + (size_t)b * HSGPU_BUCKET_SLOTS);
-        const uint4 s01 = bp[0], s23 = bp[1];
-        if (s01.y && s01.x == key) return walk_ref(t, s01.y, w0, w1, g);
-        if (s01.w && s01.z == key) return walk_ref(t, s01.w, w0, w1, g);
-        if (s23.y && s23.x == key) return walk_ref(t, s23.y, w0, w1, g);
-        if (s23.w && s23.z == key) return walk_ref(t, s23.w, w0, w1, g);
-        if (!s23.w) return; /* slots fill in order: last slot empty => bucket not full */
+        const uint4 s = ht[b];
+        const uint32_t m = bucket_match(s, tag);
+        if (m & 1) walk_ref<DEFER>(t, s.x, w0, w1, g);
+        if (m & 2) walk_ref<DEFER>(t, s.y, w0, w1, g);
+        if (m & 4) walk_ref<DEFER>(t, s.z, w0, w1, g);
+        if (m & 8) walk_ref<DEFER>(t, s.w, w0, w1, g);
+        if (!s.w) return; /* slots fill in order: last slot empty => bucket not full */
         b = (b + 1) & mask;
     }
 }
@@ -269,89 +301,6 @@ __device__ __forceinline__ void confirm_pos(const Tables &t, bool hit_a, bool hi
             if (ref) walk_ref(t, ref, w0, w1, g);
         }
     }
-}
-
-/* The confirm kernel's version of confirm_pos: the same decisions, but the dependent
- * reads of all its paths are issued together and waited for once per level --
- * level 1: the class-A and class-B hash buckets (+ the 2-byte reference),
- * level 2: the literals those buckets name directly (the common one-literal case),
- * level 3 (matches only): block hints and offsets inside check_lit.
- * Full buckets, literal lists and other rarities take the general (serial) path. */
-__device__ __forceinline__ uint32_t bucket_find(const uint4 s01, const uint4 s23, uint32_t key, bool &full) {
-    full = s23.w != 0;
-    if (s01.y && s01.x == key) return s01.y;
-    if (s01.w && s01.z == key) return s01.w;
-    if (s23.y && s23.x == key) return s23.y;
-    if (s23.w && s23.z == key) return s23.w;
-    return 0;
-}
-
-/* a list entry whose literal record is already in registers */
-__device__ __forceinline__ void check_lit_loaded(const Tables &t, uint32_t ent, const uint4 l0, const uint4 l1,
-                                                 uint64_t w0, uint64_t w1, uint64_t g) {
-    const uint32_t delta = (ent >> HSGPU_LIST_DELTA_SHIFT) & 1u;
-    const uint64_t w = delta ? w1 : w0;
-    const uint64_t v = (uint64_t)l0.y << 32 | l0.x, msk = (uint64_t)l0.w << 32 | l0.z;
-    if ((w & msk) != v) return;
-    const uint64_t ge = g + delta;
-    if (ge >= t.total) return;
-    const uint32_t id = l1.z, size = l1.w & 0xff;
-    uint64_t bstart;
-    const uint64_t b = block_of(t, ge, bstart);
-    const uint64_t end = ge - bstart;
-    if (end + 1 < size || end + 1 - size < t.start) return;
-    stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, ent & HSGPU_LIST_LIT_MASK));
-}
-
-template <bool HAS_A, bool HAS_B, bool HAS_C>
-__device__ __forceinline__ void confirm_pos_batched(const Tables &t, bool hit_a, bool hit_o, uint64_t w0, uint64_t w1,
-                                                    uint64_t g) {
-    const uint32_t w4 = (uint32_t)(w0 >> 32) & t.key_mask;
-    const bool do_a = HAS_A && hit_a, do_b = HAS_B && hit_o, do_c = HAS_C && hit_o;
-    /* level 1: issue every table read, then look at them */
-    uint4 a01 = make_uint4(0, 0, 0, 0), a23 = a01, b01 = a01, b23 = a01;
-    uint32_t ref_c = 0;
-    if (do_a) {
-        const uint4 *bp = (const uint4 *)(t.ht_a + (size_t)hsgpu_ht_bucket(w4, t.ht_a_log2) * HSGPU_BUCKET_SLOTS);
-        a01 = bp[0];
-        a23 = bp[1];
-    }
-    if (do_b) {
-        const uint4 *bp = (const uint4 *)(t.ht_b + (size_t)hsgpu_ht_bucket(w4 >> 8, t.ht_b_log2) * HSGPU_BUCKET_SLOTS);
-        b01 = bp[0];
-        b23 = bp[1];
-    }
-    if (do_c) ref_c = t.c2ref[w4 >> 16];
-    bool full_a = false, full_b = false;
-    const uint32_t ref_a = do_a ? bucket_find(a01, a23, w4, full_a) : 0;
-    const uint32_t ref_b = do_b ? bucket_find(b01, b23, w4 >> 8, full_b) : 0;
-    /* level 2: literals named directly by a slot */
-    const bool dir_a = ref_a & HSGPU_REF_DIRECT, dir_b = ref_b & HSGPU_REF_DIRECT, dir_c = ref_c & HSGPU_REF_DIRECT;
-    uint4 la0 = make_uint4(0, 0, 0, 0), la1 = la0, lb0 = la0, lb1 = la0, lc0 = la0, lc1 = la0;
-    if (dir_a) {
-        const uint4 *lp = (const uint4 *)(t.lits + (ref_a & HSGPU_LIST_LIT_MASK));
-        la0 = lp[0];
-        la1 = lp[1];
-    }
-    if (dir_b) {
-        const uint4 *lp = (const uint4 *)(t.lits + (ref_b & HSGPU_LIST_LIT_MASK));
-        lb0 = lp[0];
-        lb1 = lp[1];
-    }
-    if (dir_c) {
-        const uint4 *lp = (const uint4 *)(t.lits + (ref_c & HSGPU_LIST_LIT_MASK));
-        lc0 = lp[0];
-        lc1 = lp[1];
-    }
-    if (dir_a) check_lit_loaded(t, ref_a, la0, la1, w0, w1, g);
-    if (dir_b) check_lit_loaded(t, ref_b, lb0, lb1, w0, w1, g);
-    if (dir_c) check_lit_loaded(t, ref_c, lc0, lc1, w0, w1, g);
-    /* the rest: literal lists, and keys that may live in a later bucket */
-    if (ref_a && !dir_a) walk_ref(t, ref_a, w0, w1, g);
-    if (ref_b && !dir_b) walk_ref(t, ref_b, w0, w1, g);
-    if (ref_c && !dir_c) walk_ref(t, ref_c, w0, w1, g);
-    if (do_a && !ref_a && full_a) probe(t, t.ht_a, t.ht_a_log2, w4, w0, w1, g);
-    if (do_b && !ref_b && full_b) probe(t, t.ht_b, t.ht_b_log2, w4 >> 8, w0, w1, g);
 }
 
 /* fused kernel: {chunk, masks} entry, windows re-read from the corpus (L2 hits) */
@@ -375,23 +324,182 @@ __device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t 
     return nbytes == 8 ? hi : (lo >> (8 * nbytes)) | (hi << (64 - 8 * nbytes));
 }
 
+/* ---- the confirm kernel's candidate path ------------------------------------
+ * The kernel is bound by how many (lane x load) pairs it issues and by the depth
+ * of dependent reads inside divergent code, so the work is kept DENSE:
+ *   step:   two entries per lane; ONE candidate bit of each: bucket (16 B) ->
+ *           {v, msk} of the literal a uniquely tag-matching slot names (16 B).
+ *           A (v, msk) hit is pushed onto the wavefront's LDS match queue; an
+ *           entry with further candidate bits goes onto its LDS rest queue.
+ *   drain:  64 queued matches at a time with full lanes: id/size, block hints,
+ *           offsets, bounds, records stored straight into the wavefront's region.
+ * (Measured on fdr10k, 9.4M candidate entries, 0.8M matches: resolving each match
+ * where it is found -- three dependent reads under divergence, ~10 matching lanes
+ * per 128 entries -- cost 0.16 ms of the kernel's 0.33 ms; fetching block data
+ * speculatively for every candidate was slower still.)
+ * Several tag matches in one bucket, literal lists and displaced keys (full buckets)
+ * go through the general code, which queues its matches the same way. */
+constexpr uint32_t RQ_CAP = 256; /* rest queue: {entry index, masks still to do} */
+
+__device__ __forceinline__ uint32_t pick_slot(const uint4 s, uint32_t m) {
+    return (m & 1) ? s.x : (m & 2) ? s.y : (m & 4) ? s.z : s.w;
+}
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) { /* set bits below this lane */
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+/* (v, msk) of a literal already in registers */
+__device__ __forceinline__ void check_lit_loaded(const Tables &t, uint32_t ent, const uint4 l0, uint64_t w0, uint64_t w1,
+                                                 uint64_t g) {
+    const uint32_t delta = (ent >> HSGPU_LIST_DELTA_SHIFT) & 1u;
+    const uint64_t w = delta ? w1 : w0;
+    const uint64_t v = (uint64_t)l0.y << 32 | l0.x, msk = (uint64_t)l0.w << 32 | l0.z;
+    if ((w & msk) != v) return;
+    const uint64_t ge = g + delta;
+    if (ge >= t.total) return;
+    push_match(t, ge, ent & HSGPU_LIST_LIT_MASK);
+}
+
+/* Convergent. idx[u] / pend[u]: entry index in `region` and its candidate masks still
+ * to do (0 = idle lane, reads entry 0). `fresh`: take the masks from the entry itself. */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
-__device__ __forceinline__ void drain_fat_entry(const Tables &t, uint4 e0, uint4 e1) {
-    const uint32_t m = e0.y;
-    const uint64_t A = (uint64_t)e0.w << 32 | e0.z; /* c[-8..-1] */
-    const uint64_t B = (uint64_t)e1.y << 32 | e1.x; /* c[0..7]   */
-    const uint64_t C = (uint64_t)e1.w << 32 | e1.z; /* c[8..15]  */
-    uint32_t any = (m | m >> 16) & 0xffffu;
-    while (any) {
-        const uint32_t j = __builtin_ctz(any);
-        any &= any - 1;
-        const uint64_t g = (uint64_t)e0.x * CHUNK + j;
-        /* window ending at c[e]: e <= 7 -> (A,B) shifted by e+1 bytes, else (B,C) by e-7 */
-        const uint64_t w0 = j < 8 ? funnel64(A, B, j + 1) : funnel64(B, C, j - 7);
-        uint64_t w1 = 0;
-        if (S2) w1 = (j + 1) < 8 ? funnel64(A, B, j + 2) : funnel64(B, C, j - 6); /* j even: j + 1 <= 15 */
-        confirm_pos_batched<HAS_A, HAS_B, HAS_C>(t, m >> j & 1, m >> (16 + j) & 1, w0, w1, g);
+__device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *region, uint2 *rq, const uint32_t (&idx)[2],
+                                             uint32_t (&pend)[2], const bool (&valid)[2], bool fresh) {
+    uint4 e0[2], e1[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) e0[u] = region[2 * idx[u]], e1[u] = region[2 * idx[u] + 1];
+    uint64_t g[2], w0[2], w1[2];
+    uint32_t w4[2];
+    bool do_a[2], do_b[2], do_c[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t m = fresh ? (valid[u] ? e0[u].y : 0) : pend[u];
+        const uint32_t any = (m | m >> 16) & 0xffffu;
+        const uint32_t j = __builtin_ctz(any | 0x10000u) & 15u;
+        const uint64_t A = (uint64_t)e0[u].w << 32 | e0[u].z, B = (uint64_t)e1[u].y << 32 | e1[u].x,
+                       C = (uint64_t)e1[u].w << 32 | e1[u].z;
+        g[u] = (uint64_t)e0[u].x * CHUNK + j;
+        /* window ending at c[j]: j <= 7 -> (A,B) shifted by j+1 bytes, else (B,C) by j-7 */
+        w0[u] = j < 8 ? funnel64(A, B, j + 1) : funnel64(B, C, j - 7);
+        w1[u] = 0;
+        if (S2) w1[u] = (j + 1) < 8 ? funnel64(A, B, j + 2) : funnel64(B, C, j - 6); /* j even: j + 1 <= 15 */
+        w4[u] = (uint32_t)(w0[u] >> 32) & t.key_mask;
+        do_a[u] = HAS_A && any && (m >> j & 1);
+        do_b[u] = HAS_B && any && (m >> (16 + j) & 1);
+        do_c[u] = HAS_C && any && (m >> (16 + j) & 1);
+        const uint32_t rest = any & (any - 1);
+        pend[u] = m & (rest | rest << 16);
     }
+#ifdef HSGPU_ABLATE
+    if (t.ablate & 0x100) {
+        if ((g[0] ^ g[1] ^ w0[0] ^ w0[1]) == 0x123456789abcull) t.rec_region[0] = e0[0];
+        pend[0] = pend[1] = 0;
+        return;
+    }
+#endif
+    /* entries with candidate bits left: onto the rest queue */
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint64_t mask = __ballot(pend[u] != 0);
+        if (mask) {
+            const uint32_t base = __builtin_amdgcn_readfirstlane(t.wl->nrq);
+            if (pend[u]) rq[base + lane_rank(mask)] = make_uint2(idx[u], pend[u]);
+            if (lane_rank(~0ull) == 0) t.wl->nrq = base + (uint32_t)__popcll(mask);
+        }
+    }
+    /* level 1: one 16-byte bucket per key class */
+    uint4 sa[2], sb[2];
+    uint32_t ref_c[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (HAS_A) sa[u] = t.ht_a[do_a[u] ? hsgpu_ht_bucket(w4[u], t.ht_a_log2) : 0];
+        if (HAS_B) sb[u] = t.ht_b[do_b[u] ? hsgpu_ht_bucket(w4[u] >> 8, t.ht_b_log2) : 0];
+        if (HAS_C) ref_c[u] = t.c2ref[do_c[u] ? (w4[u] >> 16) : 0];
+    }
+    uint32_t ma[2] = {0, 0}, mb[2] = {0, 0}, ref_a[2] = {0, 0}, ref_b[2] = {0, 0};
+    bool fast_a[2], fast_b[2], fast_c[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (HAS_A && do_a[u]) ma[u] = bucket_match(sa[u], hsgpu_ht_tag(w4[u], t.ht_a_log2));
+        if (HAS_B && do_b[u]) mb[u] = bucket_match(sb[u], hsgpu_ht_tag(w4[u] >> 8, t.ht_b_log2));
+        if (!do_c[u]) ref_c[u] = 0;
+        ref_a[u] = ma[u] ? pick_slot(sa[u], ma[u]) : 0;
+        ref_b[u] = mb[u] ? pick_slot(sb[u], mb[u]) : 0;
+        /* fast = exactly one tag match, naming its literal directly, bucket not full */
+        fast_a[u] = __popc(ma[u]) == 1 && (ref_a[u] & HSGPU_REF_DIRECT) && !sa[u].w;
+        fast_b[u] = __popc(mb[u]) == 1 && (ref_b[u] & HSGPU_REF_DIRECT) && !sb[u].w;
+        fast_c[u] = (ref_c[u] & HSGPU_REF_DIRECT) != 0;
+    }
+#ifdef HSGPU_ABLATE
+    if (t.ablate & 0x200) {
+        if ((ref_a[0] ^ ref_a[1] ^ ref_b[0] ^ ref_b[1] ^ ref_c[0] ^ ref_c[1]) == 0x12345678u) t.rec_region[0] = e0[0];
+        return;
+    }
+#endif
+    /* level 2: {v, msk} of the literal the slot names */
+    uint4 la[2], lb[2], lc[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (HAS_A) la[u] = *(const uint4 *)(t.lits + (fast_a[u] ? (ref_a[u] & HSGPU_LIST_LIT_MASK) : 0));
+        if (HAS_B) lb[u] = *(const uint4 *)(t.lits + (fast_b[u] ? (ref_b[u] & HSGPU_LIST_LIT_MASK) : 0));
+        if (HAS_C) lc[u] = *(const uint4 *)(t.lits + (fast_c[u] ? (ref_c[u] & HSGPU_LIST_LIT_MASK) : 0));
+    }
+#ifdef HSGPU_ABLATE
+    if (t.ablate & 0x400) {
+        uint32_t acc = 0;
+        for (int u = 0; u < 2; u++) acc ^= (HAS_A ? la[u].x ^ la[u].w : 0) ^ (HAS_B ? lb[u].x ^ lb[u].w : 0) ^ (HAS_C ? lc[u].x : 0);
+        if (acc == 0x12345678u) t.rec_region[0] = e0[0];
+        return;
+    }
+#endif
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (HAS_A && fast_a[u]) check_lit_loaded(t, ref_a[u], la[u], w0[u], w1[u], g[u]);
+        if (HAS_B && fast_b[u]) check_lit_loaded(t, ref_b[u], lb[u], w0[u], w1[u], g[u]);
+        if (HAS_C && fast_c[u]) check_lit_loaded(t, ref_c[u], lc[u], w0[u], w1[u], g[u]);
+#ifdef HSGPU_ABLATE
+        if (t.ablate & 0x800) continue;
+#endif
+        /* everything else: the general path */
+        if (HAS_A && do_a[u] && !fast_a[u] && (ma[u] || sa[u].w)) probe<true>(t, t.ht_a, t.ht_a_log2, w4[u], w0[u], w1[u], g[u]);
+        if (HAS_B && do_b[u] && !fast_b[u] && (mb[u] || sb[u].w)) probe<true>(t, t.ht_b, t.ht_b_log2, w4[u] >> 8, w0[u], w1[u], g[u]);
+        if (HAS_C && ref_c[u] && !fast_c[u]) walk_ref<true>(t, ref_c[u], w0[u], w1[u], g[u]);
+    }
+}
+
+/* Convergent: resolve queued matches, 64 at a time with full lanes, while more than
+ * `keep` are queued; records go straight to the front of the wavefront's region. */
+__device__ __forceinline__ void drain_matches(const Tables &t, uint32_t lane, uint32_t keep) {
+    uint32_t n = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    n = min(__builtin_amdgcn_readfirstlane(n), MQ_CAP); /* pushes past the capacity resolved in place */
+    if (n <= keep) {
+        if (lane == 0) __hip_atomic_store(&t.wl->nmq, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        return;
+    }
+#ifdef HSGPU_ABLATE
+    if (t.ablate & 0x1000) n = 0;
+#endif
+    while (n > keep) {
+        const uint32_t k = min(n, 64u);
+        n -= k;
+        const bool valid = lane < k;
+        const uint2 it = t.wl->cand[valid ? n + lane : 0];
+        const uint32_t li = it.y & HSGPU_LIST_LIT_MASK;
+        const uint64_t ge = (uint64_t)(it.y >> 24) << 32 | it.x;
+        const uint4 l1 = ((const uint4 *)(t.lits + li))[1];
+        uint64_t bstart;
+        const uint64_t b = block_of(t, ge, bstart);
+        const uint32_t id = l1.z, size = l1.w & 0xff;
+        const uint64_t end = ge - bstart;
+        const bool ok = valid && !(end + 1 < size || end + 1 - size < t.start);
+        const uint64_t mask = __ballot(ok);
+        const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
+        const uint32_t at = f + lane_rank(mask);
+        if (ok && at < t.rec_cap) t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
+        if (lane == 0) t.wl->nfront = f + (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) __hip_atomic_store(&t.wl->nmq, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 struct Chunk {
@@ -503,8 +611,8 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.nblocks = args.nblocks;
     t.start = args.start;
     t.total = args.total;
-    t.ht_a = (const HsgpuHtSlot *)(args.blob + args.t_off_ht_a);
-    t.ht_b = (const HsgpuHtSlot *)(args.blob + args.t_off_ht_b);
+    t.ht_a = (const uint4 *)(args.blob + args.t_off_ht_a);
+    t.ht_b = (const uint4 *)(args.blob + args.t_off_ht_b);
     t.c2ref = (const uint32_t *)(args.blob + args.t_off_c2ref);
     t.lists = (const uint32_t *)(args.blob + args.t_off_lists);
     t.lits = (const HsgpuDevLit *)(args.blob + args.t_off_lits);
@@ -524,6 +632,8 @@ __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t l
         wl->nrec = 0;
         wl->nfront = 0;
         wl->nback = 0;
+        wl->nmq = 0;
+        wl->nrq = 0;
     }
 }
 
@@ -696,6 +806,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
 __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ WaveLds wave_lds[CONFIRM_THREADS / 64];
+    __shared__ uint2 rest_q[CONFIRM_THREADS / 64][RQ_CAP];
     if (args.cand_counts[args.cand_waves]) return; /* overflow: the fused fallback redoes the scan */
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -703,18 +814,47 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     if (cw >= args.rec_regions) return;
     const uint32_t r = cw / HSGPU_CONFIRM_SPLIT, part = cw % HSGPU_CONFIRM_SPLIT;
     const uint32_t n = args.cand_counts[r];
-    if (part * 64 >= n) return; /* nothing for this wavefront (its record counts stay zero) */
+    if (part * 128 >= n) return; /* nothing for this wavefront (its record counts stay zero) */
     Tables t;
     init_tables(t, args);
     init_wave_lds(t, wave_lds + wave, lane);
     t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
     t.rec_cap = args.rec_cap;
+#ifdef HSGPU_ABLATE
+    t.ablate = args.debug;
+#endif
     const uint4 *region = args.cand + 2ull * r * args.cand_cap;
-    for (uint32_t base = part * 64; base < n; base += 64 * HSGPU_CONFIRM_SPLIT) {
-        const uint32_t i = base + lane;
-        if (i < n) drain_fat_entry<HAS_A, HAS_B, HAS_C, S2>(t, region[2 * i], region[2 * i + 1]);
+    uint2 *rq = rest_q[wave];
+    uint32_t base = part * 128;
+    for (;;) {
+        uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
+        bool valid[2] = {false, false};
+        bool fresh;
+        const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
+        if (base < n && nrq <= RQ_CAP - 128) { /* the step may queue up to 128 more */
+            fresh = true;
+            const uint32_t i0 = base + lane, i1 = base + 64 + lane;
+            valid[0] = i0 < n, valid[1] = i1 < n;
+            idx[0] = valid[0] ? i0 : 0, idx[1] = valid[1] ? i1 : 0; /* n > 0 here: entry 0 exists */
+            base += 128 * HSGPU_CONFIRM_SPLIT;
+        } else if (nrq) { /* entries with candidate bits left: same path, next bit */
+            fresh = false;
+            const uint32_t k = min(nrq, 128u), first = nrq - k;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                valid[u] = u * 64 + lane < k;
+                const uint2 it = rq[valid[u] ? first + u * 64 + lane : 0];
+                idx[u] = valid[u] ? it.x : 0, pend[u] = valid[u] ? it.y : 0;
+            }
+            if (lane == 0) t.wl->nrq = first;
+        } else {
+            break;
+        }
+        confirm_step<HAS_A, HAS_B, HAS_C, S2>(t, region, rq, idx, pend, valid, fresh);
+        drain_matches(t, lane, 63);
         flush_records(t, lane, OFLUSH);
     }
+    drain_matches(t, lane, 0);
     publish_records(t, args, lane, cw);
 }
 

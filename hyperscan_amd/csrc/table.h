@@ -11,8 +11,8 @@
  *                      [FDR table fdr.c:157-244 / Teddy nibble masks teddy.c:918-969]
  *   c2bits   u32[2048] exact 2-byte-suffix bit table, staged in LDS (only when
  *                      some literal is keyed on <= 2 bytes)
- *   ht_a/b   open-addressed {key, list} tables keyed by the exact 4-/3-byte
- *                      suffix variant [litIndex hash, fdr_confirm_runtime.h:51-56]
+ *   ht_a/b   open-addressed tables of 16-byte buckets (4 tagged 32-bit slots) keyed by
+ *                      the 4-/3-byte suffix variant [litIndex hash, fdr_confirm_runtime.h:51-56]
  *   c2ref    u32[65536] list reference per 2-byte suffix
  *   lists    u32[]     literal indices, bit 31 marks the last entry of a list
  *   lits     DevLit[]  per literal (v, msk, groups, id, size, flags)
@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 3u
+#define HSGPU_TABLE_VERSION 4u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
@@ -44,9 +44,14 @@
 #define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
 #define HSGPU_HT_MUL 0x9E3779B1u
 #define HSGPU_LIST_END 0x80000000u
-#define HSGPU_REF_DIRECT 0x80000000u /* slot.ref: ONE list entry (literal | delta), no list */
-#define HSGPU_LIST_DELTA_SHIFT 30     /* list entry bit 30: the literal ends at q + 1, not at q */
+/* exact-table slot (32 bits): DIRECT | delta | 6-bit key tag | 24-bit index.
+ * DIRECT: index = ONE literal (ending at q + delta); else index = 1 + start of a list in
+ * lists[]. 0 = empty. A tag match is only a hint: the literal's own (v, msk) decides. */
+#define HSGPU_REF_DIRECT 0x80000000u
+#define HSGPU_LIST_DELTA_SHIFT 30     /* bit 30 (slots and list entries): the literal ends at q + 1, not at q */
 #define HSGPU_LIST_LIT_MASK 0x00ffffffu
+#define HSGPU_SLOT_TAG_SHIFT 24
+#define HSGPU_SLOT_TAG_MASK 0x3fu
 #define HSGPU_BUCKET_SLOTS 4u
 
 #define HSGPU_LIT_NORUNS 1u
@@ -76,10 +81,7 @@ struct HsgpuTableHeader {
 };
 static_assert(sizeof(HsgpuTableHeader) == 128, "header is 128 bytes");
 
-struct HsgpuHtSlot {
-    uint32_t key;
-    uint32_t ref; /* 0 = empty, else 1 + index of the list's first entry */
-};
+typedef uint32_t HsgpuHtSlot; /* see HSGPU_REF_DIRECT above; a bucket = 4 slots = one 16-byte read */
 
 struct HsgpuDevLit {
     uint64_t v;      /* literal bytes, last byte in the most significant byte */
@@ -119,5 +121,6 @@ HSGPU_HD uint32_t hsgpu_filter_words(uint32_t flags, uint32_t log2) {
 }
 
 HSGPU_HD uint32_t hsgpu_ht_bucket(uint32_t key, uint32_t log2) { return (key * HSGPU_HT_MUL) >> (32u - log2); }
+HSGPU_HD uint32_t hsgpu_ht_tag(uint32_t key, uint32_t log2) { return ((key * HSGPU_HT_MUL) >> (26u - log2)) & HSGPU_SLOT_TAG_MASK; }
 
 #endif

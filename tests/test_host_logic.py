@@ -90,8 +90,9 @@ def parse(blob):
     nw = (32 << h["filter_log2"]) if fl & F_REPL else (1 << h["filter_log2"])
     h["filter"] = np.frombuffer(blob, "<u4", nw, h["off_filter"])
     h["c2bits"] = np.frombuffer(blob, "<u4", 2048, h["off_c2bits"])
-    h["ht_a"] = np.frombuffer(blob, "<u4", 8 << h["ht_a_log2"], h["off_ht_a"]).reshape(-1, 4, 2)
-    h["ht_b"] = np.frombuffer(blob, "<u4", 8 << h["ht_b_log2"], h["off_ht_b"]).reshape(-1, 4, 2)
+    # 16-byte buckets of 4 tagged slots: DIRECT(31) | delta(30) | tag6(29..24) | index24
+    h["ht_a"] = np.frombuffer(blob, "<u4", 4 << h["ht_a_log2"], h["off_ht_a"]).reshape(-1, 4)
+    h["ht_b"] = np.frombuffer(blob, "<u4", 4 << h["ht_b_log2"], h["off_ht_b"]).reshape(-1, 4)
     h["c2ref"] = np.frombuffer(blob, "<u4", 65536 if fl & F_C else 4, h["off_c2ref"])
     h["lists"] = np.frombuffer(blob, "<u4", h["n_lists"], h["off_lists"])
     h["lits"] = np.frombuffer(blob, np.dtype([("v", "<u8"), ("msk", "<u8"), ("groups", "<u8"), ("id", "<u4"),
@@ -102,8 +103,8 @@ def parse(blob):
 
 def list_entries(h, ref):
     if ref & 0x80000000:
-        return [ref & 0x7FFFFFFF]
-    out, i = [], ref - 1
+        return [ref & 0x40FFFFFF]
+    out, i = [], (ref & 0xFFFFFF) - 1
     while True:
         e = int(h["lists"][i])
         out.append(e & 0x7FFFFFFF)
@@ -113,13 +114,18 @@ def list_entries(h, ref):
 
 
 def ht_lookup(h, tab, log2, key):
-    b = ((key * HT_MUL) & 0xFFFFFFFF) >> (32 - log2)
+    """All literals the device would compare for this key: the entries of every slot whose
+    tag matches (a tag match is a hint; (v, msk) decides), walking on while buckets are full."""
+    prod = (key * HT_MUL) & 0xFFFFFFFF
+    b, tag = prod >> (32 - log2), (prod >> (26 - log2)) & 63
+    out = []
     while True:
-        for k, ref in tab[b]:
-            if ref and k == key:
-                return list_entries(h, int(ref))
-        if not tab[b][3][1]:
-            return None
+        for slot in tab[b]:
+            slot = int(slot)
+            if slot and (slot >> 24) & 63 == tag:
+                out += list_entries(h, slot)
+        if not tab[b][3]:
+            return out or None
         b = (b + 1) & ((1 << log2) - 1)
 
 
