@@ -303,6 +303,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     HsgpuScanArgs args = a;
     args.super_shift = super_shift;
     args.t_flags = h->flags;
+    args.fold_shift = (h->flags & HSGPU_F_BFOLD) ? 16u : 0u;
     args.t_filter_log2 = h->filter_log2;
     args.t_ht_a_log2 = h->ht_a_log2;
     args.t_ht_b_log2 = h->ht_b_log2;

@@ -57,12 +57,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "scan_kernels.h"
 #include "table.h"
 
 namespace {
 
 
+#ifndef HSGPU_STAGES
+#define HSGPU_STAGES 8 /* prefetch depth of the filter kernel, in 1 KiB tiles per wavefront: 4, 6 or 8 */
+#endif
 constexpr int WG_THREADS = HSGPU_WG_THREADS; /* largest workgroup: 16 wavefronts; small tables run 8 */
 constexpr int CHUNK = 16;                     /* bytes per lane per iteration */
 constexpr int WAVE_TILE = 64 * CHUNK;         /* 1 KiB */
@@ -516,42 +521,113 @@ struct FilterCfg {
 
 /* The filter over one 16-byte chunk: candidate masks, bit q = lookup position q;
  * low half = 4-byte-key hits, high half = 3-/2-byte-key hits. Fully unrolled:
- * every window is a compile-time byte offset into {h.y, d.x, d.y, d.z, d.w}. */
+ * every window is a compile-time byte offset into {h.y, d.x, d.y, d.z, d.w}.
+ *
+ * The kernel is VALU-bound (a wave64 integer instruction occupies its SIMD for 4
+ * cycles), so the per-lookup sequence is kept to the minimum the ISA allows:
+ *   x      v_alignbyte (aligned offsets: none); case-blinding done once per dword
+ *   prod   v_mul_u32_u24
+ *   a      v_lshrrev;  addr  v_and;  word  ds_read_b32
+ *   4-byte key:  t1 = word >> (a + b3)            v_add_u32_sdwa (b3 = byte select) + v_lshrrev
+ *                t2 = word >> (prod.byte1 + b3)   same, both operands byte selects   (K2 only)
+ *   3-byte key:  t1 = word >> a, t2 = word >> prod.byte1                            (not BFOLD)
+ *   hit = t1 & t2: only bit 0 means anything; v_alignbit shifts exactly that bit into
+ *   the top of the accumulator, so no per-lookup mask / shift-into-place is needed.
+ * Shifts take their amount mod 32 in hardware, which is the "& 31" of the bit index. */
+__device__ __forceinline__ uint32_t shr_lo5(uint32_t v, uint32_t amount) { return v >> (amount & 31u); }
+/* a + byte BYTE of src: the byte select is an SDWA operand modifier, not an instruction.
+ * (Written out: left to itself the compiler extracts about half of these with shifts.) */
+template <int BYTE> __device__ __forceinline__ uint32_t add_byte(uint32_t a, uint32_t src) {
+    uint32_t r;
+    if (BYTE == 0)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(src));
+    else if (BYTE == 1)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(src));
+    else if (BYTE == 2)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(src));
+    else
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(src));
+    return r;
+}
+/* byte 1 of prod + byte BYTE of src */
+template <int BYTE> __device__ __forceinline__ uint32_t add_byte1_byte(uint32_t prod, uint32_t src) {
+    uint32_t r;
+    if (BYTE == 0)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0" : "=v"(r) : "v"(prod), "v"(src));
+    else if (BYTE == 1)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(prod), "v"(src));
+    else if (BYTE == 2)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(r) : "v"(prod), "v"(src));
+    else
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3" : "=v"(r) : "v"(prod), "v"(src));
+    return r;
+}
+/* word >> byte 1 of prod */
+__device__ __forceinline__ uint32_t shr_byte1(uint32_t word, uint32_t prod) {
+    uint32_t r;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(prod), "v"(word));
+    return r;
+}
+__device__ __forceinline__ uint32_t push_top(uint32_t hit, uint32_t acc, uint32_t nbits) {
+    return __builtin_amdgcn_alignbit(hit, acc, nbits); /* ({hit, acc} >> nbits): low nbits of hit enter at the top */
+}
+
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int Q>
+__device__ __forceinline__ void filter_pos(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
+                                           uint32_t &acc_o) {
+    constexpr uint32_t STEP = S2 ? 2 : 1;
+    /* 3 bytes ending at c[Q]: byte offset Q + 2 into arr */
+    constexpr int O = Q + 2;
+    const uint32_t x = (O & 3) ? alignbyte(arr[(O >> 2) + 1], arr[O >> 2], O & 3) : arr[O >> 2];
+    /* the byte before them, c[Q-3]: byte (Q + 1) & 3 of arr[(Q + 1) >> 2] */
+    const uint32_t b3src = arr[(Q + 1) >> 2];
+    constexpr int B3 = (Q + 1) & 3;
+    const uint32_t prod = mul_u24(x, HSGPU_FILTER_MUL);
+    const uint32_t a = prod >> f.shift;
+    const uint32_t addr = REPL ? ((a << 7) | f.lane4) : (a & f.amask);
+    const uint32_t word = lds_word(addr);
+    if (HAS_A) {
+        uint32_t hit = shr_lo5(word, add_byte<B3>(a, b3src));
+        if (K2) hit &= shr_lo5(word, add_byte1_byte<B3>(prod, b3src)); /* byte 1 of prod: second bit index */
+        acc_a = push_top(hit, acc_a, STEP);
+    }
+    if (HAS_B || HAS_C) {
+        uint32_t hit = 0;
+        if (HAS_B) {
+            hit = shr_lo5(word, a);
+            if (K2) hit &= shr_byte1(word, prod);
+        }
+        if (HAS_C) {
+            const uint32_t kc = __builtin_amdgcn_ubfe(x, 8, 16);
+            hit |= shr_lo5(lds_word(f.c2base + ((kc >> 5) << 2)), kc);
+        }
+        acc_o = push_top(hit, acc_o, STEP);
+    }
+}
+
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int... I>
+__device__ __forceinline__ void filter_positions(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
+                                                 uint32_t &acc_o, std::integer_sequence<int, I...>) {
+    (filter_pos<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, I * (S2 ? 2 : 1)>(arr, f, acc_a, acc_o), ...);
+}
+
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND>
 __device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg &f) {
-    const uint32_t arr[6] = {c.h.y, c.d.x, c.d.y, c.d.z, c.d.w, 0u};
-    uint32_t acc_a = 0, acc_o = 0;
+    uint32_t arr[6] = {c.h.y, c.d.x, c.d.y, c.d.z, c.d.w, 0u};
+    if (BLIND) {
 #pragma unroll
-    for (int q = 0; q < 16; q += (S2 ? 2 : 1)) {
-        /* 3 bytes ending at c[q]: byte offset q + 2 into arr */
-        const int o = q + 2;
-        uint32_t x = (o & 3) ? alignbyte(arr[(o >> 2) + 1], arr[o >> 2], o & 3) : arr[o >> 2];
-        if (BLIND) x &= 0xdfdfdfdfu; /* b3's bit 5 never reaches the 5-bit index either */
-        /* the byte before them, c[q-3]: byte offset q + 1 (an SDWA operand select) */
-        const uint32_t b3 = (arr[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xffu;
-        const uint32_t prod = mul_u24(x, HSGPU_FILTER_MUL);
-        const uint32_t a = prod >> f.shift;
-        const uint32_t addr = REPL ? ((a << 7) | f.lane4) : (a & f.amask);
-        const uint32_t word = lds_word(addr);
-        if (HAS_A) {
-            uint32_t hit = bfe1(word, a + b3);
-            if (K2) hit &= bfe1(word, (prod >> 11) + b3);
-            acc_a |= hit << q;
-        }
-        if (HAS_B || HAS_C) {
-            uint32_t hit = 0;
-            if (HAS_B) {
-                hit = bfe1(word, a); /* bit a & 31: no extra shift */
-                if (K2) hit &= bfe1(word, prod >> 13);
-            }
-            if (HAS_C) {
-                const uint32_t kc = __builtin_amdgcn_ubfe(x, 8, 16);
-                hit |= bfe1(lds_word(f.c2base + ((kc >> 5) << 2)), kc);
-            }
-            acc_o |= hit << q;
-        }
+        for (int i = 0; i < 5; i++) arr[i] &= 0xdfdfdfdfu; /* b3's bit 5 never reaches the 5-bit index either */
     }
-    return acc_a | acc_o << 16;
+    uint32_t acc_a = 0, acc_o = 0;
+    filter_positions<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(arr, f, acc_a, acc_o,
+#ifdef HSGPU_ABLATE_HALF /* tuning builds: half the lookups (wrong results; is the kernel lookup-bound?) */
+                                                               std::make_integer_sequence<int, S2 ? 4 : 8>{});
+#else
+                                                               std::make_integer_sequence<int, S2 ? 8 : 16>{});
+#endif
+    /* 16 / STEP pushes of STEP bits: lookup q sits at bit 16 + q (stride 2: odd bits are noise) */
+    constexpr uint32_t KEEP = S2 ? 0x5555u : 0xffffu;
+    return ((acc_a >> 16) & KEEP) | (acc_o & (KEEP << 16));
 }
 
 struct SpillState {
@@ -577,7 +653,8 @@ __device__ __forceinline__ void spill(const HsgpuScanArgs &args, SpillState &sp,
         const uint32_t rank =
             __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
         uint4 *e = sp.region + 2ull * (sp.written + rank);
-        e[0] = make_uint4((uint32_t)(coff >> 4), acc, c.h.x, c.h.y);
+        /* BFOLD tables: the one class test stands for both (fold_shift = 16, else 0) */
+        e[0] = make_uint4((uint32_t)(coff >> 4), acc | acc << args.fold_shift, c.h.x, c.h.y);
         e[1] = c.d;
     }
     sp.written += n;
@@ -710,9 +787,13 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, records, 0x00020000);
         Chunk c;
         const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 8, 0);
-        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, 0, 0);
         c.d = make_uint4(d[0], d[1], d[2], d[3]);
+#ifdef HSGPU_ABLATE_NOHALO /* tuning builds: wrong results at chunk starts; what does the halo load cost? */
+        c.h = make_uint2(d[3], d[2]);
+#else
+        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, 0, 0);
         c.h = make_uint2(h[0], h[1]);
+#endif
         return c;
     };
     /* tile 0 has nothing in front of it: descriptor at the corpus itself, and the
@@ -728,33 +809,66 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         return c;
     };
 
+#ifdef HSGPU_ABLATE_NOSPILL /* tuning builds: keep the math alive, write nothing */
+#define HSGPU_SPILL(args, sp, coff, acc, cur) (sp.written += (acc == 0x9e3779b9u))
+#else
+#define HSGPU_SPILL(args, sp, coff, acc, cur) spill(args, sp, coff, acc, cur)
+#endif
 #define HSGPU_HANDLE(CUR, COFF)                                                                   \
     {                                                                                             \
         const uint32_t acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f);      \
         if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2>(t, qcount, lane, (COFF), acc);          \
-        else spill(args, sp, (COFF), acc, CUR);                                                   \
+        else HSGPU_SPILL(args, sp, (COFF), acc, CUR);                                             \
     }
 
     if (n_full && blockIdx.x < n_full) {
         uint64_t tile = blockIdx.x;
-        /* four register stages rotate by name (loop unrolled x4): three tiles are in
-         * flight while one is filtered, a stage is never copied, and the only wait is
-         * for the stage about to be filtered */
-        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3;
-#define HSGPU_STAGE(CUR, NEW)                                   \
-    {                                                           \
-        NEW = issue(tile + 3ull * G);                           \
-        const uint64_t coff = (tile << super_shift) + lane_off;  \
-        HSGPU_HANDLE(CUR, coff)                                 \
-        tile += G;                                              \
-        if (tile >= n_full) break;                              \
+        /* HSGPU_STAGES register stages rotate by name (loop unrolled to match): all but
+         * one tile are in flight while that one is filtered, a stage is never copied, and
+         * the only wait is for the stage about to be filtered. Depth matters: at ~15 GB/s
+         * per CU and ~3 us of loaded HBM latency, 16 wavefronts x 3 KiB in flight was the
+         * limit of the 4-stage version. */
+#define HSGPU_STAGE(CUR, NEW)                                            \
+    {                                                                    \
+        NEW = issue(tile + (uint64_t)(HSGPU_STAGES - 1) * G);            \
+        const uint64_t coff = (tile << super_shift) + lane_off;           \
+        HSGPU_HANDLE(CUR, coff)                                          \
+        tile += G;                                                       \
+        if (tile >= n_full) break;                                       \
     }
+#if HSGPU_STAGES == 8
+        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3 = issue(tile + 3ull * G),
+              c4 = issue(tile + 4ull * G), c5 = issue(tile + 5ull * G), c6 = issue(tile + 6ull * G), c7;
+        for (;;) {
+            HSGPU_STAGE(c0, c7)
+            HSGPU_STAGE(c1, c0)
+            HSGPU_STAGE(c2, c1)
+            HSGPU_STAGE(c3, c2)
+            HSGPU_STAGE(c4, c3)
+            HSGPU_STAGE(c5, c4)
+            HSGPU_STAGE(c6, c5)
+            HSGPU_STAGE(c7, c6)
+        }
+#elif HSGPU_STAGES == 6
+        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3 = issue(tile + 3ull * G),
+              c4 = issue(tile + 4ull * G), c5;
+        for (;;) {
+            HSGPU_STAGE(c0, c5)
+            HSGPU_STAGE(c1, c0)
+            HSGPU_STAGE(c2, c1)
+            HSGPU_STAGE(c3, c2)
+            HSGPU_STAGE(c4, c3)
+            HSGPU_STAGE(c5, c4)
+        }
+#else
+        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3;
         for (;;) {
             HSGPU_STAGE(c0, c3)
             HSGPU_STAGE(c1, c0)
             HSGPU_STAGE(c2, c1)
             HSGPU_STAGE(c3, c2)
         }
+#endif
 #undef HSGPU_STAGE
     }
 

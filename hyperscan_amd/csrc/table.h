@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 4u
+#define HSGPU_TABLE_VERSION 5u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
@@ -40,6 +40,8 @@
 #define HSGPU_F_K2 16u   /* keys set/test two bits of their filter word */
 #define HSGPU_F_STRIDE2 32u /* lookups at even positions only; keys for delta 0 and 1 */
 #define HSGPU_F_BLIND 64u   /* hash and exact-table keys ignore bit 5 (the ASCII case bit) of every byte */
+#define HSGPU_F_BFOLD 128u  /* the (few) 3-byte keys own their whole filter word: the filter kernel runs the
+                             * 4-byte-key test only, and a hit means "probe both exact tables" */
 
 #define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
 #define HSGPU_HT_MUL 0x9E3779B1u
@@ -104,18 +106,19 @@ static_assert(sizeof(HsgpuDevLit) == 32, "DevLit is 32 bytes");
  *   a    = prod >> (32 - r);  word = a * 32 + column
  * bits tested in that word:
  *   bitA  = (a + b3) & 31              4-byte key, first bit   (v_add_u32_sdwa + v_bfe)
- *   bitA2 = ((prod >> 11) + b3) & 31   4-byte key, second bit  (only with HSGPU_F_K2)
+ *   bitA2 = ((prod >> 8) + b3) & 31    4-byte key, second bit  (only with HSGPU_F_K2; byte 1 of prod: an SDWA select)
  *   bitB  = a & 31                     3-byte key, first bit
- *   bitB2 = (prod >> 13) & 31          3-byte key, second bit  (only with HSGPU_F_K2)
+ *   bitB2 = (prod >> 8) & 31           3-byte key, second bit  (only with HSGPU_F_K2)
+ * With HSGPU_F_BFOLD a 3-byte key sets all 32 bits of its word instead (any b3 passes the bitA tests).
  */
 HSGPU_HD uint32_t hsgpu_filter_prod(uint32_t x24) { return (x24 & 0xffffffu) * HSGPU_FILTER_MUL; }
 HSGPU_HD uint32_t hsgpu_filter_shift(uint32_t flags, uint32_t log2) {
     return (flags & HSGPU_F_REPL) ? 32u - log2 : 30u - log2;
 }
 HSGPU_HD uint32_t hsgpu_filter_bit_a(uint32_t b3, uint32_t a) { return (b3 + a) & 31u; }
-HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { return (b3 + (prod >> 11)) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { return (b3 + (prod >> 8)) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t a) { return a & 31u; }
-HSGPU_HD uint32_t hsgpu_filter_bit_b2(uint32_t prod) { return (prod >> 13) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_b2(uint32_t prod) { return (prod >> 8) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_words(uint32_t flags, uint32_t log2) {
     return (flags & HSGPU_F_REPL) ? (32u << log2) : (1u << log2);
 }

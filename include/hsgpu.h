@@ -108,6 +108,7 @@ typedef struct hsgpu_hwlm_info {
 #define HSGPU_BUILD_FORCE_SMALL 128u /* 32 KiB hashed filter, run as three 8-wavefront workgroups per CU */
 #define HSGPU_BUILD_FORCE_MEDIUM 256u /* 64 KiB hashed filter: two 16-wavefront workgroups per CU where registers allow */
 #define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
+#define HSGPU_BUILD_NO_FOLD 512u    /* keep the separate 3-byte-key filter test even when only few such keys exist */
 
 /* ---- build side ---------------------------------------------------------- */
 

@@ -111,6 +111,37 @@ def test_candidate_buffer_overflow_falls_back_to_fused(scratch):
     assert as_set(got) == as_set(want)
 
 
+@pytest.mark.parametrize("flags", [FORCE_HASHED, FORCE_HASHED | 512, FORCE_HASHED | FORCE_S2, FORCE_HASHED | FORCE_K2,
+                                   FORCE_HASHED | FORCE_K2 | FORCE_BLIND])
+def test_few_three_byte_literals_folded_filter(scratch, flags):
+    """HSGPU_F_BFOLD: 3-byte keys own their filter word and the filter kernel tests one class;
+    512 = HSGPU_BUILD_NO_FOLD keeps the separate test. Same matches either way."""
+    rng = np.random.default_rng(77)
+    lits = random_literals(rng, 600, 4, 8, nocase_frac=0.3) + random_literals(rng, 25, 3, 3, nocase_frac=0.2)
+    lits = [H.HwlmLiteral(l.s, nocase=l.nocase, id=i) for i, l in enumerate(lits)]
+    corpus = random_corpus(rng, 600_000, lits, plant_every=200)
+    off = random_blocks(rng, corpus.size, mean_len=700)
+    t = H.hwlm_build(lits, flags)
+    folded = bool(t.info()["flags"] & 128)
+    if flags & 512:
+        assert not folded
+    elif not flags & FORCE_S2:  # stride 2 adds a 3-byte delta-1 key per 4-byte literal: too many to fold
+        assert folded
+    got = hw.hwlm_exec_batch(t, scratch, corpus, off)
+    want = ob.Oracle(lits).collect_blocks(corpus, off)
+    assert as_set(got) == as_set(want)
+
+
+def test_folded_filter_overflow_falls_back_to_fused(scratch):
+    lits = [H.HwlmLiteral("abcd", False, 0), H.HwlmLiteral("bcda", False, 1), H.HwlmLiteral("cda", False, 2)]
+    corpus = np.frombuffer(b"abcd" * 60_000, dtype=np.uint8)
+    t = H.hwlm_build(lits, FORCE_HASHED)
+    assert t.info()["flags"] & 128
+    got = hw.hwlm_exec_batch(t, scratch, corpus, np.array([0, corpus.size], dtype=np.uint64))
+    want = ob.Oracle(lits).collect_blocks(corpus, np.array([0, corpus.size], dtype=np.uint64))
+    assert as_set(got) == as_set(want)
+
+
 def test_serialized_table_scans_identically(scratch):
     rng = np.random.default_rng(31)
     lits = random_literals(rng, 100, 2, 8)

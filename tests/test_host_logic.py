@@ -19,8 +19,8 @@ from tests.util import random_literals
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-F_A, F_B, F_C, F_REPL, F_K2, F_S2, F_BLIND = 1, 2, 4, 8, 16, 32, 64
-FORCE_REPL, FORCE_HASHED, FORCE_K2, FORCE_K1, FORCE_S1, FORCE_BLIND, FORCE_S2 = 1, 2, 4, 8, 16, 32, 64
+F_A, F_B, F_C, F_REPL, F_K2, F_S2, F_BLIND, F_BFOLD = 1, 2, 4, 8, 16, 32, 64, 128
+FORCE_REPL, FORCE_HASHED, FORCE_K2, FORCE_K1, FORCE_S1, FORCE_BLIND, FORCE_S2, NO_FOLD = 1, 2, 4, 8, 16, 32, 64, 512
 MUL, HT_MUL = 0x9E3779, 0x9E3779B1
 
 
@@ -138,8 +138,10 @@ def filter_word_and_bits(h, x24, b3):
     else:
         a = prod >> (30 - k)
         words = [int(h["filter"][a >> 2])]
-    bit_a = [(a + b3) & 31] + ([((prod >> 11) + b3) & 31] if fl & F_K2 else [])
-    bit_b = [a & 31] + ([(prod >> 13) & 31] if fl & F_K2 else [])
+    bit_a = [(a + b3) & 31] + ([((prod >> 8) + b3) & 31] if fl & F_K2 else [])
+    bit_b = [a & 31] + ([(prod >> 8) & 31] if fl & F_K2 else [])
+    if fl & F_BFOLD:  # the filter kernel runs the 4-byte-key test only; a hit probes both exact tables
+        bit_b = bit_a
     return words, bit_a, bit_b
 
 
@@ -189,7 +191,7 @@ def check_table_covers(lits, flags):
 
 @pytest.mark.parametrize("flags", [0, FORCE_REPL, FORCE_HASHED, FORCE_HASHED | FORCE_K2, FORCE_REPL | FORCE_K2,
                                    FORCE_S1, FORCE_S1 | FORCE_HASHED | FORCE_K1, FORCE_BLIND, FORCE_S2,
-                                   FORCE_S2 | FORCE_HASHED | FORCE_BLIND | FORCE_K2])
+                                   FORCE_S2 | FORCE_HASHED | FORCE_BLIND | FORCE_K2, NO_FOLD, NO_FOLD | FORCE_S2])
 def test_table_covers_every_literal(flags):
     rng = np.random.default_rng(flags + 1)
     lits = random_literals(rng, 150, 1, 8, nocase_frac=0.4)
@@ -200,6 +202,24 @@ def test_table_covers_every_literal(flags):
         assert not h["flags"] & F_REPL
     if flags & FORCE_S1:
         assert not h["flags"] & F_S2
+    if flags & NO_FOLD or h["flags"] & (F_REPL | F_C):
+        assert not h["flags"] & F_BFOLD
+
+
+def test_few_three_byte_keys_fold_into_the_four_byte_test():
+    """Few 3-byte keys beside 4-byte ones: each owns its whole filter word (HSGPU_F_BFOLD)."""
+    rng = np.random.default_rng(11)
+    lits = random_literals(rng, 400, 4, 8, nocase_frac=0.3) + random_literals(rng, 20, 3, 3, nocase_frac=0)
+    for i, l in enumerate(lits):
+        l.id = i
+    h = check_table_covers(lits, FORCE_HASHED)
+    assert h["flags"] & F_BFOLD and h["flags"] & F_B
+    assert (h["filter"] == 0xFFFFFFFF).sum() >= 1
+    h2 = check_table_covers(lits, FORCE_HASHED | NO_FOLD)
+    assert not h2["flags"] & F_BFOLD
+    # many 3-byte keys: folding would flood the filter, so it is not chosen
+    many = random_literals(rng, 400, 4, 8, nocase_frac=0) + random_literals(rng, 2000, 3, 3, nocase_frac=0)
+    assert not H.hwlm_build(many, FORCE_HASHED).info()["flags"] & F_BFOLD
 
 
 def test_table_modes_auto():
