@@ -60,7 +60,9 @@ def pmc_traffic(table_flags):
     if not os.path.exists(path):
         return None
     b = lambda bit: "true" if table_flags & bit else "false"
-    cls = ("true, true, true" if table_flags & 4 else "true, true, false" if table_flags & 2 else "true, false, false")
+    # HSGPU_F_BFOLD (128): the two-phase filter kernel of such a table is the 4-byte-key-only variant
+    cls = ("true, true, true" if table_flags & 4 else
+           "true, true, false" if table_flags & 2 and not table_flags & 128 else "true, false, false")
     name = f"hwlm_filter_kernel<{cls}, {b(8)}, {b(16)}, {b(32)}, {b(64)}, false>"
     try:
         e = json.load(open(path)).get(name)

@@ -329,7 +329,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         uint64_t nblocks = a.nblocks, total = a.total, n_hint = args.n_hint;
         uint32_t *hint = (uint32_t *)s->hint.p;
         void *hargs[] = {&off, &nblocks, &total, &hint, &n_hint};
-        HIP_TRY(hipLaunchKernel(hsgpu_hint_kernel(), dim3((unsigned)((n_hint + 255) / 256)), dim3(256), hargs, 0, hs));
+        HIP_TRY(hipLaunchKernel(hsgpu_hint_kernel(), dim3((unsigned)((nblocks + 1 + 255) / 256)), dim3(256), hargs, 0, hs));
         return HSGPU_SUCCESS;
     };
     if (two_phase) HIP_TRY(hipEventRecord(s->ev_fork, stream)); /* everything the hints read is ready here */

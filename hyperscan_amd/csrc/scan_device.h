@@ -1090,12 +1090,39 @@ __global__ __launch_bounds__(256) void control_reset_kernel(HsgpuScanArgs args) 
 }
 
 /* ---- phase 0: hint[t] = block containing corpus byte t * 1024 ------------------- */
-__global__ void block_hint_kernel(const uint64_t *off, uint64_t nblocks, uint64_t total, uint32_t *hint,
-                                  uint64_t n_hint) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_hint) return;
-    const uint64_t g = i << HSGPU_HINT_SHIFT;
-    hint[i] = (uint32_t)(g < total ? find_block(off, 0, nblocks - 1, g) : nblocks - 1);
+/* One thread per block writes the hint of every KiB boundary inside its block (no
+ * searching: a per-tile bisection was 20 dependent reads per entry and took as long as
+ * the filter kernel it runs beside); blocks covering more than 4 boundaries are written
+ * by their whole wavefront. Thread nblocks covers boundaries at/after the last offset. */
+__global__ __launch_bounds__(256) void block_hint_kernel(const uint64_t *off, uint64_t nblocks, uint64_t total,
+                                                         uint32_t *hint, uint64_t n_hint) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t t0 = 0, t1 = 0;
+    uint32_t val = 0;
+    if (b < nblocks) {
+        const uint64_t s = b ? off[b] : 0, e = off[b + 1];
+        t0 = (s + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
+        t1 = (e + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
+        val = (uint32_t)b;
+    } else if (b == nblocks) {
+        t0 = (off[nblocks] + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
+        t1 = n_hint;
+        val = (uint32_t)(nblocks - 1);
+    }
+    t1 = min(t1, n_hint);
+    const uint64_t n = t1 > t0 ? t1 - t0 : 0;
+    if (n <= 4) {
+        for (uint64_t k = 0; k < n; k++) hint[t0 + k] = val;
+    }
+    unsigned long long wide = __ballot(n > 4);
+    while (wide) {
+        const int l = __builtin_ctzll(wide);
+        wide &= wide - 1;
+        const uint64_t T0 = __shfl(t0, l), T1 = __shfl(t1, l);
+        const uint32_t V = __shfl(val, l);
+        for (uint64_t t = T0 + lane; t < T1; t += 64) hint[t] = V;
+    }
 }
 
 
