@@ -46,6 +46,9 @@ def build_workload(name, total_bytes, seed_shift):
     elif name == "fdr10k":
         lits, _full = cp.snort_like_literals(10000, seed=4)
         corpus, off = cp.packet_corpus(total_bytes, lits, seed=10 + seed_shift)
+    elif name.startswith("lits") and name[4:].isdigit():  # tuning: N literals of len 4-8 (stride-2 tables)
+        lits = cp.teddy_literals(int(name[4:]), seed=2)
+        corpus, off = cp.packet_corpus(total_bytes, lits[:256], seed=3 + seed_shift)
     else:
         raise SystemExit(f"unknown workload {name}")
     return lits, corpus, off

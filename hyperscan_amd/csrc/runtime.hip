@@ -278,10 +278,15 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * CU; tables of <= 40 KiB run three 8-wavefront workgroups per CU (24 wavefronts
      * hide more latency; the SGPR budget admits no second 16-wavefront workgroup). */
     const bool small = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, 512) * 3 <= s->lds_per_cu;
-    unsigned wg_threads = small ? 512 : HSGPU_WG_THREADS;
+    /* Stride-2 single-bit filters are light enough (~3 VALU instructions per byte) that the
+     * kernel is bound by the memory side, and there 8 wavefronts per CU measured 7-13% faster
+     * than 16 (teddy64: 0.269 vs 0.288 ms; 1000 literals: 0.269 vs 0.309 ms); the VALU-bound
+     * variants (stride 1, two filter bits) want all 16 (fdr10k: 0.39 vs 0.45 ms). */
+    const bool light = (h->flags & HSGPU_F_STRIDE2) && !(h->flags & (HSGPU_F_K2 | HSGPU_F_HAS_C));
+    unsigned wg_threads = (small || light) ? 512 : HSGPU_WG_THREADS;
     unsigned wg_per_cu = small ? 3 : 1;
     static const char *env_wg = getenv("HSGPU_WG_THREADS"), *env_per = getenv("HSGPU_WG_PER_CU"); /* tuning knobs */
-    if (env_wg && (atoi(env_wg) == 512 || atoi(env_wg) == 1024)) wg_threads = (unsigned)atoi(env_wg);
+    if (env_wg && (atoi(env_wg) == 256 || atoi(env_wg) == 512 || atoi(env_wg) == 1024)) wg_threads = (unsigned)atoi(env_wg);
     if (!small) { /* a 64 KiB filter admits a second workgroup when the kernel's registers do */
         int nb = 0;
         const size_t l2 = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false, wg_threads);
@@ -289,7 +294,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
             wg_per_cu = 2;
     }
     if (env_per && atoi(env_per) >= 1 && atoi(env_per) <= 4) wg_per_cu = (unsigned)atoi(env_per);
-    const uint32_t super_shift = wg_threads == 512 ? 13 : 14;
+    const uint32_t super_shift = wg_threads == 256 ? 12 : wg_threads == 512 ? 13 : 14; /* 1 KiB per wavefront */
     const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads);      /* fused */
     const size_t lds_two = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false, wg_threads); /* two-phase filter */
     if (lds > s->lds_per_cu) {
