@@ -232,8 +232,13 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     # parity gate on a sample (bounded CPU time): GPU count over the first k blocks == CPU count
     cpu = None
     if do_cpu:
-        cpu, (k, n_cpu) = cpu_baseline(lits, corpus, off)
+        # records first: on this stack the scans that directly follow a large D2H copy run ~3x
+        # slower for tens of ms (measured: 1.9 vs 0.66 ms per scan, host launch time unchanged);
+        # the CPU baseline's seconds in between and one untimed scan keep that out of the timed region
         recs = job.records()
+        cpu, (k, n_cpu) = cpu_baseline(lits, corpus, off)
+        run_steps(1)
+        torch.cuda.synchronize()
         n_gpu = int((recs[:, 0] < k).sum())
         assert n_gpu == n_cpu, f"PARITY FAILURE on the sample: GPU {n_gpu} vs CPU {n_cpu}"
         cpu["parity"] = f"GPU == CPU match count on the sample ({n_cpu})"
