@@ -10,6 +10,13 @@
       src/nfa/vermicelli.h:42-104
   truffleBuildMasks(CharReach) src/nfa/trufflecompile.cpp:59  CharClass(...).to_truffle()
 
+  shuftiDoubleExec(lo1, hi1, lo2, hi2, buf, buf_end)          PairSet.from_dshufti(...) + pair_scan(...)
+      src/nfa/shufti.c:319-361
+  shuftiBuildDoubleMasks(onechar, twochar, ...)               PairSet.build(pairs, onechar)
+      src/nfa/shufticompile.cpp:135-209
+  vermicelliDoubleExec / ...MaskedExec / rvermicelliDoubleExec PairSet.from_dverm / from_dverm_masked
+      src/nfa/vermicelli.h:169-317,464-518
+
 Return convention as in the reference: offset of the first member in the block, the
 block length when there is none; for the reverse scans the last member, -1 when none.
 """
@@ -22,10 +29,16 @@ from .hwlm import HsgpuError
 
 CLASS_MAX = 8
 WORK_BYTES = 4160
+PAIR_MAX = 8
+PAIR_WORK_BYTES = 8256
 
 
 class _Class(C.Structure):
     _fields_ = [("bitmap", C.c_uint8 * 32)]
+
+
+class _Pair(C.Structure):
+    _fields_ = [("lo1", C.c_uint8 * 16), ("hi1", C.c_uint8 * 16), ("lo2", C.c_uint8 * 16), ("hi2", C.c_uint8 * 16)]
 
 
 def _lib():
@@ -43,6 +56,20 @@ def _lib():
         lib.hsgpu_class_scan_dev.argtypes = [C.POINTER(_Class), C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]
+        lib.hsgpu_pair_from_dshufti.restype = C.c_int
+        lib.hsgpu_pair_from_dshufti.argtypes = [C.c_void_p] * 4 + [C.POINTER(_Pair)]
+        lib.hsgpu_pair_from_dverm.restype = C.c_int
+        lib.hsgpu_pair_from_dverm.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.POINTER(_Pair)]
+        lib.hsgpu_pair_from_dverm_masked.restype = C.c_int
+        lib.hsgpu_pair_from_dverm_masked.argtypes = [C.c_uint8] * 4 + [C.POINTER(_Pair)]
+        lib.hsgpu_pair_build.restype = C.c_int
+        lib.hsgpu_pair_build.argtypes = [C.POINTER(_Class), C.c_void_p, C.c_size_t, C.POINTER(_Pair)]
+        lib.hsgpu_pair_test.restype = C.c_int
+        lib.hsgpu_pair_test.argtypes = [C.POINTER(_Pair), C.c_uint8, C.c_uint8]
+        lib.hsgpu_pair_scan_dev.restype = C.c_int
+        lib.hsgpu_pair_scan_dev.argtypes = [C.POINTER(_Pair), C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p,
+                                            C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
         lib._class_sigs = True
     return lib
 
@@ -129,3 +156,76 @@ def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True,
         torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
         return bitmaps, first, last
     return bitmaps, first, last, work
+
+
+class PairSet:
+    """A set of two-byte sequences in double-shufti form (<= 8 buckets, 0-active masks)."""
+
+    def __init__(self, c=None):
+        self._c = c if c is not None else _Pair()
+
+    @property
+    def masks(self):
+        return bytes(self._c.lo1), bytes(self._c.hi1), bytes(self._c.lo2), bytes(self._c.hi2)
+
+    @classmethod
+    def from_dshufti(cls, lo1, hi1, lo2, hi2):
+        c = _Pair()
+        if _lib().hsgpu_pair_from_dshufti(bytes(lo1), bytes(hi1), bytes(lo2), bytes(hi2), C.byref(c)) != 0:
+            raise HsgpuError(-1, "hsgpu_pair_from_dshufti")
+        return cls(c)
+
+    @classmethod
+    def from_dverm(cls, c1, c2, nocase=False):
+        c = _Pair()
+        o = lambda x: x if isinstance(x, int) else ord(x)
+        _lib().hsgpu_pair_from_dverm(o(c1), o(c2), int(nocase), C.byref(c))
+        return cls(c)
+
+    @classmethod
+    def from_dverm_masked(cls, c1, c2, m1, m2):
+        c = _Pair()
+        _lib().hsgpu_pair_from_dverm_masked(c1, c2, m1, m2, C.byref(c))
+        return cls(c)
+
+    @classmethod
+    def build(cls, pairs=(), onechar=None):
+        """shuftiBuildDoubleMasks: `pairs` = iterable of (first, second) byte values, `onechar` = CharClass of
+        single bytes with a wildcard second byte. Raises HsgpuError(-4) when > 8 buckets are needed."""
+        c = _Pair()
+        flat = bytes(b for p in pairs for b in (p[0] if isinstance(p[0], int) else ord(p[0]),
+                                                p[1] if isinstance(p[1], int) else ord(p[1])))
+        oc = onechar._to_c() if onechar is not None else None
+        rv = _lib().hsgpu_pair_build(C.byref(oc) if oc is not None else None, flat, len(flat) // 2, C.byref(c))
+        if rv != 0:
+            raise HsgpuError(rv, _native.load_library().hsgpu_last_error().decode())
+        return cls(c)
+
+    def test(self, a, b):
+        return bool(_lib().hsgpu_pair_test(C.byref(self._c), a, b))
+
+
+def pair_scan(pairs, d_corpus, total, d_off=None, nblocks=0, want_first=True, want_last=False, stream=None):
+    """Evaluate <= 8 two-byte sets over a device-resident block batch (torch tensors).
+    -> (bitmaps uint8 [n][ceil(total/16)*2], first int32-view uint32 [n][nblocks] | None, last | None)"""
+    import torch
+
+    lib = _lib()
+    n = len(pairs)
+    assert 1 <= n <= PAIR_MAX
+    dev = d_corpus.device
+    arr = (_Pair * n)(*[p._c for p in pairs])
+    words = (total + 15) // 16
+    bitmaps = torch.empty((n, max(1, words) * 2), dtype=torch.uint8, device=dev)
+    work = torch.zeros(PAIR_WORK_BYTES, dtype=torch.uint8, device=dev)
+    first = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_first and nblocks) else None
+    last = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_last and nblocks) else None
+    ptrs = (C.c_void_p * n)(*[bitmaps[i].data_ptr() for i in range(n)])
+    st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    rv = lib.hsgpu_pair_scan_dev(arr, n, d_corpus.data_ptr(), total, d_off.data_ptr() if d_off is not None else None,
+                                 nblocks, ptrs, first.data_ptr() if first is not None else None,
+                                 last.data_ptr() if last is not None else None, work.data_ptr(), st)
+    if rv != 0:
+        raise HsgpuError(rv, "hsgpu_pair_scan_dev")
+    torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
+    return bitmaps, first, last

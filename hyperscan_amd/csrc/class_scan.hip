@@ -26,7 +26,10 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <array>
 #include <cstring>
+#include <map>
+#include <vector>
 
 #include "internal.h"
 
@@ -77,6 +80,29 @@ __global__ __launch_bounds__(CS_THREADS) void class_bitmap_kernel(const uint8_t 
     }
 }
 
+/* first / last set bit of a bitmap inside [lo, hi); 0xffffffff when none */
+__device__ __forceinline__ uint32_t first_bit(const uint16_t *bm, uint64_t lo, uint64_t hi) {
+    if (lo >= hi) return 0xffffffffu;
+    for (uint64_t w = lo >> 4; w <= (hi - 1) >> 4; w++) {
+        uint32_t m = bm[w];
+        if (w == lo >> 4) m &= 0xffffu << (lo & 15);
+        if (w == (hi - 1) >> 4) m &= 0xffffu >> (15 - ((hi - 1) & 15));
+        if (m) return (uint32_t)((w << 4) + __builtin_ctz(m) - lo);
+    }
+    return 0xffffffffu;
+}
+__device__ __forceinline__ uint32_t last_bit(const uint16_t *bm, uint64_t lo, uint64_t hi) {
+    if (lo >= hi) return 0xffffffffu;
+    for (uint64_t w = (hi - 1) >> 4;; w--) {
+        uint32_t m = bm[w];
+        if (w == lo >> 4) m &= 0xffffu << (lo & 15);
+        if (w == (hi - 1) >> 4) m &= 0xffffu >> (15 - ((hi - 1) & 15));
+        if (m) return (uint32_t)((w << 4) + 31 - __builtin_clz(m) - lo);
+        if (w == lo >> 4) break;
+    }
+    return 0xffffffffu;
+}
+
 /* first/last member of class c inside block b, from bitmap c */
 __global__ void class_first_last_kernel(const uint64_t *off, uint64_t nblocks, uint32_t n_classes,
                                         uint16_t *const *bitmaps, uint32_t *first, uint32_t *last) {
@@ -86,33 +112,90 @@ __global__ void class_first_last_kernel(const uint64_t *off, uint64_t nblocks, u
     const uint64_t b = i % nblocks;
     const uint64_t lo = off[b], hi = off[b + 1];
     const uint16_t *bm = bitmaps[c];
-    uint32_t f = (uint32_t)(hi - lo), l = 0xffffffffu;
     if (first) {
-        for (uint64_t w = lo >> 4; w <= (hi ? (hi - 1) >> 4 : 0) && lo < hi; w++) {
-            uint32_t m = bm[w];
-            if (w == lo >> 4) m &= 0xffffu << (lo & 15);
-            if (w == (hi - 1) >> 4) m &= 0xffffu >> (15 - ((hi - 1) & 15));
-            if (m) {
-                f = (uint32_t)((w << 4) + __builtin_ctz(m) - lo);
-                break;
+        const uint32_t f = first_bit(bm, lo, hi);
+        first[i] = f == 0xffffffffu ? (uint32_t)(hi - lo) : f;
+    }
+    if (last) last[i] = last_bit(bm, lo, hi);
+}
+
+/* ---- two-byte sets (double shufti / double vermicelli) --------------------------
+ * Table entry v: T1 (first uint4) field k (16 bits) = t_k(v), T2 (second uint4) field k =
+ * u_k(v); unused fields 0xff. A pair matches set k iff (t_k | u_k) != 0xff. */
+__global__ __launch_bounds__(CS_THREADS) void pair_bitmap_kernel(const uint8_t *corpus, uint64_t total,
+                                                                  const uint4 *lut /* [256][2] */, uint32_t n_pairs,
+                                                                  uint16_t *const *bitmaps) {
+    __shared__ __attribute__((aligned(16))) uint4 table[256 * 2];
+    for (uint32_t i = threadIdx.x; i < 256 * 2; i += CS_THREADS) table[i] = lut[i];
+    __syncthreads();
+    uint16_t *bm[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) bm[c] = bitmaps[c];
+    const uint64_t n_tiles = (total + CS_TILE - 1) / CS_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t off = tile * CS_TILE + (uint64_t)threadIdx.x * 16;
+        if (off >= total) continue;
+        uint32_t d[5] = {0, 0, 0, 0, 0};
+        uint32_t valid = 16; /* positions whose SECOND byte exists too */
+        if (off + 17 <= total) {
+            const uint4 v = *(const uint4 *)(corpus + off);
+            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+            d[4] = corpus[off + 16];
+        } else {
+            const uint32_t have = (uint32_t)(total - off); /* 1..16 */
+            for (uint32_t i = 0; i < have; i++) d[i >> 2] |= (uint32_t)corpus[off + i] << (8 * (i & 3));
+            valid = have - 1;
+        }
+        uint4 acc = make_uint4(0, 0, 0, 0);
+        uint4 t1 = table[2 * (d[0] & 0xffu)];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t nb = (d[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu;
+            const uint4 u = table[2 * nb + 1];
+            const uint4 v = make_uint4(t1.x | u.x, t1.y | u.y, t1.z | u.z, t1.w | u.w);
+            /* per 16-bit field: 1 iff its low byte is not 0xff */
+            auto alive = [](uint32_t x) { return (((~x & 0x00ff00ffu) + 0x00ff00ffu) >> 8) & 0x00010001u; };
+            acc.x |= alive(v.x) << j;
+            acc.y |= alive(v.y) << j;
+            acc.z |= alive(v.z) << j;
+            acc.w |= alive(v.w) << j;
+            t1 = table[2 * nb];
+        }
+        const uint32_t keep = valid >= 16 ? 0xffffu : ((1u << valid) - 1u);
+        const uint32_t f[8] = {acc.x & 0xffffu, acc.x >> 16, acc.y & 0xffffu, acc.y >> 16,
+                               acc.z & 0xffffu, acc.z >> 16, acc.w & 0xffffu, acc.w >> 16};
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            if ((uint32_t)c < n_pairs) bm[c][off >> 4] = (uint16_t)(f[c] & keep);
+    }
+}
+
+/* per (set, block): forward = first pair inside the block, else the partial match at the
+ * block's last byte, else len; reverse = second byte of the last pair */
+__global__ void pair_first_last_kernel(const uint8_t *corpus, const uint64_t *off, uint64_t nblocks, uint32_t n_pairs,
+                                       const uint4 *lut, uint16_t *const *bitmaps, uint32_t *first, uint32_t *last) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks * n_pairs) return;
+    const uint32_t k = (uint32_t)(i / nblocks);
+    const uint64_t b = i % nblocks;
+    const uint64_t lo = off[b], hi = off[b + 1];
+    const uint16_t *bm = bitmaps[k];
+    const uint64_t hi_pairs = hi > lo ? hi - 1 : lo; /* a pair's first byte: [lo, hi - 1) */
+    if (first) {
+        uint32_t f = first_bit(bm, lo, hi_pairs);
+        if (f == 0xffffffffu) {
+            f = (uint32_t)(hi - lo);
+            if (hi > lo) {
+                const uint32_t *t1 = (const uint32_t *)&lut[2 * corpus[hi - 1]];
+                const uint32_t tk = (t1[k >> 1] >> (16 * (k & 1))) & 0xffu;
+                if (tk != 0xffu) f -= 1;
             }
         }
         first[i] = f;
     }
     if (last) {
-        if (lo < hi) {
-            for (uint64_t w = (hi - 1) >> 4;; w--) {
-                uint32_t m = bm[w];
-                if (w == lo >> 4) m &= 0xffffu << (lo & 15);
-                if (w == (hi - 1) >> 4) m &= 0xffffu >> (15 - ((hi - 1) & 15));
-                if (m) {
-                    l = (uint32_t)((w << 4) + 31 - __builtin_clz(m) - lo);
-                    break;
-                }
-                if (w == lo >> 4) break;
-            }
-        }
-        last[i] = l;
+        const uint32_t l = last_bit(bm, lo, hi_pairs);
+        last[i] = l == 0xffffffffu ? l : l + 1;
     }
 }
 
@@ -227,6 +310,153 @@ extern "C" int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_cla
         const uint64_t n = nblocks * n_classes;
         hipLaunchKernelGGL(class_first_last_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            (const uint64_t *)d_off, nblocks, n_classes, d_ptrs, (uint32_t *)d_first, (uint32_t *)d_last);
+        HIP_TRY(hipGetLastError());
+    }
+    return HSGPU_SUCCESS;
+}
+
+/* ---- two-byte sets: construction ------------------------------------------------ */
+
+static void pair_clear(hsgpu_pair_t *p) { memset(p, 0xff, sizeof(*p)); }
+
+/* bucket `bit` accepts first bytes {lo nibble in la} x {hi nibble in ha} and second bytes
+ * {lb} x {hb} (16-bit nibble sets): clear the bucket's bit in the accepting mask entries */
+static void pair_add_bucket(hsgpu_pair_t *p, unsigned bit, uint16_t la, uint16_t ha, uint16_t lb, uint16_t hb) {
+    const uint8_t clr = (uint8_t)~(1u << bit);
+    for (unsigned n = 0; n < 16; n++) {
+        if (la >> n & 1) p->lo1[n] &= clr;
+        if (ha >> n & 1) p->hi1[n] &= clr;
+        if (lb >> n & 1) p->lo2[n] &= clr;
+        if (hb >> n & 1) p->hi2[n] &= clr;
+    }
+}
+
+extern "C" int hsgpu_pair_from_dshufti(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16],
+                                       const uint8_t hi2[16], hsgpu_pair_t *out) {
+    if (!lo1 || !hi1 || !lo2 || !hi2 || !out) return HSGPU_INVALID;
+    memcpy(out->lo1, lo1, 16);
+    memcpy(out->hi1, hi1, 16);
+    memcpy(out->lo2, lo2, 16);
+    memcpy(out->hi2, hi2, 16);
+    return HSGPU_SUCCESS;
+}
+
+/* {b : (b & m) == c} is a product of a low-nibble set and a high-nibble set */
+static void masked_byte_sets(uint8_t c, uint8_t m, uint16_t *lo, uint16_t *hi) {
+    *lo = *hi = 0;
+    for (unsigned n = 0; n < 16; n++) {
+        if ((n & (m & 15u)) == (c & 15u)) *lo |= (uint16_t)(1u << n);
+        if ((n & (m >> 4)) == (unsigned)(c >> 4)) *hi |= (uint16_t)(1u << n);
+    }
+}
+
+extern "C" int hsgpu_pair_from_dverm_masked(uint8_t c1, uint8_t c2, uint8_t m1, uint8_t m2, hsgpu_pair_t *out) {
+    if (!out) return HSGPU_INVALID;
+    pair_clear(out); /* (b & m) == c, vermicelli.h:241-317; an unsatisfiable c leaves the set empty */
+    uint16_t la, ha, lb, hb;
+    masked_byte_sets(c1, m1, &la, &ha);
+    masked_byte_sets(c2, m2, &lb, &hb);
+    if ((c1 & ~m1) || (c2 & ~m2)) return HSGPU_SUCCESS;
+    pair_add_bucket(out, 0, la, ha, lb, hb);
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_pair_from_dverm(uint8_t c1, uint8_t c2, int nocase, hsgpu_pair_t *out) {
+    auto alpha = [](uint8_t c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+    /* caseless: compare with CASE_CLEAR (0xdf) on alphabetic bytes, vermicelli.h:169-239 */
+    const uint8_t m1 = (nocase && alpha(c1)) ? 0xdf : 0xff, m2 = (nocase && alpha(c2)) ? 0xdf : 0xff;
+    return hsgpu_pair_from_dverm_masked(c1 & m1, c2 & m2, m1, m2, out);
+}
+
+/* Bucketing as the reference does it (shufticompile.cpp:135-209): every sequence starts as a
+ * rectangle of four single-nibble sets; rectangles that agree in three of the four sets are
+ * merged by uniting the fourth, one dimension after the other. Exact (no over-approximation). */
+extern "C" int hsgpu_pair_build(const hsgpu_class_t *onechar, const uint8_t *pairs, size_t npairs, hsgpu_pair_t *out) {
+    if (!out || (npairs && !pairs)) return HSGPU_INVALID;
+    typedef std::array<uint16_t, 4> Rect;
+    std::vector<Rect> rects;
+    for (size_t i = 0; i < npairs; i++) {
+        const uint8_t a = pairs[2 * i], b = pairs[2 * i + 1];
+        rects.push_back(Rect{{(uint16_t)(1u << (a & 15)), (uint16_t)(1u << (a >> 4)), (uint16_t)(1u << (b & 15)),
+                              (uint16_t)(1u << (b >> 4))}});
+    }
+    if (onechar)
+        for (unsigned v = 0; v < 256; v++)
+            if (onechar->bitmap[v >> 3] >> (v & 7) & 1)
+                rects.push_back(Rect{{(uint16_t)(1u << (v & 15)), (uint16_t)(1u << (v >> 4)), 0xffff, 0xffff}});
+    for (int dim = 0; dim < 4; dim++) {
+        std::map<Rect, uint16_t> merged; /* the other three sets -> union of this one */
+        for (const Rect &r : rects) {
+            Rect key = r;
+            key[dim] = 0;
+            merged[key] |= r[dim];
+        }
+        rects.clear();
+        for (const auto &kv : merged) {
+            Rect r = kv.first;
+            r[dim] = kv.second;
+            rects.push_back(r);
+        }
+    }
+    if (rects.size() > HSGPU_PAIR_MAX) {
+        hsgpu_set_error("two-byte set needs %zu buckets (> 8)", rects.size());
+        return HSGPU_COMPILER_ERROR;
+    }
+    pair_clear(out);
+    for (size_t i = 0; i < rects.size(); i++) pair_add_bucket(out, (unsigned)i, rects[i][0], rects[i][1], rects[i][2], rects[i][3]);
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_pair_test(const hsgpu_pair_t *p, uint8_t a, uint8_t b) {
+    if (!p) return 0;
+    return (uint8_t)(p->lo1[a & 15] | p->hi1[a >> 4] | p->lo2[b & 15] | p->hi2[b >> 4]) != 0xff;
+}
+
+extern "C" int hsgpu_pair_scan_dev(const hsgpu_pair_t *pairs, unsigned n_pairs, const void *d_corpus,
+                                   uint64_t total_bytes, const void *d_off, uint64_t nblocks, void *const *d_bitmaps,
+                                   void *d_first, void *d_last, void *d_work, void *stream) {
+    if (!pairs || n_pairs == 0 || n_pairs > HSGPU_PAIR_MAX || !d_bitmaps || !d_work) return HSGPU_INVALID;
+    if (((uintptr_t)d_corpus & 15) || ((uintptr_t)d_work & 15)) return HSGPU_INVALID;
+    if ((d_first || d_last) && (!d_off || nblocks == 0)) return HSGPU_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    /* entry v: [T1: 8 x 16-bit fields t_k(v)] [T2: 8 x 16-bit fields u_k(v)]; unused sets 0xff (dead) */
+    uint32_t lut[256][8];
+    for (unsigned v = 0; v < 256; v++) {
+        for (unsigned w = 0; w < 8; w++) lut[v][w] = 0x00ff00ffu;
+        for (unsigned k = 0; k < n_pairs; k++) {
+            const uint32_t t = pairs[k].lo1[v & 15] | pairs[k].hi1[v >> 4];
+            const uint32_t u = pairs[k].lo2[v & 15] | pairs[k].hi2[v >> 4];
+            const unsigned sh = 16 * (k & 1);
+            lut[v][k >> 1] = (lut[v][k >> 1] & ~(0xffffu << sh)) | t << sh;
+            lut[v][4 + (k >> 1)] = (lut[v][4 + (k >> 1)] & ~(0xffffu << sh)) | u << sh;
+        }
+    }
+    uint8_t *work = (uint8_t *)d_work;
+    void *ptrs[8] = {nullptr};
+    for (unsigned k = 0; k < n_pairs; k++) {
+        if (!d_bitmaps[k] || ((uintptr_t)d_bitmaps[k] & 1)) return HSGPU_INVALID;
+        ptrs[k] = d_bitmaps[k];
+    }
+    static_assert(sizeof(lut) + sizeof(ptrs) == HSGPU_PAIR_WORK_BYTES, "work area layout");
+    HIP_TRY(hipMemcpyAsync(work, lut, sizeof(lut), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(work + sizeof(lut), ptrs, sizeof(ptrs), hipMemcpyHostToDevice, st));
+    if (total_bytes == 0) return HSGPU_SUCCESS;
+    const uint4 *d_lut = (const uint4 *)work;
+    uint16_t *const *d_ptrs = (uint16_t *const *)(work + sizeof(lut));
+    int dev = 0, n_cu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    const uint64_t n_tiles = (total_bytes + CS_TILE - 1) / CS_TILE;
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)n_cu * 2);
+    const uint8_t *corpus = (const uint8_t *)d_corpus;
+    hipLaunchKernelGGL(pair_bitmap_kernel, dim3(grid), dim3(CS_THREADS), 0, st, corpus, total_bytes, d_lut, n_pairs, d_ptrs);
+    HIP_TRY(hipGetLastError());
+    if (d_first || d_last) {
+        const uint64_t n = nblocks * n_pairs;
+        hipLaunchKernelGGL(pair_first_last_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, corpus,
+                           (const uint64_t *)d_off, nblocks, n_pairs, d_lut, d_ptrs, (uint32_t *)d_first,
+                           (uint32_t *)d_last);
         HIP_TRY(hipGetLastError());
     }
     return HSGPU_SUCCESS;

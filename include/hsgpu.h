@@ -204,6 +204,48 @@ int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_classes, const
                          uint64_t total_bytes, const void *d_off, uint64_t nblocks, void *const *d_bitmaps,
                          void *d_first, void *d_last, void *d_work, void *stream);
 
+/* ---- two-byte accelerators ---------------------------------------------------------
+ * shuftiDoubleExec (src/nfa/shufti.c:319-361), vermicelliDoubleExec /
+ * vermicelliDoubleMaskedExec / rvermicelliDoubleExec (src/nfa/vermicelli.h:169-317,464-518).
+ * Every one of them tests byte PAIRS against a union of <= 8 "rectangles" (a set of first
+ * bytes x a set of second bytes, each a product of a low-nibble set and a high-nibble set),
+ * which is exactly what double-shufti masks encode (0-active, one bit per bucket):
+ *   t(c) = lo1[c & 15] | hi1[c >> 4],   u(c) = lo2[c & 15] | hi2[c >> 4]
+ *   (buf[i], buf[i+1]) matches  <=>  (t(buf[i]) | u(buf[i+1])) != 0xff
+ * Forward result per block (the accelerators' return value relative to the block start):
+ * the first matching i; else len - 1 when the last byte alone passes t (the "partial match
+ * at end" of vermicelli.h:179-186, which the caller re-examines); else len.
+ * The reference's shuftiDoubleExec may stop EARLIER than that, at a first-byte-only hit in
+ * the last lane of one of its 16-byte vectors (shufti.c:224): an artefact of its vector
+ * width that callers tolerate by design (run_accel only promises not to skip a match).
+ * Reverse result: offset of the SECOND byte of the last pair, 0xffffffff when none
+ * (unit/internal/rvermicelli.cpp:116-140). */
+#define HSGPU_PAIR_MAX 8
+#define HSGPU_PAIR_WORK_BYTES 8256 /* device work area for hsgpu_pair_scan_dev */
+
+typedef struct hsgpu_pair {
+    uint8_t lo1[16], hi1[16], lo2[16], hi2[16];
+} hsgpu_pair_t;
+
+int hsgpu_pair_from_dshufti(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16],
+                            const uint8_t hi2[16], hsgpu_pair_t *out);
+int hsgpu_pair_from_dverm(uint8_t c1, uint8_t c2, int nocase, hsgpu_pair_t *out);
+int hsgpu_pair_from_dverm_masked(uint8_t c1, uint8_t c2, uint8_t m1, uint8_t m2, hsgpu_pair_t *out);
+/* shuftiBuildDoubleMasks (src/nfa/shufticompile.cpp:135-209): masks for npairs two-byte
+ * sequences (pairs[2i], pairs[2i+1]) plus the single bytes of `onechar` (may be NULL) with
+ * any second byte. HSGPU_COMPILER_ERROR when more than 8 buckets would be needed. */
+int hsgpu_pair_build(const hsgpu_class_t *onechar, const uint8_t *pairs, size_t npairs, hsgpu_pair_t *out);
+/* Does the pair (a, b) match? (host-side decode, for tests and callers' own checks) */
+int hsgpu_pair_test(const hsgpu_pair_t *p, uint8_t a, uint8_t b);
+
+/* n_pairs <= 8 pair sets over a block batch, asynchronously on `stream`. d_bitmaps[k]:
+ * (total_bytes + 15) / 16 * 2 bytes; bit i <=> (corpus[i], corpus[i+1]) matches set k
+ * (i + 1 < total_bytes; the bitmap knows no block boundaries). d_first / d_last (optional,
+ * uint32 [n_pairs][nblocks]) as described above, pairs never straddle two blocks. */
+int hsgpu_pair_scan_dev(const hsgpu_pair_t *pairs, unsigned n_pairs, const void *d_corpus, uint64_t total_bytes,
+                        const void *d_off, uint64_t nblocks, void *const *d_bitmaps, void *d_first, void *d_last,
+                        void *d_work, void *stream);
+
 const char *hsgpu_last_error(void);
 const char *hsgpu_version(void);
 

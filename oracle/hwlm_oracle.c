@@ -394,3 +394,115 @@ int64_t hso_dverm_fwd(uint8_t c1, uint8_t c2, int nocase, const uint8_t *buf, si
     if (len && (buf[len - 1] & m1) == (c1 & m1)) return (int64_t)len - 1;
     return (int64_t)len;
 }
+
+/* masked double vermicelli (vermicelli.h:241-317): first i with (buf[i] & m1) == c1 and
+ * (buf[i+1] & m2) == c2; a final byte with (b & m1) == c1 is reported as a partial match. */
+int64_t hso_dverm_masked_fwd(uint8_t c1, uint8_t c2, uint8_t m1, uint8_t m2, const uint8_t *buf, size_t len) {
+    for (size_t i = 0; i + 1 < len; i++) {
+        if ((buf[i] & m1) == c1 && (buf[i + 1] & m2) == c2) return (int64_t)i;
+    }
+    if (len && (buf[len - 1] & m1) == c1) return (int64_t)len - 1;
+    return (int64_t)len;
+}
+/* reverse double vermicelli (vermicelli.h:464-518, vermicelli_sse.h:325-341): the position of
+ * the SECOND byte of the last c1 c2 pair (unit/internal/rvermicelli.cpp:116-140), -1 if none;
+ * no partial-match rule in this direction. */
+int64_t hso_rdverm(uint8_t c1, uint8_t c2, int nocase, const uint8_t *buf, size_t len) {
+    uint8_t m1 = (nocase && is_alpha(c1)) ? 0xdf : 0xff, m2 = (nocase && is_alpha(c2)) ? 0xdf : 0xff;
+    for (size_t i = len; i-- > 1;) {
+        if ((buf[i - 1] & m1) == (c1 & m1) && (buf[i] & m2) == (c2 & m2)) return (int64_t)i;
+    }
+    return -1;
+}
+/* The reference's own return value for the reverse double scan. It is a reverse
+ * ACCELERATOR: the result r promises "no pair ends in (r, len)"; the head of the buffer
+ * below the last 16-byte boundary it visits is simply not examined and that boundary is
+ * returned (rdvermSearchAligned's final `return buf_end`, vermicelli_sse.h:325-341), so r is
+ * never below hso_rdverm and equals it whenever the pair lies in the examined part.
+ * `align` = buf mod 16. Needs len >= 16 (vermicelli.h:488). */
+int64_t hso_rdverm_ref_model(uint8_t c1, uint8_t c2, int nocase, const uint8_t *buf, size_t len, unsigned align) {
+    /* "nonalphas and nocase having interesting behaviour": caseless compares BOTH bytes with 0xdf */
+    const uint8_t m = nocase ? 0xdf : 0xff;
+    int64_t end = (int64_t)len;
+    const unsigned min = (unsigned)((align + len) & 15);
+    if (min) { /* unaligned tail vector [end-16, end): pairs inside it only (vermicelli_sse.h:367-378) */
+        for (int64_t i = end - 1; i >= end - 15; i--)
+            if ((buf[i] & m) == c2 && (buf[i - 1] & m) == c1) return i;
+        end -= min;
+        if (end <= 0) return end;
+    }
+    for (; 16 < end; end -= 16) { /* aligned vectors, plus the pair straddling the vector's start */
+        for (int64_t i = end - 1; i >= end - 16; i--)
+            if ((buf[i] & m) == c2 && (buf[i - 1] & m) == c1) return i;
+    }
+    return end;
+}
+
+/* double shufti (shufti.c:205-236 fwdBlock2, :286-361): masks are 0-active, one bit per
+ * bucket (<= 8 buckets of byte-pair "rectangles", shufticompile.cpp:135-209):
+ *   t(c) = lo1[c & 15] | hi1[c >> 4],  u(c) = lo2[c & 15] | hi2[c >> 4]
+ * the pair (buf[i], buf[i+1]) matches iff (t(buf[i]) | u(buf[i+1])) != 0xff.
+ * EXACT form: the first matching i, else len - 1 if the last byte alone passes t (a partial
+ * match the caller re-examines, as in double vermicelli), else len. */
+static uint8_t dsh_t(const uint8_t lo[16], const uint8_t hi[16], uint8_t c) { return lo[c & 15] | hi[c >> 4]; }
+int64_t hso_dshufti_fwd(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16],
+                        const uint8_t hi2[16], const uint8_t *buf, size_t len) {
+    for (size_t i = 0; i + 1 < len; i++) {
+        if ((dsh_t(lo1, hi1, buf[i]) | dsh_t(lo2, hi2, buf[i + 1])) != 0xff) return (int64_t)i;
+    }
+    if (len && dsh_t(lo1, hi1, buf[len - 1]) != 0xff) return (int64_t)len - 1;
+    return (int64_t)len;
+}
+/* The reference's own return value, which also depends on where its vectors end: the last
+ * byte of every 128-bit lane it loads is tested with t alone (rshiftbyte_m128 /
+ * rshift128_m256 shift a zero = "all buckets alive" into lane byte 15, shufti.c:224,647), so
+ * a first-byte-only hit there ends the scan early. Vectors of `width` bytes (16: SSE build,
+ * shufti.c:319-361; 32: AVX2 build, :696-752): [buf, buf+width), then width-aligned ones below
+ * buf_end - width, then [buf_end-width, buf_end); the AVX2 build scans buffers shorter than 32
+ * as two 16-byte vectors (shuftiDoubleShort, :676-694). `align` = buf mod 64.
+ * Conservative either way: never later than hso_dshufti_fwd. Needs len >= 16. */
+static int64_t dsh_vec(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16], const uint8_t hi2[16],
+                       const uint8_t *buf, size_t v, size_t width) {
+    for (size_t j = 0; j < width; j++) {
+        const size_t i = v + j;
+        const uint8_t t = dsh_t(lo1, hi1, buf[i]);
+        const uint8_t u = (j & 15) < 15 ? dsh_t(lo2, hi2, buf[i + 1]) : 0;
+        if ((t | u) != 0xff) return (int64_t)i;
+    }
+    return -1;
+}
+int64_t hso_dshufti_ref_model(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16],
+                              const uint8_t hi2[16], const uint8_t *buf, size_t len, unsigned align,
+                              unsigned width) {
+    int64_t r;
+    if (width == 32 && len < 32) {
+        if ((r = dsh_vec(lo1, hi1, lo2, hi2, buf, 0, 16)) >= 0) return r;
+        if ((r = dsh_vec(lo1, hi1, lo2, hi2, buf, len - 16, 16)) >= 0) return r;
+        return (int64_t)len;
+    }
+    if ((r = dsh_vec(lo1, hi1, lo2, hi2, buf, 0, width)) >= 0) return r;
+    size_t pos = width - (align % width);
+    while (pos + width < len) { /* buf < last_block */
+        if ((r = dsh_vec(lo1, hi1, lo2, hi2, buf, pos, width)) >= 0) return r;
+        pos += width;
+    }
+    if ((r = dsh_vec(lo1, hi1, lo2, hi2, buf, len - width, width)) >= 0) return r;
+    return (int64_t)len;
+}
+/* pair-membership bitmap: bit i <=> (buf[i], buf[i+1]) matches, i + 1 < len */
+void hso_dshufti_bitmap(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16],
+                        const uint8_t hi2[16], const uint8_t *buf, size_t len, uint8_t *out) {
+    memset(out, 0, (len + 7) / 8);
+    for (size_t i = 0; i + 1 < len; i++) {
+        if ((dsh_t(lo1, hi1, buf[i]) | dsh_t(lo2, hi2, buf[i + 1])) != 0xff) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+}
+/* last pair in the block: position of its second byte (the reverse double-vermicelli
+ * convention), -1 if none */
+int64_t hso_dshufti_rev(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16],
+                        const uint8_t hi2[16], const uint8_t *buf, size_t len) {
+    for (size_t i = len; i-- > 1;) {
+        if ((dsh_t(lo1, hi1, buf[i - 1]) | dsh_t(lo2, hi2, buf[i])) != 0xff) return (int64_t)i;
+    }
+    return -1;
+}

@@ -294,6 +294,27 @@ int64_t hsref_rverm_exec(uint8_t c, int nocase, const uint8_t *buf, size_t len) 
     return rvermicelliExec((char)c, (char)nocase, buf, buf + len) - buf;
 }
 
+/* double shufti: masks for a set of 2-byte sequences plus single bytes whose second
+ * byte is a wildcard (shuftiBuildDoubleMasks, src/nfa/shufticompile.cpp:135-209);
+ * returns 1 on success, 0 when more than 8 buckets would be needed. */
+int hsref_dshufti_build(const uint8_t onechar[32], const uint8_t *pairs, size_t npairs,
+                        uint8_t lo1[16], uint8_t hi1[16], uint8_t lo2[16], uint8_t hi2[16]) {
+    flat_set<std::pair<u8, u8>> two;
+    for (size_t i = 0; i < npairs; i++) two.insert(std::make_pair(pairs[2 * i], pairs[2 * i + 1]));
+    return shuftiBuildDoubleMasks(to_cr(onechar), two, lo1, hi1, lo2, hi2) ? 1 : 0;
+}
+int64_t hsref_dshufti_exec(const uint8_t lo1[16], const uint8_t hi1[16], const uint8_t lo2[16],
+                           const uint8_t hi2[16], const uint8_t *buf, size_t len) {
+    return shuftiDoubleExec(ld128(lo1), ld128(hi1), ld128(lo2), ld128(hi2), buf, buf + len) - buf;
+}
+int64_t hsref_dverm_masked_exec(uint8_t c1, uint8_t c2, uint8_t m1, uint8_t m2, const uint8_t *buf,
+                                size_t len) {
+    return vermicelliDoubleMaskedExec((char)c1, (char)c2, (char)m1, (char)m2, buf, buf + len) - buf;
+}
+int64_t hsref_rdverm_exec(uint8_t c1, uint8_t c2, int nocase, const uint8_t *buf, size_t len) {
+    return rvermicelliDoubleExec((char)c1, (char)c2, (char)nocase, buf, buf + len) - buf;
+}
+
 /* which engine ids are valid for hints on this host (unit/internal/fdr.cpp:114-137) */
 size_t hsref_valid_engines(uint32_t *out, size_t cap, int isa) {
     target_t target = make_target(isa);

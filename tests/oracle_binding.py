@@ -62,6 +62,19 @@ def hso():
             f.argtypes = [C.c_uint8, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.hso_dverm_fwd.restype = C.c_int64
         L.hso_dverm_fwd.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t]
+        L.hso_rdverm.restype = C.c_int64
+        L.hso_rdverm.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t]
+        L.hso_rdverm_ref_model.restype = C.c_int64
+        L.hso_rdverm_ref_model.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t, C.c_uint]
+        L.hso_dverm_masked_fwd.restype = C.c_int64
+        L.hso_dverm_masked_fwd.argtypes = [C.c_uint8] * 4 + [C.c_void_p, C.c_size_t]
+        for name in ("hso_dshufti_fwd", "hso_dshufti_rev"):
+            f = getattr(L, name)
+            f.restype = C.c_int64
+            f.argtypes = [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t]
+        L.hso_dshufti_ref_model.restype = C.c_int64
+        L.hso_dshufti_ref_model.argtypes = [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint]
+        L.hso_dshufti_bitmap.argtypes = [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
         _hso = L
     return _hso
 
@@ -156,6 +169,14 @@ def href():
             f.argtypes = [C.c_uint8, C.c_int, C.c_void_p, C.c_size_t]
         L.hsref_dverm_exec.restype = C.c_int64
         L.hsref_dverm_exec.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t]
+        L.hsref_dshufti_build.restype = C.c_int
+        L.hsref_dshufti_build.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
+        L.hsref_dshufti_exec.restype = C.c_int64
+        L.hsref_dshufti_exec.argtypes = [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t]
+        L.hsref_dverm_masked_exec.restype = C.c_int64
+        L.hsref_dverm_masked_exec.argtypes = [C.c_uint8] * 4 + [C.c_void_p, C.c_size_t]
+        L.hsref_rdverm_exec.restype = C.c_int64
+        L.hsref_rdverm_exec.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t]
         L.hsref_valid_engines.restype = C.c_size_t
         L.hsref_valid_engines.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
         _ref = L

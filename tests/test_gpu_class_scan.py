@@ -126,3 +126,102 @@ def test_vermicelli_semantics():
         if ob.ref_available() and not negate:
             R = ob.href()
             assert int(first.cpu().numpy()[0, 0]) == R.hsref_verm_exec(ch, nocase, buf.ctypes.data, buf.size)
+
+
+# ---- two-byte accelerators (double shufti / double vermicelli) ---------------------------
+
+def _pair_for(kind, params):
+    if kind == "dverm" or kind == "rdverm":
+        return accel.PairSet.from_dverm(*params)
+    if kind == "dverm_masked":
+        return accel.PairSet.from_dverm_masked(*params)
+    if kind == "dshufti":
+        return accel.PairSet.build(params)
+    raise AssertionError(kind)
+
+
+def test_pair_scan_reference_unit_test_vectors():
+    """Every two-byte golden vector (tests/golden_accel.py, from unit/internal/{vermicelli,
+    rvermicelli,shufti}.cpp): each scanned slice is one block of a batch; all slices that
+    share a set are scanned in one launch."""
+    import torch
+
+    from tests import golden_accel as ga
+    from tests.test_oracle_accel import expected
+
+    groups = {}
+    for case in ga.cases():
+        name, kind, params, text, lo, hi, _ = case
+        if kind in ("dverm", "dverm_masked", "rdverm", "dshufti"):
+            groups.setdefault((kind, params), []).append(case)
+    assert len(groups) >= 25
+    checked = 0
+    for (kind, params), cs in groups.items():
+        blocks = [c[3][c[4]: len(c[3]) - c[5]] for c in cs]
+        corpus = np.frombuffer(b"".join(blocks), dtype=np.uint8)
+        off = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.uint64)
+        d = torch.from_numpy(corpus.copy()).to("cuda:0")
+        d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+        _bm, first, last = accel.pair_scan([_pair_for(kind, params)], d, corpus.size, d_off, len(blocks), True, True)
+        got = (last if kind == "rdverm" else first).cpu().numpy().view(np.uint32)[0]
+        for b, case in enumerate(cs):
+            assert int(got[b]) == (expected(case) & 0xFFFFFFFF), case[0]
+            checked += 1
+    assert checked > 400
+
+
+def test_pair_scan_random_sets_match_oracle():
+    import torch
+
+    rng = np.random.default_rng(12)
+    alpha = np.frombuffer(b"abcdABCD01 \n\x80\xff", dtype=np.uint8)
+    total = 300_007
+    corpus = rng.choice(alpha, total).astype(np.uint8)
+    lens = rng.choice([0, 1, 2, 3, 15, 16, 17, 40, 200, 1500], 3000)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    off = np.unique(np.concatenate([off[off < total], [total]])).astype(np.uint64)
+    off = np.sort(np.concatenate([off, off[5:8]]))  # a few empty blocks
+    nb = off.size - 1
+    sets = [accel.PairSet.from_dverm(ord("a"), ord("b"), 0), accel.PairSet.from_dverm(ord("A"), ord("B"), 1),
+            accel.PairSet.from_dverm_masked(0x30, 0x0A, 0xF0, 0xFF),
+            accel.PairSet.build([(ord("a"), ord("a")), (ord("B"), ord("a")), (0x80, 0xFF)]),
+            accel.PairSet.build([(ord("0"), ord("1"))], accel.CharClass([0xFF])),
+            accel.PairSet.build([(int(rng.choice(alpha)), int(rng.choice(alpha))) for _ in range(4)])]
+    d = torch.from_numpy(corpus).to("cuda:0")
+    d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+    bitmaps, first, last = accel.pair_scan(sets, d, total, d_off, nb, True, True)
+    bm = bitmaps.cpu().numpy()
+    fi = first.cpu().numpy().view(np.uint32)
+    la = last.cpu().numpy().view(np.uint32)
+    L = ob.hso()
+    for k, ps in enumerate(sets):
+        m = ps.masks
+        want = np.zeros((total + 7) // 8, dtype=np.uint8)
+        L.hso_dshufti_bitmap(*m, corpus.ctypes.data, total, want.ctypes.data)
+        assert np.array_equal(bm[k][: want.size], want), k
+        for b in list(range(0, nb, 7)) + [nb - 1]:
+            blk = np.ascontiguousarray(corpus[int(off[b]):int(off[b + 1])])
+            assert fi[k, b] == L.hso_dshufti_fwd(*m, blk.ctypes.data, blk.size), (k, b)
+            assert la[k, b] == (L.hso_dshufti_rev(*m, blk.ctypes.data, blk.size) & 0xFFFFFFFF), (k, b)
+    if ob.ref_available():  # never later than the reference's (vector-width dependent) answer allows
+        R = ob.href()
+        m = sets[0].masks
+        for b in range(0, nb, 11):
+            blk = np.ascontiguousarray(corpus[int(off[b]):int(off[b + 1])])
+            if blk.size >= 32:
+                assert R.hsref_dshufti_exec(*m, blk.ctypes.data, blk.size) <= fi[0, b]
+
+
+@pytest.mark.parametrize("total", [1, 2, 16, 17, 16384, 16385])
+def test_pair_scan_tile_edges(total):
+    import torch
+
+    buf = np.full(total, ord("a"), dtype=np.uint8)
+    ps = accel.PairSet.from_dverm(ord("a"), ord("a"), 0)
+    d = torch.from_numpy(buf).to("cuda:0")
+    d_off = torch.from_numpy(np.array([0, total], dtype=np.int64)).to("cuda:0")
+    bitmaps, first, last = accel.pair_scan([ps], d, total, d_off, 1, True, True)
+    bits = np.unpackbits(bitmaps.cpu().numpy()[0], bitorder="little")[:total]
+    assert bits[: total - 1].all() and not bits[total - 1]  # the last byte has no successor
+    assert int(first.cpu().numpy().view(np.uint32)[0, 0]) == 0
+    assert int(last.cpu().numpy().view(np.uint32)[0, 0]) == (total - 1 if total > 1 else 0xFFFFFFFF)
