@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <set>
 #include <string>
 #include <vector>
@@ -46,6 +47,8 @@ struct Pattern {
     unsigned id = 0;
     std::vector<Unit> tail;   /* empty: pure literal */
     bool tail_nullable = true;
+    /* hs_expr_ext_t (src/hs_compile.h:244-310): bounds on `to` and on the match length */
+    unsigned long long ext_flags = 0, min_offset = 0, max_offset = 0, min_length = 0;
 };
 
 struct ParseError {
@@ -318,6 +321,7 @@ struct hs_database {
     std::vector<std::string> sources; /* for serialisation: original expressions + flags */
     std::vector<unsigned> src_flags, src_ids;
     std::vector<unsigned char> src_is_lit;
+    std::vector<hs_expr_ext_t> src_ext; /* flags == 0: none */
 };
 
 struct hs_scratch {
@@ -329,24 +333,74 @@ struct hs_scratch {
 
 namespace {
 
+/* allocation hooks, src/alloc.c / src/hs_common.h:273-439 */
+struct Hooks {
+    hs_alloc_t alloc = nullptr;
+    hs_free_t free = nullptr;
+};
+Hooks g_db, g_misc, g_scratch, g_stream;
+void *hook_alloc(const Hooks &h, size_t n) { return h.alloc ? h.alloc(n) : malloc(n); }
+void hook_free(const Hooks &h, void *p) {
+    if (!p) return;
+    if (h.free) h.free(p);
+    else free(p);
+}
+/* hs_check_alloc, src/alloc.c: NULL -> HS_NOMEM, misaligned -> HS_BAD_ALIGN */
+hs_error_t check_alloc(const void *p) {
+    if (!p) return HS_NOMEM;
+    return ((uintptr_t)p & 7) ? HS_BAD_ALIGN : HS_SUCCESS;
+}
+char *misc_strdup(const std::string &sv) {
+    char *m = (char *)hook_alloc(g_misc, sv.size() + 1);
+    if (m) memcpy(m, sv.c_str(), sv.size() + 1);
+    return m;
+}
+
 hs_compile_error_t *make_error(const std::string &msg, int expr) {
-    hs_compile_error_t *e = (hs_compile_error_t *)malloc(sizeof(*e));
+    hs_compile_error_t *e = (hs_compile_error_t *)hook_alloc(g_misc, sizeof(*e));
     if (!e) return nullptr;
-    e->message = strdup(msg.c_str());
+    e->message = misc_strdup(msg);
     e->expression = expr;
     return e;
 }
 
+void destroy_db(hs_database *d);
+
+/* hs_expr_ext_t validation as in src/compiler/compiler.cpp:97-130 (flags known, bounds
+ * consistent); approximate matching belongs to the graph compiler and is refused */
+void apply_ext(Pattern &p, const hs_expr_ext_t &e) {
+    const unsigned long long known = HS_EXT_FLAG_MIN_OFFSET | HS_EXT_FLAG_MAX_OFFSET | HS_EXT_FLAG_MIN_LENGTH |
+                                     HS_EXT_FLAG_EDIT_DISTANCE | HS_EXT_FLAG_HAMMING_DISTANCE;
+    if (e.flags & ~known) throw ParseError{"Invalid hs_expr_ext flag set."};
+    if (e.flags & (HS_EXT_FLAG_EDIT_DISTANCE | HS_EXT_FLAG_HAMMING_DISTANCE))
+        throw ParseError{"Approximate matching (edit/Hamming distance) is not supported by the GPU literal engine."};
+    if ((e.flags & HS_EXT_FLAG_MIN_OFFSET) && (e.flags & HS_EXT_FLAG_MAX_OFFSET) && e.min_offset > e.max_offset)
+        throw ParseError{"In hs_expr_ext, min_offset must be less than or equal to max_offset."};
+    if ((e.flags & HS_EXT_FLAG_MIN_LENGTH) && (e.flags & HS_EXT_FLAG_MAX_OFFSET) && e.min_length > e.max_offset)
+        throw ParseError{"In hs_expr_ext, min_length must be less than or equal to max_offset."};
+    p.ext_flags = e.flags;
+    p.min_offset = e.min_offset;
+    p.max_offset = e.max_offset;
+    p.min_length = e.min_length;
+}
+
 hs_error_t build_database(const std::vector<std::string> &exprs, const std::vector<unsigned char> &is_lit,
-                          const unsigned *flags, const unsigned *ids, unsigned mode, hs_database_t **db,
-                          hs_compile_error_t **error) {
+                          const unsigned *flags, const unsigned *ids, const hs_expr_ext_t *const *ext, unsigned mode,
+                          hs_database_t **db, hs_compile_error_t **error) {
     if (mode != HS_MODE_BLOCK) {
         *error = make_error((mode & (HS_MODE_STREAM | HS_MODE_VECTORED))
                                 ? "Only HS_MODE_BLOCK is supported by the GPU literal engine."
                                 : "Invalid parameter: unrecognised mode flags.", -1);
         return HS_COMPILER_ERROR;
     }
-    hs_database *d = new hs_database;
+    void *mem = hook_alloc(g_db, sizeof(hs_database));
+    if (hs_error_t ae = check_alloc(mem)) {
+        hook_free(g_db, mem);
+        *error = make_error(ae == HS_BAD_ALIGN ? "Database allocator returned misaligned memory."
+                                               : "Unable to allocate memory.", -1);
+        return HS_COMPILER_ERROR;
+    }
+    hs_database *d = new (mem) hs_database;
     std::vector<std::string> hw_s;
     try {
         for (size_t i = 0; i < exprs.size(); i++) {
@@ -370,9 +424,10 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                 } else {
                     d->pats.push_back(parse_pattern(exprs[i], f, id));
                 }
+                if (ext && ext[i]) apply_ext(d->pats.back(), *ext[i]);
             } catch (const ParseError &pe) {
                 *error = make_error(pe.msg, (int)i);
-                delete d;
+                destroy_db(d);
                 return HS_COMPILER_ERROR;
             }
         }
@@ -396,11 +451,11 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         int rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
         if (rv != HSGPU_SUCCESS) {
             *error = make_error(hsgpu_last_error(), -1);
-            delete d;
+            destroy_db(d);
             return HS_COMPILER_ERROR;
         }
     } catch (const std::bad_alloc &) {
-        delete d;
+        destroy_db(d);
         *error = make_error("Unable to allocate memory.", -1);
         return HS_COMPILER_ERROR;
     }
@@ -409,10 +464,20 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
     for (size_t i = 0; i < exprs.size(); i++) {
         d->src_flags.push_back(flags ? flags[i] : 0);
         d->src_ids.push_back(ids ? ids[i] : 0);
+        hs_expr_ext_t none;
+        memset(&none, 0, sizeof(none));
+        d->src_ext.push_back(ext && ext[i] ? *ext[i] : none);
     }
     *db = d;
     *error = nullptr;
     return HS_SUCCESS;
+}
+
+void destroy_db(hs_database *d) {
+    if (!d) return;
+    hsgpu_hwlm_free(d->hwlm);
+    d->~hs_database();
+    hook_free(g_db, d);
 }
 
 bool lit_matches_at(const Pattern &p, const unsigned char *buf, size_t end /* offset after the literal */) {
@@ -445,12 +510,21 @@ bool confirm_block(const hs_database *db, const unsigned char *buf, size_t len, 
         const Pattern &p = db->pats[recs[k].id];
         const size_t lit_end = (size_t)recs[k].end + 1;
         if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
-        const unsigned long long from = p.som ? lit_end - p.lit.size() : 0;
+        const unsigned long long start = lit_end - p.lit.size();
+        const unsigned long long from = p.som ? start : 0;
+        /* hs_expr_ext_t bounds: the job of the reference's CHECK_BOUNDS / CHECK_MIN_LENGTH
+         * program instructions (src/rose/program_runtime.c) */
+        auto in_bounds = [&](unsigned long long to) {
+            if ((p.ext_flags & HS_EXT_FLAG_MIN_OFFSET) && to < p.min_offset) return false;
+            if ((p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) && to > p.max_offset) return false;
+            if ((p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) && to - start < p.min_length) return false;
+            return true;
+        };
         if (p.tail.empty()) {
-            ev.push_back(Event{lit_end, from, p.id});
+            if (in_bounds(lit_end)) ev.push_back(Event{lit_end, from, p.id});
         } else {
             TailNfa::run(p.tail, buf, len, lit_end, [&](size_t to) {
-                ev.push_back(Event{to, from, p.id});
+                if (in_bounds(to)) ev.push_back(Event{to, from, p.id});
                 return true;
             });
         }
@@ -475,9 +549,9 @@ bool confirm_block(const hs_database *db, const unsigned char *buf, size_t len, 
 
 extern "C" {
 
-hs_error_t hs_compile_multi(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
-                            unsigned int elements, unsigned int mode, const hs_platform_info_t *platform,
-                            hs_database_t **db, hs_compile_error_t **error) {
+hs_error_t hs_compile_ext_multi(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
+                                const hs_expr_ext_t *const *ext, unsigned int elements, unsigned int mode,
+                                const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error) {
     (void)platform;
     if (!error) {
         if (db) *db = nullptr;
@@ -492,7 +566,13 @@ hs_error_t hs_compile_multi(const char *const *expressions, const unsigned int *
         if (!expressions[i]) { *error = make_error("Invalid parameter: expression is NULL", (int)i); return HS_COMPILER_ERROR; }
         ex.push_back(expressions[i]);
     }
-    return build_database(ex, std::vector<unsigned char>(elements, 0), flags, ids, mode, db, error);
+    return build_database(ex, std::vector<unsigned char>(elements, 0), flags, ids, ext, mode, db, error);
+}
+
+hs_error_t hs_compile_multi(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
+                            unsigned int elements, unsigned int mode, const hs_platform_info_t *platform,
+                            hs_database_t **db, hs_compile_error_t **error) {
+    return hs_compile_ext_multi(expressions, flags, ids, nullptr, elements, mode, platform, db, error);
 }
 
 hs_error_t hs_compile(const char *expression, unsigned int flags, unsigned int mode, const hs_platform_info_t *platform,
@@ -521,7 +601,7 @@ hs_error_t hs_compile_lit_multi(const char *const *expressions, const unsigned *
     if (elements == 0) { *error = make_error("Invalid parameter: elements is zero", -1); return HS_COMPILER_ERROR; }
     std::vector<std::string> ex;
     for (unsigned i = 0; i < elements; i++) ex.emplace_back(expressions[i] ? expressions[i] : "", expressions[i] ? lens[i] : 0);
-    return build_database(ex, std::vector<unsigned char>(elements, 1), flags, ids, mode, db, error);
+    return build_database(ex, std::vector<unsigned char>(elements, 1), flags, ids, nullptr, mode, db, error);
 }
 
 hs_error_t hs_compile_lit(const char *expression, unsigned flags, const size_t len, unsigned mode,
@@ -537,16 +617,15 @@ hs_error_t hs_compile_lit(const char *expression, unsigned flags, const size_t l
 
 hs_error_t hs_free_compile_error(hs_compile_error_t *error) {
     if (!error) return HS_SUCCESS;
-    free(error->message);
-    free(error);
+    hook_free(g_misc, error->message);
+    hook_free(g_misc, error);
     return HS_SUCCESS;
 }
 
 hs_error_t hs_free_database(hs_database_t *db) {
     if (!db) return HS_SUCCESS;
     if (db->magic != 0x48534744) return HS_INVALID;
-    hsgpu_hwlm_free(db->hwlm);
-    delete db;
+    destroy_db(db);
     return HS_SUCCESS;
 }
 
@@ -562,35 +641,58 @@ hs_error_t hs_database_info(const hs_database_t *db, char **info) {
     if (!db || !info || db->magic != 0x48534744) return HS_INVALID;
     char buf[160];
     snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: BLOCK", hs_version());
-    *info = strdup(buf);
-    return *info ? HS_SUCCESS : HS_NOMEM;
+    *info = misc_strdup(buf);
+    if (hs_error_t ae = check_alloc(*info)) {
+        hook_free(g_misc, *info);
+        *info = nullptr;
+        return ae;
+    }
+    return HS_SUCCESS;
 }
 
-/* serialised form: magic, count, then per pattern {is_lit, flags, id, len, bytes} -- the
- * database is rebuilt from its sources on load (compilation is cheap for this engine) */
+/* serialised form: magic "HSGE", count, then per pattern {is_lit, flags, id, len, ext flags,
+ * min_offset, max_offset, min_length, bytes} -- the database is rebuilt from its sources on
+ * load (compilation is cheap for this engine; the GPU table is rebuilt with it) */
+static const unsigned kSerialMagic = 0x48534745;
+
 hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length) {
     if (!db || !bytes || !length || db->magic != 0x48534744) return HS_INVALID;
     std::string out;
     auto put32 = [&](unsigned v) { out.append((const char *)&v, 4); };
-    put32(0x48534744);
+    auto put64 = [&](unsigned long long v) { out.append((const char *)&v, 8); };
+    put32(kSerialMagic);
     put32((unsigned)db->sources.size());
     for (size_t i = 0; i < db->sources.size(); i++) {
         put32(db->src_is_lit[i]);
         put32(db->src_flags[i]);
         put32(db->src_ids[i]);
         put32((unsigned)db->sources[i].size());
+        put64(db->src_ext[i].flags);
+        put64(db->src_ext[i].min_offset);
+        put64(db->src_ext[i].max_offset);
+        put64(db->src_ext[i].min_length);
         out += db->sources[i];
     }
-    *bytes = (char *)malloc(out.size());
-    if (!*bytes) return HS_NOMEM;
+    *bytes = (char *)hook_alloc(g_misc, out.size());
+    if (hs_error_t ae = check_alloc(*bytes)) {
+        hook_free(g_misc, *bytes);
+        *bytes = nullptr;
+        return ae;
+    }
     memcpy(*bytes, out.data(), out.size());
     *length = out.size();
     return HS_SUCCESS;
 }
 
-hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_database_t **db) {
-    if (!bytes || !db) return HS_INVALID;
-    *db = nullptr;
+namespace {
+struct Serial {
+    std::vector<std::string> ex;
+    std::vector<unsigned char> is_lit;
+    std::vector<unsigned> flags, ids;
+    std::vector<hs_expr_ext_t> ext;
+};
+hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
+    if (!bytes) return HS_INVALID;
     size_t off = 0;
     auto get32 = [&](unsigned &v) {
         if (off + 4 > length) return false;
@@ -598,34 +700,157 @@ hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_da
         off += 4;
         return true;
     };
+    auto get64 = [&](unsigned long long &v) {
+        if (off + 8 > length) return false;
+        memcpy(&v, bytes + off, 8);
+        off += 8;
+        return true;
+    };
     unsigned magic, n;
-    if (!get32(magic) || magic != 0x48534744 || !get32(n) || n == 0) return HS_INVALID;
-    std::vector<std::string> ex;
-    std::vector<unsigned char> is_lit;
-    std::vector<unsigned> flags, ids;
+    if (!get32(magic)) return HS_INVALID;
+    if ((magic & 0xffffff00u) == (kSerialMagic & 0xffffff00u) && magic != kSerialMagic) return HS_DB_VERSION_ERROR;
+    if (magic != kSerialMagic || !get32(n) || n == 0) return HS_INVALID;
     for (unsigned i = 0; i < n; i++) {
         unsigned l, f, id, len;
-        if (!get32(l) || !get32(f) || !get32(id) || !get32(len) || off + len > length) return HS_INVALID;
-        ex.emplace_back(bytes + off, len);
+        hs_expr_ext_t e;
+        memset(&e, 0, sizeof(e));
+        if (!get32(l) || !get32(f) || !get32(id) || !get32(len) || !get64(e.flags) || !get64(e.min_offset) ||
+            !get64(e.max_offset) || !get64(e.min_length) || off + len > length)
+            return HS_INVALID;
+        out.ex.emplace_back(bytes + off, len);
         off += len;
-        is_lit.push_back((unsigned char)l);
-        flags.push_back(f);
-        ids.push_back(id);
+        out.is_lit.push_back((unsigned char)l);
+        out.flags.push_back(f);
+        out.ids.push_back(id);
+        out.ext.push_back(e);
     }
+    return off == length ? HS_SUCCESS : HS_INVALID;
+}
+} // namespace
+
+hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_database_t **db) {
+    if (!bytes || !db) return HS_INVALID;
+    *db = nullptr;
+    Serial sr;
+    if (hs_error_t rv = parse_serial(bytes, length, sr)) return rv;
+    std::vector<const hs_expr_ext_t *> ext;
+    for (const hs_expr_ext_t &e : sr.ext) ext.push_back(e.flags ? &e : nullptr);
     hs_compile_error_t *err = nullptr;
-    hs_error_t rv = build_database(ex, is_lit, flags.data(), ids.data(), HS_MODE_BLOCK, db, &err);
+    hs_error_t rv = build_database(sr.ex, sr.is_lit, sr.flags.data(), sr.ids.data(), ext.data(), HS_MODE_BLOCK, db, &err);
     hs_free_compile_error(err);
     return rv == HS_SUCCESS ? HS_SUCCESS : HS_INVALID;
+}
+
+/* src/hs_common.h:196-271: how much a deserialised database will occupy / what it is,
+ * without building it */
+hs_error_t hs_serialized_database_size(const char *bytes, const size_t length, size_t *size) {
+    if (!size) return HS_INVALID;
+    Serial sr;
+    if (hs_error_t rv = parse_serial(bytes, length, sr)) return rv;
+    hs_database_t *db = nullptr;
+    if (hs_error_t rv = hs_deserialize_database(bytes, length, &db)) return rv;
+    hs_error_t rv = hs_database_size(db, size);
+    hs_free_database(db);
+    return rv;
+}
+
+hs_error_t hs_serialized_database_info(const char *bytes, size_t length, char **info) {
+    if (!info) return HS_INVALID;
+    *info = nullptr;
+    Serial sr;
+    if (hs_error_t rv = parse_serial(bytes, length, sr)) return rv;
+    char buf[160];
+    snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: BLOCK", hs_version());
+    *info = misc_strdup(buf);
+    if (hs_error_t ae = check_alloc(*info)) {
+        hook_free(g_misc, *info);
+        *info = nullptr;
+        return ae;
+    }
+    return HS_SUCCESS;
+}
+
+/* ---- allocators (src/hs_common.h:273-439, src/alloc.c) ---- */
+hs_error_t hs_set_database_allocator(hs_alloc_t a, hs_free_t f) { g_db.alloc = a; g_db.free = f; return HS_SUCCESS; }
+hs_error_t hs_set_misc_allocator(hs_alloc_t a, hs_free_t f) { g_misc.alloc = a; g_misc.free = f; return HS_SUCCESS; }
+hs_error_t hs_set_scratch_allocator(hs_alloc_t a, hs_free_t f) { g_scratch.alloc = a; g_scratch.free = f; return HS_SUCCESS; }
+hs_error_t hs_set_stream_allocator(hs_alloc_t a, hs_free_t f) { g_stream.alloc = a; g_stream.free = f; return HS_SUCCESS; }
+hs_error_t hs_set_allocator(hs_alloc_t a, hs_free_t f) {
+    hs_set_database_allocator(a, f);
+    hs_set_misc_allocator(a, f);
+    hs_set_scratch_allocator(a, f);
+    hs_set_stream_allocator(a, f);
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_populate_platform(hs_platform_info_t *platform) {
+    if (!platform) return HS_INVALID;
+    memset(platform, 0, sizeof(*platform)); /* tune = HS_TUNE_FAMILY_GENERIC, no CPU features: the engine is a GPU */
+    return HS_SUCCESS;
+}
+
+/* hs_expression_info / _ext_info (src/hs.cpp:413-516): widths of the supported pattern
+ * subset; never unordered, never EOD-anchored */
+hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, const hs_expr_ext_t *ext,
+                                  hs_expr_info_t **info, hs_compile_error_t **error) {
+    if (!error) return HS_COMPILER_ERROR;
+    *error = nullptr;
+    if (!info) { *error = make_error("Invalid parameter: info is NULL", -1); return HS_COMPILER_ERROR; }
+    *info = nullptr;
+    if (!expression) { *error = make_error("Invalid parameter: expression is NULL", -1); return HS_COMPILER_ERROR; }
+    Pattern p;
+    try {
+        p = parse_pattern(expression, flags, 0);
+        if (ext) apply_ext(p, *ext);
+    } catch (const ParseError &pe) {
+        *error = make_error(pe.msg, 0);
+        return HS_COMPILER_ERROR;
+    }
+    unsigned long long minw = p.lit.size(), maxw = p.lit.size();
+    bool unbounded = false;
+    for (const Unit &u : p.tail) {
+        minw += u.optional ? 0 : 1;
+        maxw += 1;
+        unbounded |= u.star;
+    }
+    if (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) minw = std::max(minw, p.min_length);
+    if (p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) {
+        maxw = unbounded ? p.max_offset : std::min(maxw, p.max_offset);
+        unbounded = false;
+    }
+    hs_expr_info_t *out = (hs_expr_info_t *)hook_alloc(g_misc, sizeof(*out));
+    if (hs_error_t ae = check_alloc(out)) {
+        hook_free(g_misc, out);
+        *error = make_error(ae == HS_BAD_ALIGN ? "Allocator returned misaligned memory." : "Unable to allocate memory.", -1);
+        return HS_COMPILER_ERROR;
+    }
+    out->min_width = (unsigned)std::min<unsigned long long>(minw, 0xffffffffu);
+    out->max_width = unbounded ? 0xffffffffu : (unsigned)std::min<unsigned long long>(maxw, 0xffffffffu);
+    out->unordered_matches = 0;
+    out->matches_at_eod = 0;
+    out->matches_only_at_eod = 0;
+    *info = out;
+    return HS_SUCCESS;
+}
+
+hs_error_t hs_expression_info(const char *expression, unsigned int flags, hs_expr_info_t **info,
+                              hs_compile_error_t **error) {
+    return hs_expression_ext_info(expression, flags, nullptr, info, error);
 }
 
 hs_error_t hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch) {
     if (!db || !scratch || db->magic != 0x48534744) return HS_INVALID;
     if (*scratch) return (*scratch)->magic == 0x48534753 ? ((*scratch)->in_use ? HS_SCRATCH_IN_USE : HS_SUCCESS) : HS_INVALID;
-    hs_scratch *s = new (std::nothrow) hs_scratch;
-    if (!s) return HS_NOMEM;
+    void *mem = hook_alloc(g_scratch, sizeof(hs_scratch));
+    if (hs_error_t ae = check_alloc(mem)) {
+        hook_free(g_scratch, mem);
+        return ae;
+    }
+    hs_scratch *s = new (mem) hs_scratch;
     int rv = hsgpu_scratch_alloc(&s->gpu, -1);
     if (rv != HSGPU_SUCCESS) {
-        delete s;
+        s->~hs_scratch();
+        hook_free(g_scratch, mem);
         return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
     }
     *scratch = s;
@@ -635,10 +860,15 @@ hs_error_t hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch) {
 hs_error_t hs_clone_scratch(const hs_scratch_t *src, hs_scratch_t **dest) {
     if (!src || !dest || src->magic != 0x48534753) return HS_INVALID;
     *dest = nullptr;
-    hs_scratch *s = new (std::nothrow) hs_scratch;
-    if (!s) return HS_NOMEM;
+    void *mem = hook_alloc(g_scratch, sizeof(hs_scratch));
+    if (hs_error_t ae = check_alloc(mem)) {
+        hook_free(g_scratch, mem);
+        return ae;
+    }
+    hs_scratch *s = new (mem) hs_scratch;
     if (hsgpu_scratch_alloc(&s->gpu, -1) != HSGPU_SUCCESS) {
-        delete s;
+        s->~hs_scratch();
+        hook_free(g_scratch, mem);
         return HS_UNKNOWN_ERROR;
     }
     *dest = s;
@@ -656,7 +886,8 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
     if (scratch->magic != 0x48534753) return HS_INVALID;
     if (scratch->in_use) return HS_SCRATCH_IN_USE;
     hsgpu_scratch_free(scratch->gpu);
-    delete scratch;
+    scratch->~hs_scratch();
+    hook_free(g_scratch, scratch);
     return HS_SUCCESS;
 }
 

@@ -11,6 +11,30 @@ HS_DB_MODE_ERROR, HS_SCRATCH_IN_USE, HS_UNKNOWN_ERROR = -7, -10, -13
 HS_FLAG_CASELESS, HS_FLAG_DOTALL, HS_FLAG_MULTILINE, HS_FLAG_SINGLEMATCH = 1, 2, 4, 8
 HS_FLAG_UTF8, HS_FLAG_SOM_LEFTMOST = 32, 256
 HS_MODE_BLOCK, HS_MODE_STREAM, HS_MODE_VECTORED = 1, 2, 4
+HS_EXT_FLAG_MIN_OFFSET, HS_EXT_FLAG_MAX_OFFSET, HS_EXT_FLAG_MIN_LENGTH = 1, 2, 4
+HS_EXT_FLAG_EDIT_DISTANCE, HS_EXT_FLAG_HAMMING_DISTANCE = 8, 16
+
+
+class ExprExt(C.Structure):
+    """hs_expr_ext_t (src/hs_compile.h:244-310)"""
+    _fields_ = [("flags", C.c_ulonglong), ("min_offset", C.c_ulonglong), ("max_offset", C.c_ulonglong),
+                ("min_length", C.c_ulonglong), ("edit_distance", C.c_uint), ("hamming_distance", C.c_uint)]
+
+    @classmethod
+    def make(cls, min_offset=None, max_offset=None, min_length=None, edit_distance=None):
+        e = cls()
+        for flag, name, v in ((1, "min_offset", min_offset), (2, "max_offset", max_offset),
+                              (4, "min_length", min_length), (8, "edit_distance", edit_distance)):
+            if v is not None:
+                e.flags |= flag
+                setattr(e, name, v)
+        return e
+
+
+class ExprInfo(C.Structure):
+    """hs_expr_info_t (src/hs_compile.h:160-236)"""
+    _fields_ = [("min_width", C.c_uint), ("max_width", C.c_uint), ("unordered_matches", C.c_char),
+                ("matches_at_eod", C.c_char), ("matches_only_at_eod", C.c_char)]
 
 
 class CompileErrorStruct(C.Structure):
@@ -46,6 +70,12 @@ def _lib():
         lib.hs_deserialize_database.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p)]
         lib.hs_database_size.argtypes = [C.c_void_p, P(C.c_size_t)]
         lib.hs_version.restype = C.c_char_p
+        lib.hs_compile_ext_multi.argtypes = [P(C.c_char_p), P(C.c_uint), P(C.c_uint), P(P(ExprExt)), C.c_uint, C.c_uint,
+                                             C.c_void_p, P(C.c_void_p), E]
+        lib.hs_expression_ext_info.argtypes = [C.c_char_p, C.c_uint, P(ExprExt), P(P(ExprInfo)), E]
+        lib.hs_serialized_database_size.argtypes = [C.c_void_p, C.c_size_t, P(C.c_size_t)]
+        lib.hs_serialized_database_info.argtypes = [C.c_void_p, C.c_size_t, P(C.c_char_p)]
+        lib.hs_database_info.argtypes = [C.c_void_p, P(C.c_char_p)]
         lib._hs_sigs = True
     return lib
 
@@ -55,7 +85,7 @@ class Database:
         self._h = handle
 
     @classmethod
-    def _compile(cls, fn_name, exprs, flags, ids, mode, lens=None):
+    def _compile(cls, fn_name, exprs, flags, ids, mode, lens=None, ext=None):
         lib = _lib()
         n = len(exprs)
         bufs = [e if isinstance(e, bytes) else e.encode("latin-1") for e in exprs]
@@ -67,6 +97,10 @@ class Database:
         if fn_name == "hs_compile_lit_multi":
             ln = (C.c_size_t * n)(*(lens if lens is not None else [len(b) for b in bufs]))
             rv = lib.hs_compile_lit_multi(arr, fl, idv, ln, n, mode, None, C.byref(db), C.byref(err))
+        elif ext is not None:
+            keep = [e for e in ext]
+            ev = (C.POINTER(ExprExt) * n)(*[C.pointer(e) if e is not None else C.POINTER(ExprExt)() for e in keep])
+            rv = lib.hs_compile_ext_multi(arr, fl, idv, ev, n, mode, None, C.byref(db), C.byref(err))
         else:
             rv = lib.hs_compile_multi(arr, fl, idv, n, mode, None, C.byref(db), C.byref(err))
         if rv != HS_SUCCESS:
@@ -80,6 +114,11 @@ class Database:
     @classmethod
     def compile(cls, exprs, flags=None, ids=None, mode=HS_MODE_BLOCK):
         return cls._compile("hs_compile_multi", exprs, flags, ids, mode)
+
+    @classmethod
+    def compile_ext(cls, exprs, flags=None, ids=None, ext=None, mode=HS_MODE_BLOCK):
+        """hs_compile_ext_multi: ext = list of ExprExt or None per expression"""
+        return cls._compile("hs_compile_ext_multi", exprs, flags, ids, mode, ext=ext if ext is not None else [None] * len(exprs))
 
     @classmethod
     def compile_lit(cls, exprs, flags=None, ids=None, mode=HS_MODE_BLOCK):
@@ -152,3 +191,20 @@ def scan_batch(db, data, off, scratch, on_event=None):
     off = np.ascontiguousarray(off, dtype=np.uint64)
     cb = BATCH_CB(lambda b, i, f, t, _fl, _c: 1 if (on_event and on_event(b, i, f, t)) else 0)
     return _lib().hs_scan_batch(db._h, buf.ctypes.data, off.ctypes.data, off.size - 1, 0, scratch._h, cb, None)
+
+
+def expression_info(expr, flags=0, ext=None):
+    """hs_expression_ext_info -> (min_width, max_width)"""
+    lib = _lib()
+    info = C.POINTER(ExprInfo)()
+    err = C.POINTER(CompileErrorStruct)()
+    e = expr if isinstance(expr, bytes) else expr.encode("latin-1")
+    rv = lib.hs_expression_ext_info(e, flags, C.byref(ext) if ext is not None else None, C.byref(info), C.byref(err))
+    if rv != HS_SUCCESS:
+        msg = err.contents.message.decode(errors="replace") if err else ""
+        if err:
+            lib.hs_free_compile_error(err)
+        raise HsError(rv, msg, 0)
+    out = (info.contents.min_width, info.contents.max_width)
+    C.CDLL(None).free(info)
+    return out

@@ -14,6 +14,14 @@
  *   hs_database_info / hs_serialize_database /
  *   hs_deserialize_database                  src/hs_common.h:84-271
  *   hs_version / hs_valid_platform           src/hs_common.h:450,467
+ *   hs_compile_ext_multi / hs_expr_ext_t     src/hs_compile.h:244-310,534
+ *   hs_expression_info / hs_expression_ext_info / hs_expr_info_t   src/hs_compile.h:160-236,760-821
+ *   hs_populate_platform                     src/hs_compile.h:833
+ *   hs_serialized_database_size / _info      src/hs_common.h:196-271
+ *   hs_set_allocator / hs_set_{database,misc,scratch,stream}_allocator  src/hs_common.h:273-439
+ * Not provided (no block-mode literal-engine meaning): streaming and vectored scans
+ * (the hs_open_stream family, hs_scan_vector) and the in-place hs_deserialize_database_at: the
+ * database object owns heap containers, so it cannot live in caller memory.
  *
  * What is behind it: every pattern must start with a literal (>= 1 byte). The literal
  * prefixes (their last <= 8 bytes, as Rose truncates them: rose_build_matchers.cpp:717-724)
@@ -85,6 +93,33 @@ typedef struct hs_platform_info {
     unsigned long long reserved2;
 } hs_platform_info_t;
 
+/* hs_expr_ext_t, src/hs_compile.h:244-310 */
+typedef struct hs_expr_ext {
+    unsigned long long flags;
+    unsigned long long min_offset; /* matches must END at or after this offset */
+    unsigned long long max_offset; /* ... and at or before this one */
+    unsigned long long min_length; /* to - from must be at least this */
+    unsigned edit_distance;        /* not supported here: compile error if flagged */
+    unsigned hamming_distance;     /* not supported here */
+} hs_expr_ext_t;
+#define HS_EXT_FLAG_MIN_OFFSET 1ULL
+#define HS_EXT_FLAG_MAX_OFFSET 2ULL
+#define HS_EXT_FLAG_MIN_LENGTH 4ULL
+#define HS_EXT_FLAG_EDIT_DISTANCE 8ULL
+#define HS_EXT_FLAG_HAMMING_DISTANCE 16ULL
+
+/* hs_expr_info_t, src/hs_compile.h:160-236 */
+typedef struct hs_expr_info {
+    unsigned int min_width;
+    unsigned int max_width; /* UINT_MAX: unbounded */
+    char unordered_matches;
+    char matches_at_eod;
+    char matches_only_at_eod;
+} hs_expr_info_t;
+
+typedef void *(*hs_alloc_t)(size_t size);
+typedef void (*hs_free_t)(void *ptr);
+
 typedef int (*match_event_handler)(unsigned int id, unsigned long long from, unsigned long long to,
                                    unsigned int flags, void *context);
 
@@ -99,13 +134,33 @@ hs_error_t hs_compile_lit_multi(const char *const *expressions, const unsigned *
                                 const size_t *lens, unsigned elements, unsigned mode,
                                 const hs_platform_info_t *platform, hs_database_t **db,
                                 hs_compile_error_t **error);
+hs_error_t hs_compile_ext_multi(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
+                                const hs_expr_ext_t *const *ext, unsigned int elements, unsigned int mode,
+                                const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error);
 hs_error_t hs_free_compile_error(hs_compile_error_t *error);
+hs_error_t hs_expression_info(const char *expression, unsigned int flags, hs_expr_info_t **info,
+                              hs_compile_error_t **error);
+hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, const hs_expr_ext_t *ext,
+                                  hs_expr_info_t **info, hs_compile_error_t **error);
+hs_error_t hs_populate_platform(hs_platform_info_t *platform);
 
 hs_error_t hs_free_database(hs_database_t *db);
 hs_error_t hs_database_size(const hs_database_t *database, size_t *database_size);
 hs_error_t hs_database_info(const hs_database_t *database, char **info);
 hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length);
 hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_database_t **db);
+hs_error_t hs_serialized_database_size(const char *bytes, const size_t length, size_t *deserialized_size);
+hs_error_t hs_serialized_database_info(const char *bytes, size_t length, char **info);
+
+/* Allocation hooks (src/hs_common.h:273-439): the objects handed to the caller -- databases,
+ * scratch, compile errors, info strings, serialised bytes, expression info -- are allocated
+ * with these (NULL = malloc/free) and must come back 8-byte aligned (HS_BAD_ALIGN otherwise);
+ * containers inside a database use the C++ heap. */
+hs_error_t hs_set_allocator(hs_alloc_t alloc_func, hs_free_t free_func);
+hs_error_t hs_set_database_allocator(hs_alloc_t alloc_func, hs_free_t free_func);
+hs_error_t hs_set_misc_allocator(hs_alloc_t alloc_func, hs_free_t free_func);
+hs_error_t hs_set_scratch_allocator(hs_alloc_t alloc_func, hs_free_t free_func);
+hs_error_t hs_set_stream_allocator(hs_alloc_t alloc_func, hs_free_t free_func);
 
 hs_error_t hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch);
 hs_error_t hs_clone_scratch(const hs_scratch_t *src, hs_scratch_t **dest);

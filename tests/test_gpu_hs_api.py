@@ -160,6 +160,33 @@ def test_literal_prefix_plus_tail_patterns():
         assert sorted(e[1:] for e in ev if e[0] == b) == sorted(collect(db, blk, scratch))
 
 
+def test_ext_offset_and_length_bounds():
+    """hs_compile_ext_multi: min_offset / max_offset bound `to`, min_length bounds to - start
+    (unit/hyperscan/extparam.cpp's shape, on the literal + tail subset)."""
+    data = b"..foo1.....foo22....foo333...foo4444"
+    base = hs.Database.compile(["foo\\d+"], [0], [5])
+    sb = hs.HsScratch(base)
+    every = collect(base, data, sb)
+    assert len(every) == 10
+    for kw in (dict(min_offset=15), dict(max_offset=20), dict(min_offset=10, max_offset=30), dict(min_length=6),
+               dict(min_length=5, max_offset=28)):
+        db = hs.Database.compile_ext(["foo\\d+"], [0], [5], [hs.ExprExt.make(**kw)])
+        sc = hs.HsScratch(db)
+        want = []
+        for (i, f, t) in every:
+            start = data.rfind(b"foo", 0, t)
+            if "min_offset" in kw and t < kw["min_offset"]:
+                continue
+            if "max_offset" in kw and t > kw["max_offset"]:
+                continue
+            if "min_length" in kw and t - start < kw["min_length"]:
+                continue
+            want.append((i, f, t))
+        assert collect(db, data, sc) == want and want, kw
+        db2 = hs.Database.deserialize(db.serialize())
+        assert collect(db2, data, hs.HsScratch(db2)) == want
+
+
 def test_simplegrep_example(tmp_path):
     """Config 1 plumbing: the simplegrep use case (examples/simplegrep.c of the reference)
     through the public API, on a 64 MiB printable-ASCII buffer with 64 planted literals."""

@@ -285,3 +285,95 @@ def test_replay_rules():
     out = []
     assert replay(t, [(1, 2), (2, 1), (3, 2)], 3, lambda e, i: (out.append((e, i)), 4)[1]) == 0
     assert out == [(2, 42), (3, 5)]                    # group 4 only live after the first callback
+
+
+def test_hs_facade_compile_side_extras():
+    """hs_compile_ext_multi validation, hs_expression_(ext_)info, hs_serialized_database_*,
+    hs_populate_platform and the allocator hooks: all host-only."""
+    from hyperscan_amd import hs
+
+    lib = hs._lib()
+    # ext validation (src/compiler/compiler.cpp:97-130)
+    with pytest.raises(hs.HsError) as e:
+        hs.Database.compile_ext(["abc"], ext=[hs.ExprExt.make(min_offset=10, max_offset=5)])
+    assert e.value.code == hs.HS_COMPILER_ERROR and e.value.expression == 0
+    with pytest.raises(hs.HsError):
+        hs.Database.compile_ext(["abc"], ext=[hs.ExprExt.make(edit_distance=1)])  # graph compiler territory
+    db = hs.Database.compile_ext(["abc\\d+", "xyz"], ids=[1, 2], ext=[hs.ExprExt.make(min_offset=4, max_offset=90), None])
+    blob = db.serialize()
+    db2 = hs.Database.deserialize(blob)  # the ext parameters travel with the database
+    assert db2.serialize() == blob
+    n = C.c_size_t()
+    assert lib.hs_serialized_database_size(blob, len(blob), C.byref(n)) == 0 and n.value == db.size()
+    info = C.c_char_p()
+    assert lib.hs_serialized_database_info(blob, len(blob), C.byref(info)) == 0
+    assert b"BLOCK" in info.value and b"gfx950" in info.value
+    assert lib.hs_serialized_database_size(b"junkjunk", 8, C.byref(n)) == hs.HS_INVALID
+    bad_version = bytes([blob[0] ^ 1]) + blob[1:]
+    assert lib.hs_serialized_database_size(bad_version, len(blob), C.byref(n)) == -5  # HS_DB_VERSION_ERROR
+    # expression info: widths of literal prefix + tail
+    assert hs.expression_info("abc") == (3, 3)
+    assert hs.expression_info("abc\\d{2,4}x?") == (5, 8)
+    assert hs.expression_info("abc[a-z]+") == (4, 0xFFFFFFFF)
+    assert hs.expression_info("abc[a-z]+", ext=hs.ExprExt.make(min_length=10, max_offset=64)) == (10, 64)
+    with pytest.raises(hs.HsError):
+        hs.expression_info("a(b|c)")
+    plat = (C.c_ulonglong * 4)(1, 2, 3, 4)
+    assert lib.hs_populate_platform(plat) == 0 and list(plat) == [0, 0, 0, 0]
+
+
+def test_hs_allocator_hooks():
+    from hyperscan_amd import hs
+
+    lib = hs._lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    live, calls = set(), [0, 0]
+    ALLOC, FREE = C.CFUNCTYPE(C.c_void_p, C.c_size_t), C.CFUNCTYPE(None, C.c_void_p)
+
+    @ALLOC
+    def my_alloc(n):
+        p = libc.malloc(n)
+        live.add(p)
+        calls[0] += 1
+        return p
+
+    @FREE
+    def my_free(p):
+        if p:
+            live.discard(p)
+            calls[1] += 1
+            libc.free(p)
+
+    @ALLOC
+    def misaligned(n):
+        return libc.malloc(n + 8) + 4  # leaked on purpose: the library must refuse it ...
+
+    @FREE
+    def drop(p):  # ... and hands it straight back to the matching free hook
+        calls[1] += 1
+
+    lib.hs_set_allocator.argtypes = [ALLOC, FREE]
+    lib.hs_set_database_allocator.argtypes = [ALLOC, FREE]
+    try:
+        assert lib.hs_set_allocator(my_alloc, my_free) == 0
+        db = hs.Database.compile(["hook", "lit\\d"])
+        blob_p, blob_n = C.c_void_p(), C.c_size_t()
+        assert lib.hs_serialize_database(db._h, C.byref(blob_p), C.byref(blob_n)) == 0
+        assert blob_p.value in live  # serialised bytes: misc allocator
+        my_free(blob_p.value)
+        assert calls[0] >= 2
+        with pytest.raises(hs.HsError):
+            hs.Database.compile(["a(b"])  # the error object came from the misc allocator and went back
+        db.close()
+        assert not live, "everything handed out through the hooks was returned through them"
+        assert lib.hs_set_database_allocator(misaligned, drop) == 0
+        before = calls[1]
+        with pytest.raises(hs.HsError):
+            hs.Database.compile(["x1"])
+        assert calls[1] > before
+    finally:
+        lib.hs_set_allocator(ALLOC(0), FREE(0))
+    hs.Database.compile(["back", "to", "malloc"]).close()
