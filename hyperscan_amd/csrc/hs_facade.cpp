@@ -948,6 +948,12 @@ hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int lengt
                          &c);
 }
 
+int hs_batch_count_handler(unsigned long long, unsigned int, unsigned long long, unsigned long long, unsigned int,
+                           void *context) {
+    if (context) ++*(unsigned long long *)context;
+    return 0;
+}
+
 const char *hs_version(void) { return "5.4.2-hsgpu-gfx950"; }
 
 hs_error_t hs_valid_platform(void) {

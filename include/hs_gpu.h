@@ -179,6 +179,11 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
                          unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
                          hs_batch_event_handler onEvent, void *context);
 
+/* Ready-made batch handler that counts (hsbench's onMatch, tools/hsbench/engine_hyperscan.cpp:89-97):
+ * context = unsigned long long * incremented once per match; never stops the scan. */
+int hs_batch_count_handler(unsigned long long block, unsigned int id, unsigned long long from,
+                           unsigned long long to, unsigned int flags, void *context);
+
 const char *hs_version(void);
 hs_error_t hs_valid_platform(void);
 
