@@ -22,12 +22,14 @@
 
 #include <algorithm>
 #include <bitset>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -49,6 +51,11 @@ struct Pattern {
     bool tail_nullable = true;
     /* hs_expr_ext_t (src/hs_compile.h:244-310): bounds on `to` and on the match length */
     unsigned long long ext_flags = 0, min_offset = 0, max_offset = 0, min_length = 0;
+    /* shift-and form of the tail for <= 63 units (built once by finish_pattern): bit i of
+     * reach[c] = unit i accepts byte c; star / optional unit masks */
+    bool fast = false;
+    std::vector<unsigned long long> reach; /* [256] */
+    unsigned long long star_mask = 0, opt_mask = 0;
 };
 
 struct ParseError {
@@ -281,7 +288,7 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
     return pat;
 }
 
-/* bit-parallel simulation of the linear NFA: state i = "units 0..i-1 consumed" */
+/* simulation of the linear NFA: state i = "units 0..i-1 consumed" */
 struct TailNfa {
     typedef std::bitset<kMaxStates> States;
     static States closure(const std::vector<Unit> &u, States s) {
@@ -308,7 +315,35 @@ struct TailNfa {
             if (cur[S]) { if (!report(pos)) return; }
         }
     }
+    /* the same automaton, bit-parallel (shift-and) in one 64-bit word: per input byte
+     * one table read, a shift, and the optional-unit closure (skipping unit i = bit i -> i+1) */
+    static unsigned long long closure64(unsigned long long s, unsigned long long opt) {
+        for (unsigned long long add; (add = ((s & opt) << 1) & ~s) != 0;) s |= add;
+        return s;
+    }
+    template <class F> static void run64(const Pattern &p, const unsigned char *buf, size_t len, size_t pos, F report) {
+        const unsigned long long accept = 1ull << p.tail.size();
+        unsigned long long cur = closure64(1ull, p.opt_mask);
+        if (cur & accept) { if (!report(pos)) return; }
+        while (pos < len && (cur & (accept - 1))) {
+            const unsigned long long live = cur & p.reach[buf[pos++]];
+            cur = closure64((live << 1) | (live & p.star_mask), p.opt_mask);
+            if (cur & accept) { if (!report(pos)) return; }
+        }
+    }
 };
+
+void finish_pattern(Pattern &p) {
+    p.fast = !p.tail.empty() && p.tail.size() <= 63;
+    if (!p.fast) return;
+    p.reach.assign(256, 0);
+    for (size_t i = 0; i < p.tail.size(); i++) {
+        for (unsigned c = 0; c < 256; c++)
+            if (p.tail[i].cls[c]) p.reach[c] |= 1ull << i;
+        if (p.tail[i].star) p.star_mask |= 1ull << i;
+        if (p.tail[i].optional) p.opt_mask |= 1ull << i;
+    }
+}
 
 } // namespace
 
@@ -322,13 +357,25 @@ struct hs_database {
     std::vector<unsigned> src_flags, src_ids;
     std::vector<unsigned char> src_is_lit;
     std::vector<hs_expr_ext_t> src_ext; /* flags == 0: none */
+    std::set<unsigned> single_ids;      /* report ids carrying HS_FLAG_SINGLEMATCH (built once) */
 };
 
 struct hs_scratch {
     unsigned magic = 0x48534753; /* "HSGS" */
     hsgpu_scratch_t *gpu = nullptr;
     bool in_use = false;
-    std::vector<hsgpu_match_t> recs;
+    /* record buffer: grown on demand, never value-initialised (a std::vector::resize of the
+     * worst-case capacity cost more than the scan) */
+    hsgpu_match_t *recs = nullptr;
+    size_t recs_cap = 0;
+    ~hs_scratch() { free(recs); }
+    bool reserve(size_t n) {
+        if (n <= recs_cap) return true;
+        free(recs);
+        recs = (hsgpu_match_t *)malloc(n * sizeof(hsgpu_match_t));
+        recs_cap = recs ? n : 0;
+        return recs != nullptr;
+    }
 };
 
 namespace {
@@ -425,6 +472,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                     d->pats.push_back(parse_pattern(exprs[i], f, id));
                 }
                 if (ext && ext[i]) apply_ext(d->pats.back(), *ext[i]);
+                finish_pattern(d->pats.back());
             } catch (const ParseError &pe) {
                 *error = make_error(pe.msg, (int)i);
                 destroy_db(d);
@@ -464,6 +512,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
     for (size_t i = 0; i < exprs.size(); i++) {
         d->src_flags.push_back(flags ? flags[i] : 0);
         d->src_ids.push_back(ids ? ids[i] : 0);
+        if (d->pats[i].single) d->single_ids.insert(d->pats[i].id);
         hs_expr_ext_t none;
         memset(&none, 0, sizeof(none));
         d->src_ext.push_back(ext && ext[i] ? *ext[i] : none);
@@ -501,11 +550,11 @@ struct Event {
     bool operator==(const Event &o) const { return to == o.to && id == o.id; }
 };
 
-/* turn the HWLM hits of ONE block into user events; returns true if terminated */
-template <class Emit>
-bool confirm_block(const hs_database *db, const unsigned char *buf, size_t len, const hsgpu_match_t *recs, size_t n,
-                   Emit emit) {
-    std::vector<Event> ev;
+/* turn the HWLM hits of ONE block into the user events it owes, in delivery order:
+ * appended to `out` (sorted by to, one per (id, to), SINGLEMATCH ids once) */
+void collect_block_events(const hs_database *db, const unsigned char *buf, size_t len, const hsgpu_match_t *recs,
+                          size_t n, std::vector<Event> &out) {
+    const size_t base = out.size();
     for (size_t k = 0; k < n; k++) {
         const Pattern &p = db->pats[recs[k].id];
         const size_t lit_end = (size_t)recs[k].end + 1;
@@ -521,28 +570,48 @@ bool confirm_block(const hs_database *db, const unsigned char *buf, size_t len, 
             return true;
         };
         if (p.tail.empty()) {
-            if (in_bounds(lit_end)) ev.push_back(Event{lit_end, from, p.id});
+            if (in_bounds(lit_end)) out.push_back(Event{lit_end, from, p.id});
         } else {
-            TailNfa::run(p.tail, buf, len, lit_end, [&](size_t to) {
-                if (in_bounds(to)) ev.push_back(Event{to, from, p.id});
+            auto on_to = [&](size_t to) {
+                if (in_bounds(to)) out.push_back(Event{to, from, p.id});
                 return true;
-            });
+            };
+            if (p.fast) TailNfa::run64(p, buf, len, lit_end, on_to);
+            else TailNfa::run(p.tail, buf, len, lit_end, on_to);
         }
     }
-    std::sort(ev.begin(), ev.end());
-    ev.erase(std::unique(ev.begin(), ev.end()), ev.end()); /* one report per (id, to) */
-    std::set<unsigned> exhausted;                            /* SINGLEMATCH ids already reported */
-    std::set<unsigned> single_ids;
-    for (const Pattern &p : db->pats)
-        if (p.single) single_ids.insert(p.id);
-    for (const Event &e : ev) {
-        if (single_ids.count(e.id)) {
-            if (exhausted.count(e.id)) continue;
-            exhausted.insert(e.id);
+    std::sort(out.begin() + base, out.end());
+    out.erase(std::unique(out.begin() + base, out.end()), out.end()); /* one report per (id, to) */
+    if (!db->single_ids.empty()) {
+        std::set<unsigned> exhausted; /* SINGLEMATCH ids already reported in this block */
+        size_t w = base;
+        for (size_t r = base; r < out.size(); r++) {
+            if (db->single_ids.count(out[r].id) && !exhausted.insert(out[r].id).second) continue;
+            out[w++] = out[r];
         }
-        if (emit(e)) return true;
+        out.resize(w);
     }
-    return false;
+}
+
+/* one contiguous slice of the record array, whole blocks only: events of every block in it */
+struct BlockRun {
+    unsigned long long block;
+    size_t ev_begin, ev_end;
+};
+void collect_slice(const hs_database *db, const unsigned char *data, const unsigned long long *off,
+                   const hsgpu_match_t *recs, size_t lo, size_t hi, std::vector<Event> &events,
+                   std::vector<BlockRun> &runs) {
+    size_t k = lo;
+    while (k < hi) { /* records are sorted by (block, end): one run per block */
+        const unsigned long long b = recs[k].block;
+        size_t e = k;
+        while (e < hi && recs[e].block == b) e++;
+        const size_t len = (size_t)(off[b + 1] - off[b]);
+        const size_t ev0 = events.size();
+        if (len >= db->min_width) collect_block_events(db, data + off[b], len, recs + k, e - k, events);
+        if (events.size() > ev0) runs.push_back(BlockRun{b, ev0, events.size()});
+        k = e;
+    }
 }
 
 } // namespace
@@ -903,30 +972,66 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
     scratch->in_use = true;
     struct Guard { hs_scratch *s; ~Guard() { s->in_use = false; } } guard{scratch};
     if (nblocks == 0) return HS_SUCCESS;
-    size_t cap = std::max<size_t>(4096, (size_t)(off[nblocks] - off[0]) / 64), n = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    size_t cap = std::max<size_t>(std::max<size_t>(4096, scratch->recs_cap), (size_t)(off[nblocks] - off[0]) / 1024), n = 0;
     for (int attempt = 0; attempt < 8; attempt++) {
-        scratch->recs.resize(cap);
+        if (!scratch->reserve(cap)) return HS_NOMEM;
         int rv = hsgpu_hwlm_exec_batch(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off,
-                                       (size_t)nblocks, 0, scratch->recs.data(), cap, &n);
+                                       (size_t)nblocks, 0, scratch->recs, cap, &n);
         if (rv == HSGPU_SUCCESS) break;
         if (rv != HSGPU_INSUFFICIENT_SPACE) return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
-        cap = n + n / 4;
+        cap = n + n / 4; /* n = the exact total */
         if (attempt == 7) return HS_UNKNOWN_ERROR;
     }
-    bool any_terminated = false;
-    size_t k = 0;
-    while (k < n) { /* records are sorted by (block, end): one run per block */
-        const unsigned long long b = scratch->recs[k].block;
-        size_t e = k;
-        while (e < n && scratch->recs[e].block == b) e++;
-        const unsigned char *buf = (const unsigned char *)data + off[b];
-        const size_t len = (size_t)(off[b + 1] - off[b]);
-        if (len >= db->min_width && onEvent) {
-            any_terminated |= confirm_block(db, buf, len, scratch->recs.data() + k, e - k, [&](const Event &ev) {
-                return onEvent(b, ev.id, ev.from, ev.to, 0, context) != 0;
-            });
+    static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr; /* diagnostic: where does a batch go? */
+    const auto t_scan = std::chrono::steady_clock::now();
+    /* host confirm: the events of different blocks are independent, so large batches are cut
+     * into slices of whole blocks handled by worker threads; delivery stays on the calling
+     * thread, in block order, as the callback contract requires */
+    const hsgpu_match_t *recs = scratch->recs;
+    unsigned n_thr = 1;
+    if (onEvent && n >= 8192) n_thr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<Event>> ev(n_thr);
+    std::vector<std::vector<BlockRun>> runs(n_thr);
+    if (onEvent) {
+        std::vector<size_t> cut(n_thr + 1, n);
+        cut[0] = 0;
+        for (unsigned t = 1; t < n_thr; t++) {
+            size_t c = std::max(cut[t - 1], n * t / n_thr);
+            while (c < n && c > 0 && recs[c].block == recs[c - 1].block) c++; /* snap to a block boundary */
+            cut[t] = c;
         }
-        k = e;
+        auto work = [&](unsigned t) {
+            collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t]);
+        };
+        if (n_thr == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> pool;
+            try {
+                for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(work, t);
+            } catch (...) { /* could not start every worker: the caller's thread does the rest */
+                for (unsigned t = (unsigned)pool.size() + 1; t < n_thr; t++) work(t);
+            }
+            work(0);
+            for (std::thread &th : pool) th.join();
+        }
+    }
+    bool any_terminated = false;
+    for (unsigned t = 0; t < n_thr; t++)
+        for (const BlockRun &r : runs[t])
+            for (size_t i = r.ev_begin; i < r.ev_end; i++) {
+                const Event &e = ev[t][i];
+                if (onEvent(r.block, e.id, e.from, e.to, 0, context) != 0) { /* stops THIS block only */
+                    any_terminated = true;
+                    break;
+                }
+            }
+    if (timing) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "hs_scan_batch: %zu literal hits; GPU literal scan incl. copies %.2f ms, host confirm %.2f ms\n", n,
+                std::chrono::duration<double, std::milli>(t_scan - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_scan).count());
     }
     return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
 }
