@@ -141,7 +141,8 @@ def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True,
     if buffers is not None:  # reuse (bitmaps, first, last, work) from an earlier call: no allocation, no sync
         bitmaps, first, last, work = buffers
     else:
-        bitmaps = torch.empty((n, max(1, words) * 2), dtype=torch.uint8, device=dev)
+        # rows padded to 8 bytes: 8-byte aligned bitmaps let the first/last kernel read 64-bit words
+        bitmaps = torch.empty((n, (max(1, words) * 2 + 7) // 8 * 8), dtype=torch.uint8, device=dev)
         work = torch.zeros(WORK_BYTES, dtype=torch.uint8, device=dev)
         first = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_first and nblocks) else None
         last = torch.zeros((n, nblocks), dtype=torch.int32, device=dev) if (want_last and nblocks) else None

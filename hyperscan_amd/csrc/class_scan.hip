@@ -103,20 +103,51 @@ __device__ __forceinline__ uint32_t last_bit(const uint16_t *bm, uint64_t lo, ui
     return 0xffffffffu;
 }
 
-/* first/last member of class c inside block b, from bitmap c */
+/* the same over 64-bit words (bitmaps that are 8-byte aligned): a 120-byte line is 2-3 reads
+ * instead of 8 */
+__device__ __forceinline__ uint32_t first_bit64(const uint64_t *bm, uint64_t lo, uint64_t hi) {
+    if (lo >= hi) return 0xffffffffu;
+    const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+    for (uint64_t w = w0; w <= w1; w++) {
+        uint64_t m = bm[w];
+        if (w == w0) m &= ~0ull << (lo & 63);
+        if (w == w1) m &= ~0ull >> (63 - ((hi - 1) & 63));
+        if (m) return (uint32_t)((w << 6) + __builtin_ctzll(m) - lo);
+    }
+    return 0xffffffffu;
+}
+__device__ __forceinline__ uint32_t last_bit64(const uint64_t *bm, uint64_t lo, uint64_t hi) {
+    if (lo >= hi) return 0xffffffffu;
+    const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+    for (uint64_t w = w1;; w--) {
+        uint64_t m = bm[w];
+        if (w == w0) m &= ~0ull << (lo & 63);
+        if (w == w1) m &= ~0ull >> (63 - ((hi - 1) & 63));
+        if (m) return (uint32_t)((w << 6) + 63 - __builtin_clzll(m) - lo);
+        if (w == w0) break;
+    }
+    return 0xffffffffu;
+}
+
+/* first/last member of class c inside block b, from bitmap c. (Fusing this into the
+ * classification kernel -- fields kept in LDS, a per-tile block index, atomics for blocks
+ * crossing tiles -- measured 2.1 ms/GiB against 1.27 ms for these two streaming kernels: the
+ * per-tile barriers and dependent offset reads cost more than re-reading the bitmaps.) */
 __global__ void class_first_last_kernel(const uint64_t *off, uint64_t nblocks, uint32_t n_classes,
-                                        uint16_t *const *bitmaps, uint32_t *first, uint32_t *last) {
+                                        uint16_t *const *bitmaps, uint64_t total, uint32_t *first, uint32_t *last) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nblocks * n_classes) return;
     const uint32_t c = (uint32_t)(i / nblocks);
     const uint64_t b = i % nblocks;
     const uint64_t lo = off[b], hi = off[b + 1];
     const uint16_t *bm = bitmaps[c];
+    /* the bitmap holds (total + 15) / 16 16-bit words: whole 64-bit words only below that */
+    const bool wide = (((uintptr_t)bm & 7) == 0) && (((hi + 63) >> 6) << 2) <= ((total + 15) >> 4);
     if (first) {
-        const uint32_t f = first_bit(bm, lo, hi);
+        const uint32_t f = wide ? first_bit64((const uint64_t *)bm, lo, hi) : first_bit(bm, lo, hi);
         first[i] = f == 0xffffffffu ? (uint32_t)(hi - lo) : f;
     }
-    if (last) last[i] = last_bit(bm, lo, hi);
+    if (last) last[i] = wide ? last_bit64((const uint64_t *)bm, lo, hi) : last_bit(bm, lo, hi);
 }
 
 /* ---- two-byte sets (double shufti / double vermicelli) --------------------------
@@ -309,7 +340,7 @@ extern "C" int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_cla
     if (d_first || d_last) {
         const uint64_t n = nblocks * n_classes;
         hipLaunchKernelGGL(class_first_last_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const uint64_t *)d_off, nblocks, n_classes, d_ptrs, (uint32_t *)d_first, (uint32_t *)d_last);
+                           (const uint64_t *)d_off, nblocks, n_classes, d_ptrs, total_bytes, (uint32_t *)d_first, (uint32_t *)d_last);
         HIP_TRY(hipGetLastError());
     }
     return HSGPU_SUCCESS;

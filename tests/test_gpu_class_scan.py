@@ -82,6 +82,58 @@ def test_ragged_sizes(total):
         assert last.cpu().numpy().view(np.uint32)[0, b] == (r & 0xFFFFFFFF)
 
 
+def _check_all_blocks(classes, corpus, off):
+    import torch
+
+    d = torch.from_numpy(corpus.copy()).to("cuda:0")
+    d_off = torch.from_numpy(off.astype(np.uint64).view(np.int64).copy()).to("cuda:0")
+    nb = off.size - 1
+    bitmaps, first, last = accel.class_scan(classes, d, corpus.size, d_off, nb, True, True)
+    fi = first.cpu().numpy().view(np.uint32)
+    la = last.cpu().numpy().view(np.uint32)
+    L = ob.hso()
+    for ci, cls in enumerate(classes):
+        want = oracle_bitmap(cls, corpus)
+        assert np.array_equal(bitmaps.cpu().numpy()[ci][: want.size], want)
+        for b in range(nb):
+            blk = np.ascontiguousarray(corpus[int(off[b]):int(off[b + 1])])
+            f = L.hso_class_fwd(cls.bitmap.ctypes.data, blk.ctypes.data, blk.size)
+            r = L.hso_class_rev(cls.bitmap.ctypes.data, blk.ctypes.data, blk.size)
+            assert fi[ci, b] == f, (ci, b, int(off[b]), int(off[b + 1]))
+            assert la[ci, b] == (r & 0xFFFFFFFF), (ci, b, int(off[b]), int(off[b + 1]))
+
+
+@pytest.mark.parametrize("shape", ["one_block", "tile_aligned", "tiny", "mixed", "trailing_empty", "sparse_big"])
+def test_fused_block_shapes(shape):
+    """Blocks against the kernel's 16 KiB tiles: spanning many tiles, ending exactly on a tile
+    boundary, thousands of 0/1-byte blocks in one tile, empty blocks at the very end, and a
+    class so sparse that most tiles of a long block contribute nothing."""
+    rng = np.random.default_rng(len(shape))
+    T = 16384
+    if shape == "one_block":
+        total, off = 5 * T + 123, np.array([0, 5 * T + 123])
+    elif shape == "tile_aligned":
+        total, off = 4 * T, np.array([0, T, T, 2 * T, 3 * T - 1, 3 * T, 4 * T])
+    elif shape == "tiny":
+        lens = rng.choice([0, 1, 1, 2], 40000)
+        off = np.concatenate([[0], np.cumsum(lens)])
+        total = int(off[-1])
+    elif shape == "mixed":
+        lens = rng.choice([0, 3, 17, 120, 1460, 20000, 40000], 60, p=[.1, .2, .2, .2, .2, .05, .05])
+        off = np.concatenate([[0], np.cumsum(lens)])
+        total = int(off[-1])
+    elif shape == "trailing_empty":
+        total, off = 2 * T, np.array([0, 100, 2 * T, 2 * T, 2 * T])
+    else:
+        total, off = 6 * T, np.array([0, 10, 6 * T - 5, 6 * T])
+    corpus = rng.choice(np.frombuffer(b"abcxyz ", dtype=np.uint8), total).astype(np.uint8)
+    if shape == "sparse_big":
+        corpus[:] = ord("x")
+        corpus[[7, 3 * T + 5, 6 * T - 2]] = ord("Q")
+    classes = [accel.CharClass(b"abc"), accel.CharClass(b" "), accel.CharClass(b"Q"), accel.CharClass(b"z")]
+    _check_all_blocks(classes, corpus, np.asarray(off, dtype=np.uint64))
+
+
 def test_decoders_match_reference_masks():
     """shufti / truffle masks built by the REFERENCE decode (on our side) to the class
     they were built from, and the GPU first-hit equals shuftiExec / truffleExec."""
