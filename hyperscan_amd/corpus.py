@@ -2,10 +2,10 @@
 corpora, seeded and deterministic, shared byte-for-byte by the GPU run and the
 CPU baseline. Pure numpy; nothing here is on the scan path.
 
-hsbench reads its corpora from SQLite (tools/hsbench/data_corpus.cpp:69-136);
-that reader is out of scope, the *shape* of what it yields -- an ordered list of
-independent blocks -- is what these generators reproduce in CSR form
-(one contiguous byte array + nblocks+1 offsets).
+hsbench reads its corpora from SQLite (tools/hsbench/data_corpus.cpp:69-136; reader and
+writer for that format: tools/hsbench.py); what it yields -- an ordered list of independent
+blocks -- is what these generators produce in CSR form (one contiguous byte array +
+nblocks+1 offsets).
 """
 import numpy as np
 
