@@ -585,7 +585,11 @@ __device__ __forceinline__ void filter_pos(const uint32_t (&arr)[6], const Filte
     const uint32_t prod = mul_u24(x, HSGPU_FILTER_MUL);
     const uint32_t a = prod >> f.shift;
     const uint32_t addr = REPL ? ((a << 7) | f.lane4) : (a & f.amask);
+#ifdef HSGPU_ABLATE_NOLDS /* tuning builds: same VALU work, no LDS read (wrong results: no candidates) */
+    const uint32_t word = (addr == 0xdeadbee0u) ? 1u : 0u;
+#else
     const uint32_t word = lds_word(addr);
+#endif
     if (HAS_A) {
         uint32_t hit = shr_lo5(word, add_byte<B3>(a, b3src));
         if (K2) hit &= shr_lo5(word, add_byte1_byte<B3>(prod, b3src)); /* byte 1 of prod: second bit index */
