@@ -69,7 +69,7 @@ struct hsgpu_scratch {
     hipEvent_t ev_ring[kRing][4] = {};
     hipEvent_t *ev_t = nullptr; /* the set of the scan being launched */
     uint64_t n_timed = 0;       /* scans launched with timing on */
-    DevBuf tstamp;              /* [kRing][2] device wall-clock min(start) / max(end) of the filter kernel */
+    DevBuf tstamp;              /* [kRing][4] device wall clock: filter start (min) / end (max), confirm-stage end, pipeline end */
     double wall_clock_khz = 100000.0;
     DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets, stats;
     bool ctl_clean = false;                /* every control word is zero (left so by control_reset_kernel) */
@@ -184,13 +184,13 @@ extern "C" int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable) {
     HIP_TRY(hipSetDevice(s->device));
     if (enable && !s->ev_ring[0][0]) {
         for (int r = 0; r < hsgpu_scratch::kRing; r++)
-            for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&s->ev_ring[r][i]));
+            for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreate(&s->ev_ring[r][i]));
     }
     if (enable) {
-        int rv = s->tstamp.ensure(hsgpu_scratch::kRing * 2 * sizeof(unsigned long long));
+        int rv = s->tstamp.ensure(hsgpu_scratch::kRing * 4 * sizeof(unsigned long long));
         if (rv != HSGPU_SUCCESS) return rv;
-        std::vector<unsigned long long> init(hsgpu_scratch::kRing * 2);
-        for (int r = 0; r < hsgpu_scratch::kRing; r++) init[2 * r] = ~0ull, init[2 * r + 1] = 0;
+        std::vector<unsigned long long> init(hsgpu_scratch::kRing * 4, 0);
+        for (int r = 0; r < hsgpu_scratch::kRing; r++) init[4 * r] = ~0ull;
         HIP_TRY(hipMemcpy(s->tstamp.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device) == hipSuccess && khz > 0)
@@ -201,32 +201,45 @@ extern "C" int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable) {
     return HSGPU_SUCCESS;
 }
 
+/* device wall-clock stamps of one timed scan (synchronises the device: tuning / bench API) */
+static int read_stamps(hsgpu_scratch_t *s, unsigned back, unsigned long long t[4]) {
+    if (!s || back >= hsgpu_scratch::kRing || back >= s->n_timed) return HSGPU_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t slot = (s->n_timed - 1 - back) % hsgpu_scratch::kRing;
+    HIP_TRY(hipMemcpy(t, (const unsigned long long *)s->tstamp.p + 4 * slot, 4 * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
+    return HSGPU_SUCCESS;
+}
+
 extern "C" int hsgpu_scratch_get_kernel_span(hsgpu_scratch_t *s, unsigned back, float *filter_ms) {
     /* the filter kernel's own execution span (first workgroup start to last workgroup
      * end) from the device wall clock -- what a kernel trace reports as its duration */
-    if (!s || !filter_ms || back >= hsgpu_scratch::kRing || back >= s->n_timed) return HSGPU_INVALID;
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipEventSynchronize(s->ev_ring[(s->n_timed - 1 - back) % hsgpu_scratch::kRing][3]));
-    unsigned long long t[2] = {0, 0};
-    const size_t slot = (s->n_timed - 1 - back) % hsgpu_scratch::kRing;
-    HIP_TRY(hipMemcpy(t, (const unsigned long long *)s->tstamp.p + 2 * slot, sizeof(t), hipMemcpyDeviceToHost));
+    if (!filter_ms) return HSGPU_INVALID;
+    unsigned long long t[4];
+    int rv = read_stamps(s, back, t);
+    if (rv != HSGPU_SUCCESS) return rv;
     if (t[1] < t[0]) return HSGPU_INVALID;
     *filter_ms = (float)((double)(t[1] - t[0]) / s->wall_clock_khz);
     return HSGPU_SUCCESS;
 }
 
+/* filter_ms: HIP events recorded on the launch stream right before and after the filter
+ * kernel (the only two events a timed scan records: every extra event costs ~5 us of
+ * dispatch gap, and four of them were 6% of a 0.3 ms scan). confirm_ms (filter end ->
+ * confirm stage end) and total_ms (filter start -> end of the scan's last kernel) come from
+ * the device wall clock the kernels stamp themselves. */
 extern "C" int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float *filter_ms, float *confirm_ms,
                                         float *total_ms) {
-    if (!s || back >= hsgpu_scratch::kRing || back >= s->n_timed) return HSGPU_INVALID;
+    unsigned long long t[4];
+    int rv = read_stamps(s, back, t);
+    if (rv != HSGPU_SUCCESS) return rv;
     hipEvent_t *ev = s->ev_ring[(s->n_timed - 1 - back) % hsgpu_scratch::kRing];
-    HIP_TRY(hipEventSynchronize(ev[3]));
-    float f = 0, c = 0, t = 0;
+    float f = 0;
     HIP_TRY(hipEventElapsedTime(&f, ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&c, ev[1], ev[2]));
-    HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[3]));
     if (filter_ms) *filter_ms = f;
-    if (confirm_ms) *confirm_ms = c;
-    if (total_ms) *total_ms = t;
+    if (confirm_ms) *confirm_ms = (t[2] > t[1]) ? (float)((double)(t[2] - t[1]) / s->wall_clock_khz) : 0.f;
+    if (total_ms) *total_ms = (t[3] > t[0] && t[0] != ~0ull) ? (float)((double)(t[3] - t[0]) / s->wall_clock_khz) : 0.f;
     return HSGPU_SUCCESS;
 }
 
@@ -367,8 +380,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     if (s->timing) {
         const size_t slot = s->n_timed % hsgpu_scratch::kRing;
         s->ev_t = s->ev_ring[slot];
-        args.tstamp = (unsigned long long *)s->tstamp.p + 2 * slot;
-        args.tstamp_next = (unsigned long long *)s->tstamp.p + 2 * ((slot + 1) % hsgpu_scratch::kRing);
+        args.tstamp = (unsigned long long *)s->tstamp.p + 4 * slot;
+        args.tstamp_next = (unsigned long long *)s->tstamp.p + 4 * ((slot + 1) % hsgpu_scratch::kRing);
         HIP_TRY(hipEventRecord(s->ev_t[0], stream));
     }
     if (!two_phase) {
@@ -380,7 +393,6 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
         if (s->timing) {
             HIP_TRY(hipEventRecord(s->ev_t[1], stream));
-            HIP_TRY(hipEventRecord(s->ev_t[2], stream));
         }
     } else {
         /* phase 1 + 2, then the fused kernel as overflow fallback (returns at once
@@ -402,14 +414,10 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
-        if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[2], stream));
     }
     HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
     HIP_TRY(hipLaunchKernel(hsgpu_record_pack_kernel(), dim3((n_rec + 3) / 4), dim3(256), kargs, 0, stream));
-    if (s->timing) {
-        HIP_TRY(hipEventRecord(s->ev_t[3], stream));
-        s->n_timed++;
-    }
+    if (s->timing) s->n_timed++;
     {
         const uint32_t words = std::max<uint32_t>(2 * n_rec, n_waves + 1);
         HIP_TRY(hipLaunchKernel(hsgpu_control_reset_kernel(), dim3((words + 255) / 256), dim3(256), kargs, 0, stream));

@@ -725,7 +725,11 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
     /* the fused kernel doubles as the overflow fallback: nothing to do unless the
      * two-phase pipeline ran out of candidate space */
-    if (FUSED && args.cand_counts && !args.cand_counts[args.cand_waves]) return;
+    if (FUSED && args.cand_counts && !args.cand_counts[args.cand_waves]) {
+        /* it runs right behind the confirm kernel: its start is the end of the confirm stage */
+        if (args.tstamp && blockIdx.x == 0 && threadIdx.x == 0) args.tstamp[2] = wall_clock64();
+        return;
+    }
     if (!FUSED && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
 
     const uint32_t flog2 = args.t_filter_log2;
@@ -1071,8 +1075,11 @@ __global__ __launch_bounds__(256) void control_reset_kernel(HsgpuScanArgs args) 
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < 2 * args.rec_regions) args.rec_counts[i] = 0;
     if (i == 0 && args.tstamp_next) {
+        args.tstamp[3] = wall_clock64(); /* end of this scan's pipeline (this is its last kernel) */
         args.tstamp_next[0] = ~0ull;
         args.tstamp_next[1] = 0;
+        args.tstamp_next[2] = 0;
+        args.tstamp_next[3] = 0;
     }
 
     /* cumulative statistics for hsgpu_scratch_get_stats: one atomic per wavefront */

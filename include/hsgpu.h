@@ -151,11 +151,13 @@ int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d
                         uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t start,
                         void *d_out, uint64_t cap, void *d_count, void *stream);
 
-/* Measurement aid: when enabled, hsgpu_hwlm_scan_dev brackets its kernels with
- * HIP events on the launch stream (a ring of the last 32 scans);
- * hsgpu_scratch_get_timing waits for the scan `back` launches ago (0 = the last)
- * and returns the duration of the dominant (filter) kernel, of the confirm stage
- * and of the whole pipeline, in milliseconds. */
+/* Measurement aid: when enabled, hsgpu_hwlm_scan_dev records two HIP events on the launch
+ * stream, right before and right after its dominant (filter) kernel, and the kernels stamp
+ * the device wall clock at their own start / end (a ring of the last 32 scans).
+ * hsgpu_scratch_get_timing synchronises the device and returns, for the scan `back`
+ * launches ago (0 = the last), the filter kernel's duration between the two events, and --
+ * from the device clock -- the confirm stage (filter end to confirm end) and the whole
+ * pipeline (filter start to the end of the scan's last kernel), in milliseconds. */
 int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable);
 int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float *filter_ms, float *confirm_ms,
                              float *total_ms);
