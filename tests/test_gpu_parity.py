@@ -216,3 +216,18 @@ def test_scan_dev_resident_and_properties(scratch):
         straddles = g - int(sizes[int(rec[3])]) + 1 < int(starts[b])
         assert (g in set(g1)) != straddles or not straddles
     assert len(g1) > 1000
+
+
+@pytest.mark.parametrize("env", [{"HSGPU_MODE": "fused"}, {"HSGPU_WG_THREADS": "1024"}, {"HSGPU_WG_THREADS": "512"}])
+def test_golden_vectors_under_alternative_pipelines(env):
+    """The golden-vector suite again with the always-correct fused pipeline (normally only the
+    overflow fallback) and with each workgroup geometry forced for every table."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_golden.py"), "-q", "-x",
+                          "-m", "gpu"], capture_output=True, text=True, env=dict(os.environ, **env), cwd=root, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
