@@ -338,10 +338,9 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
     args.hint = (const uint32_t *)s->hint.p;
     const bool two_phase = scan_mode() == 0;
-    /* Block hints are only needed by the confirm kernel. Two-phase: they are computed on a
-     * side stream, launched AFTER the filter kernel so that the filter's workgroups take
-     * their CUs first and the hint kernel fills the idle wavefront slots beside them.
-     * Fused: the filter itself needs them, so they run first on the same stream. */
+    /* Block hints are only needed by the confirm step. Two-phase: the filter kernel writes
+     * them in its prologue (while its LDS image loads). Fused: the filter itself needs
+     * them, so a hint kernel runs first on the same stream. */
     auto launch_hints = [&](hipStream_t hs) -> int {
         const uint64_t *off = a.off;
         uint64_t nblocks = a.nblocks, total = a.total, n_hint = args.n_hint;
@@ -350,8 +349,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipLaunchKernel(hsgpu_hint_kernel(), dim3((unsigned)((nblocks + 1 + 255) / 256)), dim3(256), hargs, 0, hs));
         return HSGPU_SUCCESS;
     };
-    if (two_phase) HIP_TRY(hipEventRecord(s->ev_fork, stream)); /* everything the hints read is ready here */
-    else if ((rv = launch_hints(stream)) != HSGPU_SUCCESS) return rv;
+    args.hint_in_filter = two_phase ? 1u : 0u;
+    if (!two_phase && (rv = launch_hints(stream)) != HSGPU_SUCCESS) return rv;
     /* staged match records: one region per producing wavefront, packed into the
      * caller's buffer by the last two kernels. 2x headroom over an even split. */
     const uint32_t n_waves = grid * (wg_threads / 64);
@@ -408,10 +407,6 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
-        HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-        if ((rv = launch_hints(s->side)) != HSGPU_SUCCESS) return rv;
-        HIP_TRY(hipEventRecord(s->ev_join, s->side));
-        HIP_TRY(hipStreamWaitEvent(stream, s->ev_join, 0));
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
     }

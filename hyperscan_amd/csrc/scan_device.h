@@ -718,6 +718,40 @@ __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t l
     }
 }
 
+/* ---- block hints: hint[t] = block containing corpus byte t * 1024 ------------------ */
+/* Convergent (whole wavefront): the lane's block b writes the hint of every KiB boundary
+ * inside it (no searching: a per-tile bisection was 20 dependent reads per entry); blocks
+ * covering more than 4 boundaries are written by the whole wavefront. Block index nblocks
+ * stands for "boundaries at/after the last offset". */
+__device__ __forceinline__ void write_block_hints(const uint64_t *off, uint64_t nblocks, uint32_t *hint, uint64_t n_hint,
+                                                  uint64_t b, uint32_t lane) {
+    uint64_t t0 = 0, t1 = 0;
+    uint32_t val = 0;
+    if (b < nblocks) {
+        const uint64_t s = b ? off[b] : 0, e = off[b + 1];
+        t0 = (s + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
+        t1 = (e + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
+        val = (uint32_t)b;
+    } else if (b == nblocks) {
+        t0 = (off[nblocks] + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
+        t1 = n_hint;
+        val = (uint32_t)(nblocks - 1);
+    }
+    t1 = min(t1, n_hint);
+    const uint64_t n = t1 > t0 ? t1 - t0 : 0;
+    if (n <= 4) {
+        for (uint64_t k = 0; k < n; k++) hint[t0 + k] = val;
+    }
+    unsigned long long wide = __ballot(n > 4);
+    while (wide) {
+        const int l = __builtin_ctzll(wide);
+        wide &= wide - 1;
+        const uint64_t T0 = __shfl(t0, l), T1 = __shfl(t1, l);
+        const uint32_t V = __shfl(val, l);
+        for (uint64_t t = T0 + lane; t < T1; t += 64) hint[t] = V;
+    }
+}
+
 /* ---- phase 1: the streaming filter (FUSED: + in-kernel confirm) ----------- */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED>
 __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs args) {
@@ -754,6 +788,13 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     const uint32_t super_shift = args.super_shift;   /* log2(WAVES * 1 KiB): 14 or 13 */
     const uint32_t n_waves = gridDim.x * WAVES;
     const uint32_t wave_global = blockIdx.x * WAVES + wave;
+
+    /* two-phase: the confirm kernel's block hints are written here, 64 blocks per wavefront
+     * per step, while the LDS filter image is still arriving (a hint kernel on a side
+     * stream needed a fork/join pair of cross-stream waits around the confirm launch) */
+    if (!FUSED && args.hint_in_filter)
+        for (uint64_t b0 = (uint64_t)wave_global * 64; b0 <= args.nblocks; b0 += (uint64_t)n_waves * 64)
+            write_block_hints(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, b0 + lane, lane);
 
     Tables t;
     uint32_t qcount = 0;
@@ -1100,40 +1141,10 @@ __global__ __launch_bounds__(256) void control_reset_kernel(HsgpuScanArgs args) 
     }
 }
 
-/* ---- phase 0: hint[t] = block containing corpus byte t * 1024 ------------------- */
-/* One thread per block writes the hint of every KiB boundary inside its block (no
- * searching: a per-tile bisection was 20 dependent reads per entry and took as long as
- * the filter kernel it runs beside); blocks covering more than 4 boundaries are written
- * by their whole wavefront. Thread nblocks covers boundaries at/after the last offset. */
+/* ---- phase 0 (fused-only pipeline): the hints as a kernel of their own ------------ */
 __global__ __launch_bounds__(256) void block_hint_kernel(const uint64_t *off, uint64_t nblocks, uint64_t total,
                                                          uint32_t *hint, uint64_t n_hint) {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
-    uint64_t t0 = 0, t1 = 0;
-    uint32_t val = 0;
-    if (b < nblocks) {
-        const uint64_t s = b ? off[b] : 0, e = off[b + 1];
-        t0 = (s + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
-        t1 = (e + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
-        val = (uint32_t)b;
-    } else if (b == nblocks) {
-        t0 = (off[nblocks] + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
-        t1 = n_hint;
-        val = (uint32_t)(nblocks - 1);
-    }
-    t1 = min(t1, n_hint);
-    const uint64_t n = t1 > t0 ? t1 - t0 : 0;
-    if (n <= 4) {
-        for (uint64_t k = 0; k < n; k++) hint[t0 + k] = val;
-    }
-    unsigned long long wide = __ballot(n > 4);
-    while (wide) {
-        const int l = __builtin_ctzll(wide);
-        wide &= wide - 1;
-        const uint64_t T0 = __shfl(t0, l), T1 = __shfl(t1, l);
-        const uint32_t V = __shfl(val, l);
-        for (uint64_t t = T0 + lane; t < T1; t += 64) hint[t] = V;
-    }
+    write_block_hints(off, nblocks, hint, n_hint, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, threadIdx.x & 63);
 }
 
 

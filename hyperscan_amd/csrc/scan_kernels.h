@@ -28,6 +28,7 @@ struct HsgpuScanArgs {
     hsgpu_match_t *out;         /* match records */
     uint64_t cap;               /* capacity of out */
     unsigned long long *count;  /* total matches (may exceed cap) */
+    uint32_t hint_in_filter;    /* 1: the two-phase filter kernel writes the block hints in its prologue */
     uint32_t fold_shift;        /* 16 for HSGPU_F_BFOLD tables (candidate masks: 4-byte-key hits copied to the other half), else 0 */
     uint32_t debug;             /* ablation knob (env HSGPU_DEBUG): 1 = no candidate spill, 2 = no filter math */
     const uint32_t *hint;       /* hint[t] = block containing byte t << HSGPU_HINT_SHIFT */
