@@ -303,6 +303,22 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         "table": info,
     }
     res["pipeline_depth"] = depth
+    if do_cpu:
+        # (never `value`) the same engine fed from HOST memory: hsgpu_hwlm_exec_batch = H2D of the
+        # corpus + the pipeline above + D2H of the sorted records, on a bounded sample
+        from hyperscan_amd import hwlm as hw
+
+        k = int(np.searchsorted(off, min(256 << 20, int(off[-1])), side="right")) - 1
+        s_off = np.ascontiguousarray(off[: k + 1])
+        sample = np.ascontiguousarray(corpus[: int(s_off[-1])])
+        hw.hwlm_exec_batch(job.table, job.scratch, sample, s_off, cap=job.cap)  # warm: buffers sized
+        t0 = time.perf_counter()
+        recs_h = hw.hwlm_exec_batch(job.table, job.scratch, sample, s_off, cap=job.cap)
+        dt_h = time.perf_counter() - t0
+        res["host_buffers"] = {"GBps": round(sample.size / dt_h / 1e9, 2), "sample_bytes": int(sample.size),
+                               "matches": int(recs_h.size),
+                               "what": "hsgpu_hwlm_exec_batch from pageable host memory: H2D of the corpus + scan + "
+                                       "D2H of the sorted records; PCIe bound, reported for completeness only"}
     if cpu:
         res["cpu_baseline"] = cpu
     del job, jobs
@@ -365,6 +381,8 @@ def main():
         }
         if "cpu_baseline" in main_res:
             out["cpu_baseline"] = main_res["cpu_baseline"]
+        if "host_buffers" in main_res:
+            out["host_buffers"] = main_res["host_buffers"]
         if also:
             other = "fdr10k" if args.workload == "teddy64" else "teddy64"
             out["also"] = {other: {k: also[k] for k in also}}
