@@ -37,6 +37,15 @@ class _Class(C.Structure):
     _fields_ = [("bitmap", C.c_uint8 * 32)]
 
 
+class _Accel(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("offset", C.c_uint8), ("c1", C.c_uint8), ("c2", C.c_uint8),
+                ("mask_lo", C.c_uint8 * 16), ("mask_hi", C.c_uint8 * 16)]
+
+
+ACCEL_NONE, ACCEL_VERM, ACCEL_VERM_NOCASE, ACCEL_DVERM, ACCEL_DVERM_NOCASE = 0, 1, 2, 3, 4
+ACCEL_SHUFTI, ACCEL_TRUFFLE = 13, 15  # enum AccelType, src/nfa/accel.h:46-65
+
+
 class _Pair(C.Structure):
     _fields_ = [("lo1", C.c_uint8 * 16), ("hi1", C.c_uint8 * 16), ("lo2", C.c_uint8 * 16), ("hi2", C.c_uint8 * 16)]
 
@@ -56,6 +65,10 @@ def _lib():
         lib.hsgpu_class_scan_dev.argtypes = [C.POINTER(_Class), C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]
+        lib.hsgpu_class_to_shufti.restype = C.c_int
+        lib.hsgpu_class_to_shufti.argtypes = [C.POINTER(_Class), C.c_void_p, C.c_void_p]
+        lib.hsgpu_accel_forward.restype = C.c_int
+        lib.hsgpu_accel_forward.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(_Accel)]
         lib.hsgpu_pair_from_dshufti.restype = C.c_int
         lib.hsgpu_pair_from_dshufti.argtypes = [C.c_void_p] * 4 + [C.POINTER(_Pair)]
         lib.hsgpu_pair_from_dverm.restype = C.c_int
@@ -115,6 +128,13 @@ class CharClass:
         ch = ch if isinstance(ch, int) else ord(ch)
         _lib().hsgpu_class_from_verm(ch, int(nocase), int(negate), C.byref(c))
         return cls._from_c(c)
+
+    def to_shufti(self):
+        """shuftiBuildMasks -> (lo, hi, n_buckets) or None when the class needs more than 8 buckets"""
+        lo, hi = (C.c_uint8 * 16)(), (C.c_uint8 * 16)()
+        c = self._to_c()
+        nb = _lib().hsgpu_class_to_shufti(C.byref(c), lo, hi)
+        return (bytes(lo), bytes(hi), nb) if nb > 0 else None
 
     def to_truffle(self):
         m1, m2 = (C.c_uint8 * 16)(), (C.c_uint8 * 16)()
@@ -230,3 +250,59 @@ def pair_scan(pairs, d_corpus, total, d_off=None, nblocks=0, want_first=True, wa
         raise HsgpuError(rv, "hsgpu_pair_scan_dev")
     torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
     return bitmaps, first, last
+
+
+class ForwardAccel:
+    """The pre-skip scheme of a literal set (buildForwardAccel, rose_build_lit_accel.cpp:459-465)."""
+
+    def __init__(self, c):
+        self.type, self.offset, self.c1, self.c2 = c.type, c.offset, c.c1, c.c2
+        self.mask_lo, self.mask_hi = bytes(c.mask_lo), bytes(c.mask_hi)
+
+    @classmethod
+    def choose(cls, lits, expected_groups=0xFFFFFFFFFFFFFFFF):
+        from .hwlm import pack_literals
+
+        arr, _keep = pack_literals(list(lits))
+        out = _Accel()
+        rv = _lib().hsgpu_accel_forward(arr, len(arr), expected_groups, C.byref(out))
+        if rv != 0:
+            raise HsgpuError(rv, _native.load_library().hsgpu_last_error().decode())
+        return cls(out)
+
+    def scanner(self):
+        """-> ("class", CharClass) | ("pair", PairSet) | None: what to hand to class_scan / pair_scan"""
+        if self.type in (ACCEL_VERM, ACCEL_VERM_NOCASE):
+            return "class", CharClass.from_verm(self.c1, self.type == ACCEL_VERM_NOCASE)
+        if self.type in (ACCEL_DVERM, ACCEL_DVERM_NOCASE):
+            return "pair", PairSet.from_dverm(self.c1, self.c2, self.type == ACCEL_DVERM_NOCASE)
+        if self.type == ACCEL_SHUFTI:
+            return "class", CharClass.from_shufti(self.mask_lo, self.mask_hi)
+        if self.type == ACCEL_TRUFFLE:
+            return "class", CharClass.from_truffle(self.mask_lo, self.mask_hi)
+        return None
+
+
+def forward_skip(fa, d_corpus, total, d_off, nblocks, start=0):
+    """do_accel_block (src/hwlm/hwlm.c:48-99) for a whole batch: per block, the earliest offset at
+    which a literal of the set could start -- the accelerator's first hit minus its offset, never
+    below `start`; blocks with fewer than 16 bytes after `start` are left alone, as is everything
+    when there is no scheme. -> int64 tensor [nblocks] (block length = nothing can match)."""
+    import torch
+
+    off = d_off.to(torch.int64)
+    lens = off[1:] - off[:-1]
+    base = torch.full_like(lens, int(start))
+    sc = fa.scanner()
+    if sc is None:
+        return base
+    if sc[0] == "class":
+        _bm, first, _l = class_scan([sc[1]], d_corpus, total, d_off, nblocks, True, False)
+    else:
+        _bm, first, _l = pair_scan([sc[1]], d_corpus, total, d_off, nblocks, True, False)
+    hit = first[0].to(torch.int64) & 0xFFFFFFFF
+    # run_hwlm_accel scans [start, len); our first hit is over the whole block: hits before
+    # `start` are simply earlier than the reference would look, which only makes the skip smaller
+    skipped = torch.clamp(hit - int(fa.offset), min=int(start))
+    skipped = torch.where(hit >= lens, lens, skipped)  # no hit: nothing in this block can match
+    return torch.where(lens - int(start) >= 16, skipped, base)

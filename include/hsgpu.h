@@ -206,6 +206,32 @@ int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_classes, const
                          uint64_t total_bytes, const void *d_off, uint64_t nblocks, void *const *d_bitmaps,
                          void *d_first, void *d_last, void *d_work, void *stream);
 
+/* ---- choosing an accelerator for a literal set (host only) ---------------------------
+ * buildForwardAccel / findForwardAccelScheme (src/rose/rose_build_lit_accel.cpp:372-465): the
+ * scheme hwlmExec's pre-skip uses (do_accel_block, src/hwlm/hwlm.c:48-99). `type` takes the
+ * values of enum AccelType (src/nfa/accel.h:46-65); `offset` is how far before the
+ * accelerator's hit a literal may start. c1 (and c2 for the pair schemes) are upper-cased for
+ * the _NOCASE types. mask_lo / mask_hi: shufti lo / hi, or truffle mask1 / mask2. */
+#define HSGPU_ACCEL_NONE 0
+#define HSGPU_ACCEL_VERM 1
+#define HSGPU_ACCEL_VERM_NOCASE 2
+#define HSGPU_ACCEL_DVERM 3
+#define HSGPU_ACCEL_DVERM_NOCASE 4
+#define HSGPU_ACCEL_SHUFTI 13
+#define HSGPU_ACCEL_TRUFFLE 15
+
+typedef struct hsgpu_accel {
+    uint8_t type, offset, c1, c2;
+    uint8_t mask_lo[16], mask_hi[16];
+} hsgpu_accel_t;
+
+/* Scheme for the literals whose groups intersect expected_groups (HSGPU_ALL_GROUPS for the
+ * reference's accel0). HSGPU_ACCEL_NONE when nothing narrower than 240 byte values exists. */
+int hsgpu_accel_forward(const hsgpu_lit_t *lits, size_t n, uint64_t expected_groups, hsgpu_accel_t *out);
+/* shuftiBuildMasks (src/nfa/shufticompile.cpp:54-109): number of buckets used, or -1 when
+ * the class needs more than 8 (the caller then uses truffle, which represents any class). */
+int hsgpu_class_to_shufti(const hsgpu_class_t *cls, uint8_t lo[16], uint8_t hi[16]);
+
 /* ---- two-byte accelerators ---------------------------------------------------------
  * shuftiDoubleExec (src/nfa/shufti.c:319-361), vermicelliDoubleExec /
  * vermicelliDoubleMaskedExec / rvermicelliDoubleExec (src/nfa/vermicelli.h:169-317,464-518).

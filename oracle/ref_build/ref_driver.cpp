@@ -30,9 +30,13 @@
 #include "fdr/fdr_engine_description.h"
 #include "fdr/teddy_engine_description.h"
 #include "fdr/fdr_internal.h"
+#include "nfa/accel.h"
 #include "nfa/shufticompile.h"
 #include "nfa/trufflecompile.h"
+#include "rose/rose_build_lit_accel.h"
+#include "util/alloc.h"
 #include "util/bytecode_ptr.h"
+#include "util/compare.h"
 #include "util/charreach.h"
 #include "util/compile_context.h"
 #include "util/target_info.h"
@@ -313,6 +317,39 @@ int64_t hsref_dverm_masked_exec(uint8_t c1, uint8_t c2, uint8_t m1, uint8_t m2, 
 }
 int64_t hsref_rdverm_exec(uint8_t c1, uint8_t c2, int nocase, const uint8_t *buf, size_t len) {
     return rvermicelliDoubleExec((char)c1, (char)c2, (char)nocase, buf, buf + len) - buf;
+}
+
+/* buildForwardAccel (src/rose/rose_build_lit_accel.cpp:459-465): the pre-skip scheme Rose
+ * attaches to a literal matcher. `lits` in the driver's hsref_lit_t form. out[0] = accel1
+ * (literals of `expected_groups`), out[1] = accel0 (all groups); each 80 bytes:
+ * [0] type [1] offset [2] c/c1 [3] c2 [16..48) lo / mask1 [48..80) hi / mask2 */
+void hsref_forward_accel(const hsref_lit_t *lits, size_t n, uint64_t expected_groups, uint8_t out[2][80]) {
+    std::vector<AccelString> v;
+    for (size_t i = 0; i < n; i++) {
+        std::string s((const char *)lits[i].s, lits[i].len);
+        if (lits[i].nocase) {
+            for (auto &c : s) c = (char)mytoupper((unsigned char)c); /* as hwlmLiteral does */
+        }
+        std::vector<u8> msk(lits[i].msk, lits[i].msk + lits[i].msk_len), cmp(lits[i].cmp, lits[i].cmp + lits[i].msk_len);
+        v.emplace_back(s, lits[i].nocase != 0, msk, cmp, lits[i].groups);
+    }
+    HWLM *h = (HWLM *)aligned_zmalloc(sizeof(HWLM));
+    buildForwardAccel(h, v, expected_groups);
+    const AccelAux *aux[2] = {&h->accel1, &h->accel0};
+    for (int k = 0; k < 2; k++) {
+        memset(out[k], 0, 80);
+        const AccelAux &a = *aux[k];
+        out[k][0] = a.accel_type;
+        out[k][1] = a.generic.offset;
+        switch (a.accel_type) {
+        case ACCEL_VERM: case ACCEL_VERM_NOCASE: out[k][2] = a.verm.c; break;
+        case ACCEL_DVERM: case ACCEL_DVERM_NOCASE: out[k][2] = a.dverm.c1; out[k][3] = a.dverm.c2; break;
+        case ACCEL_SHUFTI: memcpy(out[k] + 16, &a.shufti.lo, 16); memcpy(out[k] + 48, &a.shufti.hi, 16); break;
+        case ACCEL_TRUFFLE: memcpy(out[k] + 16, &a.truffle.mask1, 16); memcpy(out[k] + 48, &a.truffle.mask2, 16); break;
+        default: break;
+        }
+    }
+    aligned_free(h);
 }
 
 /* which engine ids are valid for hints on this host (unit/internal/fdr.cpp:114-137) */

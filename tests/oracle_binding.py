@@ -177,6 +177,7 @@ def href():
         L.hsref_dverm_masked_exec.argtypes = [C.c_uint8] * 4 + [C.c_void_p, C.c_size_t]
         L.hsref_rdverm_exec.restype = C.c_int64
         L.hsref_rdverm_exec.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t]
+        L.hsref_forward_accel.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
         L.hsref_valid_engines.restype = C.c_size_t
         L.hsref_valid_engines.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
         _ref = L

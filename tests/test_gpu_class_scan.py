@@ -277,3 +277,45 @@ def test_pair_scan_tile_edges(total):
     assert bits[: total - 1].all() and not bits[total - 1]  # the last byte has no successor
     assert int(first.cpu().numpy().view(np.uint32)[0, 0]) == 0
     assert int(last.cpu().numpy().view(np.uint32)[0, 0]) == (total - 1 if total > 1 else 0xFFFFFFFF)
+
+
+def test_forward_skip_is_do_accel_block_for_a_batch():
+    """forward_skip = hwlmExec's pre-skip (do_accel_block, src/hwlm/hwlm.c:48-99) per block: the
+    chosen scheme's first hit minus its offset; and the skip is SAFE: no literal of the set
+    matches with a start before it (checked with the HWLM oracle)."""
+    import torch
+
+    import hyperscan_amd as H
+
+    rng = np.random.default_rng(3)
+    sets = [[H.HwlmLiteral("needle", False, 0), H.HwlmLiteral("xneed", False, 1)],          # dverm
+            [H.HwlmLiteral("Hello", True, 0), H.HwlmLiteral("shell", True, 1)],              # dverm nocase
+            [H.HwlmLiteral("ab", False, 0), H.HwlmLiteral("cd", False, 1), H.HwlmLiteral("ef", False, 2)],  # shufti
+            [H.HwlmLiteral("qa", False, 0), H.HwlmLiteral("zq", False, 1)]]                  # verm
+    L = ob.hso()
+    for lits in sets:
+        fa = accel.ForwardAccel.choose(lits)
+        assert fa.type != accel.ACCEL_NONE
+        words = [l.s for l in lits] + [b"hello", b"SHELL", b"zzzz", b"    ", b"abcdef", b"q", b"nee"]
+        lens = rng.choice([5, 16, 17, 40, 200, 1000], 300)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        total = int(off[-1])
+        text = b"".join(words[int(i)] + b"." * int(rng.integers(0, 30)) for i in rng.integers(0, len(words), total // 8))
+        corpus = np.frombuffer(text[:total].ljust(total, b"."), dtype=np.uint8).copy()
+        d = torch.from_numpy(corpus).to("cuda:0")
+        d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+        skip = accel.forward_skip(fa, d, total, d_off, off.size - 1).cpu().numpy()
+        orc = ob.Oracle(lits)
+        kind, sc = fa.scanner()
+        for b in range(off.size - 1):
+            blk = np.ascontiguousarray(corpus[int(off[b]):int(off[b + 1])])
+            n = blk.size
+            if kind == "class":
+                hit = L.hso_class_fwd(sc.bitmap.ctypes.data, blk.ctypes.data, n)
+            else:
+                hit = L.hso_dshufti_fwd(*sc.masks, blk.ctypes.data, n)
+            want = 0 if n < 16 else (n if hit >= n else max(0, hit - fa.offset))
+            assert skip[b] == want, (b, n, hit, fa.offset)
+            for end, lid in orc.collect(blk):
+                size = len(lits[lid].s)
+                assert end + 1 - size >= skip[b], "a literal starts before the skip"
