@@ -12,36 +12,40 @@
  * state and no zones. See DESIGN.md "Kernel".
  *
  * Mapping. The corpus is the concatenation of all blocks (CSR offsets). A
- * workgroup of 16 wavefronts owns a 16 KiB super-tile per iteration; each
- * wavefront owns 1 KiB of it, each lane one 16-byte chunk, loaded with one
- * coalesced global_load_dwordx4 two iterations ahead of its use (register
- * double-buffering; nothing in the steady-state loop waits for HBM).
+ * workgroup of 8 or 16 wavefronts owns an 8 / 16 KiB super-tile per iteration; each
+ * wavefront owns 1 KiB of it, each lane one 16-byte chunk. Tiles are read through
+ * buffer descriptors built from wave-uniform values (one dwordx4 + one dwordx2 for the
+ * 8 bytes in front of the chunk), seven tiles ahead of their use: eight register stages
+ * rotate by name, nothing in the steady-state loop waits for HBM.
  *
  * Filter (per lookup position, all lanes): hash the 3 bytes ending there with
  * one v_mul_u32_u24, read ONE 32-bit word of the LDS-resident filter, test one
  * bit chosen by the 4th byte (optionally a second bit). With stride 2 only every
  * second byte is a lookup position: the table then also holds every literal
- * keyed one byte early, so a lookup at q catches literals ending at q and q + 1
- * (the kernel is VALU-bound at ~7 instructions per lookup, so this doubles its
- * rate). Two filter layouts:
- *   REPL   small literal sets ("Teddy class"): 32 identical columns, lane l reads
+ * keyed one byte early, so a lookup at q catches literals ending at q and q + 1.
+ * A lookup is 6.5 (one bit) to 10.5 (two bits) VALU instructions; the stride-1
+ * two-bit variant is VALU-issue bound. Two filter layouts:
+ *   REPL   small literal sets at stride 1: 32 identical columns, lane l reads
  *          column l & 31 -> every lane of a 32-lane LDS group hits its own bank,
  *          conflict-free by construction;
- *   hashed large sets ("FDR class"): one 2^k-word table, up to 128 KiB.
+ *   hashed the default: one 2^k-word table, up to 128 KiB.
  * Candidates are collected as one 16-bit mask per lane and class.
  *
  * Confirm. Candidates are rare (a fraction of a percent of positions) but each
  * one needs a chain of dependent HBM/L2 reads (window -> hash bucket -> literal
  * -> block offsets). Inside the streaming kernel every link of that chain queues
  * behind the wavefront's own prefetches, so the default pipeline is two-phase:
- *   hwlm_filter_kernel  streams the corpus, compacts {chunk, masks} candidate
- *                       entries through a per-wavefront LDS queue and writes
- *                       them to HBM 64 at a time (one reservation per 512 B);
+ *   hwlm_filter_kernel  streams the corpus; lanes with a hit append a 32-byte entry
+ *                       {chunk index, masks, 8-byte halo, 16-byte chunk} to their
+ *                       wavefront's private HBM region (ballot-ranked, no atomics);
+ *                       its prologue also writes the per-KiB block hints;
  *   hwlm_confirm_kernel two candidate entries per lane: exact hash-table bucket
  *                       (16 B: 4 tagged slots), (window & msk) == v of the literal
  *                       the slot names; hits are queued in LDS and resolved 64 at
- *                       a time (id/size, block lookup through a per-KiB hint table,
- *                       bound checks), records stored into the wavefront's region.
+ *                       a time (id/size, block lookup through the hint table, bound
+ *                       checks), records stored into the wavefront's region;
+ *   record_scan / record_pack / control_reset   pack the per-wavefront record regions
+ *                       into the caller's buffer, write *count, re-zero the control words.
  * A fused variant (confirm inside the streaming kernel) is kept as the
  * always-correct fallback for inputs so dense that the candidate buffer
  * overflows (the role of the reference's flood path, flood_runtime.h:86-335);
