@@ -61,6 +61,8 @@ struct DevBuf {
 struct hsgpu_scratch {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;           /* block hints are computed beside the filter kernel */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool timing = false;                   /* hsgpu_scratch_enable_timing */
     /* ring of event sets {start, filter done, confirm done, packed}: one per scan */
     static const int kRing = 32;
@@ -131,6 +133,9 @@ extern "C" int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device) {
     s->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&s->h_count, sizeof(unsigned long long)) != hipSuccess) {
         hsgpu_set_error("scratch setup failed");
         hsgpu_scratch_free(s);
@@ -167,6 +172,9 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     for (int r = 0; r < hsgpu_scratch::kRing; r++)
         for (int i = 0; i < 4; i++)
             if (s->ev_ring[r][i]) (void)hipEventDestroy(s->ev_ring[r][i]);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->side) (void)hipStreamDestroy(s->side);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -505,11 +513,8 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
         uint64_t n = *s->h_count;
         if (n <= cap) {
             recs.resize(n);
-            if (n) {
-                if ((rv = hsgpu_match_sort_dev(s, s->out.p, n, s->stream)) != HSGPU_SUCCESS) return rv;
-                HIP_TRY(hipMemcpyAsync(recs.data(), s->out.p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, s->stream));
-                HIP_TRY(hipStreamSynchronize(s->stream));
-            }
+            if (n) HIP_TRY(hipMemcpy(recs.data(), s->out.p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost));
+            std::sort(recs.begin(), recs.end(), rec_less);
             return HSGPU_SUCCESS;
         }
         /* overflow: the count is exact; rerun with room for all of them, and since the
@@ -575,24 +580,17 @@ extern "C" int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, 
 }
 
 extern "C" int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n, void *stream) {
-    /* delivery order (block, end, literal index), on the device: sort_records.hip.
-     * Asynchronous on `stream`; the workspace lives in the scratch. */
+    /* round 1: records are sorted on the host after the copy-out (scan_host).
+     * A device-side radix sort for the RCCL gather path lands with the
+     * multi-GPU work; until then sort through the host, loudly documented. */
     if (!s || (n && !d_out)) return HSGPU_INVALID;
-    if (n < 2) return HSGPU_SUCCESS;
-    HIP_TRY(hipSetDevice(s->device));
+    if (n == 0) return HSGPU_SUCCESS;
     hipStream_t st = stream ? (hipStream_t)stream : s->stream;
-    const size_t need = hsgpu_sort_workspace_bytes(n);
-    if (need == 0) { /* >= 2^31 records: through the host */
-        std::vector<hsgpu_match_t> recs(n);
-        HIP_TRY(hipMemcpyAsync(recs.data(), d_out, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        std::sort(recs.begin(), recs.end(), rec_less);
-        HIP_TRY(hipMemcpyAsync(d_out, recs.data(), n * sizeof(hsgpu_match_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return HSGPU_SUCCESS;
-    }
-    if (need > s->sort_tmp.cap) HIP_TRY(hipStreamSynchronize(st)); /* a growing workspace is freed first */
-    int rv = s->sort_tmp.ensure(need);
-    if (rv != HSGPU_SUCCESS) return rv;
-    return hsgpu_sort_records(d_out, n, s->sort_tmp.p, s->sort_tmp.cap, st);
+    std::vector<hsgpu_match_t> recs(n);
+    HIP_TRY(hipMemcpyAsync(recs.data(), d_out, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::sort(recs.begin(), recs.end(), rec_less);
+    HIP_TRY(hipMemcpyAsync(d_out, recs.data(), n * sizeof(hsgpu_match_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HSGPU_SUCCESS;
 }
