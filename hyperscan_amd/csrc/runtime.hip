@@ -360,9 +360,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
     /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1]; rec_offsets apart */
     const size_t ctl_words = (size_t)2 * n_rec + n_waves + 1;
-    const void *ctl_before = s->ctl.p;
+    /* a reallocated control block is garbage whatever its address: hipMalloc may hand the
+     * freed range straight back, so growth is detected by capacity, never by pointer */
+    const size_t ctl_cap_before = s->ctl.cap;
     if ((rv = s->ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
-    if (s->ctl.p != ctl_before) s->ctl_clean = false;
+    if (s->ctl.cap != ctl_cap_before) s->ctl_clean = false;
     if ((rv = s->rec_offsets.ensure((size_t)n_rec * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
     args.rec_stage = (uint4 *)s->rec_stage.p;
     args.rec_counts = (uint32_t *)s->ctl.p;
