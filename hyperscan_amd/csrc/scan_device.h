@@ -980,7 +980,7 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     const uint32_t cw = blockIdx.x * (CONFIRM_THREADS / 64) + wave; /* confirm wavefront = record region */
     if (cw >= args.rec_regions) return;
     const uint32_t r = cw / HSGPU_CONFIRM_SPLIT, part = cw % HSGPU_CONFIRM_SPLIT;
-    const uint32_t n = args.cand_counts[r];
+    const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
     if (part * 128 >= n) return; /* nothing for this wavefront (its record counts stay zero) */
     Tables t;
     init_tables(t, args);
