@@ -192,3 +192,82 @@ def noodle_cases():
             exp = [(e, 0) for e in range(n - 1, ln)] if nocase or lit == lit.lower() else []
             out.append(dict(name=f"nood[{lit!r},{ln}]", lits=[L(lit, nocase, 0)], buf=buf, expect=exp, ordered=False))
     return out
+
+
+def flood_mask_literals(c):
+    """unit/internal/fdr_flood.cpp:242-316 FDRFloodp.WithMask: literals "cccc" / "CCCC" (c and its
+    one-bit neighbour cAlt) carrying masks of length 1, 2, 4, 8 -- the mask reaches in front of
+    the literal for length 8 -- case-sensitive and caseless. msk / cmp evolve in place inside
+    one mask length exactly as in the test. -> (lits, cAlt, bit)"""
+    bit = 1 << (c & 7)
+    c_alt = c ^ bit
+    is_case = bit == 0x20 and (chr(c).isalpha() and c < 128)
+    s4, s4_alt = bytes([c]) * 4, bytes([c_alt]) * 4
+    lits = []
+    for i in range(4):
+        n = 1 << i
+        msk, cmp = bytearray(n), bytearray(n)
+
+        def add(s, nocase, k):
+            lits.append(L(s, nocase, i * 12 + k, msk=bytes(msk), cmp=bytes(cmp)))
+
+        cmp[0], msk[0] = c_alt, 0xFF
+        if n > 4:
+            add(s4, False, 0)
+            add(s4, True, 1)
+        if is_case:
+            add(s4, True, 2)
+        if (c_alt & bit) == 0:
+            msk[0] = ~bit & 0xFF
+            add(s4, False, 3)
+            add(s4, True, 4)
+        cmp[0], msk[0] = c, 0xFF
+        add(s4, False, 5)
+        add(s4, True, 6)
+        if n > 4:
+            add(s4_alt, False, 7)
+            add(s4_alt, True, 8)
+        if is_case:
+            add(s4_alt, True, 9)
+            cmp[n - 1], msk[n - 1] = c_alt, 0xFF
+            add(s4, True, 10)
+            cmp[0] = c_alt
+            add(s4, True, 11)
+    return lits, c_alt, bit
+
+
+def flood_mask_expected_counts(c, data_size=1024):
+    """fdr_flood.cpp:324-398: the per-id counts the test asserts, for a buffer of c then of cAlt
+    (only the ids it makes a statement about)."""
+    bit = 1 << (c & 7)
+    c_alt = c ^ bit
+    is_case = bit == 0x20 and (chr(c).isalpha() and c < 128)
+    cnt4 = data_size - 4 + 1
+    first, second = {}, {}
+    for i in range(4):
+        n = 1 << i
+        cm = min(cnt4, data_size - n + 1)
+        first[i * 12 + 0] = first[i * 12 + 1] = first[i * 12 + 2] = 0
+        if (c_alt & bit) == 0:
+            first[i * 12 + 3] = first[i * 12 + 4] = cm
+        if n > 4:
+            first[i * 12 + 5] = first[i * 12 + 6] = cm
+            first[i * 12 + 7] = 0
+            first[i * 12 + 8] = cm if is_case else 0
+        else:
+            first[i * 12 + 5] = first[i * 12 + 6] = cnt4
+        if is_case:
+            first[i * 12 + 9] = cm
+            first[i * 12 + 10] = first[i * 12 + 11] = 0
+        for k in (0, 3, 5, 6, 7, 8, 9):
+            second[i * 12 + k] = 0
+        if is_case:
+            second[i * 12 + 1] = cm if n > 4 else 0
+            second[i * 12 + 2] = cm
+            second[i * 12 + 4] = cm if chr(c).islower() else 0
+            second[i * 12 + 10] = cnt4 if n == 1 else 0
+            second[i * 12 + 11] = cm
+        else:
+            for k in (1, 2, 4, 10, 11):
+                second[i * 12 + k] = 0
+    return first, second

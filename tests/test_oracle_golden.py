@@ -61,6 +61,20 @@ def test_oracle_flood(c):
             assert got.get(i, 0) == n, (c, byte, i)
 
 
+@pytest.mark.parametrize("c", [0, 0x20, ord("a"), ord("A"), ord("e"), ord("Z"), ord("5"), 0x5B, 0x7F, 0x80, 0xDF, 0xFF])
+def test_oracle_flood_with_mask(c):
+    # unit/internal/fdr_flood.cpp:242-403 FDRFloodp.WithMask
+    lits, c_alt, _ = gc.flood_mask_literals(c)
+    o = ob.Oracle(lits)
+    first, second = gc.flood_mask_expected_counts(c)
+    for byte, want in ((c, first), (c_alt, second)):
+        got = {}
+        for _e, i in o.collect(bytes([byte]) * 1024):
+            got[i] = got.get(i, 0) + 1
+        for i, n in want.items():
+            assert got.get(i, 0) == n, (c, byte, i)
+
+
 def test_oracle_noodle_cases():
     for case in gc.noodle_cases():
         run_case(ob.Oracle(case["lits"]), case)
@@ -137,6 +151,22 @@ def test_oracle_equals_reference_forced_engines():
         assert sorted(r.collect(corpus)) == want, hint
         ran += 1
     assert ran >= 3
+
+
+@needs_ref
+def test_flood_with_mask_reference_agrees():
+    for c in (ord("a"), ord("A"), 0x00, 0xFF, ord("5"), 0x7B):
+        lits, c_alt, _ = gc.flood_mask_literals(c)
+        first, second = gc.flood_mask_expected_counts(c)
+        for byte, want in ((c, first), (c_alt, second)):
+            buf = bytes([byte]) * 1024
+            ref = sorted(ob.Reference(lits).collect(buf))
+            assert ref == sorted(ob.Oracle(lits).collect(buf))
+            got = {}
+            for _e, i in ref:
+                got[i] = got.get(i, 0) + 1
+            for i, n in want.items():  # the reference meets its own test's expectations as restated
+                assert got.get(i, 0) == n, (c, byte, i)
 
 
 @needs_ref
