@@ -9,6 +9,9 @@ A case: (name, kind, params, text, lo_trim, hi_trim, expect_abs)
     verm(c, nocase)  nverm(c, nocase)  rverm(c, nocase)
     dverm(c1, c2, nocase)  dverm_masked(c1, c2, m1, m2)  rdverm(c1, c2, nocase)
     dshufti(pairs)   : shuftiBuildDoubleMasks(CharReach(), pairs)
+    shufti(members) rshufti(members) : shuftiBuildMasks(CharReach of members) + shuftiExec / rshuftiExec
+    truffle(members) rtruffle(members): truffleBuildMasks + truffleExec / rtruffleExec
+                       (unit/internal/truffle.cpp; most texts are those of shufti.cpp)
 """
 CASE_CLEAR = 0xDF
 
@@ -115,6 +118,35 @@ def cases():
     for k, second in enumerate("ACca"):
         c += _sweep(f"DShufti.Match4b[{k}]", "dshufti", P("aA", "aa", "aC", "ac"),
                     "bbbbbbbbbbbbbbbbba" + second + "aaaaaaaaaaaaaabbbbbbbbbbbbbbbabbbbbbbbbbbb", 17)
+    # unit/internal/shufti.cpp:159-175 Shufti.ExecMatch1 (32 start offsets), :177-193 ExecMatch2,
+    # :195-212 ExecMatch3, :214-258 ExecMatch4, :110-157 ExecNoMatch1-3 (their bound
+    # `rv >= end & ~15` is met by "not found" = end)
+    M = lambda s_: tuple(sorted(s_.encode("latin-1")))
+    c += _sweep("shufti.Match1", "shufti", M("a"), "b" * 33 + "a" + "b" * 14 + "a" + "b" * 12, 33, n=32)
+    # unit/internal/truffle.cpp:230-247 Truffle.ExecMatch1; :249-323 ExecMatch2-4 and :94-149
+    # ExecNoMatch1-3 use the texts of their shufti namesakes
+    c += _sweep("truffle.Match1", "truffle", M("a"), "b" * 17 + "a" + "b" * 30 + "a" + "b" * 12, 17)
+    for kind in ("shufti", "truffle"):
+        c += _sweep(f"{kind}.Match2", kind, M("a"), "b" * 17 + "a" * 16 + "b" * 15 + "a" + "b" * 12, 17)
+        c += _sweep(f"{kind}.Match3", kind, M("aB"), "b" * 17 + "B" + "a" * 15 + "b" * 15 + "a" + "b" * 12, 17)
+        for k, first in enumerate("ACca"):
+            c += _sweep(f"{kind}.Match4[{k}]", kind, M("aCAc"), "b" * 17 + first + "a" * 15 + "b" * 15 + "a" + "b" * 12, 17)
+        c += _sweep(f"{kind}.NoMatch1", kind, M("a"), "b" * 61, None)
+        c += _sweep(f"{kind}.NoMatch2", kind, M("aB"), "b" * 61, None)
+        c += _sweep(f"{kind}.NoMatch3", kind, M("V"), "e" * 61, None)
+    # truffle.cpp:151-209 ExecMiniMatch0-3: buffers shorter than one vector
+    c.append(("truffle.Mini0", "truffle", M("a"), b"a", 0, 0, 0))
+    c.append(("truffle.Mini1", "truffle", M("a"), b"bbbbbbbabbb", 0, 0, 7))
+    c.append(("truffle.Mini2", "truffle", (0,), b"bbbbbbb\0bbb", 0, 0, 7))
+    c.append(("truffle.Mini3", "truffle", M("a"), b"\0" * 7 + b"a" + b"\0" * 3, 0, 0, 7))
+    # shufti.cpp:962-981 ReverseShufti.ExecMatch1 (the end moves back), :983-1002 ExecMatch2, :1004-1034
+    # ExecMatch3, :1036-1072 ExecMatch4; ReverseTruffle.ExecMatch1-4 (truffle.cpp:494-600) use the same texts
+    for kind in ("rshufti", "rtruffle"):
+        c += _sweep(f"{kind}.Match1", kind, M("a"), "bbbbbbabbbbbbbbbba" + "b" * 43, 17, lo=False, hi=True)
+        c += _sweep(f"{kind}.Match2", kind, M("a"), "bbbbabbbbbbbbbbbb" + "a" * 16 + "b" * 28, 32, lo=False, hi=True)
+        c += _sweep(f"{kind}.Match3", kind, M("aB"), "b" * 17 + "a" * 15 + "B" + "b" * 28, 32, lo=False, hi=True)
+        c += _sweep(f"{kind}.Match4", kind, M("aCAc"), "b" * 17 + "a" * 15 + "A" + "b" * 28, 32, lo=False, hi=True)
+        c += _sweep(f"{kind}.NoMatch", kind, M("a"), "b" * 61, None, lo=False, hi=True)
     return c
 
 

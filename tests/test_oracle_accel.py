@@ -48,6 +48,12 @@ def oracle_eval(kind, params, buf):
         ps = accel.PairSet.build(params)
         lo1, hi1, lo2, hi2 = ps.masks
         return L.hso_dshufti_fwd(lo1, hi1, lo2, hi2, p, n)
+    if kind in ("shufti", "rshufti"):
+        lo, hi, _nb = accel.CharClass(params).to_shufti()  # the product's shuftiBuildMasks
+        return (L.hso_shufti_fwd if kind == "shufti" else L.hso_shufti_rev)(lo, hi, p, n)
+    if kind in ("truffle", "rtruffle"):
+        m1, m2 = accel.CharClass(params).to_truffle()
+        return (L.hso_truffle_fwd if kind == "truffle" else L.hso_truffle_rev)(m1, m2, p, n)
     raise AssertionError(kind)
 
 
@@ -67,6 +73,14 @@ def ref_eval(kind, params, buf):
     if kind == "dshufti":
         lo1, hi1, lo2, hi2 = ref_dshufti_masks(params)
         return R.hsref_dshufti_exec(lo1, hi1, lo2, hi2, p, n)
+    if kind in ("shufti", "rshufti", "truffle", "rtruffle"):
+        cls = accel.CharClass(params)
+        a, b = U8x16(), U8x16()
+        if kind.endswith("shufti"):
+            assert R.hsref_shufti_build(cls.bitmap.ctypes.data, a, b) > 0
+            return (R.hsref_shufti_exec if kind == "shufti" else R.hsref_rshufti_exec)(a, b, p, n)
+        R.hsref_truffle_build(cls.bitmap.ctypes.data, a, b)
+        return (R.hsref_truffle_exec if kind == "truffle" else R.hsref_rtruffle_exec)(a, b, p, n)
     raise AssertionError(kind)
 
 
@@ -83,13 +97,13 @@ def expected(case):
     name, kind, params, text, lo, hi, want_abs = case
     n = len(text) - lo - hi
     if want_abs is None:
-        return -1 if kind in ("rverm", "rdverm") else n
+        return -1 if kind in ("rverm", "rdverm", "rshufti", "rtruffle") else n
     return want_abs - lo
 
 
 def test_oracle_on_reference_unit_test_vectors():
     cases = ga.cases()
-    assert len(cases) > 700
+    assert len(cases) > 1200
     for case in cases:
         name, kind, params, text, lo, hi, _ = case
         _raw, buf = aligned_copy(text[lo: len(text) - hi], 0)
