@@ -319,43 +319,3 @@ def test_forward_skip_is_do_accel_block_for_a_batch():
             for end, lid in orc.collect(blk):
                 size = len(lits[lid].s)
                 assert end + 1 - size >= skip[b], "a literal starts before the skip"
-
-
-def test_class_scan_reference_unit_test_vectors():
-    """The single-byte golden vectors (tests/golden_accel.py: Vermicelli / RVermicelli / Shufti /
-    ReverseShufti / Truffle / ReverseTruffle unit tests) through hsgpu_class_scan_dev: every
-    scanned slice is one block of a batch, all slices sharing a class go in one launch. The
-    shufti and truffle classes take the round trip through the product's own mask builders and
-    decoders (to_shufti -> from_shufti, to_truffle -> from_truffle)."""
-    import torch
-
-    from tests import golden_accel as ga
-    from tests.test_oracle_accel import expected
-
-    def class_for(kind, params):
-        if kind in ("verm", "rverm"):
-            return accel.CharClass.from_verm(params[0], params[1], False)
-        cls = accel.CharClass(params)
-        if kind in ("shufti", "rshufti"):
-            lo, hi, _nb = cls.to_shufti()
-            return accel.CharClass.from_shufti(lo, hi)
-        return accel.CharClass.from_truffle(*cls.to_truffle())
-
-    groups = {}
-    for case in ga.cases():
-        if case[1] in ("verm", "rverm", "shufti", "rshufti", "truffle", "rtruffle"):
-            groups.setdefault((case[1], case[2]), []).append(case)
-    assert len(groups) >= 20
-    checked = 0
-    for (kind, params), cs in groups.items():
-        blocks = [c[3][c[4]: len(c[3]) - c[5]] for c in cs]
-        corpus = np.frombuffer(b"".join(blocks), dtype=np.uint8)
-        off = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.uint64)
-        d = torch.from_numpy(corpus.copy()).to("cuda:0")
-        d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
-        _bm, first, last = accel.class_scan([class_for(kind, params)], d, corpus.size, d_off, len(blocks), True, True)
-        got = (last if kind.startswith("r") else first).cpu().numpy().view(np.uint32)[0]
-        for b, case in enumerate(cs):
-            assert int(got[b]) == (expected(case) & 0xFFFFFFFF), case[0]
-            checked += 1
-    assert checked > 600

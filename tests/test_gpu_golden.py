@@ -101,21 +101,6 @@ def test_flood_counts(scratch, engine):
                 assert cnt.get(i, 0) == n, (c, i)
 
 
-def test_flood_with_mask_counts(scratch):
-    # unit/internal/fdr_flood.cpp:242-403 FDRFloodp.WithMask, all 256 byte values
-    for c in range(256):
-        lits, c_alt, _ = gc.flood_mask_literals(c)
-        t = H.hwlm_build(lits)
-        first, second = gc.flood_mask_expected_counts(c)
-        cases = [dict(buf=bytes([c]) * 1024), dict(buf=bytes([c_alt]) * 1024)]
-        for got, want in zip(batch_cases(t, scratch, cases), (first, second)):
-            cnt = {}
-            for _e, i in got:
-                cnt[i] = cnt.get(i, 0) + 1
-            for i, n in want.items():
-                assert cnt.get(i, 0) == n, (c, i)
-
-
 def test_noodle_cases(scratch):
     cases = [c for c in gc.noodle_cases() if len(c["buf"])]
     by_lit = {}

@@ -231,30 +231,3 @@ def test_golden_vectors_under_alternative_pipelines(env):
                           "-m", "gpu"], capture_output=True, text=True, env=dict(os.environ, **env), cwd=root, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
-
-
-def test_scratch_regrowth_between_scans():
-    """A scratch's buffers grow when a later scan is bigger. The control words rely on being
-    left zeroed by the previous scan, so a regrown control block must be cleared even when
-    hipMalloc hands the freed range back at the same address (it does, now and then: that case
-    once produced garbage match counts). Small scan, then a much bigger one, on fresh
-    scratches, several times over, with allocations of other sizes in between."""
-    import torch
-
-    lits = cp.teddy_literals()
-    big, big_off = cp.packet_corpus(4 << 20, lits, seed=3, match_every=2048)
-    small, small_off = cp.packet_corpus(4096, lits, seed=4, match_every=512)
-    t = H.hwlm_build(lits)
-    orc = ob.Oracle(lits)
-    want_big = as_set(orc.collect_blocks(big, big_off))
-    want_small = as_set(orc.collect_blocks(small, small_off))
-    keep = []
-    for trial in range(8):
-        s = H.Scratch(0)
-        try:
-            assert as_set(hw.hwlm_exec_batch(t, s, small, small_off)) == want_small
-            keep.append(torch.empty((trial + 1) * 12_345, dtype=torch.uint8, device="cuda:0"))  # perturb the allocator
-            assert as_set(hw.hwlm_exec_batch(t, s, big, big_off)) == want_big
-            assert as_set(hw.hwlm_exec_batch(t, s, small, small_off)) == want_small
-        finally:
-            s.close()
