@@ -127,8 +127,28 @@ ByteSet fold_case(const ByteSet &s) {
     return o;
 }
 
+constexpr unsigned kAllFlags = 0x7ff; /* HS_FLAG_ALL: the eleven flags of src/hs_compile.h */
+
+/* the reference's own flag rules, in its order (src/compiler/compiler.cpp:286-294,166-196) */
+void check_flags(unsigned flags, bool literal_api) {
+    if (!literal_api && (flags & HS_FLAG_COMBINATION)) {
+        if (flags & ~(HS_FLAG_COMBINATION | HS_FLAG_QUIET | HS_FLAG_SINGLEMATCH))
+            throw ParseError{"only HS_FLAG_QUIET and HS_FLAG_SINGLEMATCH are supported in combination with "
+                             "HS_FLAG_COMBINATION."};
+        throw ParseError{"Logical combinations are not supported by the GPU literal engine."};
+    }
+    if (!literal_api && (flags & HS_FLAG_QUIET) && (flags & HS_FLAG_SOM_LEFTMOST))
+        throw ParseError{"HS_FLAG_QUIET is not supported in combination with HS_FLAG_SOM_LEFTMOST."};
+    if (flags & ~kAllFlags) throw ParseError{"Unrecognised flag."};
+    if ((flags & HS_FLAG_SINGLEMATCH) && (flags & HS_FLAG_SOM_LEFTMOST))
+        throw ParseError{"HS_FLAG_SINGLEMATCH is not supported in combination with HS_FLAG_SOM_LEFTMOST."};
+    if (!literal_api && (flags & HS_FLAG_PREFILTER) && (flags & HS_FLAG_SOM_LEFTMOST))
+        throw ParseError{"HS_FLAG_PREFILTER is not supported in combination with HS_FLAG_SOM_LEFTMOST."};
+}
+
 /* pattern := literal-prefix tail ; tail := (atom quantifier?)* */
 Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
+    check_flags(flags, false);
     const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_PREFILTER | HS_FLAG_COMBINATION |
                                  HS_FLAG_QUIET | HS_FLAG_ALLOWEMPTY;
     if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};
@@ -434,10 +454,23 @@ void apply_ext(Pattern &p, const hs_expr_ext_t &e) {
 hs_error_t build_database(const std::vector<std::string> &exprs, const std::vector<unsigned char> &is_lit,
                           const unsigned *flags, const unsigned *ids, const hs_expr_ext_t *const *ext, unsigned mode,
                           hs_database_t **db, hs_compile_error_t **error) {
-    if (mode != HS_MODE_BLOCK) {
-        *error = make_error((mode & (HS_MODE_STREAM | HS_MODE_VECTORED))
-                                ? "Only HS_MODE_BLOCK is supported by the GPU literal engine."
-                                : "Invalid parameter: unrecognised mode flags.", -1);
+    /* checkMode, src/hs.cpp:78-118: the reference's rules and messages first, then ours */
+    const unsigned som_modes = HS_MODE_SOM_HORIZON_LARGE | HS_MODE_SOM_HORIZON_MEDIUM | HS_MODE_SOM_HORIZON_SMALL;
+    const unsigned scan_modes = mode & (HS_MODE_BLOCK | HS_MODE_STREAM | HS_MODE_VECTORED);
+    const char *mode_err = nullptr;
+    if (mode & ~(HS_MODE_BLOCK | HS_MODE_STREAM | HS_MODE_VECTORED | som_modes))
+        mode_err = "Invalid parameter: unrecognised mode flags.";
+    else if (scan_modes == 0 || (scan_modes & (scan_modes - 1)))
+        mode_err = "Invalid parameter: mode must have one (and only one) of HS_MODE_BLOCK, HS_MODE_STREAM or "
+                   "HS_MODE_VECTORED set.";
+    else if ((mode & som_modes) && !(mode & HS_MODE_STREAM))
+        mode_err = "Invalid parameter: the HS_MODE_SOM_HORIZON_ mode flags may only be set in streaming mode.";
+    else if ((mode & som_modes) & ((mode & som_modes) - 1))
+        mode_err = "Invalid parameter: only one HS_MODE_SOM_HORIZON_ mode flag can be set.";
+    else if (mode != HS_MODE_BLOCK)
+        mode_err = "Only HS_MODE_BLOCK is supported by the GPU literal engine.";
+    if (mode_err) {
+        *error = make_error(mode_err, -1);
         return HS_COMPILER_ERROR;
     }
     void *mem = hook_alloc(g_db, sizeof(hs_database));
@@ -454,6 +487,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
             const unsigned f = flags ? flags[i] : 0, id = ids ? ids[i] : 0;
             try {
                 if (is_lit[i]) {
+                    check_flags(f, true);
                     /* src/compiler/compiler.cpp:405-419: flags the pure-literal API refuses */
                     const unsigned bad = HS_FLAG_DOTALL | HS_FLAG_ALLOWEMPTY | HS_FLAG_UTF8 | HS_FLAG_UCP |
                                          HS_FLAG_PREFILTER | HS_FLAG_COMBINATION | HS_FLAG_QUIET | HS_FLAG_MULTILINE;
@@ -621,7 +655,18 @@ extern "C" {
 hs_error_t hs_compile_ext_multi(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
                                 const hs_expr_ext_t *const *ext, unsigned int elements, unsigned int mode,
                                 const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error) {
-    (void)platform;
+    if (platform) { /* checkPlatform, src/hs.cpp:122-146 */
+        const char *perr = nullptr;
+        if (platform->cpu_features & ~(HS_CPU_FEATURES_AVX2 | HS_CPU_FEATURES_AVX512 | HS_CPU_FEATURES_AVX512VBMI))
+            perr = "Invalid cpu features specified in the platform information.";
+        else if (platform->tune > HS_TUNE_FAMILY_ICX)
+            perr = "Invalid tuning value specified in the platform information.";
+        if (perr) {
+            if (db) *db = nullptr;
+            if (error) *error = make_error(perr, -1);
+            return HS_COMPILER_ERROR;
+        }
+    }
     if (!error) {
         if (db) *db = nullptr;
         return HS_COMPILER_ERROR;
@@ -658,7 +703,18 @@ hs_error_t hs_compile(const char *expression, unsigned int flags, unsigned int m
 hs_error_t hs_compile_lit_multi(const char *const *expressions, const unsigned *flags, const unsigned *ids,
                                 const size_t *lens, unsigned elements, unsigned mode,
                                 const hs_platform_info_t *platform, hs_database_t **db, hs_compile_error_t **error) {
-    (void)platform;
+    if (platform) { /* checkPlatform, src/hs.cpp:122-146 */
+        const char *perr = nullptr;
+        if (platform->cpu_features & ~(HS_CPU_FEATURES_AVX2 | HS_CPU_FEATURES_AVX512 | HS_CPU_FEATURES_AVX512VBMI))
+            perr = "Invalid cpu features specified in the platform information.";
+        else if (platform->tune > HS_TUNE_FAMILY_ICX)
+            perr = "Invalid tuning value specified in the platform information.";
+        if (perr) {
+            if (db) *db = nullptr;
+            if (error) *error = make_error(perr, -1);
+            return HS_COMPILER_ERROR;
+        }
+    }
     if (!error) {
         if (db) *db = nullptr;
         return HS_COMPILER_ERROR;

@@ -80,6 +80,17 @@ typedef struct hs_scratch hs_scratch_t;
 #define HS_MODE_NOSTREAM 1
 #define HS_MODE_STREAM 2
 #define HS_MODE_VECTORED 4
+#define HS_MODE_SOM_HORIZON_LARGE (1U << 24)
+#define HS_MODE_SOM_HORIZON_MEDIUM (1U << 25)
+#define HS_MODE_SOM_HORIZON_SMALL (1U << 26)
+
+/* hs_platform_info_t fields (src/hs_compile.h:1010-1134): validated as the reference does,
+ * otherwise ignored -- the engine targets gfx950 whatever the host CPU is */
+#define HS_CPU_FEATURES_AVX2 (1ULL << 2)
+#define HS_CPU_FEATURES_AVX512 (1ULL << 3)
+#define HS_CPU_FEATURES_AVX512VBMI (1ULL << 4)
+#define HS_TUNE_FAMILY_GENERIC 0
+#define HS_TUNE_FAMILY_ICX 10
 
 typedef struct hs_compile_error {
     char *message;

@@ -377,3 +377,67 @@ def test_hs_allocator_hooks():
     finally:
         lib.hs_set_allocator(ALLOC(0), FREE(0))
     hs.Database.compile(["back", "to", "malloc"]).close()
+
+
+def test_hs_compile_arg_checks_like_the_reference():
+    """unit/hyperscan/arg_checks.cpp:102-337, the compile-side half (no device needed): same
+    return codes, and the reference's own messages where the test pins them."""
+    from hyperscan_amd import hs
+
+    lib = hs._lib()
+    P = C.POINTER
+    lib.hs_compile.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_void_p, P(C.c_void_p), P(P(hs.CompileErrorStruct))]
+
+    def compile_one(expr, flags, mode, platform=None, want_db=True):
+        db, err = C.c_void_p(), P(hs.CompileErrorStruct)()
+        rv = lib.hs_compile(expr, flags, mode, platform, C.byref(db) if want_db else None, C.byref(err))
+        msg = err.contents.message.decode() if err else None
+        if err:
+            lib.hs_free_compile_error(err)
+        if rv == 0:
+            lib.hs_free_database(db)
+        return rv, msg, db.value
+
+    ERR = hs.HS_COMPILER_ERROR
+    # SingleCompileBlockNoPattern / StreamingNoPattern: NULL pattern
+    for mode in (hs.HS_MODE_BLOCK, hs.HS_MODE_STREAM):
+        rv, msg, dbv = compile_one(None, 0, mode)
+        assert rv == ERR and msg and dbv is None
+    # SingleCompileBlockNoDatabase: NULL database pointer still yields an error object
+    rv, msg, _ = compile_one(b"foobar", 0, hs.HS_MODE_BLOCK, want_db=False)
+    assert rv == ERR and msg
+    # SingleCompileNoMode / SeveralModes1
+    one_mode = "Invalid parameter: mode must have one (and only one) of HS_MODE_BLOCK, HS_MODE_STREAM or HS_MODE_VECTORED set."
+    assert compile_one(b"foobar", 0, 0)[:2] == (ERR, one_mode)
+    assert compile_one(b"foobar", 0, hs.HS_MODE_STREAM | hs.HS_MODE_BLOCK)[:2] == (ERR, one_mode)
+    # SingleCompileBogusFlags: 0xdeadbeef has HS_FLAG_COMBINATION set
+    assert compile_one(b"foobar", 0xDEADBEEF, hs.HS_MODE_BLOCK)[:2] == (
+        ERR, "only HS_FLAG_QUIET and HS_FLAG_SINGLEMATCH are supported in combination with HS_FLAG_COMBINATION.")
+    assert compile_one(b"foobar", 1 << 20, hs.HS_MODE_BLOCK)[:2] == (ERR, "Unrecognised flag.")
+    assert compile_one(b"foobar", hs.HS_FLAG_SINGLEMATCH | hs.HS_FLAG_SOM_LEFTMOST, hs.HS_MODE_BLOCK)[:2] == (
+        ERR, "HS_FLAG_SINGLEMATCH is not supported in combination with HS_FLAG_SOM_LEFTMOST.")
+    # SingleCompileBogusMode1
+    assert compile_one(b"foobar", 0, hs.HS_MODE_STREAM | (1 << 30))[:2] == (ERR, "Invalid parameter: unrecognised mode flags.")
+    # SOM horizon flags belong to streaming mode (hs.cpp:100-115)
+    assert compile_one(b"foobar", 0, hs.HS_MODE_BLOCK | (1 << 24))[:2] == (
+        ERR, "Invalid parameter: the HS_MODE_SOM_HORIZON_ mode flags may only be set in streaming mode.")
+    assert compile_one(b"foobar", 0, hs.HS_MODE_STREAM | (1 << 24) | (1 << 25))[:2] == (
+        ERR, "Invalid parameter: only one HS_MODE_SOM_HORIZON_ mode flag can be set.")
+    # SingleCompileBadTune / BadFeatures: hs_platform_info_t {tune u32, cpu_features u64, reserved x2}
+    class Plat(C.Structure):
+        _fields_ = [("tune", C.c_uint), ("cpu_features", C.c_ulonglong), ("r1", C.c_ulonglong), ("r2", C.c_ulonglong)]
+    assert compile_one(b"foobar", 0, hs.HS_MODE_BLOCK, C.byref(Plat(42, 0, 0, 0)))[:2] == (
+        ERR, "Invalid tuning value specified in the platform information.")
+    assert compile_one(b"foobar", 0, hs.HS_MODE_BLOCK, C.byref(Plat(0, 42, 0, 0)))[:2] == (
+        ERR, "Invalid cpu features specified in the platform information.")
+    assert compile_one(b"foobar", 0, hs.HS_MODE_BLOCK, C.byref(Plat(10, 1 << 2, 0, 0)))[0] == 0  # ICX + AVX2: accepted, ignored
+    # streaming / vectored are well-formed requests this engine declines
+    assert compile_one(b"foobar", 0, hs.HS_MODE_STREAM)[:2] == (ERR, "Only HS_MODE_BLOCK is supported by the GPU literal engine.")
+    # MultiCompileZeroPatterns / NoPattern
+    lib.hs_compile_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, P(C.c_void_p),
+                                     P(P(hs.CompileErrorStruct))]
+    for exprs, n in ((None, 1), ((C.c_char_p * 1)(b"foobar"), 0)):
+        db, err = C.c_void_p(), P(hs.CompileErrorStruct)()
+        assert lib.hs_compile_multi(exprs, None, None, n, hs.HS_MODE_BLOCK, None, C.byref(db), C.byref(err)) == ERR
+        assert err and db.value is None
+        lib.hs_free_compile_error(err)
