@@ -441,3 +441,40 @@ def test_hs_compile_arg_checks_like_the_reference():
         assert lib.hs_compile_multi(exprs, None, None, n, hs.HS_MODE_BLOCK, None, C.byref(db), C.byref(err)) == ERR
         assert err and db.value is None
         lib.hs_free_compile_error(err)
+
+
+def test_hs_runtime_arg_checks_without_a_device():
+    """unit/hyperscan/arg_checks.cpp:875-1545, the checks that come before any device work:
+    NULL / corrupt handles are HS_INVALID, never a crash."""
+    from hyperscan_amd import hs
+
+    lib = hs._lib()
+    db = hs.Database.compile(["foobar"])
+    cb = hs.MATCH_CB(lambda *a: 0)
+    junk = C.create_string_buffer(4096)  # a "database" / "scratch" whose magic is wrong
+    # ScanBlockNoDatabase / BrokenDatabaseMagic / NoScratch / NoData
+    assert lib.hs_scan(None, b"data", 4, 0, None, cb, None) == hs.HS_INVALID
+    assert lib.hs_scan(db._h, b"data", 4, 0, None, cb, None) == hs.HS_INVALID
+    assert lib.hs_scan(C.cast(junk, C.c_void_p), b"data", 4, 0, C.cast(junk, C.c_void_p), cb, None) == hs.HS_INVALID
+    assert lib.hs_scan(db._h, None, 4, 0, C.cast(junk, C.c_void_p), cb, None) == hs.HS_INVALID
+    # AllocScratchNoDatabase / NullScratchPtr / BogusScratch / BadDatabaseMagic
+    s = C.c_void_p()
+    assert lib.hs_alloc_scratch(None, C.byref(s)) == hs.HS_INVALID
+    assert lib.hs_alloc_scratch(db._h, None) == hs.HS_INVALID
+    bogus = C.cast(junk, C.c_void_p)
+    assert lib.hs_alloc_scratch(db._h, C.byref(bogus)) == hs.HS_INVALID
+    assert lib.hs_alloc_scratch(C.cast(junk, C.c_void_p), C.byref(s)) == hs.HS_INVALID
+    # CloneScratchNoSource, scratch size / free of junk
+    lib.hs_clone_scratch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    assert lib.hs_clone_scratch(None, C.byref(s)) == hs.HS_INVALID
+    assert lib.hs_free_scratch(None) == 0 and lib.hs_free_scratch(C.cast(junk, C.c_void_p)) == hs.HS_INVALID
+    # SerializeNoDatabase / NoBuffer / NoLength; database_size / info with junk
+    p, n = C.c_void_p(), C.c_size_t()
+    assert lib.hs_serialize_database(None, C.byref(p), C.byref(n)) == hs.HS_INVALID
+    assert lib.hs_serialize_database(db._h, None, C.byref(n)) == hs.HS_INVALID
+    assert lib.hs_serialize_database(db._h, C.byref(p), None) == hs.HS_INVALID
+    assert lib.hs_database_size(C.cast(junk, C.c_void_p), C.byref(n)) == hs.HS_INVALID
+    assert lib.hs_free_database(None) == 0 and lib.hs_free_database(C.cast(junk, C.c_void_p)) == hs.HS_INVALID
+    lib.hs_deserialize_database.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    assert lib.hs_deserialize_database(None, 10, C.byref(p)) == hs.HS_INVALID
+    assert lib.hs_deserialize_database(b"x" * 10, 10, None) == hs.HS_INVALID
