@@ -775,10 +775,28 @@ hs_error_t hs_database_info(const hs_database_t *db, char **info) {
     return HS_SUCCESS;
 }
 
-/* serialised form: magic "HSGE", count, then per pattern {is_lit, flags, id, len, ext flags,
- * min_offset, max_offset, min_length, bytes} -- the database is rebuilt from its sources on
- * load (compilation is cheap for this engine; the GPU table is rebuilt with it) */
-static const unsigned kSerialMagic = 0x48534745;
+/* serialised form: magic "HSGF", CRC-32 of everything after it, count, then per pattern
+ * {is_lit, flags, id, len, ext flags, min_offset, max_offset, min_length, bytes} -- the
+ * database is rebuilt from its sources on load (compilation is cheap for this engine; the
+ * GPU table is rebuilt with it). The reference guards its bytecode with a CRC too
+ * (src/database.c:119-168): a damaged blob is HS_INVALID, never a different database. */
+static const unsigned kSerialMagic = 0x48534746;
+
+static unsigned crc32_of(const unsigned char *p, size_t n) {
+    static unsigned table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (unsigned i = 0; i < 256; i++) {
+            unsigned c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    unsigned c = ~0u;
+    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    return ~c;
+}
 
 hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length) {
     if (!db || !bytes || !length || db->magic != 0x48534744) return HS_INVALID;
@@ -786,6 +804,7 @@ hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *
     auto put32 = [&](unsigned v) { out.append((const char *)&v, 4); };
     auto put64 = [&](unsigned long long v) { out.append((const char *)&v, 8); };
     put32(kSerialMagic);
+    put32(0); /* CRC, filled in below */
     put32((unsigned)db->sources.size());
     for (size_t i = 0; i < db->sources.size(); i++) {
         put32(db->src_is_lit[i]);
@@ -798,6 +817,8 @@ hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *
         put64(db->src_ext[i].min_length);
         out += db->sources[i];
     }
+    const unsigned crc = crc32_of((const unsigned char *)out.data() + 8, out.size() - 8);
+    memcpy(&out[4], &crc, 4);
     *bytes = (char *)hook_alloc(g_misc, out.size());
     if (hs_error_t ae = check_alloc(*bytes)) {
         hook_free(g_misc, *bytes);
@@ -834,7 +855,11 @@ hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
     unsigned magic, n;
     if (!get32(magic)) return HS_INVALID;
     if ((magic & 0xffffff00u) == (kSerialMagic & 0xffffff00u) && magic != kSerialMagic) return HS_DB_VERSION_ERROR;
-    if (magic != kSerialMagic || !get32(n) || n == 0) return HS_INVALID;
+    unsigned crc = 0;
+    if (magic != kSerialMagic || !get32(crc) || length < 12 ||
+        crc != crc32_of((const unsigned char *)bytes + 8, length - 8))
+        return HS_INVALID;
+    if (!get32(n) || n == 0) return HS_INVALID;
     for (unsigned i = 0; i < n; i++) {
         unsigned l, f, id, len;
         hs_expr_ext_t e;

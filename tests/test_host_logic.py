@@ -478,3 +478,22 @@ def test_hs_runtime_arg_checks_without_a_device():
     lib.hs_deserialize_database.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     assert lib.hs_deserialize_database(None, 10, C.byref(p)) == hs.HS_INVALID
     assert lib.hs_deserialize_database(b"x" * 10, 10, None) == hs.HS_INVALID
+
+
+def test_hs_serialized_database_is_guarded_by_a_crc():
+    """unit/hyperscan/serialize.cpp: a damaged blob must not deserialise (to anything)."""
+    from hyperscan_amd import hs
+
+    db = hs.Database.compile(["alpha\\d+", "beta"], [hs.HS_FLAG_CASELESS, 0], [1, 2])
+    blob = db.serialize()
+    assert hs.Database.deserialize(blob).serialize() == blob
+    for pos in (4, 9, len(blob) // 2, len(blob) - 1):
+        bad = bytearray(blob)
+        bad[pos] ^= 0x01
+        with pytest.raises(hs.HsError) as e:
+            hs.Database.deserialize(bytes(bad))
+        assert e.value.code == hs.HS_INVALID, pos
+    with pytest.raises(hs.HsError):
+        hs.Database.deserialize(blob[:-1])  # truncated
+    with pytest.raises(hs.HsError):
+        hs.Database.deserialize(blob + b"\\0")  # trailing junk
