@@ -159,7 +159,21 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
     pat.id = id;
     const bool dotall = flags & HS_FLAG_DOTALL;
     size_t i = 0;
-    auto peek_quant = [&](size_t k) { return k < p.size() && (p[k] == '?' || p[k] == '*' || p[k] == '+' || p[k] == '{'); };
+    /* `{` opens a repeat only when a well-formed {m}, {m,} or {m,n} follows; otherwise it (and
+     * a lone `}`) is an ordinary character, as in PCRE ("foo.{,10}bar" is twelve literal-ish
+     * positions: unit/hyperscan/expr_info.cpp:211) */
+    auto is_repeat = [&](size_t k) {
+        if (k >= p.size() || p[k] != '{') return false;
+        size_t j = k + 1, d = 0;
+        while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++, d++;
+        if (d == 0) return false;
+        if (j < p.size() && p[j] == ',') {
+            j++;
+            while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++;
+        }
+        return j < p.size() && p[j] == '}';
+    };
+    auto peek_quant = [&](size_t k) { return k < p.size() && (p[k] == '?' || p[k] == '*' || p[k] == '+' || is_repeat(k)); };
     /* literal prefix: plain or escaped characters not followed by a quantifier */
     while (i < p.size()) {
         unsigned char c = (unsigned char)p[i];
@@ -172,7 +186,7 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
             if (ok) break; /* \d etc: tail */
             j = i + 1;
             if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
-        } else if (strchr(".[]()|^$*+?{}", c)) {
+        } else if (strchr(".[]()|^$*+?", c) || (c == '{' && is_repeat(i))) {
             if (c == '.' || c == '[') break;
             throw ParseError{std::string("Unsupported regex construct '") + (char)c +
                              "': only a literal prefix followed by classes and quantifiers is supported."};
@@ -260,7 +274,7 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
             }
             i = j + 1;
             if (neg) cls = ~cls;
-        } else if (strchr("()|^$*+?{}]", c)) {
+        } else if (strchr("()|^$*+?]", c) || (c == '{' && is_repeat(i))) {
             throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
         } else {
             cls.set(c);
@@ -274,7 +288,7 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
             if (q == '?') { lo = 0; hi = 1; i++; }
             else if (q == '*') { lo = 0; hi = kInf; i++; }
             else if (q == '+') { lo = 1; hi = kInf; i++; }
-            else if (q == '{') {
+            else if (q == '{' && is_repeat(i)) {
                 size_t j = i + 1;
                 auto num = [&](unsigned &v) {
                     if (j >= p.size() || p[j] < '0' || p[j] > '9') return false;

@@ -497,3 +497,21 @@ def test_hs_serialized_database_is_guarded_by_a_crc():
         hs.Database.deserialize(blob[:-1])  # truncated
     with pytest.raises(hs.HsError):
         hs.Database.deserialize(blob + b"\\0")  # trailing junk
+
+
+def test_expression_info_reference_table_subset():
+    """unit/hyperscan/expr_info.cpp:182-228: the rows of ei_test[] that lie inside the supported
+    pattern subset (literal prefix + classes / quantifiers), with and without ext parameters."""
+    from hyperscan_amd import hs
+
+    U = 0xFFFFFFFF
+    rows = [("abc", None, 3, 3), ("abc.*def", None, 6, U), ("foo.{1,13}bar", None, 7, 19), ("foo.{10,}bar", None, 16, U),
+            ("foo.{0,10}bar", None, 6, 16), ("foo.{,10}bar", None, 12, 12), ("foo.{10}bar", None, 16, 16),
+            ("abc.*def", dict(max_offset=10), 6, 10), ("abc.*def", dict(min_length=100), 100, U),
+            ("abc.*def", dict(min_length=5), 6, U)]
+    for pat, ext, mn, mx in rows:
+        assert hs.expression_info(pat, 0, hs.ExprExt.make(**ext) if ext else None) == (mn, mx), pat
+    # rows outside the subset are refused, not mis-measured
+    for pat in ("abc|defghi", "abc(def)?", "^foo", "foobar$", "\\bfoo"):
+        with pytest.raises(hs.HsError):
+            hs.expression_info(pat)
