@@ -515,3 +515,27 @@ def test_expression_info_reference_table_subset():
     for pat in ("abc|defghi", "abc(def)?", "^foo", "foobar$", "\\bfoo"):
         with pytest.raises(hs.HsError):
             hs.expression_info(pat)
+
+
+def test_headers_are_valid_c_and_the_example_links(tmp_path):
+    """include/*.h must be usable from plain C (the drop-in boundary is a C ABI), and
+    examples/simplegrep.c must build and link against libhsgpu.so with nothing but gcc."""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text('#include "hsgpu.h"\n#include "hs_gpu.h"\n'
+                   "int main(void) { hsgpu_lit_t l; hsgpu_match_t m; hsgpu_accel_t a; hsgpu_pair_t p; hs_expr_ext_t e;\n"
+                   "  (void)l; (void)m; (void)a; (void)p; (void)e; return hs_version() == 0 || hsgpu_version() == 0; }\n")
+    lib_dir = os.path.join(ROOT, "hyperscan_amd", "lib")
+    inc = os.path.join(ROOT, "include")
+    for std in ("-std=c99", "-std=c11"):
+        r = subprocess.run(["gcc", std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(tmp_path / "abi"),
+                            "-L", lib_dir, "-lhsgpu", f"-Wl,-rpath,{lib_dir}"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", inc, os.path.join(ROOT, "examples", "simplegrep.c"), "-o",
+                        str(tmp_path / "simplegrep"), "-L", lib_dir, "-lhsgpu", f"-Wl,-rpath,{lib_dir}"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # without a pattern argument the example prints its usage and fails before touching a device
+    r = subprocess.run([str(tmp_path / "simplegrep")], capture_output=True, text=True)
+    assert r.returncode != 0 and "sage" in (r.stdout + r.stderr)
