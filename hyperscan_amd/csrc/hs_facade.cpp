@@ -1055,35 +1055,14 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
     return HS_SUCCESS;
 }
 
-hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
-                         unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
-                         hs_batch_event_handler onEvent, void *context) {
-    (void)flags;
-    if (!scratch || !data || !off) return HS_INVALID;
-    if (!db || db->magic != 0x48534744) return HS_INVALID;
-    if (db->mode != HS_MODE_BLOCK) return HS_DB_MODE_ERROR;
-    if (scratch->magic != 0x48534753) return HS_INVALID;
-    if (scratch->in_use) return HS_SCRATCH_IN_USE;
-    scratch->in_use = true;
-    struct Guard { hs_scratch *s; ~Guard() { s->in_use = false; } } guard{scratch};
-    if (nblocks == 0) return HS_SUCCESS;
-    const auto t_begin = std::chrono::steady_clock::now();
-    size_t cap = std::max<size_t>(std::max<size_t>(4096, scratch->recs_cap), (size_t)(off[nblocks] - off[0]) / 1024), n = 0;
-    for (int attempt = 0; attempt < 8; attempt++) {
-        if (!scratch->reserve(cap)) return HS_NOMEM;
-        int rv = hsgpu_hwlm_exec_batch(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off,
-                                       (size_t)nblocks, 0, scratch->recs, cap, &n);
-        if (rv == HSGPU_SUCCESS) break;
-        if (rv != HSGPU_INSUFFICIENT_SPACE) return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
-        cap = n + n / 4; /* n = the exact total */
-        if (attempt == 7) return HS_UNKNOWN_ERROR;
-    }
-    static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr; /* diagnostic: where does a batch go? */
-    const auto t_scan = std::chrono::steady_clock::now();
+/* The host confirm of a batch ("Rose-lite"): literal hits -> events, delivered in block order
+ * on the calling thread. recs: sorted by (block, end), id = pattern index, as the literal
+ * engine emits them. Returns true if some callback asked to stop (its block only). */
+static bool confirm_and_deliver(const hs_database *db, const char *data, const unsigned long long *off,
+                                const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context) {
     /* host confirm: the events of different blocks are independent, so large batches are cut
      * into slices of whole blocks handled by worker threads; delivery stays on the calling
      * thread, in block order, as the callback contract requires */
-    const hsgpu_match_t *recs = scratch->recs;
     unsigned n_thr = 1;
     if (onEvent && n >= 8192) n_thr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<std::vector<Event>> ev(n_thr);
@@ -1122,6 +1101,35 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
                     break;
                 }
             }
+    return any_terminated;
+}
+
+hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
+                         unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
+                         hs_batch_event_handler onEvent, void *context) {
+    (void)flags;
+    if (!scratch || !data || !off) return HS_INVALID;
+    if (!db || db->magic != 0x48534744) return HS_INVALID;
+    if (db->mode != HS_MODE_BLOCK) return HS_DB_MODE_ERROR;
+    if (scratch->magic != 0x48534753) return HS_INVALID;
+    if (scratch->in_use) return HS_SCRATCH_IN_USE;
+    scratch->in_use = true;
+    struct Guard { hs_scratch *s; ~Guard() { s->in_use = false; } } guard{scratch};
+    if (nblocks == 0) return HS_SUCCESS;
+    const auto t_begin = std::chrono::steady_clock::now();
+    size_t cap = std::max<size_t>(std::max<size_t>(4096, scratch->recs_cap), (size_t)(off[nblocks] - off[0]) / 1024), n = 0;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        if (!scratch->reserve(cap)) return HS_NOMEM;
+        int rv = hsgpu_hwlm_exec_batch(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off,
+                                       (size_t)nblocks, 0, scratch->recs, cap, &n);
+        if (rv == HSGPU_SUCCESS) break;
+        if (rv != HSGPU_INSUFFICIENT_SPACE) return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
+        cap = n + n / 4; /* n = the exact total */
+        if (attempt == 7) return HS_UNKNOWN_ERROR;
+    }
+    static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr; /* diagnostic: where does a batch go? */
+    const auto t_scan = std::chrono::steady_clock::now();
+    const bool any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context);
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "hs_scan_batch: %zu literal hits; GPU literal scan incl. copies %.2f ms, host confirm %.2f ms\n", n,
@@ -1129,6 +1137,25 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
                 std::chrono::duration<double, std::milli>(t_end - t_scan).count());
     }
     return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
+}
+
+/* Extension: the host confirm alone, for callers that bring their own literal hits (another
+ * literal engine, a replayed capture, a test): recs as hsgpu_hwlm_exec_batch would return them
+ * for this database's literals -- sorted by (block, end), id = index of the pattern in
+ * compile order. No device is touched. */
+hs_error_t hs_confirm_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
+                            unsigned long long nblocks, const void *records, unsigned long long n_records,
+                            hs_batch_event_handler onEvent, void *context) {
+    if (!db || db->magic != 0x48534744 || !data || !off || (n_records && !records)) return HS_INVALID;
+    const hsgpu_match_t *recs = (const hsgpu_match_t *)records;
+    for (unsigned long long i = 0; i < n_records; i++) {
+        if (recs[i].block >= nblocks || recs[i].id >= db->pats.size()) return HS_INVALID;
+        if (i && (recs[i].block < recs[i - 1].block ||
+                  (recs[i].block == recs[i - 1].block && recs[i].end < recs[i - 1].end)))
+            return HS_INVALID;
+        if (recs[i].end >= off[recs[i].block + 1] - off[recs[i].block]) return HS_INVALID;
+    }
+    return confirm_and_deliver(db, data, off, recs, (size_t)n_records, onEvent, context) ? HS_SCAN_TERMINATED : HS_SUCCESS;
 }
 
 hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsigned int flags,

@@ -190,6 +190,14 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
                          unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
                          hs_batch_event_handler onEvent, void *context);
 
+/* Extension: only the host-side confirm of hs_scan_batch, over literal hits the caller supplies
+ * (hsgpu_match_t records, include/hsgpu.h: sorted by (block, end); id = index of the pattern in
+ * compile order; end = offset of the last byte of the pattern's literal prefix). Touches no
+ * device. HS_INVALID for records that are out of order or out of range. */
+hs_error_t hs_confirm_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
+                            unsigned long long nblocks, const void *records, unsigned long long n_records,
+                            hs_batch_event_handler onEvent, void *context);
+
 /* Ready-made batch handler that counts (hsbench's onMatch, tools/hsbench/engine_hyperscan.cpp:89-97):
  * context = unsigned long long * incremented once per match; never stops the scan. */
 int hs_batch_count_handler(unsigned long long block, unsigned int id, unsigned long long from,

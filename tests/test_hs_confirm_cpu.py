@@ -1,0 +1,182 @@
+"""The host-side "Rose-lite" confirm of the hs_* facade, on the CPU: literal hits come from the
+HWLM oracle instead of the GPU (hs_confirm_batch takes the records hsgpu_hwlm_exec_batch would
+return), events are checked against a brute-force model built on Python's `re`. Covers the
+long-literal check, the shift-and tail automaton, SINGLEMATCH, SOM_LEFTMOST, ext bounds, per-block
+termination and the threaded path (>= 8192 hits) with its ordered delivery."""
+import ctypes as C
+import re
+
+import numpy as np
+
+import hyperscan_amd as H
+from hyperscan_amd import hs
+from hyperscan_amd.hwlm import MATCH_DTYPE
+from tests import oracle_binding as ob
+
+
+def literal_hits(parts, corpus, off):
+    """what the literal engine reports for the facade's HWLM literals: the last <= 8 bytes of each
+    pattern's literal prefix, id = pattern index (hs_facade.cpp build_database)"""
+    lits = [H.HwlmLiteral(lit[-8:], nocase=bool(fl & hs.HS_FLAG_CASELESS), id=i) for i, (lit, _t, fl, _pid, _e) in enumerate(parts)]
+    got = ob.Oracle(lits).collect_blocks(corpus, off)
+    recs = np.zeros(len(got), dtype=MATCH_DTYPE)
+    recs["block"], recs["end"], recs["id"], recs["lit"] = got["block"], got["end"], got["id"], got["id"]
+    order = np.lexsort((recs["id"], recs["end"], recs["block"]))
+    return np.ascontiguousarray(recs[order])
+
+
+def confirm(db, corpus, off, recs, on_event=None):
+    lib = hs._lib()
+    lib.hs_confirm_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_ulonglong, hs.BATCH_CB,
+                                     C.c_void_p]
+    ev = []
+
+    def default(b, i, f, t):
+        ev.append((b, i, f, t))
+        return False
+
+    fn = on_event or default
+    cb = hs.BATCH_CB(lambda b, i, f, t, _fl, _c: 1 if fn(b, i, f, t) else 0)
+    rv = lib.hs_confirm_batch(db._h, corpus.ctypes.data, off.ctypes.data, off.size - 1, recs.ctypes.data, recs.size, cb, None)
+    return rv, ev
+
+
+def brute(parts, corpus, off):
+    """events per block: (block, id, from, to), one per (id, to), in delivery order"""
+    out = []
+    for b in range(off.size - 1):
+        data = bytes(corpus[int(off[b]):int(off[b + 1])])
+        evs = set()
+        for lit, tail, fl, pid, ext in parts:
+            rf = (re.I if fl & hs.HS_FLAG_CASELESS else 0) | (re.S if fl & hs.HS_FLAG_DOTALL else 0)
+            tre = re.compile(tail.encode("latin-1"), rf) if tail else None
+            hay, needle = (data.upper(), lit.upper()) if fl & hs.HS_FLAG_CASELESS else (data, lit)
+            k = hay.find(needle)
+            while k >= 0:
+                s = k + len(lit)
+                tos = [s] if tre is None else [to for to in range(s, len(data) + 1) if tre.fullmatch(data, s, to)]
+                for to in tos:
+                    if "min_offset" in ext and to < ext["min_offset"]:
+                        continue
+                    if "max_offset" in ext and to > ext["max_offset"]:
+                        continue
+                    if "min_length" in ext and to - k < ext["min_length"]:
+                        continue
+                    evs.add((to, pid, k if fl & hs.HS_FLAG_SOM_LEFTMOST else 0))
+                k = hay.find(needle, k + 1)
+        seen_single, per = set(), {}
+        for to, pid, frm in sorted(evs):  # one report per (id, to): the smallest `from` wins the sort
+            if (pid, to) in per:
+                continue
+            per[(pid, to)] = frm
+            single = any(p[3] == pid and p[2] & hs.HS_FLAG_SINGLEMATCH for p in parts)
+            if single:
+                if pid in seen_single:
+                    continue
+                seen_single.add(pid)
+            out.append((b, pid, frm, to))
+    return out
+
+
+def make_db(parts):
+    pats = [re.escape(l.decode("latin-1")).replace("\\ ", " ").replace("\\-", "-").replace("\\=", "=").replace("\\/", "/") + t
+            for l, t, _f, _p, _e in parts]
+    ext = [hs.ExprExt.make(**e) if e else None for _l, _t, _f, _p, e in parts]
+    return hs.Database.compile_ext(pats, [p[2] for p in parts], [p[3] for p in parts], ext)
+
+
+PARTS = [(b"GET /", r"[a-z]+\d", 0, 100, {}), (b"user=", r"\s+\w{2,8}=", hs.HS_FLAG_CASELESS, 101, {}),
+         (b"Content-Length", r".{0,16}END", hs.HS_FLAG_DOTALL, 102, {}), (b"abcdefghijkl", r"x?y*z", 0, 103, {}),
+         (b"Zq", r"[^\n]{3}", hs.HS_FLAG_CASELESS, 104, {}), (b"key", "", hs.HS_FLAG_SINGLEMATCH, 105, {}),
+         (b"0042", r"\d{2,}", hs.HS_FLAG_SOM_LEFTMOST, 106, {}), (b"BEEF", r"[A-F0-9]{4}:", 0, 107, dict(min_offset=40)),
+         # (the literal prefix runs through escaped literal characters: "html\." is all prefix)
+         (b"html.", r"\w+", 0, 108, dict(max_offset=200, min_length=6))]
+WORDS = [b"GET /", b"get /", b"user=", b"USER=", b"Content-Length", b"abcdefghijkl", b"abcdefghijkX", b"Zq", b"zQ", b"abc12",
+         b"  key=", b" END", b"xyyz", b"z", b"\n", b"0042", b"004277", b"BEEF", b"BEEF:", b"C0DE:", b"html", b".html.x", b"   ",
+         b"q9", b"END", b"key"]
+
+
+def corpus_of(rng, n_words, n_blocks):
+    data = b"".join(WORDS[int(i)] for i in rng.integers(0, len(WORDS), n_words))
+    corpus = np.frombuffer(data, dtype=np.uint8).copy()
+    cuts = np.sort(rng.integers(0, corpus.size + 1, n_blocks - 1))
+    off = np.concatenate([[0], cuts, [corpus.size]]).astype(np.uint64)
+    return corpus, off
+
+
+def test_confirm_matches_brute_force_small():
+    rng = np.random.default_rng(5)
+    db = make_db(PARTS)
+    corpus, off = corpus_of(rng, 1500, 12)
+    recs = literal_hits(PARTS, corpus, off)
+    rv, ev = confirm(db, corpus, off, recs)
+    assert rv == hs.HS_SUCCESS
+    want = brute(PARTS, corpus, off)
+    assert sorted(ev) == sorted(want) and len(want) > 100
+    # delivery: block order, then non-decreasing `to`, one event per (block, id, to)
+    assert [e[0] for e in ev] == sorted(e[0] for e in ev)
+    for b in set(e[0] for e in ev):
+        tos = [e[3] for e in ev if e[0] == b]
+        assert tos == sorted(tos)
+    assert len({(e[0], e[1], e[3]) for e in ev}) == len(ev)
+
+
+def test_confirm_threaded_path_equals_serial_and_brute_force():
+    rng = np.random.default_rng(6)
+    parts = PARTS[:5] + PARTS[6:]  # without the SINGLEMATCH pattern: more events
+    db = make_db(parts)
+    corpus, off = corpus_of(rng, 60_000, 700)
+    recs = literal_hits(parts, corpus, off)
+    assert recs.size >= 8192, "needs enough hits for the worker threads to be used"
+    rv, ev = confirm(db, corpus, off, recs)
+    assert rv == hs.HS_SUCCESS
+    # serial reference: the same records fed block by block (each call below the thread threshold)
+    serial = []
+    bounds = np.searchsorted(recs["block"], np.arange(off.size))
+    for b in range(off.size - 1):
+        sl = recs[bounds[b]:bounds[b + 1]]
+        if sl.size:
+            _rv, e1 = confirm(db, corpus, off, np.ascontiguousarray(sl))
+            serial += e1
+    assert ev == serial
+    sample = rng.choice(off.size - 1, 40, replace=False)
+    want = {e for e in brute(parts, corpus, off) if e[0] in set(sample.tolist())}
+    assert {e for e in ev if e[0] in set(sample.tolist())} == want
+
+
+def test_confirm_termination_and_argument_checks():
+    rng = np.random.default_rng(7)
+    db = make_db(PARTS)
+    corpus, off = corpus_of(rng, 800, 6)
+    recs = literal_hits(PARTS, corpus, off)
+    _rv, all_ev = confirm(db, corpus, off, recs)
+    stop_block = all_ev[len(all_ev) // 2][0]
+    seen = []
+
+    def stopper(b, i, f, t):
+        seen.append((b, i, f, t))
+        return b == stop_block  # stop that block at its first event
+
+    rv, _ = confirm(db, corpus, off, recs, stopper)
+    assert rv == hs.HS_SCAN_TERMINATED
+    assert sum(1 for e in seen if e[0] == stop_block) == 1  # a non-zero return ends THAT block only
+    assert [e for e in seen if e[0] != stop_block] == [e for e in all_ev if e[0] != stop_block]
+    # malformed record arrays are refused
+    bad = recs.copy()
+    bad[0], bad[-1] = recs[-1], recs[0]
+    assert confirm(db, corpus, off, bad)[0] == hs.HS_INVALID  # out of order
+    bad = recs.copy()
+    bad["id"][3] = 999
+    assert confirm(db, corpus, off, bad)[0] == hs.HS_INVALID  # no such pattern
+    bad = recs.copy()
+    bad["end"][0] = 1 << 30
+    assert confirm(db, corpus, off, bad)[0] == hs.HS_INVALID  # beyond its block
+    # a hit whose long literal does not really end there produces nothing (CHECK_LONG_LIT's job)
+    fake = np.zeros(1, dtype=MATCH_DTYPE)
+    pos = bytes(corpus).find(b"abcdefghijkX")
+    if pos >= 0:
+        b = int(np.searchsorted(off, pos, side="right")) - 1
+        end = pos + 11 - int(off[b])
+        if end < int(off[b + 1] - off[b]):
+            fake["block"], fake["end"], fake["id"], fake["lit"] = b, end, 3, 3
+            assert confirm(db, corpus, off, fake) == (hs.HS_SUCCESS, [])
