@@ -13,6 +13,9 @@
  *                        SINGLEMATCH = the exhaustion vector (src/report.h)
  *   TailNfa::run         the NFA engines Rose triggers after a literal (nfaQueueExec);
  *                        here a bit-parallel position NFA over <= 256 states
+ *   TailBuilder /        tails with groups and alternation: a Glushkov position automaton
+ *   run_general          (<= 63 positions; the construction of src/nfagraph's position NFA
+ *                        in miniature), simulated with one follow-set union per live position
  * Matches are reported as the reference does: `to` = offset after the last byte,
  * `from` = 0 unless HS_FLAG_SOM_LEFTMOST, every distinct (id, to) once, in
  * non-decreasing `to`.
@@ -56,7 +59,15 @@ struct Pattern {
     bool fast = false;
     std::vector<unsigned long long> reach; /* [256] */
     unsigned long long star_mask = 0, opt_mask = 0;
+    /* tails with groups / alternation: a Glushkov position automaton (<= 63 positions) instead
+     * of the linear unit list: follow[p] = positions that may come right after position p */
+    bool general = false;
+    std::vector<unsigned long long> follow;
+    unsigned long long first = 0, last = 0;
+    bool g_nullable = false;
+    unsigned long long g_min = 0, g_max = 0; /* tail width bounds; kInf64 = unbounded */
 };
+constexpr unsigned long long kInf64 = ~0ull;
 
 struct ParseError {
     std::string msg;
@@ -127,6 +138,256 @@ ByteSet fold_case(const ByteSet &s) {
     return o;
 }
 
+/* "[...]" at p[i]: the class, with i moved past the closing bracket */
+ByteSet parse_bracket_class(const std::string &p, size_t &i) {
+    ByteSet cls;
+    size_t j = i + 1;
+    bool neg = false;
+    if (j < p.size() && p[j] == '^') {
+        neg = true;
+        j++;
+    }
+    bool first = true;
+    for (;;) {
+        if (j >= p.size()) throw ParseError{"Unterminated character class."};
+        if (p[j] == ']' && !first) break;
+        first = false;
+        ByteSet item;
+        unsigned lo;
+        bool is_class = false;
+        if (p[j] == '\\') {
+            if (j + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            item = class_escape(p[j + 1], ok);
+            if (ok) {
+                is_class = true;
+                j += 2;
+            } else {
+                size_t k = j + 1;
+                unsigned char lit;
+                if (!char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                lo = lit;
+                j = k;
+            }
+        } else {
+            lo = (unsigned char)p[j++];
+        }
+        if (is_class) {
+            cls |= item;
+            continue;
+        }
+        unsigned hi = lo;
+        if (j + 1 < p.size() && p[j] == '-' && p[j + 1] != ']') {
+            j++;
+            if (p[j] == '\\') {
+                size_t k = j + 1;
+                unsigned char lit;
+                if (k >= p.size() || !char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                hi = lit;
+                j = k;
+            } else {
+                hi = (unsigned char)p[j++];
+            }
+            if (hi < lo) throw ParseError{"Range out of order in character class."};
+        }
+        add_range(cls, lo, hi);
+    }
+    i = j + 1;
+    return neg ? ~cls : cls;
+}
+
+/* ---- general tails: groups and alternation ---------------------------------------
+ * tail := alt ; alt := cat ('|' cat)* ; cat := rep* ; rep := atom ('?' | '*' | '+' | {m[,[n]]})?
+ * atom := '(' ['?:'] alt ')' | '[' class ']' | '\\' escape | '.' | character
+ * Built directly as a Glushkov automaton: every character-class occurrence is a position. */
+struct Frag {
+    unsigned long long first = 0, last = 0;
+    bool nullable = true;
+    unsigned long long wmin = 0, wmax = 0;
+};
+
+struct TailBuilder {
+    const std::string &p;
+    bool nocase, dotall;
+    std::vector<ByteSet> cls;              /* per position */
+    std::vector<unsigned long long> follow; /* per position */
+
+    static unsigned long long add_w(unsigned long long a, unsigned long long b) {
+        return (a == kInf64 || b == kInf64) ? kInf64 : a + b;
+    }
+    unsigned new_pos(const ByteSet &c) {
+        if (cls.size() >= 63) throw ParseError{"Pattern too large."};
+        cls.push_back(nocase ? fold_case(c) : c);
+        follow.push_back(0);
+        return (unsigned)cls.size() - 1;
+    }
+    void link(unsigned long long from_last, unsigned long long to_first) {
+        for (unsigned i = 0; i < follow.size(); i++)
+            if (from_last >> i & 1) follow[i] |= to_first;
+    }
+    Frag cat(const Frag &a, const Frag &b) {
+        link(a.last, b.first);
+        Frag r;
+        r.first = a.first | (a.nullable ? b.first : 0);
+        r.last = b.last | (b.nullable ? a.last : 0);
+        r.nullable = a.nullable && b.nullable;
+        r.wmin = add_w(a.wmin, b.wmin);
+        r.wmax = add_w(a.wmax, b.wmax);
+        return r;
+    }
+    static bool is_repeat_at(const std::string &p, size_t k) {
+        if (k >= p.size() || p[k] != '{') return false;
+        size_t j = k + 1, d = 0;
+        while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++, d++;
+        if (d == 0) return false;
+        if (j < p.size() && p[j] == ',') {
+            j++;
+            while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++;
+        }
+        return j < p.size() && p[j] == '}';
+    }
+
+    Frag parse_alt(size_t &i, int depth) {
+        Frag r = parse_cat(i, depth);
+        while (i < p.size() && p[i] == '|') {
+            i++;
+            const Frag b = parse_cat(i, depth);
+            r.first |= b.first;
+            r.last |= b.last;
+            r.nullable = r.nullable || b.nullable;
+            r.wmin = std::min(r.wmin, b.wmin);
+            r.wmax = std::max(r.wmax, b.wmax);
+        }
+        return r;
+    }
+    Frag parse_cat(size_t &i, int depth) {
+        Frag r; /* the empty string */
+        while (i < p.size() && p[i] != '|' && p[i] != ')') r = cat(r, parse_rep(i, depth));
+        return r;
+    }
+    /* one atom, then its quantifier; a counted repeat re-parses the atom's source for every copy
+     * (fresh positions), optional copies being x? x? ... (same language as the nested form) */
+    Frag parse_rep(size_t &i, int depth) {
+        const size_t a0 = i;
+        Frag f = parse_atom(i, depth);
+        const size_t a1 = i;
+        if (i >= p.size()) return f;
+        unsigned lo = 1, hi = 1;
+        const char q = p[i];
+        if (q == '?') { lo = 0; hi = 1; i++; }
+        else if (q == '*') { lo = 0; hi = kInf; i++; }
+        else if (q == '+') { lo = 1; hi = kInf; i++; }
+        else if (q == '{' && is_repeat_at(p, i)) {
+            size_t j = i + 1;
+            auto num = [&](unsigned &v) {
+                v = 0;
+                while (j < p.size() && p[j] >= '0' && p[j] <= '9') v = v * 10 + (p[j++] - '0');
+                return v <= 1000;
+            };
+            if (!num(lo)) throw ParseError{"Malformed repeat."};
+            hi = lo;
+            if (p[j] == ',') {
+                j++;
+                if (p[j] == '}') hi = kInf;
+                else if (!num(hi) || hi < lo) throw ParseError{"Malformed repeat."};
+            }
+            i = j + 1;
+        } else {
+            return f;
+        }
+        if (i < p.size() && (p[i] == '?' || p[i] == '+')) throw ParseError{"Lazy/possessive quantifiers are not supported."};
+        auto again = [&]() { /* a fresh copy of the atom */
+            size_t k = a0;
+            Frag c = parse_atom(k, depth);
+            (void)a1;
+            return c;
+        };
+        auto star_of = [&](Frag c) { /* c* */
+            link(c.last, c.first);
+            c.nullable = true;
+            c.wmin = 0;
+            c.wmax = c.wmax ? kInf64 : 0;
+            return c;
+        };
+        auto opt_of = [&](Frag c) {
+            c.nullable = true;
+            c.wmin = 0;
+            return c;
+        };
+        /* copies: the already parsed one is copy #1 */
+        Frag r;
+        bool used_first = false;
+        auto next_copy = [&]() {
+            if (!used_first) { used_first = true; return f; }
+            return again();
+        };
+        if (lo == 0 && hi == kInf) return star_of(next_copy());
+        for (unsigned k = 0; k < lo; k++) {
+            Frag c = next_copy();
+            if (hi == kInf && k + 1 == lo) { /* last mandatory copy loops: c+ */
+                link(c.last, c.first);
+                c.wmax = c.wmax ? kInf64 : 0;
+            }
+            r = cat(r, c);
+        }
+        if (hi != kInf)
+            for (unsigned k = lo; k < hi; k++) r = cat(r, opt_of(next_copy()));
+        if (!used_first) { /* {0} or {0,0}: the atom is parsed but contributes nothing */
+            Frag none;
+            return none;
+        }
+        return r;
+    }
+    Frag parse_atom(size_t &i, int depth) {
+        if (i >= p.size()) throw ParseError{"Unexpected end of pattern."};
+        const unsigned char c = (unsigned char)p[i];
+        if (c == '(') {
+            if (depth > 20) throw ParseError{"Groups nested too deeply."};
+            i++;
+            if (i + 1 < p.size() && p[i] == '?') {
+                if (p[i + 1] != ':') throw ParseError{"Only plain and (?:...) groups are supported."};
+                i += 2;
+            }
+            Frag f = parse_alt(i, depth + 1);
+            if (i >= p.size() || p[i] != ')') throw ParseError{"Missing closing parenthesis."};
+            i++;
+            return f;
+        }
+        ByteSet set;
+        if (c == '\\') {
+            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            set = class_escape(p[i + 1], ok);
+            if (ok) {
+                i += 2;
+            } else {
+                size_t j = i + 1;
+                unsigned char lit;
+                if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+                set.set(lit);
+                i = j;
+            }
+        } else if (c == '.') {
+            set.set();
+            if (!dotall) set.reset('\n');
+            i++;
+        } else if (c == '[') {
+            set = parse_bracket_class(p, i);
+        } else if (strchr(")|^$*+?", c) || (c == '{' && is_repeat_at(p, i))) {
+            throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
+        } else {
+            set.set(c);
+            i++;
+        }
+        const unsigned pos = new_pos(set);
+        Frag f;
+        f.first = f.last = 1ull << pos;
+        f.nullable = false;
+        f.wmin = f.wmax = 1;
+        return f;
+    }
+};
+
 constexpr unsigned kAllFlags = 0x7ff; /* HS_FLAG_ALL: the eleven flags of src/hs_compile.h */
 
 /* the reference's own flag rules, in its order (src/compiler/compiler.cpp:286-294,166-196) */
@@ -187,9 +448,9 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
             j = i + 1;
             if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
         } else if (strchr(".[]()|^$*+?", c) || (c == '{' && is_repeat(i))) {
-            if (c == '.' || c == '[') break;
+            if (c == '.' || c == '[' || c == '(') break;
             throw ParseError{std::string("Unsupported regex construct '") + (char)c +
-                             "': only a literal prefix followed by classes and quantifiers is supported."};
+                             "': only a literal prefix followed by classes, groups and quantifiers is supported."};
         } else {
             lit = c;
             j = i + 1;
@@ -199,6 +460,36 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
         i = j;
     }
     if (pat.lit.empty()) throw ParseError{"Pattern must start with a literal (no literal prefix found)."};
+    /* a tail with a group in it goes to the position automaton; the linear form below stays the
+     * path for everything it can express */
+    bool grouped = false;
+    for (size_t k = i; k < p.size() && !grouped; k++) {
+        if (p[k] == '\\') k++;
+        else if (p[k] == '[') { size_t e = k; parse_bracket_class(p, e); k = e - 1; }
+        else if (p[k] == '(') grouped = true;
+    }
+    if (grouped) {
+        TailBuilder tb{p, pat.nocase, dotall, {}, {}};
+        const Frag f = tb.parse_cat(i, 0);
+        if (i < p.size())
+            throw ParseError{p[i] == '|' ? "Top-level alternation is not supported (no common literal prefix)."
+                                         : "Unmatched closing parenthesis."};
+        if (!tb.cls.empty()) {
+            pat.general = true;
+            pat.follow = tb.follow;
+            pat.first = f.first;
+            pat.last = f.last;
+            pat.g_nullable = f.nullable;
+            pat.g_min = f.wmin;
+            pat.g_max = f.wmax;
+            pat.reach.assign(256, 0);
+            for (size_t k = 0; k < tb.cls.size(); k++)
+                for (unsigned c = 0; c < 256; c++)
+                    if (tb.cls[k][c]) pat.reach[c] |= 1ull << k;
+        }
+        pat.tail_nullable = f.nullable;
+        return pat;
+    }
     /* tail */
     while (i < p.size()) {
         ByteSet cls;
@@ -221,59 +512,7 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
             if (!dotall) cls.reset('\n');
             i++;
         } else if (c == '[') {
-            size_t j = i + 1;
-            bool neg = false;
-            if (j < p.size() && p[j] == '^') {
-                neg = true;
-                j++;
-            }
-            bool first = true;
-            for (;;) {
-                if (j >= p.size()) throw ParseError{"Unterminated character class."};
-                if (p[j] == ']' && !first) break;
-                first = false;
-                ByteSet item;
-                unsigned lo;
-                bool is_class = false;
-                if (p[j] == '\\') {
-                    if (j + 1 >= p.size()) throw ParseError{"Trailing backslash."};
-                    bool ok;
-                    item = class_escape(p[j + 1], ok);
-                    if (ok) {
-                        is_class = true;
-                        j += 2;
-                    } else {
-                        size_t k = j + 1;
-                        unsigned char lit;
-                        if (!char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
-                        lo = lit;
-                        j = k;
-                    }
-                } else {
-                    lo = (unsigned char)p[j++];
-                }
-                if (is_class) {
-                    cls |= item;
-                    continue;
-                }
-                unsigned hi = lo;
-                if (j + 1 < p.size() && p[j] == '-' && p[j + 1] != ']') {
-                    j++;
-                    if (p[j] == '\\') {
-                        size_t k = j + 1;
-                        unsigned char lit;
-                        if (k >= p.size() || !char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
-                        hi = lit;
-                        j = k;
-                    } else {
-                        hi = (unsigned char)p[j++];
-                    }
-                    if (hi < lo) throw ParseError{"Range out of order in character class."};
-                }
-                add_range(cls, lo, hi);
-            }
-            i = j + 1;
-            if (neg) cls = ~cls;
+            cls = parse_bracket_class(p, i);
         } else if (strchr("()|^$*+?]", c) || (c == '{' && is_repeat(i))) {
             throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
         } else {
@@ -365,9 +604,22 @@ struct TailNfa {
             if (cur & accept) { if (!report(pos)) return; }
         }
     }
+    /* the position automaton of a grouped tail: the active set after byte c is
+     * (first | follow[active]) & reach[c]; a match ends wherever the set meets `last` */
+    template <class F> static void run_general(const Pattern &p, const unsigned char *buf, size_t len, size_t pos, F report) {
+        if (p.g_nullable) { if (!report(pos)) return; }
+        unsigned long long next = p.first;
+        while (pos < len && next) {
+            unsigned long long cur = next & p.reach[buf[pos++]];
+            if (cur & p.last) { if (!report(pos)) return; }
+            next = 0;
+            for (; cur; cur &= cur - 1) next |= p.follow[__builtin_ctzll(cur)];
+        }
+    }
 };
 
 void finish_pattern(Pattern &p) {
+    if (p.general) return;
     p.fast = !p.tail.empty() && p.tail.size() <= 63;
     if (!p.fast) return;
     p.reach.assign(256, 0);
@@ -542,6 +794,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
             lits[i].groups = HSGPU_ALL_GROUPS;
             size_t w = p.lit.size();
             for (const Unit &u : p.tail) w += u.optional ? 0 : 1;
+            if (p.general) w += p.g_min;
             d->min_width = std::min(d->min_width, w);
         }
         int rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
@@ -617,7 +870,12 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
             if ((p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) && to - start < p.min_length) return false;
             return true;
         };
-        if (p.tail.empty()) {
+        if (p.general) {
+            TailNfa::run_general(p, buf, len, lit_end, [&](size_t to) {
+                if (in_bounds(to)) out.push_back(Event{to, from, p.id});
+                return true;
+            });
+        } else if (p.tail.empty()) {
             if (in_bounds(lit_end)) out.push_back(Event{lit_end, from, p.id});
         } else {
             auto on_to = [&](size_t to) {
@@ -771,7 +1029,7 @@ hs_error_t hs_free_database(hs_database_t *db) {
 hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
     if (!db || !size || db->magic != 0x48534744) return HS_INVALID;
     size_t s = sizeof(*db) + hsgpu_hwlm_size(db->hwlm);
-    for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit);
+    for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit) + p.follow.size() * 8 + p.reach.size() * 8;
     *size = s;
     return HS_SUCCESS;
 }
@@ -976,6 +1234,11 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
         minw += u.optional ? 0 : 1;
         maxw += 1;
         unbounded |= u.star;
+    }
+    if (p.general) {
+        minw += p.g_min;
+        unbounded = p.g_max == kInf64;
+        if (!unbounded) maxw += p.g_max;
     }
     if (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) minw = std::max(minw, p.min_length);
     if (p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) {

@@ -29,9 +29,11 @@
  * (the job of CHECK_MED_LIT / CHECK_LONG_LIT, src/rose/program_runtime.c:2896-2942) and,
  * for patterns with a tail, runs a bit-parallel NFA over the bytes that follow
  * (the job of the NFA engines Rose would trigger). Supported tail syntax: literal
- * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes, and the quantifiers
- * ? * + {m} {m,} {m,n}. Anything else (alternation, groups, anchors, leading
- * non-literals, streaming / vectored modes) is rejected with HS_COMPILER_ERROR:
+ * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes, the quantifiers
+ * ? * + {m} {m,} {m,n}, and groups `( )` / `(?: )` with alternation inside them, nested and
+ * quantified (a tail with groups compiles to a position automaton of <= 63 positions).
+ * Anything else (top-level alternation, anchors, look-around, back-references, lazy
+ * quantifiers, leading non-literals, streaming / vectored modes) is rejected with HS_COMPILER_ERROR:
  * the regex compiler proper is out of scope.
  */
 #ifndef HS_GPU_H

@@ -50,7 +50,7 @@ def test_hs_compile_errors_without_gpu():
         hs.Database.compile(["foo"], mode=hs.HS_MODE_STREAM)
     assert e.value.code == hs.HS_COMPILER_ERROR
     with pytest.raises(hs.HsError) as e:
-        hs.Database.compile(["ok", "a(b|c)"])
+        hs.Database.compile(["ok", "a(b|c"])  # unbalanced group
     assert e.value.expression == 1
     with pytest.raises(hs.HsError):
         hs.Database.compile(["\\d+abc"])  # no literal prefix
@@ -317,7 +317,7 @@ def test_hs_facade_compile_side_extras():
     assert hs.expression_info("abc[a-z]+") == (4, 0xFFFFFFFF)
     assert hs.expression_info("abc[a-z]+", ext=hs.ExprExt.make(min_length=10, max_offset=64)) == (10, 64)
     with pytest.raises(hs.HsError):
-        hs.expression_info("a(b|c)")
+        hs.expression_info("a|bc")
     plat = (C.c_ulonglong * 4)(1, 2, 3, 4)
     assert lib.hs_populate_platform(plat) == 0 and list(plat) == [0, 0, 0, 0]
 
@@ -501,18 +501,19 @@ def test_hs_serialized_database_is_guarded_by_a_crc():
 
 def test_expression_info_reference_table_subset():
     """unit/hyperscan/expr_info.cpp:182-228: the rows of ei_test[] that lie inside the supported
-    pattern subset (literal prefix + classes / quantifiers), with and without ext parameters."""
+    pattern subset (literal prefix + classes / quantifiers / groups), with and without ext parameters."""
     from hyperscan_amd import hs
 
     U = 0xFFFFFFFF
     rows = [("abc", None, 3, 3), ("abc.*def", None, 6, U), ("foo.{1,13}bar", None, 7, 19), ("foo.{10,}bar", None, 16, U),
             ("foo.{0,10}bar", None, 6, 16), ("foo.{,10}bar", None, 12, 12), ("foo.{10}bar", None, 16, 16),
             ("abc.*def", dict(max_offset=10), 6, 10), ("abc.*def", dict(min_length=100), 100, U),
-            ("abc.*def", dict(min_length=5), 6, U)]
+            ("abc.*def", dict(min_length=5), 6, U),
+            ("abc(def)?", None, 3, 6), ("abc(def){0,3}", None, 3, 12), ("abc(def){1,4}", None, 6, 15)]
     for pat, ext, mn, mx in rows:
         assert hs.expression_info(pat, 0, hs.ExprExt.make(**ext) if ext else None) == (mn, mx), pat
     # rows outside the subset are refused, not mis-measured
-    for pat in ("abc|defghi", "abc(def)?", "^foo", "foobar$", "\\bfoo"):
+    for pat in ("abc|defghi", "(foo|bar)\\z", "^foo", "foobar$", "\\bfoo"):
         with pytest.raises(hs.HsError):
             hs.expression_info(pat)
 

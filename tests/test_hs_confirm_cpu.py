@@ -180,3 +180,48 @@ def test_confirm_termination_and_argument_checks():
         if end < int(off[b + 1] - off[b]):
             fake["block"], fake["end"], fake["id"], fake["lit"] = b, end, 3, 3
             assert confirm(db, corpus, off, fake) == (hs.HS_SUCCESS, [])
+
+
+GROUPED = [(b"GET /", r"(index|home|a+b)\.html?", 0, 200, {}), (b"user=", r"(?:[a-z]+|\d{2,4})&", hs.HS_FLAG_CASELESS, 201, {}),
+           (b"key", r"(=|: ?)(true|false|[0-9]+)", 0, 202, {}), (b"BEEF", r"((ab|c)*d){1,3}", 0, 203, {}),
+           (b"Zq", r"(x(y|z)?){2,}w", hs.HS_FLAG_SOM_LEFTMOST, 204, {}), (b"0042", r"(7|77)*", 0, 205, {}),
+           (b"html", r"(\.[a-z]{1,3}){0,2}(;|$)".replace("|$", ""), 0, 206, dict(min_length=5)),
+           (b"END", r"(a|)(b|)c", 0, 207, {}), (b"abc", r"(?:1(2(3)?)?)?.", hs.HS_FLAG_DOTALL, 208, {})]
+GWORDS = [b"GET /", b"index", b"home", b"aab", b"ab", b".htm", b".html", b"l", b"user=", b"USER=", b"bob", b"123", b"12345", b"&",
+          b"key", b"=", b": ", b":", b"true", b"false", b"77", b"BEEF", b"abd", b"cd", b"d", b"Zq", b"xy", b"xz", b"x", b"w", b"0042",
+          b"7", b"html", b".x", b".abc", b";", b"END", b"a", b"b", b"c", b"abc", b"1", b"2", b"3", b"\n", b" "]
+
+
+def test_grouped_tails_match_brute_force():
+    """tails with groups and alternation run on the position automaton; same brute-force model"""
+    global WORDS
+    rng = np.random.default_rng(9)
+    db = make_db(GROUPED)
+    saved, WORDS = WORDS, GWORDS
+    try:
+        corpus, off = corpus_of(rng, 6000, 25)
+    finally:
+        WORDS = saved
+    # one directed block per pattern family on top of the random ones
+    directed = b"GET /aaab.html GET /home.htm Zqxyxzxw Zqxxxw Zqxw user=Bob& user=123& END" b"c ENDabc"
+    corpus = np.concatenate([corpus, np.frombuffer(directed, dtype=np.uint8)])
+    off = np.concatenate([off, [corpus.size]]).astype(np.uint64)
+    recs = literal_hits(GROUPED, corpus, off)
+    rv, ev = confirm(db, corpus, off, recs)
+    assert rv == hs.HS_SUCCESS
+    want = brute(GROUPED, corpus, off)
+    assert sorted(ev) == sorted(want)
+    hit_ids = {e[1] for e in ev}
+    assert hit_ids == {p[3] for p in GROUPED}, hit_ids
+
+
+def test_grouped_tail_compile_errors_and_info():
+    import pytest
+    for bad in ["foo(bar", "foo(a))", "foo(a)|b", "foo(?=a)", "foo(a*?)", "foo(" + "a?" * 64 + ")"]:
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([bad], [0], [1])
+    # widths through groups (hs_expression_info): min over alternatives, max = longest, unbounded loops
+    assert hs.expression_info("foo(a|bcd)x") == (5, 7)
+    assert hs.expression_info("foo(ab)*") == (3, 0xffffffff)
+    assert hs.expression_info("foo(ab|c){2,3}") == (5, 9)
+    assert hs.expression_info("foo(a|)") == (3, 4) and hs.expression_info("foo()") == (3, 3)
