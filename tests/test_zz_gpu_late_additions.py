@@ -96,3 +96,33 @@ def test_class_scan_reference_unit_test_vectors():
             assert int(got[b]) == (expected(case) & 0xFFFFFFFF), case[0]
             checked += 1
     assert checked > 600
+
+
+def test_hs_scan_grouped_tails():
+    """tails with groups / alternation through the whole public path (GPU literal scan, then the
+    host position automaton), against Python's re on the same buffer"""
+    import re
+
+    from hyperscan_amd import hs
+
+    pats = [r"GET /(index|home|a+b)\.html?", r"key(=|: ?)(true|false|[0-9]+)", r"BEEF((ab|c)*d){1,3}", r"END(a|)(b|)c"]
+    lits = [b"GET /", b"key", b"BEEF", b"END"]
+    tails = [p[len(l):] for p, l in zip(pats, lits)]  # (no prefix character needs escaping)
+    words = [b"GET /", b"index", b"home", b"aab", b".htm", b"l", b"key", b"=", b": ", b"true", b"77", b"BEEF", b"abd", b"cd", b"d",
+             b"END", b"a", b"b", b"c", b" ", b"\n"]
+    rng = np.random.default_rng(21)
+    data = b"".join(words[int(i)] for i in rng.integers(0, len(words), 20_000))
+    db = hs.Database.compile(pats, [0] * len(pats), list(range(len(pats))))
+    sc = hs.HsScratch(db)
+    got = []
+    assert hs.scan(db, data, sc, lambda i, f, t: got.append((i, t)) and False) == hs.HS_SUCCESS
+    want = set()
+    for i, (tl, lit) in enumerate(zip(tails, lits)):
+        tail = re.compile(tl.encode())
+        k = data.find(lit)
+        while k >= 0:
+            s = k + len(lit)
+            want |= {(i, to) for to in range(s, min(len(data), s + 64) + 1) if tail.fullmatch(data, s, to)}
+            k = data.find(lit, k + 1)
+    assert set(got) == want and len(got) == len(want) and len(want) > 200
+    assert [t for _i, t in got] == sorted(t for _i, t in got)
