@@ -49,6 +49,8 @@ struct Unit { /* one character class; `star` = may repeat, `optional` = may be s
 struct Pattern {
     std::string lit;          /* literal prefix, as written (upper-cased compare if nocase) */
     bool nocase = false, single = false, som = false;
+    /* `^` in front / `$` at the back of the branch (multiline: the HS_FLAG_MULTILINE reading) */
+    bool bol = false, eol = false, multiline = false;
     unsigned id = 0;
     std::vector<Unit> tail;   /* empty: pure literal */
     bool tail_nullable = true;
@@ -407,13 +409,23 @@ void check_flags(unsigned flags, bool literal_api) {
         throw ParseError{"HS_FLAG_PREFILTER is not supported in combination with HS_FLAG_SOM_LEFTMOST."};
 }
 
-/* pattern := literal-prefix tail ; tail := (atom quantifier?)* */
-Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
-    check_flags(flags, false);
-    const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_PREFILTER | HS_FLAG_COMBINATION |
-                                 HS_FLAG_QUIET | HS_FLAG_ALLOWEMPTY;
-    if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};
+/* branch := '^'? literal-prefix tail '$'? ; tail := (atom quantifier?)* */
+Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     Pattern pat;
+    std::string p = src;
+    if (!p.empty() && p[0] == '^') {
+        pat.bol = true;
+        p.erase(0, 1);
+    }
+    if (!p.empty() && p.back() == '$') {
+        size_t bs = 0;
+        while (bs + 1 < p.size() && p[p.size() - 2 - bs] == '\\') bs++;
+        if (bs % 2 == 0) {
+            pat.eol = true;
+            p.pop_back();
+        }
+    }
+    pat.multiline = flags & HS_FLAG_MULTILINE;
     pat.nocase = flags & HS_FLAG_CASELESS;
     pat.single = flags & HS_FLAG_SINGLEMATCH;
     pat.som = flags & HS_FLAG_SOM_LEFTMOST;
@@ -559,6 +571,38 @@ Pattern parse_pattern(const std::string &p, unsigned flags, unsigned id) {
     pat.tail_nullable = true;
     for (const Unit &u : pat.tail) pat.tail_nullable &= u.optional;
     return pat;
+}
+
+/* expression := branch ('|' branch)* at the top level: every branch is its own literal-prefixed
+ * pattern reporting the same id (the reference builds one graph; the reports are the same) */
+std::vector<Pattern> parse_pattern(const std::string &p, unsigned flags, unsigned id) {
+    check_flags(flags, false);
+    const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_PREFILTER | HS_FLAG_COMBINATION |
+                                 HS_FLAG_QUIET | HS_FLAG_ALLOWEMPTY;
+    if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};
+    std::vector<Pattern> out;
+    size_t from = 0;
+    int depth = 0;
+    for (size_t k = 0; k <= p.size(); k++) {
+        if (k < p.size()) {
+            const char c = p[k];
+            if (c == '\\') { k++; continue; }
+            if (c == '[') { /* skip the class: "]" first in a class is a member */
+                size_t j = k + 1;
+                if (j < p.size() && p[j] == '^') j++;
+                if (j < p.size() && p[j] == ']') j++;
+                while (j < p.size() && p[j] != ']') j += p[j] == '\\' ? 2 : 1;
+                k = j;
+                continue;
+            }
+            if (c == '(') depth++;
+            if (c == ')') depth--;
+            if (c != '|' || depth != 0) continue;
+        }
+        out.push_back(parse_branch(p.substr(from, k - from), flags, id));
+        from = k + 1;
+    }
+    return out;
 }
 
 /* simulation of the linear NFA: state i = "units 0..i-1 consumed" */
@@ -751,6 +795,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
     try {
         for (size_t i = 0; i < exprs.size(); i++) {
             const unsigned f = flags ? flags[i] : 0, id = ids ? ids[i] : 0;
+            const size_t first_of_expr = d->pats.size();
             try {
                 if (is_lit[i]) {
                     check_flags(f, true);
@@ -769,10 +814,12 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                     p.id = id;
                     d->pats.push_back(p);
                 } else {
-                    d->pats.push_back(parse_pattern(exprs[i], f, id));
+                    for (Pattern &b : parse_pattern(exprs[i], f, id)) d->pats.push_back(std::move(b));
                 }
-                if (ext && ext[i]) apply_ext(d->pats.back(), *ext[i]);
-                finish_pattern(d->pats.back());
+                for (size_t k = first_of_expr; k < d->pats.size(); k++) {
+                    if (ext && ext[i]) apply_ext(d->pats[k], *ext[i]);
+                    finish_pattern(d->pats[k]);
+                }
             } catch (const ParseError &pe) {
                 *error = make_error(pe.msg, (int)i);
                 destroy_db(d);
@@ -861,10 +908,13 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
         const size_t lit_end = (size_t)recs[k].end + 1;
         if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
         const unsigned long long start = lit_end - p.lit.size();
+        if (p.bol && start != 0 && !(p.multiline && buf[start - 1] == '\n')) continue;
         const unsigned long long from = p.som ? start : 0;
         /* hs_expr_ext_t bounds: the job of the reference's CHECK_BOUNDS / CHECK_MIN_LENGTH
          * program instructions (src/rose/program_runtime.c) */
         auto in_bounds = [&](unsigned long long to) {
+            /* `$`: at the end of the data or before its final newline; multiline: before any newline */
+            if (p.eol && to != len && !(buf[to] == '\n' && (p.multiline || to + 1 == len))) return false;
             if ((p.ext_flags & HS_EXT_FLAG_MIN_OFFSET) && to < p.min_offset) return false;
             if ((p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) && to > p.max_offset) return false;
             if ((p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) && to - start < p.min_length) return false;
@@ -1220,30 +1270,41 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
     if (!info) { *error = make_error("Invalid parameter: info is NULL", -1); return HS_COMPILER_ERROR; }
     *info = nullptr;
     if (!expression) { *error = make_error("Invalid parameter: expression is NULL", -1); return HS_COMPILER_ERROR; }
-    Pattern p;
+    std::vector<Pattern> branches;
     try {
-        p = parse_pattern(expression, flags, 0);
-        if (ext) apply_ext(p, *ext);
+        branches = parse_pattern(expression, flags, 0);
+        if (ext)
+            for (Pattern &b : branches) apply_ext(b, *ext);
     } catch (const ParseError &pe) {
         *error = make_error(pe.msg, 0);
         return HS_COMPILER_ERROR;
     }
-    unsigned long long minw = p.lit.size(), maxw = p.lit.size();
-    bool unbounded = false;
-    for (const Unit &u : p.tail) {
-        minw += u.optional ? 0 : 1;
-        maxw += 1;
-        unbounded |= u.star;
-    }
-    if (p.general) {
-        minw += p.g_min;
-        unbounded = p.g_max == kInf64;
-        if (!unbounded) maxw += p.g_max;
-    }
-    if (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) minw = std::max(minw, p.min_length);
-    if (p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) {
-        maxw = unbounded ? p.max_offset : std::min(maxw, p.max_offset);
-        unbounded = false;
+    unsigned long long minw = kInf64, maxw = 0;
+    bool unbounded = false, any_eol = false, all_eol = true, eol_multiline = false;
+    for (const Pattern &p : branches) {
+        unsigned long long lo = p.lit.size(), hi = p.lit.size();
+        bool inf = false;
+        for (const Unit &u : p.tail) {
+            lo += u.optional ? 0 : 1;
+            hi += 1;
+            inf |= u.star;
+        }
+        if (p.general) {
+            lo += p.g_min;
+            inf = p.g_max == kInf64;
+            if (!inf) hi += p.g_max;
+        }
+        if (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) lo = std::max(lo, p.min_length);
+        if (p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) {
+            hi = inf ? p.max_offset : std::min(hi, p.max_offset);
+            inf = false;
+        }
+        minw = std::min(minw, lo);
+        maxw = std::max(maxw, hi);
+        unbounded |= inf;
+        any_eol |= p.eol;
+        all_eol &= p.eol;
+        eol_multiline |= p.eol && p.multiline;
     }
     hs_expr_info_t *out = (hs_expr_info_t *)hook_alloc(g_misc, sizeof(*out));
     if (hs_error_t ae = check_alloc(out)) {
@@ -1253,9 +1314,11 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
     }
     out->min_width = (unsigned)std::min<unsigned long long>(minw, 0xffffffffu);
     out->max_width = unbounded ? 0xffffffffu : (unsigned)std::min<unsigned long long>(maxw, 0xffffffffu);
-    out->unordered_matches = 0;
-    out->matches_at_eod = 0;
-    out->matches_only_at_eod = 0;
+    /* a `$` branch may be satisfied by the end of the data (expr_info.cpp:199-203: "foobar$" is
+     * unordered / at EOD / only at EOD; the multiline form also matches before inner newlines) */
+    out->unordered_matches = any_eol;
+    out->matches_at_eod = any_eol;
+    out->matches_only_at_eod = all_eol && !eol_multiline;
     *info = out;
     return HS_SUCCESS;
 }

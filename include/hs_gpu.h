@@ -23,17 +23,20 @@
  * (the hs_open_stream family, hs_scan_vector) and the in-place hs_deserialize_database_at: the
  * database object owns heap containers, so it cannot live in caller memory.
  *
- * What is behind it: every pattern must start with a literal (>= 1 byte). The literal
+ * What is behind it: an expression is one or more top-level branches `b1|b2|...`, and every
+ * branch must start with a literal (>= 1 byte), optionally after `^`. The literal
  * prefixes (their last <= 8 bytes, as Rose truncates them: rose_build_matchers.cpp:717-724)
  * are matched on the GPU through hsgpu_hwlm_exec; the host then checks the full literal
  * (the job of CHECK_MED_LIT / CHECK_LONG_LIT, src/rose/program_runtime.c:2896-2942) and,
- * for patterns with a tail, runs a bit-parallel NFA over the bytes that follow
+ * for branches with a tail, runs a bit-parallel NFA over the bytes that follow
  * (the job of the NFA engines Rose would trigger). Supported tail syntax: literal
  * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes, the quantifiers
- * ? * + {m} {m,} {m,n}, and groups `( )` / `(?: )` with alternation inside them, nested and
- * quantified (a tail with groups compiles to a position automaton of <= 63 positions).
- * Anything else (top-level alternation, anchors, look-around, back-references, lazy
- * quantifiers, leading non-literals, streaming / vectored modes) is rejected with HS_COMPILER_ERROR:
+ * ? * + {m} {m,} {m,n}, groups `( )` / `(?: )` with alternation inside them, nested and
+ * quantified (a tail with groups compiles to a position automaton of <= 63 positions), and a
+ * final `$` (end of data or before its last newline, reported before the newline as the
+ * reference does; with HS_FLAG_MULTILINE `^` / `$` also match after / before any newline).
+ * Anything else (branches without a literal prefix, embedded anchors, \b \A \z, look-around,
+ * back-references, lazy quantifiers, streaming / vectored modes) is rejected with HS_COMPILER_ERROR:
  * the regex compiler proper is out of scope.
  */
 #ifndef HS_GPU_H

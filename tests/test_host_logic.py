@@ -317,7 +317,7 @@ def test_hs_facade_compile_side_extras():
     assert hs.expression_info("abc[a-z]+") == (4, 0xFFFFFFFF)
     assert hs.expression_info("abc[a-z]+", ext=hs.ExprExt.make(min_length=10, max_offset=64)) == (10, 64)
     with pytest.raises(hs.HsError):
-        hs.expression_info("a|bc")
+        hs.expression_info("a|(bc")
     plat = (C.c_ulonglong * 4)(1, 2, 3, 4)
     assert lib.hs_populate_platform(plat) == 0 and list(plat) == [0, 0, 0, 0]
 
@@ -501,7 +501,7 @@ def test_hs_serialized_database_is_guarded_by_a_crc():
 
 def test_expression_info_reference_table_subset():
     """unit/hyperscan/expr_info.cpp:182-228: the rows of ei_test[] that lie inside the supported
-    pattern subset (literal prefix + classes / quantifiers / groups), with and without ext parameters."""
+    pattern subset (anchors, alternation of literal-prefixed branches, classes / quantifiers / groups), with and without ext parameters."""
     from hyperscan_amd import hs
 
     U = 0xFFFFFFFF
@@ -509,11 +509,14 @@ def test_expression_info_reference_table_subset():
             ("foo.{0,10}bar", None, 6, 16), ("foo.{,10}bar", None, 12, 12), ("foo.{10}bar", None, 16, 16),
             ("abc.*def", dict(max_offset=10), 6, 10), ("abc.*def", dict(min_length=100), 100, U),
             ("abc.*def", dict(min_length=5), 6, U),
-            ("abc(def)?", None, 3, 6), ("abc(def){0,3}", None, 3, 12), ("abc(def){1,4}", None, 6, 15)]
+            ("abc(def)?", None, 3, 6), ("abc(def){0,3}", None, 3, 12), ("abc(def){1,4}", None, 6, 15),
+            ("abc|defghi", None, 3, 6), ("^foo", None, 3, 3), ("^foo.*bar", None, 6, U), ("^foo.*bar?", None, 5, U),
+            ("^foo.*bar$", None, 6, U), ("^foobar$", None, 6, 6), ("foobar$", None, 6, 6),
+            ("^abc.*def", dict(max_offset=10), 6, 10), ("^abc.*def", dict(min_length=100), 100, U)]
     for pat, ext, mn, mx in rows:
         assert hs.expression_info(pat, 0, hs.ExprExt.make(**ext) if ext else None) == (mn, mx), pat
     # rows outside the subset are refused, not mis-measured
-    for pat in ("abc|defghi", "(foo|bar)\\z", "^foo", "foobar$", "\\bfoo"):
+    for pat in ("(foo|bar)\\z", "(^|\n)foo", "^.*foo", "foo\\b", "\\bfoo", "\\Bfoo", "", "^", "$"):
         with pytest.raises(hs.HsError):
             hs.expression_info(pat)
 

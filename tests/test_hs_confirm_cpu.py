@@ -17,7 +17,7 @@ from tests import oracle_binding as ob
 def literal_hits(parts, corpus, off):
     """what the literal engine reports for the facade's HWLM literals: the last <= 8 bytes of each
     pattern's literal prefix, id = pattern index (hs_facade.cpp build_database)"""
-    lits = [H.HwlmLiteral(lit[-8:], nocase=bool(fl & hs.HS_FLAG_CASELESS), id=i) for i, (lit, _t, fl, _pid, _e) in enumerate(parts)]
+    lits = [H.HwlmLiteral(lit[-8:], nocase=bool(fl & hs.HS_FLAG_CASELESS), id=i) for i, (lit, _t, fl, _pid, _e, *_a) in enumerate(parts)]
     got = ob.Oracle(lits).collect_blocks(corpus, off)
     recs = np.zeros(len(got), dtype=MATCH_DTYPE)
     recs["block"], recs["end"], recs["id"], recs["lit"] = got["block"], got["end"], got["id"], got["id"]
@@ -47,7 +47,9 @@ def brute(parts, corpus, off):
     for b in range(off.size - 1):
         data = bytes(corpus[int(off[b]):int(off[b + 1])])
         evs = set()
-        for lit, tail, fl, pid, ext in parts:
+        for lit, tail, fl, pid, ext, *anch in parts:
+            anch = anch[0] if anch else ""  # "^" and/or "$" around the branch
+            ml = bool(fl & hs.HS_FLAG_MULTILINE)
             rf = (re.I if fl & hs.HS_FLAG_CASELESS else 0) | (re.S if fl & hs.HS_FLAG_DOTALL else 0)
             tre = re.compile(tail.encode("latin-1"), rf) if tail else None
             hay, needle = (data.upper(), lit.upper()) if fl & hs.HS_FLAG_CASELESS else (data, lit)
@@ -55,6 +57,10 @@ def brute(parts, corpus, off):
             while k >= 0:
                 s = k + len(lit)
                 tos = [s] if tre is None else [to for to in range(s, len(data) + 1) if tre.fullmatch(data, s, to)]
+                if "^" in anch and k != 0 and not (ml and data[k - 1:k] == b"\n"):
+                    tos = []
+                if "$" in anch:  # the end of the data, or just before its last newline (multiline: any newline)
+                    tos = [to for to in tos if to == len(data) or (data[to:to + 1] == b"\n" and (ml or to + 1 == len(data)))]
                 for to in tos:
                     if "min_offset" in ext and to < ext["min_offset"]:
                         continue
@@ -217,7 +223,7 @@ def test_grouped_tails_match_brute_force():
 
 def test_grouped_tail_compile_errors_and_info():
     import pytest
-    for bad in ["foo(bar", "foo(a))", "foo(a)|b", "foo(?=a)", "foo(a*?)", "foo(" + "a?" * 64 + ")"]:
+    for bad in ["foo(bar", "foo(a))", "foo(a)|", "foo(?=a)", "foo(a*?)", "foo(" + "a?" * 64 + ")"]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
     # widths through groups (hs_expression_info): min over alternatives, max = longest, unbounded loops
@@ -225,3 +231,52 @@ def test_grouped_tail_compile_errors_and_info():
     assert hs.expression_info("foo(ab)*") == (3, 0xffffffff)
     assert hs.expression_info("foo(ab|c){2,3}") == (5, 9)
     assert hs.expression_info("foo(a|)") == (3, 4) and hs.expression_info("foo()") == (3, 3)
+
+
+def test_top_level_alternation_and_anchors():
+    """every top-level branch is its own literal-prefixed pattern under the same id; `^` / `$`
+    (plain and HS_FLAG_MULTILINE) restrict where a branch may start / end. `$` reports the
+    offset before an optional final newline (the reference's -1 offset adjust,
+    src/parser/buildstate.cpp:234-241)."""
+    ML, SOM = hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SOM_LEFTMOST
+    exprs = [("abc|defghi\\d|abd+", 0, 300), ("^GET /x", 0, 301), ("end$", 0, 302), ("^key=\\w+$", ML, 303),
+             ("line$", ML, 304), ("^abc|xyz$", SOM, 305), ("cost\\$|(ab|b)c$", 0, 306)]
+    parts = [(b"abc", "", 0, 300, {}), (b"defghi", r"\d", 0, 300, {}), (b"ab", r"d+", 0, 300, {}),
+             (b"GET /x", "", 0, 301, {}, "^"), (b"end", "", 0, 302, {}, "$"), (b"key=", r"\w+", ML, 303, {}, "^$"),
+             (b"line", "", ML, 304, {}, "$"), (b"abc", "", SOM, 305, {}, "^"), (b"xyz", "", SOM, 305, {}, "$"),
+             (b"cost$", "", 0, 306, {}), (b"(", "", 0, 306, {})]
+    parts.pop()  # "(ab|b)c$" has no literal prefix: the whole expression is refused, see below
+    exprs[-1] = ("cost\\$|bc$", 0, 306)
+    parts.append((b"bc", "", 0, 306, {}, "$"))
+    import pytest
+    with pytest.raises(hs.HsError):
+        hs.Database.compile(["cost\\$|(ab|b)c$"], [0], [1])
+    with pytest.raises(hs.HsError):
+        hs.Database.compile(["abc|"], [0], [1])
+    with pytest.raises(hs.HsError):
+        hs.Database.compile(["ab^c"], [0], [1])
+    with pytest.raises(hs.HsError):
+        hs.Database.compile(["ab$c"], [0], [1])
+    db = hs.Database.compile([e[0] for e in exprs], [e[1] for e in exprs], [e[2] for e in exprs])
+    words = [b"abc", b"defghi", b"7", b"abdd", b"GET /x", b"end", b"key=", b"v1", b"line", b"xyz", b"cost$", b"bc", b"\n", b"\n", b" "]
+    rng = np.random.default_rng(12)
+    blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 14)))) for _ in range(400)]
+    blocks += [b"GET /x end", b"GET /x end\n", b"end\n\n", b"key=v1", b"x\nkey=v1\nline\nxyz", b"abcxyz", b"abc xyz\n", b"cost$bc\n", b""]
+    corpus = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()
+    off = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.uint64)
+    recs = literal_hits(parts, corpus, off)
+    rv, ev = confirm(db, corpus, off, recs)
+    assert rv == hs.HS_SUCCESS
+    want = brute(parts, corpus, off)
+    assert sorted(ev) == sorted(want)
+    assert {e[1] for e in ev} == {e[2] for e in exprs}
+    # expression info: reference rows with anchors and alternation (unit/hyperscan/expr_info.cpp:182-228)
+    lib = hs._lib()
+    for pat, fl, row in [("abc|defghi", 0, (3, 6, 0, 0, 0)), ("^foo", 0, (3, 3, 0, 0, 0)), ("^foo.*bar", 0, (6, 0xffffffff, 0, 0, 0)),
+                         ("^foo.*bar?", 0, (5, 0xffffffff, 0, 0, 0)), ("^foo.*bar$", 0, (6, 0xffffffff, 1, 1, 1)),
+                         ("^foobar$", 0, (6, 6, 1, 1, 1)), ("foobar$", 0, (6, 6, 1, 1, 1)), ("foobar$", ML, (6, 6, 1, 1, 0))]:
+        info, err = C.POINTER(hs.ExprInfo)(), C.POINTER(hs.CompileErrorStruct)()
+        assert lib.hs_expression_ext_info(pat.encode(), fl, None, C.byref(info), C.byref(err)) == hs.HS_SUCCESS, pat
+        i = info.contents
+        assert (i.min_width, i.max_width, ord(i.unordered_matches), ord(i.matches_at_eod), ord(i.matches_only_at_eod)) == row, pat
+        C.CDLL(None).free(info)
