@@ -68,6 +68,13 @@ struct Pattern {
     unsigned long long first = 0, last = 0;
     bool g_nullable = false;
     unsigned long long g_min = 0, g_max = 0; /* tail width bounds; kInf64 = unbounded */
+    /* branches whose literal is not at the front, R1 LIT R2: R1 as a REVERSED position automaton
+     * (run backwards from the literal's first byte), R2 as the general tail above */
+    bool has_pre = false;
+    std::vector<unsigned long long> pre_follow, pre_reach;
+    unsigned long long pre_first = 0, pre_last = 0;
+    bool pre_nullable = false;
+    unsigned long long pre_min = 0, pre_max = 0;
 };
 constexpr unsigned long long kInf64 = ~0ull;
 
@@ -390,6 +397,102 @@ struct TailBuilder {
     }
 };
 
+/* a whole regex fragment as a position automaton */
+struct Auto {
+    std::vector<unsigned long long> follow, reach;
+    unsigned long long first = 0, last = 0, wmin = 0, wmax = 0;
+    bool nullable = true;
+    size_t npos = 0;
+};
+
+Auto compile_auto(const std::string &src, bool nocase, bool dotall) {
+    TailBuilder tb{src, nocase, dotall, {}, {}};
+    size_t i = 0;
+    const Frag f = tb.parse_cat(i, 0);
+    if (i < src.size()) throw ParseError{"Unmatched closing parenthesis."};
+    Auto a;
+    a.follow = tb.follow;
+    a.first = f.first;
+    a.last = f.last;
+    a.nullable = f.nullable;
+    a.wmin = f.wmin;
+    a.wmax = f.wmax;
+    a.npos = tb.cls.size();
+    a.reach.assign(256, 0);
+    for (size_t k = 0; k < tb.cls.size(); k++)
+        for (unsigned c = 0; c < 256; c++)
+            if (tb.cls[k][c]) a.reach[c] |= 1ull << k;
+    return a;
+}
+
+/* the longest run of plain characters at the top level of a branch (not inside a group or a
+ * class, not quantified): [begin, end) in the source and the bytes; the earliest of equals */
+struct LitRun {
+    size_t begin = 0, end = 0;
+    std::string bytes;
+};
+
+LitRun longest_literal_run(const std::string &p) {
+    LitRun best, cur;
+    auto close = [&]() {
+        if (cur.bytes.size() > best.bytes.size()) best = cur;
+        cur = LitRun();
+    };
+    auto skip_quant = [&](size_t &k) {
+        if (k < p.size() && (p[k] == '?' || p[k] == '*' || p[k] == '+')) k++;
+        else if (TailBuilder::is_repeat_at(p, k)) k = p.find('}', k) + 1;
+    };
+    size_t i = 0;
+    while (i < p.size()) {
+        const unsigned char c = (unsigned char)p[i];
+        size_t j = i;
+        unsigned char lit = 0;
+        bool is_lit = false;
+        if (c == '\\') {
+            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            class_escape(p[i + 1], ok);
+            if (ok) {
+                j = i + 2;
+            } else {
+                j = i + 1;
+                if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+                is_lit = true;
+            }
+        } else if (c == '[') {
+            parse_bracket_class(p, j);
+        } else if (c == '(') {
+            int depth = 0;
+            for (;; j++) {
+                if (j >= p.size()) throw ParseError{"Missing closing parenthesis."};
+                if (p[j] == '\\') { j++; continue; }
+                if (p[j] == '[') { size_t e = j; parse_bracket_class(p, e); j = e - 1; continue; }
+                if (p[j] == '(') depth++;
+                if (p[j] == ')' && --depth == 0) break;
+            }
+            j++;
+        } else if (c == '.' || strchr(")|^$*+?", c) || (c == '{' && TailBuilder::is_repeat_at(p, i))) {
+            j = i + 1; /* not a literal; a misplaced operator is reported by the fragment compiler */
+        } else {
+            lit = c;
+            j = i + 1;
+            is_lit = true;
+        }
+        const size_t after = j;
+        skip_quant(j);
+        if (is_lit && j == after) {
+            if (cur.bytes.empty()) cur.begin = i;
+            cur.bytes.push_back((char)lit);
+            cur.end = j;
+        } else {
+            close();
+        }
+        i = j;
+    }
+    close();
+    return best;
+}
+
 constexpr unsigned kAllFlags = 0x7ff; /* HS_FLAG_ALL: the eleven flags of src/hs_compile.h */
 
 /* the reference's own flag rules, in its order (src/compiler/compiler.cpp:286-294,166-196) */
@@ -471,7 +574,42 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
         pat.lit.push_back((char)lit);
         i = j;
     }
-    if (pat.lit.empty()) throw ParseError{"Pattern must start with a literal (no literal prefix found)."};
+    const LitRun run = longest_literal_run(p);
+    if (run.bytes.size() > pat.lit.size()) {
+        /* the best literal is not at the front: R1 LIT R2 around the longest top-level run */
+        if (run.bytes.empty())
+            throw ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."};
+        pat.lit = run.bytes;
+        const Auto r1 = compile_auto(p.substr(0, run.begin), pat.nocase, dotall);
+        const Auto r2 = compile_auto(p.substr(run.end), pat.nocase, dotall);
+        if (r1.npos) {
+            /* reversed: first <-> last, follow transposed */
+            pat.has_pre = true;
+            pat.pre_first = r1.last;
+            pat.pre_last = r1.first;
+            pat.pre_nullable = r1.nullable;
+            pat.pre_min = r1.wmin;
+            pat.pre_max = r1.wmax;
+            pat.pre_reach = r1.reach;
+            pat.pre_follow.assign(r1.npos, 0);
+            for (size_t a = 0; a < r1.npos; a++)
+                for (size_t b = 0; b < r1.npos; b++)
+                    if (r1.follow[a] >> b & 1) pat.pre_follow[b] |= 1ull << a;
+        }
+        if (r2.npos) {
+            pat.general = true;
+            pat.follow = r2.follow;
+            pat.first = r2.first;
+            pat.last = r2.last;
+            pat.g_nullable = r2.nullable;
+            pat.g_min = r2.wmin;
+            pat.g_max = r2.wmax;
+            pat.reach = r2.reach;
+        }
+        pat.tail_nullable = r2.nullable;
+        return pat;
+    }
+    if (pat.lit.empty()) throw ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."};
     /* a tail with a group in it goes to the position automaton; the linear form below stays the
      * path for everything it can express */
     bool grouped = false;
@@ -660,6 +798,30 @@ struct TailNfa {
             for (; cur; cur &= cur - 1) next |= p.follow[__builtin_ctzll(cur)];
         }
     }
+    /* R1 backwards from the literal's first byte: is there a `from` with buf[from, start) in R1
+     * (and, for `^`, a line start at `from`)? leftmost = keep going for the smallest one */
+    static bool run_reverse(const Pattern &p, const unsigned char *buf, size_t start, bool leftmost, size_t &from) {
+        auto at_bol = [&](size_t pos) { return !p.bol || pos == 0 || (p.multiline && buf[pos - 1] == '\n'); };
+        bool found = false;
+        if (p.pre_nullable && at_bol(start)) {
+            found = true;
+            from = start;
+            if (!leftmost) return true;
+        }
+        unsigned long long next = p.pre_first;
+        size_t pos = start;
+        while (pos > 0 && next) {
+            unsigned long long cur = next & p.pre_reach[buf[--pos]];
+            if ((cur & p.pre_last) && at_bol(pos)) {
+                found = true;
+                from = pos;
+                if (!leftmost) return true;
+            }
+            next = 0;
+            for (; cur; cur &= cur - 1) next |= p.pre_follow[__builtin_ctzll(cur)];
+        }
+        return found;
+    }
 };
 
 void finish_pattern(Pattern &p) {
@@ -842,6 +1004,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
             size_t w = p.lit.size();
             for (const Unit &u : p.tail) w += u.optional ? 0 : 1;
             if (p.general) w += p.g_min;
+            if (p.has_pre) w += p.pre_min;
             d->min_width = std::min(d->min_width, w);
         }
         int rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
@@ -907,8 +1070,14 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
         const Pattern &p = db->pats[recs[k].id];
         const size_t lit_end = (size_t)recs[k].end + 1;
         if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
-        const unsigned long long start = lit_end - p.lit.size();
-        if (p.bol && start != 0 && !(p.multiline && buf[start - 1] == '\n')) continue;
+        unsigned long long start = lit_end - p.lit.size();
+        if (p.has_pre) { /* the part in front of the literal, backwards; `start` becomes the match start */
+            size_t f = 0;
+            if (!TailNfa::run_reverse(p, buf, start, p.som || (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH), f)) continue;
+            start = f;
+        } else if (p.bol && start != 0 && !(p.multiline && buf[start - 1] == '\n')) {
+            continue;
+        }
         const unsigned long long from = p.som ? start : 0;
         /* hs_expr_ext_t bounds: the job of the reference's CHECK_BOUNDS / CHECK_MIN_LENGTH
          * program instructions (src/rose/program_runtime.c) */
@@ -1079,7 +1248,7 @@ hs_error_t hs_free_database(hs_database_t *db) {
 hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
     if (!db || !size || db->magic != 0x48534744) return HS_INVALID;
     size_t s = sizeof(*db) + hsgpu_hwlm_size(db->hwlm);
-    for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit) + p.follow.size() * 8 + p.reach.size() * 8;
+    for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit) + (p.follow.size() + p.reach.size() + p.pre_follow.size() + p.pre_reach.size()) * 8;
     *size = s;
     return HS_SUCCESS;
 }
@@ -1293,6 +1462,11 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
             lo += p.g_min;
             inf = p.g_max == kInf64;
             if (!inf) hi += p.g_max;
+        }
+        if (p.has_pre) {
+            lo += p.pre_min;
+            inf |= p.pre_max == kInf64;
+            if (p.pre_max != kInf64) hi += p.pre_max;
         }
         if (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) lo = std::max(lo, p.min_length);
         if (p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) {

@@ -24,18 +24,20 @@
  * database object owns heap containers, so it cannot live in caller memory.
  *
  * What is behind it: an expression is one or more top-level branches `b1|b2|...`, and every
- * branch must start with a literal (>= 1 byte), optionally after `^`. The literal
- * prefixes (their last <= 8 bytes, as Rose truncates them: rose_build_matchers.cpp:717-724)
+ * branch must contain a mandatory literal (>= 1 byte) at its top level: R1 LIT R2, where R1 and
+ * R2 are regex fragments (either may be empty; LIT is the longest top-level run of plain
+ * characters, the one at the front on a tie) and `^` may lead the branch. The literals
+ * (their last <= 8 bytes, as Rose truncates them: rose_build_matchers.cpp:717-724)
  * are matched on the GPU through hsgpu_hwlm_exec; the host then checks the full literal
  * (the job of CHECK_MED_LIT / CHECK_LONG_LIT, src/rose/program_runtime.c:2896-2942) and,
- * for branches with a tail, runs a bit-parallel NFA over the bytes that follow
- * (the job of the NFA engines Rose would trigger). Supported tail syntax: literal
+ * runs bit-parallel NFAs over the bytes that follow (R2, forwards) and precede (R1, backwards
+ * from the literal: the job of Rose's suffix / prefix engines). Supported fragment syntax: literal
  * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes, the quantifiers
  * ? * + {m} {m,} {m,n}, groups `( )` / `(?: )` with alternation inside them, nested and
  * quantified (a tail with groups compiles to a position automaton of <= 63 positions), and a
  * final `$` (end of data or before its last newline, reported before the newline as the
  * reference does; with HS_FLAG_MULTILINE `^` / `$` also match after / before any newline).
- * Anything else (branches without a literal prefix, embedded anchors, \b \A \z, look-around,
+ * Anything else (branches without a mandatory top-level literal, embedded anchors, \b \A \z, look-around,
  * back-references, lazy quantifiers, streaming / vectored modes) is rejected with HS_COMPILER_ERROR:
  * the regex compiler proper is out of scope.
  */

@@ -78,10 +78,10 @@ def test_arg_checks():
         hs.Database.compile(["foo"], mode=hs.HS_MODE_STREAM)
     assert e.value.code == hs.HS_COMPILER_ERROR
     with pytest.raises(hs.HsError) as e:
-        hs.Database.compile(["(a|b)c"])
+        hs.Database.compile(["(a|b)+"])  # no mandatory literal at the top level
     assert e.value.code == hs.HS_COMPILER_ERROR and e.value.expression == 0
     with pytest.raises(hs.HsError) as e:
-        hs.Database.compile(["good", "[a-z]+tail"])
+        hs.Database.compile(["good", "[a-z]+(tail"])
     assert e.value.expression == 1
     with pytest.raises(hs.HsError) as e:
         hs.Database.compile_lit([b""])

@@ -240,17 +240,14 @@ def test_top_level_alternation_and_anchors():
     src/parser/buildstate.cpp:234-241)."""
     ML, SOM = hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SOM_LEFTMOST
     exprs = [("abc|defghi\\d|abd+", 0, 300), ("^GET /x", 0, 301), ("end$", 0, 302), ("^key=\\w+$", ML, 303),
-             ("line$", ML, 304), ("^abc|xyz$", SOM, 305), ("cost\\$|(ab|b)c$", 0, 306)]
+             ("line$", ML, 304), ("^abc|xyz$", SOM, 305), ("cost\\$|bc$", 0, 306)]
     parts = [(b"abc", "", 0, 300, {}), (b"defghi", r"\d", 0, 300, {}), (b"ab", r"d+", 0, 300, {}),
              (b"GET /x", "", 0, 301, {}, "^"), (b"end", "", 0, 302, {}, "$"), (b"key=", r"\w+", ML, 303, {}, "^$"),
              (b"line", "", ML, 304, {}, "$"), (b"abc", "", SOM, 305, {}, "^"), (b"xyz", "", SOM, 305, {}, "$"),
-             (b"cost$", "", 0, 306, {}), (b"(", "", 0, 306, {})]
-    parts.pop()  # "(ab|b)c$" has no literal prefix: the whole expression is refused, see below
-    exprs[-1] = ("cost\\$|bc$", 0, 306)
-    parts.append((b"bc", "", 0, 306, {}, "$"))
+             (b"cost$", "", 0, 306, {}), (b"bc", "", 0, 306, {}, "$")]
     import pytest
-    with pytest.raises(hs.HsError):
-        hs.Database.compile(["cost\\$|(ab|b)c$"], [0], [1])
+    with pytest.raises(hs.HsError):  # one branch without a mandatory literal refuses the whole expression
+        hs.Database.compile(["cost\\$|(ab|b)$"], [0], [1])
     with pytest.raises(hs.HsError):
         hs.Database.compile(["abc|"], [0], [1])
     with pytest.raises(hs.HsError):
@@ -280,3 +277,77 @@ def test_top_level_alternation_and_anchors():
         i = info.contents
         assert (i.min_width, i.max_width, ord(i.unordered_matches), ord(i.matches_at_eod), ord(i.matches_only_at_eod)) == row, pat
         C.CDLL(None).free(info)
+
+
+def brute_full(exprs, blocks):
+    """events from the whole expression on Python's re: for every end offset, is there a start
+    with a full match (the smallest one is the SOM_LEFTMOST `from`)"""
+    out = []
+    for b, data in enumerate(blocks):
+        for pat, fl, pid in exprs:
+            rf = (re.I if fl & hs.HS_FLAG_CASELESS else 0) | (re.S if fl & hs.HS_FLAG_DOTALL else 0) | \
+                 (re.M if fl & hs.HS_FLAG_MULTILINE else 0)
+            rx = re.compile(pat.encode("latin-1"), rf)
+            for to in range(len(data) + 1):
+                froms = [f for f in range(to) if rx.fullmatch(data, f, to)]
+                if froms:
+                    out.append((b, pid, min(froms) if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, to))
+    return out
+
+
+def run_exprs(exprs, lits, blocks, ext=None):
+    """compile `exprs`, take the literal hits for `lits` (the literal each branch is expected to be
+    keyed on, in branch order) from the oracle, and run the facade's confirm"""
+    db = hs.Database.compile_ext([e[0] for e in exprs], [e[1] for e in exprs], [e[2] for e in exprs], ext or [None] * len(exprs))
+    parts = [(l, "", fl, 0, {}) for l, fl in lits]
+    corpus = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()
+    off = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.uint64)
+    rv, ev = confirm(db, corpus, off, literal_hits(parts, corpus, off))
+    assert rv == hs.HS_SUCCESS
+    return ev
+
+
+def test_order_cpp_patterns():
+    # unit/hyperscan/order.cpp:65-96 (ordering1): counts per id on 32 x 'a'
+    D = hs.HS_FLAG_DOTALL
+    exprs = [("aa", D, 1), ("aa.", D, 2), ("aa..", D, 3), ("^.{0,4}aa..", D, 4), ("^.{0,4}aa", D, 5)]
+    ev = run_exprs(exprs, [(b"aa", D)] * 5, [b"a" * 32])
+    cnt = {i: sum(1 for e in ev if e[1] == i) for i in range(1, 6)}
+    assert cnt == {1: 31, 2: 30, 3: 29, 4: 5, 5: 5}
+    assert [e[3] for e in ev] == sorted(e[3] for e in ev)
+    assert sorted(ev) == sorted(brute_full(exprs, [b"a" * 32]))
+
+
+def test_literal_in_the_middle_matches_brute_force():
+    """branches whose literal is not at the front (R1 LIT R2): the part in front runs backwards
+    from the literal as a reversed position automaton"""
+    I, S, SOM, ML = hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL, hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_MULTILINE
+    exprs = [(r"[a-z]+@example\.(com|org)", 0, 1), (r"\d{1,3}\.\d{1,3}:8080", 0, 2), (r"(GET|POST) /index", 0, 3),
+             (r"^\s*key\s*=", ML, 4), (r"x?y*zfoo[0-9]", I, 5), (r"[ab]+cd[ab]+", SOM, 6), (r"^.{2,5}END", S, 7),
+             (r"(ab|c)+def(g|hi)*j", SOM, 8), (r"a.cab", 0, 9), (r"\w+\.txt|\d+\.dat", 0, 10)]
+    lits = [(b"@example.", 0), (b":8080", 0), (b" /index", 0), (b"key", ML), (b"zfoo", I), (b"cd", SOM), (b"END", S), (b"def", SOM),
+            (b"cab", 0), (b".txt", 0), (b".dat", 0)]
+    words = [b"bob", b"@example.", b"com", b"org", b"10", b".", b"255", b":8080", b"GET", b"POST", b" /index", b"  ", b"key", b"=",
+             b"\n", b"xy", b"yyZFOO7", b"zfoo", b"ab", b"ba", b"cd", b"END", b"c", b"def", b"g", b"hi", b"j", b"a", b"cab", b"acab",
+             b"f1.txt", b"77.dat", b" "]
+    rng = np.random.default_rng(31)
+    blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 22)))) for _ in range(120)]
+    blocks += [b"key=", b"\n key =", b"xkey=", b"abEND", b"aEND", b"abcdefEND", b"ababcdab", b"abcdefghij", b"cdefj", b"a\ncab", b"",
+               b"mail bob@example.com, ba@example.org!", b"at 10.255:8080 and 1234.5:8080"]
+    ev = run_exprs(exprs, lits, blocks)
+    want = brute_full(exprs, blocks)
+    assert sorted(ev) == sorted(want)
+    assert {e[1] for e in ev} == set(range(1, 11))
+    # min_length counts from the leftmost start of the match
+    ext = [None] * len(exprs)
+    ext[5] = hs.ExprExt.make(min_length=6)
+    ev2 = run_exprs(exprs, lits, blocks, ext)
+    want2 = [e for e in want if e[1] != 6 or e[3] - e[2] >= 6]
+    assert sorted(ev2) == sorted(want2) and len(want2) < len(want)
+    # widths (hs_expression_info) through both sides
+    assert hs.expression_info(r"^.{0,4}aa..") == (4, 8)
+    assert hs.expression_info(r"[a-z]+@example\.(com|org)") == (13, 0xffffffff)
+    import pytest
+    for bad in [r"[a-z]+", r"(foo|bar)z?", r"a*", r"(abc)"]:  # no top-level mandatory literal
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([bad], [0], [1])
