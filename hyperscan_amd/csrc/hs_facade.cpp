@@ -50,7 +50,13 @@ struct Pattern {
     std::string lit;          /* literal prefix, as written (upper-cased compare if nocase) */
     bool nocase = false, single = false, som = false;
     /* `^` in front / `$` at the back of the branch (multiline: the HS_FLAG_MULTILINE reading) */
-    bool bol = false, eol = false, multiline = false;
+    bool bol = false, eol = false;
+    bool bol_ml = false; /* `^` under HS_FLAG_MULTILINE: also after any newline (never for \A) */
+    bool eol_ml = false; /* `$` under HS_FLAG_MULTILINE: also before any newline */
+    bool eol_nl = false; /* `$` and \Z: also before the data's final newline (never for \z) */
+    /* \b (1) / \B (2) at the four places they are supported: the start of the match, just before
+     * and just after the literal, the end of the match */
+    unsigned char as_start = 0, as_lit_pre = 0, as_lit_post = 0, as_end = 0;
     unsigned id = 0;
     std::vector<Unit> tail;   /* empty: pure literal */
     bool tail_nullable = true;
@@ -452,7 +458,7 @@ LitRun longest_literal_run(const std::string &p) {
             if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
             bool ok;
             class_escape(p[i + 1], ok);
-            if (ok) {
+            if (ok || strchr("bBAzZ", p[i + 1])) { /* a class, or a zero-width assertion: ends the run */
                 j = i + 2;
             } else {
                 j = i + 1;
@@ -516,72 +522,70 @@ void check_flags(unsigned flags, bool literal_api) {
 Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     Pattern pat;
     std::string p = src;
+    const bool multiline = flags & HS_FLAG_MULTILINE;
+    /* is the two-character escape "\\<c>" at p[k], with its backslash not itself escaped? */
+    auto escape_at = [&](size_t k, const char *cs) {
+        if (k + 1 >= p.size() || p[k] != '\\' || !strchr(cs, p[k + 1])) return false;
+        size_t bs = 0;
+        while (bs < k && p[k - 1 - bs] == '\\') bs++;
+        return bs % 2 == 0;
+    };
+    auto assertion = [](char c) { return (unsigned char)(c == 'b' ? 1 : 2); };
+    /* front: ^ or \A, then \b / \B */
     if (!p.empty() && p[0] == '^') {
         pat.bol = true;
+        pat.bol_ml = multiline;
         p.erase(0, 1);
+    } else if (escape_at(0, "A")) {
+        pat.bol = true;
+        p.erase(0, 2);
     }
-    if (!p.empty() && p.back() == '$') {
-        size_t bs = 0;
-        while (bs + 1 < p.size() && p[p.size() - 2 - bs] == '\\') bs++;
-        if (bs % 2 == 0) {
-            pat.eol = true;
-            p.pop_back();
-        }
+    if (escape_at(0, "bB")) {
+        pat.as_start = assertion(p[1]);
+        p.erase(0, 2);
     }
-    pat.multiline = flags & HS_FLAG_MULTILINE;
+    /* back: $, \z or \Z, before it \b / \B */
+    if (!p.empty() && p.back() == '$' && !escape_at(p.size() - 2, "$")) {
+        pat.eol = pat.eol_nl = true;
+        pat.eol_ml = multiline;
+        p.pop_back();
+    } else if (p.size() >= 2 && escape_at(p.size() - 2, "zZ")) {
+        pat.eol = true;
+        pat.eol_nl = p.back() == 'Z';
+        p.erase(p.size() - 2);
+    }
+    if (p.size() >= 2 && escape_at(p.size() - 2, "bB")) {
+        pat.as_end = assertion(p.back());
+        p.erase(p.size() - 2);
+    }
     pat.nocase = flags & HS_FLAG_CASELESS;
     pat.single = flags & HS_FLAG_SINGLEMATCH;
     pat.som = flags & HS_FLAG_SOM_LEFTMOST;
     pat.id = id;
     const bool dotall = flags & HS_FLAG_DOTALL;
-    size_t i = 0;
     /* `{` opens a repeat only when a well-formed {m}, {m,} or {m,n} follows; otherwise it (and
      * a lone `}`) is an ordinary character, as in PCRE ("foo.{,10}bar" is twelve literal-ish
      * positions: unit/hyperscan/expr_info.cpp:211) */
-    auto is_repeat = [&](size_t k) {
-        if (k >= p.size() || p[k] != '{') return false;
-        size_t j = k + 1, d = 0;
-        while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++, d++;
-        if (d == 0) return false;
-        if (j < p.size() && p[j] == ',') {
-            j++;
-            while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++;
-        }
-        return j < p.size() && p[j] == '}';
-    };
-    auto peek_quant = [&](size_t k) { return k < p.size() && (p[k] == '?' || p[k] == '*' || p[k] == '+' || is_repeat(k)); };
-    /* literal prefix: plain or escaped characters not followed by a quantifier */
-    while (i < p.size()) {
-        unsigned char c = (unsigned char)p[i];
-        size_t j = i;
-        unsigned char lit;
-        if (c == '\\') {
-            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
-            bool ok;
-            class_escape(p[i + 1], ok);
-            if (ok) break; /* \d etc: tail */
-            j = i + 1;
-            if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
-        } else if (strchr(".[]()|^$*+?", c) || (c == '{' && is_repeat(i))) {
-            if (c == '.' || c == '[' || c == '(') break;
-            throw ParseError{std::string("Unsupported regex construct '") + (char)c +
-                             "': only a literal prefix followed by classes, groups and quantifiers is supported."};
-        } else {
-            lit = c;
-            j = i + 1;
-        }
-        if (peek_quant(j)) break; /* this character belongs to the tail */
-        pat.lit.push_back((char)lit);
-        i = j;
+    auto is_repeat = [&](size_t k) { return TailBuilder::is_repeat_at(p, k); };
+    /* the branch is R1 LIT R2 around its longest top-level literal run (the front one on a tie);
+     * \b / \B may hug the literal on either side */
+    LitRun run = longest_literal_run(p);
+    if (run.bytes.empty()) throw ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."};
+    size_t r1_end = run.begin, r2_begin = run.end;
+    if (run.begin >= 2 && escape_at(run.begin - 2, "bB")) {
+        pat.as_lit_pre = assertion(p[run.begin - 1]);
+        r1_end -= 2;
     }
-    const LitRun run = longest_literal_run(p);
-    if (run.bytes.size() > pat.lit.size()) {
-        /* the best literal is not at the front: R1 LIT R2 around the longest top-level run */
-        if (run.bytes.empty())
-            throw ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."};
-        pat.lit = run.bytes;
-        const Auto r1 = compile_auto(p.substr(0, run.begin), pat.nocase, dotall);
-        const Auto r2 = compile_auto(p.substr(run.end), pat.nocase, dotall);
+    if (escape_at(run.end, "bB")) {
+        pat.as_lit_post = assertion(p[run.end + 1]);
+        r2_begin += 2;
+    }
+    pat.lit = run.bytes;
+    size_t i = r2_begin;
+    if (r1_end != 0) {
+        /* the literal is not at the front: R1 backwards, R2 as a position automaton */
+        const Auto r1 = compile_auto(p.substr(0, r1_end), pat.nocase, dotall);
+        const Auto r2 = compile_auto(p.substr(r2_begin), pat.nocase, dotall);
         if (r1.npos) {
             /* reversed: first <-> last, follow transposed */
             pat.has_pre = true;
@@ -609,7 +613,6 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
         pat.tail_nullable = r2.nullable;
         return pat;
     }
-    if (pat.lit.empty()) throw ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."};
     /* a tail with a group in it goes to the position automaton; the linear form below stays the
      * path for everything it can express */
     bool grouped = false;
@@ -743,6 +746,16 @@ std::vector<Pattern> parse_pattern(const std::string &p, unsigned flags, unsigne
     return out;
 }
 
+/* \b / \B between buf[pos - 1] and buf[pos]; outside the block counts as a non-word byte */
+inline bool is_word_byte(unsigned char c) {
+    return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_';
+}
+inline bool assert_ok(unsigned char kind, const unsigned char *buf, size_t len, size_t pos) {
+    if (!kind) return true;
+    const bool before = pos > 0 && is_word_byte(buf[pos - 1]), after = pos < len && is_word_byte(buf[pos]);
+    return (before != after) == (kind == 1);
+}
+
 /* simulation of the linear NFA: state i = "units 0..i-1 consumed" */
 struct TailNfa {
     typedef std::bitset<kMaxStates> States;
@@ -800,8 +813,11 @@ struct TailNfa {
     }
     /* R1 backwards from the literal's first byte: is there a `from` with buf[from, start) in R1
      * (and, for `^`, a line start at `from`)? leftmost = keep going for the smallest one */
-    static bool run_reverse(const Pattern &p, const unsigned char *buf, size_t start, bool leftmost, size_t &from) {
-        auto at_bol = [&](size_t pos) { return !p.bol || pos == 0 || (p.multiline && buf[pos - 1] == '\n'); };
+    static bool run_reverse(const Pattern &p, const unsigned char *buf, size_t len, size_t start, bool leftmost,
+                            size_t &from) {
+        auto at_bol = [&](size_t pos) {
+            return (!p.bol || pos == 0 || (p.bol_ml && buf[pos - 1] == '\n')) && assert_ok(p.as_start, buf, len, pos);
+        };
         bool found = false;
         if (p.pre_nullable && at_bol(start)) {
             found = true;
@@ -1071,11 +1087,12 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
         const size_t lit_end = (size_t)recs[k].end + 1;
         if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
         unsigned long long start = lit_end - p.lit.size();
+        if (!assert_ok(p.as_lit_pre, buf, len, start) || !assert_ok(p.as_lit_post, buf, len, lit_end)) continue;
         if (p.has_pre) { /* the part in front of the literal, backwards; `start` becomes the match start */
             size_t f = 0;
-            if (!TailNfa::run_reverse(p, buf, start, p.som || (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH), f)) continue;
+            if (!TailNfa::run_reverse(p, buf, len, start, p.som || (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH), f)) continue;
             start = f;
-        } else if (p.bol && start != 0 && !(p.multiline && buf[start - 1] == '\n')) {
+        } else if ((p.bol && start != 0 && !(p.bol_ml && buf[start - 1] == '\n')) || !assert_ok(p.as_start, buf, len, start)) {
             continue;
         }
         const unsigned long long from = p.som ? start : 0;
@@ -1083,7 +1100,8 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
          * program instructions (src/rose/program_runtime.c) */
         auto in_bounds = [&](unsigned long long to) {
             /* `$`: at the end of the data or before its final newline; multiline: before any newline */
-            if (p.eol && to != len && !(buf[to] == '\n' && (p.multiline || to + 1 == len))) return false;
+            if (p.eol && to != len && !(buf[to] == '\n' && (p.eol_ml || (p.eol_nl && to + 1 == len)))) return false;
+            if (!assert_ok(p.as_end, buf, len, to)) return false;
             if ((p.ext_flags & HS_EXT_FLAG_MIN_OFFSET) && to < p.min_offset) return false;
             if ((p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) && to > p.max_offset) return false;
             if ((p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) && to - start < p.min_length) return false;
@@ -1449,7 +1467,7 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
         return HS_COMPILER_ERROR;
     }
     unsigned long long minw = kInf64, maxw = 0;
-    bool unbounded = false, any_eol = false, all_eol = true, eol_multiline = false;
+    bool unbounded = false, any_eol = false, all_eol = true, eol_multiline = false, unordered = false, at_eod = false;
     for (const Pattern &p : branches) {
         unsigned long long lo = p.lit.size(), hi = p.lit.size();
         bool inf = false;
@@ -1478,7 +1496,9 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
         unbounded |= inf;
         any_eol |= p.eol;
         all_eol &= p.eol;
-        eol_multiline |= p.eol && p.multiline;
+        eol_multiline |= p.eol && p.eol_ml;
+        unordered |= (p.eol && p.eol_nl) || p.as_end;
+        at_eod |= p.eol || p.as_end;
     }
     hs_expr_info_t *out = (hs_expr_info_t *)hook_alloc(g_misc, sizeof(*out));
     if (hs_error_t ae = check_alloc(out)) {
@@ -1488,10 +1508,11 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
     }
     out->min_width = (unsigned)std::min<unsigned long long>(minw, 0xffffffffu);
     out->max_width = unbounded ? 0xffffffffu : (unsigned)std::min<unsigned long long>(maxw, 0xffffffffu);
-    /* a `$` branch may be satisfied by the end of the data (expr_info.cpp:199-203: "foobar$" is
-     * unordered / at EOD / only at EOD; the multiline form also matches before inner newlines) */
-    out->unordered_matches = any_eol;
-    out->matches_at_eod = any_eol;
+    /* a branch may be completed by the end of the data (expr_info.cpp:190-206): "foobar$" and \Z
+     * are unordered / at EOD / only at EOD (the multiline `$` also matches before inner newlines),
+     * \z is ordered and only at EOD, a closing \b is unordered and at EOD but not only there */
+    out->unordered_matches = unordered;
+    out->matches_at_eod = at_eod;
     out->matches_only_at_eod = all_eol && !eol_multiline;
     *info = out;
     return HS_SUCCESS;
@@ -1637,6 +1658,19 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
                 std::chrono::duration<double, std::milli>(t_end - t_scan).count());
     }
     return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
+}
+
+/* the literal the GPU matcher holds for one branch (hs_gpu.h) */
+hs_error_t hs_database_literal(const hs_database_t *db, unsigned int index, const char **bytes, size_t *len,
+                               int *nocase, unsigned int *id) {
+    if (!db || db->magic != 0x48534744 || index >= db->pats.size()) return HS_INVALID;
+    const Pattern &p = db->pats[index];
+    const size_t n = std::min<size_t>(p.lit.size(), 8);
+    if (bytes) *bytes = p.lit.data() + p.lit.size() - n;
+    if (len) *len = n;
+    if (nocase) *nocase = p.nocase;
+    if (id) *id = p.id;
+    return HS_SUCCESS;
 }
 
 /* Extension: the host confirm alone, for callers that bring their own literal hits (another

@@ -142,6 +142,18 @@ class Database:
             raise HsError(rv)
         return cls(db)
 
+    def literals(self):
+        """hs_database_literal for every branch: [(bytes, nocase, report id)] -- what the GPU
+        matcher is keyed on, in the order of the literal ids it reports"""
+        lib, out = _lib(), []
+        lib.hs_database_literal.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_uint)]
+        while True:
+            b, n, nc, rid = C.c_void_p(), C.c_size_t(), C.c_int(), C.c_uint()
+            if lib.hs_database_literal(self._h, len(out), C.byref(b), C.byref(n), C.byref(nc), C.byref(rid)) != HS_SUCCESS:
+                return out
+            out.append((C.string_at(b, n.value), bool(nc.value), rid.value))
+
     def size(self):
         n = C.c_size_t()
         _lib().hs_database_size(self._h, C.byref(n))

@@ -34,11 +34,14 @@
  * from the literal: the job of Rose's suffix / prefix engines). Supported fragment syntax: literal
  * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes, the quantifiers
  * ? * + {m} {m,} {m,n}, groups `( )` / `(?: )` with alternation inside them, nested and
- * quantified (a tail with groups compiles to a position automaton of <= 63 positions), and a
- * final `$` (end of data or before its last newline, reported before the newline as the
- * reference does; with HS_FLAG_MULTILINE `^` / `$` also match after / before any newline).
- * Anything else (branches without a mandatory top-level literal, embedded anchors, \b \A \z, look-around,
- * back-references, lazy quantifiers, streaming / vectored modes) is rejected with HS_COMPILER_ERROR:
+ * quantified (a fragment compiles to a position automaton of <= 63 positions). Anchors and
+ * assertions at the edges of a branch: `^` / \A in front, `$` / \z / \Z at the back (`$` and \Z
+ * also before the data's final newline, reported before the newline as the reference does; with
+ * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline), and \b / \B at the start,
+ * at the end, and directly before or after the literal.
+ * Anything else (branches without a mandatory top-level literal, anchors or assertions elsewhere,
+ * look-around, back-references, lazy quantifiers, inline flags, streaming / vectored modes) is
+ * rejected with HS_COMPILER_ERROR:
  * the regex compiler proper is out of scope.
  */
 #ifndef HS_GPU_H
@@ -198,12 +201,20 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
                          hs_batch_event_handler onEvent, void *context);
 
 /* Extension: only the host-side confirm of hs_scan_batch, over literal hits the caller supplies
- * (hsgpu_match_t records, include/hsgpu.h: sorted by (block, end); id = index of the pattern in
- * compile order; end = offset of the last byte of the pattern's literal prefix). Touches no
+ * (hsgpu_match_t records, include/hsgpu.h: sorted by (block, end); id = index of the branch, see
+ * hs_database_literal; end = offset of the last byte of that branch's literal). Touches no
  * device. HS_INVALID for records that are out of order or out of range. */
 hs_error_t hs_confirm_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
                             unsigned long long nblocks, const void *records, unsigned long long n_records,
                             hs_batch_event_handler onEvent, void *context);
+
+/* Extension: what the GPU matcher of this database is keyed on (the part of the reference's
+ * dump output that names Rose's literals). Branch `index` (expressions in compile order, the
+ * top-level alternatives of each left to right; HS_INVALID past the last): *bytes / *len = the
+ * HWLM literal (the last <= 8 bytes of the branch's literal, not NUL-terminated, owned by the
+ * database), *nocase = compared caselessly, *id = the report id of its expression. */
+hs_error_t hs_database_literal(const hs_database_t *db, unsigned int index, const char **bytes, size_t *len,
+                               int *nocase, unsigned int *id);
 
 /* Ready-made batch handler that counts (hsbench's onMatch, tools/hsbench/engine_hyperscan.cpp:89-97):
  * context = unsigned long long * incremented once per match; never stops the scan. */

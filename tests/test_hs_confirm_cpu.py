@@ -271,7 +271,11 @@ def test_top_level_alternation_and_anchors():
     lib = hs._lib()
     for pat, fl, row in [("abc|defghi", 0, (3, 6, 0, 0, 0)), ("^foo", 0, (3, 3, 0, 0, 0)), ("^foo.*bar", 0, (6, 0xffffffff, 0, 0, 0)),
                          ("^foo.*bar?", 0, (5, 0xffffffff, 0, 0, 0)), ("^foo.*bar$", 0, (6, 0xffffffff, 1, 1, 1)),
-                         ("^foobar$", 0, (6, 6, 1, 1, 1)), ("foobar$", 0, (6, 6, 1, 1, 1)), ("foobar$", ML, (6, 6, 1, 1, 0))]:
+                         ("^foobar$", 0, (6, 6, 1, 1, 1)), ("foobar$", 0, (6, 6, 1, 1, 1)), ("foobar$", ML, (6, 6, 1, 1, 0)),
+                         ("foo\\b", 0, (3, 3, 1, 1, 0)), ("\\bfoo", 0, (3, 3, 0, 0, 0)), ("^\\bfoo", 0, (3, 3, 0, 0, 0)),
+                         ("\\Bfoo", 0, (3, 3, 0, 0, 0)),
+                         # \z / \Z flags as in the table's bare "\\z" (0, 1, 1) and "\\Z" (1, 1, 1) rows
+                         ("eod\\z", 0, (3, 3, 0, 1, 1)), ("eod\\Z", 0, (3, 3, 1, 1, 1))]:
         info, err = C.POINTER(hs.ExprInfo)(), C.POINTER(hs.CompileErrorStruct)()
         assert lib.hs_expression_ext_info(pat.encode(), fl, None, C.byref(info), C.byref(err)) == hs.HS_SUCCESS, pat
         i = info.contents
@@ -349,5 +353,51 @@ def test_literal_in_the_middle_matches_brute_force():
     assert hs.expression_info(r"[a-z]+@example\.(com|org)") == (13, 0xffffffff)
     import pytest
     for bad in [r"[a-z]+", r"(foo|bar)z?", r"a*", r"(abc)"]:  # no top-level mandatory literal
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([bad], [0], [1])
+
+
+def brute_context(exprs, blocks):
+    """like brute_full, but every candidate end offset is tested with the whole block visible
+    (a lookahead pins the end), so \\b, \\B and the end anchors see the real neighbours.
+    Dialect: the reference's \\z is Python's \\Z; its \\Z is Python's (?=\\n?\\Z)."""
+    out = []
+    for b, data in enumerate(blocks):
+        for pat, fl, pid in exprs:
+            rf = (re.I if fl & hs.HS_FLAG_CASELESS else 0) | (re.S if fl & hs.HS_FLAG_DOTALL else 0) | \
+                 (re.M if fl & hs.HS_FLAG_MULTILINE else 0)
+            py = pat.replace("\\Z", "(?=\\n?\\Z)").replace("\\z", "\\Z")
+            for to in range(len(data) + 1):
+                rx = re.compile(("(?:%s)(?=[\\s\\S]{%d}\\Z)" % (py, len(data) - to)).encode("latin-1"), rf)
+                froms = [f for f in range(to) if rx.match(data, f)]
+                if froms:
+                    out.append((b, pid, min(froms) if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, to))
+    return out
+
+
+def run_exprs_auto(exprs, blocks):
+    """run_exprs with the literals taken from the database itself (hs_database_literal)"""
+    db = hs.Database.compile([e[0] for e in exprs], [e[1] for e in exprs], [e[2] for e in exprs])
+    return run_exprs(exprs, [(b, hs.HS_FLAG_CASELESS if nc else 0) for b, nc, _rid in db.literals()], blocks)
+
+
+def test_word_boundaries_and_absolute_anchors():
+    """\\b / \\B at the edges of a branch and hugging its literal, \\A, \\z, \\Z"""
+    I, SOM, ML = hs.HS_FLAG_CASELESS, hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_MULTILINE
+    exprs = [(r"\bcat\b", 0, 1), (r"\Bcat", 0, 2), (r"cat\B", I, 3), (r"\bdog\b\s+\w+", SOM, 4), (r"\s+\bfish", 0, 5),
+             (r"\Astart", ML, 6), (r"end\z", 0, 7), (r"end\Z", 0, 8), (r"\bend\b$", ML, 9), (r"[a-z]+\B7up", SOM, 10),
+             (r"\b\d+ cats?\b", 0, 11), (r"x\W*\bcat", 0, 12), (r"^\bstart|\bfish\b$", 0, 13)]
+    words = [b"cat", b"CAT", b"cats", b"dog", b" ", b"  ", b"fish", b"start", b"end", b"\n", b"7up", b"ab", b"12", b" cat", b"x",
+             b"-", b"_"]
+    rng = np.random.default_rng(44)
+    blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 12)))) for _ in range(150)]
+    blocks += [b"cat", b"concat cat", b"cat\n", b"start\nstart", b"end", b"end\n", b"end\n\n", b"x end\nend", b"ab7up 7up", b"12 cats",
+               b"dog  fish", b"a dog fish-", b"xcat", b"x-cat", b"start fish", b"fish\n"]
+    ev = run_exprs_auto(exprs, blocks)
+    want = brute_context(exprs, blocks)
+    assert sorted(ev) == sorted(want)
+    assert {e[1] for e in ev} == set(range(1, 14))
+    import pytest
+    for bad in [r"c.\bt+x", r"(\bcat)+s", r"a\zb", r"\b", r"cat\b+"]:  # assertions elsewhere are refused
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])

@@ -1,0 +1,139 @@
+"""The reference's API-level unit tests (unit/hyperscan/*.cpp) that lie inside the supported
+pattern subset, on the CPU: the database is compiled by the facade, the literal hits come from
+the HWLM oracle for the literals the database reports it is keyed on (hs_database_literal), and
+the host confirm (hs_confirm_batch) turns them into events. The same cases run through the GPU
+in tests/test_gpu_hs_api.py / test_zz_gpu_late_additions.py; here every expected (to, id) list
+is the reference's own."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hyperscan_amd as H
+from hyperscan_amd import hs
+from hyperscan_amd.hwlm import MATCH_DTYPE
+from tests import oracle_binding as ob
+
+
+def cpu_scan(db, data, halt_after=None):
+    """hs_scan with the oracle in the GPU's place -> [(to, id)] in delivery order, return code"""
+    lits = [H.HwlmLiteral(b, nocase=nc, id=i) for i, (b, nc, _rid) in enumerate(db.literals())]
+    corpus = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(0, np.uint8)
+    off = np.array([0, corpus.size], dtype=np.uint64)
+    got = ob.Oracle(lits).collect_blocks(corpus, off)
+    recs = np.zeros(len(got), dtype=MATCH_DTYPE)
+    recs["block"], recs["end"], recs["id"], recs["lit"] = got["block"], got["end"], got["id"], got["id"]
+    recs = np.ascontiguousarray(recs[np.lexsort((recs["id"], recs["end"], recs["block"]))])
+    lib = hs._lib()
+    lib.hs_confirm_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_ulonglong, hs.BATCH_CB,
+                                     C.c_void_p]
+    ev = []
+
+    def on(_b, i, f, t, _fl, _c):
+        ev.append((t, i, f))
+        return 1 if halt_after is not None and len(ev) >= halt_after else 0
+
+    cb = hs.BATCH_CB(on)
+    buf = corpus if corpus.size else np.zeros(1, np.uint8)
+    rv = lib.hs_confirm_batch(db._h, buf.ctypes.data, off.ctypes.data, 1, recs.ctypes.data, recs.size, cb, None)
+    return ev, rv
+
+
+def to_id(ev):
+    return [(t, i) for t, i, _f in ev]
+
+
+def test_multi_cpp():
+    # unit/hyperscan/multi.cpp:40-290 (MMAdaptor): two patterns, with and without SINGLEMATCH / halting
+    exprs, ids = ["aoo[A-K]", "bar[L-Z]"], [30, 31]
+    for data in (b"aooAaooAbarZ", b"aooAaooAbarZ" + b" " * 22):
+        db = hs.Database.compile(exprs, [0, 0], ids)
+        assert to_id(cpu_scan(db, data)[0]) == [(4, 30), (8, 30), (12, 31)]            # norm_cont
+        assert to_id(cpu_scan(db, data, halt_after=1)[0]) == [(4, 30)]                 # norm_halt
+        db = hs.Database.compile(exprs, [hs.HS_FLAG_SINGLEMATCH, 0], ids)
+        assert sorted(to_id(cpu_scan(db, data)[0])) == [(4, 30), (12, 31)]             # high_cont
+        assert to_id(cpu_scan(db, data, halt_after=1)[0]) == [(4, 30)]                 # high_halt
+    # :331-366 MMRoseLiteralPath.issue_141: ids default to 0
+    S = hs.HS_FLAG_DOTALL | hs.HS_FLAG_SINGLEMATCH
+    db = hs.Database.compile(["/odezhda-dlya-bega/", "kurtki-i-vetrovki-dlya-bega", "futbolki-i-mayki-dlya-bega"], [S] * 3, [0] * 3)
+    assert to_id(cpu_scan(db, b"/odezhda-dlya-bega/")[0]) == [(19, 0)]
+
+
+def test_multi_cpp_dot_runs():
+    # unit/hyperscan/multi.cpp:294-331: "aaa" (id 3) fires at every offset 3..300 of 300 x 'a'
+    # (ids 1 and 2, "^.{200}" and ".{40,}", have no literal: outside the subset)
+    db = hs.Database.compile(["aaa"], [hs.HS_FLAG_DOTALL], [3])
+    ev, _ = cpu_scan(db, b"a" * 300)
+    assert to_id(ev) == [(t, 3) for t in range(3, 301)]
+    for pat in ("^.{200}", ".{40,}"):
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([pat], [hs.HS_FLAG_DOTALL], [1])
+
+
+def test_order_cpp():
+    # unit/hyperscan/order.cpp:65-~330: per-id counts over 32 x 'a', matches in offset order
+    D = hs.HS_FLAG_DOTALL
+    pats = {1: "aa", 2: "aa.", 3: "aa..", 4: "^.{0,4}aa..", 5: "^.{0,4}aa"}
+    expect = {1: 31, 2: 30, 3: 29, 4: 5, 5: 5}
+    for subset in ([1, 2, 3, 4, 5], [2, 3, 4, 5], [1, 3, 4, 5], [1, 2, 4, 5], [1, 2, 3, 5], [1, 2, 3, 4]):  # ordering1..6
+        db = hs.Database.compile([pats[i] for i in subset], [D] * len(subset), subset)
+        ev, rv = cpu_scan(db, b"a" * 32)
+        assert rv == hs.HS_SUCCESS
+        for i in range(1, 6):
+            assert sum(1 for e in ev if e[1] == i) == (expect[i] if i in subset else 0)
+        assert [e[0] for e in ev] == sorted(e[0] for e in ev)
+
+
+def test_behaviour_cpp_cases():
+    I, ONE, SOM = hs.HS_FLAG_CASELESS, hs.HS_FLAG_SINGLEMATCH, hs.HS_FLAG_SOM_LEFTMOST
+    # behaviour.cpp:361-389 BlockThereCanBeOnlyOne
+    data = (b"hackhackHACKhackHACkhAcKzofunvuynlslijlnikshvb ar yhtkubq45ytvb iuyh "
+            b"ackeruniou viytdfjhg nvldkrjgnal")
+    db = hs.Database.compile([".ck"], [I | ONE], [0])
+    assert len(cpu_scan(db, data)[0]) == 1
+    db = hs.Database.compile([".ck"], [I], [0])
+    assert len(cpu_scan(db, data)[0]) == 7
+    # behaviour.cpp:1426-1465 UE_2763 (the scan is one chunk: block mode owes the same matches;
+    # HS_FLAG_UTF8 dropped from pattern 2, the data is ASCII)
+    db = hs.Database.compile(["aaa.a+$", "aaa.a"], [I, I | ONE], [1, 2])
+    assert sorted(to_id(cpu_scan(db, b"aAasaA")[0])) == [(5, 2), (6, 1)]
+    # behaviour.cpp:1467-1511 UE_2798: patterns 2 and 3 (pattern 1 has no mandatory literal)
+    db = hs.Database.compile(["ab+", "a(b.)?ba+b"], [SOM, 0], [2, 3])
+    ev, _ = cpu_scan(db, b"ab_baab\n")
+    assert sorted(to_id(ev)) == [(2, 2), (7, 2), (7, 3)]
+    assert {(t, f) for t, i, f in ev if i == 2} == {(2, 0), (7, 5)}
+    with pytest.raises(hs.HsError):
+        hs.Database.compile(["([ab]b|aab+)$"], [hs.HS_FLAG_DOTALL], [1])
+    # behaviour.cpp:400-476 HyperscanLiteralLengthTest: floating and anchored literals of every length
+    for n in (1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 32, 33, 100, 255):
+        lit = "".join(chr(ord("a") + (k % 26)) for k in range(n))
+        for pat, data, want in ((lit, b"x" * 50 + lit.encode() + b"yy", [(50 + n, 0)]),
+                                ("^" + lit, lit.encode() + b"yy" + lit.encode(), [(n, 0)])):
+            db = hs.Database.compile([pat], [0], [0])
+            assert to_id(cpu_scan(db, data)[0]) == want, (n, pat)
+
+
+def test_callback_return_stop():
+    # behaviour.cpp:490-518 CallbackReturnStop.Block: a non-zero return ends the scan after one match
+    for pat, fl in (("foo", 0), ("foo.*bar", hs.HS_FLAG_DOTALL), ("fo+", hs.HS_FLAG_SOM_LEFTMOST)):
+        db = hs.Database.compile([pat], [fl], [0])
+        ev, rv = cpu_scan(db, b"foo bar foo barfoooo" * 4, halt_after=1)
+        assert len(ev) == 1
+
+
+def test_identical_cpp():
+    # unit/hyperscan/identical.cpp:46-82,160-188: 100 copies of one pattern under ids 0..99: one
+    # match per id, all at the table's offset (every row of the table)
+    ONE, SOM = hs.HS_FLAG_SINGLEMATCH, hs.HS_FLAG_SOM_LEFTMOST
+    rows = [("a", 0, b"a", 1), ("a", ONE, b"a", 1), ("handbasket", 0, b"__handbasket__", 12),
+            ("handbasket", ONE, b"__handbasket__", 12), ("handbasket", SOM, b"__handbasket__", 12),
+            ("foo.*bar", 0, b"a foolish embarrassment", 15), ("foo.*bar", ONE, b"a foolish embarrassment", 15),
+            ("foo.*bar", SOM, b"a foolish embarrassment", 15),
+            ("\\bword\\b(..)+\\d{3,7}", 0, b"    word    012", 15), ("\\bword\\b(..)+\\d{3,7}", ONE, b"    word    012", 15),
+            ("\\bword\\b(..)+\\d{3,7}", SOM, b"    word    012", 15),
+            ("eod\\z", 0, b"eod", 3), ("eod\\z", ONE, b"eod", 3), ("eod\\z", SOM, b"eod", 3)]
+    for pat, fl, corpus, match in rows:
+        db = hs.Database.compile([pat] * 100, [fl] * 100, list(range(100)))
+        ev, rv = cpu_scan(db, corpus)
+        assert rv == hs.HS_SUCCESS and len(ev) == 100 and all(t == match for t, _i, _f in ev), (pat, fl)
+        assert sorted(i for _t, i, _f in ev) == list(range(100))
