@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <bitset>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -153,6 +154,30 @@ ByteSet fold_case(const ByteSet &s) {
     return o;
 }
 
+/* [:name:] inside a bracket class (PCRE's set, ASCII semantics) */
+bool posix_class(const std::string &name, ByteSet &s) {
+    auto fill = [&](int (*fn)(int)) {
+        for (unsigned c = 0; c < 128; c++)
+            if (fn((int)c)) s.set(c);
+        return true;
+    };
+    if (name == "alpha") return fill(isalpha);
+    if (name == "digit") return fill(isdigit);
+    if (name == "alnum") return fill(isalnum);
+    if (name == "upper") return fill(isupper);
+    if (name == "lower") return fill(islower);
+    if (name == "space") return fill(isspace);
+    if (name == "blank") { s.set(' '); s.set('\t'); return true; }
+    if (name == "punct") return fill(ispunct);
+    if (name == "print") return fill(isprint);
+    if (name == "graph") return fill(isgraph);
+    if (name == "cntrl") return fill(iscntrl);
+    if (name == "xdigit") return fill(isxdigit);
+    if (name == "ascii") { add_range(s, 0, 127); return true; }
+    if (name == "word") { fill(isalnum); s.set('_'); return true; }
+    return false;
+}
+
 /* "[...]" at p[i]: the class, with i moved past the closing bracket */
 ByteSet parse_bracket_class(const std::string &p, size_t &i) {
     ByteSet cls;
@@ -170,6 +195,17 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i) {
         ByteSet item;
         unsigned lo;
         bool is_class = false;
+        if (p[j] == '[' && j + 1 < p.size() && p[j + 1] == ':') { /* [:alpha:] and friends */
+            const size_t e = p.find(":]", j + 2);
+            if (e == std::string::npos) throw ParseError{"Unterminated POSIX class."};
+            std::string name = p.substr(j + 2, e - j - 2);
+            const bool inv = !name.empty() && name[0] == '^';
+            if (inv) name.erase(0, 1);
+            if (!posix_class(name, item)) throw ParseError{"Unknown POSIX character class."};
+            cls |= inv ? ~item : item;
+            j = e + 2;
+            continue;
+        }
         if (p[j] == '\\') {
             if (j + 1 >= p.size()) throw ParseError{"Trailing backslash."};
             bool ok;
@@ -310,7 +346,8 @@ struct TailBuilder {
         } else {
             return f;
         }
-        if (i < p.size() && (p[i] == '?' || p[i] == '+')) throw ParseError{"Lazy/possessive quantifiers are not supported."};
+        if (i < p.size() && p[i] == '?') i++; /* lazy: every end offset is reported anyway, greed is immaterial */
+        else if (i < p.size() && p[i] == '+') throw ParseError{"Possessive quantifiers are not supported."};
         auto again = [&]() { /* a fresh copy of the atom */
             size_t k = a0;
             Frag c = parse_atom(k, depth);
@@ -360,8 +397,23 @@ struct TailBuilder {
             if (depth > 20) throw ParseError{"Groups nested too deeply."};
             i++;
             if (i + 1 < p.size() && p[i] == '?') {
-                if (p[i + 1] != ':') throw ParseError{"Only plain and (?:...) groups are supported."};
-                i += 2;
+                const char k = p[i + 1];
+                if (k == ':') {
+                    i += 2;
+                } else if (k == '#') { /* (?# comment ) */
+                    const size_t e = p.find(')', i);
+                    if (e == std::string::npos) throw ParseError{"Missing closing parenthesis."};
+                    i = e + 1;
+                    return Frag();
+                } else if ((k == '<' && i + 2 < p.size() && p[i + 2] != '=' && p[i + 2] != '!') || k == '\'' ||
+                           (k == 'P' && i + 2 < p.size() && p[i + 2] == '<')) { /* named group: a plain group here */
+                    const char close = k == '\'' ? '\'' : '>';
+                    const size_t e = p.find(close, i + (k == 'P' ? 3 : 2));
+                    if (e == std::string::npos) throw ParseError{"Unterminated group name."};
+                    i = e + 1;
+                } else {
+                    throw ParseError{"Only plain, named and (?:...) groups are supported."};
+                }
             }
             Frag f = parse_alt(i, depth + 1);
             if (i >= p.size() || p[i] != ')') throw ParseError{"Missing closing parenthesis."};
@@ -445,8 +497,10 @@ LitRun longest_literal_run(const std::string &p) {
         cur = LitRun();
     };
     auto skip_quant = [&](size_t &k) {
+        const size_t k0 = k;
         if (k < p.size() && (p[k] == '?' || p[k] == '*' || p[k] == '+')) k++;
         else if (TailBuilder::is_repeat_at(p, k)) k = p.find('}', k) + 1;
+        if (k != k0 && k < p.size() && (p[k] == '?' || p[k] == '+')) k++; /* lazy / possessive marker */
     };
     size_t i = 0;
     while (i < p.size()) {
@@ -698,7 +752,8 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
                 if (j >= p.size() || p[j] != '}') throw ParseError{"Malformed repeat."};
                 i = j + 1;
             }
-            if (i < p.size() && (p[i] == '?' || p[i] == '+')) throw ParseError{"Lazy/possessive quantifiers are not supported."};
+            if (i < p.size() && p[i] == '?') i++; /* lazy: immaterial, as above */
+            else if (i < p.size() && p[i] == '+') throw ParseError{"Possessive quantifiers are not supported."};
         }
         for (unsigned k = 0; k < lo; k++) pat.tail.push_back(Unit{cls, false, false});
         if (hi == kInf) {
@@ -716,8 +771,24 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
 
 /* expression := branch ('|' branch)* at the top level: every branch is its own literal-prefixed
  * pattern reporting the same id (the reference builds one graph; the reports are the same) */
-std::vector<Pattern> parse_pattern(const std::string &p, unsigned flags, unsigned id) {
+std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsigned id) {
     check_flags(flags, false);
+    /* leading inline options: (?i) (?s) (?m), combined and negated forms */
+    std::string p = expr;
+    while (p.size() >= 4 && p[0] == '(' && p[1] == '?') {
+        size_t k = 2;
+        bool on = true, any = false;
+        unsigned set = 0, clear = 0;
+        for (; k < p.size() && strchr("ims-", p[k]); k++) {
+            if (p[k] == '-') { on = false; continue; }
+            const unsigned f = p[k] == 'i' ? HS_FLAG_CASELESS : p[k] == 's' ? HS_FLAG_DOTALL : HS_FLAG_MULTILINE;
+            (on ? set : clear) |= f;
+            any = true;
+        }
+        if (!any || k >= p.size() || p[k] != ')') break;
+        flags = (flags | set) & ~clear;
+        p.erase(0, k + 1);
+    }
     const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_PREFILTER | HS_FLAG_COMBINATION |
                                  HS_FLAG_QUIET | HS_FLAG_ALLOWEMPTY;
     if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};

@@ -32,15 +32,18 @@
  * (the job of CHECK_MED_LIT / CHECK_LONG_LIT, src/rose/program_runtime.c:2896-2942) and,
  * runs bit-parallel NFAs over the bytes that follow (R2, forwards) and precede (R1, backwards
  * from the literal: the job of Rose's suffix / prefix engines). Supported fragment syntax: literal
- * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes, the quantifiers
- * ? * + {m} {m,} {m,n}, groups `( )` / `(?: )` with alternation inside them, nested and
+ * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes (with [:posix:] names), the
+ * quantifiers ? * + {m} {m,} {m,n} and their lazy forms (every end offset is reported, so greed
+ * is immaterial), leading (?ims-ims) options, groups `( )` / `(?: )` / named / `(?# )` with
+ * alternation inside them, nested and
  * quantified (a fragment compiles to a position automaton of <= 63 positions). Anchors and
  * assertions at the edges of a branch: `^` / \A in front, `$` / \z / \Z at the back (`$` and \Z
  * also before the data's final newline, reported before the newline as the reference does; with
  * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline), and \b / \B at the start,
  * at the end, and directly before or after the literal.
  * Anything else (branches without a mandatory top-level literal, anchors or assertions elsewhere,
- * look-around, back-references, lazy quantifiers, inline flags, streaming / vectored modes) is
+ * look-around, back-references, possessive quantifiers, options after the start, streaming /
+ * vectored modes) is
  * rejected with HS_COMPILER_ERROR:
  * the regex compiler proper is out of scope.
  */

@@ -223,7 +223,7 @@ def test_grouped_tails_match_brute_force():
 
 def test_grouped_tail_compile_errors_and_info():
     import pytest
-    for bad in ["foo(bar", "foo(a))", "foo(a)|", "foo(?=a)", "foo(a*?)", "foo(" + "a?" * 64 + ")"]:
+    for bad in ["foo(bar", "foo(a))", "foo(a)|", "foo(?=a)", "foo(a*+)", "foo(" + "a?" * 64 + ")"]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
     # widths through groups (hs_expression_info): min over alternatives, max = longest, unbounded loops
@@ -399,5 +399,35 @@ def test_word_boundaries_and_absolute_anchors():
     assert {e[1] for e in ev} == set(range(1, 14))
     import pytest
     for bad in [r"c.\bt+x", r"(\bcat)+s", r"a\zb", r"\b", r"cat\b+"]:  # assertions elsewhere are refused
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([bad], [0], [1])
+
+
+def test_lazy_quantifiers_inline_flags_named_groups_posix_classes():
+    """syntax that changes nothing about WHICH end offsets match: lazy quantifiers (every end is
+    reported anyway), leading (?ims-ims) options, named / commented groups, [:posix:] classes"""
+    SOM = hs.HS_FLAG_SOM_LEFTMOST
+    I, S, M = hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL, hs.HS_FLAG_MULTILINE
+    # (expression, flags) as compiled here | (expression, flags) of the same language for Python's re
+    pairs = [((r"foo.+?bar", 0), (r"foo.+bar", 0)), ((r"ab??c*?d{1,2}?e", SOM), (r"ab?c*d{1,2}e", SOM)),
+             ((r"(?i)select\s+\w+", 0), (r"select\s+\w+", I)), ((r"(?is)begin.{0,6}end", 0), (r"begin.{0,6}end", I | S)),
+             ((r"(?-i)Case[a-z]", I), (r"Case[a-z]", 0)), ((r"id=(?<num>\d+);", 0), (r"id=(\d+);", 0)),
+             ((r"id=(?P<n>[a-f]+)(?#hex);", 0), (r"id=([a-f]+);", 0)),
+             ((r"tag[[:digit:][:upper:]]+[[:^alnum:]]", 0), (r"tag[0-9A-Z]+[^0-9A-Za-z]", 0)),
+             ((r"[[:space:]]+key[[:punct:]]", 0), (r"\s+key[!-/:-@\[-`{-~]", 0)), ((r"(?m)^row\d$", 0), (r"^row\d$", M))]
+    exprs = [(h[0], h[1], i + 1) for i, (h, _p) in enumerate(pairs)]
+    pyexprs = [(p[0], p[1], i + 1) for i, (_h, p) in enumerate(pairs)]
+    words = [b"foo", b"bar", b"x", b"ab", b"a", b"b", b"c", b"d", b"e", b"SELECT", b"select", b" ", b"name", b"begin", b"\n", b"END",
+             b"end", b"Case", b"case", b"id=", b"42", b"cafe", b";", b"tag", b"7", b"Q", b"-", b"key", b"=", b"row", b"3"]
+    rng = np.random.default_rng(52)
+    blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 14)))) for _ in range(160)]
+    blocks += [b"fooxbarxbar", b"abccdde abe ade", b"Select  x", b"BEGIN\n\nEnd", b"Casex CASEx", b"id=42;id=cafe;", b"tag7Q-", b" \tkey=",
+               b"row3\nrow4\nrow55\n"]
+    ev = run_exprs_auto(exprs, blocks)
+    want = brute_context(pyexprs, blocks)
+    assert sorted(ev) == sorted(want)
+    assert {e[1] for e in ev} == set(range(1, len(pairs) + 1))
+    import pytest
+    for bad in [r"foo.*+bar", r"foo(?=bar)", r"foo(?<!x)bar", r"(?x)foo", r"foo[[:nope:]]", r"foo(?i)bar"]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
