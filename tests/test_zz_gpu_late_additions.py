@@ -126,3 +126,24 @@ def test_hs_scan_grouped_tails():
             k = data.find(lit, k + 1)
     assert set(got) == want and len(got) == len(want) and len(want) > 200
     assert [t for _i, t in got] == sorted(t for _i, t in got)
+
+
+def test_collider_subset_on_gpu():
+    """the reference's hscollider corpus for the accepted patterns (tests/golden/collider_subset.json,
+    6256 corpus lines with the reference's own expected end offsets) through hs_scan_batch: one
+    database per pattern, its corpora as the blocks of one batch. CPU form: test_collider_cpu.py."""
+    from hyperscan_amd import hs
+    from tests.test_collider_cpu import check_ends, compile_case, load_cases
+
+    n, sc = 0, None
+    for c in load_cases():
+        db, flags = compile_case(c)
+        sc = sc or hs.HsScratch(db)  # a scratch serves every database (it grows on demand)
+        blocks = [bytes.fromhex(h) for h in c["corpora"]]
+        data = np.frombuffer(b"".join(blocks) or b"\0", dtype=np.uint8).copy()
+        off = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.uint64)
+        got = [[] for _ in blocks]
+        assert hs.scan_batch(db, data, off, sc, lambda b, _i, f, t: got[b].append((t, f)) and False) == hs.HS_SUCCESS
+        check_ends(c, flags, got)
+        n += len(blocks)
+    assert n >= 6300
