@@ -11,11 +11,11 @@
  *                        program_runtime.c): CHECK_MED/LONG_LIT = full-literal compare,
  *                        then the tail engine; REPORT -> the user's match_event_handler;
  *                        SINGLEMATCH = the exhaustion vector (src/report.h)
- *   TailNfa::run         the NFA engines Rose triggers after a literal (nfaQueueExec);
- *                        here a bit-parallel position NFA over <= 256 states
- *   TailBuilder /        tails with groups and alternation: a Glushkov position automaton
- *   run_general          (<= 63 positions; the construction of src/nfagraph's position NFA
- *                        in miniature), simulated with one follow-set union per live position
+ *   TailNfa::run64       the NFA engines Rose triggers after a literal (nfaQueueExec):
+ *                        linear tails of <= 63 units as one shift-and word
+ *   TailBuilder / Auto   every other fragment (groups, alternation, long repeats, and R1 in
+ *   run_general/_reverse front of the literal): a Glushkov position automaton of <= 4096
+ *                        positions in LimEx shape (shift + exception rows)
  * Matches are reported as the reference does: `to` = offset after the last byte,
  * `from` = 0 unless HS_FLAG_SOM_LEFTMOST, every distinct (id, to) once, in
  * non-decreasing `to`.
@@ -39,12 +39,35 @@
 namespace {
 
 typedef std::bitset<256> ByteSet;
-constexpr unsigned kMaxStates = 256;
 constexpr unsigned kInf = ~0u;
 
 struct Unit { /* one character class; `star` = may repeat, `optional` = may be skipped */
     ByteSet cls;
     bool optional = false, star = false;
+};
+
+constexpr unsigned long long kInf64 = ~0ull;
+constexpr size_t kMaxPositions = 4096;
+typedef std::vector<unsigned long long> Bits;
+
+/* A regex fragment as a Glushkov position automaton (one position per character-class
+ * occurrence; the construction of src/nfagraph's position NFA in miniature) in the shape of the
+ * reference's LimEx engines (src/nfa/limex_*): most positions are followed by the next one, so
+ *     next = ((cur & shift_ok) << 1) | OR of exc_row[p] for p in cur & exc
+ * -- one shift for the chains, a row per "exceptional" position for everything else. */
+struct Auto {
+    size_t npos = 0, W = 0;       /* positions, 64-bit words per position set */
+    Bits first, last;             /* [W] */
+    Bits reach;                   /* [256][W]: positions accepting byte c */
+    Bits shift_ok, exc;           /* [W] */
+    std::vector<Bits> exc_row;    /* [npos]: follow[p] minus {p+1}; empty unless p is in exc */
+    bool nullable = true;
+    unsigned long long wmin = 0, wmax = 0; /* width bounds; kInf64 = unbounded */
+    size_t bytes() const {
+        size_t n = (first.size() + last.size() + reach.size() + shift_ok.size() + exc.size()) * 8;
+        for (const Bits &r : exc_row) n += r.size() * 8;
+        return n;
+    }
 };
 
 struct Pattern {
@@ -68,22 +91,12 @@ struct Pattern {
     bool fast = false;
     std::vector<unsigned long long> reach; /* [256] */
     unsigned long long star_mask = 0, opt_mask = 0;
-    /* tails with groups / alternation: a Glushkov position automaton (<= 63 positions) instead
-     * of the linear unit list: follow[p] = positions that may come right after position p */
-    bool general = false;
-    std::vector<unsigned long long> follow;
-    unsigned long long first = 0, last = 0;
-    bool g_nullable = false;
-    unsigned long long g_min = 0, g_max = 0; /* tail width bounds; kInf64 = unbounded */
-    /* branches whose literal is not at the front, R1 LIT R2: R1 as a REVERSED position automaton
-     * (run backwards from the literal's first byte), R2 as the general tail above */
-    bool has_pre = false;
-    std::vector<unsigned long long> pre_follow, pre_reach;
-    unsigned long long pre_first = 0, pre_last = 0;
-    bool pre_nullable = false;
-    unsigned long long pre_min = 0, pre_max = 0;
+    /* fragments with groups / alternation / long repeats, and every R1 in front of a literal:
+     * position automata (see Auto). `general`: R2 forwards from the literal's end; `has_pre`: R1
+     * REVERSED, run backwards from the literal's first byte */
+    bool general = false, has_pre = false;
+    Auto g, pre;
 };
-constexpr unsigned long long kInf64 = ~0ull;
 
 struct ParseError {
     std::string msg;
@@ -251,8 +264,19 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i) {
  * tail := alt ; alt := cat ('|' cat)* ; cat := rep* ; rep := atom ('?' | '*' | '+' | {m[,[n]]})?
  * atom := '(' ['?:'] alt ')' | '[' class ']' | '\\' escape | '.' | character
  * Built directly as a Glushkov automaton: every character-class occurrence is a position. */
+/* position sets that grow with the automaton */
+inline void bits_or(Bits &a, const Bits &b) {
+    if (a.size() < b.size()) a.resize(b.size(), 0);
+    for (size_t i = 0; i < b.size(); i++) a[i] |= b[i];
+}
+inline void bits_set(Bits &a, size_t i) {
+    if (a.size() <= i / 64) a.resize(i / 64 + 1, 0);
+    a[i / 64] |= 1ull << (i % 64);
+}
+inline bool bits_test(const Bits &a, size_t i) { return i / 64 < a.size() && (a[i / 64] >> (i % 64) & 1); }
+
 struct Frag {
-    unsigned long long first = 0, last = 0;
+    Bits first, last;
     bool nullable = true;
     unsigned long long wmin = 0, wmax = 0;
 };
@@ -260,27 +284,29 @@ struct Frag {
 struct TailBuilder {
     const std::string &p;
     bool nocase, dotall;
-    std::vector<ByteSet> cls;              /* per position */
-    std::vector<unsigned long long> follow; /* per position */
+    std::vector<ByteSet> cls; /* per position */
+    std::vector<Bits> follow; /* per position */
 
     static unsigned long long add_w(unsigned long long a, unsigned long long b) {
         return (a == kInf64 || b == kInf64) ? kInf64 : a + b;
     }
     unsigned new_pos(const ByteSet &c) {
-        if (cls.size() >= 63) throw ParseError{"Pattern too large."};
+        if (cls.size() >= kMaxPositions) throw ParseError{"Pattern too large."};
         cls.push_back(nocase ? fold_case(c) : c);
-        follow.push_back(0);
+        follow.emplace_back();
         return (unsigned)cls.size() - 1;
     }
-    void link(unsigned long long from_last, unsigned long long to_first) {
-        for (unsigned i = 0; i < follow.size(); i++)
-            if (from_last >> i & 1) follow[i] |= to_first;
+    void link(const Bits &from_last, const Bits &to_first) {
+        for (size_t w = 0; w < from_last.size(); w++)
+            for (unsigned long long m = from_last[w]; m; m &= m - 1) bits_or(follow[w * 64 + __builtin_ctzll(m)], to_first);
     }
     Frag cat(const Frag &a, const Frag &b) {
         link(a.last, b.first);
         Frag r;
-        r.first = a.first | (a.nullable ? b.first : 0);
-        r.last = b.last | (b.nullable ? a.last : 0);
+        r.first = a.first;
+        if (a.nullable) bits_or(r.first, b.first);
+        r.last = b.last;
+        if (b.nullable) bits_or(r.last, a.last);
         r.nullable = a.nullable && b.nullable;
         r.wmin = add_w(a.wmin, b.wmin);
         r.wmax = add_w(a.wmax, b.wmax);
@@ -303,8 +329,8 @@ struct TailBuilder {
         while (i < p.size() && p[i] == '|') {
             i++;
             const Frag b = parse_cat(i, depth);
-            r.first |= b.first;
-            r.last |= b.last;
+            bits_or(r.first, b.first);
+            bits_or(r.last, b.last);
             r.nullable = r.nullable || b.nullable;
             r.wmin = std::min(r.wmin, b.wmin);
             r.wmax = std::max(r.wmax, b.wmax);
@@ -448,39 +474,68 @@ struct TailBuilder {
         }
         const unsigned pos = new_pos(set);
         Frag f;
-        f.first = f.last = 1ull << pos;
+        bits_set(f.first, pos);
+        bits_set(f.last, pos);
         f.nullable = false;
         f.wmin = f.wmax = 1;
         return f;
     }
 };
 
-/* a whole regex fragment as a position automaton */
-struct Auto {
-    std::vector<unsigned long long> follow, reach;
-    unsigned long long first = 0, last = 0, wmin = 0, wmax = 0;
-    bool nullable = true;
-    size_t npos = 0;
-};
+/* builder output -> the runtime form; `reversed`: the automaton of the reversed language, with
+ * the positions renumbered back to front so that its chains are left shifts again */
+Auto finish_auto(const TailBuilder &tb, const Frag &f, bool reversed) {
+    Auto a;
+    const size_t n = tb.cls.size(), W = (n + 63) / 64;
+    a.npos = n;
+    a.W = W;
+    a.nullable = f.nullable;
+    a.wmin = f.wmin;
+    a.wmax = f.wmax;
+    if (!n) return a;
+    auto idx = [&](size_t p) { return reversed ? n - 1 - p : p; };
+    std::vector<Bits> follow(n, Bits(W, 0));
+    for (size_t x = 0; x < n; x++)
+        for (size_t y = 0; y < n; y++)
+            if (bits_test(tb.follow[x], y)) {
+                if (reversed) bits_set(follow[idx(y)], idx(x));
+                else bits_set(follow[x], y);
+            }
+    a.first.assign(W, 0);
+    a.last.assign(W, 0);
+    for (size_t x = 0; x < n; x++) {
+        if (bits_test(f.first, x)) bits_set(reversed ? a.last : a.first, idx(x));
+        if (bits_test(f.last, x)) bits_set(reversed ? a.first : a.last, idx(x));
+    }
+    a.reach.assign(256 * W, 0);
+    for (size_t x = 0; x < n; x++)
+        for (unsigned c = 0; c < 256; c++)
+            if (tb.cls[x][c]) a.reach[c * W + idx(x) / 64] |= 1ull << (idx(x) % 64);
+    a.shift_ok.assign(W, 0);
+    a.exc.assign(W, 0);
+    a.exc_row.assign(n, Bits());
+    for (size_t x = 0; x < n; x++) {
+        Bits row = follow[x];
+        if (x + 1 < n && bits_test(row, x + 1)) {
+            bits_set(a.shift_ok, x);
+            row[(x + 1) / 64] &= ~(1ull << ((x + 1) % 64));
+        }
+        bool any = false;
+        for (unsigned long long w : row) any |= w != 0;
+        if (any) {
+            bits_set(a.exc, x);
+            a.exc_row[x] = row;
+        }
+    }
+    return a;
+}
 
-Auto compile_auto(const std::string &src, bool nocase, bool dotall) {
+Auto compile_auto(const std::string &src, bool nocase, bool dotall, bool reversed = false) {
     TailBuilder tb{src, nocase, dotall, {}, {}};
     size_t i = 0;
     const Frag f = tb.parse_cat(i, 0);
     if (i < src.size()) throw ParseError{"Unmatched closing parenthesis."};
-    Auto a;
-    a.follow = tb.follow;
-    a.first = f.first;
-    a.last = f.last;
-    a.nullable = f.nullable;
-    a.wmin = f.wmin;
-    a.wmax = f.wmax;
-    a.npos = tb.cls.size();
-    a.reach.assign(256, 0);
-    for (size_t k = 0; k < tb.cls.size(); k++)
-        for (unsigned c = 0; c < 256; c++)
-            if (tb.cls[k][c]) a.reach[c] |= 1ull << k;
-    return a;
+    return finish_auto(tb, f, reversed);
 }
 
 /* the longest run of plain characters at the top level of a branch (not inside a group or a
@@ -638,33 +693,11 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     size_t i = r2_begin;
     if (r1_end != 0) {
         /* the literal is not at the front: R1 backwards, R2 as a position automaton */
-        const Auto r1 = compile_auto(p.substr(0, r1_end), pat.nocase, dotall);
-        const Auto r2 = compile_auto(p.substr(r2_begin), pat.nocase, dotall);
-        if (r1.npos) {
-            /* reversed: first <-> last, follow transposed */
-            pat.has_pre = true;
-            pat.pre_first = r1.last;
-            pat.pre_last = r1.first;
-            pat.pre_nullable = r1.nullable;
-            pat.pre_min = r1.wmin;
-            pat.pre_max = r1.wmax;
-            pat.pre_reach = r1.reach;
-            pat.pre_follow.assign(r1.npos, 0);
-            for (size_t a = 0; a < r1.npos; a++)
-                for (size_t b = 0; b < r1.npos; b++)
-                    if (r1.follow[a] >> b & 1) pat.pre_follow[b] |= 1ull << a;
-        }
-        if (r2.npos) {
-            pat.general = true;
-            pat.follow = r2.follow;
-            pat.first = r2.first;
-            pat.last = r2.last;
-            pat.g_nullable = r2.nullable;
-            pat.g_min = r2.wmin;
-            pat.g_max = r2.wmax;
-            pat.reach = r2.reach;
-        }
-        pat.tail_nullable = r2.nullable;
+        pat.pre = compile_auto(p.substr(0, r1_end), pat.nocase, dotall, true);
+        pat.g = compile_auto(p.substr(r2_begin), pat.nocase, dotall);
+        pat.has_pre = pat.pre.npos != 0;
+        pat.general = pat.g.npos != 0;
+        pat.tail_nullable = pat.g.nullable;
         return pat;
     }
     /* a tail with a group in it goes to the position automaton; the linear form below stays the
@@ -676,27 +709,12 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
         else if (p[k] == '(') grouped = true;
     }
     if (grouped) {
-        TailBuilder tb{p, pat.nocase, dotall, {}, {}};
-        const Frag f = tb.parse_cat(i, 0);
-        if (i < p.size())
-            throw ParseError{p[i] == '|' ? "Top-level alternation is not supported (no common literal prefix)."
-                                         : "Unmatched closing parenthesis."};
-        if (!tb.cls.empty()) {
-            pat.general = true;
-            pat.follow = tb.follow;
-            pat.first = f.first;
-            pat.last = f.last;
-            pat.g_nullable = f.nullable;
-            pat.g_min = f.wmin;
-            pat.g_max = f.wmax;
-            pat.reach.assign(256, 0);
-            for (size_t k = 0; k < tb.cls.size(); k++)
-                for (unsigned c = 0; c < 256; c++)
-                    if (tb.cls[k][c]) pat.reach[c] |= 1ull << k;
-        }
-        pat.tail_nullable = f.nullable;
+        pat.g = compile_auto(p.substr(i), pat.nocase, dotall);
+        pat.general = pat.g.npos != 0;
+        pat.tail_nullable = pat.g.nullable;
         return pat;
     }
+    const size_t tail_begin = i;
     /* tail */
     while (i < p.size()) {
         ByteSet cls;
@@ -762,7 +780,13 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
         } else {
             for (unsigned k = lo; k < hi; k++) pat.tail.push_back(Unit{cls, true, false});
         }
-        if (pat.tail.size() > kMaxStates - 1) throw ParseError{"Pattern too large."};
+        if (pat.tail.size() > 63) { /* too long for one shift-and word: the position automaton takes it */
+            pat.tail.clear();
+            pat.g = compile_auto(p.substr(tail_begin), pat.nocase, dotall);
+            pat.general = true;
+            pat.tail_nullable = pat.g.nullable;
+            return pat;
+        }
     }
     pat.tail_nullable = true;
     for (const Unit &u : pat.tail) pat.tail_nullable &= u.optional;
@@ -829,33 +853,9 @@ inline bool assert_ok(unsigned char kind, const unsigned char *buf, size_t len, 
 
 /* simulation of the linear NFA: state i = "units 0..i-1 consumed" */
 struct TailNfa {
-    typedef std::bitset<kMaxStates> States;
-    static States closure(const std::vector<Unit> &u, States s) {
-        for (size_t i = 0; i < u.size(); i++)
-            if (s[i] && u[i].optional) s.set(i + 1);
-        return s;
-    }
-    /* calls report(to) for every offset after which the tail has matched */
-    template <class F> static void run(const std::vector<Unit> &u, const unsigned char *buf, size_t len, size_t pos, F report) {
-        States cur;
-        cur.set(0);
-        cur = closure(u, cur);
-        const size_t S = u.size();
-        if (cur[S]) { if (!report(pos)) return; }
-        while (pos < len && cur.any()) {
-            const unsigned char c = buf[pos++];
-            States nxt;
-            for (size_t i = 0; i < S; i++)
-                if (cur[i] && u[i].cls[c]) {
-                    nxt.set(i + 1);
-                    if (u[i].star) nxt.set(i);
-                }
-            cur = closure(u, nxt);
-            if (cur[S]) { if (!report(pos)) return; }
-        }
-    }
-    /* the same automaton, bit-parallel (shift-and) in one 64-bit word: per input byte
-     * one table read, a shift, and the optional-unit closure (skipping unit i = bit i -> i+1) */
+    /* the linear tail, bit-parallel (shift-and) in one 64-bit word: state i = "units 0..i-1
+     * consumed"; per input byte one table read, a shift, and the optional-unit closure (skipping
+     * unit i = bit i -> i+1). Calls report(to) for every offset after which the tail has matched. */
     static unsigned long long closure64(unsigned long long s, unsigned long long opt) {
         for (unsigned long long add; (add = ((s & opt) << 1) & ~s) != 0;) s |= add;
         return s;
@@ -870,42 +870,101 @@ struct TailNfa {
             if (cur & accept) { if (!report(pos)) return; }
         }
     }
-    /* the position automaton of a grouped tail: the active set after byte c is
-     * (first | follow[active]) & reach[c]; a match ends wherever the set meets `last` */
-    template <class F> static void run_general(const Pattern &p, const unsigned char *buf, size_t len, size_t pos, F report) {
-        if (p.g_nullable) { if (!report(pos)) return; }
-        unsigned long long next = p.first;
-        while (pos < len && next) {
-            unsigned long long cur = next & p.reach[buf[pos++]];
-            if (cur & p.last) { if (!report(pos)) return; }
-            next = 0;
-            for (; cur; cur &= cur - 1) next |= p.follow[__builtin_ctzll(cur)];
+
+    /* one step of a position automaton (Auto): cur = positions that consumed the last byte */
+    static constexpr size_t kMaxW = kMaxPositions / 64;
+    static inline unsigned long long step1(const Auto &a, unsigned long long cur) {
+        unsigned long long next = (cur & a.shift_ok[0]) << 1;
+        for (unsigned long long e = cur & a.exc[0]; e; e &= e - 1) next |= a.exc_row[__builtin_ctzll(e)][0];
+        return next;
+    }
+    static inline void step(const Auto &a, const unsigned long long *cur, unsigned long long *next) {
+        const size_t W = a.W;
+        unsigned long long carry = 0;
+        for (size_t w = 0; w < W; w++) {
+            const unsigned long long v = cur[w] & a.shift_ok[w];
+            next[w] = (v << 1) | carry;
+            carry = v >> 63;
+        }
+        for (size_t w = 0; w < W; w++)
+            for (unsigned long long e = cur[w] & a.exc[w]; e; e &= e - 1) {
+                const Bits &row = a.exc_row[w * 64 + __builtin_ctzll(e)];
+                for (size_t k = 0; k < W; k++) next[k] |= row[k];
+            }
+    }
+    /* cur = next & reach[c]; returns whether anything is live, *acc whether `last` was met */
+    static inline bool advance(const Auto &a, unsigned char c, const unsigned long long *next, unsigned long long *cur, bool *acc) {
+        const unsigned long long *r = &a.reach[(size_t)c * a.W];
+        unsigned long long any = 0, hit = 0;
+        for (size_t w = 0; w < a.W; w++) {
+            cur[w] = next[w] & r[w];
+            any |= cur[w];
+            hit |= cur[w] & a.last[w];
+        }
+        *acc = hit != 0;
+        return any != 0;
+    }
+
+    /* R2 forwards from `pos`: the active set after byte c is (first | follow[active]) & reach[c];
+     * a match ends wherever the set meets `last` */
+    template <class F> static void run_general(const Auto &a, const unsigned char *buf, size_t len, size_t pos, F report) {
+        if (a.nullable) { if (!report(pos)) return; }
+        if (a.W == 1) {
+            unsigned long long next = a.first[0];
+            while (pos < len && next) {
+                const unsigned long long cur = next & a.reach[buf[pos++]];
+                if (cur & a.last[0]) { if (!report(pos)) return; }
+                next = step1(a, cur);
+            }
+            return;
+        }
+        unsigned long long cur[kMaxW], next[kMaxW];
+        std::copy(a.first.begin(), a.first.end(), next);
+        bool acc;
+        while (pos < len && advance(a, buf[pos++], next, cur, &acc)) {
+            if (acc) { if (!report(pos)) return; }
+            step(a, cur, next);
         }
     }
-    /* R1 backwards from the literal's first byte: is there a `from` with buf[from, start) in R1
-     * (and, for `^`, a line start at `from`)? leftmost = keep going for the smallest one */
+    /* R1 backwards from the literal's first byte (the automaton is the reversed one): is there a
+     * `from` with buf[from, start) in R1 (and, for `^`, a line start at `from`)? leftmost = keep
+     * going for the smallest one */
     static bool run_reverse(const Pattern &p, const unsigned char *buf, size_t len, size_t start, bool leftmost,
                             size_t &from) {
+        const Auto &a = p.pre;
         auto at_bol = [&](size_t pos) {
             return (!p.bol || pos == 0 || (p.bol_ml && buf[pos - 1] == '\n')) && assert_ok(p.as_start, buf, len, pos);
         };
         bool found = false;
-        if (p.pre_nullable && at_bol(start)) {
+        if (a.nullable && at_bol(start)) {
             found = true;
             from = start;
             if (!leftmost) return true;
         }
-        unsigned long long next = p.pre_first;
         size_t pos = start;
-        while (pos > 0 && next) {
-            unsigned long long cur = next & p.pre_reach[buf[--pos]];
-            if ((cur & p.pre_last) && at_bol(pos)) {
+        if (a.W == 1) {
+            unsigned long long next = a.first[0];
+            while (pos > 0 && next) {
+                const unsigned long long cur = next & a.reach[buf[--pos]];
+                if ((cur & a.last[0]) && at_bol(pos)) {
+                    found = true;
+                    from = pos;
+                    if (!leftmost) return true;
+                }
+                next = step1(a, cur);
+            }
+            return found;
+        }
+        unsigned long long cur[kMaxW], next[kMaxW];
+        std::copy(a.first.begin(), a.first.end(), next);
+        bool acc;
+        while (pos > 0 && advance(a, buf[--pos], next, cur, &acc)) {
+            if (acc && at_bol(pos)) {
                 found = true;
                 from = pos;
                 if (!leftmost) return true;
             }
-            next = 0;
-            for (; cur; cur &= cur - 1) next |= p.pre_follow[__builtin_ctzll(cur)];
+            step(a, cur, next);
         }
         return found;
     }
@@ -913,7 +972,7 @@ struct TailNfa {
 
 void finish_pattern(Pattern &p) {
     if (p.general) return;
-    p.fast = !p.tail.empty() && p.tail.size() <= 63;
+    p.fast = !p.tail.empty(); /* parse_branch keeps linear tails to <= 63 units */
     if (!p.fast) return;
     p.reach.assign(256, 0);
     for (size_t i = 0; i < p.tail.size(); i++) {
@@ -1090,8 +1149,8 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
             lits[i].groups = HSGPU_ALL_GROUPS;
             size_t w = p.lit.size();
             for (const Unit &u : p.tail) w += u.optional ? 0 : 1;
-            if (p.general) w += p.g_min;
-            if (p.has_pre) w += p.pre_min;
+            if (p.general) w += p.g.wmin;
+            if (p.has_pre) w += p.pre.wmin;
             d->min_width = std::min(d->min_width, w);
         }
         int rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
@@ -1179,7 +1238,7 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
             return true;
         };
         if (p.general) {
-            TailNfa::run_general(p, buf, len, lit_end, [&](size_t to) {
+            TailNfa::run_general(p.g, buf, len, lit_end, [&](size_t to) {
                 if (in_bounds(to)) out.push_back(Event{to, from, p.id});
                 return true;
             });
@@ -1190,8 +1249,7 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
                 if (in_bounds(to)) out.push_back(Event{to, from, p.id});
                 return true;
             };
-            if (p.fast) TailNfa::run64(p, buf, len, lit_end, on_to);
-            else TailNfa::run(p.tail, buf, len, lit_end, on_to);
+            TailNfa::run64(p, buf, len, lit_end, on_to);
         }
     }
     std::sort(out.begin() + base, out.end());
@@ -1337,7 +1395,7 @@ hs_error_t hs_free_database(hs_database_t *db) {
 hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
     if (!db || !size || db->magic != 0x48534744) return HS_INVALID;
     size_t s = sizeof(*db) + hsgpu_hwlm_size(db->hwlm);
-    for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit) + (p.follow.size() + p.reach.size() + p.pre_follow.size() + p.pre_reach.size()) * 8;
+    for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit) + p.reach.size() * 8 + p.g.bytes() + p.pre.bytes();
     *size = s;
     return HS_SUCCESS;
 }
@@ -1548,14 +1606,14 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
             inf |= u.star;
         }
         if (p.general) {
-            lo += p.g_min;
-            inf = p.g_max == kInf64;
-            if (!inf) hi += p.g_max;
+            lo += p.g.wmin;
+            inf = p.g.wmax == kInf64;
+            if (!inf) hi += p.g.wmax;
         }
         if (p.has_pre) {
-            lo += p.pre_min;
-            inf |= p.pre_max == kInf64;
-            if (p.pre_max != kInf64) hi += p.pre_max;
+            lo += p.pre.wmin;
+            inf |= p.pre.wmax == kInf64;
+            if (p.pre.wmax != kInf64) hi += p.pre.wmax;
         }
         if (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) lo = std::max(lo, p.min_length);
         if (p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) {

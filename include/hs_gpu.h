@@ -36,7 +36,8 @@
  * quantifiers ? * + {m} {m,} {m,n} and their lazy forms (every end offset is reported, so greed
  * is immaterial), leading (?ims-ims) options, groups `( )` / `(?: )` / named / `(?# )` with
  * alternation inside them, nested and
- * quantified (a fragment compiles to a position automaton of <= 63 positions). Anchors and
+ * quantified (a fragment compiles to a position automaton of <= 4096 positions, run LimEx-style:
+ * one shift for the chains, exception rows for the rest). Anchors and
  * assertions at the edges of a branch: `^` / \A in front, `$` / \z / \Z at the back (`$` and \Z
  * also before the data's final newline, reported before the newline as the reference does; with
  * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline), and \b / \B at the start,

@@ -223,7 +223,7 @@ def test_grouped_tails_match_brute_force():
 
 def test_grouped_tail_compile_errors_and_info():
     import pytest
-    for bad in ["foo(bar", "foo(a))", "foo(a)|", "foo(?=a)", "foo(a*+)", "foo(" + "a?" * 64 + ")"]:
+    for bad in ["foo(bar", "foo(a))", "foo(a)|", "foo(?=a)", "foo(a*+)", "foo(" + "a?" * 4097 + ")", "foo.{4097}x"]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
     # widths through groups (hs_expression_info): min over alternatives, max = longest, unbounded loops
@@ -369,9 +369,11 @@ def brute_context(exprs, blocks):
             py = pat.replace("\\Z", "(?=\\n?\\Z)").replace("\\z", "\\Z")
             for to in range(len(data) + 1):
                 rx = re.compile(("(?:%s)(?=[\\s\\S]{%d}\\Z)" % (py, len(data) - to)).encode("latin-1"), rf)
-                froms = [f for f in range(to) if rx.match(data, f)]
-                if froms:
-                    out.append((b, pid, min(froms) if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, to))
+                m = rx.search(data)  # the leftmost start that can end at `to`
+                if m and m.start() == to:  # (an empty match there is no match: look further left is moot)
+                    m = None
+                if m:
+                    out.append((b, pid, m.start() if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, to))
     return out
 
 
@@ -431,3 +433,30 @@ def test_lazy_quantifiers_inline_flags_named_groups_posix_classes():
     for bad in [r"foo.*+bar", r"foo(?=bar)", r"foo(?<!x)bar", r"(?x)foo", r"foo[[:nope:]]", r"foo(?i)bar"]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
+
+
+def test_wide_position_automata():
+    """fragments of more than 63 positions (several 64-bit words per position set; chains by
+    shift, the rest through exception rows), forwards and reversed"""
+    S, SOM = hs.HS_FLAG_DOTALL, hs.HS_FLAG_SOM_LEFTMOST
+    exprs = [(r"^foo.{64}b(a?)r", S, 1), (r"foo.{100,120}bar", S, 2), (r"[a-z]{70}END", SOM, 3), (r"(ab|cd){40}x", 0, 4),
+             (r"\d{70,}:8080", SOM, 5), (r"(x|yz){35}end(ing)?", 0, 6), (r"key(=[a-f]{2}){33}", 0, 7), (r"a.{200}b", S, 8),
+             (r"q[ab]{0,70}q", 0, 9)]
+    rng = np.random.default_rng(61)
+
+    def rnd(alpha, n):
+        return bytes(rng.choice(np.frombuffer(alpha, np.uint8), n))
+
+    blocks = [b"foo" + rnd(b"xyz\n", 64) + b"bar" + b"foo" + rnd(b"xy", 64) + b"br", b"xfoo" + rnd(b"xyz", 64) + b"bar",
+              b"foo" + rnd(b"abr", 130) + b"bar", b"foo" + rnd(b"a", 99) + b"bar", b"foo" + rnd(b"a", 121) + b"bar",
+              rnd(b"abcxyz", 90) + b"END", rnd(b"abc", 69) + b"END", rnd(b"abc", 40) + b"1" + rnd(b"abc", 70) + b"END",
+              b"".join([b"ab", b"cd"][int(i)] for i in rng.integers(0, 2, 47)) + b"x", b"ab" * 39 + b"x", b"ab" * 40 + b"y" + b"cd" * 40 + b"x",
+              rnd(b"0123456789", 85) + b":8080", rnd(b"0123456789", 69) + b":8080",
+              b"".join([b"x", b"yz"][int(i)] for i in rng.integers(0, 2, 44)) + b"ending", b"yz" * 34 + b"end",
+              b"key" + b"".join(b"=" + rnd(b"abcdef", 2) for _ in range(36)), b"key" + b"=ab" * 32 + b"=a",
+              b"a" * 150 + rnd(b"ab\n", 120) + b"b" * 5, b"q" + rnd(b"ab", 70) + b"q" + rnd(b"ab", 30) + b"q", b"q" + b"a" * 71 + b"q", b"qq"]
+    ev = run_exprs_auto(exprs, blocks)
+    want = brute_context(exprs, blocks)
+    assert sorted(ev) == sorted(want)
+    assert {e[1] for e in ev} == set(range(1, 10))
+    assert hs.expression_info(r"^foo.{600}bar") == (606, 606) and hs.expression_info(r"[a-z]{70,}END") == (73, 0xffffffff)
