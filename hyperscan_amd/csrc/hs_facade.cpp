@@ -1085,8 +1085,8 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         mode_err = "Invalid parameter: the HS_MODE_SOM_HORIZON_ mode flags may only be set in streaming mode.";
     else if ((mode & som_modes) & ((mode & som_modes) - 1))
         mode_err = "Invalid parameter: only one HS_MODE_SOM_HORIZON_ mode flag can be set.";
-    else if (mode != HS_MODE_BLOCK)
-        mode_err = "Only HS_MODE_BLOCK is supported by the GPU literal engine.";
+    else if (mode != HS_MODE_BLOCK && mode != HS_MODE_VECTORED)
+        mode_err = "Only HS_MODE_BLOCK and HS_MODE_VECTORED are supported by the GPU literal engine.";
     if (mode_err) {
         *error = make_error(mode_err, -1);
         return HS_COMPILER_ERROR;
@@ -1164,6 +1164,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         *error = make_error("Unable to allocate memory.", -1);
         return HS_COMPILER_ERROR;
     }
+    d->mode = mode;
     d->sources = exprs;
     d->src_is_lit = is_lit;
     for (size_t i = 0; i < exprs.size(); i++) {
@@ -1403,7 +1404,8 @@ hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
 hs_error_t hs_database_info(const hs_database_t *db, char **info) {
     if (!db || !info || db->magic != 0x48534744) return HS_INVALID;
     char buf[160];
-    snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: BLOCK", hs_version());
+    snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: %s", hs_version(),
+             db->mode == HS_MODE_VECTORED ? "VECTORED" : "BLOCK");
     *info = misc_strdup(buf);
     if (hs_error_t ae = check_alloc(*info)) {
         hook_free(g_misc, *info);
@@ -1414,11 +1416,12 @@ hs_error_t hs_database_info(const hs_database_t *db, char **info) {
 }
 
 /* serialised form: magic "HSGF", CRC-32 of everything after it, count, then per pattern
- * {is_lit, flags, id, len, ext flags, min_offset, max_offset, min_length, bytes} -- the
+ * (top bit: vectored mode) {is_lit, flags, id, len, ext flags, min_offset, max_offset, min_length, bytes} -- the
  * database is rebuilt from its sources on load (compilation is cheap for this engine; the
  * GPU table is rebuilt with it). The reference guards its bytecode with a CRC too
  * (src/database.c:119-168): a damaged blob is HS_INVALID, never a different database. */
 static const unsigned kSerialMagic = 0x48534746;
+static const unsigned kSerialVectored = 0x80000000u; /* top bit of the count word: HS_MODE_VECTORED */
 
 static unsigned crc32_of(const unsigned char *p, size_t n) {
     static unsigned table[256];
@@ -1443,7 +1446,7 @@ hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *
     auto put64 = [&](unsigned long long v) { out.append((const char *)&v, 8); };
     put32(kSerialMagic);
     put32(0); /* CRC, filled in below */
-    put32((unsigned)db->sources.size());
+    put32((unsigned)db->sources.size() | (db->mode == HS_MODE_VECTORED ? kSerialVectored : 0));
     for (size_t i = 0; i < db->sources.size(); i++) {
         put32(db->src_is_lit[i]);
         put32(db->src_flags[i]);
@@ -1474,6 +1477,7 @@ struct Serial {
     std::vector<unsigned char> is_lit;
     std::vector<unsigned> flags, ids;
     std::vector<hs_expr_ext_t> ext;
+    unsigned mode = HS_MODE_BLOCK;
 };
 hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
     if (!bytes) return HS_INVALID;
@@ -1497,7 +1501,10 @@ hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
     if (magic != kSerialMagic || !get32(crc) || length < 12 ||
         crc != crc32_of((const unsigned char *)bytes + 8, length - 8))
         return HS_INVALID;
-    if (!get32(n) || n == 0) return HS_INVALID;
+    if (!get32(n)) return HS_INVALID;
+    if (n & kSerialVectored) out.mode = HS_MODE_VECTORED;
+    n &= ~kSerialVectored;
+    if (n == 0) return HS_INVALID;
     for (unsigned i = 0; i < n; i++) {
         unsigned l, f, id, len;
         hs_expr_ext_t e;
@@ -1524,7 +1531,7 @@ hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_da
     std::vector<const hs_expr_ext_t *> ext;
     for (const hs_expr_ext_t &e : sr.ext) ext.push_back(e.flags ? &e : nullptr);
     hs_compile_error_t *err = nullptr;
-    hs_error_t rv = build_database(sr.ex, sr.is_lit, sr.flags.data(), sr.ids.data(), ext.data(), HS_MODE_BLOCK, db, &err);
+    hs_error_t rv = build_database(sr.ex, sr.is_lit, sr.flags.data(), sr.ids.data(), ext.data(), sr.mode, db, &err);
     hs_free_compile_error(err);
     return rv == HS_SUCCESS ? HS_SUCCESS : HS_INVALID;
 }
@@ -1548,7 +1555,8 @@ hs_error_t hs_serialized_database_info(const char *bytes, size_t length, char **
     Serial sr;
     if (hs_error_t rv = parse_serial(bytes, length, sr)) return rv;
     char buf[160];
-    snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: BLOCK", hs_version());
+    snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: %s", hs_version(),
+             sr.mode == HS_MODE_VECTORED ? "VECTORED" : "BLOCK");
     *info = misc_strdup(buf);
     if (hs_error_t ae = check_alloc(*info)) {
         hook_free(g_misc, *info);
@@ -1754,6 +1762,10 @@ static bool confirm_and_deliver(const hs_database *db, const char *data, const u
     return any_terminated;
 }
 
+static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const unsigned long long *off,
+                              unsigned long long nblocks, hs_scratch_t *scratch, hs_batch_event_handler onEvent,
+                              void *context);
+
 hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
                          unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
                          hs_batch_event_handler onEvent, void *context) {
@@ -1761,6 +1773,12 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
     if (!scratch || !data || !off) return HS_INVALID;
     if (!db || db->magic != 0x48534744) return HS_INVALID;
     if (db->mode != HS_MODE_BLOCK) return HS_DB_MODE_ERROR;
+    return scan_blocks(db, data, off, nblocks, scratch, onEvent, context);
+}
+
+static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const unsigned long long *off,
+                              unsigned long long nblocks, hs_scratch_t *scratch, hs_batch_event_handler onEvent,
+                              void *context) {
     if (scratch->magic != 0x48534753) return HS_INVALID;
     if (scratch->in_use) return HS_SCRATCH_IN_USE;
     scratch->in_use = true;
@@ -1836,6 +1854,35 @@ hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int lengt
                                        unsigned fl, void *cc) { return ((Ctx *)cc)->cb(id, from, to, fl, ((Ctx *)cc)->user); }
                                  : (hs_batch_event_handler) nullptr,
                          &c);
+}
+
+/* src/runtime.c:1106-1174 hs_scan_vector: the segments are one logical buffer (offsets run
+ * through them). Here they are gathered into one block and scanned as such -- on this engine a
+ * vectored scan IS a block scan of the concatenation, so the semantics hold by construction. */
+hs_error_t hs_scan_vector(const hs_database_t *db, const char *const *data, const unsigned int *length,
+                          unsigned int count, unsigned int flags, hs_scratch_t *scratch, match_event_handler onEvent,
+                          void *context) {
+    (void)flags;
+    if (!scratch || !data || !length) return HS_INVALID; /* src/runtime.c:1113-1115 */
+    if (!db || db->magic != 0x48534744) return HS_INVALID;
+    if (db->mode != HS_MODE_VECTORED) return HS_DB_MODE_ERROR;
+    if (scratch->magic != 0x48534753) return HS_INVALID;
+    unsigned long long total = 0;
+    for (unsigned i = 0; i < count; i++) {
+        if (length[i] && !data[i]) return HS_INVALID;
+        total += length[i];
+    }
+    if (total < db->min_width) return scratch->in_use ? HS_SCRATCH_IN_USE : HS_SUCCESS;
+    std::string joined;
+    joined.reserve((size_t)total);
+    for (unsigned i = 0; i < count; i++) joined.append(data[i], length[i]);
+    struct Ctx { match_event_handler cb; void *user; } c{onEvent, context};
+    const unsigned long long off[2] = {0, total};
+    return scan_blocks(db, joined.data(), off, 1, scratch,
+                       onEvent ? +[](unsigned long long, unsigned id, unsigned long long from, unsigned long long to,
+                                     unsigned fl, void *cc) { return ((Ctx *)cc)->cb(id, from, to, fl, ((Ctx *)cc)->user); }
+                               : (hs_batch_event_handler) nullptr,
+                       &c);
 }
 
 int hs_batch_count_handler(unsigned long long, unsigned int, unsigned long long, unsigned long long, unsigned int,

@@ -198,6 +198,19 @@ def scan(db, data, scratch, on_event=None):
     return _lib().hs_scan(db._h, buf.ctypes.data if buf.size else b"", buf.size, 0, scratch._h, cb, None)
 
 
+def scan_vector(db, segments, scratch, on_event=None):
+    """hs_scan_vector over a list of bytes-like segments"""
+    n = len(segments)
+    keep = [bytes(s) for s in segments]
+    arr = (C.c_char_p * n)(*keep)
+    lens = (C.c_uint * n)(*[len(s) for s in keep])
+    cb = MATCH_CB(lambda i, f, t, _fl, _c: 1 if (on_event and on_event(i, f, t)) else 0)
+    lib = _lib()
+    lib.hs_scan_vector.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.c_uint, C.c_uint, C.c_void_p, MATCH_CB,
+                                   C.c_void_p]
+    return lib.hs_scan_vector(db._h, arr, lens, n, 0, scratch._h, cb, None)
+
+
 def scan_batch(db, data, off, scratch, on_event=None):
     buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
     off = np.ascontiguousarray(off, dtype=np.uint64)

@@ -19,9 +19,10 @@
  *   hs_populate_platform                     src/hs_compile.h:833
  *   hs_serialized_database_size / _info      src/hs_common.h:196-271
  *   hs_set_allocator / hs_set_{database,misc,scratch,stream}_allocator  src/hs_common.h:273-439
- * Not provided (no block-mode literal-engine meaning): streaming and vectored scans
- * (the hs_open_stream family, hs_scan_vector) and the in-place hs_deserialize_database_at: the
- * database object owns heap containers, so it cannot live in caller memory.
+ *   hs_scan_vector (HS_MODE_VECTORED)        src/hs_runtime.h:480-527, src/runtime.c:1106-1174
+ * Not provided: streaming scans (the hs_open_stream family: the literal path this engine
+ * replaces is block-shaped) and the in-place hs_deserialize_database_at:
+ * the database object owns heap containers, so it cannot live in caller memory.
  *
  * What is behind it: an expression is one or more top-level branches `b1|b2|...`, and every
  * branch must contain a mandatory literal (>= 1 byte) at its top level: R1 LIT R2, where R1 and
@@ -43,8 +44,8 @@
  * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline), and \b / \B at the start,
  * at the end, and directly before or after the literal.
  * Anything else (branches without a mandatory top-level literal, anchors or assertions elsewhere,
- * look-around, back-references, possessive quantifiers, options after the start, streaming /
- * vectored modes) is
+ * look-around, back-references, possessive quantifiers, options after the start, streaming
+ * mode) is
  * rejected with HS_COMPILER_ERROR:
  * the regex compiler proper is out of scope.
  */
@@ -194,6 +195,13 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch);
 
 hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsigned int flags,
                    hs_scratch_t *scratch, match_event_handler onEvent, void *context);
+
+/* Vectored mode: the `count` segments are one logical buffer; offsets run through them. The
+ * database must have been compiled with HS_MODE_VECTORED (HS_DB_MODE_ERROR otherwise, and
+ * hs_scan on a vectored database likewise). */
+hs_error_t hs_scan_vector(const hs_database_t *db, const char *const *data, const unsigned int *length,
+                          unsigned int count, unsigned int flags, hs_scratch_t *scratch, match_event_handler onEvent,
+                          void *context);
 
 /* Extension (no reference equivalent): scan nblocks independent blocks
  * data[off[i] .. off[i+1]) in one GPU batch; events carry the block index. A non-zero

@@ -544,3 +544,32 @@ def test_headers_are_valid_c_and_the_example_links(tmp_path):
     # without a pattern argument the example prints its usage and fails before touching a device
     r = subprocess.run([str(tmp_path / "simplegrep")], capture_output=True, text=True)
     assert r.returncode != 0 and "sage" in (r.stdout + r.stderr)
+
+
+def test_vectored_mode_without_gpu():
+    """HS_MODE_VECTORED compiles, survives serialisation, names itself in the info string, and the
+    scan entry points insist on the matching mode before touching a device
+    (src/runtime.c:343-345,1127-1129)."""
+    from hyperscan_amd import hs
+
+    lib = hs._lib()
+    vdb = hs.Database.compile(["^foo.*bar"], [hs.HS_FLAG_DOTALL], [0], mode=hs.HS_MODE_VECTORED)
+    bdb = hs.Database.compile(["^foo.*bar"], [hs.HS_FLAG_DOTALL], [0])
+    info = C.c_char_p()
+    for db, word in ((vdb, b"VECTORED"), (bdb, b"BLOCK"), (hs.Database.deserialize(vdb.serialize()), b"VECTORED")):
+        assert lib.hs_database_info(db._h, C.byref(info)) == 0 and word in info.value
+    blob = vdb.serialize()
+    assert lib.hs_serialized_database_info(blob, len(blob), C.byref(info)) == 0 and b"VECTORED" in info.value
+    fake_scratch = C.create_string_buffer(256)  # never dereferenced: the mode check comes first
+    cb = hs.MATCH_CB(lambda *a: 0)
+    seg = (C.c_char_p * 1)(b"foobar")
+    ln = (C.c_uint * 1)(6)
+    lib.hs_scan_vector.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint), C.c_uint, C.c_uint, C.c_void_p, hs.MATCH_CB,
+                                   C.c_void_p]
+    assert lib.hs_scan_vector(bdb._h, seg, ln, 1, 0, fake_scratch, cb, None) == hs.HS_DB_MODE_ERROR
+    assert lib.hs_scan(vdb._h, b"foobar", 6, 0, fake_scratch, cb, None) == hs.HS_DB_MODE_ERROR
+    assert lib.hs_scan_vector(vdb._h, None, ln, 1, 0, fake_scratch, cb, None) == hs.HS_INVALID
+    assert lib.hs_scan_vector(vdb._h, seg, None, 1, 0, fake_scratch, cb, None) == hs.HS_INVALID
+    assert lib.hs_scan_vector(vdb._h, seg, ln, 1, 0, None, cb, None) == hs.HS_INVALID
+    with pytest.raises(hs.HsError):
+        hs.Database.compile(["foo"], mode=hs.HS_MODE_STREAM)

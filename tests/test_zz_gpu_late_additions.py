@@ -147,3 +147,27 @@ def test_collider_subset_on_gpu():
         check_ends(c, flags, got)
         n += len(blocks)
     assert n >= 7400
+
+
+def test_scan_vector_behaviour_cpp():
+    """unit/hyperscan/behaviour.cpp:972-1115 Vectored1-5 (6 and 7 need HS_FLAG_ALLOWEMPTY): the
+    segments are one logical buffer wherever the empty ones sit; count 0 scans nothing. Plus
+    offsets that run through the segments and the mode errors."""
+    from hyperscan_amd import hs
+
+    db = hs.Database.compile(["^foo.*bar"], [hs.HS_FLAG_DOTALL], [0], mode=hs.HS_MODE_VECTORED)
+    sc = hs.HsScratch(db)
+    for segs in ([b"foo", b"   ", b"bar"], [b"", b"foo", b"   ", b"bar"], [b"foo", b"   ", b"", b"bar"], [b"foo", b"   ", b"bar", b""]):
+        got = []
+        assert hs.scan_vector(db, segs, sc, lambda i, f, t: got.append((i, f, t)) and False) == hs.HS_SUCCESS
+        assert got == [(0, 0, 9)]
+    got = []
+    assert hs.scan_vector(db, [], sc, lambda i, f, t: got.append(t) and False) == hs.HS_SUCCESS and got == []
+    db2 = hs.Database.compile(["needle", r"ab\d+"], [0, hs.HS_FLAG_SOM_LEFTMOST], [1, 2], mode=hs.HS_MODE_VECTORED)
+    segs = [b"xxnee", b"dle ab", b"1", b"2 need", b"", b"le"]
+    got = []
+    assert hs.scan_vector(db2, segs, sc, lambda i, f, t: got.append((i, f, t)) and False) == hs.HS_SUCCESS
+    assert got == [(1, 0, 8), (2, 9, 12), (2, 9, 13), (1, 0, 20)]
+    assert hs.scan(db2, b"needle", sc) == hs.HS_DB_MODE_ERROR
+    block_db = hs.Database.compile(["needle"])
+    assert hs.scan_vector(block_db, [b"needle"], sc) == hs.HS_DB_MODE_ERROR
