@@ -431,8 +431,10 @@ def test_hs_compile_arg_checks_like_the_reference():
     assert compile_one(b"foobar", 0, hs.HS_MODE_BLOCK, C.byref(Plat(0, 42, 0, 0)))[:2] == (
         ERR, "Invalid cpu features specified in the platform information.")
     assert compile_one(b"foobar", 0, hs.HS_MODE_BLOCK, C.byref(Plat(10, 1 << 2, 0, 0)))[0] == 0  # ICX + AVX2: accepted, ignored
-    # streaming / vectored are well-formed requests this engine declines
-    assert compile_one(b"foobar", 0, hs.HS_MODE_STREAM)[:2] == (ERR, "Only HS_MODE_BLOCK is supported by the GPU literal engine.")
+    # streaming is a well-formed request this engine declines
+    assert compile_one(b"foobar", 0, hs.HS_MODE_STREAM)[:2] == (
+        ERR, "Only HS_MODE_BLOCK and HS_MODE_VECTORED are supported by the GPU literal engine.")
+    assert compile_one(b"foobar", 0, hs.HS_MODE_VECTORED)[0] == 0
     # MultiCompileZeroPatterns / NoPattern
     lib.hs_compile_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, P(C.c_void_p),
                                      P(P(hs.CompileErrorStruct))]
