@@ -72,7 +72,7 @@ struct Auto {
 
 struct Pattern {
     std::string lit;          /* literal prefix, as written (upper-cased compare if nocase) */
-    bool nocase = false, single = false, som = false;
+    bool nocase = false, single = false, som = false, quiet = false;
     /* `^` in front / `$` at the back of the branch (multiline: the HS_FLAG_MULTILINE reading) */
     bool bol = false, eol = false;
     bool bol_ml = false; /* `^` under HS_FLAG_MULTILINE: also after any newline (never for \A) */
@@ -813,8 +813,10 @@ std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsi
         flags = (flags | set) & ~clear;
         p.erase(0, k + 1);
     }
-    const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_PREFILTER | HS_FLAG_COMBINATION |
-                                 HS_FLAG_QUIET | HS_FLAG_ALLOWEMPTY;
+    /* HS_FLAG_PREFILTER allows a superset of the matches: the exact set is one. HS_FLAG_ALLOWEMPTY
+     * permits patterns that can match the empty string: none here can (a mandatory literal).
+     * HS_FLAG_QUIET: the expression reports nothing (src/hs_compile.h:328-330 "ignore match reporting"). */
+    const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_COMBINATION;
     if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};
     std::vector<Pattern> out;
     size_t from = 0;
@@ -836,6 +838,7 @@ std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsi
             if (c != '|' || depth != 0) continue;
         }
         out.push_back(parse_branch(p.substr(from, k - from), flags, id));
+        out.back().quiet = flags & HS_FLAG_QUIET;
         from = k + 1;
     }
     return out;
@@ -1215,6 +1218,7 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
     const size_t base = out.size();
     for (size_t k = 0; k < n; k++) {
         const Pattern &p = db->pats[recs[k].id];
+        if (p.quiet) continue;
         const size_t lit_end = (size_t)recs[k].end + 1;
         if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
         unsigned long long start = lit_end - p.lit.size();

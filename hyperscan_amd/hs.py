@@ -10,6 +10,7 @@ HS_SUCCESS, HS_INVALID, HS_NOMEM, HS_SCAN_TERMINATED, HS_COMPILER_ERROR = 0, -1,
 HS_DB_MODE_ERROR, HS_SCRATCH_IN_USE, HS_UNKNOWN_ERROR = -7, -10, -13
 HS_FLAG_CASELESS, HS_FLAG_DOTALL, HS_FLAG_MULTILINE, HS_FLAG_SINGLEMATCH = 1, 2, 4, 8
 HS_FLAG_UTF8, HS_FLAG_SOM_LEFTMOST = 32, 256
+HS_FLAG_ALLOWEMPTY, HS_FLAG_UCP, HS_FLAG_PREFILTER, HS_FLAG_COMBINATION, HS_FLAG_QUIET = 16, 64, 128, 512, 1024
 HS_MODE_BLOCK, HS_MODE_STREAM, HS_MODE_VECTORED = 1, 2, 4
 HS_EXT_FLAG_MIN_OFFSET, HS_EXT_FLAG_MAX_OFFSET, HS_EXT_FLAG_MIN_LENGTH = 1, 2, 4
 HS_EXT_FLAG_EDIT_DISTANCE, HS_EXT_FLAG_HAMMING_DISTANCE = 8, 16

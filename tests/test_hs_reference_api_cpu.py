@@ -137,3 +137,16 @@ def test_identical_cpp():
         ev, rv = cpu_scan(db, corpus)
         assert rv == hs.HS_SUCCESS and len(ev) == 100 and all(t == match for t, _i, _f in ev), (pat, fl)
         assert sorted(i for _t, i, _f in ev) == list(range(100))
+
+
+def test_quiet_prefilter_allowempty_flags():
+    """HS_FLAG_QUIET reports nothing (src/hs_compile.h:328-330); HS_FLAG_PREFILTER may over-report,
+    and the exact matches are a legal answer; HS_FLAG_ALLOWEMPTY has nothing to allow when every
+    pattern holds a mandatory literal. The reference's combination rules still apply
+    (src/compiler/compiler.cpp:286-294)."""
+    db = hs.Database.compile(["foo", "bar", "ba[rz]"], [hs.HS_FLAG_QUIET, hs.HS_FLAG_PREFILTER, hs.HS_FLAG_ALLOWEMPTY], [1, 2, 3])
+    assert to_id(cpu_scan(db, b"foo bar baz")[0]) == [(7, 2), (7, 3), (11, 3)]
+    for fl in (hs.HS_FLAG_UTF8, hs.HS_FLAG_UCP, hs.HS_FLAG_QUIET | hs.HS_FLAG_SOM_LEFTMOST,
+               hs.HS_FLAG_PREFILTER | hs.HS_FLAG_SOM_LEFTMOST):
+        with pytest.raises(hs.HsError):
+            hs.Database.compile(["foo"], [fl], [1])
