@@ -1737,8 +1737,13 @@ static bool confirm_and_deliver(const hs_database *db, const char *data, const u
             while (c < n && c > 0 && recs[c].block == recs[c - 1].block) c++; /* snap to a block boundary */
             cut[t] = c;
         }
+        static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr;
         auto work = [&](unsigned t) {
+            const auto t0 = std::chrono::steady_clock::now();
             collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t]);
+            if (timing)
+                fprintf(stderr, "  confirm worker %u: %zu hits in %.2f ms\n", t, cut[t + 1] - cut[t],
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         };
         if (n_thr == 1) {
             work(0);

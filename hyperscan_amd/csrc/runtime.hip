@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <functional>
 #include <vector>
 #include <cstdlib>
 #include <cstring>
@@ -467,10 +469,57 @@ static bool device_sort_enabled() { /* opt-in, see hsgpu_match_sort_dev */
     return e && e[0] == '1';
 }
 
-static bool rec_less(const hsgpu_match_t &a, const hsgpu_match_t &b) {
-    if (a.block != b.block) return a.block < b.block;
-    if (a.end != b.end) return a.end < b.end;
-    return a.lit < b.lit;
+struct RecLess { /* a functor, so that std::sort / std::merge inline the comparison */
+    bool operator()(const hsgpu_match_t &a, const hsgpu_match_t &b) const {
+        const uint64_t ka = (uint64_t)a.block << 32 | a.end, kb = (uint64_t)b.block << 32 | b.end;
+        return ka != kb ? ka < kb : a.lit < b.lit;
+    }
+};
+static const RecLess rec_less;
+
+/* delivery order on the host. Large sets are cut into per-thread chunks, sorted concurrently and
+ * merged pairwise (ping-pong through one scratch copy): the single-threaded std::sort of a few
+ * hundred thousand records was the largest host cost of a host-buffer scan. */
+extern "C" void hsgpu_match_sort_host(hsgpu_match_t *r, size_t n) {
+    if (!r || n < 2) return;
+    unsigned T = 1;
+    if (n >= (1u << 16)) T = (unsigned)std::min<size_t>(std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency())), n >> 15);
+    if (T <= 1) {
+        std::sort(r, r + n, rec_less);
+        return;
+    }
+    std::vector<size_t> b(T + 1);
+    for (unsigned i = 0; i <= T; i++) b[i] = n * i / T;
+    std::vector<hsgpu_match_t> tmp;
+    try {
+        tmp.resize(n);
+    } catch (...) {
+        std::sort(r, r + n, rec_less);
+        return;
+    }
+    /* run f(i) for i in [0, jobs) on up to `jobs` threads; whatever cannot be started runs here */
+    auto parallel = [](unsigned jobs, const std::function<void(unsigned)> &f) {
+        std::vector<std::thread> pool;
+        unsigned started = 1; /* job 0 is ours */
+        try {
+            for (; started < jobs; started++) pool.emplace_back(f, started);
+        } catch (...) {
+            for (unsigned i = started; i < jobs; i++) f(i);
+        }
+        f(0);
+        for (std::thread &th : pool) th.join();
+    };
+    parallel(T, [&](unsigned i) { std::sort(r + b[i], r + b[i + 1], rec_less); });
+    hsgpu_match_t *src = r, *dst = tmp.data();
+    for (unsigned width = 1; width < T; width *= 2) {
+        const unsigned jobs = (T + 2 * width - 1) / (2 * width);
+        parallel(jobs, [&](unsigned j) {
+            const unsigned lo = j * 2 * width, mid = std::min(T, lo + width), hi = std::min(T, lo + 2 * width);
+            std::merge(src + b[lo], src + b[mid], src + b[mid], src + b[hi], dst + b[lo], rec_less);
+        });
+        std::swap(src, dst);
+    }
+    if (src != r) memcpy(r, src, n * sizeof(hsgpu_match_t));
 }
 
 struct InUse {
@@ -523,7 +572,7 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
             const bool on_device = device_sort_enabled() && n >= 2;
             if (on_device && (rv = hsgpu_match_sort_dev(s, s->out.p, n, s->stream)) != HSGPU_SUCCESS) return rv;
             if (n) HIP_TRY(hipMemcpy(recs.data(), s->out.p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost));
-            if (!on_device) std::sort(recs.begin(), recs.end(), rec_less);
+            if (!on_device) hsgpu_match_sort_host(recs.data(), recs.size());
             return HSGPU_SUCCESS;
         }
         /* overflow: the count is exact; rerun with room for all of them, and since the
@@ -603,7 +652,7 @@ extern "C" int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n,
         std::vector<hsgpu_match_t> recs(n);
         HIP_TRY(hipMemcpyAsync(recs.data(), d_out, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        std::sort(recs.begin(), recs.end(), rec_less);
+        hsgpu_match_sort_host(recs.data(), recs.size());
         HIP_TRY(hipMemcpyAsync(d_out, recs.data(), n * sizeof(hsgpu_match_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         return HSGPU_SUCCESS;

@@ -173,6 +173,10 @@ int hsgpu_scratch_get_stats(hsgpu_scratch_t *s, uint64_t *cand_entries, int *ove
 /* Sort cap' = min(count, cap) device records in place by (block, end, lit). */
 int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n, void *stream);
 
+/* The same order for records already on the host (what hsgpu_hwlm_exec_batch applies before it
+ * returns); multi-threaded above 64 Ki records. Touches no device. */
+void hsgpu_match_sort_host(hsgpu_match_t *recs, size_t n);
+
 /* Replay sorted records of ONE block through a callback with the reference's
  * sequential semantics (groups gate, noruns, terminate). Host only. */
 int hsgpu_hwlm_replay(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n,

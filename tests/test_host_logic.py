@@ -575,3 +575,27 @@ def test_vectored_mode_without_gpu():
     assert lib.hs_scan_vector(vdb._h, seg, ln, 1, 0, None, cb, None) == hs.HS_INVALID
     with pytest.raises(hs.HsError):
         hs.Database.compile(["foo"], mode=hs.HS_MODE_STREAM)
+
+
+def test_host_record_sort_matches_lexsort():
+    """hsgpu_match_sort_host (the delivery order of hsgpu_hwlm_exec_batch): serial below 64 Ki
+    records, chunked over threads and merged above; equal to a lexicographic sort at every size."""
+    from hyperscan_amd.hwlm import MATCH_DTYPE
+
+    lib = _native.load_library()
+    lib.hsgpu_match_sort_host.argtypes = [C.c_void_p, C.c_size_t]
+    lib.hsgpu_match_sort_host.restype = None
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 2, 1000, 65535, 65536, 65537, 100_003, 300_000, 1_000_000):
+        r = np.zeros(n, dtype=MATCH_DTYPE)
+        r["block"] = rng.integers(0, max(1, n // 50), n)
+        r["end"] = rng.integers(0, 1500, n)
+        r["lit"] = rng.integers(0, 1000, n)
+        r["id"] = r["lit"] * 7 + 1
+        if n > 4:  # nearly sorted input and runs of equal keys, as the device hands them over
+            r[: n // 2] = np.sort(r[: n // 2], order=["block", "end", "lit"])
+            r[n // 2: n // 2 + 3] = r[0]
+        want = r[np.lexsort((r["lit"], r["end"], r["block"]))]
+        lib.hsgpu_match_sort_host(r.ctypes.data, n)
+        assert np.array_equal(r["block"], want["block"]) and np.array_equal(r["end"], want["end"])
+        assert np.array_equal(r["lit"], want["lit"]) and np.array_equal(r["id"], want["id"])
