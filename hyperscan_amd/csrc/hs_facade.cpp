@@ -101,6 +101,9 @@ struct Pattern {
 struct ParseError {
     std::string msg;
 };
+struct NoLiteral : ParseError { /* the branch is well-formed but offers no top-level literal */
+    NoLiteral() : ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."} {}
+};
 
 bool is_alpha(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
 
@@ -679,7 +682,7 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     /* the branch is R1 LIT R2 around its longest top-level literal run (the front one on a tie);
      * \b / \B may hug the literal on either side */
     LitRun run = longest_literal_run(p);
-    if (run.bytes.empty()) throw ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."};
+    if (run.bytes.empty()) throw NoLiteral();
     size_t r1_end = run.begin, r2_begin = run.end;
     if (run.begin >= 2 && escape_at(run.begin - 2, "bB")) {
         pat.as_lit_pre = assertion(p[run.begin - 1]);
@@ -793,6 +796,92 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     return pat;
 }
 
+/* A branch without a top-level literal may still hold one inside an alternation: X(A|B)Y is
+ * XAY|XBY, so the first unquantified top-level group is distributed over its alternatives and
+ * every product is tried again (Rose gets the same literals by cutting the graph at the
+ * alternation). "\\b(foo|bar)\\b" and "(GET|POST) /" are the everyday cases. */
+constexpr size_t kMaxBranches = 256;
+void distribute_group(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth);
+
+void expand_branch(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
+    /* as written, if it has a usable literal; with only a 1-2 byte one, distributing a group is
+     * tried as well and kept when every product gets a longer literal ("(GET|POST) /x": " /" ->
+     * "GET /", "POST /") */
+    bool have = false;
+    Pattern whole;
+    try {
+        whole = parse_branch(b, flags, id);
+        have = true;
+    } catch (const NoLiteral &) {
+        if (depth >= 8) throw;
+    } catch (const ParseError &first) {
+        /* an anchor or assertion inside a group, e.g. "(^|\n)foo": fine once the group is distributed */
+        if (depth >= 8) throw;
+        try {
+            distribute_group(b, flags, id, out, depth);
+        } catch (const ParseError &) {
+            throw first;
+        }
+        return;
+    }
+    if (have && (whole.lit.size() > 2 || depth >= 8)) {
+        out.push_back(std::move(whole));
+        return;
+    }
+    if (have) {
+        std::vector<Pattern> alt;
+        bool better = false;
+        try {
+            distribute_group(b, flags, id, alt, depth);
+            better = !alt.empty() && out.size() + alt.size() <= kMaxBranches;
+            for (const Pattern &a : alt) better = better && a.lit.size() > whole.lit.size();
+        } catch (const ParseError &) {
+            better = false;
+        }
+        if (better) {
+            for (Pattern &a : alt) out.push_back(std::move(a));
+        } else {
+            out.push_back(std::move(whole));
+        }
+        return;
+    }
+    distribute_group(b, flags, id, out, depth);
+}
+
+void distribute_group(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
+    /* the first top-level group that is not quantified, not special, and has its alternatives */
+    size_t i = 0;
+    while (i < b.size()) {
+        const char c = b[i];
+        if (c == '\\') { i += 2; continue; }
+        if (c == '[') { size_t e = i; parse_bracket_class(b, e); i = e; continue; }
+        if (c != '(') { i++; continue; }
+        size_t body = i + 1;
+        bool plain = true;
+        if (body < b.size() && b[body] == '?') {
+            if (body + 1 < b.size() && b[body + 1] == ':') body += 2;
+            else plain = false; /* named / comment / look-around: leave it alone */
+        }
+        std::vector<std::string> alts;
+        size_t j = i, last = body;
+        for (int d = 0;; j++) {
+            if (j >= b.size()) throw ParseError{"Missing closing parenthesis."};
+            if (b[j] == '\\') { j++; continue; }
+            if (b[j] == '[') { size_t e = j; parse_bracket_class(b, e); j = e - 1; continue; }
+            if (b[j] == '(') d++;
+            else if (b[j] == '|' && d == 1) { alts.push_back(b.substr(last, j - last)); last = j + 1; }
+            else if (b[j] == ')' && --d == 0) { alts.push_back(b.substr(last, j - last)); break; }
+        }
+        const size_t end = j + 1;
+        const bool quantified = end < b.size() && (b[end] == '?' || b[end] == '*' || b[end] == '+' || TailBuilder::is_repeat_at(b, end));
+        if (!plain || quantified) { i = end; continue; }
+        if (out.size() + alts.size() > kMaxBranches) throw ParseError{"Pattern too large."};
+        for (const std::string &a : alts) expand_branch(b.substr(0, i) + a + b.substr(end), flags, id, out, depth + 1);
+        return;
+    }
+    throw NoLiteral();
+}
+
 /* expression := branch ('|' branch)* at the top level: every branch is its own literal-prefixed
  * pattern reporting the same id (the reference builds one graph; the reports are the same) */
 std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsigned id) {
@@ -837,10 +926,10 @@ std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsi
             if (c == ')') depth--;
             if (c != '|' || depth != 0) continue;
         }
-        out.push_back(parse_branch(p.substr(from, k - from), flags, id));
-        out.back().quiet = flags & HS_FLAG_QUIET;
+        expand_branch(p.substr(from, k - from), flags, id, out, 0);
         from = k + 1;
     }
+    for (Pattern &b : out) b.quiet = flags & HS_FLAG_QUIET;
     return out;
 }
 

@@ -27,7 +27,9 @@
  * What is behind it: an expression is one or more top-level branches `b1|b2|...`, and every
  * branch must contain a mandatory literal (>= 1 byte) at its top level: R1 LIT R2, where R1 and
  * R2 are regex fragments (either may be empty; LIT is the longest top-level run of plain
- * characters, the one at the front on a tie) and `^` may lead the branch. The literals
+ * characters, the one at the front on a tie) and `^` may lead the branch. A branch whose only
+ * literals sit inside an unquantified group, X(A|B)Y, is distributed into XAY|XBY first
+ * ("\b(foo|bar)\b", "(GET|POST) /"). The literals
  * (their last <= 8 bytes, as Rose truncates them: rose_build_matchers.cpp:717-724)
  * are matched on the GPU through hsgpu_hwlm_exec; the host then checks the full literal
  * (the job of CHECK_MED_LIT / CHECK_LONG_LIT, src/rose/program_runtime.c:2896-2942) and,

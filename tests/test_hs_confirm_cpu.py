@@ -247,7 +247,7 @@ def test_top_level_alternation_and_anchors():
              (b"cost$", "", 0, 306, {}), (b"bc", "", 0, 306, {}, "$")]
     import pytest
     with pytest.raises(hs.HsError):  # one branch without a mandatory literal refuses the whole expression
-        hs.Database.compile(["cost\\$|(ab|b)$"], [0], [1])
+        hs.Database.compile(["cost\\$|[ab]+$"], [0], [1])
     with pytest.raises(hs.HsError):
         hs.Database.compile(["abc|"], [0], [1])
     with pytest.raises(hs.HsError):
@@ -275,7 +275,10 @@ def test_top_level_alternation_and_anchors():
                          ("foo\\b", 0, (3, 3, 1, 1, 0)), ("\\bfoo", 0, (3, 3, 0, 0, 0)), ("^\\bfoo", 0, (3, 3, 0, 0, 0)),
                          ("\\Bfoo", 0, (3, 3, 0, 0, 0)),
                          # \z / \Z flags as in the table's bare "\\z" (0, 1, 1) and "\\Z" (1, 1, 1) rows
-                         ("eod\\z", 0, (3, 3, 0, 1, 1)), ("eod\\Z", 0, (3, 3, 1, 1, 1))]:
+                         ("eod\\z", 0, (3, 3, 0, 1, 1)), ("eod\\Z", 0, (3, 3, 1, 1, 1)),
+                         # groups distributed into branches: expr_info.cpp:212-213,218-219
+                         ("(^|\n)foo", 0, (3, 4, 0, 0, 0)), ("(^\n|)foo", 0, (3, 4, 0, 0, 0)),
+                         ("(foo|bar\\z)", 0, (3, 3, 0, 1, 0)), ("(foo|bar)\\z", 0, (3, 3, 0, 1, 1))]:
         info, err = C.POINTER(hs.ExprInfo)(), C.POINTER(hs.CompileErrorStruct)()
         assert lib.hs_expression_ext_info(pat.encode(), fl, None, C.byref(info), C.byref(err)) == hs.HS_SUCCESS, pat
         i = info.contents
@@ -352,7 +355,7 @@ def test_literal_in_the_middle_matches_brute_force():
     assert hs.expression_info(r"^.{0,4}aa..") == (4, 8)
     assert hs.expression_info(r"[a-z]+@example\.(com|org)") == (13, 0xffffffff)
     import pytest
-    for bad in [r"[a-z]+", r"(foo|bar)z?", r"a*", r"(abc)"]:  # no top-level mandatory literal
+    for bad in [r"[a-z]+", r"(foo|[a-z])z?", r"a*", r"(abc)?"]:  # no mandatory literal
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
 
@@ -460,3 +463,27 @@ def test_wide_position_automata():
     assert sorted(ev) == sorted(want)
     assert {e[1] for e in ev} == set(range(1, 10))
     assert hs.expression_info(r"^foo.{600}bar") == (606, 606) and hs.expression_info(r"[a-z]{70,}END") == (73, 0xffffffff)
+
+
+def test_literals_inside_an_alternation_group():
+    """X(A|B)Y without a top-level literal is distributed into XAY|XBY (nested groups too)"""
+    SOM = hs.HS_FLAG_SOM_LEFTMOST
+    exprs = [(r"\b(foo|bar|baz)\b", 0, 1), (r"(GET|POST|HEAD) /[a-z]*", 0, 2), (r"(a|b|b$)", 0, 3), (r"(foo|bar).*\z", hs.HS_FLAG_DOTALL, 4),
+             (r"[0-9]+(px|em|(r|v)em)\b", SOM, 5), (r"(?:x|yy)(?:1|22)\d", 0, 6), (r"(^GET|^PUT)\s", hs.HS_FLAG_MULTILINE, 7)]
+    db = hs.Database.compile([e[0] for e in exprs], [e[1] for e in exprs], [e[2] for e in exprs])
+    assert [b for b, _nc, _id in db.literals()] == [b"foo", b"bar", b"baz", b"GET /", b"POST /", b"HEAD /", b"a", b"b", b"b", b"foo", b"bar",
+                                                   b"px", b"em", b"rem", b"vem", b"x1", b"x22", b"yy1", b"yy22", b"GET", b"PUT"]
+    words = [b"foo", b"bar", b"baz", b" ", b"GET", b"POST", b"HEAD", b" /", b"idx", b"a", b"b", b"\n", b"12", b"px", b"em", b"rem", b"vem",
+             b"x", b"yy", b"1", b"22", b"7", b"PUT", b"-"]
+    rng = np.random.default_rng(71)
+    blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 12)))) for _ in range(200)]
+    blocks += [b"foo bar,baz", b"foobar", b"GET /idx POST /", b"ab", b"b", b"xfoo\nbar", b"12px 3rem 4vemx 5em", b"x17 yy229 x2 yy1", b"GET \nPUT\t",
+               b"xGET "]
+    ev = run_exprs_auto(exprs, blocks)
+    want = brute_context(exprs, blocks)
+    assert sorted(ev) == sorted(want)
+    assert {e[1] for e in ev} == set(range(1, 8))
+    import pytest
+    for bad in [r"(foo|[a-z])x?", r"(foo|bar)?", r"(a|b)+", r"(?=foo|bar)"]:
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([bad], [0], [1])

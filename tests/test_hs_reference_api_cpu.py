@@ -97,13 +97,11 @@ def test_behaviour_cpp_cases():
     # HS_FLAG_UTF8 dropped from pattern 2, the data is ASCII)
     db = hs.Database.compile(["aaa.a+$", "aaa.a"], [I, I | ONE], [1, 2])
     assert sorted(to_id(cpu_scan(db, b"aAasaA")[0])) == [(5, 2), (6, 1)]
-    # behaviour.cpp:1467-1511 UE_2798: patterns 2 and 3 (pattern 1 has no mandatory literal)
-    db = hs.Database.compile(["ab+", "a(b.)?ba+b"], [SOM, 0], [2, 3])
+    # behaviour.cpp:1467-1511 UE_2798 (pattern 1's literals come out of its group: "[ab]b$|aab+$")
+    db = hs.Database.compile(["([ab]b|aab+)$", "ab+", "a(b.)?ba+b"], [hs.HS_FLAG_DOTALL, SOM, 0], [1, 2, 3])
     ev, _ = cpu_scan(db, b"ab_baab\n")
-    assert sorted(to_id(ev)) == [(2, 2), (7, 2), (7, 3)]
+    assert sorted(to_id(ev)) == [(2, 2), (7, 1), (7, 2), (7, 3)]
     assert {(t, f) for t, i, f in ev if i == 2} == {(2, 0), (7, 5)}
-    with pytest.raises(hs.HsError):
-        hs.Database.compile(["([ab]b|aab+)$"], [hs.HS_FLAG_DOTALL], [1])
     # behaviour.cpp:400-476 HyperscanLiteralLengthTest: floating and anchored literals of every length
     for n in (1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 32, 33, 100, 255):
         lit = "".join(chr(ord("a") + (k % 26)) for k in range(n))
