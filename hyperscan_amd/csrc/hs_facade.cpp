@@ -63,9 +63,20 @@ struct Auto {
     std::vector<Bits> exc_row;    /* [npos]: follow[p] minus {p+1}; empty unless p is in exc */
     bool nullable = true;
     unsigned long long wmin = 0, wmax = 0; /* width bounds; kInf64 = unbounded */
+    /* \b / \B inside the fragment: a second and third layer of the same sets, valid only across
+     * a boundary where the assertion holds ([0] = \b, [1] = \B). Entering a position, following
+     * an edge, ending and matching the empty string can each be conditional. */
+    bool has_cond = false;
+    Bits cfirst[2], clast[2], cshift_ok[2], cexc[2];
+    std::vector<Bits> cexc_row[2];
+    bool cnullable[2] = {false, false};
     size_t bytes() const {
         size_t n = (first.size() + last.size() + reach.size() + shift_ok.size() + exc.size()) * 8;
         for (const Bits &r : exc_row) n += r.size() * 8;
+        for (int k = 0; k < 2; k++) {
+            n += (cfirst[k].size() + clast[k].size() + cshift_ok[k].size() + cexc[k].size()) * 8;
+            for (const Bits &r : cexc_row[k]) n += r.size() * 8;
+        }
         return n;
     }
 };
@@ -278,17 +289,22 @@ inline void bits_set(Bits &a, size_t i) {
 }
 inline bool bits_test(const Bits &a, size_t i) { return i / 64 < a.size() && (a[i / 64] >> (i % 64) & 1); }
 
+/* conditions on a boundary between two bytes: 0 = none, 1 = \b, 2 = \B; -1 = contradictory */
+inline int cond_and(int a, int b) { return a == 0 ? b : (b == 0 || a == b) ? a : -1; }
+
 struct Frag {
-    Bits first, last;
-    bool nullable = true;
+    Bits first[3], last[3];     /* per condition: to enter a first position / after a last one */
+    unsigned char nullmask = 1; /* bit c: the empty string is in the language under condition c */
     unsigned long long wmin = 0, wmax = 0;
+    bool nullable() const { return nullmask != 0; }
 };
 
 struct TailBuilder {
     const std::string &p;
     bool nocase, dotall;
-    std::vector<ByteSet> cls; /* per position */
-    std::vector<Bits> follow; /* per position */
+    std::vector<ByteSet> cls;    /* per position */
+    std::vector<Bits> follow[3]; /* per condition, per position */
+    bool has_cond = false;
 
     static unsigned long long add_w(unsigned long long a, unsigned long long b) {
         return (a == kInf64 || b == kInf64) ? kInf64 : a + b;
@@ -296,21 +312,38 @@ struct TailBuilder {
     unsigned new_pos(const ByteSet &c) {
         if (cls.size() >= kMaxPositions) throw ParseError{"Pattern too large."};
         cls.push_back(nocase ? fold_case(c) : c);
-        follow.emplace_back();
+        for (int k = 0; k < 3; k++) follow[k].emplace_back();
         return (unsigned)cls.size() - 1;
     }
-    void link(const Bits &from_last, const Bits &to_first) {
-        for (size_t w = 0; w < from_last.size(); w++)
-            for (unsigned long long m = from_last[w]; m; m &= m - 1) bits_or(follow[w * 64 + __builtin_ctzll(m)], to_first);
+    /* every last position of a, then every first position of b: the conditions on the two sides
+     * speak about the same boundary, so they combine */
+    void link(const Frag &a, const Frag &b) {
+        for (int ca = 0; ca < 3; ca++)
+            for (int cb = 0; cb < 3; cb++) {
+                const int c = cond_and(ca, cb);
+                if (c < 0) continue;
+                const Bits &from = a.last[ca];
+                for (size_t w = 0; w < from.size(); w++)
+                    for (unsigned long long m = from[w]; m; m &= m - 1)
+                        bits_or(follow[c][w * 64 + __builtin_ctzll(m)], b.first[cb]);
+            }
     }
     Frag cat(const Frag &a, const Frag &b) {
-        link(a.last, b.first);
+        link(a, b);
         Frag r;
-        r.first = a.first;
-        if (a.nullable) bits_or(r.first, b.first);
-        r.last = b.last;
-        if (b.nullable) bits_or(r.last, a.last);
-        r.nullable = a.nullable && b.nullable;
+        r.nullmask = 0;
+        for (int c = 0; c < 3; c++) {
+            r.first[c] = a.first[c];
+            r.last[c] = b.last[c];
+        }
+        for (int n = 0; n < 3; n++)
+            for (int c = 0; c < 3; c++) {
+                const int k = cond_and(n, c);
+                if (k < 0) continue;
+                if (a.nullmask >> n & 1) bits_or(r.first[k], b.first[c]);
+                if (b.nullmask >> n & 1) bits_or(r.last[k], a.last[c]);
+                if ((a.nullmask >> n & 1) && (b.nullmask >> c & 1)) r.nullmask |= 1u << k;
+            }
         r.wmin = add_w(a.wmin, b.wmin);
         r.wmax = add_w(a.wmax, b.wmax);
         return r;
@@ -332,9 +365,11 @@ struct TailBuilder {
         while (i < p.size() && p[i] == '|') {
             i++;
             const Frag b = parse_cat(i, depth);
-            bits_or(r.first, b.first);
-            bits_or(r.last, b.last);
-            r.nullable = r.nullable || b.nullable;
+            for (int c = 0; c < 3; c++) {
+                bits_or(r.first[c], b.first[c]);
+                bits_or(r.last[c], b.last[c]);
+            }
+            r.nullmask |= b.nullmask;
             r.wmin = std::min(r.wmin, b.wmin);
             r.wmax = std::max(r.wmax, b.wmax);
         }
@@ -384,14 +419,14 @@ struct TailBuilder {
             return c;
         };
         auto star_of = [&](Frag c) { /* c* */
-            link(c.last, c.first);
-            c.nullable = true;
+            link(c, c);
+            c.nullmask |= 1;
             c.wmin = 0;
             c.wmax = c.wmax ? kInf64 : 0;
             return c;
         };
         auto opt_of = [&](Frag c) {
-            c.nullable = true;
+            c.nullmask |= 1;
             c.wmin = 0;
             return c;
         };
@@ -406,7 +441,7 @@ struct TailBuilder {
         for (unsigned k = 0; k < lo; k++) {
             Frag c = next_copy();
             if (hi == kInf && k + 1 == lo) { /* last mandatory copy loops: c+ */
-                link(c.last, c.first);
+                link(c, c);
                 c.wmax = c.wmax ? kInf64 : 0;
             }
             r = cat(r, c);
@@ -449,6 +484,13 @@ struct TailBuilder {
             i++;
             return f;
         }
+        if (c == '\\' && i + 1 < p.size() && (p[i + 1] == 'b' || p[i + 1] == 'B')) {
+            Frag f; /* zero width: the empty string, under a condition */
+            f.nullmask = p[i + 1] == 'b' ? 2 : 4;
+            has_cond = true;
+            i += 2;
+            return f;
+        }
         ByteSet set;
         if (c == '\\') {
             if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
@@ -477,9 +519,9 @@ struct TailBuilder {
         }
         const unsigned pos = new_pos(set);
         Frag f;
-        bits_set(f.first, pos);
-        bits_set(f.last, pos);
-        f.nullable = false;
+        bits_set(f.first[0], pos);
+        bits_set(f.last[0], pos);
+        f.nullmask = 0;
         f.wmin = f.wmax = 1;
         return f;
     }
@@ -492,49 +534,58 @@ Auto finish_auto(const TailBuilder &tb, const Frag &f, bool reversed) {
     const size_t n = tb.cls.size(), W = (n + 63) / 64;
     a.npos = n;
     a.W = W;
-    a.nullable = f.nullable;
+    a.nullable = f.nullmask & 1;
+    a.cnullable[0] = f.nullmask & 2;
+    a.cnullable[1] = f.nullmask & 4;
     a.wmin = f.wmin;
     a.wmax = f.wmax;
+    a.has_cond = tb.has_cond;
     if (!n) return a;
     auto idx = [&](size_t p) { return reversed ? n - 1 - p : p; };
-    std::vector<Bits> follow(n, Bits(W, 0));
-    for (size_t x = 0; x < n; x++)
-        for (size_t y = 0; y < n; y++)
-            if (bits_test(tb.follow[x], y)) {
-                if (reversed) bits_set(follow[idx(y)], idx(x));
-                else bits_set(follow[x], y);
-            }
-    a.first.assign(W, 0);
-    a.last.assign(W, 0);
-    for (size_t x = 0; x < n; x++) {
-        if (bits_test(f.first, x)) bits_set(reversed ? a.last : a.first, idx(x));
-        if (bits_test(f.last, x)) bits_set(reversed ? a.first : a.last, idx(x));
-    }
     a.reach.assign(256 * W, 0);
     for (size_t x = 0; x < n; x++)
         for (unsigned c = 0; c < 256; c++)
             if (tb.cls[x][c]) a.reach[c * W + idx(x) / 64] |= 1ull << (idx(x) % 64);
-    a.shift_ok.assign(W, 0);
-    a.exc.assign(W, 0);
-    a.exc_row.assign(n, Bits());
-    for (size_t x = 0; x < n; x++) {
-        Bits row = follow[x];
-        if (x + 1 < n && bits_test(row, x + 1)) {
-            bits_set(a.shift_ok, x);
-            row[(x + 1) / 64] &= ~(1ull << ((x + 1) % 64));
+    for (int layer = 0; layer < 3; layer++) { /* 0 = unconditional, 1 = \b, 2 = \B */
+        if (layer && !tb.has_cond) break;
+        Bits &first = layer ? a.cfirst[layer - 1] : a.first, &last = layer ? a.clast[layer - 1] : a.last;
+        Bits &shift_ok = layer ? a.cshift_ok[layer - 1] : a.shift_ok, &exc = layer ? a.cexc[layer - 1] : a.exc;
+        std::vector<Bits> &exc_row = layer ? a.cexc_row[layer - 1] : a.exc_row;
+        std::vector<Bits> follow(n, Bits(W, 0));
+        for (size_t x = 0; x < n; x++)
+            for (size_t y = 0; y < n; y++)
+                if (bits_test(tb.follow[layer][x], y)) {
+                    if (reversed) bits_set(follow[idx(y)], idx(x));
+                    else bits_set(follow[x], y);
+                }
+        first.assign(W, 0);
+        last.assign(W, 0);
+        for (size_t x = 0; x < n; x++) {
+            if (bits_test(f.first[layer], x)) bits_set(reversed ? last : first, idx(x));
+            if (bits_test(f.last[layer], x)) bits_set(reversed ? first : last, idx(x));
         }
-        bool any = false;
-        for (unsigned long long w : row) any |= w != 0;
-        if (any) {
-            bits_set(a.exc, x);
-            a.exc_row[x] = row;
+        shift_ok.assign(W, 0);
+        exc.assign(W, 0);
+        exc_row.assign(n, Bits());
+        for (size_t x = 0; x < n; x++) {
+            Bits row = follow[x];
+            if (x + 1 < n && bits_test(row, x + 1)) {
+                bits_set(shift_ok, x);
+                row[(x + 1) / 64] &= ~(1ull << ((x + 1) % 64));
+            }
+            bool any = false;
+            for (unsigned long long w : row) any |= w != 0;
+            if (any) {
+                bits_set(exc, x);
+                exc_row[x] = row;
+            }
         }
     }
     return a;
 }
 
 Auto compile_auto(const std::string &src, bool nocase, bool dotall, bool reversed = false) {
-    TailBuilder tb{src, nocase, dotall, {}, {}};
+    TailBuilder tb{src, nocase, dotall, {}, {}, false};
     size_t i = 0;
     const Frag f = tb.parse_cat(i, 0);
     if (i < src.size()) throw ParseError{"Unmatched closing parenthesis."};
@@ -698,23 +749,23 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
         /* the literal is not at the front: R1 backwards, R2 as a position automaton */
         pat.pre = compile_auto(p.substr(0, r1_end), pat.nocase, dotall, true);
         pat.g = compile_auto(p.substr(r2_begin), pat.nocase, dotall);
-        pat.has_pre = pat.pre.npos != 0;
-        pat.general = pat.g.npos != 0;
-        pat.tail_nullable = pat.g.nullable;
+        pat.has_pre = pat.pre.npos != 0 || pat.pre.has_cond;
+        pat.general = pat.g.npos != 0 || pat.g.has_cond;
+        pat.tail_nullable = pat.g.nullable || pat.g.cnullable[0] || pat.g.cnullable[1];
         return pat;
     }
     /* a tail with a group in it goes to the position automaton; the linear form below stays the
      * path for everything it can express */
     bool grouped = false;
     for (size_t k = i; k < p.size() && !grouped; k++) {
-        if (p[k] == '\\') k++;
+        if (p[k] == '\\') { grouped = k + 1 < p.size() && (p[k + 1] == 'b' || p[k + 1] == 'B'); k++; }
         else if (p[k] == '[') { size_t e = k; parse_bracket_class(p, e); k = e - 1; }
         else if (p[k] == '(') grouped = true;
     }
     if (grouped) {
         pat.g = compile_auto(p.substr(i), pat.nocase, dotall);
-        pat.general = pat.g.npos != 0;
-        pat.tail_nullable = pat.g.nullable;
+        pat.general = pat.g.npos != 0 || pat.g.has_cond;
+        pat.tail_nullable = pat.g.nullable || pat.g.cnullable[0] || pat.g.cnullable[1];
         return pat;
     }
     const size_t tail_begin = i;
@@ -787,7 +838,7 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
             pat.tail.clear();
             pat.g = compile_auto(p.substr(tail_begin), pat.nocase, dotall);
             pat.general = true;
-            pat.tail_nullable = pat.g.nullable;
+            pat.tail_nullable = pat.g.nullable || pat.g.cnullable[0] || pat.g.cnullable[1];
             return pat;
         }
     }
@@ -872,7 +923,11 @@ void distribute_group(const std::string &b, unsigned flags, unsigned id, std::ve
             else if (b[j] == '|' && d == 1) { alts.push_back(b.substr(last, j - last)); last = j + 1; }
             else if (b[j] == ')' && --d == 0) { alts.push_back(b.substr(last, j - last)); break; }
         }
-        const size_t end = j + 1;
+        size_t end = j + 1;
+        if (plain && end < b.size() && b[end] == '?' && !(end + 1 < b.size() && b[end + 1] == '+')) {
+            alts.push_back(std::string()); /* (X)? is (X|): distributable too */
+            end += (end + 1 < b.size() && b[end + 1] == '?') ? 2 : 1;
+        }
         const bool quantified = end < b.size() && (b[end] == '?' || b[end] == '*' || b[end] == '+' || TailBuilder::is_repeat_at(b, end));
         if (!plain || quantified) { i = end; continue; }
         if (out.size() + alts.size() > kMaxBranches) throw ParseError{"Pattern too large."};
@@ -997,9 +1052,62 @@ struct TailNfa {
         return any != 0;
     }
 
+    /* ---- fragments with \b / \B inside: three layers of every set. Whether a layer applies is
+     * known once the bytes on both sides of a boundary are: N[0] always, N[1] across a word
+     * boundary, N[2] across a non-boundary. `dir` = +1 forwards from pos, -1 backwards. ---- */
+    static inline void step_layer(size_t W, const Bits &shift_ok, const Bits &exc, const std::vector<Bits> &exc_row,
+                                  const unsigned long long *cur, unsigned long long *next) {
+        unsigned long long carry = 0;
+        for (size_t w = 0; w < W; w++) {
+            const unsigned long long v = cur[w] & shift_ok[w];
+            next[w] = (v << 1) | carry;
+            carry = v >> 63;
+        }
+        for (size_t w = 0; w < W; w++)
+            for (unsigned long long e = cur[w] & exc[w]; e; e &= e - 1) {
+                const Bits &row = exc_row[w * 64 + __builtin_ctzll(e)];
+                for (size_t k = 0; k < W; k++) next[k] |= row[k];
+            }
+    }
+    /* on_accept(pos) for every boundary at which the fragment can end, nullable included; it returns
+     * false to stop. Forwards: pos runs up from `pos`; backwards: down. */
+    template <class F> static void run_cond(const Auto &a, const unsigned char *buf, size_t len, size_t pos, int dir, F on_accept) {
+        const size_t W = a.W;
+        auto boundary = [&](size_t at) {
+            return (at > 0 && is_word_byte(buf[at - 1])) != (at < len && is_word_byte(buf[at]));
+        };
+        bool bd = boundary(pos);
+        if (a.nullable || a.cnullable[bd ? 0 : 1]) { if (!on_accept(pos)) return; }
+        if (!a.npos) return;
+        unsigned long long cur[kMaxW], N0[kMaxW], N1[kMaxW], N2[kMaxW];
+        std::copy(a.first.begin(), a.first.end(), N0);
+        std::copy(a.cfirst[0].begin(), a.cfirst[0].end(), N1);
+        std::copy(a.cfirst[1].begin(), a.cfirst[1].end(), N2);
+        while (dir > 0 ? pos < len : pos > 0) {
+            const unsigned char c = dir > 0 ? buf[pos] : buf[pos - 1];
+            const unsigned long long *r = &a.reach[(size_t)c * W], *cond = bd ? N1 : N2;
+            unsigned long long any = 0;
+            for (size_t w = 0; w < W; w++) any |= cur[w] = (N0[w] | cond[w]) & r[w];
+            if (!any) return;
+            pos = dir > 0 ? pos + 1 : pos - 1;
+            bd = boundary(pos);
+            const Bits &cl = a.clast[bd ? 0 : 1];
+            unsigned long long hit = 0;
+            for (size_t w = 0; w < W; w++) hit |= cur[w] & (a.last[w] | cl[w]);
+            if (hit) { if (!on_accept(pos)) return; }
+            step_layer(W, a.shift_ok, a.exc, a.exc_row, cur, N0);
+            step_layer(W, a.cshift_ok[0], a.cexc[0], a.cexc_row[0], cur, N1);
+            step_layer(W, a.cshift_ok[1], a.cexc[1], a.cexc_row[1], cur, N2);
+        }
+    }
+
     /* R2 forwards from `pos`: the active set after byte c is (first | follow[active]) & reach[c];
      * a match ends wherever the set meets `last` */
     template <class F> static void run_general(const Auto &a, const unsigned char *buf, size_t len, size_t pos, F report) {
+        if (a.has_cond) {
+            run_cond(a, buf, len, pos, +1, report);
+            return;
+        }
         if (a.nullable) { if (!report(pos)) return; }
         if (a.W == 1) {
             unsigned long long next = a.first[0];
@@ -1028,6 +1136,15 @@ struct TailNfa {
             return (!p.bol || pos == 0 || (p.bol_ml && buf[pos - 1] == '\n')) && assert_ok(p.as_start, buf, len, pos);
         };
         bool found = false;
+        if (a.has_cond) {
+            run_cond(a, buf, len, start, -1, [&](size_t pos) {
+                if (!at_bol(pos)) return true;
+                found = true;
+                from = pos;
+                return leftmost;
+            });
+            return found;
+        }
         if (a.nullable && at_bol(start)) {
             found = true;
             from = start;

@@ -43,9 +43,9 @@
  * one shift for the chains, exception rows for the rest). Anchors and
  * assertions at the edges of a branch: `^` / \A in front, `$` / \z / \Z at the back (`$` and \Z
  * also before the data's final newline, reported before the newline as the reference does; with
- * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline), and \b / \B at the start,
- * at the end, and directly before or after the literal.
- * Anything else (branches without a mandatory top-level literal, anchors or assertions elsewhere,
+ * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline). \b / \B anywhere
+ * (inside a fragment they become conditional layers of its automaton).
+ * Anything else (branches without a mandatory literal, anchors away from the edges of a branch,
  * look-around, back-references, possessive quantifiers, options after the start, streaming
  * mode) is
  * rejected with HS_COMPILER_ERROR:

@@ -403,7 +403,7 @@ def test_word_boundaries_and_absolute_anchors():
     assert sorted(ev) == sorted(want)
     assert {e[1] for e in ev} == set(range(1, 14))
     import pytest
-    for bad in [r"c.\bt+x", r"(\bcat)+s", r"a\zb", r"\b", r"cat\b+"]:  # assertions elsewhere are refused
+    for bad in [r"a\zb", r"ca(\z)*t", r"\b", r"cat\b+"]:  # anchors inside, assertions alone or quantified at the literal
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
 
@@ -487,3 +487,22 @@ def test_literals_inside_an_alternation_group():
     for bad in [r"(foo|[a-z])x?", r"(foo|bar)?", r"(a|b)+", r"(?=foo|bar)"]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
+
+
+def test_word_boundaries_inside_fragments():
+    """\\b / \\B anywhere in R1 or R2: conditional layers of the position automaton"""
+    SOM, S = hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_DOTALL
+    exprs = [(r"foo.*\bbar", 0, 1), (r"foo\b.*\bbar\b", S, 2), (r"\w+\b\s+\bneedle", SOM, 3), (r"(\bcat|x)dog\B.", 0, 4),
+             (r"a(\b|c)d!", 0, 5), (r"key\b\b=\B\B-", 0, 6), (r"(?:\w\b.)+end", SOM, 7), (r"one(\b.|\B-)*two", S, 8),
+             (r"\d+\b\W*[a-z]*\Bzz9", SOM, 9)]
+    words = [b"foo", b"bar", b" ", b"x", b"needle", b"cat", b"dog", b"a", b"c", b"d!", b"key", b"=", b"v", b"-", b"end", b"one", b"two", b"12",
+             b"ab", b"zz9", b"\n", b"q", b"r", b"s", b"t", b"u", b"_", b"."]
+    rng = np.random.default_rng(83)
+    blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 13)))) for _ in range(300)]
+    blocks += [b"foo bar", b"foobar", b"foo xbar bar.", b"ab  needle", b"ab needlex", b"catdogs xdogs dog.", b"xcatdogs", b"ad! acd! a d!",
+               b"key=-v key =-", b"12 abzz9 7-azz9", b"a.b-end", b"ab.end", b"one - two", b"one--two", b"one-.-two", b"12abzz9", b"12 zz9", b"12azz9", b"qr stu st u"]
+    ev = run_exprs_auto(exprs, blocks)
+    want = brute_context(exprs, blocks)
+    assert sorted(ev) == sorted(want)
+    hit = {e[1] for e in ev}
+    assert hit >= {1, 2, 3, 4, 5, 6, 7, 8, 9}, hit
