@@ -132,6 +132,11 @@ ByteSet class_escape(char e, bool &ok) {
     case 'D': s = ~class_escape('d', ok); break;
     case 'W': s = ~class_escape('w', ok); break;
     case 'S': s = ~class_escape('s', ok); break;
+    /* src/parser/ComponentClass.cpp:87-88,114-115: horizontal / vertical white space */
+    case 'h': s.set(0x09); s.set(0x20); s.set(0xa0); break;
+    case 'H': s = ~class_escape('h', ok); break;
+    case 'v': s.set(0x0a); s.set(0x0b); s.set(0x0c); s.set(0x0d); s.set(0x85); break;
+    case 'V': s = ~class_escape('v', ok); break;
     default: ok = false;
     }
     return s;
@@ -145,10 +150,16 @@ bool char_escape(const std::string &p, size_t &i, unsigned char &out) {
     case 't': out = '\t'; i++; return true;
     case 'r': out = '\r'; i++; return true;
     case 'f': out = '\f'; i++; return true;
-    case 'v': out = '\v'; i++; return true;
     case 'a': out = 7; i++; return true;
     case 'e': out = 27; i++; return true;
-    case '0': out = 0; i++; return true;
+    case '0': { /* \0 and up to two more octal digits (Parser.rl:503) */
+        unsigned v = 0;
+        size_t k = i + 1;
+        for (int d = 0; d < 2 && k < p.size() && p[k] >= '0' && p[k] <= '7'; d++, k++) v = v * 8 + (p[k] - '0');
+        out = (unsigned char)v;
+        i = k;
+        return true;
+    }
     case 'x': {
         unsigned v = 0;
         for (int k = 1; k <= 2; k++) {
@@ -169,6 +180,19 @@ bool char_escape(const std::string &p, size_t &i, unsigned char &out) {
         i++;
         return true;
     }
+}
+
+/* an escaped single character inside a bracket class: everything char_escape knows, plus \b
+ * (backspace) and \ddd octal, which mean something else outside a class */
+bool class_char_escape(const std::string &p, size_t &i, unsigned char &out) {
+    if (i < p.size() && p[i] == 'b') { out = 8; i++; return true; }
+    if (i < p.size() && p[i] >= '1' && p[i] <= '7') {
+        unsigned v = 0;
+        for (int d = 0; d < 3 && i < p.size() && p[i] >= '0' && p[i] <= '7'; d++, i++) v = v * 8 + (p[i] - '0');
+        out = (unsigned char)v;
+        return true;
+    }
+    return char_escape(p, i, out);
 }
 
 ByteSet fold_case(const ByteSet &s) {
@@ -243,7 +267,7 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i) {
             } else {
                 size_t k = j + 1;
                 unsigned char lit;
-                if (!char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                if (!class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
                 lo = lit;
                 j = k;
             }
@@ -260,7 +284,7 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i) {
             if (p[j] == '\\') {
                 size_t k = j + 1;
                 unsigned char lit;
-                if (k >= p.size() || !char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                if (k >= p.size() || !class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
                 hi = lit;
                 j = k;
             } else {

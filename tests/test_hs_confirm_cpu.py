@@ -419,7 +419,9 @@ def test_lazy_quantifiers_inline_flags_named_groups_posix_classes():
              ((r"(?-i)Case[a-z]", I), (r"Case[a-z]", 0)), ((r"id=(?<num>\d+);", 0), (r"id=(\d+);", 0)),
              ((r"id=(?P<n>[a-f]+)(?#hex);", 0), (r"id=([a-f]+);", 0)),
              ((r"tag[[:digit:][:upper:]]+[[:^alnum:]]", 0), (r"tag[0-9A-Z]+[^0-9A-Za-z]", 0)),
-             ((r"[[:space:]]+key[[:punct:]]", 0), (r"\s+key[!-/:-@\[-`{-~]", 0)), ((r"(?m)^row\d$", 0), (r"^row\d$", M))]
+             ((r"[[:space:]]+key[[:punct:]]", 0), (r"\s+key[!-/:-@\[-`{-~]", 0)), ((r"(?m)^row\d$", 0), (r"^row\d$", M)),
+             # \h \v are classes (src/parser/ComponentClass.cpp:87-88,114-115), [\b] is a backspace, octal escapes
+             ((r"foo\h+bar\v", 0), (r"foo[\x09\x20\xa0]+bar[\x0a-\x0d\x85]", 0)), ((r"tag\H\V[\b\41-\43]\041\0", 0), (r"tag[^\x09\x20\xa0][^\x0a-\x0d\x85][\x08!-#]!\x00", 0))]
     exprs = [(h[0], h[1], i + 1) for i, (h, _p) in enumerate(pairs)]
     pyexprs = [(p[0], p[1], i + 1) for i, (_h, p) in enumerate(pairs)]
     words = [b"foo", b"bar", b"x", b"ab", b"a", b"b", b"c", b"d", b"e", b"SELECT", b"select", b" ", b"name", b"begin", b"\n", b"END",
@@ -427,7 +429,7 @@ def test_lazy_quantifiers_inline_flags_named_groups_posix_classes():
     rng = np.random.default_rng(52)
     blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 14)))) for _ in range(160)]
     blocks += [b"fooxbarxbar", b"abccdde abe ade", b"Select  x", b"BEGIN\n\nEnd", b"Casex CASEx", b"id=42;id=cafe;", b"tag7Q-", b" \tkey=",
-               b"row3\nrow4\nrow55\n"]
+               b"row3\nrow4\nrow55\n", b"foo \t\xa0bar\x85 foo bar\n foo  bar\x0b", b"tagxy\x08!\x00 tagzz#!\x00 tag z!!\x00 tagz\n!!\x00"]
     ev = run_exprs_auto(exprs, blocks)
     want = brute_context(pyexprs, blocks)
     assert sorted(ev) == sorted(want)

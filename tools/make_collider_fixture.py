@@ -72,7 +72,7 @@ def split_new_format(rest):
 
 def python_dialect(pat):
     """the same language in Python's re, or None when the dialects differ"""
-    if re.search(r"\{,|\\0\d|\\[1-9]|\\[eQEhHRNKGXCpPcgk]|\[:|\(\?[^:<#imsP-]|\(\?<[=!]|\\x\{|\(\*|\(\?[ims-]*x", pat):
+    if re.search(r"\{,|\\0\d|\\[1-9]|\\[eQEhHvVRNKGXCpPcgko]|\[:|\(\?[^:<#imsP-]|\(\?<[=!]|\\x\{|\(\*|\(\?[ims-]*x", pat):
         return None
     if re.search(r"(?<!^)\(\?[ims-]+\)", pat):  # options after the start
         return None
