@@ -112,10 +112,14 @@ struct Pattern {
 struct ParseError {
     std::string msg;
 };
+struct NeverMatch : ParseError { /* well-formed, but its language is empty: the branch is dropped */
+    NeverMatch() : ParseError{"Pattern can never match."} {}
+};
 struct NoLiteral : ParseError { /* the branch is well-formed but offers no top-level literal */
     NoLiteral() : ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."} {}
 };
 
+bool is_word_char(unsigned char c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
 bool is_alpha(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
 
 void add_range(ByteSet &s, unsigned lo, unsigned hi) {
@@ -246,6 +250,9 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i) {
         ByteSet item;
         unsigned lo;
         bool is_class = false;
+        if (p[j] == '[' && j + 1 < p.size() && (p[j + 1] == '.' || p[j + 1] == '=') &&
+            p.find(std::string(1, p[j + 1]) + "]", j + 2) != std::string::npos)
+            throw ParseError{"Unsupported POSIX collating element."};
         if (p[j] == '[' && j + 1 < p.size() && p[j + 1] == ':') { /* [:alpha:] and friends */
             const size_t e = p.find(":]", j + 2);
             if (e == std::string::npos) throw ParseError{"Unterminated POSIX class."};
@@ -281,6 +288,7 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i) {
         unsigned hi = lo;
         if (j + 1 < p.size() && p[j] == '-' && p[j + 1] != ']') {
             j++;
+            if (p[j] == '[' && j + 1 < p.size() && p[j + 1] == ':') throw ParseError{"Invalid range in character class."};
             if (p[j] == '\\') {
                 size_t k = j + 1;
                 unsigned char lit;
@@ -332,6 +340,21 @@ struct TailBuilder {
 
     static unsigned long long add_w(unsigned long long a, unsigned long long b) {
         return (a == kInf64 || b == kInf64) ? kInf64 : a + b;
+    }
+    /* can an edge x -> y under condition c (1 = \b, 2 = \B) ever be taken? not when both classes
+     * sit wholly on one side of the word / non-word divide in the wrong way */
+    bool edge_possible(int c, size_t x, size_t y) const {
+        if (c == 0) return true;
+        static const ByteSet word = [] {
+            ByteSet w;
+            for (unsigned b = 0; b < 256; b++)
+                if (is_word_char((unsigned char)b)) w.set(b);
+            return w;
+        }();
+        const bool xw = (cls[x] & word).any(), xn = (cls[x] & ~word).any();
+        const bool yw = (cls[y] & word).any(), yn = (cls[y] & ~word).any();
+        const bool can_differ = (xw && yn) || (xn && yw), can_agree = (xw && yw) || (xn && yn);
+        return c == 1 ? can_differ : can_agree;
     }
     unsigned new_pos(const ByteSet &c) {
         if (cls.size() >= kMaxPositions) throw ParseError{"Pattern too large."};
@@ -578,7 +601,7 @@ Auto finish_auto(const TailBuilder &tb, const Frag &f, bool reversed) {
         std::vector<Bits> follow(n, Bits(W, 0));
         for (size_t x = 0; x < n; x++)
             for (size_t y = 0; y < n; y++)
-                if (bits_test(tb.follow[layer][x], y)) {
+                if (bits_test(tb.follow[layer][x], y) && tb.edge_possible(layer, x, y)) {
                     if (reversed) bits_set(follow[idx(y)], idx(x));
                     else bits_set(follow[x], y);
                 }
@@ -608,11 +631,40 @@ Auto finish_auto(const TailBuilder &tb, const Frag &f, bool reversed) {
     return a;
 }
 
+/* is anything in the fragment's language? (an empty class, or stacked contradictory assertions,
+ * can leave none: the reference refuses such patterns, "Pattern can never match.") */
+bool language_nonempty(const TailBuilder &tb, const Frag &f) {
+    if (f.nullmask) return true;
+    const size_t n = tb.cls.size();
+    std::vector<char> seen(n, 0);
+    std::vector<size_t> todo;
+    auto visit = [&](size_t x) {
+        if (!seen[x] && tb.cls[x].any()) {
+            seen[x] = 1;
+            todo.push_back(x);
+        }
+    };
+    for (int c = 0; c < 3; c++)
+        for (size_t x = 0; x < n; x++)
+            if (bits_test(f.first[c], x)) visit(x);
+    while (!todo.empty()) {
+        const size_t x = todo.back();
+        todo.pop_back();
+        for (int c = 0; c < 3; c++) {
+            if (bits_test(f.last[c], x)) return true;
+            for (size_t y = 0; y < n; y++)
+                if (bits_test(tb.follow[c][x], y) && tb.edge_possible(c, x, y)) visit(y);
+        }
+    }
+    return false;
+}
+
 Auto compile_auto(const std::string &src, bool nocase, bool dotall, bool reversed = false) {
     TailBuilder tb{src, nocase, dotall, {}, {}, false};
     size_t i = 0;
     const Frag f = tb.parse_cat(i, 0);
     if (i < src.size()) throw ParseError{"Unmatched closing parenthesis."};
+    if (!language_nonempty(tb, f)) throw NeverMatch();
     return finish_auto(tb, f, reversed);
 }
 
@@ -731,6 +783,8 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
         pat.as_start = assertion(p[1]);
         p.erase(0, 2);
     }
+    if (!p.empty() && (strchr("*+?", p[0]) || TailBuilder::is_repeat_at(p, 0)))
+        throw ParseError{"Invalid repeat."}; /* a quantifier needs something that consumes bytes before it */
     /* back: $, \z or \Z, before it \b / \B */
     if (!p.empty() && p.back() == '$' && !escape_at(p.size() - 2, "$")) {
         pat.eol = pat.eol_nl = true;
@@ -766,8 +820,26 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     if (escape_at(run.end, "bB")) {
         pat.as_lit_post = assertion(p[run.end + 1]);
         r2_begin += 2;
+        if (r2_begin < p.size() && (strchr("*+?", p[r2_begin]) || TailBuilder::is_repeat_at(p, r2_begin)))
+            throw ParseError{"Invalid repeat."};
     }
     pat.lit = run.bytes;
+    if (pat.bol && !pat.bol_ml && r1_end == 0) {
+        /* the match starts at offset 0: what is in front is not a word byte */
+        const unsigned char k = pat.as_start ? pat.as_start : pat.as_lit_pre;
+        if (k && (is_word_char((unsigned char)pat.lit[0]) != (k == 1))) throw NeverMatch();
+    }
+    if (pat.as_start && pat.as_lit_pre && r1_end == 0 && pat.as_start != pat.as_lit_pre)
+        throw NeverMatch();
+    if (pat.as_end && pat.as_lit_post && r2_begin == p.size() && pat.as_end != pat.as_lit_post)
+        throw NeverMatch();
+    if (pat.as_lit_post && r2_begin < p.size() && !strchr("\\.[]()|^$*+?{", p[r2_begin]) &&
+        !(r2_begin + 1 < p.size() && (strchr("*+?", p[r2_begin + 1]) || TailBuilder::is_repeat_at(p, r2_begin + 1)))) {
+        /* literal, assertion, plain character: both neighbours of the boundary are known */
+        unsigned char nx = (unsigned char)p[r2_begin];
+        const bool differ = is_word_char((unsigned char)pat.lit.back()) != is_word_char(nx);
+        if (differ != (pat.as_lit_post == 1)) throw NeverMatch();
+    }
     size_t i = r2_begin;
     if (r1_end != 0) {
         /* the literal is not at the front: R1 backwards, R2 as a position automaton */
@@ -851,6 +923,7 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
             if (i < p.size() && p[i] == '?') i++; /* lazy: immaterial, as above */
             else if (i < p.size() && p[i] == '+') throw ParseError{"Possessive quantifiers are not supported."};
         }
+        if (lo > 0 && cls.none()) throw NeverMatch();
         for (unsigned k = 0; k < lo; k++) pat.tail.push_back(Unit{cls, false, false});
         if (hi == kInf) {
             if (lo == 0) pat.tail.push_back(Unit{cls, true, true});
@@ -887,6 +960,8 @@ void expand_branch(const std::string &b, unsigned flags, unsigned id, std::vecto
     try {
         whole = parse_branch(b, flags, id);
         have = true;
+    } catch (const NeverMatch &) {
+        throw;
     } catch (const NoLiteral &) {
         if (depth >= 8) throw;
     } catch (const ParseError &first) {
@@ -954,8 +1029,17 @@ void distribute_group(const std::string &b, unsigned flags, unsigned id, std::ve
         }
         const bool quantified = end < b.size() && (b[end] == '?' || b[end] == '*' || b[end] == '+' || TailBuilder::is_repeat_at(b, end));
         if (!plain || quantified) { i = end; continue; }
+        for (const std::string &a : alts) /* "(*VERB)", "(+x)": not ours to rearrange */
+            if (!a.empty() && (strchr("*+?", a[0]) || TailBuilder::is_repeat_at(a, 0))) throw NoLiteral();
         if (out.size() + alts.size() > kMaxBranches) throw ParseError{"Pattern too large."};
-        for (const std::string &a : alts) expand_branch(b.substr(0, i) + a + b.substr(end), flags, id, out, depth + 1);
+        const size_t before = out.size();
+        for (const std::string &a : alts) {
+            try {
+                expand_branch(b.substr(0, i) + a + b.substr(end), flags, id, out, depth + 1);
+            } catch (const NeverMatch &) { /* this product contributes nothing */
+            }
+        }
+        if (out.size() == before) throw NeverMatch();
         return;
     }
     throw NoLiteral();
@@ -1005,9 +1089,13 @@ std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsi
             if (c == ')') depth--;
             if (c != '|' || depth != 0) continue;
         }
-        expand_branch(p.substr(from, k - from), flags, id, out, 0);
+        try {
+            expand_branch(p.substr(from, k - from), flags, id, out, 0);
+        } catch (const NeverMatch &) { /* an alternative that cannot match is dropped; all of them: an error */
+        }
         from = k + 1;
     }
+    if (out.empty()) throw NeverMatch();
     for (Pattern &b : out) b.quiet = flags & HS_FLAG_QUIET;
     return out;
 }
@@ -1302,6 +1390,58 @@ void apply_ext(Pattern &p, const hs_expr_ext_t &e) {
     p.min_length = e.min_length;
 }
 
+/* width of one branch as written (no ext parameters): [lo, hi], hi meaningless when inf */
+void raw_widths(const Pattern &p, unsigned long long &lo, unsigned long long &hi, bool &inf) {
+    lo = hi = p.lit.size();
+    inf = false;
+    for (const Unit &u : p.tail) {
+        lo += u.optional ? 0 : 1;
+        hi += 1;
+        inf |= u.star;
+    }
+    if (p.general) {
+        lo += p.g.wmin;
+        inf |= p.g.wmax == kInf64;
+        if (p.g.wmax != kInf64) hi += p.g.wmax;
+    }
+    if (p.has_pre) {
+        lo += p.pre.wmin;
+        inf |= p.pre.wmax == kInf64;
+        if (p.pre.wmax != kInf64) hi += p.pre.wmax;
+    }
+}
+
+/* ext parameters no match could satisfy, with the reference's messages
+ * (propagateExtendedParams, src/nfagraph/ng_extparam.cpp:871-905) */
+void check_ext_widths(const Pattern *b, size_t n, const hs_expr_ext_t &e) {
+    unsigned long long minw = kInf64, maxw = 0;
+    bool unbounded = false, anchored = true;
+    for (size_t k = 0; k < n; k++) {
+        unsigned long long lo, hi;
+        bool inf;
+        raw_widths(b[k], lo, hi, inf);
+        minw = std::min(minw, lo);
+        maxw = std::max(maxw, hi);
+        unbounded |= inf;
+        anchored &= b[k].bol && !b[k].bol_ml;
+    }
+    char msg[200];
+    if ((e.flags & HS_EXT_FLAG_MIN_OFFSET) && anchored && !unbounded && e.min_offset > maxw) {
+        snprintf(msg, sizeof(msg), "Expression is anchored and cannot satisfy min_offset=%llu as it can only produce matches "
+                 "of length %llu bytes at most.", e.min_offset, maxw);
+        throw ParseError{msg};
+    }
+    if ((e.flags & HS_EXT_FLAG_MAX_OFFSET) && minw > e.max_offset) {
+        snprintf(msg, sizeof(msg), "Expression has max_offset=%llu but requires %llu bytes to match.", e.max_offset, minw);
+        throw ParseError{msg};
+    }
+    if ((e.flags & HS_EXT_FLAG_MIN_LENGTH) && !unbounded && maxw < e.min_length) {
+        snprintf(msg, sizeof(msg), "Expression has min_length=%llu but can only produce matches of length %llu bytes at most.",
+                 e.min_length, maxw);
+        throw ParseError{msg};
+    }
+}
+
 hs_error_t build_database(const std::vector<std::string> &exprs, const std::vector<unsigned char> &is_lit,
                           const unsigned *flags, const unsigned *ids, const hs_expr_ext_t *const *ext, unsigned mode,
                           hs_database_t **db, hs_compile_error_t **error) {
@@ -1361,6 +1501,8 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                     if (ext && ext[i]) apply_ext(d->pats[k], *ext[i]);
                     finish_pattern(d->pats[k]);
                 }
+                if (ext && ext[i] && !is_lit[i])
+                    check_ext_widths(&d->pats[first_of_expr], d->pats.size() - first_of_expr, *ext[i]);
             } catch (const ParseError &pe) {
                 *error = make_error(pe.msg, (int)i);
                 destroy_db(d);
@@ -1831,8 +1973,10 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
     std::vector<Pattern> branches;
     try {
         branches = parse_pattern(expression, flags, 0);
-        if (ext)
+        if (ext) {
             for (Pattern &b : branches) apply_ext(b, *ext);
+            check_ext_widths(branches.data(), branches.size(), *ext);
+        }
     } catch (const ParseError &pe) {
         *error = make_error(pe.msg, 0);
         return HS_COMPILER_ERROR;
@@ -1840,23 +1984,9 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
     unsigned long long minw = kInf64, maxw = 0;
     bool unbounded = false, any_eol = false, all_eol = true, eol_multiline = false, unordered = false, at_eod = false;
     for (const Pattern &p : branches) {
-        unsigned long long lo = p.lit.size(), hi = p.lit.size();
-        bool inf = false;
-        for (const Unit &u : p.tail) {
-            lo += u.optional ? 0 : 1;
-            hi += 1;
-            inf |= u.star;
-        }
-        if (p.general) {
-            lo += p.g.wmin;
-            inf = p.g.wmax == kInf64;
-            if (!inf) hi += p.g.wmax;
-        }
-        if (p.has_pre) {
-            lo += p.pre.wmin;
-            inf |= p.pre.wmax == kInf64;
-            if (p.pre.wmax != kInf64) hi += p.pre.wmax;
-        }
+        unsigned long long lo, hi;
+        bool inf;
+        raw_widths(p, lo, hi, inf);
         if (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) lo = std::max(lo, p.min_length);
         if (p.ext_flags & HS_EXT_FLAG_MAX_OFFSET) {
             hi = inf ? p.max_offset : std::min(hi, p.max_offset);

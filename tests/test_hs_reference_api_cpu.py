@@ -148,3 +148,35 @@ def test_quiet_prefilter_allowempty_flags():
                hs.HS_FLAG_PREFILTER | hs.HS_FLAG_SOM_LEFTMOST):
         with pytest.raises(hs.HsError):
             hs.Database.compile(["foo"], [fl], [1])
+
+
+def test_bad_patterns_txt_are_all_refused():
+    """unit/hyperscan/bad_patterns.txt (tests/golden/bad_patterns.json): every pattern the reference
+    refuses to compile is refused here too; where the reason is one this engine reasons about the
+    same way (ext parameters against the pattern's widths, patterns that can never match), with
+    the reference's message."""
+    import json
+    import os
+
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bad_patterns.json")))["rows"]
+    assert len(rows) >= 150
+    letters = {"i": hs.HS_FLAG_CASELESS, "s": hs.HS_FLAG_DOTALL, "m": hs.HS_FLAG_MULTILINE, "H": hs.HS_FLAG_SINGLEMATCH,
+               "L": hs.HS_FLAG_SOM_LEFTMOST, "V": hs.HS_FLAG_ALLOWEMPTY, "8": hs.HS_FLAG_UTF8, "W": hs.HS_FLAG_UCP,
+               "P": hs.HS_FLAG_PREFILTER, "C": hs.HS_FLAG_COMBINATION, "Q": hs.HS_FLAG_QUIET, "O": 0}
+    same_message = 0
+    for r in rows:
+        flags = 0
+        for ch in r["flags"]:
+            flags |= letters[ch]
+        ext = None
+        if r["ext"]:
+            known = {k: v for k, v in r["ext"].items() if k in ("min_offset", "max_offset", "min_length")}
+            if len(known) != len(r["ext"]):
+                continue  # edit_distance / hamming_distance rows: refused wholesale, nothing to compare
+            ext = hs.ExprExt.make(**known)
+        with pytest.raises(hs.HsError) as e:
+            hs.Database.compile_ext([bytes.fromhex(r["pattern_hex"])], [flags], [r["id"]], [ext])
+        assert e.value.code == hs.HS_COMPILER_ERROR
+        if r["message"].startswith(("Expression has m", "Expression is anchored", "Pattern can never match")):
+            same_message += e.value.message == r["message"]
+    assert same_message >= 12, same_message
