@@ -180,3 +180,20 @@ def test_bad_patterns_txt_are_all_refused():
         if r["message"].startswith(("Expression has m", "Expression is anchored", "Pattern can never match")):
             same_message += e.value.message == r["message"]
     assert same_message >= 12, same_message
+
+
+def test_extparam_cpp():
+    # unit/hyperscan/extparam.cpp:40-160: large min_offset, exact offset window, large min_length
+    def scan(ext, corpus):
+        db = hs.Database.compile_ext(["hatstand.*teakettle"], [0], [0], [hs.ExprExt.make(**ext)])
+        return to_id(cpu_scan(db, corpus)[0])
+
+    u = lambda n: b"_" * n  # noqa: E731
+    assert scan(dict(min_offset=100000), b"hatstand" + u(80000) + b"teakettle") == []                      # LargeMinOffset
+    assert scan(dict(min_offset=100000), b"hatstand" + u(99983) + b"teakettle") == [(100000, 0)]
+    exact = dict(min_offset=200000, max_offset=200000)                                                         # LargeExactOffset
+    assert scan(exact, b"hatstand" + u(199982) + b"teakettle") == []
+    assert scan(exact, b"hatstand" + u(199983) + b"teakettle") == [(200000, 0)]
+    assert scan(exact, b"hatstand" + u(199984) + b"teakettle") == []
+    assert scan(dict(min_length=100000), u(10000) + b"hatstand" + u(80000) + b"teakettle") == []            # LargeMinLength
+    assert scan(dict(min_length=100000), u(10000) + b"hatstand" + u(99983) + b"teakettle") == [(110000, 0)]
