@@ -2212,6 +2212,7 @@ hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int lengt
                    hs_scratch_t *scratch, match_event_handler onEvent, void *context) {
     if (!scratch || !data) return HS_INVALID; /* src/runtime.c:320-322 */
     if (!db || db->magic != 0x48534744) return HS_INVALID;
+    if (db->mode != HS_MODE_BLOCK) return HS_DB_MODE_ERROR; /* src/runtime.c:334-336 */
     struct Ctx { match_event_handler cb; void *user; } c{onEvent, context};
     const unsigned long long off[2] = {0, length};
     if (length < db->min_width) { /* src/runtime.c:346-350 */
