@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <unordered_map>
 
@@ -150,10 +151,13 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 } // namespace
 
+/* Adler-32 over the whole image, the header included (its checksum field read as zero): a
+ * damaged geometry field must not get as far as the device */
 uint32_t hsgpu_blob_checksum(const uint8_t *blob, size_t len) {
     uint32_t a = 1, b = 0;
-    for (size_t i = sizeof(HsgpuTableHeader); i < len; i++) {
-        a = (a + blob[i]) % 65521u;
+    const size_t c0 = offsetof(HsgpuTableHeader, checksum), c1 = c0 + sizeof(uint32_t);
+    for (size_t i = 0; i < len; i++) {
+        a = (a + ((i >= c0 && i < c1) ? 0u : blob[i])) % 65521u;
         b = (b + a) % 65521u;
     }
     return (b << 16) | a;
@@ -378,6 +382,8 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     memcpy(blob.data() + h.off_c2ref, c2ref.data(), c2ref.size() * 4);
     memcpy(blob.data() + h.off_lists, lists.data(), lists.size() * 4);
     memcpy(blob.data() + h.off_lits, dl.data(), n * sizeof(HsgpuDevLit));
+    h.checksum = 0;
+    memcpy(blob.data(), &h, sizeof(h));
     h.checksum = hsgpu_blob_checksum(blob.data(), blob.size());
     memcpy(blob.data(), &h, sizeof(h));
     return HSGPU_SUCCESS;

@@ -1444,7 +1444,8 @@ void check_ext_widths(const Pattern *b, size_t n, const hs_expr_ext_t &e) {
 
 hs_error_t build_database(const std::vector<std::string> &exprs, const std::vector<unsigned char> &is_lit,
                           const unsigned *flags, const unsigned *ids, const hs_expr_ext_t *const *ext, unsigned mode,
-                          hs_database_t **db, hs_compile_error_t **error) {
+                          hs_database_t **db, hs_compile_error_t **error,
+                          const std::vector<unsigned char> *gpu_table = nullptr) {
     /* checkMode, src/hs.cpp:78-118: the reference's rules and messages first, then ours */
     const unsigned som_modes = HS_MODE_SOM_HORIZON_LARGE | HS_MODE_SOM_HORIZON_MEDIUM | HS_MODE_SOM_HORIZON_SMALL;
     const unsigned scan_modes = mode & (HS_MODE_BLOCK | HS_MODE_STREAM | HS_MODE_VECTORED);
@@ -1528,7 +1529,9 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
             if (p.has_pre) w += p.pre.wmin;
             d->min_width = std::min(d->min_width, w);
         }
-        int rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
+        /* a deserialised database brings its GPU table along: no literal compile on load */
+        int rv = gpu_table && !gpu_table->empty() ? hsgpu_hwlm_deserialize(gpu_table->data(), gpu_table->size(), &d->hwlm)
+                                                  : hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
         if (rv != HSGPU_SUCCESS) {
             *error = make_error(hsgpu_last_error(), -1);
             destroy_db(d);
@@ -1545,11 +1548,12 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
     for (size_t i = 0; i < exprs.size(); i++) {
         d->src_flags.push_back(flags ? flags[i] : 0);
         d->src_ids.push_back(ids ? ids[i] : 0);
-        if (d->pats[i].single) d->single_ids.insert(d->pats[i].id);
         hs_expr_ext_t none;
         memset(&none, 0, sizeof(none));
         d->src_ext.push_back(ext && ext[i] ? *ext[i] : none);
     }
+    for (const Pattern &p : d->pats) /* (an expression may have several branches: walk the branches) */
+        if (p.single) d->single_ids.insert(p.id);
     *db = d;
     *error = nullptr;
     return HS_SUCCESS;
@@ -1792,11 +1796,12 @@ hs_error_t hs_database_info(const hs_database_t *db, char **info) {
 }
 
 /* serialised form: magic "HSGF", CRC-32 of everything after it, count, then per pattern
- * (top bit: vectored mode) {is_lit, flags, id, len, ext flags, min_offset, max_offset, min_length, bytes} -- the
- * database is rebuilt from its sources on load (compilation is cheap for this engine; the
- * GPU table is rebuilt with it). The reference guards its bytecode with a CRC too
+ * (top bit: vectored mode) {is_lit, flags, id, len, ext flags, min_offset, max_offset, min_length, bytes},
+ * then the GPU table section {u64 length, the hsgpu_hwlm_serialize image}. On load the host
+ * automata are rebuilt from the sources (microseconds each) and the GPU table is taken from its
+ * section as it is. The reference guards its bytecode with a CRC too
  * (src/database.c:119-168): a damaged blob is HS_INVALID, never a different database. */
-static const unsigned kSerialMagic = 0x48534746;
+static const unsigned kSerialMagic = 0x48534747; /* "HSGG": version 2 = sources + GPU table section */
 static const unsigned kSerialVectored = 0x80000000u; /* top bit of the count word: HS_MODE_VECTORED */
 
 static unsigned crc32_of(const unsigned char *p, size_t n) {
@@ -1834,6 +1839,14 @@ hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *
         put64(db->src_ext[i].min_length);
         out += db->sources[i];
     }
+    /* the GPU literal table, as hsgpu_hwlm_serialize writes it: a deserialised database scans
+     * without compiling its literals again */
+    size_t tlen = 0;
+    if (hsgpu_hwlm_serialize(db->hwlm, nullptr, 0, &tlen) != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
+    std::string table(tlen, '\0');
+    if (hsgpu_hwlm_serialize(db->hwlm, &table[0], table.size(), &tlen) != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
+    put64(tlen);
+    out += table;
     const unsigned crc = crc32_of((const unsigned char *)out.data() + 8, out.size() - 8);
     memcpy(&out[4], &crc, 4);
     *bytes = (char *)hook_alloc(g_misc, out.size());
@@ -1854,6 +1867,7 @@ struct Serial {
     std::vector<unsigned> flags, ids;
     std::vector<hs_expr_ext_t> ext;
     unsigned mode = HS_MODE_BLOCK;
+    std::vector<unsigned char> table; /* the GPU table section */
 };
 hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
     if (!bytes) return HS_INVALID;
@@ -1895,6 +1909,10 @@ hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
         out.ids.push_back(id);
         out.ext.push_back(e);
     }
+    unsigned long long tlen = 0;
+    if (!get64(tlen) || tlen > length - off) return HS_INVALID;
+    out.table.assign((const unsigned char *)bytes + off, (const unsigned char *)bytes + off + tlen);
+    off += tlen;
     return off == length ? HS_SUCCESS : HS_INVALID;
 }
 } // namespace
@@ -1907,7 +1925,7 @@ hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_da
     std::vector<const hs_expr_ext_t *> ext;
     for (const hs_expr_ext_t &e : sr.ext) ext.push_back(e.flags ? &e : nullptr);
     hs_compile_error_t *err = nullptr;
-    hs_error_t rv = build_database(sr.ex, sr.is_lit, sr.flags.data(), sr.ids.data(), ext.data(), sr.mode, db, &err);
+    hs_error_t rv = build_database(sr.ex, sr.is_lit, sr.flags.data(), sr.ids.data(), ext.data(), sr.mode, db, &err, &sr.table);
     hs_free_compile_error(err);
     return rv == HS_SUCCESS ? HS_SUCCESS : HS_INVALID;
 }

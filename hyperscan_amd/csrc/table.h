@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 5u
+#define HSGPU_TABLE_VERSION 6u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */

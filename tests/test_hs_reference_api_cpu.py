@@ -197,3 +197,36 @@ def test_extparam_cpp():
     assert scan(exact, b"hatstand" + u(199984) + b"teakettle") == []
     assert scan(dict(min_length=100000), u(10000) + b"hatstand" + u(80000) + b"teakettle") == []            # LargeMinLength
     assert scan(dict(min_length=100000), u(10000) + b"hatstand" + u(99983) + b"teakettle") == [(110000, 0)]
+
+
+def test_serialised_database_carries_the_gpu_table():
+    """hs_serialize_database = sources + the GPU literal table image: loading takes
+    the table from its section instead of compiling the literals again, and the result scans alike"""
+    import struct
+    import zlib
+
+    pats = ["alpha\\d+", "bet(a|o)x", "\\bgamma\\b|delta$"]
+    db = hs.Database.compile(pats, [0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_SINGLEMATCH], [7, 8, 9])
+    blob = db.serialize()
+    lits = [H.HwlmLiteral(b, nocase=nc, id=i) for i, (b, nc, _r) in enumerate(db.literals())]
+    image = H.hwlm_build(lits).serialize()
+    at = blob.find(image)
+    assert at > 0 and struct.unpack_from("<Q", blob, at - 8)[0] == len(image) and at + len(image) == len(blob)
+    db2 = hs.Database.deserialize(blob)
+    data = b"alpha12 BETAX betox gamma gammas delta\n delta"
+    assert cpu_scan(db2, data) == cpu_scan(db, data) and len(cpu_scan(db, data)[0]) == 5
+    assert db2.literals() == db.literals() and db2.serialize() == blob
+    # a damaged table section with a CRC made to fit: the table's own validation refuses it
+    bad = bytearray(blob)
+    bad[at + 40] ^= 0xFF  # a geometry field of the table header
+    struct.pack_into("<I", bad, 4, zlib.crc32(bytes(bad[8:])) & 0xFFFFFFFF)
+    with pytest.raises(hs.HsError):
+        hs.Database.deserialize(bytes(bad))
+
+
+def test_singlematch_with_branches_in_other_expressions():
+    # the exhaustion set is keyed by report id over all branches, wherever their expression sits
+    ONE = hs.HS_FLAG_SINGLEMATCH
+    db = hs.Database.compile(["cat|dog", "emu", "fox|gnu|ibis"], [0, ONE, ONE], [1, 2, 3])
+    ev = to_id(cpu_scan(db, b"cat emu dog emu fox gnu ibis emu cat")[0])
+    assert ev == [(3, 1), (7, 2), (11, 1), (19, 3), (36, 1)]
