@@ -1,0 +1,1042 @@
+/*
+ * hs_pattern.cpp -- pattern compiler of the hs_* facade: an expression becomes branches
+ * R1 LIT R2 around a mandatory literal (the subset of src/parser/ + src/nfagraph/ this engine
+ * needs; the Ragel parser and the graph compiler proper are out of scope, SURVEY.md section 2
+ * rows 11-15).
+ *
+ *   parse_pattern        top-level alternation, leading (?ims) options, never-matching branches
+ *   expand_branch /      literals inside unquantified groups: X(A|B)Y -> XAY|XBY (what Rose gets
+ *   distribute_group     by cutting the graph at the alternation)
+ *   parse_branch         anchors and edge assertions, the longest top-level literal run,
+ *                        R1 / R2 as fragments
+ *   TailBuilder          fragment -> Glushkov position automaton, with \b / \B as conditions
+ *   finish_auto          -> LimEx shape (shift + exception rows), reversed for R1
+ */
+#include "../../include/hs_gpu.h"
+#include "hs_pattern.h"
+
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace hsf {
+
+bool is_word_char(unsigned char c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
+bool is_alpha(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+void add_range(ByteSet &s, unsigned lo, unsigned hi) {
+    for (unsigned c = lo; c <= hi && c < 256; c++) s.set(c);
+}
+
+ByteSet class_escape(char e, bool &ok) {
+    ByteSet s;
+    ok = true;
+    switch (e) {
+    case 'd': add_range(s, '0', '9'); break;
+    case 'w': add_range(s, '0', '9'); add_range(s, 'a', 'z'); add_range(s, 'A', 'Z'); s.set('_'); break;
+    case 's': s.set(' '); s.set('\t'); s.set('\n'); s.set('\r'); s.set('\f'); s.set('\v'); break;
+    case 'D': s = ~class_escape('d', ok); break;
+    case 'W': s = ~class_escape('w', ok); break;
+    case 'S': s = ~class_escape('s', ok); break;
+    /* src/parser/ComponentClass.cpp:87-88,114-115: horizontal / vertical white space */
+    case 'h': s.set(0x09); s.set(0x20); s.set(0xa0); break;
+    case 'H': s = ~class_escape('h', ok); break;
+    case 'v': s.set(0x0a); s.set(0x0b); s.set(0x0c); s.set(0x0d); s.set(0x85); break;
+    case 'V': s = ~class_escape('v', ok); break;
+    default: ok = false;
+    }
+    return s;
+}
+
+/* a single escaped literal character: \n \t \r \f \v \a \e \0 \xHH \\ \. etc. */
+bool char_escape(const std::string &p, size_t &i, unsigned char &out) {
+    char e = p[i];
+    switch (e) {
+    case 'n': out = '\n'; i++; return true;
+    case 't': out = '\t'; i++; return true;
+    case 'r': out = '\r'; i++; return true;
+    case 'f': out = '\f'; i++; return true;
+    case 'a': out = 7; i++; return true;
+    case 'e': out = 27; i++; return true;
+    case '0': { /* \0 and up to two more octal digits (Parser.rl:503) */
+        unsigned v = 0;
+        size_t k = i + 1;
+        for (int d = 0; d < 2 && k < p.size() && p[k] >= '0' && p[k] <= '7'; d++, k++) v = v * 8 + (p[k] - '0');
+        out = (unsigned char)v;
+        i = k;
+        return true;
+    }
+    case 'x': {
+        unsigned v = 0;
+        for (int k = 1; k <= 2; k++) {
+            if (i + k >= p.size()) return false;
+            char h = p[i + k];
+            unsigned d = (h >= '0' && h <= '9') ? h - '0' : (h >= 'a' && h <= 'f') ? h - 'a' + 10
+                         : (h >= 'A' && h <= 'F') ? h - 'A' + 10 : 99;
+            if (d == 99) return false;
+            v = v * 16 + d;
+        }
+        out = (unsigned char)v;
+        i += 3;
+        return true;
+    }
+    default:
+        if ((e >= 'a' && e <= 'z') || (e >= 'A' && e <= 'Z') || (e >= '1' && e <= '9')) return false;
+        out = (unsigned char)e;
+        i++;
+        return true;
+    }
+}
+
+/* an escaped single character inside a bracket class: everything char_escape knows, plus \b
+ * (backspace) and \ddd octal, which mean something else outside a class */
+bool class_char_escape(const std::string &p, size_t &i, unsigned char &out) {
+    if (i < p.size() && p[i] == 'b') { out = 8; i++; return true; }
+    if (i < p.size() && p[i] >= '1' && p[i] <= '7') {
+        unsigned v = 0;
+        for (int d = 0; d < 3 && i < p.size() && p[i] >= '0' && p[i] <= '7'; d++, i++) v = v * 8 + (p[i] - '0');
+        out = (unsigned char)v;
+        return true;
+    }
+    return char_escape(p, i, out);
+}
+
+ByteSet fold_case(const ByteSet &s) {
+    ByteSet o = s;
+    for (unsigned c = 'a'; c <= 'z'; c++)
+        if (s[c] || s[c - 32]) {
+            o.set(c);
+            o.set(c - 32);
+        }
+    return o;
+}
+
+/* [:name:] inside a bracket class (PCRE's set, ASCII semantics) */
+bool posix_class(const std::string &name, ByteSet &s) {
+    auto fill = [&](int (*fn)(int)) {
+        for (unsigned c = 0; c < 128; c++)
+            if (fn((int)c)) s.set(c);
+        return true;
+    };
+    if (name == "alpha") return fill(isalpha);
+    if (name == "digit") return fill(isdigit);
+    if (name == "alnum") return fill(isalnum);
+    if (name == "upper") return fill(isupper);
+    if (name == "lower") return fill(islower);
+    if (name == "space") return fill(isspace);
+    if (name == "blank") { s.set(' '); s.set('\t'); return true; }
+    if (name == "punct") return fill(ispunct);
+    if (name == "print") return fill(isprint);
+    if (name == "graph") return fill(isgraph);
+    if (name == "cntrl") return fill(iscntrl);
+    if (name == "xdigit") return fill(isxdigit);
+    if (name == "ascii") { add_range(s, 0, 127); return true; }
+    if (name == "word") { fill(isalnum); s.set('_'); return true; }
+    return false;
+}
+
+/* "[...]" at p[i]: the class, with i moved past the closing bracket */
+ByteSet parse_bracket_class(const std::string &p, size_t &i) {
+    ByteSet cls;
+    size_t j = i + 1;
+    bool neg = false;
+    if (j < p.size() && p[j] == '^') {
+        neg = true;
+        j++;
+    }
+    bool first = true;
+    for (;;) {
+        if (j >= p.size()) throw ParseError{"Unterminated character class."};
+        if (p[j] == ']' && !first) break;
+        first = false;
+        ByteSet item;
+        unsigned lo;
+        bool is_class = false;
+        if (p[j] == '[' && j + 1 < p.size() && (p[j + 1] == '.' || p[j + 1] == '=') &&
+            p.find(std::string(1, p[j + 1]) + "]", j + 2) != std::string::npos)
+            throw ParseError{"Unsupported POSIX collating element."};
+        if (p[j] == '[' && j + 1 < p.size() && p[j + 1] == ':') { /* [:alpha:] and friends */
+            const size_t e = p.find(":]", j + 2);
+            if (e == std::string::npos) throw ParseError{"Unterminated POSIX class."};
+            std::string name = p.substr(j + 2, e - j - 2);
+            const bool inv = !name.empty() && name[0] == '^';
+            if (inv) name.erase(0, 1);
+            if (!posix_class(name, item)) throw ParseError{"Unknown POSIX character class."};
+            cls |= inv ? ~item : item;
+            j = e + 2;
+            continue;
+        }
+        if (p[j] == '\\') {
+            if (j + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            item = class_escape(p[j + 1], ok);
+            if (ok) {
+                is_class = true;
+                j += 2;
+            } else {
+                size_t k = j + 1;
+                unsigned char lit;
+                if (!class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                lo = lit;
+                j = k;
+            }
+        } else {
+            lo = (unsigned char)p[j++];
+        }
+        if (is_class) {
+            cls |= item;
+            continue;
+        }
+        unsigned hi = lo;
+        if (j + 1 < p.size() && p[j] == '-' && p[j + 1] != ']') {
+            j++;
+            if (p[j] == '[' && j + 1 < p.size() && p[j + 1] == ':') throw ParseError{"Invalid range in character class."};
+            if (p[j] == '\\') {
+                size_t k = j + 1;
+                unsigned char lit;
+                if (k >= p.size() || !class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                hi = lit;
+                j = k;
+            } else {
+                hi = (unsigned char)p[j++];
+            }
+            if (hi < lo) throw ParseError{"Range out of order in character class."};
+        }
+        add_range(cls, lo, hi);
+    }
+    i = j + 1;
+    return neg ? ~cls : cls;
+}
+
+/* ---- general tails: groups and alternation ---------------------------------------
+ * tail := alt ; alt := cat ('|' cat)* ; cat := rep* ; rep := atom ('?' | '*' | '+' | {m[,[n]]})?
+ * atom := '(' ['?:'] alt ')' | '[' class ']' | '\\' escape | '.' | character
+ * Built directly as a Glushkov automaton: every character-class occurrence is a position. */
+/* position sets that grow with the automaton */
+inline void bits_or(Bits &a, const Bits &b) {
+    if (a.size() < b.size()) a.resize(b.size(), 0);
+    for (size_t i = 0; i < b.size(); i++) a[i] |= b[i];
+}
+inline void bits_set(Bits &a, size_t i) {
+    if (a.size() <= i / 64) a.resize(i / 64 + 1, 0);
+    a[i / 64] |= 1ull << (i % 64);
+}
+inline bool bits_test(const Bits &a, size_t i) { return i / 64 < a.size() && (a[i / 64] >> (i % 64) & 1); }
+
+/* conditions on a boundary between two bytes: 0 = none, 1 = \b, 2 = \B; -1 = contradictory */
+inline int cond_and(int a, int b) { return a == 0 ? b : (b == 0 || a == b) ? a : -1; }
+
+struct Frag {
+    Bits first[3], last[3];     /* per condition: to enter a first position / after a last one */
+    unsigned char nullmask = 1; /* bit c: the empty string is in the language under condition c */
+    unsigned long long wmin = 0, wmax = 0;
+    bool nullable() const { return nullmask != 0; }
+};
+
+struct TailBuilder {
+    const std::string &p;
+    bool nocase, dotall;
+    std::vector<ByteSet> cls;    /* per position */
+    std::vector<Bits> follow[3]; /* per condition, per position */
+    bool has_cond = false;
+
+    static unsigned long long add_w(unsigned long long a, unsigned long long b) {
+        return (a == kInf64 || b == kInf64) ? kInf64 : a + b;
+    }
+    /* can an edge x -> y under condition c (1 = \b, 2 = \B) ever be taken? not when both classes
+     * sit wholly on one side of the word / non-word divide in the wrong way */
+    bool edge_possible(int c, size_t x, size_t y) const {
+        if (c == 0) return true;
+        static const ByteSet word = [] {
+            ByteSet w;
+            for (unsigned b = 0; b < 256; b++)
+                if (is_word_char((unsigned char)b)) w.set(b);
+            return w;
+        }();
+        const bool xw = (cls[x] & word).any(), xn = (cls[x] & ~word).any();
+        const bool yw = (cls[y] & word).any(), yn = (cls[y] & ~word).any();
+        const bool can_differ = (xw && yn) || (xn && yw), can_agree = (xw && yw) || (xn && yn);
+        return c == 1 ? can_differ : can_agree;
+    }
+    unsigned new_pos(const ByteSet &c) {
+        if (cls.size() >= kMaxPositions) throw ParseError{"Pattern too large."};
+        cls.push_back(nocase ? fold_case(c) : c);
+        for (int k = 0; k < 3; k++) follow[k].emplace_back();
+        return (unsigned)cls.size() - 1;
+    }
+    /* every last position of a, then every first position of b: the conditions on the two sides
+     * speak about the same boundary, so they combine */
+    void link(const Frag &a, const Frag &b) {
+        for (int ca = 0; ca < 3; ca++)
+            for (int cb = 0; cb < 3; cb++) {
+                const int c = cond_and(ca, cb);
+                if (c < 0) continue;
+                const Bits &from = a.last[ca];
+                for (size_t w = 0; w < from.size(); w++)
+                    for (unsigned long long m = from[w]; m; m &= m - 1)
+                        bits_or(follow[c][w * 64 + __builtin_ctzll(m)], b.first[cb]);
+            }
+    }
+    Frag cat(const Frag &a, const Frag &b) {
+        link(a, b);
+        Frag r;
+        r.nullmask = 0;
+        for (int c = 0; c < 3; c++) {
+            r.first[c] = a.first[c];
+            r.last[c] = b.last[c];
+        }
+        for (int n = 0; n < 3; n++)
+            for (int c = 0; c < 3; c++) {
+                const int k = cond_and(n, c);
+                if (k < 0) continue;
+                if (a.nullmask >> n & 1) bits_or(r.first[k], b.first[c]);
+                if (b.nullmask >> n & 1) bits_or(r.last[k], a.last[c]);
+                if ((a.nullmask >> n & 1) && (b.nullmask >> c & 1)) r.nullmask |= 1u << k;
+            }
+        r.wmin = add_w(a.wmin, b.wmin);
+        r.wmax = add_w(a.wmax, b.wmax);
+        return r;
+    }
+    static bool is_repeat_at(const std::string &p, size_t k) {
+        if (k >= p.size() || p[k] != '{') return false;
+        size_t j = k + 1, d = 0;
+        while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++, d++;
+        if (d == 0) return false;
+        if (j < p.size() && p[j] == ',') {
+            j++;
+            while (j < p.size() && p[j] >= '0' && p[j] <= '9') j++;
+        }
+        return j < p.size() && p[j] == '}';
+    }
+
+    Frag parse_alt(size_t &i, int depth) {
+        Frag r = parse_cat(i, depth);
+        while (i < p.size() && p[i] == '|') {
+            i++;
+            const Frag b = parse_cat(i, depth);
+            for (int c = 0; c < 3; c++) {
+                bits_or(r.first[c], b.first[c]);
+                bits_or(r.last[c], b.last[c]);
+            }
+            r.nullmask |= b.nullmask;
+            r.wmin = std::min(r.wmin, b.wmin);
+            r.wmax = std::max(r.wmax, b.wmax);
+        }
+        return r;
+    }
+    Frag parse_cat(size_t &i, int depth) {
+        Frag r; /* the empty string */
+        while (i < p.size() && p[i] != '|' && p[i] != ')') r = cat(r, parse_rep(i, depth));
+        return r;
+    }
+    /* one atom, then its quantifier; a counted repeat re-parses the atom's source for every copy
+     * (fresh positions), optional copies being x? x? ... (same language as the nested form) */
+    Frag parse_rep(size_t &i, int depth) {
+        const size_t a0 = i;
+        Frag f = parse_atom(i, depth);
+        const size_t a1 = i;
+        if (i >= p.size()) return f;
+        unsigned lo = 1, hi = 1;
+        const char q = p[i];
+        if (q == '?') { lo = 0; hi = 1; i++; }
+        else if (q == '*') { lo = 0; hi = kInf; i++; }
+        else if (q == '+') { lo = 1; hi = kInf; i++; }
+        else if (q == '{' && is_repeat_at(p, i)) {
+            size_t j = i + 1;
+            auto num = [&](unsigned &v) {
+                v = 0;
+                while (j < p.size() && p[j] >= '0' && p[j] <= '9') v = v * 10 + (p[j++] - '0');
+                return v <= 1000;
+            };
+            if (!num(lo)) throw ParseError{"Malformed repeat."};
+            hi = lo;
+            if (p[j] == ',') {
+                j++;
+                if (p[j] == '}') hi = kInf;
+                else if (!num(hi) || hi < lo) throw ParseError{"Malformed repeat."};
+            }
+            i = j + 1;
+        } else {
+            return f;
+        }
+        if (i < p.size() && p[i] == '?') i++; /* lazy: every end offset is reported anyway, greed is immaterial */
+        else if (i < p.size() && p[i] == '+') throw ParseError{"Possessive quantifiers are not supported."};
+        auto again = [&]() { /* a fresh copy of the atom */
+            size_t k = a0;
+            Frag c = parse_atom(k, depth);
+            (void)a1;
+            return c;
+        };
+        auto star_of = [&](Frag c) { /* c* */
+            link(c, c);
+            c.nullmask |= 1;
+            c.wmin = 0;
+            c.wmax = c.wmax ? kInf64 : 0;
+            return c;
+        };
+        auto opt_of = [&](Frag c) {
+            c.nullmask |= 1;
+            c.wmin = 0;
+            return c;
+        };
+        /* copies: the already parsed one is copy #1 */
+        Frag r;
+        bool used_first = false;
+        auto next_copy = [&]() {
+            if (!used_first) { used_first = true; return f; }
+            return again();
+        };
+        if (lo == 0 && hi == kInf) return star_of(next_copy());
+        for (unsigned k = 0; k < lo; k++) {
+            Frag c = next_copy();
+            if (hi == kInf && k + 1 == lo) { /* last mandatory copy loops: c+ */
+                link(c, c);
+                c.wmax = c.wmax ? kInf64 : 0;
+            }
+            r = cat(r, c);
+        }
+        if (hi != kInf)
+            for (unsigned k = lo; k < hi; k++) r = cat(r, opt_of(next_copy()));
+        if (!used_first) { /* {0} or {0,0}: the atom is parsed but contributes nothing */
+            Frag none;
+            return none;
+        }
+        return r;
+    }
+    Frag parse_atom(size_t &i, int depth) {
+        if (i >= p.size()) throw ParseError{"Unexpected end of pattern."};
+        const unsigned char c = (unsigned char)p[i];
+        if (c == '(') {
+            if (depth > 20) throw ParseError{"Groups nested too deeply."};
+            i++;
+            if (i + 1 < p.size() && p[i] == '?') {
+                const char k = p[i + 1];
+                if (k == ':') {
+                    i += 2;
+                } else if (k == '#') { /* (?# comment ) */
+                    const size_t e = p.find(')', i);
+                    if (e == std::string::npos) throw ParseError{"Missing closing parenthesis."};
+                    i = e + 1;
+                    return Frag();
+                } else if ((k == '<' && i + 2 < p.size() && p[i + 2] != '=' && p[i + 2] != '!') || k == '\'' ||
+                           (k == 'P' && i + 2 < p.size() && p[i + 2] == '<')) { /* named group: a plain group here */
+                    const char close = k == '\'' ? '\'' : '>';
+                    const size_t e = p.find(close, i + (k == 'P' ? 3 : 2));
+                    if (e == std::string::npos) throw ParseError{"Unterminated group name."};
+                    i = e + 1;
+                } else {
+                    throw ParseError{"Only plain, named and (?:...) groups are supported."};
+                }
+            }
+            Frag f = parse_alt(i, depth + 1);
+            if (i >= p.size() || p[i] != ')') throw ParseError{"Missing closing parenthesis."};
+            i++;
+            return f;
+        }
+        if (c == '\\' && i + 1 < p.size() && (p[i + 1] == 'b' || p[i + 1] == 'B')) {
+            Frag f; /* zero width: the empty string, under a condition */
+            f.nullmask = p[i + 1] == 'b' ? 2 : 4;
+            has_cond = true;
+            i += 2;
+            return f;
+        }
+        ByteSet set;
+        if (c == '\\') {
+            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            set = class_escape(p[i + 1], ok);
+            if (ok) {
+                i += 2;
+            } else {
+                size_t j = i + 1;
+                unsigned char lit;
+                if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+                set.set(lit);
+                i = j;
+            }
+        } else if (c == '.') {
+            set.set();
+            if (!dotall) set.reset('\n');
+            i++;
+        } else if (c == '[') {
+            set = parse_bracket_class(p, i);
+        } else if (strchr(")|^$*+?", c) || (c == '{' && is_repeat_at(p, i))) {
+            throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
+        } else {
+            set.set(c);
+            i++;
+        }
+        const unsigned pos = new_pos(set);
+        Frag f;
+        bits_set(f.first[0], pos);
+        bits_set(f.last[0], pos);
+        f.nullmask = 0;
+        f.wmin = f.wmax = 1;
+        return f;
+    }
+};
+
+/* builder output -> the runtime form; `reversed`: the automaton of the reversed language, with
+ * the positions renumbered back to front so that its chains are left shifts again */
+Auto finish_auto(const TailBuilder &tb, const Frag &f, bool reversed) {
+    Auto a;
+    const size_t n = tb.cls.size(), W = (n + 63) / 64;
+    a.npos = n;
+    a.W = W;
+    a.nullable = f.nullmask & 1;
+    a.cnullable[0] = f.nullmask & 2;
+    a.cnullable[1] = f.nullmask & 4;
+    a.wmin = f.wmin;
+    a.wmax = f.wmax;
+    a.has_cond = tb.has_cond;
+    if (!n) return a;
+    auto idx = [&](size_t p) { return reversed ? n - 1 - p : p; };
+    a.reach.assign(256 * W, 0);
+    for (size_t x = 0; x < n; x++)
+        for (unsigned c = 0; c < 256; c++)
+            if (tb.cls[x][c]) a.reach[c * W + idx(x) / 64] |= 1ull << (idx(x) % 64);
+    for (int layer = 0; layer < 3; layer++) { /* 0 = unconditional, 1 = \b, 2 = \B */
+        if (layer && !tb.has_cond) break;
+        Bits &first = layer ? a.cfirst[layer - 1] : a.first, &last = layer ? a.clast[layer - 1] : a.last;
+        Bits &shift_ok = layer ? a.cshift_ok[layer - 1] : a.shift_ok, &exc = layer ? a.cexc[layer - 1] : a.exc;
+        std::vector<Bits> &exc_row = layer ? a.cexc_row[layer - 1] : a.exc_row;
+        std::vector<Bits> follow(n, Bits(W, 0));
+        for (size_t x = 0; x < n; x++)
+            for (size_t y = 0; y < n; y++)
+                if (bits_test(tb.follow[layer][x], y) && tb.edge_possible(layer, x, y)) {
+                    if (reversed) bits_set(follow[idx(y)], idx(x));
+                    else bits_set(follow[x], y);
+                }
+        first.assign(W, 0);
+        last.assign(W, 0);
+        for (size_t x = 0; x < n; x++) {
+            if (bits_test(f.first[layer], x)) bits_set(reversed ? last : first, idx(x));
+            if (bits_test(f.last[layer], x)) bits_set(reversed ? first : last, idx(x));
+        }
+        shift_ok.assign(W, 0);
+        exc.assign(W, 0);
+        exc_row.assign(n, Bits());
+        for (size_t x = 0; x < n; x++) {
+            Bits row = follow[x];
+            if (x + 1 < n && bits_test(row, x + 1)) {
+                bits_set(shift_ok, x);
+                row[(x + 1) / 64] &= ~(1ull << ((x + 1) % 64));
+            }
+            bool any = false;
+            for (unsigned long long w : row) any |= w != 0;
+            if (any) {
+                bits_set(exc, x);
+                exc_row[x] = row;
+            }
+        }
+    }
+    return a;
+}
+
+/* is anything in the fragment's language? (an empty class, or stacked contradictory assertions,
+ * can leave none: the reference refuses such patterns, "Pattern can never match.") */
+bool language_nonempty(const TailBuilder &tb, const Frag &f) {
+    if (f.nullmask) return true;
+    const size_t n = tb.cls.size();
+    std::vector<char> seen(n, 0);
+    std::vector<size_t> todo;
+    auto visit = [&](size_t x) {
+        if (!seen[x] && tb.cls[x].any()) {
+            seen[x] = 1;
+            todo.push_back(x);
+        }
+    };
+    for (int c = 0; c < 3; c++)
+        for (size_t x = 0; x < n; x++)
+            if (bits_test(f.first[c], x)) visit(x);
+    while (!todo.empty()) {
+        const size_t x = todo.back();
+        todo.pop_back();
+        for (int c = 0; c < 3; c++) {
+            if (bits_test(f.last[c], x)) return true;
+            for (size_t y = 0; y < n; y++)
+                if (bits_test(tb.follow[c][x], y) && tb.edge_possible(c, x, y)) visit(y);
+        }
+    }
+    return false;
+}
+
+Auto compile_auto(const std::string &src, bool nocase, bool dotall, bool reversed = false) {
+    TailBuilder tb{src, nocase, dotall, {}, {}, false};
+    size_t i = 0;
+    const Frag f = tb.parse_cat(i, 0);
+    if (i < src.size()) throw ParseError{"Unmatched closing parenthesis."};
+    if (!language_nonempty(tb, f)) throw NeverMatch();
+    return finish_auto(tb, f, reversed);
+}
+
+/* the longest run of plain characters at the top level of a branch (not inside a group or a
+ * class, not quantified): [begin, end) in the source and the bytes; the earliest of equals */
+struct LitRun {
+    size_t begin = 0, end = 0;
+    std::string bytes;
+};
+
+LitRun longest_literal_run(const std::string &p) {
+    LitRun best, cur;
+    auto close = [&]() {
+        if (cur.bytes.size() > best.bytes.size()) best = cur;
+        cur = LitRun();
+    };
+    auto skip_quant = [&](size_t &k) {
+        const size_t k0 = k;
+        if (k < p.size() && (p[k] == '?' || p[k] == '*' || p[k] == '+')) k++;
+        else if (TailBuilder::is_repeat_at(p, k)) k = p.find('}', k) + 1;
+        if (k != k0 && k < p.size() && (p[k] == '?' || p[k] == '+')) k++; /* lazy / possessive marker */
+    };
+    size_t i = 0;
+    while (i < p.size()) {
+        const unsigned char c = (unsigned char)p[i];
+        size_t j = i;
+        unsigned char lit = 0;
+        bool is_lit = false;
+        if (c == '\\') {
+            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            class_escape(p[i + 1], ok);
+            if (ok || strchr("bBAzZ", p[i + 1])) { /* a class, or a zero-width assertion: ends the run */
+                j = i + 2;
+            } else {
+                j = i + 1;
+                if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+                is_lit = true;
+            }
+        } else if (c == '[') {
+            parse_bracket_class(p, j);
+        } else if (c == '(') {
+            int depth = 0;
+            for (;; j++) {
+                if (j >= p.size()) throw ParseError{"Missing closing parenthesis."};
+                if (p[j] == '\\') { j++; continue; }
+                if (p[j] == '[') { size_t e = j; parse_bracket_class(p, e); j = e - 1; continue; }
+                if (p[j] == '(') depth++;
+                if (p[j] == ')' && --depth == 0) break;
+            }
+            j++;
+        } else if (c == '.' || strchr(")|^$*+?", c) || (c == '{' && TailBuilder::is_repeat_at(p, i))) {
+            j = i + 1; /* not a literal; a misplaced operator is reported by the fragment compiler */
+        } else {
+            lit = c;
+            j = i + 1;
+            is_lit = true;
+        }
+        const size_t after = j;
+        skip_quant(j);
+        if (is_lit && j == after) {
+            if (cur.bytes.empty()) cur.begin = i;
+            cur.bytes.push_back((char)lit);
+            cur.end = j;
+        } else {
+            close();
+        }
+        i = j;
+    }
+    close();
+    return best;
+}
+
+constexpr unsigned kAllFlags = 0x7ff; /* HS_FLAG_ALL: the eleven flags of src/hs_compile.h */
+
+/* the reference's own flag rules, in its order (src/compiler/compiler.cpp:286-294,166-196) */
+void check_flags(unsigned flags, bool literal_api) {
+    if (!literal_api && (flags & HS_FLAG_COMBINATION)) {
+        if (flags & ~(HS_FLAG_COMBINATION | HS_FLAG_QUIET | HS_FLAG_SINGLEMATCH))
+            throw ParseError{"only HS_FLAG_QUIET and HS_FLAG_SINGLEMATCH are supported in combination with "
+                             "HS_FLAG_COMBINATION."};
+        throw ParseError{"Logical combinations are not supported by the GPU literal engine."};
+    }
+    if (!literal_api && (flags & HS_FLAG_QUIET) && (flags & HS_FLAG_SOM_LEFTMOST))
+        throw ParseError{"HS_FLAG_QUIET is not supported in combination with HS_FLAG_SOM_LEFTMOST."};
+    if (flags & ~kAllFlags) throw ParseError{"Unrecognised flag."};
+    if ((flags & HS_FLAG_SINGLEMATCH) && (flags & HS_FLAG_SOM_LEFTMOST))
+        throw ParseError{"HS_FLAG_SINGLEMATCH is not supported in combination with HS_FLAG_SOM_LEFTMOST."};
+    if (!literal_api && (flags & HS_FLAG_PREFILTER) && (flags & HS_FLAG_SOM_LEFTMOST))
+        throw ParseError{"HS_FLAG_PREFILTER is not supported in combination with HS_FLAG_SOM_LEFTMOST."};
+}
+
+/* branch := '^'? literal-prefix tail '$'? ; tail := (atom quantifier?)* */
+Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
+    Pattern pat;
+    std::string p = src;
+    const bool multiline = flags & HS_FLAG_MULTILINE;
+    /* is the two-character escape "\\<c>" at p[k], with its backslash not itself escaped? */
+    auto escape_at = [&](size_t k, const char *cs) {
+        if (k + 1 >= p.size() || p[k] != '\\' || !strchr(cs, p[k + 1])) return false;
+        size_t bs = 0;
+        while (bs < k && p[k - 1 - bs] == '\\') bs++;
+        return bs % 2 == 0;
+    };
+    auto assertion = [](char c) { return (unsigned char)(c == 'b' ? 1 : 2); };
+    /* front: ^ or \A, then \b / \B */
+    if (!p.empty() && p[0] == '^') {
+        pat.bol = true;
+        pat.bol_ml = multiline;
+        p.erase(0, 1);
+    } else if (escape_at(0, "A")) {
+        pat.bol = true;
+        p.erase(0, 2);
+    }
+    if (escape_at(0, "bB")) {
+        pat.as_start = assertion(p[1]);
+        p.erase(0, 2);
+    }
+    if (!p.empty() && (strchr("*+?", p[0]) || TailBuilder::is_repeat_at(p, 0)))
+        throw ParseError{"Invalid repeat."}; /* a quantifier needs something that consumes bytes before it */
+    /* back: $, \z or \Z, before it \b / \B */
+    if (!p.empty() && p.back() == '$' && !escape_at(p.size() - 2, "$")) {
+        pat.eol = pat.eol_nl = true;
+        pat.eol_ml = multiline;
+        p.pop_back();
+    } else if (p.size() >= 2 && escape_at(p.size() - 2, "zZ")) {
+        pat.eol = true;
+        pat.eol_nl = p.back() == 'Z';
+        p.erase(p.size() - 2);
+    }
+    if (p.size() >= 2 && escape_at(p.size() - 2, "bB")) {
+        pat.as_end = assertion(p.back());
+        p.erase(p.size() - 2);
+    }
+    pat.nocase = flags & HS_FLAG_CASELESS;
+    pat.single = flags & HS_FLAG_SINGLEMATCH;
+    pat.som = flags & HS_FLAG_SOM_LEFTMOST;
+    pat.id = id;
+    const bool dotall = flags & HS_FLAG_DOTALL;
+    /* `{` opens a repeat only when a well-formed {m}, {m,} or {m,n} follows; otherwise it (and
+     * a lone `}`) is an ordinary character, as in PCRE ("foo.{,10}bar" is twelve literal-ish
+     * positions: unit/hyperscan/expr_info.cpp:211) */
+    auto is_repeat = [&](size_t k) { return TailBuilder::is_repeat_at(p, k); };
+    /* the branch is R1 LIT R2 around its longest top-level literal run (the front one on a tie);
+     * \b / \B may hug the literal on either side */
+    LitRun run = longest_literal_run(p);
+    if (run.bytes.empty()) throw NoLiteral();
+    size_t r1_end = run.begin, r2_begin = run.end;
+    if (run.begin >= 2 && escape_at(run.begin - 2, "bB")) {
+        pat.as_lit_pre = assertion(p[run.begin - 1]);
+        r1_end -= 2;
+    }
+    if (escape_at(run.end, "bB")) {
+        pat.as_lit_post = assertion(p[run.end + 1]);
+        r2_begin += 2;
+        if (r2_begin < p.size() && (strchr("*+?", p[r2_begin]) || TailBuilder::is_repeat_at(p, r2_begin)))
+            throw ParseError{"Invalid repeat."};
+    }
+    pat.lit = run.bytes;
+    if (pat.bol && !pat.bol_ml && r1_end == 0) {
+        /* the match starts at offset 0: what is in front is not a word byte */
+        const unsigned char k = pat.as_start ? pat.as_start : pat.as_lit_pre;
+        if (k && (is_word_char((unsigned char)pat.lit[0]) != (k == 1))) throw NeverMatch();
+    }
+    if (pat.as_start && pat.as_lit_pre && r1_end == 0 && pat.as_start != pat.as_lit_pre)
+        throw NeverMatch();
+    if (pat.as_end && pat.as_lit_post && r2_begin == p.size() && pat.as_end != pat.as_lit_post)
+        throw NeverMatch();
+    if (pat.as_lit_post && r2_begin < p.size() && !strchr("\\.[]()|^$*+?{", p[r2_begin]) &&
+        !(r2_begin + 1 < p.size() && (strchr("*+?", p[r2_begin + 1]) || TailBuilder::is_repeat_at(p, r2_begin + 1)))) {
+        /* literal, assertion, plain character: both neighbours of the boundary are known */
+        unsigned char nx = (unsigned char)p[r2_begin];
+        const bool differ = is_word_char((unsigned char)pat.lit.back()) != is_word_char(nx);
+        if (differ != (pat.as_lit_post == 1)) throw NeverMatch();
+    }
+    size_t i = r2_begin;
+    if (r1_end != 0) {
+        /* the literal is not at the front: R1 backwards, R2 as a position automaton */
+        pat.pre = compile_auto(p.substr(0, r1_end), pat.nocase, dotall, true);
+        pat.g = compile_auto(p.substr(r2_begin), pat.nocase, dotall);
+        pat.has_pre = pat.pre.npos != 0 || pat.pre.has_cond;
+        pat.general = pat.g.npos != 0 || pat.g.has_cond;
+        pat.tail_nullable = pat.g.nullable || pat.g.cnullable[0] || pat.g.cnullable[1];
+        return pat;
+    }
+    /* a tail with a group in it goes to the position automaton; the linear form below stays the
+     * path for everything it can express */
+    bool grouped = false;
+    for (size_t k = i; k < p.size() && !grouped; k++) {
+        if (p[k] == '\\') { grouped = k + 1 < p.size() && (p[k + 1] == 'b' || p[k + 1] == 'B'); k++; }
+        else if (p[k] == '[') { size_t e = k; parse_bracket_class(p, e); k = e - 1; }
+        else if (p[k] == '(') grouped = true;
+    }
+    if (grouped) {
+        pat.g = compile_auto(p.substr(i), pat.nocase, dotall);
+        pat.general = pat.g.npos != 0 || pat.g.has_cond;
+        pat.tail_nullable = pat.g.nullable || pat.g.cnullable[0] || pat.g.cnullable[1];
+        return pat;
+    }
+    const size_t tail_begin = i;
+    /* tail */
+    while (i < p.size()) {
+        ByteSet cls;
+        unsigned char c = (unsigned char)p[i];
+        if (c == '\\') {
+            if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
+            bool ok;
+            cls = class_escape(p[i + 1], ok);
+            if (ok) {
+                i += 2;
+            } else {
+                size_t j = i + 1;
+                unsigned char lit;
+                if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+                cls.set(lit);
+                i = j;
+            }
+        } else if (c == '.') {
+            cls.set();
+            if (!dotall) cls.reset('\n');
+            i++;
+        } else if (c == '[') {
+            cls = parse_bracket_class(p, i);
+        } else if (strchr("()|^$*+?]", c) || (c == '{' && is_repeat(i))) {
+            throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
+        } else {
+            cls.set(c);
+            i++;
+        }
+        if (pat.nocase) cls = fold_case(cls);
+        /* quantifier */
+        unsigned lo = 1, hi = 1;
+        if (i < p.size()) {
+            char q = p[i];
+            if (q == '?') { lo = 0; hi = 1; i++; }
+            else if (q == '*') { lo = 0; hi = kInf; i++; }
+            else if (q == '+') { lo = 1; hi = kInf; i++; }
+            else if (q == '{' && is_repeat(i)) {
+                size_t j = i + 1;
+                auto num = [&](unsigned &v) {
+                    if (j >= p.size() || p[j] < '0' || p[j] > '9') return false;
+                    v = 0;
+                    while (j < p.size() && p[j] >= '0' && p[j] <= '9') v = v * 10 + (p[j++] - '0');
+                    return v <= 1000;
+                };
+                if (!num(lo)) throw ParseError{"Malformed repeat."};
+                hi = lo;
+                if (j < p.size() && p[j] == ',') {
+                    j++;
+                    if (j < p.size() && p[j] == '}') hi = kInf;
+                    else if (!num(hi) || hi < lo) throw ParseError{"Malformed repeat."};
+                }
+                if (j >= p.size() || p[j] != '}') throw ParseError{"Malformed repeat."};
+                i = j + 1;
+            }
+            if (i < p.size() && p[i] == '?') i++; /* lazy: immaterial, as above */
+            else if (i < p.size() && p[i] == '+') throw ParseError{"Possessive quantifiers are not supported."};
+        }
+        if (lo > 0 && cls.none()) throw NeverMatch();
+        for (unsigned k = 0; k < lo; k++) pat.tail.push_back(Unit{cls, false, false});
+        if (hi == kInf) {
+            if (lo == 0) pat.tail.push_back(Unit{cls, true, true});
+            else pat.tail.back().star = true;
+        } else {
+            for (unsigned k = lo; k < hi; k++) pat.tail.push_back(Unit{cls, true, false});
+        }
+        if (pat.tail.size() > 63) { /* too long for one shift-and word: the position automaton takes it */
+            pat.tail.clear();
+            pat.g = compile_auto(p.substr(tail_begin), pat.nocase, dotall);
+            pat.general = true;
+            pat.tail_nullable = pat.g.nullable || pat.g.cnullable[0] || pat.g.cnullable[1];
+            return pat;
+        }
+    }
+    pat.tail_nullable = true;
+    for (const Unit &u : pat.tail) pat.tail_nullable &= u.optional;
+    return pat;
+}
+
+/* A branch without a top-level literal may still hold one inside an alternation: X(A|B)Y is
+ * XAY|XBY, so the first unquantified top-level group is distributed over its alternatives and
+ * every product is tried again (Rose gets the same literals by cutting the graph at the
+ * alternation). "\\b(foo|bar)\\b" and "(GET|POST) /" are the everyday cases. */
+constexpr size_t kMaxBranches = 256;
+void distribute_group(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth);
+
+void expand_branch(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
+    /* as written, if it has a usable literal; with only a 1-2 byte one, distributing a group is
+     * tried as well and kept when every product gets a longer literal ("(GET|POST) /x": " /" ->
+     * "GET /", "POST /") */
+    bool have = false;
+    Pattern whole;
+    try {
+        whole = parse_branch(b, flags, id);
+        have = true;
+    } catch (const NeverMatch &) {
+        throw;
+    } catch (const NoLiteral &) {
+        if (depth >= 8) throw;
+    } catch (const ParseError &first) {
+        /* an anchor or assertion inside a group, e.g. "(^|\n)foo": fine once the group is distributed */
+        if (depth >= 8) throw;
+        try {
+            distribute_group(b, flags, id, out, depth);
+        } catch (const ParseError &) {
+            throw first;
+        }
+        return;
+    }
+    if (have && (whole.lit.size() > 2 || depth >= 8)) {
+        out.push_back(std::move(whole));
+        return;
+    }
+    if (have) {
+        std::vector<Pattern> alt;
+        bool better = false;
+        try {
+            distribute_group(b, flags, id, alt, depth);
+            better = !alt.empty() && out.size() + alt.size() <= kMaxBranches;
+            for (const Pattern &a : alt) better = better && a.lit.size() > whole.lit.size();
+        } catch (const ParseError &) {
+            better = false;
+        }
+        if (better) {
+            for (Pattern &a : alt) out.push_back(std::move(a));
+        } else {
+            out.push_back(std::move(whole));
+        }
+        return;
+    }
+    distribute_group(b, flags, id, out, depth);
+}
+
+void distribute_group(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
+    /* the first top-level group that is not quantified, not special, and has its alternatives */
+    size_t i = 0;
+    while (i < b.size()) {
+        const char c = b[i];
+        if (c == '\\') { i += 2; continue; }
+        if (c == '[') { size_t e = i; parse_bracket_class(b, e); i = e; continue; }
+        if (c != '(') { i++; continue; }
+        size_t body = i + 1;
+        bool plain = true;
+        if (body < b.size() && b[body] == '?') {
+            if (body + 1 < b.size() && b[body + 1] == ':') body += 2;
+            else plain = false; /* named / comment / look-around: leave it alone */
+        }
+        std::vector<std::string> alts;
+        size_t j = i, last = body;
+        for (int d = 0;; j++) {
+            if (j >= b.size()) throw ParseError{"Missing closing parenthesis."};
+            if (b[j] == '\\') { j++; continue; }
+            if (b[j] == '[') { size_t e = j; parse_bracket_class(b, e); j = e - 1; continue; }
+            if (b[j] == '(') d++;
+            else if (b[j] == '|' && d == 1) { alts.push_back(b.substr(last, j - last)); last = j + 1; }
+            else if (b[j] == ')' && --d == 0) { alts.push_back(b.substr(last, j - last)); break; }
+        }
+        size_t end = j + 1;
+        if (plain && end < b.size() && b[end] == '?' && !(end + 1 < b.size() && b[end + 1] == '+')) {
+            alts.push_back(std::string()); /* (X)? is (X|): distributable too */
+            end += (end + 1 < b.size() && b[end + 1] == '?') ? 2 : 1;
+        }
+        const bool quantified = end < b.size() && (b[end] == '?' || b[end] == '*' || b[end] == '+' || TailBuilder::is_repeat_at(b, end));
+        if (!plain || quantified) { i = end; continue; }
+        for (const std::string &a : alts) /* "(*VERB)", "(+x)": not ours to rearrange */
+            if (!a.empty() && (strchr("*+?", a[0]) || TailBuilder::is_repeat_at(a, 0))) throw NoLiteral();
+        if (out.size() + alts.size() > kMaxBranches) throw ParseError{"Pattern too large."};
+        const size_t before = out.size();
+        for (const std::string &a : alts) {
+            try {
+                expand_branch(b.substr(0, i) + a + b.substr(end), flags, id, out, depth + 1);
+            } catch (const NeverMatch &) { /* this product contributes nothing */
+            }
+        }
+        if (out.size() == before) throw NeverMatch();
+        return;
+    }
+    throw NoLiteral();
+}
+
+/* expression := branch ('|' branch)* at the top level: every branch is its own literal-prefixed
+ * pattern reporting the same id (the reference builds one graph; the reports are the same) */
+std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsigned id) {
+    check_flags(flags, false);
+    /* leading inline options: (?i) (?s) (?m), combined and negated forms */
+    std::string p = expr;
+    while (p.size() >= 4 && p[0] == '(' && p[1] == '?') {
+        size_t k = 2;
+        bool on = true, any = false;
+        unsigned set = 0, clear = 0;
+        for (; k < p.size() && strchr("ims-", p[k]); k++) {
+            if (p[k] == '-') { on = false; continue; }
+            const unsigned f = p[k] == 'i' ? HS_FLAG_CASELESS : p[k] == 's' ? HS_FLAG_DOTALL : HS_FLAG_MULTILINE;
+            (on ? set : clear) |= f;
+            any = true;
+        }
+        if (!any || k >= p.size() || p[k] != ')') break;
+        flags = (flags | set) & ~clear;
+        p.erase(0, k + 1);
+    }
+    /* HS_FLAG_PREFILTER allows a superset of the matches: the exact set is one. HS_FLAG_ALLOWEMPTY
+     * permits patterns that can match the empty string: none here can (a mandatory literal).
+     * HS_FLAG_QUIET: the expression reports nothing (src/hs_compile.h:328-330 "ignore match reporting"). */
+    const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_COMBINATION;
+    if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};
+    std::vector<Pattern> out;
+    size_t from = 0;
+    int depth = 0;
+    for (size_t k = 0; k <= p.size(); k++) {
+        if (k < p.size()) {
+            const char c = p[k];
+            if (c == '\\') { k++; continue; }
+            if (c == '[') { /* skip the class: "]" first in a class is a member */
+                size_t j = k + 1;
+                if (j < p.size() && p[j] == '^') j++;
+                if (j < p.size() && p[j] == ']') j++;
+                while (j < p.size() && p[j] != ']') j += p[j] == '\\' ? 2 : 1;
+                k = j;
+                continue;
+            }
+            if (c == '(') depth++;
+            if (c == ')') depth--;
+            if (c != '|' || depth != 0) continue;
+        }
+        try {
+            expand_branch(p.substr(from, k - from), flags, id, out, 0);
+        } catch (const NeverMatch &) { /* an alternative that cannot match is dropped; all of them: an error */
+        }
+        from = k + 1;
+    }
+    if (out.empty()) throw NeverMatch();
+    for (Pattern &b : out) b.quiet = flags & HS_FLAG_QUIET;
+    return out;
+}
+
+
+void finish_pattern(Pattern &p) {
+    if (p.general) return;
+    p.fast = !p.tail.empty(); /* parse_branch keeps linear tails to <= 63 units */
+    if (!p.fast) return;
+    p.reach.assign(256, 0);
+    for (size_t i = 0; i < p.tail.size(); i++) {
+        for (unsigned c = 0; c < 256; c++)
+            if (p.tail[i].cls[c]) p.reach[c] |= 1ull << i;
+        if (p.tail[i].star) p.star_mask |= 1ull << i;
+        if (p.tail[i].optional) p.opt_mask |= 1ull << i;
+    }
+}
+
+
+/* width of one branch as written (no ext parameters): [lo, hi], hi meaningless when inf */
+void raw_widths(const Pattern &p, unsigned long long &lo, unsigned long long &hi, bool &inf) {
+    lo = hi = p.lit.size();
+    inf = false;
+    for (const Unit &u : p.tail) {
+        lo += u.optional ? 0 : 1;
+        hi += 1;
+        inf |= u.star;
+    }
+    if (p.general) {
+        lo += p.g.wmin;
+        inf |= p.g.wmax == kInf64;
+        if (p.g.wmax != kInf64) hi += p.g.wmax;
+    }
+    if (p.has_pre) {
+        lo += p.pre.wmin;
+        inf |= p.pre.wmax == kInf64;
+        if (p.pre.wmax != kInf64) hi += p.pre.wmax;
+    }
+}
+
+} // namespace hsf
