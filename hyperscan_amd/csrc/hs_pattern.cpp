@@ -137,7 +137,7 @@ bool posix_class(const std::string &name, ByteSet &s) {
 }
 
 /* "[...]" at p[i]: the class, with i moved past the closing bracket */
-ByteSet parse_bracket_class(const std::string &p, size_t &i) {
+ByteSet parse_bracket_class(const std::string &p, size_t &i, bool nocase = false) {
     ByteSet cls;
     size_t j = i + 1;
     bool neg = false;
@@ -206,6 +206,7 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i) {
         add_range(cls, lo, hi);
     }
     i = j + 1;
+    if (nocase) cls = fold_case(cls); /* before the negation: caseless [^a] excludes both a and A */
     return neg ? ~cls : cls;
 }
 
@@ -460,7 +461,7 @@ struct TailBuilder {
             if (!dotall) set.reset('\n');
             i++;
         } else if (c == '[') {
-            set = parse_bracket_class(p, i);
+            set = parse_bracket_class(p, i, nocase);
         } else if (strchr(")|^$*+?", c) || (c == '{' && is_repeat_at(p, i))) {
             throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
         } else {
@@ -790,7 +791,7 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
             if (!dotall) cls.reset('\n');
             i++;
         } else if (c == '[') {
-            cls = parse_bracket_class(p, i);
+            cls = parse_bracket_class(p, i, pat.nocase);
         } else if (strchr("()|^$*+?]", c) || (c == '{' && is_repeat(i))) {
             throw ParseError{std::string("Unsupported regex construct '") + (char)c + "'."};
         } else {

@@ -508,3 +508,36 @@ def test_word_boundaries_inside_fragments():
     assert sorted(ev) == sorted(want)
     hit = {e[1] for e in ev}
     assert hit >= {1, 2, 3, 4, 5, 6, 7, 8, 9}, hit
+
+
+def test_caseless_negated_class():
+    # found by tools/fuzz_patterns.py: caseless [^a] excludes a AND A (fold before negating)
+    exprs = [(r"XY??[^a\n]+?", hs.HS_FLAG_CASELESS | hs.HS_FLAG_MULTILINE, 1), (r"ab[^b-c]x", hs.HS_FLAG_CASELESS, 2)]
+    blocks = [b"XYa-b_aa-b", b"xyAz", b"abBx abCx abdx ABDX abax"]
+    assert sorted(run_exprs_auto(exprs, blocks)) == sorted(brute_context(exprs, blocks))
+
+
+def test_differential_fuzz_against_re():
+    """a fixed slice of tools/fuzz_patterns.py: random expressions from its grammar, every accepted
+    one compared with the brute-force model on random blocks"""
+    import random
+    import sys
+    import os
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_patterns as fz
+
+    r = random.Random(5)
+    flags = [0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL, hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SOM_LEFTMOST]
+    compared = 0
+    for _ in range(500):
+        expr, fl = fz.gen_expr(r), r.choice(flags)
+        try:
+            re.compile(expr.replace("\\Z", "(?=\\n?\\Z)").replace("\\z", "\\Z").encode())
+            hs.Database.compile([expr], [fl], [1])
+        except (re.error, hs.HsError):
+            continue
+        blocks = [fz.gen_block(r) for _ in range(4)]
+        assert sorted(run_exprs_auto([(expr, fl, 1)], blocks)) == sorted(brute_context([(expr, fl, 1)], blocks)), (expr, fl, blocks)
+        compared += 1
+    assert compared >= 250

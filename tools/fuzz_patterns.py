@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the hs_* pattern compiler + host confirm against Python's re, no GPU:
+random expressions from a small grammar (literals, classes, groups, alternation, quantifiers incl.
+lazy and counted, \\b \\B, ^ $ with and without MULTILINE, CASELESS / DOTALL / SOM_LEFTMOST); for
+every expression the facade accepts, the events over random blocks (literal hits from the HWLM
+oracle -> hs_confirm_batch) must equal the brute-force model with the whole block visible.
+  python tools/fuzz_patterns.py [--seed S] [--n N]
+Exits non-zero on the first disagreement, printing the expression, flags and block."""
+import argparse
+import os
+import random
+import re
+import signal
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hyperscan_amd import hs  # noqa: E402
+from tests.test_hs_confirm_cpu import brute_context, run_exprs_auto  # noqa: E402
+
+ALPHA = "abcABCXYxy01 _-\n"
+WORDS = ["ab", "abc", "cab", "X1", "Y0", "a-b", "01", "_a", "ba", "XY", "AB", "aBc", "xy", "Cab"]
+
+
+def gen_atom(r, depth):
+    k = r.random()
+    if k < 0.40:
+        return re.escape(r.choice(WORDS)).replace("\\ ", " ").replace("\\-", "-").replace("\\_", "_")
+    if k < 0.55:
+        return r.choice(["[a-c]", "[^a\\n]", "\\d", "\\w", "\\s", ".", "[XY01]", "[ab_-]", "\\W", "[^\\w]", "[^XY]", "[A-c]", "[a-cX]",
+                         "[^\\d\\s]", "\\S", "\\D", "[\\w-]", "[]a]", "[^]a]", ".{0,3}", "\\w{2,4}", "[^b]{1,2}"])
+    if k < 0.62:
+        return r.choice(["\\b", "\\B"])
+    if k < 0.85 and depth < 3:
+        n = r.randint(1, 3)
+        alts = [gen_cat(r, depth + 1, r.randint(0, 3)) for _ in range(n)]
+        g = r.choice(["(", "(?:"]) + "|".join(alts) + ")"
+        if r.random() < 0.25:
+            g += r.choice(["?", "*", "+", "{2}", "{1,2}", "{0,3}", "{2,}"])
+        return g
+    return r.choice(list("abcXY01"))
+
+
+def gen_cat(r, depth, n):
+    out = []
+    for _ in range(n):
+        a = gen_atom(r, depth)
+        if a not in ("\\b", "\\B") and r.random() < 0.3:
+            a += r.choice(["?", "*", "+", "{2}", "{1,3}", "{0,2}", "{2,}", "??", "*?", "+?"])
+        out.append(a)
+    return "".join(out)
+
+
+def gen_expr(r):
+    branches = []
+    for _ in range(r.choice([1, 1, 1, 2, 3])):
+        b = gen_cat(r, 0, r.randint(1, 5))
+        k = r.random()
+        if k < 0.15:
+            b = "^" + b
+        elif k < 0.20:
+            b = "\\A" + b
+        k = r.random()
+        if k < 0.15:
+            b = b + "$"
+        elif k < 0.20:
+            b = b + "\\z"
+        elif k < 0.25:
+            b = b + "\\Z"
+        branches.append(b)
+    return "|".join(branches)
+
+
+def gen_block(r):
+    parts = []
+    for _ in range(r.randint(0, 10)):
+        parts.append(r.choice(WORDS) if r.random() < 0.6 else "".join(r.choice(ALPHA) for _ in range(r.randint(1, 4))))
+    return "".join(parts).encode()
+
+
+class Timeout(Exception):
+    pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--n", type=int, default=2000)
+    a = ap.parse_args()
+    r = random.Random(a.seed)
+    signal.signal(signal.SIGALRM, lambda *_: (_ for _ in ()).throw(Timeout()))
+    tried = accepted = compared = 0
+    flag_choices = [0, 0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL, hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SOM_LEFTMOST,
+                    hs.HS_FLAG_CASELESS | hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SINGLEMATCH]
+    for _ in range(a.n):
+        expr, fl = gen_expr(r), r.choice(flag_choices)
+        tried += 1
+        try:
+            re.compile(expr.replace("\\Z", "(?=\\n?\\Z)").replace("\\z", "\\Z").encode())
+        except re.error:
+            continue
+        try:
+            hs.Database.compile([expr], [fl], [1])
+        except hs.HsError:
+            continue
+        accepted += 1
+        blocks = [gen_block(r) for _ in range(6)]
+        exprs = [(expr, fl, 1)]
+        try:
+            signal.alarm(10)
+            want = brute_context(exprs, blocks)
+            signal.alarm(0)
+        except Timeout:
+            continue
+        if fl & hs.HS_FLAG_SINGLEMATCH:  # only the first event of each block
+            first, seen = [], set()
+            for e in sorted(want, key=lambda e: (e[0], e[3])):
+                if e[0] not in seen:
+                    seen.add(e[0])
+                    first.append(e)
+            want = first
+        got = run_exprs_auto(exprs, blocks)
+        compared += 1
+        if sorted(got) != sorted(want):
+            bad = sorted(set(got) ^ set(want))[0][0]
+            print("MISMATCH", repr(expr), "flags", fl, "block", blocks[bad])
+            print("  got ", sorted(e for e in got if e[0] == bad))
+            print("  want", sorted(e for e in want if e[0] == bad))
+            sys.exit(1)
+    print(f"{tried} expressions, {accepted} accepted by the facade, {compared} compared: all equal")
+
+
+if __name__ == "__main__":
+    main()
