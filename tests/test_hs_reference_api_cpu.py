@@ -230,3 +230,43 @@ def test_singlematch_with_branches_in_other_expressions():
     db = hs.Database.compile(["cat|dog", "emu", "fox|gnu|ibis"], [0, ONE, ONE], [1, 2, 3])
     ev = to_id(cpu_scan(db, b"cat emu dog emu fox gnu ibis emu cat")[0])
     assert ev == [(3, 1), (7, 2), (11, 1), (19, 3), (36, 1)]
+
+
+def test_literal_api_random_sets_on_cpu():
+    """hs_compile_lit_multi through the host confirm: binary literals of 1..40 bytes (NULs and
+    bytes >= 0x80 included), caseless ones, planted in random data; the long-literal check must
+    leave exactly the naive search's matches (unit/hyperscan/literals.cpp's shape on the CPU)"""
+    rng = np.random.default_rng(17)
+    for trial in range(6):
+        n = int(rng.integers(1, 60))
+        lits, flags = [], []
+        for _ in range(n):
+            ln = int(rng.integers(1, 41))
+            alpha = rng.choice([4, 26, 256])
+            b = bytes(rng.integers(0, alpha, ln, dtype=np.uint8) + (97 if alpha < 256 else 0) & 0xFF)
+            lits.append(b)
+            flags.append(hs.HS_FLAG_CASELESS if rng.random() < 0.4 else 0)
+        keep = {}
+        for b, f in zip(lits, flags):
+            keep.setdefault(b, f)
+        lits, flags = list(keep), list(keep.values())
+        db = hs.Database.compile_lit(lits, flags, list(range(len(lits))))
+        parts = []
+        for _ in range(300):
+            if rng.random() < 0.5:
+                b = lits[int(rng.integers(0, len(lits)))]
+                parts.append(b.upper() if rng.random() < 0.3 else b)
+            else:
+                parts.append(bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)))
+        data = b"".join(parts)
+        want = set()
+        for i, (b, f) in enumerate(zip(lits, flags)):
+            up = lambda x: bytes(c - 32 if 97 <= c <= 122 else c for c in x)  # noqa: E731 (ASCII letters only)
+            hay, needle = (up(data), up(b)) if f else (data, b)
+            k = hay.find(needle)
+            while k >= 0:
+                want.add((k + len(b), i))
+                k = hay.find(needle, k + 1)
+        got = to_id(cpu_scan(db, data)[0])
+        assert set(got) == want and len(got) == len(want), trial
+        assert [t for t, _i in got] == sorted(t for t, _i in got)
