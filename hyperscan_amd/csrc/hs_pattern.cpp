@@ -225,6 +225,30 @@ inline void bits_set(Bits &a, size_t i) {
 }
 inline bool bits_test(const Bits &a, size_t i) { return i / 64 < a.size() && (a[i / 64] >> (i % 64) & 1); }
 
+/* "(?i)" "(?-s)" "(?is-m:" ... at p[i] == '(': which flags it switches and whether it opens a
+ * scoped group. Only i and s may change inside a pattern here (m would move the meaning of the
+ * edge anchors, x is not supported). Returns 0 = not an option group, 1 = "(?..)" setting, 2 =
+ * "(?..:" scoped group; `end` = index after the ")" or ":". */
+int option_group_at(const std::string &p, size_t i, bool &nocase, bool &dotall, size_t &end) {
+    if (i + 2 >= p.size() || p[i] != '(' || p[i + 1] != '?') return 0;
+    size_t k = i + 2;
+    bool on = true, any = false, nc = nocase, ds = dotall;
+    for (; k < p.size(); k++) {
+        const char c = p[k];
+        if (c == '-') { if (!on) return 0; on = false; continue; }
+        if (c == 'i') nc = on;
+        else if (c == 's') ds = on;
+        else if (c == 'm' || c == 'x') throw ParseError{"Only the i and s options may change inside a pattern."};
+        else break;
+        any = true;
+    }
+    if (!any || k >= p.size() || (p[k] != ')' && p[k] != ':')) return 0;
+    nocase = nc;
+    dotall = ds;
+    end = k + 1;
+    return p[k] == ')' ? 1 : 2;
+}
+
 /* conditions on a boundary between two bytes: 0 = none, 1 = \b, 2 = \B; -1 = contradictory */
 inline int cond_and(int a, int b) { return a == 0 ? b : (b == 0 || a == b) ? a : -1; }
 
@@ -410,6 +434,30 @@ struct TailBuilder {
         const unsigned char c = (unsigned char)p[i];
         if (c == '(') {
             if (depth > 20) throw ParseError{"Groups nested too deeply."};
+            { /* option settings: "(?i)" lasts to the end of the enclosing group, "(?i:...)" is its own group */
+                bool nc = nocase, ds = dotall;
+                size_t e = i;
+                const int kind = option_group_at(p, i, nc, ds, e);
+                if (kind == 1) {
+                    nocase = nc;
+                    dotall = ds;
+                    i = e;
+                    return Frag();
+                }
+                if (kind == 2) {
+                    const bool nc0 = nocase, ds0 = dotall;
+                    nocase = nc;
+                    dotall = ds;
+                    i = e;
+                    Frag f = parse_alt(i, depth + 1);
+                    if (i >= p.size() || p[i] != ')') throw ParseError{"Missing closing parenthesis."};
+                    i++;
+                    nocase = nc0;
+                    dotall = ds0;
+                    return f;
+                }
+            }
+            const bool nc_outer = nocase, ds_outer = dotall; /* settings made inside end with the group */
             i++;
             if (i + 1 < p.size() && p[i] == '?') {
                 const char k = p[i + 1];
@@ -433,6 +481,8 @@ struct TailBuilder {
             Frag f = parse_alt(i, depth + 1);
             if (i >= p.size() || p[i] != ')') throw ParseError{"Missing closing parenthesis."};
             i++;
+            nocase = nc_outer;
+            dotall = ds_outer;
             return f;
         }
         if (c == '\\' && i + 1 < p.size() && (p[i + 1] == 'b' || p[i + 1] == 'B')) {
@@ -577,9 +627,10 @@ Auto compile_auto(const std::string &src, bool nocase, bool dotall, bool reverse
 struct LitRun {
     size_t begin = 0, end = 0;
     std::string bytes;
+    bool nocase = false, dotall = false; /* the option state where the run sits ("ab(?i)cd": cd is caseless) */
 };
 
-LitRun longest_literal_run(const std::string &p) {
+LitRun longest_literal_run(const std::string &p, bool nocase, bool dotall) {
     LitRun best, cur;
     auto close = [&]() {
         if (cur.bytes.size() > best.bytes.size()) best = cur;
@@ -610,6 +661,15 @@ LitRun longest_literal_run(const std::string &p) {
             }
         } else if (c == '[') {
             parse_bracket_class(p, j);
+        } else if (c == '(' && [&] { /* "(?i)" at the top level: the state changes for the rest of the branch */
+                       bool nc = nocase, ds = dotall;
+                       size_t e = i;
+                       if (option_group_at(p, i, nc, ds, e) != 1) return false;
+                       nocase = nc;
+                       dotall = ds;
+                       j = e;
+                       return true;
+                   }()) {
         } else if (c == '(') {
             int depth = 0;
             for (;; j++) {
@@ -630,7 +690,11 @@ LitRun longest_literal_run(const std::string &p) {
         const size_t after = j;
         skip_quant(j);
         if (is_lit && j == after) {
-            if (cur.bytes.empty()) cur.begin = i;
+            if (cur.bytes.empty()) {
+                cur.begin = i;
+                cur.nocase = nocase;
+                cur.dotall = dotall;
+            }
             cur.bytes.push_back((char)lit);
             cur.end = j;
         } else {
@@ -703,19 +767,21 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
         pat.as_end = assertion(p.back());
         p.erase(p.size() - 2);
     }
-    pat.nocase = flags & HS_FLAG_CASELESS;
+    const bool base_nocase = flags & HS_FLAG_CASELESS, base_dotall = flags & HS_FLAG_DOTALL;
     pat.single = flags & HS_FLAG_SINGLEMATCH;
     pat.som = flags & HS_FLAG_SOM_LEFTMOST;
     pat.id = id;
-    const bool dotall = flags & HS_FLAG_DOTALL;
     /* `{` opens a repeat only when a well-formed {m}, {m,} or {m,n} follows; otherwise it (and
      * a lone `}`) is an ordinary character, as in PCRE ("foo.{,10}bar" is twelve literal-ish
      * positions: unit/hyperscan/expr_info.cpp:211) */
     auto is_repeat = [&](size_t k) { return TailBuilder::is_repeat_at(p, k); };
     /* the branch is R1 LIT R2 around its longest top-level literal run (the front one on a tie);
      * \b / \B may hug the literal on either side */
-    LitRun run = longest_literal_run(p);
+    LitRun run = longest_literal_run(p, base_nocase, base_dotall);
     if (run.bytes.empty()) throw NoLiteral();
+    /* i / s settings in front of the literal ("ab(?i)cdef") reach it and what follows it */
+    pat.nocase = run.nocase;
+    const bool dotall = run.dotall;
     size_t r1_end = run.begin, r2_begin = run.end;
     if (run.begin >= 2 && escape_at(run.begin - 2, "bB")) {
         pat.as_lit_pre = assertion(p[run.begin - 1]);
@@ -747,7 +813,7 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     size_t i = r2_begin;
     if (r1_end != 0) {
         /* the literal is not at the front: R1 backwards, R2 as a position automaton */
-        pat.pre = compile_auto(p.substr(0, r1_end), pat.nocase, dotall, true);
+        pat.pre = compile_auto(p.substr(0, r1_end), base_nocase, base_dotall, true);
         pat.g = compile_auto(p.substr(r2_begin), pat.nocase, dotall);
         pat.has_pre = pat.pre.npos != 0 || pat.pre.has_cond;
         pat.general = pat.g.npos != 0 || pat.g.has_cond;
@@ -933,8 +999,15 @@ void distribute_group(const std::string &b, unsigned flags, unsigned id, std::ve
         }
         const bool quantified = end < b.size() && (b[end] == '?' || b[end] == '*' || b[end] == '+' || TailBuilder::is_repeat_at(b, end));
         if (!plain || quantified) { i = end; continue; }
-        for (const std::string &a : alts) /* "(*VERB)", "(+x)": not ours to rearrange */
+        for (const std::string &a : alts) { /* "(*VERB)", "(+x)": not ours to rearrange */
             if (!a.empty() && (strchr("*+?", a[0]) || TailBuilder::is_repeat_at(a, 0))) throw NoLiteral();
+            for (size_t k = 0; k + 2 < a.size(); k++) { /* an option set inside would outlive its group */
+                bool nc = false, ds = false;
+                size_t e = 0;
+                if (a[k] == '\\') { k++; continue; }
+                if (a[k] == '(' && option_group_at(a, k, nc, ds, e) == 1) throw NoLiteral();
+            }
+        }
         if (out.size() + alts.size() > kMaxBranches) throw ParseError{"Pattern too large."};
         const size_t before = out.size();
         for (const std::string &a : alts) {
@@ -993,9 +1066,31 @@ std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsi
             if (c == ')') depth--;
             if (c != '|' || depth != 0) continue;
         }
+        const std::string branch = p.substr(from, k - from);
         try {
-            expand_branch(p.substr(from, k - from), flags, id, out, 0);
+            expand_branch(branch, flags, id, out, 0);
         } catch (const NeverMatch &) { /* an alternative that cannot match is dropped; all of them: an error */
+        }
+        { /* "a(?i)b|c": a setting at the top level also governs the alternatives after it */
+            bool nc = flags & HS_FLAG_CASELESS, ds = flags & HS_FLAG_DOTALL;
+            int d = 0;
+            for (size_t q = 0; q < branch.size(); q++) {
+                size_t e = q;
+                if (branch[q] == '\\') { q++; continue; }
+                if (branch[q] == '[') { parse_bracket_class(branch, e); q = e - 1; continue; }
+                if (branch[q] == '(' && d == 0) { /* (a scoped "(?i:" group keeps its setting to itself) */
+                    bool n2 = nc, s2 = ds;
+                    if (option_group_at(branch, q, n2, s2, e) == 1) {
+                        nc = n2;
+                        ds = s2;
+                        q = e - 1;
+                        continue;
+                    }
+                }
+                if (branch[q] == '(') d++;
+                if (branch[q] == ')') d--;
+            }
+            flags = (flags & ~(HS_FLAG_CASELESS | HS_FLAG_DOTALL)) | (nc ? HS_FLAG_CASELESS : 0) | (ds ? HS_FLAG_DOTALL : 0);
         }
         from = k + 1;
     }

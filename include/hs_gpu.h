@@ -37,7 +37,7 @@
  * from the literal: the job of Rose's suffix / prefix engines). Supported fragment syntax: literal
  * characters, escapes, `.`, \d \D \w \W \s \S, [...] classes (with [:posix:] names), the
  * quantifiers ? * + {m} {m,} {m,n} and their lazy forms (every end offset is reported, so greed
- * is immaterial), leading (?ims-ims) options, groups `( )` / `(?: )` / named / `(?# )` with
+ * is immaterial), (?ims-ims) options in front, (?is-is) settings and (?i:...) groups inside, groups `( )` / `(?: )` / named / `(?# )` with
  * alternation inside them, nested and
  * quantified (a fragment compiles to a position automaton of <= 4096 positions, run LimEx-style:
  * one shift for the chains, exception rows for the rest). Anchors and
@@ -46,7 +46,7 @@
  * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline). \b / \B anywhere
  * (inside a fragment they become conditional layers of its automaton).
  * Anything else (branches without a mandatory literal, anchors away from the edges of a branch,
- * look-around, back-references, possessive quantifiers, options after the start, streaming
+ * look-around, back-references, possessive quantifiers, (?m) / (?x) after the start, streaming
  * mode) is
  * rejected with HS_COMPILER_ERROR:
  * the regex compiler proper is out of scope.

@@ -1,6 +1,6 @@
 """The reference's hscollider regression corpus (tools/hscollider/test_cases) for the patterns the
 hs_* facade accepts: tests/golden/collider_subset.json, made by tools/make_collider_fixture.py.
-8853 of its corpus lines carry the end offsets the reference itself must report (the `id="corpus":
+8905 of its corpus lines carry the end offsets the reference itself must report (the `id="corpus":
 to, ...` lines); the rest come from the Python model that agrees with all of those.
 
 CPU form: literal hits from the HWLM oracle for the literals each database is keyed on, then the
@@ -78,7 +78,7 @@ def cpu_events(db, blocks):
 def test_fixture_shape():
     cases = load_cases()
     kinds = [k for c in cases for k in c["kind"]]
-    assert len(cases) >= 980 and kinds.count("reference") >= 8800
+    assert len(cases) >= 1000 and kinds.count("reference") >= 8800
     assert len({c["file"] for c in cases}) >= 15  # spread over the corpus's files
 
 

@@ -435,7 +435,7 @@ def test_lazy_quantifiers_inline_flags_named_groups_posix_classes():
     assert sorted(ev) == sorted(want)
     assert {e[1] for e in ev} == set(range(1, len(pairs) + 1))
     import pytest
-    for bad in [r"foo.*+bar", r"foo(?=bar)", r"foo(?<!x)bar", r"(?x)foo", r"foo[[:nope:]]", r"foo(?i)bar"]:
+    for bad in [r"foo.*+bar", r"foo(?=bar)", r"foo(?<!x)bar", r"(?x)foo", r"foo[[:nope:]]", r"foo(?m)bar", r"foo(?x)bar"]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
 
@@ -541,3 +541,28 @@ def test_differential_fuzz_against_re():
         assert sorted(run_exprs_auto([(expr, fl, 1)], blocks)) == sorted(brute_context([(expr, fl, 1)], blocks)), (expr, fl, blocks)
         compared += 1
     assert compared >= 250
+
+
+def test_options_inside_a_pattern():
+    """(?i) / (?s) set inside a pattern hold to the end of the enclosing group (and through its
+    later alternatives); (?i:...) holds inside its own group. The scoped form means the same in
+    Python; the unscoped form is modelled by writing its scope out."""
+    S = hs.HS_FLAG_DOTALL
+    # (expression here, the same language for Python)
+    pairs = [(r"foo(?i:bar)baz", r"foo(?i:bar)baz"), (r"nested(?i:less(?-i:ful)less)lit", r"nested(?i:less(?-i:ful)less)lit"),
+             (r"(?i:hat|kettle)s", r"(?i:hat|kettle)s"), (r"foo.*(?i-s:bar.*baz).*bing", r"foo.*(?i-s:bar.*baz).*bing"),
+             (r"ab(?i)cdef(?-i)ghi", r"ab(?i:cdef)ghi"), (r"g(?i)odzilla", r"g(?i:odzilla)"), (r"(?i)god(?-i)z(?i)illa", r"(?i:god)z(?i:illa)"),
+             (r"x(a(?i)b|c)d", r"x(a(?i:b)|(?i:c))d"), (r"k(?s).y|m.n", r"k(?s:.)y|m(?s:.)n"), (r"[a-c]+(?i)lit\d", r"[a-c]+(?i:lit)\d")]
+    exprs = [(h, S if "bing" in h else 0, i + 1) for i, (h, _p) in enumerate(pairs)]
+    pyexprs = [(p, S if "bing" in p else 0, i + 1) for i, (_h, p) in enumerate(pairs)]
+    words = [b"foo", b"bar", b"BAR", b"baz", b"BAZ", b"nested", b"less", b"LESS", b"ful", b"FUL", b"lit", b"LIT", b"hat", b"HAT", b"kettle",
+             b"s", b"bing", b"\n", b"ab", b"cdef", b"CDEF", b"ghi", b"GHI", b"g", b"G", b"odzilla", b"ODZILLA", b"god", b"GOD", b"z", b"Z", b"illa",
+             b"x", b"a", b"b", b"B", b"c", b"C", b"d", b"k", b"y", b"m", b"n", b"7", b" "]
+    rng = np.random.default_rng(93)
+    blocks = [b"".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 9)))) for _ in range(400)]
+    blocks += [b"fooBARbaz fooBARBAZ", b"nestedLESSfulLESSlit nestedlessFULlesslit", b"HATs kettleS", b"foo BAR\nbaz", b"foo bar baz bing",
+               b"abCDEFghi ABcdefghi abcdefGHI", b"gODZILLA Godzilla", b"GODzILLA godZilla", b"xaBd xCd xAbd", b"k\ny m\nn", b"abcLIT7 ABlit7"]
+    ev = run_exprs_auto(exprs, blocks)
+    want = brute_context(pyexprs, blocks)
+    assert sorted(ev) == sorted(want)
+    assert {e[1] for e in ev} == set(range(1, len(pairs) + 1))

@@ -34,7 +34,7 @@ def gen_atom(r, depth):
     if k < 0.85 and depth < 3:
         n = r.randint(1, 3)
         alts = [gen_cat(r, depth + 1, r.randint(0, 3)) for _ in range(n)]
-        g = r.choice(["(", "(?:"]) + "|".join(alts) + ")"
+        g = r.choice(["(", "(?:", "(?:", "(?i:", "(?s:", "(?-i:"]) + "|".join(alts) + ")"
         if r.random() < 0.25:
             g += r.choice(["?", "*", "+", "{2}", "{1,2}", "{0,3}", "{2,}"])
         return g
