@@ -363,10 +363,13 @@ def test_literal_in_the_middle_matches_brute_force():
 def brute_context(exprs, blocks):
     """like brute_full, but every candidate end offset is tested with the whole block visible
     (a lookahead pins the end), so \\b, \\B and the end anchors see the real neighbours.
-    Dialect: the reference's \\z is Python's \\Z; its \\Z is Python's (?=\\n?\\Z)."""
+    Dialect: the reference's \\z is Python's \\Z; its \\Z is Python's (?=\\n?\\Z).
+    exprs: (pattern, flags, id[, ext dict]); ext bounds as hs_expr_ext_t (min_length from the
+    leftmost start)."""
     out = []
     for b, data in enumerate(blocks):
-        for pat, fl, pid in exprs:
+        for pat, fl, pid, *rest in exprs:
+            ext = rest[0] if rest else {}
             rf = (re.I if fl & hs.HS_FLAG_CASELESS else 0) | (re.S if fl & hs.HS_FLAG_DOTALL else 0) | \
                  (re.M if fl & hs.HS_FLAG_MULTILINE else 0)
             py = pat.replace("\\Z", "(?=\\n?\\Z)").replace("\\z", "\\Z")
@@ -375,15 +378,24 @@ def brute_context(exprs, blocks):
                 m = rx.search(data)  # the leftmost start that can end at `to`
                 if m and m.start() == to:  # (an empty match there is no match: look further left is moot)
                     m = None
-                if m:
-                    out.append((b, pid, m.start() if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, to))
+                if not m:
+                    continue
+                if "min_offset" in ext and to < ext["min_offset"]:
+                    continue
+                if "max_offset" in ext and to > ext["max_offset"]:
+                    continue
+                if "min_length" in ext and to - m.start() < ext["min_length"]:
+                    continue
+                out.append((b, pid, m.start() if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, to))
     return out
 
 
 def run_exprs_auto(exprs, blocks):
-    """run_exprs with the literals taken from the database itself (hs_database_literal)"""
-    db = hs.Database.compile([e[0] for e in exprs], [e[1] for e in exprs], [e[2] for e in exprs])
-    return run_exprs(exprs, [(b, hs.HS_FLAG_CASELESS if nc else 0) for b, nc, _rid in db.literals()], blocks)
+    """run_exprs with the literals taken from the database itself (hs_database_literal);
+    exprs: (pattern, flags, id[, ext dict])"""
+    ext = [hs.ExprExt.make(**e[3]) if len(e) > 3 and e[3] else None for e in exprs]
+    db = hs.Database.compile_ext([e[0] for e in exprs], [e[1] for e in exprs], [e[2] for e in exprs], ext)
+    return run_exprs(exprs, [(b, hs.HS_FLAG_CASELESS if nc else 0) for b, nc, _rid in db.literals()], blocks, ext)
 
 
 def test_word_boundaries_and_absolute_anchors():

@@ -86,7 +86,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--n", type=int, default=2000)
+    ap.add_argument("--multi", action="store_true", help="databases of 2-6 expressions with ext bounds and SINGLEMATCH mixed in")
     a = ap.parse_args()
+    if a.multi:
+        return main_multi(a)
     r = random.Random(a.seed)
     signal.signal(signal.SIGALRM, lambda *_: (_ for _ in ()).throw(Timeout()))
     tried = accepted = compared = 0
@@ -128,6 +131,69 @@ def main():
             print("  want", sorted(e for e in want if e[0] == bad))
             sys.exit(1)
     print(f"{tried} expressions, {accepted} accepted by the facade, {compared} compared: all equal")
+
+
+def singlematch_filter(want, single_ids):
+    """under SINGLEMATCH only the first event of an id in a block is owed"""
+    out, seen = [], set()
+    for e in sorted(want, key=lambda e: (e[0], e[3], e[1])):
+        if e[1] in single_ids:
+            if (e[0], e[1]) in seen:
+                continue
+            seen.add((e[0], e[1]))
+        out.append(e)
+    return out
+
+
+def main_multi(a):
+    r = random.Random(a.seed)
+    signal.signal(signal.SIGALRM, lambda *_: (_ for _ in ()).throw(Timeout()))
+    flag_choices = [0, 0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL, hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_SINGLEMATCH]
+    dbs = compared = 0
+    for _ in range(a.n):
+        exprs = []
+        for pid in range(1, r.randint(2, 6) + 1):
+            for _try in range(20):
+                expr, fl = gen_expr(r), r.choice(flag_choices)
+                ext = {}
+                if r.random() < 0.3:
+                    ext["min_offset"] = r.randint(0, 12)
+                if r.random() < 0.3:
+                    ext["max_offset"] = ext.get("min_offset", 0) + r.randint(0, 25)
+                if r.random() < 0.2:
+                    ext["min_length"] = r.randint(1, 6)
+                if "min_length" in ext and "max_offset" in ext and ext["min_length"] > ext["max_offset"]:
+                    del ext["min_length"]
+                try:
+                    re.compile(expr.replace("\\Z", "(?=\\n?\\Z)").replace("\\z", "\\Z").encode())
+                    hs.Database.compile_ext([expr], [fl], [pid], [hs.ExprExt.make(**ext) if ext else None])
+                except (re.error, hs.HsError):
+                    continue
+                exprs.append((expr, fl, pid, ext))
+                break
+        if len(exprs) < 2:
+            continue
+        dbs += 1
+        blocks = [gen_block(r) for _ in range(5)]
+        try:
+            signal.alarm(20)
+            want = brute_context(exprs, blocks)
+            signal.alarm(0)
+        except Timeout:
+            continue
+        want = singlematch_filter(want, {e[2] for e in exprs if e[1] & hs.HS_FLAG_SINGLEMATCH})
+        got = run_exprs_auto(exprs, blocks)
+        compared += 1
+        if sorted(got) != sorted(want):
+            bad = sorted(set(got) ^ set(want))[0][0]
+            print("MISMATCH", exprs, "block", blocks[bad])
+            print("  got ", sorted(e for e in got if e[0] == bad))
+            print("  want", sorted(e for e in want if e[0] == bad))
+            sys.exit(1)
+        for b in range(len(blocks)):  # delivery order inside a block
+            tos = [e[3] for e in got if e[0] == b]
+            assert tos == sorted(tos), ("order", exprs, blocks[b])
+    print(f"{dbs} databases, {compared} compared: all equal")
 
 
 if __name__ == "__main__":
