@@ -67,18 +67,26 @@ bool char_escape(const std::string &p, size_t &i, unsigned char &out) {
         i = k;
         return true;
     }
-    case 'x': {
+    case 'x': { /* \xH, \xHH (PCRE: zero to two hex digits), \x{H...} with a value that fits a byte */
+        auto hex = [](char h) {
+            return (h >= '0' && h <= '9') ? h - '0' : (h >= 'a' && h <= 'f') ? h - 'a' + 10 : (h >= 'A' && h <= 'F') ? h - 'A' + 10 : -1;
+        };
         unsigned v = 0;
-        for (int k = 1; k <= 2; k++) {
-            if (i + k >= p.size()) return false;
-            char h = p[i + k];
-            unsigned d = (h >= '0' && h <= '9') ? h - '0' : (h >= 'a' && h <= 'f') ? h - 'a' + 10
-                         : (h >= 'A' && h <= 'F') ? h - 'A' + 10 : 99;
-            if (d == 99) return false;
-            v = v * 16 + d;
+        size_t k = i + 1;
+        if (k < p.size() && p[k] == '{') {
+            size_t j = k + 1, digits = 0;
+            for (; j < p.size() && hex(p[j]) >= 0; j++, digits++) {
+                v = v * 16 + (unsigned)hex(p[j]);
+                if (v > 0xff) return false; /* beyond one byte: a UTF-8 mode matter */
+            }
+            if (j >= p.size() || p[j] != '}' || digits == 0) return false;
+            out = (unsigned char)v;
+            i = j + 1;
+            return true;
         }
+        for (int d = 0; d < 2 && k < p.size() && hex(p[k]) >= 0; d++, k++) v = v * 16 + (unsigned)hex(p[k]);
         out = (unsigned char)v;
-        i += 3;
+        i = k;
         return true;
     }
     default:
