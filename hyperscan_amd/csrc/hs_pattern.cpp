@@ -1034,8 +1034,24 @@ void distribute_group(const std::string &b, unsigned flags, unsigned id, std::ve
  * pattern reporting the same id (the reference builds one graph; the reports are the same) */
 std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsigned id) {
     check_flags(flags, false);
+    /* \Q...\E quotes: rewritten as escaped characters first (also inside classes) */
+    std::string p;
+    for (size_t k = 0; k < expr.size(); k++) {
+        if (expr[k] == '\\' && k + 1 < expr.size() && expr[k + 1] == 'Q') {
+            size_t e = expr.find("\\E", k + 2);
+            const size_t stop = e == std::string::npos ? expr.size() : e;
+            for (size_t q = k + 2; q < stop; q++) {
+                const unsigned char c = (unsigned char)expr[q];
+                if (!isalnum(c) && c < 0x80) p.push_back('\\');
+                p.push_back((char)c);
+            }
+            k = e == std::string::npos ? expr.size() : e + 1;
+            continue;
+        }
+        p.push_back(expr[k]);
+        if (expr[k] == '\\' && k + 1 < expr.size()) p.push_back(expr[++k]);
+    }
     /* leading inline options: (?i) (?s) (?m), combined and negated forms */
-    std::string p = expr;
     while (p.size() >= 4 && p[0] == '(' && p[1] == '?') {
         size_t k = 2;
         bool on = true, any = false;

@@ -270,3 +270,10 @@ def test_literal_api_random_sets_on_cpu():
         got = to_id(cpu_scan(db, data)[0])
         assert set(got) == want and len(got) == len(want), trial
         assert [t for t, _i in got] == sorted(t for t, _i in got)
+
+
+def test_quoted_sequences():
+    # \Q...\E: everything between is literal (also inside a class; an unclosed \Q runs to the end)
+    db = hs.Database.compile([r"a\Q.*+?(x)[y]\Eb+", r"[\Q^]\E-]{2}end", r"tail\Qopen"], [0, 0, 0], [1, 2, 3])
+    assert [b for b, _n, _i in db.literals()] == [b"+?(x)[y]", b"end", b"tailopen"]
+    assert to_id(cpu_scan(db, b"a.*+?(x)[y]bb  ^]end -^end tailopen")[0]) == [(12, 1), (13, 1), (20, 2), (26, 2), (35, 3)]
