@@ -4,7 +4,8 @@ random expressions from a small grammar (literals, classes, groups, alternation,
 lazy and counted, \\b \\B, ^ $ with and without MULTILINE, CASELESS / DOTALL / SOM_LEFTMOST); for
 every expression the facade accepts, the events over random blocks (literal hits from the HWLM
 oracle -> hs_confirm_batch) must equal the brute-force model with the whole block visible.
-  python tools/fuzz_patterns.py [--seed S] [--n N]
+  python tests/fuzz_patterns.py [--seed S] [--n N] [--multi]
+(lives under tests/: it drives the oracle, which only test code may do)
 Exits non-zero on the first disagreement, printing the expression, flags and block."""
 import argparse
 import os

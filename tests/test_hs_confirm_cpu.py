@@ -523,21 +523,20 @@ def test_word_boundaries_inside_fragments():
 
 
 def test_caseless_negated_class():
-    # found by tools/fuzz_patterns.py: caseless [^a] excludes a AND A (fold before negating)
+    # found by tests/fuzz_patterns.py: caseless [^a] excludes a AND A (fold before negating)
     exprs = [(r"XY??[^a\n]+?", hs.HS_FLAG_CASELESS | hs.HS_FLAG_MULTILINE, 1), (r"ab[^b-c]x", hs.HS_FLAG_CASELESS, 2)]
     blocks = [b"XYa-b_aa-b", b"xyAz", b"abBx abCx abdx ABDX abax"]
     assert sorted(run_exprs_auto(exprs, blocks)) == sorted(brute_context(exprs, blocks))
 
 
 def test_differential_fuzz_against_re():
-    """a fixed slice of tools/fuzz_patterns.py: random expressions from its grammar, every accepted
+    """a fixed slice of tests/fuzz_patterns.py: random expressions from its grammar, every accepted
     one compared with the brute-force model on random blocks"""
     import random
     import sys
     import os
 
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import fuzz_patterns as fz
+    from tests import fuzz_patterns as fz
 
     r = random.Random(5)
     flags = [0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL, hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SOM_LEFTMOST]

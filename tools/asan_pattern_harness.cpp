@@ -1,6 +1,6 @@
 // tools/asan_pattern_harness.cpp -- the pattern compiler and the host automata under
 // AddressSanitizer + UBSan: every line of the input file is compiled (grammar strings, mutated
-// grammar strings and plain garbage from tools/fuzz_patterns.py's generator); what compiles is
+// grammar strings and plain garbage from tests/fuzz_patterns.py's generator); what compiles is
 // run forwards and backwards over random data. No GPU, no library: only hs_pattern.cpp.
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -Iinclude tools/asan_pattern_harness.cpp \
 //       hyperscan_amd/csrc/hs_pattern.cpp -o /tmp/asan_harness && /tmp/asan_harness patterns.txt
