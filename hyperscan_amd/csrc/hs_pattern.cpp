@@ -22,6 +22,26 @@
 
 namespace hsf {
 
+/* HS_FLAG_UTF8 for the expression being compiled (set by parse_pattern): positions are code
+ * points. Literal text is its UTF-8 bytes either way; what changes is that `.`, negated classes
+ * and \W \D \S take a whole multi-byte code point, that a non-ASCII character is one atom for a
+ * quantifier, and that caseless k and s also match U+212A KELVIN SIGN and U+017F LONG S (the
+ * reference folds those without HS_FLAG_UCP too: tools/hscollider/test_cases/pcre/utf8.txt). */
+thread_local bool g_utf8 = false;
+
+inline size_t utf8_len(unsigned char lead) { return lead < 0x80 ? 1 : lead < 0xc2 ? 0 : lead < 0xe0 ? 2 : lead < 0xf0 ? 3 : lead < 0xf5 ? 4 : 0; }
+
+bool utf8_valid(const std::string &s) {
+    for (size_t i = 0; i < s.size();) {
+        const size_t n = utf8_len((unsigned char)s[i]);
+        if (!n || i + n > s.size()) return false;
+        for (size_t k = 1; k < n; k++)
+            if (((unsigned char)s[i + k] & 0xc0) != 0x80) return false;
+        i += n;
+    }
+    return true;
+}
+
 bool is_word_char(unsigned char c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
 bool is_alpha(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
 
@@ -191,6 +211,7 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i, bool nocase = false
             }
         } else {
             lo = (unsigned char)p[j++];
+            if (g_utf8 && lo >= 0x80) throw ParseError{"Non-ASCII class members are not supported in UTF-8 mode."};
         }
         if (is_class) {
             cls |= item;
@@ -211,6 +232,7 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i, bool nocase = false
             }
             if (hi < lo) throw ParseError{"Range out of order in character class."};
         }
+        if (g_utf8 && hi >= 0x80) throw ParseError{"Non-ASCII class members are not supported in UTF-8 mode."};
         add_range(cls, lo, hi);
     }
     i = j + 1;
@@ -232,6 +254,44 @@ inline void bits_set(Bits &a, size_t i) {
     a[i / 64] |= 1ull << (i % 64);
 }
 inline bool bits_test(const Bits &a, size_t i) { return i / 64 < a.size() && (a[i / 64] >> (i % 64) & 1); }
+
+/* UTF-8 mode: "\xHH" / "\x{H...}" at p[i] (the backslash) naming a code point above 0x7f ->
+ * its UTF-8 bytes; false for anything else (the byte-valued paths handle those) */
+bool utf8_hex_escape(const std::string &p, size_t i, std::string &bytes, size_t &end) {
+    if (!g_utf8 || i + 1 >= p.size() || p[i] != '\\' || p[i + 1] != 'x') return false;
+    auto hex = [](char h) {
+        return (h >= '0' && h <= '9') ? h - '0' : (h >= 'a' && h <= 'f') ? h - 'a' + 10 : (h >= 'A' && h <= 'F') ? h - 'A' + 10 : -1;
+    };
+    unsigned long cp = 0;
+    size_t k = i + 2;
+    if (k < p.size() && p[k] == '{') {
+        size_t j = k + 1, digits = 0;
+        for (; j < p.size() && hex(p[j]) >= 0; j++, digits++) {
+            cp = cp * 16 + (unsigned)hex(p[j]);
+            if (cp > 0x10ffff) throw ParseError{"Code point beyond U+10FFFF."};
+        }
+        if (j >= p.size() || p[j] != '}' || digits == 0) return false;
+        k = j + 1;
+    } else {
+        for (int d = 0; d < 2 && k < p.size() && hex(p[k]) >= 0; d++, k++) cp = cp * 16 + (unsigned)hex(p[k]);
+    }
+    if (cp < 0x80) return false;
+    if (cp >= 0xd800 && cp <= 0xdfff) throw ParseError{"Surrogate code points are not characters."};
+    bytes.clear();
+    if (cp < 0x800) {
+        bytes.push_back((char)(0xc0 | cp >> 6));
+    } else if (cp < 0x10000) {
+        bytes.push_back((char)(0xe0 | cp >> 12));
+        bytes.push_back((char)(0x80 | (cp >> 6 & 0x3f)));
+    } else {
+        bytes.push_back((char)(0xf0 | cp >> 18));
+        bytes.push_back((char)(0x80 | (cp >> 12 & 0x3f)));
+        bytes.push_back((char)(0x80 | (cp >> 6 & 0x3f)));
+    }
+    bytes.push_back((char)(0x80 | (cp & 0x3f)));
+    end = k;
+    return true;
+}
 
 /* "(?i)" "(?-s)" "(?is-m:" ... at p[i] == '(': which flags it switches and whether it opens a
  * scoped group. Only i and s may change inside a pattern here (m would move the meaning of the
@@ -500,6 +560,27 @@ struct TailBuilder {
             i += 2;
             return f;
         }
+        {
+            std::string seq; /* a non-ASCII character, written raw or as \x..: one atom made of its bytes */
+            size_t end = i;
+            if (g_utf8 && c >= 0x80) {
+                const size_t n = utf8_len(c);
+                if (!n || i + n > p.size()) throw ParseError{"Expression is not valid UTF-8."};
+                seq = p.substr(i, n);
+                end = i + n;
+            }
+            if (!seq.empty() || utf8_hex_escape(p, i, seq, end)) {
+                if (nocase) throw ParseError{"Caseless non-ASCII characters need HS_FLAG_UCP tables: not supported."};
+                Frag f;
+                for (char b : seq) {
+                    ByteSet one;
+                    one.set((unsigned char)b);
+                    f = cat(f, leaf(one));
+                }
+                i = end;
+                return f;
+            }
+        }
         ByteSet set;
         if (c == '\\') {
             if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
@@ -511,6 +592,7 @@ struct TailBuilder {
                 size_t j = i + 1;
                 unsigned char lit;
                 if (!char_escape(p, j, lit)) throw ParseError{"Unsupported escape sequence."};
+                if (g_utf8 && lit >= 0x80) throw ParseError{"Escapes above \\x7f are code points in UTF-8 mode: not supported."};
                 set.set(lit);
                 i = j;
             }
@@ -526,7 +608,52 @@ struct TailBuilder {
             set.set(c);
             i++;
         }
+        if (!g_utf8) return leaf(set);
+        /* UTF-8: the ASCII members as one position; "everything else" as the multi-byte code
+         * points; caseless k / s bring their non-ASCII partners */
+        size_t high = 0;
+        for (unsigned b = 0x80; b < 0x100; b++) high += set[b];
+        if (high != 0 && high != 128) throw ParseError{"Classes with some non-ASCII members are not supported in UTF-8 mode."};
+        ByteSet ascii = nocase ? fold_case(set) : set;
+        for (unsigned b = 0x80; b < 0x100; b++) ascii.reset(b);
+        Frag f;
+        bool have = false;
+        auto add = [&](const Frag &x) {
+            if (!have) { f = x; have = true; return; }
+            for (int k = 0; k < 3; k++) {
+                bits_or(f.first[k], x.first[k]);
+                bits_or(f.last[k], x.last[k]);
+            }
+            f.wmin = std::min(f.wmin, x.wmin);
+            f.wmax = std::max(f.wmax, x.wmax);
+        };
+        auto seq = [&](std::initializer_list<std::pair<unsigned, unsigned>> ranges) {
+            Frag x;
+            for (const auto &r : ranges) {
+                ByteSet one;
+                add_range(one, r.first, r.second);
+                x = cat(x, leaf(one, false));
+            }
+            return x;
+        };
+        if (ascii.any()) add(leaf(ascii, false));
+        if (high == 128) { /* any multi-byte code point (input is valid UTF-8 by contract) */
+            add(seq({{0xc2, 0xdf}, {0x80, 0xbf}}));
+            add(seq({{0xe0, 0xef}, {0x80, 0xbf}, {0x80, 0xbf}}));
+            add(seq({{0xf0, 0xf4}, {0x80, 0xbf}, {0x80, 0xbf}, {0x80, 0xbf}}));
+        } else if (nocase) {
+            if (ascii['k']) add(seq({{0xe2, 0xe2}, {0x84, 0x84}, {0xaa, 0xaa}})); /* U+212A */
+            if (ascii['s']) add(seq({{0xc5, 0xc5}, {0xbf, 0xbf}}));               /* U+017F */
+        }
+        if (!have) throw NeverMatch();
+        return f;
+    }
+    /* one position */
+    Frag leaf(const ByteSet &set, bool fold = true) {
+        const bool keep = nocase;
+        if (!fold) nocase = false;
         const unsigned pos = new_pos(set);
+        nocase = keep;
         Frag f;
         bits_set(f.first[0], pos);
         bits_set(f.last[0], pos);
@@ -656,7 +783,10 @@ LitRun longest_literal_run(const std::string &p, bool nocase, bool dotall) {
         size_t j = i;
         unsigned char lit = 0;
         bool is_lit = false;
-        if (c == '\\') {
+        std::string useq;
+        if (utf8_hex_escape(p, i, useq, j)) { /* \x.. naming a non-ASCII character: its bytes */
+            is_lit = !nocase;
+        } else if (c == '\\') {
             if (i + 1 >= p.size()) throw ParseError{"Trailing backslash."};
             bool ok;
             class_escape(p[i + 1], ok);
@@ -690,11 +820,18 @@ LitRun longest_literal_run(const std::string &p, bool nocase, bool dotall) {
             j++;
         } else if (c == '.' || strchr(")|^$*+?", c) || (c == '{' && TailBuilder::is_repeat_at(p, i))) {
             j = i + 1; /* not a literal; a misplaced operator is reported by the fragment compiler */
+        } else if (g_utf8 && c >= 0x80) { /* a non-ASCII character: all its bytes, or none */
+            const size_t n = utf8_len(c);
+            if (!n || i + n > p.size()) throw ParseError{"Expression is not valid UTF-8."};
+            j = i + n;
+            is_lit = !nocase;
         } else {
             lit = c;
             j = i + 1;
             is_lit = true;
         }
+        /* caseless k / s have non-ASCII partners in UTF-8 mode: a class, not a literal byte */
+        if (is_lit && g_utf8 && nocase && j == i + 1 && strchr("kKsS", (char)lit)) is_lit = false;
         const size_t after = j;
         skip_quant(j);
         if (is_lit && j == after) {
@@ -703,7 +840,9 @@ LitRun longest_literal_run(const std::string &p, bool nocase, bool dotall) {
                 cur.nocase = nocase;
                 cur.dotall = dotall;
             }
-            cur.bytes.push_back((char)lit);
+            if (!useq.empty()) cur.bytes += useq;
+            else if (g_utf8 && c >= 0x80) cur.bytes.append(p, i, after - i);
+            else cur.bytes.push_back((char)lit);
             cur.end = j;
         } else {
             close();
@@ -830,7 +969,7 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
     }
     /* a tail with a group in it goes to the position automaton; the linear form below stays the
      * path for everything it can express */
-    bool grouped = false;
+    bool grouped = g_utf8 && i < p.size(); /* (UTF-8 mode lives in the builder only) */
     for (size_t k = i; k < p.size() && !grouped; k++) {
         if (p[k] == '\\') { grouped = k + 1 < p.size() && (p[k + 1] == 'b' || p[k + 1] == 'B'); k++; }
         else if (p[k] == '[') { size_t e = k; parse_bracket_class(p, e); k = e - 1; }
@@ -1069,8 +1208,13 @@ std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsi
     /* HS_FLAG_PREFILTER allows a superset of the matches: the exact set is one. HS_FLAG_ALLOWEMPTY
      * permits patterns that can match the empty string: none here can (a mandatory literal).
      * HS_FLAG_QUIET: the expression reports nothing (src/hs_compile.h:328-330 "ignore match reporting"). */
-    const unsigned unsupported = HS_FLAG_UTF8 | HS_FLAG_UCP | HS_FLAG_COMBINATION;
+    const unsigned unsupported = HS_FLAG_UCP | HS_FLAG_COMBINATION;
     if (flags & unsupported) throw ParseError{"Unsupported flag for the GPU literal engine."};
+    struct Utf8Mode { /* the builder's mode for this expression */
+        explicit Utf8Mode(bool on) { g_utf8 = on; }
+        ~Utf8Mode() { g_utf8 = false; }
+    } utf8_mode((flags & HS_FLAG_UTF8) != 0);
+    if ((flags & HS_FLAG_UTF8) && !utf8_valid(expr)) throw ParseError{"Expression is not valid UTF-8."};
     std::vector<Pattern> out;
     size_t from = 0;
     int depth = 0;

@@ -45,6 +45,9 @@
  * also before the data's final newline, reported before the newline as the reference does; with
  * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline). \b / \B anywhere
  * (inside a fragment they become conditional layers of its automaton).
+ * HS_FLAG_UTF8 (without HS_FLAG_UCP): `.`, negated classes and \W \D \S take whole code points, a
+ * non-ASCII character is one atom, \x{...} names a code point, caseless k / s also match U+212A /
+ * U+017F; non-ASCII class members and caseless non-ASCII letters are refused.
  * Anything else (branches without a mandatory literal, anchors away from the edges of a branch,
  * look-around, back-references, possessive quantifiers, (?m) / (?x) after the start, streaming
  * mode) is

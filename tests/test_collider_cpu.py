@@ -1,6 +1,6 @@
 """The reference's hscollider regression corpus (tools/hscollider/test_cases) for the patterns the
 hs_* facade accepts: tests/golden/collider_subset.json, made by tools/make_collider_fixture.py.
-8905 of its corpus lines carry the end offsets the reference itself must report (the `id="corpus":
+9149 of its corpus lines carry the end offsets the reference itself must report (the `id="corpus":
 to, ...` lines); the rest come from the Python model that agrees with all of those.
 
 CPU form: literal hits from the HWLM oracle for the literals each database is keyed on, then the
@@ -19,7 +19,7 @@ from tests import oracle_binding as ob
 
 FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "collider_subset.json")
 FLAGS = {"i": hs.HS_FLAG_CASELESS, "s": hs.HS_FLAG_DOTALL, "m": hs.HS_FLAG_MULTILINE, "H": hs.HS_FLAG_SINGLEMATCH,
-         "L": hs.HS_FLAG_SOM_LEFTMOST, "V": hs.HS_FLAG_ALLOWEMPTY}
+         "L": hs.HS_FLAG_SOM_LEFTMOST, "V": hs.HS_FLAG_ALLOWEMPTY, "8": hs.HS_FLAG_UTF8}
 
 
 def load_cases():

@@ -577,3 +577,59 @@ def test_options_inside_a_pattern():
     want = brute_context(pyexprs, blocks)
     assert sorted(ev) == sorted(want)
     assert {e[1] for e in ev} == set(range(1, len(pairs) + 1))
+
+
+def brute_utf8(exprs, blocks, ascii_classes=True):
+    """the model in the code-point domain: blocks are valid UTF-8, Python matches the decoded
+    string (re.ASCII keeps \\w \\d \\s \\b ASCII-only, as HS_FLAG_UTF8 without HS_FLAG_UCP does) and
+    offsets are mapped back to bytes"""
+    out = []
+    for b, raw in enumerate(blocks):
+        text = raw.decode("utf-8")
+        at = [0]
+        for ch in text:
+            at.append(at[-1] + len(ch.encode("utf-8")))
+        for pat, fl, pid in exprs:
+            rf = (re.I if fl & hs.HS_FLAG_CASELESS else 0) | (re.S if fl & hs.HS_FLAG_DOTALL else 0) | \
+                 (re.M if fl & hs.HS_FLAG_MULTILINE else 0) | (re.ASCII if ascii_classes else 0)
+            for to in range(len(text) + 1):
+                rx = re.compile("(?:%s)(?=[\\s\\S]{%d}\\Z)" % (pat, len(text) - to), rf)
+                m = rx.search(text)
+                if m and m.start() < to:
+                    out.append((b, pid, at[m.start()] if fl & hs.HS_FLAG_SOM_LEFTMOST else 0, at[to]))
+    return out
+
+
+def test_utf8_mode():
+    """HS_FLAG_UTF8: `.`, negated classes and \\W \\D \\S take whole code points, a non-ASCII character
+    is one atom, \\x{...} names code points, offsets stay byte offsets; caseless k / s also match
+    KELVIN SIGN / LONG S (tools/hscollider/test_cases/pcre/utf8.txt has the reference doing so)"""
+    U, SOM, I = hs.HS_FLAG_UTF8, hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_CASELESS
+    exprs = [("foo.bar", U, 1), ("café+x", U, 2), ("[^a]end", U | SOM, 3), (r"x\W{2}y", U, 4), (r"€\d+(\.\d\d)?", U, 5),
+             (r"naïve|über\b", U, 6), (r".{2}\bzip", U | SOM, 7), (r"q[^\n\d]*ß", U, 8), (r"tag\S+\s", U, 9),
+             (r"(é|ab)+c", U | SOM, 10)]
+    # written with \x{...} instead of raw characters: the same expressions
+    hexed = [(p.encode("ascii", "backslashreplace").decode().replace("\\u", "\\x{").replace("\\x{00e9", "\\x{e9}").replace(
+        "\\x{20ac", "\\x{20ac}").replace("\\x{00ef", "\\x{ef}").replace("\\x{00fc", "\\x{fc}").replace("\\x{00df", "\\x{df}"), f, i)
+        for p, f, i in exprs]
+    words = ["foo", "bar", "é", "€", "\U0001f600", "x", "caf", "end", "a", "b", "y", "..", "12", ".50", "naïve", "über",
+             " ", "zip", "q", "ß", "tag", "\n", "ab", "c", "_", "-"]
+    rng = np.random.default_rng(101)
+    blocks = ["".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 12)))).encode() for _ in range(250)]
+    blocks += [s.encode() for s in ["fooébar foo\U0001f600bar fooxxbar", "caféééx cafex", "éend aend", "xé€y x..y xaby",
+                                    "€12.50 €x", "naïve über übers", "éézip a-zip abzip", "qabß q1ß qéß",
+                                    "tagé€ x", "éabéc abc éc"]]
+    for variant in (exprs, hexed):
+        ev = run_exprs_auto([(p.encode("utf-8"), f, i) for p, f, i in variant], blocks)
+        want = brute_utf8(exprs, blocks)
+        assert sorted(ev) == sorted(want)
+        assert {e[1] for e in ev} == set(range(1, 11))
+    # caseless k and s: partners U+212A and U+017F (the model folds them too, without re.ASCII)
+    cexprs = [("mask", U | I, 1), ("KS[a-s]x", U | I, 2)]
+    cblocks = [s.encode() for s in ["mask MASK maſk maſK", "ksſx Kſkx KSSX kstx"]]
+    ev = run_exprs_auto([(p.encode(), f, i) for p, f, i in cexprs], cblocks)
+    assert sorted(ev) == sorted(brute_utf8(cexprs, cblocks, ascii_classes=False)) and len(ev) == 7
+    import pytest
+    for bad, fl in [(b"caf\xe9", U), ("é".encode(), U | I), ("[éa]".encode(), U), (rb"[\x80-\xff]x", U), (b"x", U | hs.HS_FLAG_UCP)]:
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([bad], [fl], [1])

@@ -144,7 +144,7 @@ def test_quiet_prefilter_allowempty_flags():
     (src/compiler/compiler.cpp:286-294)."""
     db = hs.Database.compile(["foo", "bar", "ba[rz]"], [hs.HS_FLAG_QUIET, hs.HS_FLAG_PREFILTER, hs.HS_FLAG_ALLOWEMPTY], [1, 2, 3])
     assert to_id(cpu_scan(db, b"foo bar baz")[0]) == [(7, 2), (7, 3), (11, 3)]
-    for fl in (hs.HS_FLAG_UTF8, hs.HS_FLAG_UCP, hs.HS_FLAG_QUIET | hs.HS_FLAG_SOM_LEFTMOST,
+    for fl in (hs.HS_FLAG_UCP, hs.HS_FLAG_UTF8 | hs.HS_FLAG_UCP, hs.HS_FLAG_QUIET | hs.HS_FLAG_SOM_LEFTMOST,
                hs.HS_FLAG_PREFILTER | hs.HS_FLAG_SOM_LEFTMOST):
         with pytest.raises(hs.HsError):
             hs.Database.compile(["foo"], [fl], [1])
