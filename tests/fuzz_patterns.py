@@ -88,9 +88,12 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--n", type=int, default=2000)
     ap.add_argument("--multi", action="store_true", help="databases of 2-6 expressions with ext bounds and SINGLEMATCH mixed in")
+    ap.add_argument("--utf8", action="store_true", help="HS_FLAG_UTF8: non-ASCII characters in expressions and blocks, code-point model")
     a = ap.parse_args()
     if a.multi:
         return main_multi(a)
+    if a.utf8:
+        return main_utf8(a)
     r = random.Random(a.seed)
     signal.signal(signal.SIGALRM, lambda *_: (_ for _ in ()).throw(Timeout()))
     tried = accepted = compared = 0
@@ -132,6 +135,58 @@ def main():
             print("  want", sorted(e for e in want if e[0] == bad))
             sys.exit(1)
     print(f"{tried} expressions, {accepted} accepted by the facade, {compared} compared: all equal")
+
+
+UNI = ["é", "€", "ß", "\U0001f600", "ü", "ı"]
+
+
+def main_utf8(a):
+    """the byte grammar with non-ASCII characters spliced into expressions and blocks, under
+    HS_FLAG_UTF8, against the code-point model (no caseless flags: re.ASCII keeps the model's
+    classes ASCII but also its case folding)"""
+    from tests.test_hs_confirm_cpu import brute_utf8
+
+    r = random.Random(a.seed)
+    signal.signal(signal.SIGALRM, lambda *_: (_ for _ in ()).throw(Timeout()))
+    flag_choices = [0, 0, hs.HS_FLAG_DOTALL, hs.HS_FLAG_MULTILINE, hs.HS_FLAG_SOM_LEFTMOST]
+    accepted = compared = 0
+    for _ in range(a.n):
+        expr, fl = gen_expr(r), r.choice(flag_choices) | hs.HS_FLAG_UTF8
+        if "(?i" in expr or "\\z" in expr or "\\Z" in expr:
+            continue
+        pieces = list(expr)
+        for _k in range(r.randint(0, 2)):  # splice whole characters in where they stay atoms
+            pos = r.randrange(len(pieces) + 1)
+            if pos > 0 and pieces[pos - 1] == "\\":
+                continue
+            pieces.insert(pos, r.choice(UNI))
+        expr = "".join(pieces)
+        try:
+            re.compile(expr)
+            hs.Database.compile([expr.encode("utf-8")], [fl], [1])
+        except (re.error, hs.HsError):
+            continue
+        accepted += 1
+        blocks = []
+        for _b in range(5):
+            t = gen_block(r).decode("latin-1")
+            t = "".join(ch + (r.choice(UNI) if r.random() < 0.15 else "") for ch in t)
+            blocks.append(t.encode("utf-8"))
+        try:
+            signal.alarm(10)
+            want = brute_utf8([(expr, fl, 1)], blocks)
+            signal.alarm(0)
+        except Timeout:
+            continue
+        got = run_exprs_auto([(expr.encode("utf-8"), fl, 1)], blocks)
+        compared += 1
+        if sorted(got) != sorted(want):
+            bad = sorted(set(got) ^ set(want))[0][0]
+            print("MISMATCH", repr(expr), "flags", fl, "block", blocks[bad])
+            print("  got ", sorted(e for e in got if e[0] == bad))
+            print("  want", sorted(e for e in want if e[0] == bad))
+            sys.exit(1)
+    print(f"utf8: {accepted} accepted, {compared} compared: all equal")
 
 
 def singlematch_filter(want, single_ids):
