@@ -19,7 +19,7 @@ from tests import oracle_binding as ob
 
 FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "collider_subset.json")
 FLAGS = {"i": hs.HS_FLAG_CASELESS, "s": hs.HS_FLAG_DOTALL, "m": hs.HS_FLAG_MULTILINE, "H": hs.HS_FLAG_SINGLEMATCH,
-         "L": hs.HS_FLAG_SOM_LEFTMOST, "V": hs.HS_FLAG_ALLOWEMPTY, "8": hs.HS_FLAG_UTF8}
+         "L": hs.HS_FLAG_SOM_LEFTMOST, "V": hs.HS_FLAG_ALLOWEMPTY, "8": hs.HS_FLAG_UTF8, "P": hs.HS_FLAG_PREFILTER}
 
 
 def load_cases():

@@ -28,7 +28,7 @@ from hyperscan_amd import hs  # noqa: E402
 
 REF = "/root/reference/tools/hscollider/test_cases"
 FLAGS = {"i": hs.HS_FLAG_CASELESS, "s": hs.HS_FLAG_DOTALL, "m": hs.HS_FLAG_MULTILINE, "H": hs.HS_FLAG_SINGLEMATCH,
-         "L": hs.HS_FLAG_SOM_LEFTMOST, "O": 0, "V": hs.HS_FLAG_ALLOWEMPTY, "8": hs.HS_FLAG_UTF8}
+         "L": hs.HS_FLAG_SOM_LEFTMOST, "O": 0, "V": hs.HS_FLAG_ALLOWEMPTY, "8": hs.HS_FLAG_UTF8, "P": hs.HS_FLAG_PREFILTER}
 MAX_CORPUS = 600  # bytes; longer corpora are left out (the model is quadratic-ish)
 
 
