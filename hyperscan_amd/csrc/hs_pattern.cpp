@@ -28,6 +28,7 @@ namespace hsf {
  * quantifier, and that caseless k and s also match U+212A KELVIN SIGN and U+017F LONG S (the
  * reference folds those without HS_FLAG_UCP too: tools/hscollider/test_cases/pcre/utf8.txt). */
 thread_local bool g_utf8 = false;
+bool utf8_hex_escape(const std::string &p, size_t i, std::string &bytes, size_t &end);
 
 inline size_t utf8_len(unsigned char lead) { return lead < 0x80 ? 1 : lead < 0xc2 ? 0 : lead < 0xe0 ? 2 : lead < 0xf0 ? 3 : lead < 0xf5 ? 4 : 0; }
 
@@ -205,13 +206,14 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i, bool nocase = false
             } else {
                 size_t k = j + 1;
                 unsigned char lit;
-                if (!class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                std::string useq;
+                if (utf8_hex_escape(p, j, useq, k)) lit = 0x80; /* (UTF-8 mode only skips with this function) */
+                else if (!class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
                 lo = lit;
                 j = k;
             }
         } else {
             lo = (unsigned char)p[j++];
-            if (g_utf8 && lo >= 0x80) throw ParseError{"Non-ASCII class members are not supported in UTF-8 mode."};
         }
         if (is_class) {
             cls |= item;
@@ -224,15 +226,16 @@ ByteSet parse_bracket_class(const std::string &p, size_t &i, bool nocase = false
             if (p[j] == '\\') {
                 size_t k = j + 1;
                 unsigned char lit;
-                if (k >= p.size() || !class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
+                std::string useq;
+                if (k < p.size() && utf8_hex_escape(p, j, useq, k)) lit = 0xff;
+                else if (k >= p.size() || !class_char_escape(p, k, lit)) throw ParseError{"Unsupported escape sequence."};
                 hi = lit;
                 j = k;
             } else {
                 hi = (unsigned char)p[j++];
             }
-            if (hi < lo) throw ParseError{"Range out of order in character class."};
+            if (hi < lo && !g_utf8) throw ParseError{"Range out of order in character class."};
         }
-        if (g_utf8 && hi >= 0x80) throw ParseError{"Non-ASCII class members are not supported in UTF-8 mode."};
         add_range(cls, lo, hi);
     }
     i = j + 1;
@@ -315,6 +318,180 @@ int option_group_at(const std::string &p, size_t i, bool &nocase, bool &dotall, 
     dotall = ds;
     end = k + 1;
     return p[k] == ')' ? 1 : 2;
+}
+
+/* ---- UTF-8 mode: a bracket class as a set of code points ------------------------------ */
+typedef std::vector<std::pair<unsigned, unsigned>> CpRanges;
+
+unsigned utf8_decode(const std::string &p, size_t &i) {
+    const unsigned char c = (unsigned char)p[i];
+    const size_t n = utf8_len(c);
+    if (!n || i + n > p.size()) throw ParseError{"Expression is not valid UTF-8."};
+    unsigned cp = n == 1 ? c : c & (0xff >> (n + 1));
+    for (size_t k = 1; k < n; k++) cp = cp << 6 | ((unsigned char)p[i + k] & 0x3f);
+    i += n;
+    return cp;
+}
+
+void cp_normalise(CpRanges &r) {
+    std::sort(r.begin(), r.end());
+    CpRanges out;
+    for (const auto &x : r) {
+        if (!out.empty() && x.first <= out.back().second + 1) out.back().second = std::max(out.back().second, x.second);
+        else out.push_back(x);
+    }
+    r.swap(out);
+}
+
+/* "[...]" at p[i] in UTF-8 mode -> sorted disjoint code-point ranges (surrogates never included) */
+CpRanges parse_bracket_class_cp(const std::string &p, size_t &i, bool nocase) {
+    CpRanges r;
+    size_t j = i + 1;
+    bool neg = false;
+    if (j < p.size() && p[j] == '^') {
+        neg = true;
+        j++;
+    }
+    auto add_byteset = [&](const ByteSet &item) { /* an ASCII-defined class; its complement forms reach every code point above */
+        size_t high = 0;
+        for (unsigned b = 0x80; b < 0x100; b++) high += item[b];
+        if (high != 0 && high != 128) throw ParseError{"\\h \\v and their complements are not supported inside a UTF-8 class."};
+        for (unsigned b = 0; b < 0x80; b++)
+            if (item[b]) r.push_back({b, b});
+        if (high == 128) r.push_back({0x80, 0x10ffff});
+    };
+    auto one = [&](size_t &k) -> unsigned { /* one member character at p[k] */
+        if (p[k] == '\\') {
+            std::string useq;
+            size_t e = k;
+            if (utf8_hex_escape(p, k, useq, e)) {
+                size_t z = 0;
+                k = e;
+                return utf8_decode(useq, z);
+            }
+            size_t q = k + 1;
+            unsigned char lit;
+            if (q >= p.size() || !class_char_escape(p, q, lit)) throw ParseError{"Unsupported escape sequence."};
+            k = q;
+            return lit;
+        }
+        return utf8_decode(p, k);
+    };
+    bool first = true;
+    for (;;) {
+        if (j >= p.size()) throw ParseError{"Unterminated character class."};
+        if (p[j] == ']' && !first) break;
+        first = false;
+        if (p[j] == '[' && j + 1 < p.size() && (p[j + 1] == '.' || p[j + 1] == '=') &&
+            p.find(std::string(1, p[j + 1]) + "]", j + 2) != std::string::npos)
+            throw ParseError{"Unsupported POSIX collating element."};
+        if (p[j] == '[' && j + 1 < p.size() && p[j + 1] == ':') {
+            const size_t e = p.find(":]", j + 2);
+            if (e == std::string::npos) throw ParseError{"Unterminated POSIX class."};
+            std::string name = p.substr(j + 2, e - j - 2);
+            const bool inv = !name.empty() && name[0] == '^';
+            if (inv) name.erase(0, 1);
+            ByteSet item;
+            if (!posix_class(name, item)) throw ParseError{"Unknown POSIX character class."};
+            add_byteset(inv ? ~item : item);
+            j = e + 2;
+            continue;
+        }
+        if (p[j] == '\\' && j + 1 < p.size()) {
+            bool ok;
+            const ByteSet item = class_escape(p[j + 1], ok);
+            if (ok) {
+                add_byteset(item);
+                j += 2;
+                continue;
+            }
+        }
+        const unsigned lo = one(j);
+        unsigned hi = lo;
+        if (j + 1 < p.size() && p[j] == '-' && p[j + 1] != ']') {
+            j++;
+            if (p[j] == '[' && j + 1 < p.size() && p[j + 1] == ':') throw ParseError{"Invalid range in character class."};
+            hi = one(j);
+            if (hi < lo) throw ParseError{"Range out of order in character class."};
+        }
+        r.push_back({lo, hi});
+    }
+    i = j + 1;
+    if (nocase) { /* ASCII letters, and the two non-ASCII partners the reference folds without UCP */
+        CpRanges extra;
+        for (const auto &x : r)
+            for (unsigned c = std::max(x.first, 0x41u); c <= std::min(x.second, 0x7au); c++)
+                if (is_alpha((unsigned char)c)) extra.push_back({c ^ 0x20, c ^ 0x20});
+        auto has = [&](unsigned c) { for (const auto &x : r) if (x.first <= c && c <= x.second) return true; return false; };
+        if (has('k') || has('K')) extra.push_back({0x212a, 0x212a});
+        if (has('s') || has('S')) extra.push_back({0x17f, 0x17f});
+        if (has(0x212a)) { extra.push_back({'k', 'k'}); extra.push_back({'K', 'K'}); }
+        if (has(0x17f)) { extra.push_back({'s', 's'}); extra.push_back({'S', 'S'}); }
+        r.insert(r.end(), extra.begin(), extra.end());
+    }
+    cp_normalise(r);
+    if (neg) {
+        CpRanges c;
+        unsigned next = 0;
+        for (const auto &x : r) {
+            if (x.first > next) c.push_back({next, x.first - 1});
+            next = x.second + 1;
+        }
+        if (next <= 0x10ffff) c.push_back({next, 0x10ffff});
+        r.swap(c);
+    }
+    /* cut the surrogate block out */
+    CpRanges out;
+    for (const auto &x : r) {
+        if (x.second < 0xd800 || x.first > 0xdfff) { out.push_back(x); continue; }
+        if (x.first < 0xd800) out.push_back({x.first, 0xd7ff});
+        if (x.second > 0xdfff) out.push_back({0xe000, x.second});
+    }
+    return out;
+}
+
+/* [lo, hi] -> sequences of byte ranges whose concatenations are exactly the UTF-8 encodings of
+ * the code points in it (the classic split: by encoded length, then until every continuation
+ * level is a full rectangle) */
+void utf8_split(unsigned lo, unsigned hi, std::vector<std::vector<std::pair<unsigned, unsigned>>> &out) {
+    if (lo > hi) return;
+    for (unsigned b : {0x7fu, 0x7ffu, 0xffffu})
+        if (lo <= b && b < hi) {
+            utf8_split(lo, b, out);
+            utf8_split(b + 1, hi, out);
+            return;
+        }
+    if (hi < 0x80) {
+        out.push_back({{lo, hi}});
+        return;
+    }
+    const int n = lo < 0x800 ? 2 : lo < 0x10000 ? 3 : 4;
+    for (int k = 1; k < n; k++) {
+        const unsigned m = (1u << (6 * k)) - 1;
+        if ((lo & ~m) != (hi & ~m)) {
+            if (lo & m) {
+                utf8_split(lo, lo | m, out);
+                utf8_split((lo | m) + 1, hi, out);
+                return;
+            }
+            if ((hi & m) != m) {
+                utf8_split(lo, (hi & ~m) - 1, out);
+                utf8_split(hi & ~m, hi, out);
+                return;
+            }
+        }
+    }
+    auto enc = [&](unsigned cp, unsigned char *b) {
+        if (n == 2) { b[0] = 0xc0 | cp >> 6; b[1] = 0x80 | (cp & 0x3f); }
+        else if (n == 3) { b[0] = 0xe0 | cp >> 12; b[1] = 0x80 | (cp >> 6 & 0x3f); b[2] = 0x80 | (cp & 0x3f); }
+        else { b[0] = 0xf0 | cp >> 18; b[1] = 0x80 | (cp >> 12 & 0x3f); b[2] = 0x80 | (cp >> 6 & 0x3f); b[3] = 0x80 | (cp & 0x3f); }
+    };
+    unsigned char a[4], z[4];
+    enc(lo, a);
+    enc(hi, z);
+    std::vector<std::pair<unsigned, unsigned>> seq;
+    for (int k = 0; k < n; k++) seq.push_back({a[k], z[k]});
+    out.push_back(seq);
 }
 
 /* conditions on a boundary between two bytes: 0 = none, 1 = \b, 2 = \B; -1 = contradictory */
@@ -600,6 +777,35 @@ struct TailBuilder {
             set.set();
             if (!dotall) set.reset('\n');
             i++;
+        } else if (c == '[' && g_utf8) { /* a set of code points: one branch per UTF-8 byte-range sequence */
+            const CpRanges r = parse_bracket_class_cp(p, i, nocase);
+            std::vector<std::vector<std::pair<unsigned, unsigned>>> seqs;
+            for (const auto &x : r) utf8_split(x.first, x.second, seqs);
+            if (seqs.empty()) throw NeverMatch();
+            ByteSet ascii; /* all one-byte sequences share a position */
+            Frag f;
+            bool have = false;
+            auto add = [&](const Frag &x) {
+                if (!have) { f = x; have = true; return; }
+                for (int k = 0; k < 3; k++) {
+                    bits_or(f.first[k], x.first[k]);
+                    bits_or(f.last[k], x.last[k]);
+                }
+                f.wmin = std::min(f.wmin, x.wmin);
+                f.wmax = std::max(f.wmax, x.wmax);
+            };
+            for (const auto &sq : seqs) {
+                if (sq.size() == 1) { add_range(ascii, sq[0].first, sq[0].second); continue; }
+                Frag x;
+                for (const auto &br : sq) {
+                    ByteSet one;
+                    add_range(one, br.first, br.second);
+                    x = cat(x, leaf(one, false));
+                }
+                add(x);
+            }
+            if (ascii.any()) add(leaf(ascii, false));
+            return f;
         } else if (c == '[') {
             set = parse_bracket_class(p, i, nocase);
         } else if (strchr(")|^$*+?", c) || (c == '{' && is_repeat_at(p, i))) {

@@ -46,8 +46,9 @@
  * HS_FLAG_MULTILINE `^` / `$` also match after / before any newline). \b / \B anywhere
  * (inside a fragment they become conditional layers of its automaton).
  * HS_FLAG_UTF8 (without HS_FLAG_UCP): `.`, negated classes and \W \D \S take whole code points, a
- * non-ASCII character is one atom, \x{...} names a code point, caseless k / s also match U+212A /
- * U+017F; non-ASCII class members and caseless non-ASCII letters are refused.
+ * non-ASCII character is one atom, \x{...} names a code point, classes hold code points and
+ * code-point ranges, caseless k / s also match U+212A / U+017F; caseless non-ASCII letters and
+ * \h \v in classes are refused.
  * Anything else (branches without a mandatory literal, anchors away from the edges of a branch,
  * look-around, back-references, possessive quantifiers, (?m) / (?x) after the start, streaming
  * mode) is

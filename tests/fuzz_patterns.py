@@ -137,7 +137,7 @@ def main():
     print(f"{tried} expressions, {accepted} accepted by the facade, {compared} compared: all equal")
 
 
-UNI = ["é", "€", "ß", "\U0001f600", "ü", "ı"]
+UNI = ["é", "€", "ß", "\U0001f600", "ü", "ı", "α", "ω", "ÿ"]
 
 
 def main_utf8(a):
@@ -154,6 +154,9 @@ def main_utf8(a):
         expr, fl = gen_expr(r), r.choice(flag_choices) | hs.HS_FLAG_UTF8
         if "(?i" in expr or "\\z" in expr or "\\Z" in expr:
             continue
+        if r.random() < 0.5:  # a class of code points somewhere at the top level
+            cls = r.choice(["[é€a]", "[^éb]", "[α-ω]", "[ü-ÿX]", "[^\\dß]", "[\\x{e9}-\\x{fc}_]"]) + r.choice(["", "+", "?", "{1,2}"])
+            expr = r.choice([cls + expr, expr + cls]) if "|" not in expr else expr
         pieces = list(expr)
         for _k in range(r.randint(0, 2)):  # splice whole characters in where they stay atoms
             pos = r.randrange(len(pieces) + 1)
@@ -161,8 +164,9 @@ def main_utf8(a):
                 continue
             pieces.insert(pos, r.choice(UNI))
         expr = "".join(pieces)
+        pyexpr = re.sub(r"\\x\{([0-9a-f]+)\}", lambda m: chr(int(m.group(1), 16)), expr)  # Python has no \x{..}
         try:
-            re.compile(expr)
+            re.compile(pyexpr)
             hs.Database.compile([expr.encode("utf-8")], [fl], [1])
         except (re.error, hs.HsError):
             continue
@@ -174,7 +178,7 @@ def main_utf8(a):
             blocks.append(t.encode("utf-8"))
         try:
             signal.alarm(10)
-            want = brute_utf8([(expr, fl, 1)], blocks)
+            want = brute_utf8([(pyexpr, fl, 1)], blocks)
             signal.alarm(0)
         except Timeout:
             continue

@@ -607,29 +607,30 @@ def test_utf8_mode():
     U, SOM, I = hs.HS_FLAG_UTF8, hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_CASELESS
     exprs = [("foo.bar", U, 1), ("café+x", U, 2), ("[^a]end", U | SOM, 3), (r"x\W{2}y", U, 4), (r"€\d+(\.\d\d)?", U, 5),
              (r"naïve|über\b", U, 6), (r".{2}\bzip", U | SOM, 7), (r"q[^\n\d]*ß", U, 8), (r"tag\S+\s", U, 9),
-             (r"(é|ab)+c", U | SOM, 10)]
+             (r"(é|ab)+c", U | SOM, 10), (r"x[éa€]+y", U, 11), (r"[α-ω]{2,}s", U | SOM, 12), (r"k[^é\d]z", U, 13),
+             (r"<[é-ü\w]*>", U, 14)]
     # written with \x{...} instead of raw characters: the same expressions
     hexed = [(p.encode("ascii", "backslashreplace").decode().replace("\\u", "\\x{").replace("\\x{00e9", "\\x{e9}").replace(
-        "\\x{20ac", "\\x{20ac}").replace("\\x{00ef", "\\x{ef}").replace("\\x{00fc", "\\x{fc}").replace("\\x{00df", "\\x{df}"), f, i)
+        "\\x{20ac", "\\x{20ac}").replace("\\x{00ef", "\\x{ef}").replace("\\x{00fc", "\\x{fc}").replace("\\x{00df", "\\x{df}").replace("\\x{03b1", "\\x{3b1}").replace("\\x{03c9", "\\x{3c9}"), f, i)
         for p, f, i in exprs]
     words = ["foo", "bar", "é", "€", "\U0001f600", "x", "caf", "end", "a", "b", "y", "..", "12", ".50", "naïve", "über",
-             " ", "zip", "q", "ß", "tag", "\n", "ab", "c", "_", "-"]
+             " ", "zip", "q", "ß", "tag", "\n", "ab", "c", "_", "-", "αβ", "ω", "s", "k", "z", "<", ">", "ü", "ÿ"]
     rng = np.random.default_rng(101)
     blocks = ["".join(words[int(i)] for i in rng.integers(0, len(words), int(rng.integers(1, 12)))).encode() for _ in range(250)]
     blocks += [s.encode() for s in ["fooébar foo\U0001f600bar fooxxbar", "caféééx cafex", "éend aend", "xé€y x..y xaby",
                                     "€12.50 €x", "naïve über übers", "éézip a-zip abzip", "qabß q1ß qéß",
-                                    "tagé€ x", "éabéc abc éc"]]
+                                    "tagé€ x", "éabéc abc éc", "xéa€y x€üy", "αβγs ωs aαs", "kéz k5z k€z kaz", "<éü_a> <ÿ> <>"]]
     for variant in (exprs, hexed):
         ev = run_exprs_auto([(p.encode("utf-8"), f, i) for p, f, i in variant], blocks)
         want = brute_utf8(exprs, blocks)
         assert sorted(ev) == sorted(want)
-        assert {e[1] for e in ev} == set(range(1, 11))
+        assert {e[1] for e in ev} == set(range(1, 15))
     # caseless k and s: partners U+212A and U+017F (the model folds them too, without re.ASCII)
-    cexprs = [("mask", U | I, 1), ("KS[a-s]x", U | I, 2)]
-    cblocks = [s.encode() for s in ["mask MASK maſk maſK", "ksſx Kſkx KSSX kstx"]]
+    cexprs = [("mask", U | I, 1), ("KS[a-s]x", U | I, 2), ("[^ks]:[ſ]!", U | I, 3)]
+    cblocks = [s.encode() for s in ["mask MASK maſk maſK", "ksſx Kſkx KSSX kstx", "a:s! K:s! ſ:S! b:ſ!"]]
     ev = run_exprs_auto([(p.encode(), f, i) for p, f, i in cexprs], cblocks)
-    assert sorted(ev) == sorted(brute_utf8(cexprs, cblocks, ascii_classes=False)) and len(ev) == 7
+    assert sorted(ev) == sorted(brute_utf8(cexprs, cblocks, ascii_classes=False)) and len(ev) == 9
     import pytest
-    for bad, fl in [(b"caf\xe9", U), ("é".encode(), U | I), ("[éa]".encode(), U), (rb"[\x80-\xff]x", U), (b"x", U | hs.HS_FLAG_UCP)]:
+    for bad, fl in [(b"caf\xe9", U), ("é".encode(), U | I), (rb"a[\h]", U), (rb"a[\x{fc}-\x{e9}]", U), (b"x", U | hs.HS_FLAG_UCP)]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [fl], [1])
