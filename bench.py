@@ -203,7 +203,12 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         from hyperscan_amd import dist as hd
 
         n = min(int(jb.d_count.item()), jb.cap)  # waits for THIS job's stream only
-        return hd.all_gather_records(jb.d_out.view(-1, 4), n, rank * jb.nblocks, dist, world, jb.dev)
+        recs, base = jb.d_out.view(-1, 4), rank * jb.nblocks
+        if args.exchange == "exact":  # no padding to the largest count (skewed shards)
+            return hd.all_gather_records_exact(recs, n, base, dist, world, rank, jb.dev)
+        if args.exchange == "root":  # only rank 0's host would deliver the callbacks
+            return hd.gather_records_to_root(recs, n, base, dist, world, rank, 0, jb.dev)
+        return hd.all_gather_records(recs, n, base, dist, world, jb.dev)
 
     def run_steps(n):
         for i in range(n):
@@ -334,6 +339,9 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0, help="corpus GiB per GPU")
     ap.add_argument("--workload", default="teddy64", choices=["teddy64", "fdr10k"])
     ap.add_argument("--no-also", action="store_true", help="skip the second workload line")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "exact", "root"],
+                    help="N>1 record exchange: padded all-gather (default, what BASELINE names), exact-size "
+                         "all-gather, or gather to rank 0 (hyperscan_amd/dist.py)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
                     help="scans in flight: 2 overlaps a step's confirm/pack/gather with the next step's filter "

@@ -62,3 +62,63 @@ def all_gather_records(records, count, block_base, dist, world, device=None):
         p[:, 0] += int(bases[r])
         parts.append(p)
     return torch.cat(parts, dim=0), counts
+
+
+def _exchange_counts(count, block_base, dist, world, device):
+    import torch
+
+    cnt = torch.tensor([int(count), int(block_base)], dtype=torch.int64, device=device)
+    allc = torch.empty(world * 2, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allc, cnt)
+    allc = allc.view(world, 2).cpu()
+    return allc[:, 0].tolist(), allc[:, 1].tolist()
+
+
+def all_gather_records_exact(records, count, block_base, dist, world, rank, device=None):
+    """Same result as all_gather_records, but no rank is padded to the largest count: after
+    the counts, rank r's rows travel as one broadcast of exactly counts[r] rows into their
+    final place in the output (all `world` broadcasts in flight at once). With skewed shards
+    (one flood-dense shard among quiet ones) this moves sum(counts) rows per rank instead of
+    world * max(counts)."""
+    import torch
+
+    device = device if device is not None else records.device
+    counts, bases = _exchange_counts(count, block_base, dist, world, device)
+    total = sum(counts)
+    out = torch.empty((total, 4), dtype=torch.int32, device=device)
+    starts = np.concatenate([[0], np.cumsum(counts)]).tolist()
+    n = int(count)
+    if n:
+        mine = out[starts[rank]:starts[rank] + n]
+        mine.copy_(records[:n])
+        mine[:, 0] += int(block_base)
+    pending = [dist.broadcast(out[starts[r]:starts[r + 1]], src=r, async_op=True) for r in range(world) if counts[r]]
+    for h in pending:
+        h.wait()
+    return out, counts
+
+
+def gather_records_to_root(records, count, block_base, dist, world, rank, root=0, device=None):
+    """When only one rank's host delivers the callbacks: counts to everyone, then every other
+    rank sends exactly its rows to `root` (1/world of the all-gather's traffic per link).
+    Returns (records with GLOBAL block indices ordered by rank, counts) on root and
+    (None, counts) elsewhere."""
+    import torch
+
+    device = device if device is not None else records.device
+    counts, bases = _exchange_counts(count, block_base, dist, world, device)
+    n = int(count)
+    if rank != root:
+        if n:
+            dist.send(records[:n].contiguous(), dst=root)
+        return None, counts
+    out = torch.empty((sum(counts), 4), dtype=torch.int32, device=device)
+    starts = np.concatenate([[0], np.cumsum(counts)]).tolist()
+    pending = [dist.irecv(out[starts[r]:starts[r + 1]], src=r) for r in range(world) if r != root and counts[r]]
+    if n:
+        out[starts[root]:starts[root] + n].copy_(records[:n])
+    for h in pending:
+        h.wait()
+    for r in range(world):
+        out[starts[r]:starts[r + 1], 0] += int(bases[r])
+    return out, counts

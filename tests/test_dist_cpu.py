@@ -56,6 +56,13 @@ def _worker(rank, world, port, out_path):
     if rank == 0:
         np.save(out_path, allr.numpy())
     assert sum(counts) == allr.shape[0]
+    # the exact-size exchanges deliver the same rows in the same order
+    exact, counts2 = hd.all_gather_records_exact(t, recs.size, base, dist, world, rank)
+    assert counts2 == counts and torch.equal(exact, allr)
+    for root in range(world):
+        rooted, counts3 = hd.gather_records_to_root(t, recs.size, base, dist, world, rank, root=root)
+        assert counts3 == counts
+        assert (rooted is None) if rank != root else torch.equal(rooted, allr)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,3 +81,39 @@ def test_two_rank_gloo_gather_equals_single_scan(tmp_path):
     assert len(w) > 100 and g == w
     # shards are contiguous block ranges, so rank order == global block order
     assert np.all(np.diff(got[:, 0]) >= 0)
+
+
+def _skew_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 1 holds a flood-dense shard, rank 0 a few rows, rank 2 nothing at all
+    n = [5, 40_000, 0][rank]
+    base = [0, 100, 1000][rank]
+    g = torch.Generator().manual_seed(rank)
+    t = torch.randint(0, 1 << 20, (max(1, n), 4), dtype=torch.int32, generator=g)
+    want = []
+    for r in range(world):
+        m = [5, 40_000, 0][r]
+        w = torch.randint(0, 1 << 20, (max(1, m), 4), dtype=torch.int32, generator=torch.Generator().manual_seed(r))[:m].clone()
+        w[:, 0] += [0, 100, 1000][r]
+        want.append(w)
+    want = torch.cat(want)
+    padded, counts = hd.all_gather_records(t, n, base, dist, world)
+    exact, counts2 = hd.all_gather_records_exact(t, n, base, dist, world, rank)
+    assert counts == counts2 == [5, 40_000, 0]
+    assert torch.equal(padded, want) and torch.equal(exact, want)
+    rooted, _ = hd.gather_records_to_root(t, n, base, dist, world, rank, root=2)  # the empty rank collects
+    assert (rooted is None) if rank != 2 else torch.equal(rooted, want)
+    # nobody has anything
+    e, c = hd.all_gather_records_exact(t, 0, base, dist, world, rank)
+    assert c == [0, 0, 0] and e.shape == (0, 4)
+    r0, c = hd.gather_records_to_root(t, 0, base, dist, world, rank)
+    assert c == [0, 0, 0] and ((r0 is None) if rank else r0.shape == (0, 4))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_three_rank_skewed_exact_exchanges():
+    mp.spawn(_skew_worker, args=(3, _free_port()), nprocs=3, join=True)
