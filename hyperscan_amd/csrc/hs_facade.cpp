@@ -505,6 +505,13 @@ hs_error_t hs_database_info(const hs_database_t *db, char **info) {
     return HS_SUCCESS;
 }
 
+/* src/hs_runtime.h:294 / src/runtime.c hs_stream_size: a database that was not compiled for
+ * streaming answers HS_DB_MODE_ERROR (unit/hyperscan/single.cpp:72-83), and none here is. */
+hs_error_t hs_stream_size(const hs_database_t *db, size_t *stream_size) {
+    if (!db || !stream_size || db->magic != 0x48534744) return HS_INVALID;
+    return HS_DB_MODE_ERROR;
+}
+
 /* serialised form: magic "HSGF", CRC-32 of everything after it, count, then per pattern
  * (top bit: vectored mode) {is_lit, flags, id, len, ext flags, min_offset, max_offset, min_length, bytes},
  * then the GPU table section {u64 length, the hsgpu_hwlm_serialize image}. On load the host

@@ -166,7 +166,20 @@ bool posix_class(const std::string &name, ByteSet &s) {
 }
 
 /* "[...]" at p[i]: the class, with i moved past the closing bracket */
+/* "[:digit:]", "[.ch.]", "[=ch=]" where a class would start: the reference refuses them by name
+ * (src/parser/Parser.rl:1280-1290: '[' d ( '\\]' | [^\]] )* d ']' for d in ": . =") */
+void refuse_posix_outside_class(const std::string &p, size_t i) {
+    if (i + 1 >= p.size() || !strchr(":.=", p[i + 1])) return;
+    const char d = p[i + 1];
+    for (size_t k = i + 2; k < p.size(); k++) {
+        if (p[k] == d && k + 1 < p.size() && p[k + 1] == ']')
+            throw ParseError{d == ':' ? "POSIX named classes are only supported inside a class." : "Unsupported POSIX collating element."};
+        if (p[k] == ']' && p[k - 1] != '\\') return;
+    }
+}
+
 ByteSet parse_bracket_class(const std::string &p, size_t &i, bool nocase = false) {
+    refuse_posix_outside_class(p, i);
     ByteSet cls;
     size_t j = i + 1;
     bool neg = false;
@@ -345,6 +358,7 @@ void cp_normalise(CpRanges &r) {
 
 /* "[...]" at p[i] in UTF-8 mode -> sorted disjoint code-point ranges (surrogates never included) */
 CpRanges parse_bracket_class_cp(const std::string &p, size_t &i, bool nocase) {
+    refuse_posix_outside_class(p, i);
     CpRanges r;
     size_t j = i + 1;
     bool neg = false;
@@ -1273,6 +1287,7 @@ Pattern parse_branch(const std::string &src, unsigned flags, unsigned id) {
  * alternation). "\\b(foo|bar)\\b" and "(GET|POST) /" are the everyday cases. */
 constexpr size_t kMaxBranches = 256;
 void distribute_group(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth);
+bool rewrite_for_literal(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth);
 
 void expand_branch(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
     /* as written, if it has a usable literal; with only a 1-2 byte one, distributing a group is
@@ -1318,7 +1333,15 @@ void expand_branch(const std::string &b, unsigned flags, unsigned id, std::vecto
         }
         return;
     }
-    distribute_group(b, flags, id, out, depth);
+    const size_t before = out.size();
+    try {
+        distribute_group(b, flags, id, out, depth);
+    } catch (const NeverMatch &) {
+        throw;
+    } catch (const NoLiteral &) {
+        out.erase(out.begin() + before, out.end());
+        if (!rewrite_for_literal(b, flags, id, out, depth)) throw;
+    }
 }
 
 void distribute_group(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
@@ -1373,6 +1396,136 @@ void distribute_group(const std::string &b, unsigned flags, unsigned id, std::ve
         return;
     }
     throw NoLiteral();
+}
+
+/* Two more identities reach a literal where neither the branch nor a group offers one (all end
+ * offsets are reported and nothing is captured, so they hold exactly):
+ *   - a repeat that must run at least once gives up its first turn:  A+ = A A*,
+ *     A{n,m} = A A{n-1,m-1}  ("(foobar)+", "((foo){2}){3}", "[a-z]{3,7}");
+ *   - a small class standing alone is the alternation of its members:  [pqr] = (?:p|q|r)
+ *     ("[pqr]", "\\s"; one-byte literals, so every member byte in the data becomes a candidate
+ *     for the host automaton: correct, and as slow as that sounds on text full of them).
+ * Each candidate rewrite goes back through expand_branch; the first that compiles is kept.
+ * The reference has no such limit (unit/hyperscan/single.cpp:320-345 lists these forms): its
+ * Rose build falls back to NFA/DFA engines over the whole buffer where there is no literal. */
+constexpr size_t kMaxClassMembers = 40;
+
+bool rewrite_for_literal(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
+    if (depth >= 8) return false;
+    struct Atom {
+        size_t begin, end, qend; /* [begin,end) the atom, [end,qend) its quantifier */
+        bool is_class, quantified;
+        unsigned long long lo, hi; /* hi == ~0ull: unbounded */
+        ByteSet set;
+    };
+    const bool has_options = b.find("(?") != std::string::npos && [&] { /* "(?:" alone is harmless */
+        for (size_t k = b.find("(?"); k != std::string::npos; k = b.find("(?", k + 1))
+            if (k + 2 >= b.size() || b[k + 2] != ':') return true;
+        return false;
+    }();
+    const bool nocase = flags & HS_FLAG_CASELESS;
+    std::vector<Atom> atoms;
+    size_t i = 0;
+    while (i < b.size()) {
+        Atom a{i, i, i, false, false, 1, 1, ByteSet()};
+        const unsigned char c = (unsigned char)b[i];
+        size_t j = i;
+        bool candidate = false;
+        std::string useq;
+        if (utf8_hex_escape(b, i, useq, j)) {
+        } else if (c == '\\') {
+            if (i + 1 >= b.size()) return false;
+            bool ok;
+            const ByteSet cs = class_escape(b[i + 1], ok);
+            if (ok) {
+                j = i + 2;
+                a.is_class = candidate = !g_utf8 && !has_options;
+                a.set = nocase ? fold_case(cs) : cs;
+            } else if (strchr("bBAzZ", b[i + 1])) {
+                j = i + 2;
+            } else {
+                unsigned char lit;
+                j = i + 1;
+                if (!char_escape(b, j, lit)) return false;
+            }
+        } else if (c == '[') {
+            a.set = parse_bracket_class(b, j, nocase);
+            a.is_class = candidate = !g_utf8 && !has_options;
+        } else if (c == '(') {
+            int d = 0;
+            for (;; j++) {
+                if (j >= b.size()) return false;
+                if (b[j] == '\\') { j++; continue; }
+                if (b[j] == '[') { size_t e = j; parse_bracket_class(b, e); j = e - 1; continue; }
+                if (b[j] == '(') d++;
+                if (b[j] == ')' && --d == 0) break;
+            }
+            j++;
+            candidate = !(i + 1 < b.size() && b[i + 1] == '?') || (i + 2 < b.size() && b[i + 2] == ':');
+            if (i + 1 < b.size() && (b[i + 1] == '*' || b[i + 1] == '+')) candidate = false; /* "(*VERB)" */
+        } else {
+            j = i + 1;
+        }
+        a.end = j;
+        if (j < b.size() && (b[j] == '?' || b[j] == '*' || b[j] == '+')) {
+            a.quantified = true;
+            a.lo = b[j] == '+' ? 1 : 0;
+            a.hi = b[j] == '?' ? 1 : ~0ull;
+            j++;
+        } else if (TailBuilder::is_repeat_at(b, j)) {
+            a.quantified = true;
+            const size_t close = b.find('}', j), comma = b.find(',', j);
+            a.lo = strtoull(b.c_str() + j + 1, nullptr, 10);
+            a.hi = comma == std::string::npos || comma > close ? a.lo : comma + 1 == close ? ~0ull : strtoull(b.c_str() + comma + 1, nullptr, 10);
+            j = close + 1;
+        }
+        if (a.quantified && j < b.size() && b[j] == '+') candidate = false; /* possessive: not ours to rearrange */
+        if (a.quantified && j < b.size() && (b[j] == '?' || b[j] == '+')) j++;
+        a.qend = j;
+        if (a.quantified && (a.lo == 0 || a.lo > 32767 || (a.hi != ~0ull && a.hi < a.lo))) candidate = false;
+        if (a.is_class && nocase) /* caseless: one literal serves both letters of a pair */
+            for (unsigned v = 'a'; v <= 'z'; v++)
+                if (a.set[v] && a.set[v - 32]) a.set.reset(v);
+        if (a.is_class && (a.set.none() || a.set.count() > kMaxClassMembers)) candidate = false;
+        if (candidate && (a.quantified || a.is_class)) atoms.push_back(a);
+        i = j;
+    }
+    /* groups before classes (longer literals), small classes before large ones */
+    std::stable_sort(atoms.begin(), atoms.end(), [](const Atom &x, const Atom &y) {
+        if (x.is_class != y.is_class) return !x.is_class;
+        return x.is_class && x.set.count() < y.set.count();
+    });
+    for (const Atom &a : atoms) {
+        const std::string atom = b.substr(a.begin, a.end - a.begin);
+        std::string first = atom, rest;
+        if (a.is_class) { /* the alternation of its members */
+            first = "(?:";
+            bool any = false;
+            for (unsigned v = 0; v < 256; v++) {
+                if (!a.set[v]) continue;
+                char hex[8];
+                snprintf(hex, sizeof hex, "%s\\x%02x", any ? "|" : "", v);
+                first += hex;
+                any = true;
+            }
+            first += ")";
+        }
+        if (a.quantified) {
+            const unsigned long long lo = a.lo - 1, hi = a.hi == ~0ull ? a.hi : a.hi - 1;
+            if (hi == ~0ull) rest = atom + (lo == 0 ? std::string("*") : "{" + std::to_string(lo) + ",}");
+            else if (hi > 0) rest = atom + "{" + std::to_string(lo) + "," + std::to_string(hi) + "}";
+        }
+        const size_t before = out.size();
+        try {
+            expand_branch(b.substr(0, a.begin) + first + rest + b.substr(a.qend), flags, id, out, depth + 1);
+            return true;
+        } catch (const NeverMatch &) {
+            throw;
+        } catch (const ParseError &) {
+            out.erase(out.begin() + before, out.end());
+        }
+    }
+    return false;
 }
 
 /* expression := branch ('|' branch)* at the top level: every branch is its own literal-prefixed

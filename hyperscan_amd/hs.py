@@ -160,6 +160,21 @@ class Database:
         _lib().hs_database_size(self._h, C.byref(n))
         return n.value
 
+    def info(self):
+        """hs_database_info: "Version: ... Features: ... Mode: ..." """
+        s = C.c_char_p()
+        rv = _lib().hs_database_info(self._h, C.byref(s))
+        if rv != HS_SUCCESS:
+            raise HsError(rv, "hs_database_info")
+        return s.value.decode()  # (the few bytes stay with the misc allocator, as a ctypes c_char_p cannot hand them back)
+
+    def stream_size(self):
+        """hs_stream_size -> error code (no database here is a streaming one)"""
+        n = C.c_size_t()
+        lib = _lib()
+        lib.hs_stream_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        return lib.hs_stream_size(self._h, C.byref(n))
+
     def close(self):
         if self._h:
             _lib().hs_free_database(self._h)

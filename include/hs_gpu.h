@@ -179,6 +179,9 @@ hs_error_t hs_populate_platform(hs_platform_info_t *platform);
 hs_error_t hs_free_database(hs_database_t *db);
 hs_error_t hs_database_size(const hs_database_t *database, size_t *database_size);
 hs_error_t hs_database_info(const hs_database_t *database, char **info);
+/* src/hs_runtime.h:294: only streaming databases have a stream size; block and vectored ones
+ * (all there are here) answer HS_DB_MODE_ERROR, as the reference does for them */
+hs_error_t hs_stream_size(const hs_database_t *database, size_t *stream_size);
 hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length);
 hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_database_t **db);
 hs_error_t hs_serialized_database_size(const char *bytes, const size_t length, size_t *deserialized_size);

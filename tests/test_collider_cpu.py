@@ -1,6 +1,6 @@
 """The reference's hscollider regression corpus (tools/hscollider/test_cases) for the patterns the
 hs_* facade accepts: tests/golden/collider_subset.json, made by tools/make_collider_fixture.py.
-9149 of its corpus lines carry the end offsets the reference itself must report (the `id="corpus":
+9734 of its corpus lines carry the end offsets the reference itself must report (the `id="corpus":
 to, ...` lines); the rest come from the Python model that agrees with all of those.
 
 CPU form: literal hits from the HWLM oracle for the literals each database is keyed on, then the
@@ -78,7 +78,7 @@ def cpu_events(db, blocks):
 def test_fixture_shape():
     cases = load_cases()
     kinds = [k for c in cases for k in c["kind"]]
-    assert len(cases) >= 1000 and kinds.count("reference") >= 8800
+    assert len(cases) >= 1150 and kinds.count("reference") >= 9700
     assert len({c["file"] for c in cases}) >= 15  # spread over the corpus's files
 
 
@@ -90,4 +90,4 @@ def test_collider_subset_on_cpu():
         blocks = [bytes.fromhex(h) for h in c["corpora"]]
         check_ends(c, flags, cpu_events(db, blocks))
         n += len(blocks)
-    assert n >= 8900
+    assert n >= 9800

@@ -78,7 +78,7 @@ def test_arg_checks():
         hs.Database.compile(["foo"], mode=hs.HS_MODE_STREAM)
     assert e.value.code == hs.HS_COMPILER_ERROR
     with pytest.raises(hs.HsError) as e:
-        hs.Database.compile(["(a|b)+"])  # no mandatory literal at the top level
+        hs.Database.compile(["(\\w|.)+"])  # no mandatory literal at the top level, no small class either
     assert e.value.code == hs.HS_COMPILER_ERROR and e.value.expression == 0
     with pytest.raises(hs.HsError) as e:
         hs.Database.compile(["good", "[a-z]+(tail"])

@@ -53,7 +53,8 @@ def test_hs_compile_errors_without_gpu():
         hs.Database.compile(["ok", "a(b|c"])  # unbalanced group
     assert e.value.expression == 1
     with pytest.raises(hs.HsError):
-        hs.Database.compile(["\\d+[abc]"])  # no mandatory literal
+        hs.Database.compile(["\\w+[^abc]"])  # no mandatory literal, and no class small enough to stand in for one
+    assert len(hs.Database.compile(["\\d+[abc]"]).literals()) == 3  # [abc] as a|b|c: one-byte literals
     db = hs.Database.compile(["needle[a-z]{2,5}\\d", "x\\.y"], [hs.HS_FLAG_CASELESS, 0], [3, 4])
     assert hs.Database.deserialize(db.serialize()).size() == db.size()
 

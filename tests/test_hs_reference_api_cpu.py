@@ -277,3 +277,78 @@ def test_quoted_sequences():
     db = hs.Database.compile([r"a\Q.*+?(x)[y]\Eb+", r"[\Q^]\E-]{2}end", r"tail\Qopen"], [0, 0, 0], [1, 2, 3])
     assert [b for b, _n, _i in db.literals()] == [b"+?(x)[y]", b"end", b"tailopen"]
     assert to_id(cpu_scan(db, b"a.*+?(x)[y]bb  ^]end -^end tailopen")[0]) == [(12, 1), (13, 1), (20, 2), (26, 2), (35, 3)]
+
+
+# unit/hyperscan/single.cpp:320-345 (the HyperscanTestRuntime / Compile parameter list) and :610-627
+# (TerminateMatchData). True = inside the pattern subset; the rest have no literal and no small
+# class to stand in for one, and must be refused cleanly.
+SINGLE_CPP_PATTERNS = [
+    ("foobar", True), ("abd.*def", True), ("abc[123]def", True), ("[pqr]", True), (".", False), ("\\s", True),
+    ("hatstand.*(teakettle|badgerbrush)", True), ("abc{1,3}", True), ("abc", True), ("^.{1,10}flibble", True),
+    ("(foobar)+", True), ("(foo){2,5}", True), ("((foo){2}){3}", True), ("^.*test[a-f]{3}pattern.*$", True),
+    ("(([^u]|.){16}|x){1,2}", False),
+    ("fooa?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?", True),
+    ("fooa?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?a?", True),
+    ("((aaa|[aaa]aa|aa[^aaaa]a|a.aaa.|a)){27}", True),
+    ("^.{0,40}((e{0,9}|b){16}a.A|[da]..ecbcbcc[^e]de{10,20}[Bb]{3}[dEe]*){2}", True),
+]
+SINGLE_CPP_TERMINATE = [
+    ("foobar", 0, b"foobarfoobarfoobar"), ("a", 0, b"a a a a a a a a a a a"), (".", 0, b"zzzzzzzzzzzzaaaaaaaaaaaaa"),
+    ("...", 0, b"zzzzzzzzzzzzaaaaaaaaaaaaa"), ("[a-z]{3,7}", 0, b"zzzzzzzzzzzzaaaaaaaaaaaaa"),
+    ("a", hs.HS_FLAG_CASELESS, b"   xAaAa"), ("xyzzy", hs.HS_FLAG_CASELESS, b"abcdef XYZZy xyzzy XyZzY"),
+    ("abc.*def", 0, b"abc   abc   abc   def def"), ("abc.*def", hs.HS_FLAG_DOTALL, b"abc   abc   abc   def def"),
+    ("(01234|abcde).*(foo|bar)", 0, b"abcde  xxxx   bar foo abcde foo"),
+    ("(01234|abcde).*(foo|bar)", hs.HS_FLAG_DOTALL, b"abcde  xxxx   bar foo abcde foo"),
+    ("[0-9a-f]{4,10}.*(foobar|bazbaz)", 0, b"0123456789abcdef  bazbaz foobar"),
+    ("[0-9a-f]{4,10}.*(foobar|bazbaz)", hs.HS_FLAG_DOTALL, b"0123456789abcdef  bazbaz foobar"),
+    ("^foobar[^z]{20,}", 0, b"foobarxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxxx"),
+    ("hatstand|teakettle|badgerbrush|mnemosyne", 0, b"hatstand teakettle badgerbrush mnemosyne"),
+    ("a|b|c|d", 0, b"a b c d a b c d a b c d"),
+    ("bat|cat|mat|rat|fat|sat|pat|hat|vat", hs.HS_FLAG_CASELESS, b"VAt hat pat sat fat rat mat caT BAT"),
+]
+
+
+def _re_ends(pat, fl, data):
+    import re
+
+    rf = (re.I if fl & hs.HS_FLAG_CASELESS else 0) | (re.S if fl & hs.HS_FLAG_DOTALL else 0)
+    rx = re.compile(pat.encode(), rf)
+    return [to for to in range(1, len(data) + 1) if any(rx.fullmatch(data, f, to) for f in range(to))]
+
+
+def test_single_cpp_patterns_compile_and_scan():
+    """single.cpp HyperscanTestRuntime: every pattern compiles to a non-empty database whose info
+    starts with "Version:", hs_stream_size says HS_DB_MODE_ERROR for a block database
+    (:59-84), and 2048 bytes of 'X' scan cleanly (:117-160). 17 of the 19 patterns are inside
+    the subset (repeats unrolled to reach their literal, small classes as alternations)."""
+    for flags in (0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_DOTALL, hs.HS_FLAG_SINGLEMATCH):
+        for pat, inside in SINGLE_CPP_PATTERNS:
+            if not inside:
+                with pytest.raises(hs.HsError) as e:
+                    hs.Database.compile([pat], [flags], [0])
+                assert e.value.code == hs.HS_COMPILER_ERROR
+                continue
+            db = hs.Database.compile([pat], [flags], [0])
+            assert db.size() > 0 and db.info().startswith("Version:") and db.stream_size() == hs.HS_DB_MODE_ERROR
+            ev, rv = cpu_scan(db, b"X" * 2048)
+            assert rv == hs.HS_SUCCESS and ev == []
+
+
+def test_single_cpp_match_terminate():
+    """single.cpp HyperscanTestMatchTerminate.MoreThanOne / .Block (:520-552): more than one match
+    with a handler that continues; exactly one and HS_SCAN_TERMINATED with one that stops. On top
+    of the reference's assertions, the end offsets are compared with Python's re."""
+    checked = 0
+    for pat, fl, corpus in SINGLE_CPP_TERMINATE:
+        if pat in (".", "..."):  # no literal anywhere: outside the subset
+            with pytest.raises(hs.HsError):
+                hs.Database.compile([pat], [fl], [0])
+            continue
+        db = hs.Database.compile([pat], [fl], [0])
+        ev, rv = cpu_scan(db, corpus)
+        assert rv == hs.HS_SUCCESS and len(ev) > 1, pat
+        assert [t for t, _i, _f in ev] == _re_ends(pat, fl, corpus), pat
+        ev1, rv1 = cpu_scan(db, corpus, halt_after=1)
+        assert rv1 == hs.HS_SCAN_TERMINATED and len(ev1) == 1 and ev1[0] == ev[0], pat
+        checked += 1
+    assert checked == 15
