@@ -1409,6 +1409,10 @@ void distribute_group(const std::string &b, unsigned flags, unsigned id, std::ve
  * The reference has no such limit (unit/hyperscan/single.cpp:320-345 lists these forms): its
  * Rose build falls back to NFA/DFA engines over the whole buffer where there is no literal. */
 constexpr size_t kMaxClassMembers = 40;
+/* rewrites tried per expression: a pattern with many literal-less repeats would otherwise try
+ * every order of unrolling them (reset by parse_pattern) */
+constexpr int kRewriteBudget = 48;
+thread_local int g_rewrites_left = kRewriteBudget;
 
 bool rewrite_for_literal(const std::string &b, unsigned flags, unsigned id, std::vector<Pattern> &out, int depth) {
     if (depth >= 8) return false;
@@ -1516,6 +1520,8 @@ bool rewrite_for_literal(const std::string &b, unsigned flags, unsigned id, std:
             else if (hi > 0) rest = atom + "{" + std::to_string(lo) + "," + std::to_string(hi) + "}";
         }
         const size_t before = out.size();
+        if (g_rewrites_left <= 0) return false;
+        g_rewrites_left--;
         try {
             expand_branch(b.substr(0, a.begin) + first + rest + b.substr(a.qend), flags, id, out, depth + 1);
             return true;
@@ -1577,6 +1583,7 @@ std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsi
     std::vector<Pattern> out;
     size_t from = 0;
     int depth = 0;
+    g_rewrites_left = kRewriteBudget;
     for (size_t k = 0; k <= p.size(); k++) {
         if (k < p.size()) {
             const char c = p[k];

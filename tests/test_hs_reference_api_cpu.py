@@ -352,3 +352,21 @@ def test_single_cpp_match_terminate():
         assert rv1 == hs.HS_SCAN_TERMINATED and len(ev1) == 1 and ev1[0] == ev[0], pat
         checked += 1
     assert checked == 15
+
+
+def test_literal_less_patterns_are_refused_quickly():
+    """the rewrites that look for a literal (repeat unrolling, class expansion) work to a budget:
+    a pattern made of many literal-less repeats is refused in milliseconds, not after trying
+    every order of unrolling them"""
+    import time
+
+    hs.Database.compile(["warm"])
+    for pat in ["(.)+" * 6, "(.)+" * 20, "(\\w|.){2}" * 10, "([^a]x?)+" * 15, "(.)+" * 40 + "|" + "(.)+" * 40]:
+        t = time.time()
+        with pytest.raises(hs.HsError) as e:
+            hs.Database.compile([pat])
+        assert e.value.code == hs.HS_COMPILER_ERROR and time.time() - t < 5.0, pat
+    for pat in ["[ab]+" * 30, "(a|b)+" * 30]:
+        t = time.time()
+        hs.Database.compile([pat])
+        assert time.time() - t < 5.0, pat
