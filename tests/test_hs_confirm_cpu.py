@@ -634,3 +634,33 @@ def test_utf8_mode():
     for bad, fl in [(b"caf\xe9", U), ("é".encode(), U | I), (rb"a[\h]", U), (rb"a[\x{fc}-\x{e9}]", U), (b"x", U | hs.HS_FLAG_UCP)]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [fl], [1])
+
+
+def test_repeats_unrolled_and_small_classes():
+    """patterns whose literal is only reachable through a rewrite (rewrite_for_literal in
+    csrc/hs_pattern.cpp): a repeat that must run at least once gives up its first turn
+    (A+ = A A*, A{n,m} = A A{n-1,m-1}), a class of <= 40 members stands as the alternation of
+    its members. Against Python's re with the whole block visible, under four flag settings."""
+    import random
+
+    r = random.Random(3)
+    pats = ["[pqr]", r"\s", "(foobar)+", "(foo){2,5}", "((foo){2}){3}", "[a-z]{3,7}", r"\d+x", "[ab]+c?", "(a|ab)+", "(ab|b)+a",
+            "(?:fo|o)+b", "x?[ab]{2,}", "[a-c]{2}", "(a|ab)(b|)c", "[aA]b+", "(?:ab){1,}c?", "^(ab)+", "(ab)+$", r"\b[ab]+\b",
+            "(a[bc]){2,3}d?", "[^\\x00-\\xfd]+", "(fo+){2}", "((a|b)c)+", r"\d{2,3}", "[f-h]+?o", "[]a]", "[.][$]", r"[\]]x*"]
+    alphabet = b"abcfoqprxd 01\n\tAB].$\xfe\xff"
+    fixed = [b"foofoofoofoofoofoofoo", b"foobarfoobar foobarfoobarfoobar", b"abababab ab", b""]
+    n = 0
+    for p in pats:
+        for fl in (0, hs.HS_FLAG_CASELESS, hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_MULTILINE):
+            blocks = [bytes(r.choice(alphabet) for _ in range(r.randint(0, 40))) for _ in range(4)] + fixed
+            got, want = sorted(run_exprs_auto([(p, fl, 1)], blocks)), sorted(brute_context([(p, fl, 1)], blocks))
+            assert got == want, (p, fl, sorted(set(got) ^ set(want))[:4])
+            n += len(want)
+    assert n > 800
+    # the members of a caseless class pair up: 26 literals for [a-zA-Z], not 52
+    assert len(hs.Database.compile(["[a-zA-Z]+"], [hs.HS_FLAG_CASELESS], [1]).literals()) == 26
+    # what stays outside: classes above 40 members, possessive repeats, repeats that may run zero times
+    import pytest
+    for bad in [r"\w+", r"[^a]{2}", r"(ab)*", r"[ab]?", r"[ab]++", r"."]:
+        with pytest.raises(hs.HsError):
+            hs.Database.compile([bad], [0], [1])
