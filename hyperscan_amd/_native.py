@@ -7,7 +7,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libhsgpu.so")
+    # HSGPU_LIB_VARIANT: a tuning build of the same sources (csrc/Makefile VARIANT=...), tools/ only
+    return os.path.join(_HERE, "lib", "libhsgpu%s.so" % os.environ.get("HSGPU_LIB_VARIANT", ""))
 
 
 class HsgpuLit(C.Structure):

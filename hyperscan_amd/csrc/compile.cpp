@@ -149,6 +149,53 @@ uint32_t ceil_log2(uint64_t x) {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+/* ---- the pair filter (table.h, HSGPU_F_PAIR) ------------------------------------------------ */
+
+constexpr uint32_t PAIR_MAX_VARIANTS = 1u << 12; /* filter entries one literal may need per parity */
+
+/* byte of the literal at distance p from its end (p = 0: last byte) and its compare mask */
+inline void lit_byte(const HsgpuDevLit &l, int p, uint32_t &v, uint32_t &m) {
+    if (p < 0 || p > 7) {
+        v = m = 0;
+        return;
+    }
+    v = (uint32_t)(l.v >> (8 * (7 - p))) & 0xffu;
+    m = (uint32_t)(l.msk >> (8 * (7 - p))) & 0xffu;
+}
+
+/* One literal at one delta (it ends at q + delta): the 24-bit hash input and its unknown bits, the B-plane
+ * bits of every admissible byte before it, the A-plane bits of every admissible byte after it. */
+struct PairKey {
+    uint32_t val, unk; /* hash input under hash_mask; bits to enumerate */
+    uint32_t bbits, abits;
+    bool use_a;
+    uint32_t variants() const { return 1u << popc(unk); }
+};
+
+PairKey pair_key(const HsgpuDevLit &l, int delta, uint32_t hash_mask) {
+    PairKey k;
+    k.val = k.unk = 0;
+    for (int i = 0; i < 3; i++) { /* b2 (i = 2) is the low byte of the hash input */
+        uint32_t v, m;
+        lit_byte(l, delta + i, v, m);
+        const uint32_t rel = (hash_mask >> (8 * (2 - i))) & 0xffu;
+        k.val |= (v & m & rel) << (8 * (2 - i));
+        k.unk |= (rel & ~m) << (8 * (2 - i));
+    }
+    uint32_t v3, m3, vn, mn;
+    lit_byte(l, delta + 3, v3, m3);
+    lit_byte(l, delta - 1, vn, mn);
+    k.bbits = k.abits = 0;
+    for (uint32_t b = 0; b < 256; b++) {
+        if ((b & m3) == (v3 & m3)) k.bbits |= 1u << hsgpu_pair_bit_b1(b) | 1u << hsgpu_pair_bit_b2(b);
+        if ((b & mn) == (vn & mn)) k.abits |= 1u << hsgpu_pair_bit_a(b);
+    }
+    /* which plane says more about this key: two probes of B against one of A */
+    const uint32_t pb = popc(k.bbits), pa = popc(k.abits);
+    k.use_a = pa * 32 < pb * pb;
+    return k;
+}
+
 } // namespace
 
 /* Adler-32 over the whole image, the header included (its checksum field read as zero): a
@@ -185,9 +232,6 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
      * have at least one byte left at delta 1. */
     uint32_t min_size = 8;
     for (size_t i = 0; i < n; i++) min_size = std::min<uint32_t>(min_size, dl[i].size);
-    /* below 4 bytes the delta-1 key would be a bare 2-gram: too many candidates */
-    const bool stride2 = !(flags & HSGPU_BUILD_FORCE_STRIDE1) && (min_size >= 4 || ((flags & HSGPU_BUILD_FORCE_STRIDE2) && min_size >= 2));
-    const uint32_t n_delta = stride2 ? 2 : 1;
 
     /* Case-blind keys: when any literal is caseless, hash and exact-table keys drop
      * bit 5 of every byte (one v_and per lookup), so a caseless literal needs ONE
@@ -196,21 +240,73 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     for (size_t i = 0; i < n && !blind; i++) blind = lits[i].nocase != 0;
     const uint32_t blind4 = blind ? 0x20202020u : 0u;
 
-    /* key -> (literal index | delta << 30), per class (literal order preserved) */
+    /* The pair filter (table.h): the layout for large sets, short literals included. Every literal is
+     * keyed at delta 0 and at delta +1 or -1, whichever needs fewer filter entries. Sets it cannot hold
+     * (a literal that needs thousands of entries, or one keyed on two bytes) stay with the layouts below. */
+    const unsigned old_layout = HSGPU_BUILD_FORCE_REPL | HSGPU_BUILD_FORCE_HASHED | HSGPU_BUILD_FORCE_K2 | HSGPU_BUILD_FORCE_K1 |
+                                HSGPU_BUILD_FORCE_STRIDE1 | HSGPU_BUILD_FORCE_STRIDE2 | HSGPU_BUILD_NO_FOLD | HSGPU_BUILD_NO_PAIR;
+    bool pair = (flags & HSGPU_BUILD_FORCE_PAIR) || (!(flags & old_layout) && n >= 2048);
+    std::vector<int8_t> odd_delta(n, 1);
+    uint32_t pair_hash_mask = 0;
+    if (pair) {
+        const uint32_t hm_late = blind ? 0x1fdfdfu : 0x1fffffu; /* 5 bits of b0: a key at delta -1 enumerates them */
+        bool any_late = false;
+        for (size_t i = 0; i < n && pair; i++) {
+            const uint32_t c0 = pair_key(dl[i], 0, hm_late).variants(), cp = pair_key(dl[i], 1, hm_late).variants(),
+                           cm = pair_key(dl[i], -1, hm_late).variants();
+            odd_delta[i] = cm < cp ? -1 : 1;
+            any_late |= odd_delta[i] < 0;
+            if (c0 > PAIR_MAX_VARIANTS || std::min(cp, cm) > PAIR_MAX_VARIANTS) pair = false;
+            /* its exact-table keys must be 3- or 4-byte ones (class A / B) */
+            HsgpuDevLit l = dl[i];
+            l.msk |= (uint64_t)blind4 << 32;
+            if (choose_class(l).cls == 2) pair = false;
+            if (odd_delta[i] > 0) {
+                l = dl[i];
+                l.v <<= 8;
+                l.msk = l.msk << 8 | (uint64_t)blind4 << 32;
+                if (choose_class(l).cls == 2) pair = false;
+            } else if (popc(~(uint32_t)(dl[i].msk >> 40) & 0xffffffu & ~(blind4 >> 8)) > 4) {
+                pair = false; /* a late key with more than 16 variants */
+            }
+        }
+        if (!pair && (flags & HSGPU_BUILD_FORCE_PAIR)) {
+            hsgpu_set_error("the pair filter cannot hold this literal set");
+            return HSGPU_COMPILER_ERROR;
+        }
+        pair_hash_mask = any_late ? hm_late : (blind ? 0xffdfdfu : 0xffffffu);
+    }
+
+    /* below 4 bytes the delta-1 key would be a bare 2-gram: too many candidates */
+    const bool stride2 = pair || (!(flags & HSGPU_BUILD_FORCE_STRIDE1) && (min_size >= 4 || ((flags & HSGPU_BUILD_FORCE_STRIDE2) && min_size >= 2)));
+    const uint32_t n_delta = stride2 ? 2 : 1;
+
+    /* key -> (literal index | delta << 30), per class (literal order preserved). Exact-table keys: the last
+     * 4 (A) / 3 (B) / 2 (C) bytes of the window ending at q; a literal keyed one byte late (pair filter,
+     * delta -1) has a 3-byte key of the window ending at q - 1, marked HSGPU_KEY_M, and no delta bit. */
     std::unordered_map<uint32_t, std::vector<uint32_t>> keys[3];
-    uint32_t n_cls[3] = {0, 0, 0}, max_size = 0;
+    uint32_t n_cls[3] = {0, 0, 0}, max_size = 0, n_late = 0;
     for (size_t i = 0; i < n; i++) {
         max_size = std::max<uint32_t>(max_size, dl[i].size);
-        for (uint32_t delta = 0; delta < n_delta; delta++) {
+        for (uint32_t k = 0; k < n_delta; k++) {
+            const int delta = k == 0 ? 0 : (pair ? odd_delta[i] : 1);
             HsgpuDevLit l = dl[i];
-            l.v <<= 8 * delta;
-            l.msk <<= 8 * delta;
+            if (delta > 0) {
+                l.v <<= 8;
+                l.msk <<= 8;
+            }
             /* blind: bit 5 is neither a constraint nor a wildcard to enumerate */
             l.msk |= (uint64_t)blind4 << 32;
             l.v &= ~((uint64_t)blind4 << 32);
+            uint32_t m4 = (uint32_t)(l.msk >> 32), v4 = (uint32_t)(l.v >> 32);
+            if (delta < 0) {
+                const uint32_t wild = ~(m4 >> 8) & 0xffffffu; /* <= 4 bits: checked when the layout was chosen */
+                n_late++;
+                for_each_variant(v4 >> 8, wild, [&](uint32_t key) { keys[1][key | HSGPU_KEY_M].push_back((uint32_t)i); });
+                continue;
+            }
             int cls = choose_class(l).cls;
             if (delta == 0) n_cls[cls]++;
-            uint32_t m4 = (uint32_t)(l.msk >> 32), v4 = (uint32_t)(l.v >> 32);
             uint32_t v, wild;
             if (cls == 0) {
                 v = v4;
@@ -222,15 +318,14 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
                 v = v4 >> 16;
                 wild = ~(m4 >> 16) & 0xffffu;
             }
-            const uint32_t ent = (uint32_t)i | delta << HSGPU_LIST_DELTA_SHIFT;
+            const uint32_t ent = (uint32_t)i | (uint32_t)delta << HSGPU_LIST_DELTA_SHIFT;
             for_each_variant(v, wild, [&](uint32_t key) { keys[cls][key].push_back(ent); });
         }
     }
-
     const uint32_t entries = (uint32_t)(keys[0].size() + keys[1].size());
     uint32_t tflags = (keys[0].size() ? HSGPU_F_HAS_A : 0) | (keys[1].size() ? HSGPU_F_HAS_B : 0) |
                       (keys[2].size() ? HSGPU_F_HAS_C : 0) | (stride2 ? HSGPU_F_STRIDE2 : 0) |
-                      (blind ? HSGPU_F_BLIND : 0);
+                      (blind ? HSGPU_F_BLIND : 0) | (pair ? HSGPU_F_PAIR : 0);
     /* Filter layout.
      *  - small sets ("Teddy class", <= 1024 key variants): bank-replicated rows; every
      *    lane reads its own LDS bank, so lookups are conflict-free. 128 bits per
@@ -240,7 +335,10 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     uint32_t k;
     /* replicated only pays at stride 1, where the lookup rate is high enough for LDS
      * bank conflicts to matter; at stride 2 the hashed table's 32x more bits win */
-    if (!(flags & HSGPU_BUILD_FORCE_HASHED) && ((entries <= 1024 && !stride2) || (flags & HSGPU_BUILD_FORCE_REPL))) {
+    if (pair) {
+        /* 2^k entries of 8 bytes: 128 KiB at k = 14 */
+        k = (flags & HSGPU_BUILD_FORCE_SMALL) ? 12 : (flags & HSGPU_BUILD_FORCE_MEDIUM) ? 13 : 14;
+    } else if (!(flags & HSGPU_BUILD_FORCE_HASHED) && ((entries <= 1024 && !stride2) || (flags & HSGPU_BUILD_FORCE_REPL))) {
         tflags |= HSGPU_F_REPL;
         /* 160 KiB of LDS = 128 KiB filter + 8 KiB 2-byte table + 24 KiB per-wavefront areas (fused kernel) */
         k = 10;
@@ -252,7 +350,7 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
         if ((uint64_t)entries * 128 > ((uint64_t)32 << k)) tflags |= HSGPU_F_K2;
     }
     if (flags & HSGPU_BUILD_FORCE_K2) tflags |= HSGPU_F_K2;
-    if (flags & HSGPU_BUILD_FORCE_K1) tflags &= ~HSGPU_F_K2;
+    if ((flags & HSGPU_BUILD_FORCE_K1) || pair) tflags &= ~HSGPU_F_K2;
     const uint32_t fwords = hsgpu_filter_words(tflags, k);
     /* Few 3-byte keys beside 4-byte ones at stride 1 (a handful of short literals in a large
      * set): give each its whole filter word. The filter kernel then runs ONE class test per
@@ -294,6 +392,8 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     h.n_a = n_cls[0];
     h.n_b = n_cls[1];
     h.n_c = n_cls[2];
+    h.hash_mask = pair_hash_mask;
+    h.n_m = n_late;
     h.off_filter = (uint32_t)off;
     off += (size_t)4 * fwords;
     h.off_c2bits = (uint32_t)off;
@@ -328,7 +428,11 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
             uint32_t x1 = (c == 0) ? (key >> 8) : key; /* 3-byte suffix */
             uint32_t prod1 = hsgpu_filter_prod(x1);
             uint32_t a1 = prod1 >> fshift;
-            if (c == 0) {
+            if (pair) {
+                /* the pair filter is filled from the literals themselves, below; a 3-byte key of either kind
+                 * marks the gate bitmap the confirm step consults before it probes this table */
+                if (c == 1) c2bits[hsgpu_gate_bit(key) >> 5] |= 1u << (hsgpu_gate_bit(key) & 31);
+            } else if (c == 0) {
                 set_bit(a1, hsgpu_filter_bit_a(key & 0xff, a1));
                 if (tflags & HSGPU_F_K2) set_bit(a1, hsgpu_filter_bit_a2(key & 0xff, prod1));
             } else if (tflags & HSGPU_F_BFOLD) {
@@ -358,6 +462,20 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
         for (uint32_t key : ks) {
             c2bits[key >> 5] |= 1u << (key & 31);
             c2ref[key] = add_list(keys[2][key]);
+        }
+    }
+    if (pair) {
+        for (size_t i = 0; i < n; i++) {
+            const int deltas[2] = {0, odd_delta[i]};
+            for (int delta : deltas) {
+                const PairKey pk = pair_key(dl[i], delta, pair_hash_mask);
+                for_each_variant(pk.val, pk.unk, [&](uint32_t x) {
+                    const uint32_t prod = hsgpu_filter_prod(x), e = hsgpu_pair_entry(prod, k);
+                    filter[2 * e + 1] |= 1u << hsgpu_pair_bit_h(prod);
+                    if (pk.use_a) filter[2 * e + 1] |= pk.abits;
+                    else filter[2 * e] |= pk.bbits;
+                });
+            }
         }
     }
     if (lists.empty()) lists.push_back(HSGPU_LIST_END);
@@ -397,6 +515,8 @@ int hsgpu_validate_blob(const void *buf, size_t len) {
     if (h.version != HSGPU_TABLE_VERSION) return HSGPU_DB_VERSION_ERROR;
     if (h.blob_bytes != len) return HSGPU_INVALID;
     if (h.filter_log2 < 4 || h.filter_log2 > 15 || ((h.flags & HSGPU_F_REPL) && h.filter_log2 > 10) ||
+        ((h.flags & HSGPU_F_PAIR) && (h.filter_log2 > 14 || (h.flags & (HSGPU_F_REPL | HSGPU_F_K2 | HSGPU_F_HAS_C | HSGPU_F_BFOLD)) ||
+                                      !(h.flags & HSGPU_F_STRIDE2) || !(h.hash_mask & 0xff0000u) || h.hash_mask > 0xffffffu)) ||
         h.ht_a_log2 < 2 || h.ht_a_log2 > 26 || h.ht_b_log2 < 2 || h.ht_b_log2 > 26)
         return HSGPU_INVALID;
     auto in = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(h) && off + bytes <= len; };

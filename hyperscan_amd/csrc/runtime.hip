@@ -297,7 +297,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * kernel is bound by the memory side, and there 8 wavefronts per CU measured 7-13% faster
      * than 16 (teddy64: 0.269 vs 0.288 ms; 1000 literals: 0.269 vs 0.309 ms); the VALU-bound
      * variants (stride 1, two filter bits) want all 16 (fdr10k: 0.39 vs 0.45 ms). */
-    const bool light = (h->flags & HSGPU_F_STRIDE2) && !(h->flags & (HSGPU_F_K2 | HSGPU_F_HAS_C));
+    const bool light = (h->flags & HSGPU_F_STRIDE2) && !(h->flags & (HSGPU_F_K2 | HSGPU_F_HAS_C | HSGPU_F_PAIR));
     unsigned wg_threads = (small || light) ? 512 : HSGPU_WG_THREADS;
     unsigned wg_per_cu = small ? 3 : 1;
     static const char *env_wg = getenv("HSGPU_WG_THREADS"), *env_per = getenv("HSGPU_WG_PER_CU"); /* tuning knobs */
@@ -323,7 +323,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     HsgpuScanArgs args = a;
     args.super_shift = super_shift;
     args.t_flags = h->flags;
-    args.fold_shift = (h->flags & HSGPU_F_BFOLD) ? 16u : 0u;
+    args.fold_shift = (h->flags & (HSGPU_F_BFOLD | HSGPU_F_PAIR)) ? 16u : 0u; /* one filter test stands for every key class */
+    args.t_hash_mask = h->hash_mask;
     args.t_filter_log2 = h->filter_log2;
     args.t_ht_a_log2 = h->ht_a_log2;
     args.t_ht_b_log2 = h->ht_b_log2;
@@ -403,7 +404,9 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
          * owns a private region of the candidate buffer: one 32-byte entry per 64
          * corpus bytes on average, i.e. room for candidates in a quarter of all chunks. */
         args.cand_waves = n_waves;
-        args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / 64 + n_waves - 1) / n_waves);
+        static const char *env_div = getenv("HSGPU_CAND_DIV"); /* tuning knob: corpus bytes per candidate entry of capacity */
+        const uint64_t cand_div = (env_div && atoi(env_div) >= 8 && atoi(env_div) <= 4096) ? (uint64_t)atoi(env_div) : 64;
+        args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / cand_div + n_waves - 1) / n_waves);
         if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32)) != HSGPU_SUCCESS) return rv;
         args.cand = (uint4 *)s->cand.p;
         args.cand_counts = (uint32_t *)s->ctl.p + 2 * (size_t)n_rec;
@@ -455,10 +458,6 @@ extern "C" int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, co
     a.out = (hsgpu_match_t *)d_out;
     a.cap = cap;
     a.count = (unsigned long long *)d_count;
-    {
-        static const char *dbg = getenv("HSGPU_DEBUG");
-        a.debug = dbg ? (uint32_t)atoi(dbg) : 0;
-    }
     return launch_scan(t, s, a, stream ? (hipStream_t)stream : s->stream);
 }
 

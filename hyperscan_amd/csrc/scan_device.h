@@ -72,6 +72,9 @@ namespace {
 #ifndef HSGPU_STAGES
 #define HSGPU_STAGES 8 /* prefetch depth of the filter kernel, in 1 KiB tiles per wavefront: 4, 6 or 8 */
 #endif
+#ifndef HSGPU_LOAD_AUX
+#define HSGPU_LOAD_AUX 0 /* cache policy of the corpus loads (buffer-load aux bits): 0 default, 2 nt (read once) */
+#endif
 constexpr int WG_THREADS = HSGPU_WG_THREADS; /* largest workgroup: 16 wavefronts; small tables run 8 */
 constexpr int CHUNK = 16;                     /* bytes per lane per iteration */
 constexpr int WAVE_TILE = 64 * CHUNK;         /* 1 KiB */
@@ -111,20 +114,24 @@ __device__ __forceinline__ uint64_t rfl64(uint64_t v) {
 typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
 __device__ __forceinline__ uint32_t lds_word(uint32_t byte_addr) { return *(lds_u32_t *)(uintptr_t)byte_addr; }
 
+typedef __attribute__((address_space(3))) const uint64_t lds_u64_t;
+__device__ __forceinline__ uint2 lds_pair(uint32_t byte_addr) { /* one ds_read_b64 at an absolute LDS address */
+    const uint64_t v = *(lds_u64_t *)(uintptr_t)byte_addr;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
 struct Tables {
     const uint8_t *corpus;
     const uint64_t *off;
     uint64_t nblocks, start, total;
     const uint4 *ht_a, *ht_b; /* 16-byte buckets of 4 tagged slots */
     const uint32_t *c2ref, *lists;
+    const uint32_t *gate; /* pair tables: 64 Kbit "some 3-byte key has this hash" (hsgpu_gate_bit) */
     const HsgpuDevLit *lits;
     uint32_t ht_a_log2, ht_b_log2;
     uint32_t key_mask;    /* 0xdfdfdfdf when the exact-table keys are case-blind, else all ones */
     const uint32_t *hint; /* block containing byte t << HSGPU_HINT_SHIFT, t < n_hint */
     uint64_t n_hint;
-#ifdef HSGPU_ABLATE
-    uint32_t ablate; /* tuning builds only: stop the confirm path early (HSGPU_DEBUG bits 8..11) */
-#endif
     WaveLds *wl;       /* this wavefront's LDS area */
     uint4 *rec_region; /* this wavefront's private region of the staged-record buffer */
     uint32_t rec_cap;  /* its capacity in records */
@@ -312,8 +319,27 @@ __device__ __forceinline__ void confirm_pos(const Tables &t, bool hit_a, bool hi
     }
 }
 
+/* pair tables: the filter does not say which kind of key passed. Probe the 4-byte table with the window
+ * ending at g (its entries end at g or g + 1) and, when the gate bitmap knows the hash, the 3-byte table with
+ * the 3 bytes ending at g (literals ending at g / g + 1) and with the 3 bytes ending at g - 1 (HSGPU_KEY_M:
+ * literals keyed one byte late, which end at g - 1; wm = the window ending there). */
+__device__ __forceinline__ bool gate_hit(const Tables &t, uint32_t key25) {
+    const uint32_t h = hsgpu_gate_bit(key25);
+    return (t.gate[h >> 5] >> (h & 31)) & 1u;
+}
+template <bool HAS_A, bool HAS_B, bool DEFER>
+__device__ __forceinline__ void confirm_pos_pair(const Tables &t, uint64_t wm, uint64_t w0, uint64_t w1, uint64_t g) {
+    const uint32_t w4 = (uint32_t)(w0 >> 32) & t.key_mask;
+    if (HAS_A) probe<DEFER>(t, t.ht_a, t.ht_a_log2, w4, w0, w1, g);
+    if (HAS_B) {
+        const uint32_t kb = w4 >> 8, km = (((uint32_t)(wm >> 32) & t.key_mask) >> 8) | HSGPU_KEY_M;
+        if (gate_hit(t, kb)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, kb, w0, w1, g);
+        if (g && gate_hit(t, km)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, km, wm, 0, g - 1);
+    }
+}
+
 /* fused kernel: {chunk, masks} entry, windows re-read from the corpus (L2 hits) */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
 __device__ __forceinline__ void drain_entry(const Tables &t, uint2 e) {
     const uint32_t m = e.y;
     uint32_t any = (m | m >> 16) & 0xffffu;
@@ -323,7 +349,8 @@ __device__ __forceinline__ void drain_entry(const Tables &t, uint2 e) {
         const uint64_t g = (uint64_t)e.x * CHUNK + j;
         const uint64_t w0 = window8(t.corpus, g);
         const uint64_t w1 = (S2 && g + 1 < t.total) ? window8(t.corpus, g + 1) : 0;
-        confirm_pos<HAS_A, HAS_B, HAS_C>(t, m >> j & 1, m >> (16 + j) & 1, w0, w1, g);
+        if (PAIR) confirm_pos_pair<HAS_A, HAS_B, false>(t, g ? window8(t.corpus, g - 1) : 0, w0, w1, g);
+        else confirm_pos<HAS_A, HAS_B, HAS_C>(t, m >> j & 1, m >> (16 + j) & 1, w0, w1, g);
     }
 }
 
@@ -372,15 +399,15 @@ __device__ __forceinline__ void check_lit_loaded(const Tables &t, uint32_t ent, 
 
 /* Convergent. idx[u] / pend[u]: entry index in `region` and its candidate masks still
  * to do (0 = idle lane, reads entry 0). `fresh`: take the masks from the entry itself. */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR>
 __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *region, uint2 *rq, const uint32_t (&idx)[2],
                                              uint32_t (&pend)[2], const bool (&valid)[2], bool fresh) {
     uint4 e0[2], e1[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) e0[u] = region[2 * idx[u]], e1[u] = region[2 * idx[u] + 1];
-    uint64_t g[2], w0[2], w1[2];
+    uint64_t g[2], w0[2], w1[2], wm[2];
     uint32_t w4[2];
-    bool do_a[2], do_b[2], do_c[2];
+    bool do_a[2], do_b[2], do_c[2], cnd[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const uint32_t m = fresh ? (valid[u] ? e0[u].y : 0) : pend[u];
@@ -393,20 +420,16 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
         w0[u] = j < 8 ? funnel64(A, B, j + 1) : funnel64(B, C, j - 7);
         w1[u] = 0;
         if (S2) w1[u] = (j + 1) < 8 ? funnel64(A, B, j + 2) : funnel64(B, C, j - 6); /* j even: j + 1 <= 15 */
+        wm[u] = 0;
+        if (PAIR) wm[u] = j == 0 ? A : j <= 8 ? funnel64(A, B, j) : funnel64(B, C, j - 8); /* the window ending at c[j - 1] */
         w4[u] = (uint32_t)(w0[u] >> 32) & t.key_mask;
+        cnd[u] = any && (m >> j & 1);
         do_a[u] = HAS_A && any && (m >> j & 1);
-        do_b[u] = HAS_B && any && (m >> (16 + j) & 1);
+        do_b[u] = !PAIR && HAS_B && any && (m >> (16 + j) & 1); /* pair tables: through the gate bitmap, below */
         do_c[u] = HAS_C && any && (m >> (16 + j) & 1);
         const uint32_t rest = any & (any - 1);
         pend[u] = m & (rest | rest << 16);
     }
-#ifdef HSGPU_ABLATE
-    if (t.ablate & 0x100) {
-        if ((g[0] ^ g[1] ^ w0[0] ^ w0[1]) == 0x123456789abcull) t.rec_region[0] = e0[0];
-        pend[0] = pend[1] = 0;
-        return;
-    }
-#endif
     /* entries with candidate bits left: onto the rest queue */
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -420,10 +443,21 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
     /* level 1: one 16-byte bucket per key class */
     uint4 sa[2], sb[2];
     uint32_t ref_c[2] = {0, 0};
+    /* pair tables: the two 3-byte keys of the position and their gate words (read beside the 4-byte bucket) */
+    uint32_t kb[2] = {0, 0}, km[2] = {0, 0}, gb[2] = {0, 0}, gm[2] = {0, 0};
+    if (PAIR && HAS_B) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            kb[u] = w4[u] >> 8;
+            km[u] = (((uint32_t)(wm[u] >> 32) & t.key_mask) >> 8) | HSGPU_KEY_M;
+            gb[u] = t.gate[cnd[u] ? hsgpu_gate_bit(kb[u]) >> 5 : 0];
+            gm[u] = t.gate[cnd[u] ? hsgpu_gate_bit(km[u]) >> 5 : 0];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         if (HAS_A) sa[u] = t.ht_a[do_a[u] ? hsgpu_ht_bucket(w4[u], t.ht_a_log2) : 0];
-        if (HAS_B) sb[u] = t.ht_b[do_b[u] ? hsgpu_ht_bucket(w4[u] >> 8, t.ht_b_log2) : 0];
+        if (HAS_B && !PAIR) sb[u] = t.ht_b[do_b[u] ? hsgpu_ht_bucket(w4[u] >> 8, t.ht_b_log2) : 0];
         if (HAS_C) ref_c[u] = t.c2ref[do_c[u] ? (w4[u] >> 16) : 0];
     }
     uint32_t ma[2] = {0, 0}, mb[2] = {0, 0}, ref_a[2] = {0, 0}, ref_b[2] = {0, 0};
@@ -431,49 +465,37 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         if (HAS_A && do_a[u]) ma[u] = bucket_match(sa[u], hsgpu_ht_tag(w4[u], t.ht_a_log2));
-        if (HAS_B && do_b[u]) mb[u] = bucket_match(sb[u], hsgpu_ht_tag(w4[u] >> 8, t.ht_b_log2));
+        if (HAS_B && !PAIR && do_b[u]) mb[u] = bucket_match(sb[u], hsgpu_ht_tag(w4[u] >> 8, t.ht_b_log2));
         if (!do_c[u]) ref_c[u] = 0;
         ref_a[u] = ma[u] ? pick_slot(sa[u], ma[u]) : 0;
         ref_b[u] = mb[u] ? pick_slot(sb[u], mb[u]) : 0;
         /* fast = exactly one tag match, naming its literal directly, bucket not full */
         fast_a[u] = __popc(ma[u]) == 1 && (ref_a[u] & HSGPU_REF_DIRECT) && !sa[u].w;
-        fast_b[u] = __popc(mb[u]) == 1 && (ref_b[u] & HSGPU_REF_DIRECT) && !sb[u].w;
+        fast_b[u] = !PAIR && __popc(mb[u]) == 1 && (ref_b[u] & HSGPU_REF_DIRECT) && !sb[u].w;
         fast_c[u] = (ref_c[u] & HSGPU_REF_DIRECT) != 0;
     }
-#ifdef HSGPU_ABLATE
-    if (t.ablate & 0x200) {
-        if ((ref_a[0] ^ ref_a[1] ^ ref_b[0] ^ ref_b[1] ^ ref_c[0] ^ ref_c[1]) == 0x12345678u) t.rec_region[0] = e0[0];
-        return;
-    }
-#endif
     /* level 2: {v, msk} of the literal the slot names */
     uint4 la[2], lb[2], lc[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         if (HAS_A) la[u] = *(const uint4 *)(t.lits + (fast_a[u] ? (ref_a[u] & HSGPU_LIST_LIT_MASK) : 0));
-        if (HAS_B) lb[u] = *(const uint4 *)(t.lits + (fast_b[u] ? (ref_b[u] & HSGPU_LIST_LIT_MASK) : 0));
+        if (HAS_B && !PAIR) lb[u] = *(const uint4 *)(t.lits + (fast_b[u] ? (ref_b[u] & HSGPU_LIST_LIT_MASK) : 0));
         if (HAS_C) lc[u] = *(const uint4 *)(t.lits + (fast_c[u] ? (ref_c[u] & HSGPU_LIST_LIT_MASK) : 0));
     }
-#ifdef HSGPU_ABLATE
-    if (t.ablate & 0x400) {
-        uint32_t acc = 0;
-        for (int u = 0; u < 2; u++) acc ^= (HAS_A ? la[u].x ^ la[u].w : 0) ^ (HAS_B ? lb[u].x ^ lb[u].w : 0) ^ (HAS_C ? lc[u].x : 0);
-        if (acc == 0x12345678u) t.rec_region[0] = e0[0];
-        return;
-    }
-#endif
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         if (HAS_A && fast_a[u]) check_lit_loaded(t, ref_a[u], la[u], w0[u], w1[u], g[u]);
-        if (HAS_B && fast_b[u]) check_lit_loaded(t, ref_b[u], lb[u], w0[u], w1[u], g[u]);
+        if (HAS_B && !PAIR && fast_b[u]) check_lit_loaded(t, ref_b[u], lb[u], w0[u], w1[u], g[u]);
         if (HAS_C && fast_c[u]) check_lit_loaded(t, ref_c[u], lc[u], w0[u], w1[u], g[u]);
-#ifdef HSGPU_ABLATE
-        if (t.ablate & 0x800) continue;
-#endif
         /* everything else: the general path */
         if (HAS_A && do_a[u] && !fast_a[u] && (ma[u] || sa[u].w)) probe<true>(t, t.ht_a, t.ht_a_log2, w4[u], w0[u], w1[u], g[u]);
-        if (HAS_B && do_b[u] && !fast_b[u] && (mb[u] || sb[u].w)) probe<true>(t, t.ht_b, t.ht_b_log2, w4[u] >> 8, w0[u], w1[u], g[u]);
+        if (HAS_B && !PAIR && do_b[u] && !fast_b[u] && (mb[u] || sb[u].w)) probe<true>(t, t.ht_b, t.ht_b_log2, w4[u] >> 8, w0[u], w1[u], g[u]);
         if (HAS_C && ref_c[u] && !fast_c[u]) walk_ref<true>(t, ref_c[u], w0[u], w1[u], g[u]);
+        if (PAIR && HAS_B && cnd[u]) { /* rare: a few percent of the candidates have a 3-byte key with their hash */
+            if ((gb[u] >> (hsgpu_gate_bit(kb[u]) & 31)) & 1u) probe<true>(t, t.ht_b, t.ht_b_log2, kb[u], w0[u], w1[u], g[u]);
+            if (g[u] && ((gm[u] >> (hsgpu_gate_bit(km[u]) & 31)) & 1u))
+                probe<true>(t, t.ht_b, t.ht_b_log2, km[u], wm[u], 0, g[u] - 1);
+        }
     }
 }
 
@@ -486,9 +508,6 @@ __device__ __forceinline__ void drain_matches(const Tables &t, uint32_t lane, ui
         if (lane == 0) __hip_atomic_store(&t.wl->nmq, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         return;
     }
-#ifdef HSGPU_ABLATE
-    if (t.ablate & 0x1000) n = 0;
-#endif
     while (n > keep) {
         const uint32_t k = min(n, 64u);
         n -= k;
@@ -521,6 +540,7 @@ struct FilterCfg {
     uint32_t amask;  /* hashed: byte-address mask for a */
     uint32_t lane4;  /* replicated: (lane & 31) * 4 */
     uint32_t c2base; /* LDS byte address of the 2-byte table */
+    uint32_t hmask;  /* pair filter: bits of the 3 hashed bytes that enter the hash */
 };
 
 /* The filter over one 16-byte chunk: candidate masks, bit q = lookup position q;
@@ -576,24 +596,28 @@ __device__ __forceinline__ uint32_t push_top(uint32_t hit, uint32_t acc, uint32_
     return __builtin_amdgcn_alignbit(hit, acc, nbits); /* ({hit, acc} >> nbits): low nbits of hit enter at the top */
 }
 
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int Q>
-__device__ __forceinline__ void filter_pos(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
-                                           uint32_t &acc_o) {
-    constexpr uint32_t STEP = S2 ? 2 : 1;
+/* Two passes over the chunk's lookup positions: first every hash and every LDS read (8 or 16 reads in
+ * flight per lane), then the bit tests. Interleaved, the compiler kept at most two reads ahead of their use
+ * and every second lookup waited out the whole LDS latency. */
+template <bool REPL, int Q>
+__device__ __forceinline__ uint32_t filter_hash(const uint32_t (&arr)[6]) {
     /* 3 bytes ending at c[Q]: byte offset Q + 2 into arr */
     constexpr int O = Q + 2;
     const uint32_t x = (O & 3) ? alignbyte(arr[(O >> 2) + 1], arr[O >> 2], O & 3) : arr[O >> 2];
-    /* the byte before them, c[Q-3]: byte (Q + 1) & 3 of arr[(Q + 1) >> 2] */
+    return mul_u24(x, HSGPU_FILTER_MUL);
+}
+template <bool REPL> __device__ __forceinline__ uint32_t filter_addr(uint32_t prod, const FilterCfg &f) {
+    const uint32_t a = prod >> f.shift;
+    return REPL ? ((a << 7) | f.lane4) : (a & f.amask);
+}
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int Q>
+__device__ __forceinline__ void filter_test(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t prod, uint32_t word,
+                                            uint32_t &acc_a, uint32_t &acc_o) {
+    constexpr uint32_t STEP = S2 ? 2 : 1;
+    /* the byte before the hashed ones, c[Q-3]: byte (Q + 1) & 3 of arr[(Q + 1) >> 2] */
     const uint32_t b3src = arr[(Q + 1) >> 2];
     constexpr int B3 = (Q + 1) & 3;
-    const uint32_t prod = mul_u24(x, HSGPU_FILTER_MUL);
     const uint32_t a = prod >> f.shift;
-    const uint32_t addr = REPL ? ((a << 7) | f.lane4) : (a & f.amask);
-#ifdef HSGPU_ABLATE_NOLDS /* tuning builds: same VALU work, no LDS read (wrong results: no candidates) */
-    const uint32_t word = (addr == 0xdeadbee0u) ? 1u : 0u;
-#else
-    const uint32_t word = lds_word(addr);
-#endif
     if (HAS_A) {
         uint32_t hit = shr_lo5(word, add_byte<B3>(a, b3src));
         if (K2) hit &= shr_lo5(word, add_byte1_byte<B3>(prod, b3src)); /* byte 1 of prod: second bit index */
@@ -606,6 +630,8 @@ __device__ __forceinline__ void filter_pos(const uint32_t (&arr)[6], const Filte
             if (K2) hit &= shr_byte1(word, prod);
         }
         if (HAS_C) {
+            constexpr int O = Q + 2;
+            const uint32_t x = (O & 3) ? alignbyte(arr[(O >> 2) + 1], arr[O >> 2], O & 3) : arr[O >> 2];
             const uint32_t kc = __builtin_amdgcn_ubfe(x, 8, 16);
             hit |= shr_lo5(lds_word(f.c2base + ((kc >> 5) << 2)), kc);
         }
@@ -616,7 +642,11 @@ __device__ __forceinline__ void filter_pos(const uint32_t (&arr)[6], const Filte
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int... I>
 __device__ __forceinline__ void filter_positions(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
                                                  uint32_t &acc_o, std::integer_sequence<int, I...>) {
-    (filter_pos<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, I * (S2 ? 2 : 1)>(arr, f, acc_a, acc_o), ...);
+    constexpr int STEP = S2 ? 2 : 1;
+    const uint32_t prod[sizeof...(I)] = {filter_hash<REPL, I * STEP>(arr)...};
+    const uint32_t word[sizeof...(I)] = {lds_word(filter_addr<REPL>(prod[I], f))...};
+    __builtin_amdgcn_sched_barrier(0);
+    (filter_test<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, I * STEP>(arr, f, prod[I], word[I], acc_a, acc_o), ...);
 }
 
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND>
@@ -628,14 +658,53 @@ __device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg
     }
     uint32_t acc_a = 0, acc_o = 0;
     filter_positions<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(arr, f, acc_a, acc_o,
-#ifdef HSGPU_ABLATE_HALF /* tuning builds: half the lookups (wrong results; is the kernel lookup-bound?) */
-                                                               std::make_integer_sequence<int, S2 ? 4 : 8>{});
-#else
                                                                std::make_integer_sequence<int, S2 ? 8 : 16>{});
-#endif
     /* 16 / STEP pushes of STEP bits: lookup q sits at bit 16 + q (stride 2: odd bits are noise) */
     constexpr uint32_t KEEP = S2 ? 0x5555u : 0xffffu;
     return ((acc_a >> 16) & KEEP) | (acc_o & (KEEP << 16));
+}
+
+
+/* ---- the pair filter over one 16-byte chunk (table.h "the pair filter") --------------------
+ * Lookups at the 8 even positions Q. X(Q) = the dword starting at c[Q-2] = {b2, b1, b0, nx}; the dword
+ * starting at c[Q-4] = {b4, b3, b2, b1} is X(Q-2), already there. Plain VOP2 logic (v_and / v_or /
+ * v_lshrrev) issues at one wave64 instruction per 2 cycles on gfx950, VOP3 and SDWA forms and v_mul_u32_u24
+ * at one per 4 (tools/ubench/valu_rates.hip); byte fields are therefore moved to bit 0 with a plain shift
+ * and used as shift amounts (the hardware reads their low 5 bits):
+ *   X            aligned dword, or v_alignbit by 16 (every other lookup)
+ *   x, prod      v_and (hash mask), v_mul_u32_u24
+ *   entry        v_lshrrev, v_and, ds_read_b64 -> {B, A}
+ *   tB1, tB2     B >> (W >> 8), B >> (W >> 11)        b3 bits 0..4 and 3..7
+ *   tA, tH       A >> (X >> 24), A >> (prod >> 8)     nx bits 0..4; hash bits 8..12
+ *   hit          ((tB1 & tB2) | tA) & tH, bit 0 pushed into the accumulator by v_alignbit */
+template <int Q> __device__ __forceinline__ uint32_t pair_window(const uint32_t (&arr)[5]) {
+    constexpr int O = Q + 2; /* byte offset of c[Q-2] in arr */
+    if constexpr ((O & 3) == 0) return arr[O >> 2];
+    else return __builtin_amdgcn_alignbit(arr[(O >> 2) + 1], arr[O >> 2], 16);
+}
+/* all 8 entry reads of a chunk are issued before the first one is used: the LDS latency is paid once per
+ * chunk, not once per lookup */
+template <int... I>
+__device__ __forceinline__ uint32_t pair_chunk_unrolled(const uint32_t (&arr)[5], const FilterCfg &f,
+                                                        std::integer_sequence<int, I...>) {
+    const uint32_t X[8] = {pair_window<2 * I>(arr)...};
+    const uint32_t prod[8] = {mul_u24(X[I] & f.hmask, HSGPU_FILTER_MUL)...};
+    const uint2 e[8] = {lds_pair((prod[I] >> f.shift) & f.amask)...};
+    __builtin_amdgcn_sched_barrier(0); /* left alone the scheduler keeps only one read ahead of its use */
+    uint32_t acc = 0;
+    auto test = [&](int i) {
+        const uint32_t W = i ? X[i - 1] : arr[0];
+        const uint32_t hit = ((shr_lo5(e[i].x, W >> 8) & shr_lo5(e[i].x, W >> 11)) | shr_lo5(e[i].y, X[i] >> 24)) &
+                             shr_lo5(e[i].y, prod[i] >> 8);
+        acc = push_top(hit, acc, 2);
+    };
+    (test(I), ...);
+    return acc;
+}
+__device__ __forceinline__ uint32_t pair_filter_chunk(const Chunk &c, const FilterCfg &f) {
+    const uint32_t arr[5] = {c.h.y, c.d.x, c.d.y, c.d.z, c.d.w};
+    const uint32_t acc = pair_chunk_unrolled(arr, f, std::make_integer_sequence<int, 8>{});
+    return (acc >> 16) & 0x5555u; /* lookup Q at bit Q; the spill copies the mask to the other class half */
 }
 
 struct SpillState {
@@ -669,7 +738,7 @@ __device__ __forceinline__ void spill(const HsgpuScanArgs &args, SpillState &sp,
 }
 
 /* fused: push into the wavefront's LDS queue; confirm 64 at a time */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
 __device__ __forceinline__ void enqueue_fused(const Tables &t, uint32_t &qcount, uint32_t lane, uint64_t coff,
                                               uint32_t acc) {
     uint2 *queue = t.wl->cand;
@@ -684,7 +753,7 @@ __device__ __forceinline__ void enqueue_fused(const Tables &t, uint32_t &qcount,
         qcount += __popcll(bal);
         if (qcount >= 64) {
             qcount -= 64;
-            drain_entry<HAS_A, HAS_B, HAS_C, S2>(t, queue[qcount + lane]);
+            drain_entry<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, queue[qcount + lane]);
             flush_records(t, lane, OFLUSH);
         }
     }
@@ -699,6 +768,7 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.ht_a = (const uint4 *)(args.blob + args.t_off_ht_a);
     t.ht_b = (const uint4 *)(args.blob + args.t_off_ht_b);
     t.c2ref = (const uint32_t *)(args.blob + args.t_off_c2ref);
+    t.gate = (const uint32_t *)(args.blob + args.t_off_c2bits);
     t.lists = (const uint32_t *)(args.blob + args.t_off_lists);
     t.lits = (const HsgpuDevLit *)(args.blob + args.t_off_lits);
     t.ht_a_log2 = args.t_ht_a_log2;
@@ -723,21 +793,20 @@ __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t l
 }
 
 /* ---- block hints: hint[t] = block containing corpus byte t * 1024 ------------------ */
-/* Convergent (whole wavefront): the lane's block b writes the hint of every KiB boundary
- * inside it (no searching: a per-tile bisection was 20 dependent reads per entry); blocks
- * covering more than 4 boundaries are written by the whole wavefront. Block index nblocks
- * stands for "boundaries at/after the last offset". */
-__device__ __forceinline__ void write_block_hints(const uint64_t *off, uint64_t nblocks, uint32_t *hint, uint64_t n_hint,
-                                                  uint64_t b, uint32_t lane) {
+/* Convergent (whole wavefront): the lane's block b, spanning corpus bytes [s, e), writes the hint of every
+ * KiB boundary inside it (no searching: a per-tile bisection was 20 dependent reads per entry); blocks
+ * covering more than 4 boundaries are written by the whole wavefront. Block index nblocks stands for
+ * "boundaries at/after the last offset" (s = off[nblocks]). */
+__device__ __forceinline__ void write_block_hints_of(uint64_t s, uint64_t e, uint64_t nblocks, uint32_t *hint,
+                                                     uint64_t n_hint, uint64_t b, uint32_t lane) {
     uint64_t t0 = 0, t1 = 0;
     uint32_t val = 0;
     if (b < nblocks) {
-        const uint64_t s = b ? off[b] : 0, e = off[b + 1];
         t0 = (s + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
         t1 = (e + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
         val = (uint32_t)b;
     } else if (b == nblocks) {
-        t0 = (off[nblocks] + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
+        t0 = (s + ((1ull << HSGPU_HINT_SHIFT) - 1)) >> HSGPU_HINT_SHIFT;
         t1 = n_hint;
         val = (uint32_t)(nblocks - 1);
     }
@@ -755,9 +824,30 @@ __device__ __forceinline__ void write_block_hints(const uint64_t *off, uint64_t 
         for (uint64_t t = T0 + lane; t < T1; t += 64) hint[t] = V;
     }
 }
+__device__ __forceinline__ void write_block_hints(const uint64_t *off, uint64_t nblocks, uint32_t *hint, uint64_t n_hint,
+                                                  uint64_t b, uint32_t lane) {
+    const uint64_t s = (b && b <= nblocks) ? off[b] : 0, e = b < nblocks ? off[b + 1] : 0;
+    write_block_hints_of(s, e, nblocks, hint, n_hint, b, lane);
+}
+/* K x 64 consecutive blocks per wavefront, every offset read before the first is used: one round trip to
+ * memory for the whole batch (with one block per lane and step, a 1 GiB corpus of packets cost every
+ * wavefront seven dependent round trips before it could start streaming) */
+template <int K>
+__device__ __forceinline__ void write_block_hints_batch(const uint64_t *off, uint64_t nblocks, uint32_t *hint,
+                                                        uint64_t n_hint, uint64_t b0, uint32_t lane) {
+    uint64_t s[K], e[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint64_t b = b0 + (uint64_t)k * 64 + lane;
+        s[k] = (b && b <= nblocks) ? off[b] : 0;
+        e[k] = b < nblocks ? off[b + 1] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) write_block_hints_of(s[k], e[k], nblocks, hint, n_hint, b0 + (uint64_t)k * 64 + lane, lane);
+}
 
 /* ---- phase 1: the streaming filter (FUSED: + in-kernel confirm) ----------- */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false>
 __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
@@ -771,20 +861,9 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     if (!FUSED && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
 
     const uint32_t flog2 = args.t_filter_log2;
-    const uint32_t nw = REPL ? (32u << flog2) : (1u << flog2);
+    const uint32_t nw = PAIR ? (2u << flog2) : REPL ? (32u << flog2) : (1u << flog2);
     uint32_t *filter = lds;
     uint32_t *c2bits = lds + nw;
-
-    /* stage the filter(s) in LDS: once per workgroup, 16 B per lane per step */
-    {
-        const uint4 *src = (const uint4 *)(args.blob + args.t_off_filter);
-        for (uint32_t i = threadIdx.x; i < nw / 4; i += blockDim.x) ((uint4 *)filter)[i] = src[i];
-        if (HAS_C) {
-            const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
-            for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
-        }
-    }
-    __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -792,34 +871,6 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     const uint32_t super_shift = args.super_shift;   /* log2(WAVES * 1 KiB): 14 or 13 */
     const uint32_t n_waves = gridDim.x * WAVES;
     const uint32_t wave_global = blockIdx.x * WAVES + wave;
-
-    /* two-phase: the confirm kernel's block hints are written here, 64 blocks per wavefront
-     * per step, while the LDS filter image is still arriving (a hint kernel on a side
-     * stream needed a fork/join pair of cross-stream waits around the confirm launch) */
-    if (!FUSED && args.hint_in_filter)
-        for (uint64_t b0 = (uint64_t)wave_global * 64; b0 <= args.nblocks; b0 += (uint64_t)n_waves * 64)
-            write_block_hints(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, b0 + lane, lane);
-
-    Tables t;
-    uint32_t qcount = 0;
-    SpillState sp;
-    sp.region = nullptr;
-    sp.written = 0;
-    sp.overflow = 0;
-    if (FUSED) {
-        init_tables(t, args);
-        init_wave_lds(t, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)) + wave, lane);
-        t.rec_region = args.rec_stage + (uint64_t)wave_global * args.rec_cap;
-        t.rec_cap = args.rec_cap;
-    } else {
-        sp.region = args.cand + 2ull * wave_global * args.cand_cap;
-    }
-
-    FilterCfg f;
-    f.shift = REPL ? 32u - flog2 : 30u - flog2;
-    f.amask = (nw - 1u) << 2;
-    f.lane4 = (lane & 31u) << 2;
-    f.c2base = nw * 4;
 
     const uint8_t *corpus = args.corpus;
     const uint64_t total = args.total;
@@ -839,14 +890,10 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         const int records = tile < n_full ? (int)0x7ffffff0 : 0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, records, 0x00020000);
         Chunk c;
-        const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 8, 0);
+        const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 8, HSGPU_LOAD_AUX);
         c.d = make_uint4(d[0], d[1], d[2], d[3]);
-#ifdef HSGPU_ABLATE_NOHALO /* tuning builds: wrong results at chunk starts; what does the halo load cost? */
-        c.h = make_uint2(d[3], d[2]);
-#else
-        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, 0, 0);
+        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, 0, HSGPU_LOAD_AUX);
         c.h = make_uint2(h[0], h[1]);
-#endif
         return c;
     };
     /* tile 0 has nothing in front of it: descriptor at the corpus itself, and the
@@ -855,32 +902,83 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         if (tile) return issue(tile);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)corpus, 0, (int)0x7ffffff0, 0x00020000);
         Chunk c;
-        const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 0, 0);
-        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off - 8u, 0, 0);
+        const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 0, HSGPU_LOAD_AUX);
+        const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off - 8u, 0, HSGPU_LOAD_AUX);
         c.d = make_uint4(d[0], d[1], d[2], d[3]);
         c.h = make_uint2(h[0], h[1]);
         return c;
     };
 
-#ifdef HSGPU_ABLATE_NOSPILL /* tuning builds: keep the math alive, write nothing */
-#define HSGPU_SPILL(args, sp, coff, acc, cur) (sp.written += (acc == 0x9e3779b9u))
-#else
-#define HSGPU_SPILL(args, sp, coff, acc, cur) spill(args, sp, coff, acc, cur)
+    /* The first tiles are requested before anything else: the corpus stream starts while the filter image
+     * is copied into LDS and the block hints are written (with both in front, the memory pipeline idled
+     * for the first 25-30 us of every scan). */
+    const bool streaming = n_full && blockIdx.x < n_full;
+    uint64_t tile = blockIdx.x;
+    Chunk c0, c1, c2, c3, c4, c5, c6, c7;
+    c0.d = c1.d = c2.d = c3.d = c4.d = c5.d = c6.d = c7.d = make_uint4(0, 0, 0, 0);
+    c0.h = c1.h = c2.h = c3.h = c4.h = c5.h = c6.h = c7.h = make_uint2(0, 0);
+    if (streaming) {
+        c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G);
+#if HSGPU_STAGES >= 6
+        c3 = issue(tile + 3ull * G), c4 = issue(tile + 4ull * G);
 #endif
+#if HSGPU_STAGES >= 8
+        c5 = issue(tile + 5ull * G), c6 = issue(tile + 6ull * G);
+#endif
+    }
+
+    /* stage the filter(s) in LDS: once per workgroup, 16 B per lane per step */
+    {
+        const uint4 *src = (const uint4 *)(args.blob + args.t_off_filter);
+        for (uint32_t i = threadIdx.x; i < nw / 4; i += blockDim.x) ((uint4 *)filter)[i] = src[i];
+        if (HAS_C) {
+            const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
+            for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
+        }
+    }
+    /* two-phase: the confirm kernel's block hints are written here, 512 blocks per wavefront and step,
+     * beside the LDS copy (a hint kernel on a side stream needed a fork/join pair of cross-stream waits
+     * around the confirm launch) */
+    if (!FUSED && args.hint_in_filter)
+        for (uint64_t b0 = (uint64_t)wave_global * 512; b0 <= args.nblocks; b0 += (uint64_t)n_waves * 512)
+            write_block_hints_batch<8>(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, b0, lane);
+    __syncthreads();
+
+    Tables t;
+    uint32_t qcount = 0;
+    SpillState sp;
+    sp.region = nullptr;
+    sp.written = 0;
+    sp.overflow = 0;
+    if (FUSED) {
+        init_tables(t, args);
+        init_wave_lds(t, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)) + wave, lane);
+        t.rec_region = args.rec_stage + (uint64_t)wave_global * args.rec_cap;
+        t.rec_cap = args.rec_cap;
+    } else {
+        sp.region = args.cand + 2ull * wave_global * args.cand_cap;
+    }
+
+    FilterCfg f;
+    f.shift = PAIR ? 29u - flog2 : REPL ? 32u - flog2 : 30u - flog2;
+    f.amask = PAIR ? ((1u << flog2) - 1u) << 3 : (nw - 1u) << 2;
+    f.hmask = args.t_hash_mask;
+    f.lane4 = (lane & 31u) << 2;
+    f.c2base = nw * 4;
+
+#define HSGPU_SPILL(args, sp, coff, acc, cur) spill(args, sp, coff, acc, cur)
 #define HSGPU_HANDLE(CUR, COFF)                                                                   \
     {                                                                                             \
-        const uint32_t acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f);      \
-        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2>(t, qcount, lane, (COFF), acc);          \
+        const uint32_t acc = PAIR ? pair_filter_chunk(CUR, f)                                     \
+                                  : filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f); \
+        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, qcount, lane, (COFF), acc);    \
         else HSGPU_SPILL(args, sp, (COFF), acc, CUR);                                             \
     }
 
-    if (n_full && blockIdx.x < n_full) {
-        uint64_t tile = blockIdx.x;
+    if (streaming) {
         /* HSGPU_STAGES register stages rotate by name (loop unrolled to match): all but
          * one tile are in flight while that one is filtered, a stage is never copied, and
-         * the only wait is for the stage about to be filtered. Depth matters: at ~15 GB/s
-         * per CU and ~3 us of loaded HBM latency, 16 wavefronts x 3 KiB in flight was the
-         * limit of the 4-stage version. */
+         * the only wait is for the stage about to be filtered. */
 #define HSGPU_STAGE(CUR, NEW)                                            \
     {                                                                    \
         NEW = issue(tile + (uint64_t)(HSGPU_STAGES - 1) * G);            \
@@ -890,8 +988,6 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         if (tile >= n_full) break;                                       \
     }
 #if HSGPU_STAGES == 8
-        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3 = issue(tile + 3ull * G),
-              c4 = issue(tile + 4ull * G), c5 = issue(tile + 5ull * G), c6 = issue(tile + 6ull * G), c7;
         for (;;) {
             HSGPU_STAGE(c0, c7)
             HSGPU_STAGE(c1, c0)
@@ -903,8 +999,6 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
             HSGPU_STAGE(c7, c6)
         }
 #elif HSGPU_STAGES == 6
-        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3 = issue(tile + 3ull * G),
-              c4 = issue(tile + 4ull * G), c5;
         for (;;) {
             HSGPU_STAGE(c0, c5)
             HSGPU_STAGE(c1, c0)
@@ -914,7 +1008,6 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
             HSGPU_STAGE(c5, c4)
         }
 #else
-        Chunk c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G), c3;
         for (;;) {
             HSGPU_STAGE(c0, c3)
             HSGPU_STAGE(c1, c0)
@@ -944,17 +1037,17 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
             }
             if (coff) c.h = *(const uint2 *)(corpus + coff - 8);
         }
-        uint32_t acc = filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(c, f);
+        uint32_t acc = PAIR ? pair_filter_chunk(c, f) : filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(c, f);
         uint32_t valid = 0;
         if (coff < total) valid = (coff + CHUNK <= total) ? 0xffffu : ((1u << (uint32_t)(total - coff)) - 1u);
         acc &= valid | valid << 16;
-        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2>(t, qcount, lane, coff, acc);
+        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, qcount, lane, coff, acc);
         else spill(args, sp, coff, acc, c);
     }
 #undef HSGPU_HANDLE
 
     if (FUSED) {
-        if (lane < qcount) drain_entry<HAS_A, HAS_B, HAS_C, S2>(t, t.wl->cand[lane]);
+        if (lane < qcount) drain_entry<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, t.wl->cand[lane]);
         publish_records(t, args, lane, wave_global);
     } else if (lane == 0) {
         args.cand_counts[wave_global] = sp.written;
@@ -970,7 +1063,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
  * wavefront's candidate region (batch b of 64 entries goes to wavefront
  * b % SPLIT), so that even a few thousand entries per region are confirmed by
  * many short dependent-read chains in parallel rather than one long one. ---- */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
 __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ WaveLds wave_lds[CONFIRM_THREADS / 64];
     __shared__ uint2 rest_q[CONFIRM_THREADS / 64][RQ_CAP];
@@ -987,9 +1080,6 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     init_wave_lds(t, wave_lds + wave, lane);
     t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
     t.rec_cap = args.rec_cap;
-#ifdef HSGPU_ABLATE
-    t.ablate = args.debug;
-#endif
     const uint4 *region = args.cand + 2ull * r * args.cand_cap;
     uint2 *rq = rest_q[wave];
     uint32_t base = part * 128;
@@ -1017,7 +1107,7 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
         } else {
             break;
         }
-        confirm_step<HAS_A, HAS_B, HAS_C, S2>(t, region, rq, idx, pend, valid, fresh);
+        confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, fresh);
         drain_matches(t, lane, 63);
         flush_records(t, lane, OFLUSH);
     }

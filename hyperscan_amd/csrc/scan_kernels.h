@@ -23,14 +23,13 @@ struct HsgpuScanArgs {
     const uint8_t *blob;        /* compiled table in HBM */
     /* table header fields the kernels need, copied here by the host so that no
      * kernel starts with a dependent read of the header */
-    uint32_t t_flags, t_filter_log2, t_ht_a_log2, t_ht_b_log2;
+    uint32_t t_flags, t_filter_log2, t_ht_a_log2, t_ht_b_log2, t_hash_mask;
     uint32_t t_off_filter, t_off_c2bits, t_off_ht_a, t_off_ht_b, t_off_c2ref, t_off_lists, t_off_lits;
     hsgpu_match_t *out;         /* match records */
     uint64_t cap;               /* capacity of out */
     unsigned long long *count;  /* total matches (may exceed cap) */
     uint32_t hint_in_filter;    /* 1: the two-phase filter kernel writes the block hints in its prologue */
     uint32_t fold_shift;        /* 16 for HSGPU_F_BFOLD tables (candidate masks: 4-byte-key hits copied to the other half), else 0 */
-    uint32_t debug;             /* ablation knob (env HSGPU_DEBUG): 1 = no candidate spill, 2 = no filter math */
     const uint32_t *hint;       /* hint[t] = block containing byte t << HSGPU_HINT_SHIFT */
     uint64_t n_hint;
     uint4 *cand;                /* two-phase: 32-byte candidate entries (2 x uint4), one region per filter wavefront */

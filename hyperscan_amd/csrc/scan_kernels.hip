@@ -16,7 +16,11 @@ const void *hsgpu_filter_kernels_r1f0k1(uint32_t flags);
 const void *hsgpu_filter_kernels_r1f1k0(uint32_t flags);
 const void *hsgpu_filter_kernels_r1f1k1(uint32_t flags);
 
+const void *hsgpu_pair_filter_kernel(uint32_t flags, bool fused); /* scan_inst_pair.hip */
+const void *hsgpu_pair_confirm_kernel(uint32_t flags);
+
 const void *hsgpu_filter_kernel_for(uint32_t flags, bool fused) {
+    if (flags & HSGPU_F_PAIR) return hsgpu_pair_filter_kernel(flags, fused);
     typedef const void *(*pick_t)(uint32_t);
     static const pick_t tab[2][2][2] = {
         {{hsgpu_filter_kernels_r0f0k0, hsgpu_filter_kernels_r0f0k1}, {hsgpu_filter_kernels_r0f1k0, hsgpu_filter_kernels_r0f1k1}},
@@ -30,6 +34,7 @@ template <bool S2> static const void *pick_confirm(uint32_t flags) {
     return (const void *)hwlm_confirm_kernel<true, false, false, S2>;
 }
 const void *hsgpu_confirm_kernel_for(uint32_t flags) {
+    if (flags & HSGPU_F_PAIR) return hsgpu_pair_confirm_kernel(flags);
     return (flags & HSGPU_F_STRIDE2) ? pick_confirm<true>(flags) : pick_confirm<false>(flags);
 }
 

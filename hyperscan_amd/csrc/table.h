@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 6u
+#define HSGPU_TABLE_VERSION 7u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
@@ -42,6 +42,9 @@
 #define HSGPU_F_BLIND 64u   /* hash and exact-table keys ignore bit 5 (the ASCII case bit) of every byte */
 #define HSGPU_F_BFOLD 128u  /* the (few) 3-byte keys own their whole filter word: the filter kernel runs the
                              * 4-byte-key test only, and a hit means "probe both exact tables" */
+#define HSGPU_F_PAIR 256u   /* pair filter (large sets, short literals included): stride 2, 64-bit entries hashed on the
+                             * 3 bytes ending at the lookup position, one 32-bit plane indexed by the byte BEFORE them
+                             * and one by the byte AFTER them; see "the pair filter" below */
 
 #define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
 #define HSGPU_HT_MUL 0x9E3779B1u
@@ -79,7 +82,9 @@ struct HsgpuTableHeader {
     uint32_t n_lists;
     uint32_t off_lits;
     uint32_t checksum; /* adler-style sum over everything after the header */
-    uint32_t reserved[10];
+    uint32_t hash_mask; /* pair filter: bits of the 3 hashed bytes that enter the hash (byte q-2 in bits 0..7) */
+    uint32_t n_m;       /* pair filter: literals keyed one byte late (they end at q - 1) */
+    uint32_t reserved[8];
 };
 static_assert(sizeof(HsgpuTableHeader) == 128, "header is 128 bytes");
 
@@ -120,8 +125,35 @@ HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { return (b3 +
 HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t a) { return a & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b2(uint32_t prod) { return (prod >> 8) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_words(uint32_t flags, uint32_t log2) {
-    return (flags & HSGPU_F_REPL) ? (32u << log2) : (1u << log2);
+    return (flags & HSGPU_F_PAIR) ? (2u << log2) : (flags & HSGPU_F_REPL) ? (32u << log2) : (1u << log2);
 }
+
+/* ---- the pair filter (HSGPU_F_PAIR) ------------------------------------------------------
+ * Lookups at even positions q only. With b0 = buf[q], b1 = buf[q-1], b2 = buf[q-2], b3 = buf[q-3] and
+ * nx = buf[q+1]:
+ *   x     = (b2 | b1 << 8 | b0 << 16) & hash_mask     (hash_mask drops the case bit when the table is
+ *                                                      case-blind and keeps only 5 bits of b0)
+ *   prod  = x * HSGPU_FILTER_MUL mod 2^32
+ *   entry = prod >> (32 - filter_log2)                 64-bit entries {B, A}, 2^filter_log2 of them
+ *   pass  = ((B >> (b3 & 31)) & (B >> ((b3 >> 3) & 31)) | (A >> (nx & 31))) & (A >> ((prod >> 8) & 31)) & 1
+ * Every literal is keyed twice, once per parity of its end offset e:
+ *   e even: lookup q = e (delta 0);
+ *   e odd:  lookup q = e - 1 (delta +1: its last byte is nx) or q = e + 1 (delta -1: b0 is not part of
+ *           it and is enumerated), whichever needs fewer entries.
+ * A key sets bit (prod >> 8) & 31 of A in each of its entries, and either the two B bits of every b3 value it
+ * admits ("B key": all 32 when b3 lies outside the literal) or the A bit of every nx value it admits
+ * ("A key": literals of 4 bytes at delta +1, whose b3 is unknown but whose last byte is nx). */
+HSGPU_HD uint32_t hsgpu_pair_entry(uint32_t prod, uint32_t log2) { return prod >> (32u - log2); }
+HSGPU_HD uint32_t hsgpu_pair_bit_h(uint32_t prod) { return (prod >> 8) & 31u; }
+HSGPU_HD uint32_t hsgpu_pair_bit_b1(uint32_t b3) { return b3 & 31u; }
+HSGPU_HD uint32_t hsgpu_pair_bit_b2(uint32_t b3) { return (b3 >> 3) & 31u; }
+HSGPU_HD uint32_t hsgpu_pair_bit_a(uint32_t nx) { return nx & 31u; }
+/* exact-table key of a literal keyed one byte late: the 3 bytes ending at q - 1, told apart from the 3-byte
+ * keys ending at q by bit 24 */
+#define HSGPU_KEY_M 0x01000000u
+/* gate bitmap (64 Kbit, in the c2bits section of a pair table): is there ANY 3-byte key (of either kind)
+ * with this hash? The confirm step probes the 3-byte exact table only then. */
+HSGPU_HD uint32_t hsgpu_gate_bit(uint32_t key25) { return (key25 * HSGPU_HT_MUL) >> 16; }
 
 HSGPU_HD uint32_t hsgpu_ht_bucket(uint32_t key, uint32_t log2) { return (key * HSGPU_HT_MUL) >> (32u - log2); }
 HSGPU_HD uint32_t hsgpu_ht_tag(uint32_t key, uint32_t log2) { return ((key * HSGPU_HT_MUL) >> (26u - log2)) & HSGPU_SLOT_TAG_MASK; }

@@ -109,6 +109,8 @@ typedef struct hsgpu_hwlm_info {
 #define HSGPU_BUILD_FORCE_MEDIUM 256u /* 64 KiB hashed filter: two 16-wavefront workgroups per CU where registers allow */
 #define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
 #define HSGPU_BUILD_NO_FOLD 512u    /* keep the separate 3-byte-key filter test even when only few such keys exist */
+#define HSGPU_BUILD_FORCE_PAIR 1024u /* the pair filter (the default from 2048 literals up) whatever the size of the set */
+#define HSGPU_BUILD_NO_PAIR 2048u    /* never the pair filter */
 
 /* ---- build side ---------------------------------------------------------- */
 

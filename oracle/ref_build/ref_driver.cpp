@@ -49,6 +49,9 @@ extern "C" {
 }
 
 #include <cstdint>
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -238,6 +241,158 @@ uint64_t hsref_hwlm_count_blocks(void *h, const uint8_t *base,
     }
     tl_ctx = prev;
     return c.count;
+}
+
+/* Every match of every block as (block, end, id) in the reference's own delivery order
+ * (block by block, callbacks as hwlmExec issues them). Returns the total number of matches;
+ * only the first `cap` are stored. Used for content-level parity checks. */
+struct CollectCtx {
+    uint32_t *block, *end, *id;
+    size_t cap, n;
+    uint32_t cur;
+};
+static thread_local CollectCtx *tl_collect = nullptr;
+extern "C" hwlmcb_rv_t collecting_cb(size_t end, u32 id, struct hs_scratch *) {
+    CollectCtx *c = tl_collect;
+    if (c->n < c->cap) {
+        c->block[c->n] = c->cur;
+        c->end[c->n] = (uint32_t)end;
+        c->id[c->n] = id;
+    }
+    c->n++;
+    return HWLM_CONTINUE_MATCHING;
+}
+size_t hsref_hwlm_collect_blocks(void *h, const uint8_t *base, const uint64_t *off, size_t nblocks,
+                                 size_t start, uint64_t groups, uint32_t *block, uint32_t *end,
+                                 uint32_t *id, size_t cap) {
+    CollectCtx c{block, end, id, cap, 0, 0};
+    CollectCtx *prev = tl_collect;
+    tl_collect = &c;
+    for (size_t i = 0; i < nblocks; i++) {
+        c.cur = (uint32_t)i;
+        run_one((RefTable *)h, base + off[i], (size_t)(off[i + 1] - off[i]), start, collecting_cb, groups);
+    }
+    tl_collect = prev;
+    return c.n;
+}
+
+/* hsbench's thread model (tools/hsbench/main.cpp:957-963, 990-1030): T native threads, each
+ * pinned to its own CPU (-T style affinity) and scanning its own contiguous slice of the
+ * blocks (balanced by bytes) over and over until `seconds` have passed; all threads start
+ * behind one barrier. out[0] = bytes scanned (all threads, all passes), out[1] = wall seconds,
+ * out[2] = matches of ONE pass over all slices (must equal the single-thread count),
+ * out[3] = passes completed by the slowest thread. Returns 0, or -1 when threads cannot start. */
+struct BenchArg {
+    RefTable *t;
+    const uint8_t *base;
+    const uint64_t *off;
+    size_t lo, hi, start;
+    uint64_t groups;
+    double seconds;
+    int cpu;
+    pthread_barrier_t *bar;
+    uint64_t bytes, matches_one_pass, passes;
+    double t_begin, t_end;
+};
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void *bench_thread(void *p) {
+    BenchArg *a = (BenchArg *)p;
+    if (a->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(a->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    CallCtx c{nullptr, nullptr, 0};
+    tl_ctx = &c;
+    pthread_barrier_wait(a->bar);
+    a->t_begin = now_s();
+    const double deadline = a->t_begin + a->seconds;
+    const uint64_t slice = a->off[a->hi] - a->off[a->lo];
+    do {
+        c.count = 0;
+        for (size_t i = a->lo; i < a->hi; i++)
+            run_one(a->t, a->base + a->off[i], (size_t)(a->off[i + 1] - a->off[i]), a->start, counting_cb, a->groups);
+        a->bytes += slice;
+        a->passes++;
+        a->matches_one_pass = c.count;
+    } while (now_s() < deadline);
+    a->t_end = now_s();
+    tl_ctx = nullptr;
+    return nullptr;
+}
+int hsref_hwlm_bench_threads(void *h, const uint8_t *base, const uint64_t *off, size_t nblocks, size_t start,
+                             uint64_t groups, int nthreads, double seconds, int pin, double out[4]) {
+    if (nthreads < 1 || nblocks == 0) return -1;
+    if ((size_t)nthreads > nblocks) nthreads = (int)nblocks;
+    std::vector<BenchArg> args((size_t)nthreads);
+    std::vector<pthread_t> th((size_t)nthreads);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, (unsigned)nthreads);
+    /* the CPUs this process may run on, in order: thread i is pinned to the i-th of them */
+    std::vector<int> cpus;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (pin && sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+    /* slices balanced by bytes */
+    const uint64_t total = off[nblocks] - off[0];
+    size_t lo = 0;
+    for (int i = 0; i < nthreads; i++) {
+        const uint64_t want = off[0] + total * (uint64_t)(i + 1) / (uint64_t)nthreads;
+        size_t hi = lo;
+        while (hi < nblocks && (off[hi + 1] <= want || hi == lo)) hi++;
+        if (i == nthreads - 1) hi = nblocks;
+        if (hi > nblocks) hi = nblocks;
+        BenchArg &a = args[(size_t)i];
+        a = BenchArg{(RefTable *)h, base, off, lo, hi, start, groups, seconds,
+                     cpus.empty() ? -1 : cpus[(size_t)i % cpus.size()], &bar, 0, 0, 0, 0.0, 0.0};
+        lo = hi;
+    }
+    int started = 0;
+    for (; started < nthreads; started++)
+        if (pthread_create(&th[(size_t)started], nullptr, bench_thread, &args[(size_t)started]) != 0) break;
+    if (started != nthreads) { /* cannot release the barrier with fewer threads: give up cleanly */
+        for (int i = 0; i < started; i++) pthread_cancel(th[(size_t)i]);
+        for (int i = 0; i < started; i++) pthread_join(th[(size_t)i], nullptr);
+        pthread_barrier_destroy(&bar);
+        return -1;
+    }
+    for (int i = 0; i < nthreads; i++) pthread_join(th[(size_t)i], nullptr);
+    pthread_barrier_destroy(&bar);
+    double t0 = args[0].t_begin, t1 = args[0].t_end;
+    uint64_t bytes = 0, matches = 0, min_passes = ~0ull;
+    for (const BenchArg &a : args) {
+        t0 = a.t_begin < t0 ? a.t_begin : t0;
+        t1 = a.t_end > t1 ? a.t_end : t1;
+        bytes += a.bytes;
+        matches += a.matches_one_pass;
+        min_passes = a.passes < min_passes ? a.passes : min_passes;
+    }
+    out[0] = (double)bytes;
+    out[1] = t1 - t0;
+    out[2] = (double)matches;
+    out[3] = (double)min_passes;
+    return 0;
+}
+
+/* the ISA this copy of the reference was compiled for (the Teddy / FDR variants are chosen
+ * at compile time, src/util/arch.h) */
+const char *hsref_build_isa(void) {
+#if defined(__AVX512VBMI__)
+    return "avx512vbmi";
+#elif defined(__AVX512BW__)
+    return "avx512bw";
+#elif defined(__AVX2__)
+    return "avx2";
+#else
+    return "sse";
+#endif
 }
 
 /* ---- character-class accelerators ---- */

@@ -134,17 +134,41 @@ class Oracle:
             cap = n
 
 
-_ref = None
+_ref = {}
 
 
 def ref_available():
     return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhsref.so"))
 
 
-def href():
-    global _ref
-    if _ref is None:
-        L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libhsref.so"))
+def _cpu_flags():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def ref_variants():
+    """The builds of the reference this host can run: 'avx2' always (when built), 'avx512' when
+    oracle/_ref/libhsref_avx512.so exists and /proc/cpuinfo lists every flag it was compiled
+    for (oracle/ref_build/Makefile VARIANT=_avx512)."""
+    out = []
+    if ref_available():
+        out.append("avx2")
+    need = {"avx512f", "avx512bw", "avx512vl", "avx512dq", "avx512cd", "avx512vbmi", "avx2", "bmi2"}
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libhsref_avx512.so")) and need <= _cpu_flags():
+        out.append("avx512")
+    return out
+
+
+def href(variant="avx2"):
+    if variant not in _ref:
+        name = "libhsref.so" if variant == "avx2" else "libhsref_avx512.so"
+        L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", name))
         L.hsref_hwlm_build.restype = C.c_void_p
         L.hsref_hwlm_build.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int]
         L.hsref_hwlm_free.argtypes = [C.c_void_p]
@@ -155,6 +179,13 @@ def href():
         L.hsref_hwlm_count_blocks.restype = C.c_uint64
         L.hsref_hwlm_count_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                               C.c_uint64]
+        L.hsref_hwlm_collect_blocks.restype = C.c_size_t
+        L.hsref_hwlm_collect_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hsref_hwlm_bench_threads.restype = C.c_int
+        L.hsref_hwlm_bench_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                               C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.hsref_build_isa.restype = C.c_char_p
         L.hsref_shufti_build.restype = C.c_int
         L.hsref_shufti_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hsref_truffle_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -180,8 +211,8 @@ def href():
         L.hsref_forward_accel.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
         L.hsref_valid_engines.restype = C.c_size_t
         L.hsref_valid_engines.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
-        _ref = L
-    return _ref
+        _ref[variant] = L
+    return _ref[variant]
 
 
 NO_HINT = 0xFFFFFFFF
@@ -190,8 +221,9 @@ NO_HINT = 0xFFFFFFFF
 class Reference:
     """The reference's own hwlmBuild/hwlmExec (or fdrExec with an engine hint)."""
 
-    def __init__(self, lits, hint=NO_HINT, make_small=False, isa=0):
-        self.L = href()
+    def __init__(self, lits, hint=NO_HINT, make_small=False, isa=0, variant="avx2"):
+        self.L = href(variant)
+        self.variant = variant
         arr, self._keep = pack_literals(list(lits))
         self.h = self.L.hsref_hwlm_build(arr, len(arr), 1 if make_small else 0, hint, isa)
         if not self.h:
@@ -204,7 +236,37 @@ class Reference:
             pass
 
     def info(self):
-        return self.L.hsref_hwlm_info(self.h).decode()
+        return self.L.hsref_hwlm_info(self.h).decode() + " isa=" + self.L.hsref_build_isa().decode()
+
+    def collect_blocks(self, base, off, start=0, groups=HWLM_ALL_GROUPS):
+        """Every match as (block, end, id), in the reference's own delivery order."""
+        a = _u8(base)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        cap = 1 << 16
+        while True:
+            b = np.zeros(cap, dtype=np.uint32)
+            e = np.zeros(cap, dtype=np.uint32)
+            i = np.zeros(cap, dtype=np.uint32)
+            n = self.L.hsref_hwlm_collect_blocks(self.h, a.ctypes.data, off.ctypes.data, off.size - 1, start, groups,
+                                                 b.ctypes.data, e.ctypes.data, i.ctypes.data, cap)
+            if n <= cap:
+                out = np.zeros(n, dtype=REC)
+                out["block"], out["end"], out["id"] = b[:n], e[:n], i[:n]
+                return out
+            cap = n
+
+    def bench_threads(self, base, off, threads, seconds, pin=True, start=0, groups=HWLM_ALL_GROUPS):
+        """hsbench's thread model in native code: `threads` pinned pthreads, each looping over its own
+        slice of the blocks for `seconds`. Returns (bytes scanned, wall seconds, matches of one pass,
+        passes of the slowest thread)."""
+        a = _u8(base)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        out = (C.c_double * 4)()
+        rv = self.L.hsref_hwlm_bench_threads(self.h, a.ctypes.data, off.ctypes.data, off.size - 1, start, groups,
+                                             int(threads), float(seconds), 1 if pin else 0, out)
+        if rv != 0:
+            raise RuntimeError("reference bench threads could not start")
+        return float(out[0]), float(out[1]), int(out[2]), int(out[3])
 
     def exec(self, buf, start, cb, groups=HWLM_ALL_GROUPS):
         a = _u8(buf)
