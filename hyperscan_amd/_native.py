@@ -51,7 +51,6 @@ _SIGS = {
                                             C.POINTER(C.c_float)]),
     "hsgpu_scratch_get_kernel_span": (C.c_int, [C.c_void_p, C.c_uint, C.POINTER(C.c_float)]),
     "hsgpu_scratch_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
-    "hsgpu_match_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "hsgpu_hwlm_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, HWLM_CB, C.c_void_p, C.c_uint64]),
     "hsgpu_last_error": (C.c_char_p, []),
     "hsgpu_version": (C.c_char_p, []),

@@ -30,10 +30,4 @@ uint32_t hsgpu_blob_checksum(const uint8_t *blob, size_t len);
 /* runtime.hip */
 void hsgpu_release_device_copies(hsgpu_hwlm *t);
 
-#ifdef __HIPCC__
-/* sort_records.hip */
-size_t hsgpu_sort_workspace_bytes(uint64_t n);
-int hsgpu_sort_records(void *d_rec, uint64_t n, void *d_ws, size_t ws_bytes, hipStream_t st);
-#endif
-
 #endif

@@ -73,8 +73,8 @@ struct hsgpu_scratch {
     uint64_t n_timed = 0;       /* scans launched with timing on */
     DevBuf tstamp;              /* [kRing][4] device wall clock: filter start (min) / end (max), confirm-stage end, pipeline end */
     double wall_clock_khz = 100000.0;
-    DevBuf corpus, off, out, count, sort_tmp, hint, cand, ctl, rec_stage, rec_offsets, stats;
-    bool ctl_clean = false;                /* every control word is zero (left so by control_reset_kernel) */
+    DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, rec_aux, order, order_tmp, stats;
+    bool ctl_clean = false;                /* every control word is zero (left so by record_order_kernel) */
     unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
     int n_cu = 0;
@@ -162,14 +162,15 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->off.release();
     s->out.release();
     s->count.release();
-    s->sort_tmp.release();
+    s->order.release();
+    s->order_tmp.release();
     s->hint.release();
     s->cand.release();
     s->ctl.release();
     s->stats.release();
     s->tstamp.release();
     s->rec_stage.release();
-    s->rec_offsets.release();
+    s->rec_aux.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
     for (int r = 0; r < hsgpu_scratch::kRing; r++)
         for (int i = 0; i < 4; i++)
@@ -361,22 +362,44 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.rec_regions = n_rec;
     args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
     if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
-    /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1]; rec_offsets apart */
-    const size_t ctl_words = (size_t)2 * n_rec + n_waves + 1;
+    if ((rv = s->rec_aux.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint2))) != HSGPU_SUCCESS) return rv;
+    args.rec_aux = (uint2 *)s->rec_aux.p;
+    /* ordered output: records are counted per corpus slice; at most 2^18 slices of at least 4 KiB */
+    uint32_t slice_shift = 12;
+    while (((a.total - 1) >> slice_shift) >= (1u << 18)) slice_shift++;
+    const uint32_t n_slices = (uint32_t)((a.total - 1) >> slice_shift) + 1;
+    /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1] | slice_cnt | super_cnt | order_ctl, each
+     * part 16-byte aligned, 16 bytes of padding at the end (record_scan reads slice_cnt four words at a time) */
+    auto up4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
+    const size_t cand_ofs = up4((size_t)2 * n_rec), slice_ofs = cand_ofs + up4((size_t)n_waves + 1);
+    const uint32_t n_super = (n_slices + (1u << HSGPU_SUPER_SHIFT) - 1) >> HSGPU_SUPER_SHIFT;
+    const size_t super_ofs = slice_ofs + up4(n_slices), ctl_words = super_ofs + up4(n_super) + 8;
     /* a reallocated control block is garbage whatever its address: hipMalloc may hand the
      * freed range straight back, so growth is detected by capacity, never by pointer */
     const size_t ctl_cap_before = s->ctl.cap;
     if ((rv = s->ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
     if (s->ctl.cap != ctl_cap_before) s->ctl_clean = false;
-    if ((rv = s->rec_offsets.ensure((size_t)n_rec * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
+    /* slice_off[n_slices + 1] | heavy[n_slices] | order_state[4], and the scatter target */
+    if ((rv = s->order.ensure(((size_t)2 * n_slices + 8) * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->order_tmp.ensure(std::max<uint64_t>(a.cap, 1) * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
     args.rec_stage = (uint4 *)s->rec_stage.p;
     args.rec_counts = (uint32_t *)s->ctl.p;
-    args.rec_offsets = (unsigned long long *)s->rec_offsets.p;
+    args.ctl_words = (uint32_t)ctl_words;
+    args.cand_ofs = (uint32_t)cand_ofs;
+    args.slice_shift = slice_shift;
+    args.n_slices = n_slices;
+    args.slice_cnt = (uint32_t *)s->ctl.p + slice_ofs;
+    args.slice_off = (uint32_t *)s->order.p;
+    args.heavy = args.slice_off + n_slices + 1;
+    args.order_state = args.heavy + n_slices;
+    args.super_cnt = (uint32_t *)s->ctl.p + super_ofs;
+    args.order_ctl = args.super_cnt + up4(n_super);
+    args.order_tmp = (uint4 *)s->order_tmp.p;
     args.stats = (unsigned long long *)s->stats.p;
     /* the control words are left zeroed by the previous scan's last kernel; only a
      * fresh (or possibly dirty) buffer needs a memset */
     if (!s->ctl_clean) HIP_TRY(hipMemsetAsync(s->ctl.p, 0, s->ctl.cap, stream));
-    s->ctl_clean = false; /* until this scan's control_reset_kernel has been queued */
+    s->ctl_clean = false; /* until this scan's record_order_kernel has been queued */
 
     void *kargs[] = {&args};
     args.tstamp = nullptr;
@@ -409,7 +432,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / cand_div + n_waves - 1) / n_waves);
         if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32)) != HSGPU_SUCCESS) return rv;
         args.cand = (uint4 *)s->cand.p;
-        args.cand_counts = (uint32_t *)s->ctl.p + 2 * (size_t)n_rec;
+        args.cand_counts = (uint32_t *)s->ctl.p + cand_ofs;
         if ((rv = set_dyn_lds(f_two, lds_two)) != HSGPU_SUCCESS) return rv;
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
@@ -417,14 +440,12 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
     }
-    HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
-    HIP_TRY(hipLaunchKernel(hsgpu_record_pack_kernel(), dim3((n_rec + 3) / 4), dim3(256), kargs, 0, stream));
+    HIP_TRY(hipLaunchKernel(hsgpu_record_offsets_kernel(), dim3(n_super), dim3(256), kargs, 0, stream));
+    HIP_TRY(hipLaunchKernel(hsgpu_record_scatter_kernel(), dim3((n_rec + 3) / 4), dim3(256), kargs, 0, stream));
     if (s->timing) s->n_timed++;
-    {
-        const uint32_t words = std::max<uint32_t>(2 * n_rec, n_waves + 1);
-        HIP_TRY(hipLaunchKernel(hsgpu_control_reset_kernel(), dim3((words + 255) / 256), dim3(256), kargs, 0, stream));
-        s->ctl_clean = true;
-    }
+    /* ranks inside the slices, heavy slices, and the control block back to zero */
+    HIP_TRY(hipLaunchKernel(hsgpu_record_order_kernel(), dim3((unsigned)s->n_cu * 4), dim3(256), kargs, 0, stream));
+    s->ctl_clean = true;
     return HSGPU_SUCCESS;
 }
 
@@ -434,6 +455,10 @@ extern "C" int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, co
     if (!t || !s || !d_off || !d_count || (cap && !d_out) || (total_bytes && !d_corpus)) return HSGPU_INVALID;
     if (((uintptr_t)d_corpus & 15) || ((uintptr_t)d_out & 15)) {
         hsgpu_set_error("corpus and record buffers must be 16-byte aligned");
+        return HSGPU_INVALID;
+    }
+    if (cap >= (1ull << 32)) {
+        hsgpu_set_error("record buffer larger than 2^32 records");
         return HSGPU_INVALID;
     }
     if (total_bytes >= (1ull << 36)) { /* chunk index is 32 bits of 16-byte chunks */
@@ -462,11 +487,6 @@ extern "C" int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, co
 }
 
 /* ---- host-buffer forms ------------------------------------------------------- */
-
-static bool device_sort_enabled() { /* opt-in, see hsgpu_match_sort_dev */
-    static const char *e = getenv("HSGPU_DEVICE_SORT");
-    return e && e[0] == '1';
-}
 
 struct RecLess { /* a functor, so that std::sort / std::merge inline the comparison */
     bool operator()(const hsgpu_match_t &a, const hsgpu_match_t &b) const {
@@ -567,11 +587,8 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
         HIP_TRY(hipStreamSynchronize(s->stream));
         uint64_t n = *s->h_count;
         if (n <= cap) {
-            recs.resize(n);
-            const bool on_device = device_sort_enabled() && n >= 2;
-            if (on_device && (rv = hsgpu_match_sort_dev(s, s->out.p, n, s->stream)) != HSGPU_SUCCESS) return rv;
+            recs.resize(n); /* already in delivery order: (block, end, literal index) */
             if (n) HIP_TRY(hipMemcpy(recs.data(), s->out.p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost));
-            if (!on_device) hsgpu_match_sort_host(recs.data(), recs.size());
             return HSGPU_SUCCESS;
         }
         /* overflow: the count is exact; rerun with room for all of them, and since the
@@ -634,30 +651,4 @@ extern "C" int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, 
     size_t n = std::min(cap, recs.size());
     if (n) memcpy(out, recs.data(), n * sizeof(hsgpu_match_t));
     return recs.size() > cap ? HSGPU_INSUFFICIENT_SPACE : HSGPU_SUCCESS;
-}
-
-extern "C" int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n, void *stream) {
-    /* Delivery order (block, end, literal index). Default: through the host (copy out,
-     * std::sort, copy back). With HSGPU_DEVICE_SORT=1: on the device (sort_records.hip: two
-     * stable radix sorts + a gather, asynchronous on `stream`, workspace in the scratch) --
-     * measured 24 -> 36 GB/s end to end on config 5, opt-in until it has been through the
-     * whole GPU suite again. */
-    if (!s || (n && !d_out)) return HSGPU_INVALID;
-    if (n < 2) return HSGPU_SUCCESS;
-    HIP_TRY(hipSetDevice(s->device));
-    hipStream_t st = stream ? (hipStream_t)stream : s->stream;
-    const size_t need = device_sort_enabled() ? hsgpu_sort_workspace_bytes(n) : 0;
-    if (need == 0) {
-        std::vector<hsgpu_match_t> recs(n);
-        HIP_TRY(hipMemcpyAsync(recs.data(), d_out, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        hsgpu_match_sort_host(recs.data(), recs.size());
-        HIP_TRY(hipMemcpyAsync(d_out, recs.data(), n * sizeof(hsgpu_match_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return HSGPU_SUCCESS;
-    }
-    if (need > s->sort_tmp.cap) HIP_TRY(hipStreamSynchronize(st)); /* a growing workspace is freed first */
-    int rv = s->sort_tmp.ensure(need);
-    if (rv != HSGPU_SUCCESS) return rv;
-    return hsgpu_sort_records(d_out, n, s->sort_tmp.p, s->sort_tmp.cap, st);
 }

@@ -132,8 +132,12 @@ struct Tables {
     uint32_t key_mask;    /* 0xdfdfdfdf when the exact-table keys are case-blind, else all ones */
     const uint32_t *hint; /* block containing byte t << HSGPU_HINT_SHIFT, t < n_hint */
     uint64_t n_hint;
+    uint32_t *slice_cnt;  /* records per corpus slice (1 << slice_shift bytes): the key of the ordered output */
+    uint32_t *super_cnt;  /* the same per group of 256 slices */
+    uint32_t slice_shift;
     WaveLds *wl;       /* this wavefront's LDS area */
     uint4 *rec_region; /* this wavefront's private region of the staged-record buffer */
+    uint2 *aux_region; /* beside it: {corpus slice, ticket inside the slice} of each staged record */
     uint32_t rec_cap;  /* its capacity in records */
 };
 
@@ -191,13 +195,26 @@ __device__ __forceinline__ uint64_t block_of(const Tables &t, uint64_t g, uint64
  * which would cap the whole scan at a few tens of thousands of matches per ms.
  * Staged records are appended to the wavefront's private HBM region at
  * convergent points (flush_records); a compaction pass packs the regions. */
-__device__ __forceinline__ void stage_record(const Tables &t, const uint4 rec) {
+/* The ordered output is a counting sort by corpus slice (record_offsets / record_scatter) followed by an
+ * ordering pass inside each slice (record_order). A staged record carries its slice beside it; its ticket
+ * inside the slice is drawn when the wavefront is done (take_tickets): atomics inside the confirm loop sat in
+ * front of every later wait for a load. */
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) { /* set bits below this lane */
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+__device__ __forceinline__ uint32_t slice_of_rec(const Tables &t, const uint4 rec) {
+    return (uint32_t)((t.off[rec.x] + rec.y) >> t.slice_shift);
+}
+__device__ __forceinline__ void stage_record(const Tables &t, const uint4 rec, uint64_t ge) {
     const uint32_t s = __hip_atomic_fetch_add(&t.wl->nrec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (s < OCAP) {
         t.wl->rec[s] = rec;
     } else { /* staging full inside one drain: spill to the back of the region */
         const uint32_t k = __hip_atomic_fetch_add(&t.wl->nback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (k < t.rec_cap) t.rec_region[t.rec_cap - 1 - k] = rec;
+        if (k < t.rec_cap) {
+            t.rec_region[t.rec_cap - 1 - k] = rec;
+            t.aux_region[t.rec_cap - 1 - k] = make_uint2((uint32_t)(ge >> t.slice_shift), 0);
+        }
     }
 }
 
@@ -211,7 +228,7 @@ __device__ __forceinline__ void resolve_match(const Tables &t, uint64_t ge, uint
     const uint64_t b = block_of(t, ge, bstart);
     const uint64_t end = ge - bstart;
     if (end + 1 < size || end + 1 - size < t.start) return;
-    stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, li));
+    stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, li), ge);
 }
 
 /* Confirm kernel: queue the match in the wavefront's LDS match queue (wl->cand,
@@ -247,7 +264,11 @@ __device__ __forceinline__ void flush_records(const Tables &t, uint32_t lane, ui
     if (n < threshold) return;
     if (n > OCAP) n = OCAP;
     const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
-    if (lane < n && f + lane < t.rec_cap) t.rec_region[f + lane] = t.wl->rec[lane];
+    if (lane < n && f + lane < t.rec_cap) {
+        const uint4 rec = t.wl->rec[lane];
+        t.rec_region[f + lane] = rec;
+        t.aux_region[f + lane] = make_uint2(slice_of_rec(t, rec), 0);
+    }
     if (lane == 0) {
         t.wl->nfront = f + n; /* keeps counting past the capacity: the total stays exact */
         __hip_atomic_store(&t.wl->nrec, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -258,6 +279,20 @@ __device__ __forceinline__ void flush_records(const Tables &t, uint32_t lane, ui
 __device__ __forceinline__ void publish_records(const Tables &t, const HsgpuScanArgs &args, uint32_t lane,
                                                 uint32_t region) {
     flush_records(t, lane, 1);
+    {   /* tickets: every staged record counts itself into its slice (and the slice's group). The slices were
+         * stored by other lanes of this wavefront a moment ago: their stores must have landed first. */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const uint32_t nf = min(__builtin_amdgcn_readfirstlane(t.wl->nfront), t.rec_cap);
+        const uint32_t nb = min(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&t.wl->nback, __ATOMIC_RELAXED,
+                                                                                    __HIP_MEMORY_SCOPE_WAVEFRONT)),
+                                t.rec_cap);
+        for (uint32_t i = lane; i < nf + nb; i += 64) {
+            const uint32_t slot = i < nf ? i : t.rec_cap - 1 - (i - nf);
+            const uint32_t sl = __hip_atomic_load(&t.aux_region[slot].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t.aux_region[slot].y = __hip_atomic_fetch_add(&t.slice_cnt[sl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&t.super_cnt[sl >> HSGPU_SUPER_SHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (lane == 0) {
         args.rec_counts[2 * region] = t.wl->nfront;
         args.rec_counts[2 * region + 1] =
@@ -379,10 +414,6 @@ constexpr uint32_t RQ_CAP = 256; /* rest queue: {entry index, masks still to do}
 
 __device__ __forceinline__ uint32_t pick_slot(const uint4 s, uint32_t m) {
     return (m & 1) ? s.x : (m & 2) ? s.y : (m & 4) ? s.z : s.w;
-}
-
-__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) { /* set bits below this lane */
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
 /* (v, msk) of a literal already in registers */
@@ -524,7 +555,10 @@ __device__ __forceinline__ void drain_matches(const Tables &t, uint32_t lane, ui
         const uint64_t mask = __ballot(ok);
         const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
         const uint32_t at = f + lane_rank(mask);
-        if (ok && at < t.rec_cap) t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
+        if (ok && at < t.rec_cap) {
+            t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
+            t.aux_region[at] = make_uint2((uint32_t)(ge >> t.slice_shift), 0);
+        }
         if (lane == 0) t.wl->nfront = f + (uint32_t)__popcll(mask);
     }
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -776,8 +810,12 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.key_mask = (args.t_flags & HSGPU_F_BLIND) ? 0xdfdfdfdfu : 0xffffffffu;
     t.hint = args.hint;
     t.n_hint = args.n_hint;
+    t.slice_cnt = args.slice_cnt;
+    t.super_cnt = args.super_cnt;
+    t.slice_shift = args.slice_shift;
     t.wl = nullptr;
     t.rec_region = nullptr;
+    t.aux_region = nullptr;
     t.rec_cap = 0;
 }
 
@@ -954,6 +992,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         init_tables(t, args);
         init_wave_lds(t, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)) + wave, lane);
         t.rec_region = args.rec_stage + (uint64_t)wave_global * args.rec_cap;
+        t.aux_region = args.rec_aux + (uint64_t)wave_global * args.rec_cap;
         t.rec_cap = args.rec_cap;
     } else {
         sp.region = args.cand + 2ull * wave_global * args.cand_cap;
@@ -1079,6 +1118,7 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     init_tables(t, args);
     init_wave_lds(t, wave_lds + wave, lane);
     t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
+    t.aux_region = args.rec_aux + (uint64_t)cw * args.rec_cap;
     t.rec_cap = args.rec_cap;
     const uint4 *region = args.cand + 2ull * r * args.cand_cap;
     uint2 *rq = rest_q[wave];
@@ -1115,116 +1155,194 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     publish_records(t, args, lane, cw);
 }
 
-/* ---- phase 3: pack the per-wavefront record regions into the caller's buffer ---- */
-/* one workgroup: exclusive scan of the region fills, total into *count. Thread t
- * owns regions t, t + 1024, ... (coalesced, independent loads); the order in
- * which regions land in the output is immaterial. */
-__global__ __launch_bounds__(1024) void record_scan_kernel(HsgpuScanArgs args) {
-    __shared__ unsigned long long part[1024];
-    __shared__ uint32_t any_overflow;
-    const uint32_t n = args.rec_regions, tid = threadIdx.x;
-    const uint2 *counts = (const uint2 *)args.rec_counts;
-    if (tid == 0) any_overflow = 0;
-    __syncthreads();
-    unsigned long long sum = 0;
-    bool ovf = false;
-    for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) { /* 8 independent loads in flight per thread */
-        uint2 c[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t i = i0 + u * 1024;
-            c[u] = i < n ? counts[i] : make_uint2(0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            ovf |= (unsigned long long)c[u].x + c[u].y > args.rec_cap;
-            sum += (unsigned long long)c[u].x + c[u].y;
-        }
+/* ---- phase 3: the records in delivery order ---------------------------------------------------
+ * hwlmExec delivers callbacks in non-decreasing `end` (src/hwlm/hwlm.h:101-118) and Rose relies on it
+ * (src/rose/match.c:396-476); a batch delivers block by block. The output of a scan is therefore sorted by
+ * (block, end, literal index), which is also the order of the corpus position g = off[block] + end. The
+ * producing wavefronts have drawn a ticket per record in its corpus slice (publish_records):
+ *   record_offsets  exclusive scan of the slice counts (one workgroup per 256 slices, on top of the counts
+ *                   per group), the list of slices with more than ORDER_LIGHT records, region overflow check
+ *   record_scatter  *count; every staged record to tmp[slice_off[slice] + ticket] (a counting sort by slice)
+ *   record_order    each record of a light slice finds its rank inside the slice by counting (slices hold
+ *                   a handful of records); heavy slices are sorted by a workgroup each (bitonic network in
+ *                   LDS up to ORDER_LDS records, in place in global memory beyond); then every control word
+ *                   goes back to zero for the next scan. */
+constexpr uint32_t ORDER_LIGHT = 64;  /* largest slice ranked by counting */
+constexpr uint32_t ORDER_LDS = 2048;  /* largest slice sorted in LDS */
+
+__device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (block, end, literal index) */
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    return a.w < b.w;
+}
+
+/* One workgroup per group of 256 slices ("super-slice"): the records before the group from the per-group
+ * counts (every workgroup sums the at most 1024 of them itself: 4 KiB out of L2, no workgroup waits for
+ * another), an exclusive scan of its own 256 slice counts behind that, the heavy slices appended to their
+ * list; the workgroups also share out the check "did a staging region run out of space?". */
+__global__ __launch_bounds__(256) void record_offsets_kernel(HsgpuScanArgs args) {
+    __shared__ unsigned long long red[2][4];
+    __shared__ uint32_t wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, sg = blockIdx.x;
+    const uint32_t n_super = gridDim.x;
+    /* records in the groups before this one, and in all of them */
+    unsigned long long before = 0, all = 0;
+    for (uint32_t i = tid; i < n_super; i += 256) {
+        const uint32_t c = args.super_cnt[i];
+        all += c;
+        if (i < sg) before += c;
     }
-    if (ovf) any_overflow = 1;
-    /* inclusive scan of the 1024 per-thread sums: shuffles inside each wavefront,
-     * then the 16 wavefront totals, two barriers in all */
-    const uint32_t lane = tid & 63, wv = tid >> 6;
-    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d), all += __shfl_xor(all, d);
+    if (lane == 0) red[0][wv] = before, red[1][wv] = all;
+    /* this group's slices */
+    const uint32_t sl = sg * 256 + tid;
+    const uint32_t c = sl < args.n_slices ? args.slice_cnt[sl] : 0;
+    uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long v = __shfl_up(incl, d);
+        const uint32_t v = __shfl_up(incl, d);
         if (lane >= (uint32_t)d) incl += v;
     }
-    if (lane == 63) part[wv] = incl;
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    if (wv == 0) {
-        unsigned long long w = lane < 16 ? part[lane] : 0;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const unsigned long long v = __shfl_up(w, d);
-            if (lane >= (uint32_t)d) w += v;
-        }
-        if (lane < 16) part[16 + lane] = w; /* inclusive totals of wavefronts 0..lane */
+    before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    uint32_t wbefore = 0;
+    for (uint32_t w = 0; w < wv; w++) wbefore += wsum[w];
+    if (sl < args.n_slices) {
+        args.slice_off[sl] = (uint32_t)before + wbefore + incl - c;
+        if (c > ORDER_LIGHT) args.heavy[atomicAdd(&args.order_ctl[0], 1u)] = sl;
     }
-    __syncthreads();
-    const unsigned long long before_wave = wv ? part[16 + wv - 1] : 0;
-    unsigned long long run = before_wave + incl - sum; /* exclusive prefix of this thread */
-    for (uint32_t i0 = tid; i0 < n; i0 += 8 * 1024) {
-        uint2 c[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t i = i0 + u * 1024;
-            c[u] = i < n ? counts[i] : make_uint2(0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t i = i0 + u * 1024;
-            if (i < n) args.rec_offsets[i] = run;
-            run += (unsigned long long)c[u].x + c[u].y;
-        }
+    if (sg == 0 && tid == 0) {
+        args.slice_off[args.n_slices] = (uint32_t)all;
     }
-    if (tid == 1023) {
-        const unsigned long long total = before_wave + incl;
-        /* a region that ran out of space lost records; its fill counters kept
-         * counting, so the total is still exact: report it, but never a value
-         * <= cap (that would claim the output is complete) */
-        *args.count = (any_overflow && total <= args.cap) ? args.cap + 1 : total;
+    /* staging regions: a region that ran out of space lost records (its fill counters kept counting, so
+     * the total stays exact) */
+    const uint32_t n = args.rec_regions, per = (n + n_super - 1) / n_super;
+    const uint2 *counts = (const uint2 *)args.rec_counts;
+    bool ovf = false;
+    unsigned long long found = 0; /* the exact number of matches, delivered or not */
+    for (uint32_t i = sg * per + tid; i < min(n, (sg + 1) * per); i += 256) {
+        const uint2 rc = counts[i];
+        ovf |= (unsigned long long)rc.x + rc.y > args.rec_cap;
+        found += (unsigned long long)rc.x + rc.y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d);
+    const bool any_ovf = __ballot(ovf) != 0;
+    if (lane == 0) {
+        if (any_ovf) atomicOr(&args.order_ctl[1], 1u);
+        if (found) atomicAdd((unsigned long long *)(args.order_ctl + 2), found);
     }
 }
 
-/* wavefront w copies region w to out[rec_offsets[w] ...) */
-__global__ __launch_bounds__(256) void record_pack_kernel(HsgpuScanArgs args) {
+/* the slice a staged record belongs to: one read of the block's offset */
+__device__ __forceinline__ uint32_t slice_of(const HsgpuScanArgs &args, const uint4 r) {
+    return (uint32_t)((args.off[r.x] + r.y) >> args.slice_shift);
+}
+
+/* wavefront w moves the records of region w to their places in their slices */
+__global__ __launch_bounds__(256) void record_scatter_kernel(HsgpuScanArgs args) {
+    /* the output is complete only when no region overflowed and everything fits the caller's buffer;
+     * otherwise the count says how much room a second scan needs and no record is delivered */
+    const unsigned long long total = *(const unsigned long long *)(args.order_ctl + 2);
+    const bool ovf = args.order_ctl[1] != 0, complete = !ovf && total <= args.cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *args.count = (ovf && total <= args.cap) ? args.cap + 1 : total;
+        args.order_state[0] = complete ? 1u : 0u; /* for record_order, which zeroes the control words it came from */
+        args.order_state[1] = complete ? args.order_ctl[0] : 0u;
+    }
+    if (!complete) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= args.rec_regions) return;
     const uint32_t f = args.rec_counts[2 * w], b = args.rec_counts[2 * w + 1];
-    if ((unsigned long long)f + b > args.rec_cap) return;
-    const unsigned long long o = args.rec_offsets[w];
     const uint4 *region = args.rec_stage + (uint64_t)w * args.rec_cap;
-    uint4 *out = (uint4 *)args.out;
-    for (uint32_t i = lane; i < f; i += 64)
-        if (o + i < args.cap) out[o + i] = region[i];
-    for (uint32_t i = lane; i < b; i += 64)
-        if (o + f + i < args.cap) out[o + f + i] = region[args.rec_cap - 1 - i];
+    const uint2 *aux = args.rec_aux + (uint64_t)w * args.rec_cap;
+    for (uint32_t i = lane; i < f + b; i += 64) {
+        const uint32_t slot = i < f ? i : args.rec_cap - 1 - (i - f);
+        const uint2 a = aux[slot]; /* {slice, ticket} */
+        args.order_tmp[args.slice_off[a.x] + a.y] = region[slot];
+    }
 }
 
-/* last kernel of a scan: every control word this scan used goes back to zero, so the
- * next scan on this scratch needs no memset in front of it */
-__global__ __launch_bounds__(256) void control_reset_kernel(HsgpuScanArgs args) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < 2 * args.rec_regions) args.rec_counts[i] = 0;
-    if (i == 0 && args.tstamp_next) {
-        args.tstamp[3] = wall_clock64(); /* end of this scan's pipeline (this is its last kernel) */
+/* normalized bitonic network (every comparator ascending) over n records at x, n <= P = a power of two;
+ * positions >= n stand for records greater than all: a comparator that touches one is a no-op. One workgroup. */
+template <class PTR>
+__device__ __forceinline__ void bitonic_sort(PTR x, uint32_t n) {
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t l = (j == (k >> 1)) ? i ^ (k - 1) : i ^ j;
+                if (l > i && l < n) {
+                    const uint4 a = x[i], b = x[l];
+                    if (rec_less(b, a)) x[i] = b, x[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void record_order_kernel(HsgpuScanArgs args) {
+    __shared__ uint4 buf[ORDER_LDS];
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+    const uint32_t complete = args.order_state[0], n_heavy = args.order_state[1];
+    uint4 *out = (uint4 *)args.out;
+    if (complete) {
+        const uint32_t total = args.slice_off[args.n_slices];
+        /* light slices: one lane per record, rank = records of its slice that sort before it */
+        for (uint32_t p = tid; p < total; p += nthreads) {
+            const uint4 r = args.order_tmp[p];
+            const uint32_t sl = slice_of(args, r);
+            const uint32_t a = args.slice_off[sl], b = args.slice_off[sl + 1];
+            if (b - a > ORDER_LIGHT) continue;
+            uint32_t rank = 0;
+            for (uint32_t q = a; q < b; q++) { /* equal keys cannot occur; if they did, tmp order keeps ranks distinct */
+                const uint4 o = args.order_tmp[q];
+                rank += (rec_less(o, r) || (q < p && !rec_less(r, o))) ? 1u : 0u;
+            }
+            out[a + rank] = r;
+        }
+        /* heavy slices: one workgroup each */
+        for (uint32_t hidx = blockIdx.x; hidx < n_heavy; hidx += gridDim.x) {
+            const uint32_t sl = args.heavy[hidx];
+            const uint32_t a = args.slice_off[sl], n = args.slice_off[sl + 1] - a;
+            if (n <= ORDER_LDS) {
+                for (uint32_t i = threadIdx.x; i < n; i += 256) buf[i] = args.order_tmp[a + i];
+                __syncthreads();
+                bitonic_sort(buf, n);
+                for (uint32_t i = threadIdx.x; i < n; i += 256) out[a + i] = buf[i];
+            } else {
+                __syncthreads();
+                bitonic_sort(args.order_tmp + a, n);
+                for (uint32_t i = threadIdx.x; i < n; i += 256) out[a + i] = args.order_tmp[a + i];
+            }
+            __syncthreads();
+        }
+    }
+    /* last kernel of a scan: every control word this scan used goes back to zero, so the next scan on
+     * this scratch needs no memset in front of it (nothing in this kernel reads them) */
+    uint32_t v = 0, o = 0;
+    for (uint32_t i = tid; i < args.ctl_words; i += nthreads) {
+        if (args.cand_counts && i >= args.cand_ofs && i <= args.cand_ofs + args.cand_waves) {
+            const uint32_t c = args.rec_counts[i];
+            if (i == args.cand_ofs + args.cand_waves) o = c;
+            else v += c;
+        }
+        args.rec_counts[i] = 0;
+    }
+    if (tid == 0 && args.tstamp_next) {
+        args.tstamp[3] = wall_clock64(); /* the scan's last kernel (its start: the stages before it are done) */
         args.tstamp_next[0] = ~0ull;
         args.tstamp_next[1] = 0;
         args.tstamp_next[2] = 0;
         args.tstamp_next[3] = 0;
     }
-
     /* cumulative statistics for hsgpu_scratch_get_stats: one atomic per wavefront */
-    uint32_t v = 0, o = 0;
-    if (args.cand_counts && i <= args.cand_waves) {
-        const uint32_t c = args.cand_counts[i];
-        args.cand_counts[i] = 0;
-        if (i == args.cand_waves) o = c;
-        else v = c;
-    }
     unsigned long long vs = v;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) vs += __shfl_xor(vs, d);

@@ -146,9 +146,13 @@ int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8
 /* Device-resident form (the hot path): corpus, offsets, records and counter all
  * live in HBM; asynchronous on `stream` (a hipStream_t passed as void*, NULL =
  * the scratch's own stream); no host synchronisation. d_off holds nblocks+1
- * ascending uint64 offsets with d_off[nblocks] == total_bytes. *d_count receives
- * the TOTAL number of matches (records beyond cap are
- * dropped, unsorted). d_corpus must be 16-byte aligned. */
+ * ascending uint64 offsets with d_off[nblocks] == total_bytes. The records arrive in delivery
+ * order, sorted by (block, end, lit) -- hwlmExec's non-decreasing `end` (src/hwlm/hwlm.h:101-118),
+ * block by block -- and *d_count receives the TOTAL number of matches. *d_count > cap means the
+ * buffer was too small and no record is delivered: scan again with room for *d_count records (the
+ * count is exact), or with twice the room when *d_count == cap + 1 (then the records would have
+ * fitted in total, but the staging area of one wavefront, sized from cap, was too small for a
+ * dense run of matches). cap < 2^32. d_corpus must be 16-byte aligned. */
 int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus,
                         uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t start,
                         void *d_out, uint64_t cap, void *d_count, void *stream);
@@ -172,11 +176,8 @@ int hsgpu_scratch_get_kernel_span(hsgpu_scratch_t *s, unsigned back, float *filt
  * candidate region (and were redone by the fused fallback kernel). */
 int hsgpu_scratch_get_stats(hsgpu_scratch_t *s, uint64_t *cand_entries, int *overflowed);
 
-/* Sort cap' = min(count, cap) device records in place by (block, end, lit). */
-int hsgpu_match_sort_dev(hsgpu_scratch_t *s, void *d_out, uint64_t n, void *stream);
-
-/* The same order for records already on the host (what hsgpu_hwlm_exec_batch applies before it
- * returns); multi-threaded above 64 Ki records. Touches no device. */
+/* The delivery order (block, end, lit) for records on the host, e.g. after merging the records of
+ * several scans; multi-threaded above 64 Ki records. Touches no device. */
 void hsgpu_match_sort_host(hsgpu_match_t *recs, size_t n);
 
 /* Replay sorted records of ONE block through a callback with the reference's

@@ -19,8 +19,9 @@ from tests.util import random_literals
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-F_A, F_B, F_C, F_REPL, F_K2, F_S2, F_BLIND, F_BFOLD = 1, 2, 4, 8, 16, 32, 64, 128
+F_A, F_B, F_C, F_REPL, F_K2, F_S2, F_BLIND, F_BFOLD, F_PAIR = 1, 2, 4, 8, 16, 32, 64, 128, 256
 FORCE_REPL, FORCE_HASHED, FORCE_K2, FORCE_K1, FORCE_S1, FORCE_BLIND, FORCE_S2, NO_FOLD = 1, 2, 4, 8, 16, 32, 64, 512
+FORCE_PAIR, KEY_M = 1024, 0x01000000
 MUL, HT_MUL = 0x9E3779, 0x9E3779B1
 
 
@@ -88,7 +89,7 @@ def parse(blob):
              "off_c2ref", "off_lists", "n_lists", "off_lits", "checksum"]
     h = dict(zip(names, f))
     fl = h["flags"]
-    nw = (32 << h["filter_log2"]) if fl & F_REPL else (1 << h["filter_log2"])
+    nw = (2 << h["filter_log2"]) if fl & F_PAIR else (32 << h["filter_log2"]) if fl & F_REPL else (1 << h["filter_log2"])
     h["filter"] = np.frombuffer(blob, "<u4", nw, h["off_filter"])
     h["c2bits"] = np.frombuffer(blob, "<u4", 2048, h["off_c2bits"])
     # 16-byte buckets of 4 tagged slots: DIRECT(31) | delta(30) | tag6(29..24) | index24
@@ -221,6 +222,88 @@ def test_few_three_byte_keys_fold_into_the_four_byte_test():
     # many 3-byte keys: folding would flood the filter, so it is not chosen
     many = random_literals(rng, 400, 4, 8, nocase_frac=0) + random_literals(rng, 2000, 3, 3, nocase_frac=0)
     assert not H.hwlm_build(many, FORCE_HASHED).info()["flags"] & F_BFOLD
+
+
+def check_pair_table_covers(lits, flags=FORCE_PAIR):
+    """The pair filter (csrc/table.h, HSGPU_F_PAIR): for every literal, in both parities of its end offset
+    and every case variant, the lookup that is responsible for it passes the filter rule (evaluated by
+    tests/pair_model.py on the serialised table) and reaches the literal through the exact tables -- the
+    4-byte table, the 3-byte table, or the 3-byte table under a late key (HSGPU_KEY_M)."""
+    from tests import pair_model as pm
+
+    t = H.hwlm_build(lits, flags)
+    blob = t.serialize()
+    h = parse(blob)
+    fl = h["flags"]
+    assert fl & F_PAIR and fl & F_S2 and not fl & (F_REPL | F_K2 | F_C | F_BFOLD)
+    key_mask = 0xDFDFDFDF if fl & F_BLIND else 0xFFFFFFFF
+    gate = h["c2bits"]
+    rng = np.random.default_rng(6)
+    n_late = 0
+    for li, lit in enumerate(lits):
+        for variant in range(4):
+            s = bytearray(lit.s)
+            if lit.nocase:
+                for i, c in enumerate(s):
+                    if chr(c).isalpha() and c < 128 and (variant >> (i & 1)) & 1:
+                        s[i] = c ^ 0x20
+            for parity in (0, 1):
+                pre = 8 + ((8 + len(s) - 1 - parity) & 1)  # the literal ends at an offset of this parity
+                buf = np.concatenate([rng.integers(0, 256, pre, dtype=np.uint8), np.frombuffer(bytes(s), dtype=np.uint8),
+                                      rng.integers(0, 256, 6, dtype=np.uint8)])
+                e = pre + len(s) - 1
+                assert e & 1 == parity
+                cand, _ = pm.candidates(blob, buf)
+                w = lambda q: int(buf[q - 3]) | int(buf[q - 2]) << 8 | int(buf[q - 1]) << 16 | int(buf[q]) << 24
+
+                def reaches(q, delta):
+                    """lookup q passes the filter and the exact tables lead to (li, delta)"""
+                    if not cand[q // 2]:
+                        return False
+                    w4 = w(q) & key_mask
+                    if delta >= 0:
+                        want = li | delta << 30
+                        ents = ht_lookup(h, h["ht_a"], h["ht_a_log2"], w4) if fl & F_A else None
+                        if ents and want in ents:
+                            return True
+                        kb = w4 >> 8
+                    else:
+                        want = li
+                        kb = ((w(q - 1) & key_mask) >> 8) | KEY_M
+                    g = ((kb * HT_MUL) & 0xFFFFFFFF) >> 16
+                    if not gate[g >> 5] >> (g & 31) & 1:
+                        return False
+                    ents = ht_lookup(h, h["ht_b"], h["ht_b_log2"], kb)
+                    return bool(ents) and want in ents
+
+                if parity == 0:
+                    assert reaches(e, 0), (lit, variant)
+                else:
+                    late = reaches(e + 1, -1)
+                    n_late += late
+                    assert reaches(e - 1, 1) or late, (lit, variant)
+    return h, n_late
+
+
+def test_pair_table_covers_every_literal():
+    rng = np.random.default_rng(21)
+    lits = random_literals(rng, 400, 3, 8, nocase_frac=0.4)
+    h, n_late = check_pair_table_covers(lits)
+    n3 = sum(len(l.s) == 3 for l in lits)
+    assert n3 and n_late >= 4 * n3  # 3-byte literals are keyed one byte late at odd ends
+    assert struct.unpack_from("<2I", H.hwlm_build(lits, FORCE_PAIR).serialize(), 88)[1] == n3
+    # literals of 4 to 8 bytes only: nothing is keyed late, every byte of b0 enters the hash
+    h2, n_late2 = check_pair_table_covers(random_literals(rng, 300, 4, 8, nocase_frac=0))
+    assert n_late2 == 0 and not h2["flags"] & F_BLIND
+    # msk / cmp literals, wildcards in front of and inside the string
+    extra = [H.HwlmLiteral("bcd", False, 900, msk=b"\xf0\xff\xff\xff", cmp=b"\x30bcd"),
+             H.HwlmLiteral("wxyz", True, 901, msk=b"\xff\x00\x00\x00\x00", cmp=b"Q\x00\x00\x00\x00"),
+             H.HwlmLiteral("klm", False, 902, msk=b"\xdf\x00\xff\xff\xff", cmp=b"A\x00klm")]
+    t = H.hwlm_build(random_literals(rng, 50, 3, 8) + extra, FORCE_PAIR)
+    assert t.info()["flags"] & F_PAIR
+    # a set the pair filter cannot hold (a 1-byte literal needs 2^14 entries): refused, like a bad engine hint
+    with pytest.raises(H.HsgpuError):
+        H.hwlm_build([H.HwlmLiteral("a", False, 1), H.HwlmLiteral("abcd", False, 2)], FORCE_PAIR)
 
 
 def test_table_modes_auto():

@@ -122,9 +122,12 @@ int main(int argc, char **argv) {
     const int ncu = prop.multiProcessorCount;
     for (auto &v : vs) CHECK(hipFuncSetAttribute((const void *)v.f, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     struct Geo { int threads, per_cu; size_t lds; } geos[] = {{1024, 1, 131072}, {512, 1, 131072}, {512, 2, 65536 + 8192}, {256, 4, 32768 + 4096}};
+    const bool one = argc > 1 && !strcmp(argv[1], "one");
     for (auto &g : geos) {
+        if (one && g.threads != 1024) continue;
         printf("---- %d threads x %d per CU, %zu B LDS each\n", g.threads, g.per_cu, g.lds);
         for (auto &v : vs) {
+            if (one && strcmp(v.name, "stages=8 aux=0 mode=1 early=false")) continue;
             ExpArgs a;
             a.corpus = d_corpus; a.total = total; a.table = d_table; a.hits = d_hits;
             a.super_shift = g.threads == 1024 ? 14 : g.threads == 512 ? 13 : 12;
