@@ -73,8 +73,8 @@ struct hsgpu_scratch {
     uint64_t n_timed = 0;       /* scans launched with timing on */
     DevBuf tstamp;              /* [kRing][4] device wall clock: filter start (min) / end (max), confirm-stage end, pipeline end */
     double wall_clock_khz = 100000.0;
-    DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, rec_aux, order, order_tmp, stats;
-    bool ctl_clean = false;                /* every control word is zero (left so by record_order_kernel) */
+    DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, order, stats;
+    bool ctl_clean = false;                /* every control word is zero (left so by record_sort_kernel) */
     unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
     int n_cu = 0;
@@ -163,14 +163,12 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->out.release();
     s->count.release();
     s->order.release();
-    s->order_tmp.release();
     s->hint.release();
     s->cand.release();
     s->ctl.release();
     s->stats.release();
     s->tstamp.release();
     s->rec_stage.release();
-    s->rec_aux.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
     for (int r = 0; r < hsgpu_scratch::kRing; r++)
         for (int i = 0; i < 4; i++)
@@ -322,7 +320,6 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)s->n_cu * wg_per_cu);
 
     HsgpuScanArgs args = a;
-    args.super_shift = super_shift;
     args.t_flags = h->flags;
     args.fold_shift = (h->flags & (HSGPU_F_BFOLD | HSGPU_F_PAIR)) ? 16u : 0u; /* one filter test stands for every key class */
     args.t_hash_mask = h->hash_mask;
@@ -362,44 +359,26 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.rec_regions = n_rec;
     args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
     if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
-    if ((rv = s->rec_aux.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint2))) != HSGPU_SUCCESS) return rv;
-    args.rec_aux = (uint2 *)s->rec_aux.p;
-    /* ordered output: records are counted per corpus slice; at most 2^18 slices of at least 4 KiB */
-    uint32_t slice_shift = 12;
-    while (((a.total - 1) >> slice_shift) >= (1u << 18)) slice_shift++;
-    const uint32_t n_slices = (uint32_t)((a.total - 1) >> slice_shift) + 1;
-    /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1] | slice_cnt | super_cnt | order_ctl, each
-     * part 16-byte aligned, 16 bytes of padding at the end (record_scan reads slice_cnt four words at a time) */
-    auto up4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
-    const size_t cand_ofs = up4((size_t)2 * n_rec), slice_ofs = cand_ofs + up4((size_t)n_waves + 1);
-    const uint32_t n_super = (n_slices + (1u << HSGPU_SUPER_SHIFT) - 1) >> HSGPU_SUPER_SHIFT;
-    const size_t super_ofs = slice_ofs + up4(n_slices), ctl_words = super_ofs + up4(n_super) + 8;
+    /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1] */
+    const size_t cand_ofs = (size_t)2 * n_rec, ctl_words = cand_ofs + n_waves + 1;
     /* a reallocated control block is garbage whatever its address: hipMalloc may hand the
      * freed range straight back, so growth is detected by capacity, never by pointer */
     const size_t ctl_cap_before = s->ctl.cap;
     if ((rv = s->ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
     if (s->ctl.cap != ctl_cap_before) s->ctl_clean = false;
-    /* slice_off[n_slices + 1] | heavy[n_slices] | order_state[4], and the scatter target */
-    if ((rv = s->order.ensure(((size_t)2 * n_slices + 8) * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
-    if ((rv = s->order_tmp.ensure(std::max<uint64_t>(a.cap, 1) * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
+    /* rec_offsets[n_rec + 1] | order_state */
+    if ((rv = s->order.ensure(((size_t)n_rec + 2) * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
     args.rec_stage = (uint4 *)s->rec_stage.p;
     args.rec_counts = (uint32_t *)s->ctl.p;
-    args.ctl_words = (uint32_t)ctl_words;
-    args.cand_ofs = (uint32_t)cand_ofs;
-    args.slice_shift = slice_shift;
-    args.n_slices = n_slices;
-    args.slice_cnt = (uint32_t *)s->ctl.p + slice_ofs;
-    args.slice_off = (uint32_t *)s->order.p;
-    args.heavy = args.slice_off + n_slices + 1;
-    args.order_state = args.heavy + n_slices;
-    args.super_cnt = (uint32_t *)s->ctl.p + super_ofs;
-    args.order_ctl = args.super_cnt + up4(n_super);
-    args.order_tmp = (uint4 *)s->order_tmp.p;
+    args.rec_offsets = (unsigned long long *)s->order.p;
+    args.order_state = (uint32_t *)(args.rec_offsets + n_rec + 1);
+    /* the regions fed by one filter wavefront: the records of one contiguous share of the corpus */
+    args.group_regions = HSGPU_CONFIRM_SPLIT;
     args.stats = (unsigned long long *)s->stats.p;
     /* the control words are left zeroed by the previous scan's last kernel; only a
      * fresh (or possibly dirty) buffer needs a memset */
     if (!s->ctl_clean) HIP_TRY(hipMemsetAsync(s->ctl.p, 0, s->ctl.cap, stream));
-    s->ctl_clean = false; /* until this scan's record_order_kernel has been queued */
+    s->ctl_clean = false; /* until this scan's record_sort_kernel has been queued */
 
     void *kargs[] = {&args};
     args.tstamp = nullptr;
@@ -440,11 +419,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
     }
-    HIP_TRY(hipLaunchKernel(hsgpu_record_offsets_kernel(), dim3(n_super), dim3(256), kargs, 0, stream));
-    HIP_TRY(hipLaunchKernel(hsgpu_record_scatter_kernel(), dim3((n_rec + 3) / 4), dim3(256), kargs, 0, stream));
+    HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
     if (s->timing) s->n_timed++;
-    /* ranks inside the slices, heavy slices, and the control block back to zero */
-    HIP_TRY(hipLaunchKernel(hsgpu_record_order_kernel(), dim3((unsigned)s->n_cu * 4), dim3(256), kargs, 0, stream));
+    /* one (single-wavefront) workgroup per share of the corpus: its records sorted into place; the control block back to zero */
+    HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions), dim3(64),
+                            kargs, 0, stream));
     s->ctl_clean = true;
     return HSGPU_SUCCESS;
 }

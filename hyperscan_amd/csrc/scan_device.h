@@ -132,12 +132,8 @@ struct Tables {
     uint32_t key_mask;    /* 0xdfdfdfdf when the exact-table keys are case-blind, else all ones */
     const uint32_t *hint; /* block containing byte t << HSGPU_HINT_SHIFT, t < n_hint */
     uint64_t n_hint;
-    uint32_t *slice_cnt;  /* records per corpus slice (1 << slice_shift bytes): the key of the ordered output */
-    uint32_t *super_cnt;  /* the same per group of 256 slices */
-    uint32_t slice_shift;
     WaveLds *wl;       /* this wavefront's LDS area */
     uint4 *rec_region; /* this wavefront's private region of the staged-record buffer */
-    uint2 *aux_region; /* beside it: {corpus slice, ticket inside the slice} of each staged record */
     uint32_t rec_cap;  /* its capacity in records */
 };
 
@@ -195,26 +191,16 @@ __device__ __forceinline__ uint64_t block_of(const Tables &t, uint64_t g, uint64
  * which would cap the whole scan at a few tens of thousands of matches per ms.
  * Staged records are appended to the wavefront's private HBM region at
  * convergent points (flush_records); a compaction pass packs the regions. */
-/* The ordered output is a counting sort by corpus slice (record_offsets / record_scatter) followed by an
- * ordering pass inside each slice (record_order). A staged record carries its slice beside it; its ticket
- * inside the slice is drawn when the wavefront is done (take_tickets): atomics inside the confirm loop sat in
- * front of every later wait for a load. */
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) { /* set bits below this lane */
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
-__device__ __forceinline__ uint32_t slice_of_rec(const Tables &t, const uint4 rec) {
-    return (uint32_t)((t.off[rec.x] + rec.y) >> t.slice_shift);
-}
-__device__ __forceinline__ void stage_record(const Tables &t, const uint4 rec, uint64_t ge) {
+__device__ __forceinline__ void stage_record(const Tables &t, const uint4 rec) {
     const uint32_t s = __hip_atomic_fetch_add(&t.wl->nrec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (s < OCAP) {
         t.wl->rec[s] = rec;
     } else { /* staging full inside one drain: spill to the back of the region */
         const uint32_t k = __hip_atomic_fetch_add(&t.wl->nback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (k < t.rec_cap) {
-            t.rec_region[t.rec_cap - 1 - k] = rec;
-            t.aux_region[t.rec_cap - 1 - k] = make_uint2((uint32_t)(ge >> t.slice_shift), 0);
-        }
+        if (k < t.rec_cap) t.rec_region[t.rec_cap - 1 - k] = rec;
     }
 }
 
@@ -228,7 +214,7 @@ __device__ __forceinline__ void resolve_match(const Tables &t, uint64_t ge, uint
     const uint64_t b = block_of(t, ge, bstart);
     const uint64_t end = ge - bstart;
     if (end + 1 < size || end + 1 - size < t.start) return;
-    stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, li), ge);
+    stage_record(t, make_uint4((uint32_t)b, (uint32_t)end, id, li));
 }
 
 /* Confirm kernel: queue the match in the wavefront's LDS match queue (wl->cand,
@@ -264,11 +250,7 @@ __device__ __forceinline__ void flush_records(const Tables &t, uint32_t lane, ui
     if (n < threshold) return;
     if (n > OCAP) n = OCAP;
     const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
-    if (lane < n && f + lane < t.rec_cap) {
-        const uint4 rec = t.wl->rec[lane];
-        t.rec_region[f + lane] = rec;
-        t.aux_region[f + lane] = make_uint2(slice_of_rec(t, rec), 0);
-    }
+    if (lane < n && f + lane < t.rec_cap) t.rec_region[f + lane] = t.wl->rec[lane];
     if (lane == 0) {
         t.wl->nfront = f + n; /* keeps counting past the capacity: the total stays exact */
         __hip_atomic_store(&t.wl->nrec, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -279,20 +261,6 @@ __device__ __forceinline__ void flush_records(const Tables &t, uint32_t lane, ui
 __device__ __forceinline__ void publish_records(const Tables &t, const HsgpuScanArgs &args, uint32_t lane,
                                                 uint32_t region) {
     flush_records(t, lane, 1);
-    {   /* tickets: every staged record counts itself into its slice (and the slice's group). The slices were
-         * stored by other lanes of this wavefront a moment ago: their stores must have landed first. */
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        const uint32_t nf = min(__builtin_amdgcn_readfirstlane(t.wl->nfront), t.rec_cap);
-        const uint32_t nb = min(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&t.wl->nback, __ATOMIC_RELAXED,
-                                                                                    __HIP_MEMORY_SCOPE_WAVEFRONT)),
-                                t.rec_cap);
-        for (uint32_t i = lane; i < nf + nb; i += 64) {
-            const uint32_t slot = i < nf ? i : t.rec_cap - 1 - (i - nf);
-            const uint32_t sl = __hip_atomic_load(&t.aux_region[slot].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t.aux_region[slot].y = __hip_atomic_fetch_add(&t.slice_cnt[sl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_add(&t.super_cnt[sl >> HSGPU_SUPER_SHIFT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if (lane == 0) {
         args.rec_counts[2 * region] = t.wl->nfront;
         args.rec_counts[2 * region + 1] =
@@ -555,10 +523,7 @@ __device__ __forceinline__ void drain_matches(const Tables &t, uint32_t lane, ui
         const uint64_t mask = __ballot(ok);
         const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
         const uint32_t at = f + lane_rank(mask);
-        if (ok && at < t.rec_cap) {
-            t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
-            t.aux_region[at] = make_uint2((uint32_t)(ge >> t.slice_shift), 0);
-        }
+        if (ok && at < t.rec_cap) t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
         if (lane == 0) t.wl->nfront = f + (uint32_t)__popcll(mask);
     }
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -810,12 +775,8 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.key_mask = (args.t_flags & HSGPU_F_BLIND) ? 0xdfdfdfdfu : 0xffffffffu;
     t.hint = args.hint;
     t.n_hint = args.n_hint;
-    t.slice_cnt = args.slice_cnt;
-    t.super_cnt = args.super_cnt;
-    t.slice_shift = args.slice_shift;
     t.wl = nullptr;
     t.rec_region = nullptr;
-    t.aux_region = nullptr;
     t.rec_cap = 0;
 }
 
@@ -906,26 +867,31 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t WAVES = blockDim.x >> 6;           /* 16 or 8 */
-    const uint32_t super_shift = args.super_shift;   /* log2(WAVES * 1 KiB): 14 or 13 */
     const uint32_t n_waves = gridDim.x * WAVES;
     const uint32_t wave_global = blockIdx.x * WAVES + wave;
 
     const uint8_t *corpus = args.corpus;
     const uint64_t total = args.total;
-    const uint64_t n_full = total >> super_shift; /* super-tiles with every load in bounds */
-    const uint32_t G = gridDim.x;
-    const uint32_t lane_off = wave * WAVE_TILE + lane * CHUNK;
+    /* Every wavefront streams ONE contiguous share of the corpus, 1 KiB tiles [tile, tile_end): measured
+     * 8-20% faster than all workgroups walking the corpus together (tile = blockIdx + k * grid), and the
+     * records found in a wavefront's candidates are then the records of one corpus range: delivery order
+     * costs one small sort per share instead of a global one (phase 3). */
+    const uint64_t n_full = total >> 10; /* 1 KiB tiles with every load in bounds */
+    const uint64_t per_wave = (n_full + n_waves - 1) / n_waves;
+    uint64_t tile = min(n_full, (uint64_t)wave_global * per_wave);
+    const uint64_t tile_end = min(n_full, tile + per_wave);
+    const uint32_t lane_off = lane * CHUNK;
 
     /* Loads of one tile through a buffer descriptor built from wave-uniform values only
      * (scalar registers): the lane offset is a 32-bit voffset, so a stage costs no vector
      * address arithmetic at all, nothing branches, and the compiler keeps the loads in
      * flight across iterations with counted s_waitcnt. The descriptor starts 8 bytes in
      * front of the tile (halo at voffset, chunk at voffset + 8 via soffset); a tile past
-     * the last full one gets an empty descriptor: its loads return zeros and touch no
-     * memory, which replaces every bounds check. */
+     * the end of the wavefront's share gets an empty descriptor: its loads return zeros and
+     * touch no memory, which replaces every bounds check. */
     auto issue = [&](uint64_t tile) -> Chunk {
-        const uint8_t *base = corpus + (tile << super_shift) - 8;
-        const int records = tile < n_full ? (int)0x7ffffff0 : 0;
+        const uint8_t *base = corpus + (tile << 10) - 8;
+        const int records = tile < tile_end ? (int)0x7ffffff0 : 0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, records, 0x00020000);
         Chunk c;
         const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 8, HSGPU_LOAD_AUX);
@@ -950,18 +916,17 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
     /* The first tiles are requested before anything else: the corpus stream starts while the filter image
      * is copied into LDS and the block hints are written (with both in front, the memory pipeline idled
      * for the first 25-30 us of every scan). */
-    const bool streaming = n_full && blockIdx.x < n_full;
-    uint64_t tile = blockIdx.x;
+    const bool streaming = tile < tile_end;
     Chunk c0, c1, c2, c3, c4, c5, c6, c7;
     c0.d = c1.d = c2.d = c3.d = c4.d = c5.d = c6.d = c7.d = make_uint4(0, 0, 0, 0);
     c0.h = c1.h = c2.h = c3.h = c4.h = c5.h = c6.h = c7.h = make_uint2(0, 0);
     if (streaming) {
-        c0 = issue_first(tile), c1 = issue(tile + G), c2 = issue(tile + 2ull * G);
+        c0 = issue_first(tile), c1 = issue(tile + 1), c2 = issue(tile + 2);
 #if HSGPU_STAGES >= 6
-        c3 = issue(tile + 3ull * G), c4 = issue(tile + 4ull * G);
+        c3 = issue(tile + 3), c4 = issue(tile + 4);
 #endif
 #if HSGPU_STAGES >= 8
-        c5 = issue(tile + 5ull * G), c6 = issue(tile + 6ull * G);
+        c5 = issue(tile + 5), c6 = issue(tile + 6);
 #endif
     }
 
@@ -992,7 +957,6 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         init_tables(t, args);
         init_wave_lds(t, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)) + wave, lane);
         t.rec_region = args.rec_stage + (uint64_t)wave_global * args.rec_cap;
-        t.aux_region = args.rec_aux + (uint64_t)wave_global * args.rec_cap;
         t.rec_cap = args.rec_cap;
     } else {
         sp.region = args.cand + 2ull * wave_global * args.cand_cap;
@@ -1020,11 +984,11 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
          * the only wait is for the stage about to be filtered. */
 #define HSGPU_STAGE(CUR, NEW)                                            \
     {                                                                    \
-        NEW = issue(tile + (uint64_t)(HSGPU_STAGES - 1) * G);            \
-        const uint64_t coff = (tile << super_shift) + lane_off;           \
+        NEW = issue(tile + (HSGPU_STAGES - 1));                          \
+        const uint64_t coff = (tile << 10) + lane_off;                    \
         HSGPU_HANDLE(CUR, coff)                                          \
-        tile += G;                                                       \
-        if (tile >= n_full) break;                                       \
+        tile += 1;                                                       \
+        if (tile >= tile_end) break;                                     \
     }
 #if HSGPU_STAGES == 8
         for (;;) {
@@ -1057,11 +1021,11 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
 #undef HSGPU_STAGE
     }
 
-    /* the partial last super-tile: guarded, byte-wise where needed; one workgroup.
-     * Bytes at/after the end of the corpus read as zero and their lookup
-     * positions are masked off. */
-    if ((total & ((1ull << super_shift) - 1)) && blockIdx.x == n_full % G) {
-        const uint64_t coff = (n_full << super_shift) + lane_off;
+    /* the partial last tile: guarded, byte-wise where needed; the wavefront whose share would hold tile n_full
+     * (the last one when the shares come out even). Bytes at/after the end of the corpus read as zero and
+     * their lookup positions are masked off. */
+    if ((total & 1023) && wave_global == (per_wave ? min((uint64_t)n_waves - 1, n_full / per_wave) : 0)) {
+        const uint64_t coff = (n_full << 10) + lane_off;
         Chunk c;
         c.d = make_uint4(0, 0, 0, 0);
         c.h = make_uint2(0, 0);
@@ -1118,7 +1082,6 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     init_tables(t, args);
     init_wave_lds(t, wave_lds + wave, lane);
     t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
-    t.aux_region = args.rec_aux + (uint64_t)cw * args.rec_cap;
     t.rec_cap = args.rec_cap;
     const uint4 *region = args.cand + 2ull * r * args.cand_cap;
     uint2 *rq = rest_q[wave];
@@ -1158,17 +1121,17 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
 /* ---- phase 3: the records in delivery order ---------------------------------------------------
  * hwlmExec delivers callbacks in non-decreasing `end` (src/hwlm/hwlm.h:101-118) and Rose relies on it
  * (src/rose/match.c:396-476); a batch delivers block by block. The output of a scan is therefore sorted by
- * (block, end, literal index), which is also the order of the corpus position g = off[block] + end. The
- * producing wavefronts have drawn a ticket per record in its corpus slice (publish_records):
- *   record_offsets  exclusive scan of the slice counts (one workgroup per 256 slices, on top of the counts
- *                   per group), the list of slices with more than ORDER_LIGHT records, region overflow check
- *   record_scatter  *count; every staged record to tmp[slice_off[slice] + ticket] (a counting sort by slice)
- *   record_order    each record of a light slice finds its rank inside the slice by counting (slices hold
- *                   a handful of records); heavy slices are sorted by a workgroup each (bitonic network in
- *                   LDS up to ORDER_LDS records, in place in global memory beyond); then every control word
- *                   goes back to zero for the next scan. */
-constexpr uint32_t ORDER_LIGHT = 64;  /* largest slice ranked by counting */
-constexpr uint32_t ORDER_LDS = 2048;  /* largest slice sorted in LDS */
+ * (block, end, literal index). Every filter wavefront streams ONE contiguous share of the corpus (see the
+ * tile loop), so the staging regions fed from its candidates -- consecutive region numbers -- hold exactly
+ * the records of that share, and the shares follow each other in region order:
+ *   record_scan  one workgroup: exclusive scan of the region fills (where each region's records go in the
+ *                output), *count, "is the output complete"
+ *   record_sort  one workgroup per share: gathers the records of its regions, sorts them (bitonic network in
+ *                LDS up to SORT_LDS records, in place in the output beyond) and writes them to their place;
+ *                then every control word goes back to zero for the next scan.
+ * No global atomics and no global sort: a share holds a few thousand records at most on ordinary input. */
+constexpr uint32_t SORT_LDS = 1024; /* largest share sorted in LDS (16 KiB of records) */
+constexpr uint32_t SORT_THREADS = 64;
 
 __device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (block, end, literal index) */
     if (a.x != b.x) return a.x < b.x;
@@ -1176,107 +1139,73 @@ __device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (blo
     return a.w < b.w;
 }
 
-/* One workgroup per group of 256 slices ("super-slice"): the records before the group from the per-group
- * counts (every workgroup sums the at most 1024 of them itself: 4 KiB out of L2, no workgroup waits for
- * another), an exclusive scan of its own 256 slice counts behind that, the heavy slices appended to their
- * list; the workgroups also share out the check "did a staging region run out of space?". */
-__global__ __launch_bounds__(256) void record_offsets_kernel(HsgpuScanArgs args) {
-    __shared__ unsigned long long red[2][4];
-    __shared__ uint32_t wsum[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, sg = blockIdx.x;
-    const uint32_t n_super = gridDim.x;
-    /* records in the groups before this one, and in all of them */
-    unsigned long long before = 0, all = 0;
-    for (uint32_t i = tid; i < n_super; i += 256) {
-        const uint32_t c = args.super_cnt[i];
-        all += c;
-        if (i < sg) before += c;
+/* one workgroup: exclusive scan of the region fills IN REGION ORDER (thread t owns the run of regions
+ * [t * per, (t + 1) * per)), the total into *count */
+__global__ __launch_bounds__(1024) void record_scan_kernel(HsgpuScanArgs args) {
+    __shared__ unsigned long long part[32];
+    __shared__ uint32_t any_overflow;
+    const uint32_t n = args.rec_regions, tid = threadIdx.x;
+    const uint2 *counts = (const uint2 *)args.rec_counts;
+    if (tid == 0) any_overflow = 0;
+    __syncthreads();
+    const uint32_t per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
+    unsigned long long sum = 0;
+    bool ovf = false;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint2 c = counts[i];
+        ovf |= (unsigned long long)c.x + c.y > args.rec_cap;
+        sum += (unsigned long long)c.x + c.y;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d), all += __shfl_xor(all, d);
-    if (lane == 0) red[0][wv] = before, red[1][wv] = all;
-    /* this group's slices */
-    const uint32_t sl = sg * 256 + tid;
-    const uint32_t c = sl < args.n_slices ? args.slice_cnt[sl] : 0;
-    uint32_t incl = c;
+    if (ovf) any_overflow = 1;
+    /* inclusive scan of the 1024 per-thread sums: shuffles inside each wavefront,
+     * then the 16 wavefront totals, two barriers in all */
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    unsigned long long incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t v = __shfl_up(incl, d);
+        const unsigned long long v = __shfl_up(incl, d);
         if (lane >= (uint32_t)d) incl += v;
     }
-    if (lane == 63) wsum[wv] = incl;
+    if (lane == 63) part[wv] = incl;
     __syncthreads();
-    before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    uint32_t wbefore = 0;
-    for (uint32_t w = 0; w < wv; w++) wbefore += wsum[w];
-    if (sl < args.n_slices) {
-        args.slice_off[sl] = (uint32_t)before + wbefore + incl - c;
-        if (c > ORDER_LIGHT) args.heavy[atomicAdd(&args.order_ctl[0], 1u)] = sl;
-    }
-    if (sg == 0 && tid == 0) {
-        args.slice_off[args.n_slices] = (uint32_t)all;
-    }
-    /* staging regions: a region that ran out of space lost records (its fill counters kept counting, so
-     * the total stays exact) */
-    const uint32_t n = args.rec_regions, per = (n + n_super - 1) / n_super;
-    const uint2 *counts = (const uint2 *)args.rec_counts;
-    bool ovf = false;
-    unsigned long long found = 0; /* the exact number of matches, delivered or not */
-    for (uint32_t i = sg * per + tid; i < min(n, (sg + 1) * per); i += 256) {
-        const uint2 rc = counts[i];
-        ovf |= (unsigned long long)rc.x + rc.y > args.rec_cap;
-        found += (unsigned long long)rc.x + rc.y;
-    }
+    if (wv == 0) {
+        unsigned long long w = lane < 16 ? part[lane] : 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d);
-    const bool any_ovf = __ballot(ovf) != 0;
-    if (lane == 0) {
-        if (any_ovf) atomicOr(&args.order_ctl[1], 1u);
-        if (found) atomicAdd((unsigned long long *)(args.order_ctl + 2), found);
+        for (int d = 1; d < 16; d <<= 1) {
+            const unsigned long long v = __shfl_up(w, d);
+            if (lane >= (uint32_t)d) w += v;
+        }
+        if (lane < 16) part[16 + lane] = w; /* inclusive totals of wavefronts 0..lane */
+    }
+    __syncthreads();
+    const unsigned long long before_wave = wv ? part[16 + wv - 1] : 0;
+    unsigned long long run = before_wave + incl - sum; /* exclusive prefix of this thread */
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint2 c = counts[i];
+        args.rec_offsets[i] = run;
+        run += (unsigned long long)c.x + c.y;
+    }
+    if (tid == 1023) {
+        const unsigned long long total = before_wave + incl;
+        args.rec_offsets[n] = total;
+        /* a region that ran out of space lost records; its fill counters kept
+         * counting, so the total is still exact: report it, but never a value
+         * <= cap (that would claim the output is complete) */
+        *args.count = (any_overflow && total <= args.cap) ? args.cap + 1 : total;
+        args.order_state[0] = (!any_overflow && total <= args.cap) ? 1u : 0u; /* the output is complete */
     }
 }
 
-/* the slice a staged record belongs to: one read of the block's offset */
-__device__ __forceinline__ uint32_t slice_of(const HsgpuScanArgs &args, const uint4 r) {
-    return (uint32_t)((args.off[r.x] + r.y) >> args.slice_shift);
-}
-
-/* wavefront w moves the records of region w to their places in their slices */
-__global__ __launch_bounds__(256) void record_scatter_kernel(HsgpuScanArgs args) {
-    /* the output is complete only when no region overflowed and everything fits the caller's buffer;
-     * otherwise the count says how much room a second scan needs and no record is delivered */
-    const unsigned long long total = *(const unsigned long long *)(args.order_ctl + 2);
-    const bool ovf = args.order_ctl[1] != 0, complete = !ovf && total <= args.cap;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *args.count = (ovf && total <= args.cap) ? args.cap + 1 : total;
-        args.order_state[0] = complete ? 1u : 0u; /* for record_order, which zeroes the control words it came from */
-        args.order_state[1] = complete ? args.order_ctl[0] : 0u;
-    }
-    if (!complete) return;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= args.rec_regions) return;
-    const uint32_t f = args.rec_counts[2 * w], b = args.rec_counts[2 * w + 1];
-    const uint4 *region = args.rec_stage + (uint64_t)w * args.rec_cap;
-    const uint2 *aux = args.rec_aux + (uint64_t)w * args.rec_cap;
-    for (uint32_t i = lane; i < f + b; i += 64) {
-        const uint32_t slot = i < f ? i : args.rec_cap - 1 - (i - f);
-        const uint2 a = aux[slot]; /* {slice, ticket} */
-        args.order_tmp[args.slice_off[a.x] + a.y] = region[slot];
-    }
-}
-
-/* normalized bitonic network (every comparator ascending) over n records at x, n <= P = a power of two;
- * positions >= n stand for records greater than all: a comparator that touches one is a no-op. One workgroup. */
+/* normalized bitonic network (every comparator ascending) over n records at x; positions from n up to the
+ * next power of two stand for records greater than all: a comparator that touches one is a no-op. One workgroup. */
 template <class PTR>
 __device__ __forceinline__ void bitonic_sort(PTR x, uint32_t n) {
-    uint32_t P = 2;
+    uint64_t P = 2;
     while (P < n) P <<= 1;
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+    for (uint64_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = (uint32_t)(k >> 1); j > 0; j >>= 1) {
             for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-                const uint32_t l = (j == (k >> 1)) ? i ^ (k - 1) : i ^ j;
+                const uint32_t l = (j == (uint32_t)(k >> 1)) ? i ^ (uint32_t)(k - 1) : i ^ j;
                 if (l > i && l < n) {
                     const uint4 a = x[i], b = x[l];
                     if (rec_less(b, a)) x[i] = b, x[l] = a;
@@ -1287,55 +1216,54 @@ __device__ __forceinline__ void bitonic_sort(PTR x, uint32_t n) {
     }
 }
 
-__global__ __launch_bounds__(256) void record_order_kernel(HsgpuScanArgs args) {
-    __shared__ uint4 buf[ORDER_LDS];
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
-    const uint32_t complete = args.order_state[0], n_heavy = args.order_state[1];
+__global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs args) {
+    __shared__ uint4 buf[SORT_LDS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint4 *out = (uint4 *)args.out;
-    if (complete) {
-        const uint32_t total = args.slice_off[args.n_slices];
-        /* light slices: one lane per record, rank = records of its slice that sort before it */
-        for (uint32_t p = tid; p < total; p += nthreads) {
-            const uint4 r = args.order_tmp[p];
-            const uint32_t sl = slice_of(args, r);
-            const uint32_t a = args.slice_off[sl], b = args.slice_off[sl + 1];
-            if (b - a > ORDER_LIGHT) continue;
-            uint32_t rank = 0;
-            for (uint32_t q = a; q < b; q++) { /* equal keys cannot occur; if they did, tmp order keeps ranks distinct */
-                const uint4 o = args.order_tmp[q];
-                rank += (rec_less(o, r) || (q < p && !rec_less(r, o))) ? 1u : 0u;
-            }
-            out[a + rank] = r;
-        }
-        /* heavy slices: one workgroup each */
-        for (uint32_t hidx = blockIdx.x; hidx < n_heavy; hidx += gridDim.x) {
-            const uint32_t sl = args.heavy[hidx];
-            const uint32_t a = args.slice_off[sl], n = args.slice_off[sl + 1] - a;
-            if (n <= ORDER_LDS) {
-                for (uint32_t i = threadIdx.x; i < n; i += 256) buf[i] = args.order_tmp[a + i];
-                __syncthreads();
-                bitonic_sort(buf, n);
-                for (uint32_t i = threadIdx.x; i < n; i += 256) out[a + i] = buf[i];
-            } else {
-                __syncthreads();
-                bitonic_sort(args.order_tmp + a, n);
-                for (uint32_t i = threadIdx.x; i < n; i += 256) out[a + i] = args.order_tmp[a + i];
+    if (args.order_state[0]) {
+        const uint32_t first = blockIdx.x * args.group_regions, last = min(args.rec_regions, first + args.group_regions);
+        const unsigned long long base = args.rec_offsets[first];
+        const uint32_t n = (uint32_t)(args.rec_offsets[last] - base);
+        if (n && n <= args.cap) { /* (complete: the shares add up to at most cap) */
+            const bool in_lds = n <= SORT_LDS;
+            /* gather: wavefront per region, front records then the ones spilled to its back */
+            for (uint32_t r = first + wv; r < last; r += SORT_THREADS / 64) {
+                const uint32_t f = args.rec_counts[2 * r], b = args.rec_counts[2 * r + 1];
+                const uint32_t at = (uint32_t)(args.rec_offsets[r] - base);
+                const uint4 *region = args.rec_stage + (uint64_t)r * args.rec_cap;
+                for (uint32_t i = lane; i < f + b; i += 64) {
+                    const uint4 rec = i < f ? region[i] : region[args.rec_cap - 1 - (i - f)];
+                    if (in_lds) buf[at + i] = rec;
+                    else out[base + at + i] = rec;
+                }
             }
             __syncthreads();
+            if (in_lds) {
+                bitonic_sort(buf, n);
+                for (uint32_t i = tid; i < n; i += SORT_THREADS) out[base + i] = buf[i];
+            } else {
+                bitonic_sort(out + base, n);
+            }
         }
     }
     /* last kernel of a scan: every control word this scan used goes back to zero, so the next scan on
-     * this scratch needs no memset in front of it (nothing in this kernel reads them) */
-    uint32_t v = 0, o = 0;
-    for (uint32_t i = tid; i < args.ctl_words; i += nthreads) {
-        if (args.cand_counts && i >= args.cand_ofs && i <= args.cand_ofs + args.cand_waves) {
-            const uint32_t c = args.rec_counts[i];
-            if (i == args.cand_ofs + args.cand_waves) o = c;
-            else v += c;
-        }
-        args.rec_counts[i] = 0;
+     * this scratch needs no memset in front of it. Each workgroup zeroes what only it has read (the fill
+     * counters of its own regions); the candidate counters were last read by the confirm stage. */
+    __syncthreads();
+    {
+        const uint32_t first = blockIdx.x * args.group_regions, last = min(args.rec_regions, first + args.group_regions);
+        for (uint32_t i = 2 * first + tid; i < 2 * last; i += SORT_THREADS) args.rec_counts[i] = 0;
     }
-    if (tid == 0 && args.tstamp_next) {
+    uint32_t v = 0, o = 0;
+    if (args.cand_counts) {
+        for (uint32_t i = blockIdx.x * SORT_THREADS + tid; i <= args.cand_waves; i += gridDim.x * SORT_THREADS) {
+            const uint32_t c = args.cand_counts[i];
+            if (i == args.cand_waves) o = c;
+            else v += c;
+            args.cand_counts[i] = 0;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0 && args.tstamp_next) {
         args.tstamp[3] = wall_clock64(); /* the scan's last kernel (its start: the stages before it are done) */
         args.tstamp_next[0] = ~0ull;
         args.tstamp_next[1] = 0;
@@ -1347,7 +1275,7 @@ __global__ __launch_bounds__(256) void record_order_kernel(HsgpuScanArgs args) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) vs += __shfl_xor(vs, d);
     const unsigned long long any_o = __ballot(o != 0);
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         if (vs) atomicAdd(&args.stats[0], vs);
         if (any_o) atomicAdd(&args.stats[1], 1ull);
     }

@@ -12,7 +12,6 @@
 #define HSGPU_CONFIRM_THREADS 256
 #define HSGPU_CONFIRM_SPLIT 4 /* confirm wavefronts per candidate region */
 #define HSGPU_HINT_SHIFT 10 /* one block hint per KiB of corpus */
-#define HSGPU_SUPER_SHIFT 8 /* ordered output: slices per group */
 
 struct HsgpuScanArgs {
     const uint8_t *corpus;      /* all blocks, concatenated; 16-byte aligned */
@@ -20,7 +19,6 @@ struct HsgpuScanArgs {
     const uint64_t *off;        /* nblocks + 1 ascending offsets, off[nblocks] == total */
     uint64_t nblocks;
     uint64_t start;             /* hwlmExec's `start`, applied inside every block */
-    uint32_t super_shift;       /* log2 of the bytes a filter workgroup owns per iteration (wavefronts x 1 KiB) */
     const uint8_t *blob;        /* compiled table in HBM */
     /* table header fields the kernels need, copied here by the host so that no
      * kernel starts with a dependent read of the header */
@@ -40,32 +38,20 @@ struct HsgpuScanArgs {
     uint4 *rec_stage;           /* staged match records, one region of rec_cap per producing wavefront */
     uint32_t rec_cap;
     uint32_t rec_regions;       /* number of record regions */
-    uint32_t *rec_counts;       /* [rec_regions][2]: records at the front / at the back of each region; also the base
-                                 * of the control block: rec_counts | cand_counts | slice_cnt | super_cnt | order_ctl */
-    uint32_t ctl_words;         /* words of the control block (all zero between scans) */
-    uint32_t cand_ofs;          /* cand_counts = rec_counts + cand_ofs */
-    /* ordered output (scan_device.h "phase 3"): a counting sort by corpus slice, then ranks inside each slice */
-    uint32_t slice_shift;       /* a slice = 1 << slice_shift corpus bytes */
-    uint32_t n_slices;
-    uint32_t *slice_cnt;        /* [n_slices] records ending in each slice (control block) */
-    uint32_t *slice_off;        /* [n_slices + 1] exclusive scan of slice_cnt */
-    uint32_t *heavy;            /* [n_slices] slices with more records than one lane ranks by counting */
-    uint32_t *super_cnt;        /* [n_slices / 256 rounded up] records per group of 256 slices (control block) */
-    uint32_t *order_ctl;        /* control block: [0] heavy slices so far, [1] a staging region overflowed, [2..3] matches found */
-    uint32_t *order_state;      /* [0] output complete (no overflow, fits cap), [1] heavy slices */
-    uint2 *rec_aux;             /* beside rec_stage: {slice, ticket} of every staged record */
-    uint4 *order_tmp;           /* [cap] records grouped by slice */
+    uint32_t *rec_counts;       /* [rec_regions][2]: records at the front / at the back of each region */
+    unsigned long long *rec_offsets; /* [rec_regions + 1]: exclusive scan of the region fills; [rec_regions] = the total */
+    uint32_t group_regions;     /* consecutive regions that hold the records of one filter workgroup's corpus share */
+    uint32_t *order_state;      /* [0] the output is complete (no region overflowed, everything fits cap) */
     unsigned long long *stats;  /* [2] cumulative: candidate entries spilled, overflowed scans */
     unsigned long long *tstamp; /* timing only: [2] min start / max end of the filter kernel (device wall clock) */
-    unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by record_order_kernel */
+    unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by record_sort_kernel */
 };
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
 const void *hsgpu_confirm_kernel_for(uint32_t table_flags);
 const void *hsgpu_hint_kernel(void);
-const void *hsgpu_record_offsets_kernel(void);
-const void *hsgpu_record_scatter_kernel(void);
-const void *hsgpu_record_order_kernel(void);
+const void *hsgpu_record_scan_kernel(void);
+const void *hsgpu_record_sort_kernel(void);
 size_t hsgpu_filter_lds_bytes(uint32_t table_flags, uint32_t filter_log2, bool fused, uint32_t wg_threads);
 
 #endif

@@ -39,9 +39,8 @@ const void *hsgpu_confirm_kernel_for(uint32_t flags) {
 }
 
 const void *hsgpu_hint_kernel(void) { return (const void *)block_hint_kernel; }
-const void *hsgpu_record_offsets_kernel(void) { return (const void *)record_offsets_kernel; }
-const void *hsgpu_record_scatter_kernel(void) { return (const void *)record_scatter_kernel; }
-const void *hsgpu_record_order_kernel(void) { return (const void *)record_order_kernel; }
+const void *hsgpu_record_scan_kernel(void) { return (const void *)record_scan_kernel; }
+const void *hsgpu_record_sort_kernel(void) { return (const void *)record_sort_kernel; }
 
 size_t hsgpu_filter_lds_bytes(uint32_t flags, uint32_t filter_log2, bool fused, uint32_t wg_threads) {
     size_t words = (size_t)hsgpu_filter_words(flags, filter_log2) + ((flags & HSGPU_F_HAS_C) ? 2048 : 0);

@@ -149,10 +149,11 @@ int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8
  * ascending uint64 offsets with d_off[nblocks] == total_bytes. The records arrive in delivery
  * order, sorted by (block, end, lit) -- hwlmExec's non-decreasing `end` (src/hwlm/hwlm.h:101-118),
  * block by block -- and *d_count receives the TOTAL number of matches. *d_count > cap means the
- * buffer was too small and no record is delivered: scan again with room for *d_count records (the
- * count is exact), or with twice the room when *d_count == cap + 1 (then the records would have
- * fitted in total, but the staging area of one wavefront, sized from cap, was too small for a
- * dense run of matches). cap < 2^32. d_corpus must be 16-byte aligned. */
+ * buffer was too small and no record is delivered: scan again with room for at least *d_count
+ * records, or with twice the room when *d_count == cap + 1 (then the staging area of one
+ * wavefront, sized from cap, was too small for a dense run of matches; in that case *d_count is a
+ * lower bound). hsgpu_hwlm_exec_batch repeats the scan itself. cap < 2^32. d_corpus must be
+ * 16-byte aligned. */
 int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus,
                         uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t start,
                         void *d_out, uint64_t cap, void *d_count, void *stream);

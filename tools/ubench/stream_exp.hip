@@ -23,7 +23,7 @@ struct ExpArgs {
 // MODE 0: no lookups (xor the bytes), 1: classic stride-2 one-bit (teddy64 shape), 2: classic stride-1 two-bit
 // blind (fdr10k shape), 3: pair filter.  AUX: buffer-load cache policy bits.  EARLY: first tiles requested
 // before the filter image is staged in LDS.
-template <int STAGES, int AUX, int MODE, bool EARLY>
+template <int STAGES, int AUX, int MODE, bool EARLY, int MAP = 0>
 __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x & 63;
@@ -33,9 +33,25 @@ __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
     const uint64_t n_full = args.total >> super_shift;
     const uint32_t G = gridDim.x;
     const uint32_t lane_off = wave * WAVE_TILE + lane * CHUNK;
+    const uint64_t n_wt = args.total >> 10, n_wv = (uint64_t)G * (blockDim.x >> 6), per_wv = (n_wt + n_wv - 1) / n_wv;
+    const uint64_t wv_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const uint64_t tile_end_ = MAP == 2 ? min(n_wt, (wv_global + 1) * per_wv)
+                               : MAP == 1 ? min(n_full, (uint64_t)(blockIdx.x + 1) * ((n_full + G - 1) / G)) : n_full;
+    const uint32_t lane_off2 = lane * CHUNK;
     auto issue = [&](uint64_t tile) -> Chunk {
+        if (MAP == 2) { /* tile counts 1 KiB wavefront tiles here */
+            const uint8_t *base = corpus + (tile << 10) - 8;
+            const int records = (tile < tile_end_ && tile) ? (int)0x7ffffff0 : 0;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, records, 0x00020000);
+            Chunk c;
+            const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off2, 8, AUX);
+            c.d = make_uint4(d[0], d[1], d[2], d[3]);
+            const auto h = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off2, 0, AUX);
+            c.h = make_uint2(h[0], h[1]);
+            return c;
+        }
         const uint8_t *base = corpus + (tile << super_shift) - 8;
-        const int records = (tile < n_full && tile) ? (int)0x7ffffff0 : 0;
+        const int records = (tile < tile_end_ && tile) ? (int)0x7ffffff0 : 0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, records, 0x00020000);
         Chunk c;
         const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 8, AUX);
@@ -45,17 +61,23 @@ __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
         return c;
     };
     Chunk c[STAGES];
-    uint64_t tile = blockIdx.x + G; /* tile 0 skipped: keeps the descriptor arithmetic of the product's common case */
+    /* MAP 0: tile = blockIdx + k * G (all workgroups walk the corpus together); MAP 1: every workgroup streams
+     * its own contiguous share (tile = blockIdx * per + k) */
+    const uint64_t per = (n_full + G - 1) / G;
+    const uint64_t step = MAP ? 1 : G;
+    const uint64_t tile_end = MAP == 2 ? tile_end_ : MAP == 1 ? min(n_full, (uint64_t)(blockIdx.x + 1) * per) : n_full;
+    uint64_t tile = MAP == 2 ? max((uint64_t)1, wv_global * per_wv)
+                    : MAP == 1 ? max((uint64_t)1, (uint64_t)blockIdx.x * per) : blockIdx.x + G; /* tile 0 skipped */
     if (EARLY) {
 #pragma unroll
-        for (int s = 0; s < STAGES - 1; s++) c[s] = issue(tile + (uint64_t)s * G);
+        for (int s = 0; s < STAGES - 1; s++) c[s] = issue(tile + (uint64_t)s * step);
     }
     const uint32_t nw = 32768;
     for (uint32_t i = threadIdx.x; i < nw / 4; i += blockDim.x) ((uint4 *)lds)[i] = ((const uint4 *)args.table)[i];
     __syncthreads();
     if (!EARLY) {
 #pragma unroll
-        for (int s = 0; s < STAGES - 1; s++) c[s] = issue(tile + (uint64_t)s * G);
+        for (int s = 0; s < STAGES - 1; s++) c[s] = issue(tile + (uint64_t)s * step);
     }
     FilterCfg f;
     f.shift = MODE == 3 ? 29u - args.flog2 : 30u - args.flog2;
@@ -64,10 +86,10 @@ __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
     f.c2base = nw * 4;
     f.hmask = args.hmask;
     uint32_t nhit = 0, x = 0;
-    while (tile < n_full) {
+    while (tile < tile_end) {
 #pragma unroll
         for (int s = 0; s < STAGES; s++) {
-            c[(s + STAGES - 1) % STAGES] = issue(tile + (uint64_t)(STAGES - 1) * G);
+            c[(s + STAGES - 1) % STAGES] = issue(tile + (uint64_t)(STAGES - 1) * step);
             const Chunk &cur = c[s];
             uint32_t acc;
             if (MODE == 0) acc = (cur.d.x ^ cur.d.y ^ cur.d.z ^ cur.d.w ^ cur.h.x ^ cur.h.y) == 0x12345678u;
@@ -76,7 +98,7 @@ __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
             else acc = pair_filter_chunk(cur, f);
             const unsigned long long bal = __ballot(acc != 0);
             if (bal) nhit += __popcll(bal), x ^= acc;
-            tile += G; /* tiles past the end have empty descriptors: zeros, no hits */
+            tile += step; /* tiles past the end have empty descriptors: zeros, no hits */
         }
     }
     if (lane == 0 && (nhit | x)) atomicAdd(args.hits, (unsigned long long)nhit);
@@ -85,6 +107,8 @@ __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
 typedef void (*kfn)(ExpArgs);
 struct Variant { const char *name; kfn f; };
 #define V(S, A, M, E) {"stages=" #S " aux=" #A " mode=" #M " early=" #E, exp_kernel<S, A, M, E>}
+#define VW(S, A, M, E) {"stages=" #S " aux=" #A " mode=" #M " early=" #E " WAVE-BLOCKED", exp_kernel<S, A, M, E, 2>}
+#define VB(S, A, M, E) {"stages=" #S " aux=" #A " mode=" #M " early=" #E " BLOCKED", exp_kernel<S, A, M, E, 1>}
 
 int main(int argc, char **argv) {
     const uint64_t total = 1ull << 30;
@@ -112,7 +136,8 @@ int main(int argc, char **argv) {
         V(8, 0, 0, false), V(8, 0, 1, false), V(8, 0, 2, false), V(8, 0, 3, false),
         V(8, 2, 0, false), V(8, 2, 1, false), V(8, 2, 3, false),
         V(8, 0, 1, true), V(4, 0, 1, false), V(12, 0, 1, false), V(12, 0, 0, false), V(12, 2, 1, false),
-        V(8, 1, 1, false), V(8, 3, 1, false), V(8, 16, 1, false), V(8, 17, 1, false),
+        VB(8, 0, 0, false), VB(8, 0, 1, false), VB(8, 0, 2, false), VB(8, 2, 0, false), VB(8, 2, 1, false), VB(4, 0, 1, false),
+        VW(8, 0, 0, false), VW(8, 0, 1, false), VW(8, 0, 2, false), VW(8, 2, 1, false), VW(4, 0, 1, false), VW(8, 0, 3, false), VB(8, 0, 3, false),
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
