@@ -5,23 +5,27 @@ Metric (BASELINE.json): GB/s scanned in block mode (+ matches/s), whole job over
 N GPUs, inputs resident in HBM when the timed region starts.
 
 A "step" is one pass of the hot path over one batch: every rank scans its own
-shard (all blocks of the corpus, one kernel launch) and, for N > 1, the match
-records are all-gathered over RCCL. hsbench protocol (tools/hsbench/main.cpp:
-502-528, 720-724, 823-839): corpus pre-loaded, barrier, K repeats, bytes*K/secs.
+shard (all blocks of the corpus; filter + confirm + records in delivery order on
+the device) and, for N > 1, the match records are all-gathered over RCCL.
+hsbench protocol (tools/hsbench/main.cpp:502-528, 720-724, 823-839): corpus
+pre-loaded, barrier, K repeats, bytes*K/secs.
 
-Workloads:
-  teddy64   config 2: 64 literals len 4-8, 1 GiB synthetic packet corpus per GPU
-  fdr10k    config 3: 10 000 snort-like literals, 1 GiB packet shard per GPU
-The default is teddy64 (configs[1]); the fdr10k line is measured in the same run
-and attached as "also".
+Workloads; the headline is the one BASELINE.json quotes its
+target on:
+  fdr10k    config 3's per-GPU shard: 10 000 snort-like literals, 1 GiB of packets per GPU
+  teddy64   config 2: 64 literals len 4-8, 1 GiB synthetic packet corpus       ("also", N = 1)
+  class256  config 4: 256 class-heavy patterns -> their distinct classes in passes of 8
+            over a 4 GiB line corpus (shufti/truffle semantics)                  ("also", N = 1)
+  rose1000  config 5: 1000 literal-prefix + tail patterns through hs_scan_batch: GPU literal
+            hits feeding the host-side confirm, 2 GiB of packets                  ("also", N = 1)
 
 One JSON line on stdout (rank 0).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -31,6 +35,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REC_BYTES = 16
+WORKLOAD_DESC = {
+    "fdr10k": "10000 snort-like literals (8-byte suffixes)",
+    "teddy64": "64 literals len 4-8",
+}
 
 
 def log(*a):
@@ -54,24 +62,32 @@ def build_workload(name, total_bytes, seed_shift):
     return lits, corpus, off
 
 
-def pmc_traffic(table_flags):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
-    command (profiles/r01_bench_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
-    in separate runs). Units are KB; on gfx950 FETCH_SIZE counts a wide coalesced read stream at
-    half its bytes (MI355X_MICROARCH.md, HBM section), hence the factor 2 on the read side."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/r02_bench_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
+    runs, tools/round_profile.sh). Units are KB; on gfx950 FETCH_SIZE counts a wide coalesced read
+    stream at half its bytes (MI355X_MICROARCH.md, HBM section), hence the factor 2 on the read side.
+    -> (bytes | None, source)"""
+    src = os.path.join("profiles", "r02_bench_pmc_summary.json")
+    path = os.path.join(ROOT, src)
     if not os.path.exists(path):
-        return None
-    b = lambda bit: "true" if table_flags & bit else "false"
-    # HSGPU_F_BFOLD (128): the two-phase filter kernel of such a table is the 4-byte-key-only variant
-    cls = ("true, true, true" if table_flags & 4 else
-           "true, true, false" if table_flags & 2 and not table_flags & 128 else "true, false, false")
-    name = f"hwlm_filter_kernel<{cls}, {b(8)}, {b(16)}, {b(32)}, {b(64)}, false>"
+        return None, None
     try:
-        e = json.load(open(path)).get(name)
-        return int(e["FETCH_SIZE"]["avg_KB"] * 1024 * 2 + e["WRITE_SIZE"]["avg_KB"] * 1024) if e else None
+        for name, e in json.load(open(path)).items():
+            if name.startswith(kernel_prefix):
+                return int(e["FETCH_SIZE"]["avg_KB"] * 1024 * 2 + e["WRITE_SIZE"]["avg_KB"] * 1024), src
     except Exception:
-        return None
+        pass
+    return None, None
+
+
+def filter_kernel_name(flags):
+    b = lambda bit: "true" if flags & bit else "false"
+    if flags & 256:
+        return "hwlm_filter_kernel<true, false, false, false, false, true, false, false, true>"
+    cls = ("true, true, true" if flags & 4 else
+           "true, true, false" if flags & 2 and not flags & 128 else "true, false, false")
+    return f"hwlm_filter_kernel<{cls}, {b(8)}, {b(16)}, {b(32)}, {b(64)}, false, false>"
 
 
 class GpuJob:
@@ -117,66 +133,78 @@ class GpuJob:
         return self.d_out[: n * 4].view(n, 4).cpu().numpy().astype(np.uint32)
 
 
-def cpu_baseline(lits, corpus, off, want_seconds=6.0, sample_bytes=64 << 20):
-    """The reference's own hwlmExec (oracle/_ref, compiled from /root/reference) -- or
-    the C restatement when that library is absent -- timed on this box's host cores
-    over a bounded sample of the same workload, hsbench style: T threads, each
-    scanning its own slice of the sample, repeated until ~want_seconds elapsed."""
+def host_cpu_desc():
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model
+
+
+def cpu_baseline(lits, corpus, off, want_seconds=9.0, sample_bytes=256 << 20):
+    """The reference's own hwlmExec (oracle/_ref, compiled from /root/reference) -- or the C restatement
+    when that library is absent -- timed on this box's host cores over a bounded sample of the same
+    workload in hsbench's thread model (tools/hsbench/main.cpp:957-963, 990-1030): T native threads
+    pinned one per CPU, each looping over its own slice of the blocks; T = 1 and T = every CPU this
+    process may use; with the AVX2 build and -- where the host has the flags -- the AVX-512 VBMI build.
+    -> (cpu_baseline object, reference records of the first blocks for the parity gate)"""
     from tests import oracle_binding as ob
 
-    k = int(np.searchsorted(off, min(sample_bytes, int(off[-1])), side="right")) - 1
-    k = max(k, 1)
-    s_off = off[: k + 1].copy()
+    k = max(1, int(np.searchsorted(off, min(sample_bytes, int(off[-1])), side="right")) - 1)
+    s_off = np.ascontiguousarray(off[: k + 1])
     s_bytes = int(s_off[-1])
     sample = corpus[:s_bytes]
-    kind = "reference" if ob.ref_available() else "port"
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    eng = [ob.Reference(lits) if kind == "reference" else ob.Oracle(lits) for _ in range(threads)]
-    info = eng[0].info() if kind == "reference" else "oracle/hwlm_oracle.c"
-    # slice the sample's blocks evenly (by block count) over the threads
-    bounds = np.linspace(0, k, threads + 1).astype(np.int64)
-    counts = [0] * threads
-    passes = [0] * threads
+    cpus = len(os.sched_getaffinity(0))
+    if not ob.ref_available():  # the restatement, one thread: a port, not the reference
+        o = ob.Oracle(lits)
+        t0 = time.perf_counter()
+        n = o.count_blocks(sample, s_off)
+        dt = time.perf_counter() - t0
+        kg = max(1, int(np.searchsorted(s_off, 16 << 20, side="right")) - 1)
+        return ({"value": round(s_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                 "sample": f"first {s_bytes} bytes / {k} blocks of the same corpus, oracle/hwlm_oracle.c, 1 thread",
+                 "matches_in_sample": int(n)}, (kg, o.collect_blocks(sample[: int(s_off[kg])], s_off[: kg + 1])))
+    runs, best = {}, None
+    per = want_seconds / (2 * len(ob.ref_variants()))
+    engine = None
+    for variant in ob.ref_variants():
+        ref = ob.Reference(lits, variant=variant)
+        engine = engine or ref.info()
+        for T in (1, cpus):
+            nbytes, secs, matches, passes = ref.bench_threads(sample, s_off, T, per)
+            gbs = nbytes / secs / 1e9
+            runs[f"{variant}_T{T}"] = {"GBps": round(gbs, 3), "threads": T, "passes_slowest_thread": passes,
+                                       "matches_per_pass": matches}
+            if best is None or gbs > best[0]:
+                best = (gbs, T, variant, matches)
+        kg = max(1, int(np.searchsorted(s_off, 32 << 20, side="right")) - 1)
+        gate = (kg, ref.collect_blocks(sample[: int(s_off[kg])], s_off[: kg + 1]))
+    return ({"value": round(best[0], 3), "unit": "GB/s", "cores": best[1], "kind": "reference",
+             "sample": f"first {s_bytes} bytes / {k} blocks of the same corpus; hwlmExec per block, {best[1]} pinned "
+                       f"pthreads x own slice, ~{per:.1f}s per run; best of the runs below ({best[2]} build)",
+             "engine": engine, "cpu": host_cpu_desc(), "cpus_available": cpus, "runs": runs,
+             "matches_in_sample": int(best[3])}, gate)
 
-    def work(i, deadline):
-        lo, hi = int(bounds[i]), int(bounds[i + 1])
-        if hi <= lo:
-            return
-        o = s_off[lo:hi + 1]
-        while True:
-            counts[i] = eng[i].count_blocks(sample, o)
-            passes[i] += 1
-            if time.perf_counter() >= deadline:
-                break
 
-    # single-thread number first (T=1 over the whole sample), then all cores
-    t0 = time.perf_counter()
-    n1 = eng[0].count_blocks(sample, s_off)
-    t1 = time.perf_counter() - t0
-    reps1 = 1
-    while t1 < want_seconds / 3:
-        eng[0].count_blocks(sample, s_off)
-        reps1 += 1
-        t1 = time.perf_counter() - t0
-    single = s_bytes * reps1 / t1 / 1e9
-
-    t0 = time.perf_counter()
-    deadline = t0 + want_seconds * 2 / 3
-    ths = [threading.Thread(target=work, args=(i, deadline)) for i in range(threads)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
-    scanned = sum(int(s_off[int(bounds[i + 1])] - s_off[int(bounds[i])]) * passes[i] for i in range(threads))
-    multi = scanned / dt / 1e9
-    assert sum(counts) == n1, "CPU baseline: per-thread counts do not add up"
-    return {
-        "value": round(multi, 4), "unit": "GB/s", "cores": threads, "kind": kind,
-        "sample": f"first {s_bytes} bytes / {k} blocks of the same corpus, {threads} threads x own slice, "
-                  f"~{want_seconds * 2 / 3:.0f}s; engine: {info}",
-        "single_thread_GBps": round(single, 4), "matches_in_sample": int(n1),
-    }, (k, int(n1))
+def parity_gate(recs, gate, lits):
+    """Content-level parity on the first blocks: the sorted (block, end, id) multisets of the GPU and of
+    the reference are identical (unit/internal/fdr.cpp:185-188 compares (end, id) lists the same way),
+    and the GPU's records arrive in delivery order."""
+    kg, want = gate
+    g = recs[recs[:, 0] < kg]
+    key = (g[:, 0].astype(np.uint64) << np.uint64(32)) | g[:, 1].astype(np.uint64)
+    assert np.all((key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (g[1:, 3] > g[:-1, 3]))), "records not in delivery order"
+    gi = np.lexsort((g[:, 2], g[:, 1], g[:, 0]))
+    wi = np.lexsort((want["id"], want["end"], want["block"]))
+    ok = (len(g) == len(want) and np.array_equal(g[gi, 0], want["block"][wi]) and np.array_equal(g[gi, 1], want["end"][wi])
+          and np.array_equal(g[gi, 2], want["id"][wi]))
+    assert ok, f"PARITY FAILURE on the first {kg} blocks: GPU {len(g)} records vs CPU {len(want)}"
+    return f"sorted (block,end,id) multisets identical on the first {kg} blocks ({len(want)} matches); delivery order checked"
 
 
 def run_workload(name, args, rank, world, dist, do_cpu):
@@ -189,42 +217,25 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     job = GpuJob(lits, corpus, off, torch.cuda.current_device())
     info = job.table.info()
 
-    # Optional software pipelining (--pipeline-depth 2): step i+1's scan is launched on a
-    # second stream (its own scratch and record buffer, same table and resident corpus)
-    # while step i's confirm / pack kernels and -- for N > 1 -- its record all-gather
-    # finish on the first. Every step still does all of its work. Default: serial steps.
-    depth = max(1, min(2, args.pipeline_depth))
+    # Software pipelining (--pipeline-depth 2, the default for N > 1): step i+1's scan is launched on a
+    # second stream (its own scratch and record buffer, same table and resident corpus) while step i's
+    # record all-gather runs on the first. Every step still does all of its work. N = 1 runs serial
+    # steps, so that the per-kernel figures are those of the kernels alone.
+    depth = max(1, min(2, args.pipeline_depth if args.pipeline_depth else (2 if world > 1 else 1)))
     jobs = [job] + [GpuJob(None, None, None, torch.cuda.current_device(), sibling=job) for _ in range(depth - 1)]
     streams = [torch.cuda.Stream(device=job.dev) for _ in range(depth)]
 
-    def gather(jb):
-        """The path's one exchange step: RCCL all-gather of match records over xGMI
-        (counts, then records padded to the largest count) -- hyperscan_amd/dist.py."""
-        from hyperscan_amd import dist as hd
-
-        n = min(int(jb.d_count.item()), jb.cap)  # waits for THIS job's stream only
-        recs, base = jb.d_out.view(-1, 4), rank * jb.nblocks
-        if args.exchange == "exact":  # no padding to the largest count (skewed shards)
-            return hd.all_gather_records_exact(recs, n, base, dist, world, rank, jb.dev)
-        if args.exchange == "root":  # only rank 0's host would deliver the callbacks
-            return hd.gather_records_to_root(recs, n, base, dist, world, rank, 0, jb.dev)
-        return hd.all_gather_records(recs, n, base, dist, world, jb.dev)
-
-    def run_steps(n):
+    def run_steps(n, exch=None, ev=None):
         for i in range(n):
             j = i % depth
             with torch.cuda.stream(streams[j]):
                 jobs[j].launch()
-            if world > 1:
-                p = (i - (depth - 1)) % depth  # the step launched depth-1 steps ago
-                if i >= depth - 1:
-                    with torch.cuda.stream(streams[p]):
-                        gather(jobs[p])
-        if world > 1:  # drain: the last depth-1 steps still owe their gather
-            for i in range(max(0, n - (depth - 1)), n):
-                if depth > 1:
-                    with torch.cuda.stream(streams[i % depth]):
-                        gather(jobs[i % depth])
+                if exch is not None:  # the path's one exchange step: RCCL all-gather of the records over xGMI
+                    if ev is not None:
+                        ev[i][0].record()
+                    exch[j].step(jobs[j].d_out.view(-1, 4), jobs[j].d_count)
+                    if ev is not None:
+                        ev[i][1].record()
         for st in streams:
             st.synchronize()
 
@@ -234,36 +245,52 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     assert n_matches <= job.cap, "record buffer too small"
     assert all(jb.count() == n_matches for jb in jobs)
 
-    # parity gate on a sample (bounded CPU time): GPU count over the first k blocks == CPU count
+    exch = None
+    if world > 1:
+        from hyperscan_amd import dist as hd
+
+        # global block indices: shards are contiguous block ranges, rank r's first block = blocks of ranks < r
+        nb = torch.tensor([job.nblocks, n_matches], dtype=torch.int64, device=job.dev)
+        allnb = torch.empty(world * 2, dtype=torch.int64, device=job.dev)
+        dist.all_gather_into_tensor(allnb, nb)
+        allnb = allnb.view(world, 2).cpu()
+        base = int(allnb[:rank, 0].sum())
+        rows = min(job.cap, int(int(allnb[:, 1].max()) * 1.25) + 1024)  # every rank posts the same fixed size
+        exch = [hd.RecordExchange(dist, world, rank, job.dev, rows, base) for _ in jobs]
+        run_steps(depth, exch)  # untimed: RCCL sets up its rings on first use
+        allr, counts = exch[0].compact()
+        assert counts[rank] == n_matches and allr.shape[0] == sum(counts)
+        assert bool((allr[1:, 0].to(torch.int64) & 0xFFFFFFFF >= allr[:-1, 0].to(torch.int64) & 0xFFFFFFFF).all()), \
+            "gathered records are not in global block order"
+
+    # parity gate on the first blocks (bounded CPU time) + the CPU baseline
     cpu = None
     if do_cpu:
         # records first: on this stack the scans that directly follow a large D2H copy run ~3x
         # slower for tens of ms (measured: 1.9 vs 0.66 ms per scan, host launch time unchanged);
         # the CPU baseline's seconds in between and one untimed scan keep that out of the timed region
         recs = job.records()
-        cpu, (k, n_cpu) = cpu_baseline(lits, corpus, off)
+        cpu, gate = cpu_baseline(lits, corpus, off)
+        cpu["parity"] = parity_gate(recs, gate, lits)
         run_steps(1)
         torch.cuda.synchronize()
-        n_gpu = int((recs[:, 0] < k).sum())
-        assert n_gpu == n_cpu, f"PARITY FAILURE on the sample: GPU {n_gpu} vs CPU {n_cpu}"
-        cpu["parity"] = f"GPU == CPU match count on the sample ({n_cpu})"
 
     # timed region: barrier + sync on both sides, exactly K steps
-    filt_ms, conf_ms, pipe_ms = [], [], []
+    ev = None
     if world > 1:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, exch, ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     assert all(jb.count() == n_matches for jb in jobs), "match count changed between repeats"  # hsbench main.cpp:778-787
-    # HIP events the library recorded on the launch stream around its kernels during
-    # the timed steps (ring of the last 32 scans); read only now, so the timed loop
-    # itself never waited on them
-    span_ms = []
+    # HIP events the library recorded on the launch stream around its filter kernel during the timed
+    # steps (ring of the last 32 scans); read only now, so the timed loop itself never waited on them
+    filt_ms, conf_ms, pipe_ms, span_ms = [], [], [], []
     for jb in jobs:
         for back in range(min(args.steps // depth, 32)):
             f, c, t = jb.scratch.timing(back)
@@ -284,7 +311,8 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         all_bytes, all_matches = job.total, n_matches
 
     alg_bytes = job.total + REC_BYTES * n_matches
-    traffic = pmc_traffic(info["flags"])
+    kname = filter_kernel_name(info["flags"])
+    traffic, traffic_src = pmc_traffic(kname)
     achieved = alg_bytes / kern_avg_s / 1e9
     res = {
         "value": round(all_bytes * args.steps / dt / 1e9, 3),
@@ -293,8 +321,8 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         "matches_per_step": all_matches,
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "hwlm_filter_kernel", "kernel_ms_avg": round(kern_avg_s * 1e3, 4),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kname, "kernel_ms_avg": round(kern_avg_s * 1e3, 4),
             "kernel_ms_best": round(float(np.min(filt_ms)), 4),
             "algorithmic_bytes_per_launch": alg_bytes,
             # the kernel's own execution span from the device wall clock (what rocprofv3's kernel
@@ -306,13 +334,45 @@ def run_workload(name, args, rank, world, dist, do_cpu):
             "pipeline_GBps": round(alg_bytes / (float(np.mean(pipe_ms)) / 1e3) / 1e9, 2),
         },
         "table": info,
+        "records": "in delivery order (block, end, lit), sorted on the device inside the step",
     }
     res["pipeline_depth"] = depth
+    if world > 1:
+        g = [a.elapsed_time(b) for a, b in ev]
+        res["exchange"] = {"collective": "all_gather_into_tensor x2 (counts, records padded to a fixed size)",
+                           "rows_per_rank": exch[0].rows, "bytes_per_rank_per_step": exch[0].rows * 16 + 16,
+                           "gather_ms_avg_rank0": round(float(np.mean(g)), 4), "gather_ms_max_rank0": round(float(np.max(g)), 4)}
     if do_cpu:
-        # (never `value`) the same engine fed from HOST memory: hsgpu_hwlm_exec_batch = H2D of the
-        # corpus + the pipeline above + D2H of the sorted records, on a bounded sample
         from hyperscan_amd import hwlm as hw
 
+        # (ii) end to end for the resident case, hsbench's definition (engine_hyperscan.cpp:89-97, 132-145): the scan,
+        # then the records to the host and through hsgpu_hwlm_replay into a counting callback
+        n_cb = [0]
+
+        def count_cb(end, lit_id, _ctx):
+            n_cb[0] += 1
+            return hw.HWLM_CONTINUE_MATCHING
+
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            job.launch()
+            torch.cuda.synchronize()
+            t_scan = time.perf_counter() - t0
+            recs_h = job.records()
+            t_copy = time.perf_counter() - t0
+            n_del = hw.hwlm_replay_count(job.table, recs_h)
+            ts.append((t_scan, t_copy, time.perf_counter() - t0))
+        assert n_del == n_matches
+        sc, cp_, e2e = [float(np.median([t[i] for t in ts])) for i in range(3)]
+        res["end_to_end_resident"] = {
+            "GBps": round(job.total / e2e / 1e9, 2), "ms": round(e2e * 1e3, 3), "scan_ms": round(sc * 1e3, 3),
+            "records_to_host_ms": round((cp_ - sc) * 1e3, 3), "replay_ms": round((e2e - cp_) * 1e3, 3),
+            "matches_delivered": int(n_del),
+            "what": "scan (synchronous) + D2H of the sorted records + hsgpu_hwlm_replay into a native counting callback"}
+        # (iii) (never `value`) the same engine fed from HOST memory: hsgpu_hwlm_exec_batch = H2D of the
+        # corpus + the pipeline above + D2H of the records, on a bounded sample
         k = int(np.searchsorted(off, min(256 << 20, int(off[-1])), side="right")) - 1
         s_off = np.ascontiguousarray(off[: k + 1])
         sample = np.ascontiguousarray(corpus[: int(s_off[-1])])
@@ -323,11 +383,173 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         res["host_buffers"] = {"GBps": round(sample.size / dt_h / 1e9, 2), "sample_bytes": int(sample.size),
                                "matches": int(recs_h.size),
                                "what": "hsgpu_hwlm_exec_batch from pageable host memory: H2D of the corpus + scan + "
-                                       "D2H of the sorted records; PCIe bound, reported for completeness only"}
+                                       "D2H of the records; PCIe bound, reported for completeness only"}
     if cpu:
         res["cpu_baseline"] = cpu
     del job, jobs
     torch.cuda.empty_cache()
+    return res
+
+
+# ---- config 4: class accelerators -----------------------------------------------------------
+
+CLASS_POOL = [("[a-z]", range(ord("a"), ord("z") + 1)), ("[A-Z]", range(ord("A"), ord("Z") + 1)),
+              ("[0-9]", range(ord("0"), ord("9") + 1)), ("[a-f0-9]", b"0123456789abcdef"),
+              ("\\s", b" \t\r\n\x0b\x0c"), ("[^\\x00-\\x7f]", range(128, 256)), ("[aeiou]", b"aeiou"),
+              ("[,.;:]", b",.;:"), ("[A-Za-z_]", b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz_"),
+              ("[()\\[\\]]", b"()[]"), ("[-_]", b"-_"), ("\\n", b"\n")]
+
+
+def run_class256(args):
+    """256 patterns A_k{m,}B_k+ ([a-z]{3,}\\d+ style) over a line corpus, one block per line: the GPU work item is
+    what the reference's accelerators deliver for such patterns -- class membership and the first / last member per
+    block, for every distinct class of the set (src/nfa/shufti.c:150-199, src/nfa/truffle.c:118-165)."""
+    import torch
+
+    from hyperscan_amd import accel
+    from hyperscan_amd import corpus as cp
+    from tests import oracle_binding as ob
+
+    rng = np.random.default_rng(5)
+    pats, used = [], set()
+    for k in range(256):
+        a, b = rng.choice(len(CLASS_POOL), 2, replace=False)
+        pats.append(f"{CLASS_POOL[a][0]}{{{int(rng.integers(3, 9))},}}{CLASS_POOL[b][0]}+")
+        used |= {int(a), int(b)}
+    classes = [accel.CharClass(CLASS_POOL[i][1]) for i in sorted(used)]
+    names = [CLASS_POOL[i][0] for i in sorted(used)]
+    total_gib = args.class_gib
+    t0 = time.perf_counter()
+    unit, uoff = cp.line_corpus(1 << 30, seed=5)  # 1 GiB of lines, laid out total_gib times (offsets shifted)
+    reps = max(1, int(total_gib))
+    corpus = np.tile(unit, reps)
+    off = np.concatenate([uoff[:-1] + np.uint64(r * unit.size) for r in range(reps)] + [np.array([reps * unit.size], dtype=np.uint64)])
+    total, nb = int(corpus.size), int(off.size - 1)
+    log(f"class256: {len(classes)} distinct classes of 256 patterns, {total} bytes / {nb} lines in {time.perf_counter() - t0:.1f}s")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_corpus = torch.from_numpy(corpus).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    passes = [classes[i:i + 8] for i in range(0, len(classes), 8)]
+    bufs = []
+    for p in passes:
+        bm, first, last = accel.class_scan(p, d_corpus, total, d_off, nb, True, True)
+        bufs.append((bm, first, last, torch.zeros(accel.WORK_BYTES, dtype=torch.uint8, device=dev)))
+    # parity on a slice: membership bit i <=> corpus[i] in class; first / last of the first lines against the reference
+    n = 1 << 20
+    cpu = None
+    for pi, p in enumerate(passes):
+        for ci, cls in enumerate(p):
+            want = np.packbits(np.isin(corpus[:n], np.array(cls.members(), dtype=np.uint8)), bitorder="little")
+            assert np.array_equal(bufs[pi][0][ci][: n // 8].cpu().numpy(), want), "class bitmap parity"
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        for p, b in zip(passes, bufs):
+            accel.class_scan(p, d_corpus, total, d_off, nb, True, True, buffers=b)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    # algorithmic bytes: every pass reads the corpus once and writes one bit per byte and class + first/last per line
+    alg = sum(total * (1 + len(p) / 8) + nb * len(p) * 8 for p in passes)
+    res = {"workload": f"class256: 256 patterns -> {len(classes)} distinct classes {names} in {len(passes)} passes of <= 8, "
+                       f"{total / (1 << 30):g} GiB line corpus (1 GiB of lines x {reps}), {nb} blocks",
+           "value": round(total * args.steps / dt / 1e9, 2), "unit": "GB/s of corpus (all classes)", "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "roofline": {"bound": "hbm", "achieved": round(alg / (ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "class_bitmap_kernel + class_first_last_kernel (HIP events around all passes)",
+                        "ms_all_passes": round(ms, 3), "algorithmic_bytes_per_step": int(alg)}}
+    if ob.ref_available():
+        R = ob.href(ob.ref_variants()[-1])
+        packed = np.zeros((len(classes), 33), dtype=np.uint8)
+        for i, cls in enumerate(classes):
+            lo, hi = np.zeros(16, np.uint8), np.zeros(16, np.uint8)
+            bm = np.ascontiguousarray(cls.bitmap)
+            if R.hsref_shufti_build(bm.ctypes.data, lo.ctypes.data, hi.ctypes.data) > 0:
+                packed[i, 0] = 0
+            else:
+                R.hsref_truffle_build(bm.ctypes.data, lo.ctypes.data, hi.ctypes.data)
+                packed[i, 0] = 1
+            packed[i, 1:17], packed[i, 17:33] = lo, hi
+        k = int(np.searchsorted(uoff, 64 << 20, side="right")) - 1
+        s_off = np.ascontiguousarray(uoff[: k + 1])
+        cpus = len(os.sched_getaffinity(0))
+        out = (C.c_double * 4)()
+        R.hsref_class_bench_threads.restype = C.c_int
+        R.hsref_class_bench_threads.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                                C.c_double, C.c_int, C.c_void_p]
+        rv = R.hsref_class_bench_threads(packed.ctypes.data, len(classes), unit.ctypes.data, s_off.ctypes.data, k, cpus, 3.0, 1, out)
+        assert rv == 0
+        res["cpu_baseline"] = {"value": round(out[0] / out[1] / 1e9, 3), "unit": "GB/s of corpus (all classes)", "cores": cpus,
+                               "kind": "reference", "cpu": host_cpu_desc(),
+                               "sample": f"first {int(s_off[-1])} bytes / {k} lines; per line and class shuftiExec / truffleExec + "
+                                         f"their reverse forms (first and last member), {cpus} pinned pthreads x own slice, ~3 s"}
+    del d_corpus, bufs
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---- config 5: literal hits feeding the host-side confirm ---------------------------------------
+
+def run_rose1000(args):
+    import torch
+
+    from hyperscan_amd import corpus as cp
+    from hyperscan_amd import hs
+    from tests import oracle_binding as ob
+
+    rng = np.random.default_rng(6)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ", dtype=np.uint8)
+    tails = [r"[a-z]+\d", r"\s+\w{2,8}=", r".{0,16}END"]
+    lits = sorted({bytes(rng.choice(alpha, int(rng.integers(6, 13)))) for _ in range(1000)})
+    pats = [l.decode() + tails[i % 3] for i, l in enumerate(lits)]
+    db = hs.Database.compile(pats, [0] * len(pats), list(range(len(pats))))
+    scratch = hs.HsScratch(db)
+    total = int(args.rose_gib * (1 << 30))
+
+    class L:  # corpus generator wants objects with .s
+        def __init__(self, s):
+            self.s = s
+    follow = [b"abc7", b"  key=", b"....END"]
+    plant = [L(l + follow[i % 3]) if i % 2 == 0 else L(l) for i, l in enumerate(lits)]
+    corpus, off = cp.packet_corpus(total, plant, seed=6, match_every=4096)
+    lib = hs._lib()
+    handler = C.cast(lib.hs_batch_count_handler, hs.BATCH_CB)  # hsbench's counting callback, native
+    # the corpus in pinned host memory: the H2D leg runs at PCIe speed instead of through the pageable path
+    pinned = torch.from_numpy(corpus).pin_memory()
+    buf = pinned.numpy()
+    offs = np.ascontiguousarray(off, dtype=np.uint64)
+    ts, n_ev = [], 0
+    for _ in range(max(3, min(args.steps, 5)) + 1):
+        cnt = C.c_ulonglong(0)
+        t0 = time.perf_counter()
+        rv = lib.hs_scan_batch(db._h, buf.ctypes.data, offs.ctypes.data, offs.size - 1, 0, scratch._h, handler, C.byref(cnt))
+        ts.append(time.perf_counter() - t0)
+        assert rv == 0
+        assert n_ev in (0, cnt.value), "match count changed between repeats"
+        n_ev = cnt.value
+    t = float(np.median(ts[1:]))
+    res = {"workload": f"rose1000: 1000 literal-prefix + tail patterns, {args.rose_gib:g} GiB of packets through hs_scan_batch from pinned host "
+                       "memory (H2D of the corpus + GPU literal scan + D2H of the records + host confirm + counting callback)",
+           "value": round(total / t / 1e9, 2), "unit": "GB/s end to end", "ms": round(t * 1e3, 1), "matches": int(n_ev),
+           "matches_per_s": round(n_ev / t, 1)}
+    if ob.ref_available():
+        from hyperscan_amd.hwlm import HwlmLiteral
+
+        hl = [HwlmLiteral(l[-8:], False, i) for i, l in enumerate(lits)]
+        k = int(np.searchsorted(off, 256 << 20, side="right")) - 1
+        s_off = np.ascontiguousarray(off[: k + 1])
+        cpus = len(os.sched_getaffinity(0))
+        ref = ob.Reference(hl, variant=ob.ref_variants()[-1])
+        nbytes, secs, matches, _p = ref.bench_threads(corpus[: int(s_off[-1])], s_off, cpus, 3.0)
+        res["cpu_baseline"] = {"value": round(nbytes / secs / 1e9, 3), "unit": "GB/s", "cores": cpus, "kind": "reference",
+                               "cpu": host_cpu_desc(), "engine": ref.info(),
+                               "sample": f"first {int(s_off[-1])} bytes; the reference's hwlmExec over the 1000 literal prefixes (their last 8 "
+                                         f"bytes, as Rose hands them to HWLM), {cpus} pinned pthreads, ~3 s: the literal stage of the reference "
+                                         "alone, without its confirm (an upper bound on what full hs_scan would do)",
+                               "literal_hits_per_pass": int(matches)}
     return res
 
 
@@ -337,16 +559,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gib", type=float, default=1.0, help="corpus GiB per GPU")
-    ap.add_argument("--workload", default="teddy64", choices=["teddy64", "fdr10k"])
-    ap.add_argument("--no-also", action="store_true", help="skip the second workload line")
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "exact", "root"],
-                    help="N>1 record exchange: padded all-gather (default, what BASELINE names), exact-size "
-                         "all-gather, or gather to rank 0 (hyperscan_amd/dist.py)")
+    ap.add_argument("--workload", default="fdr10k", choices=["teddy64", "fdr10k"])
+    ap.add_argument("--no-also", action="store_true", help="skip the other workloads' lines")
+    ap.add_argument("--also", default="teddy64,class256,rose1000", help="comma-separated extra workloads at N = 1")
+    ap.add_argument("--class-gib", type=float, default=4.0)
+    ap.add_argument("--rose-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
-    ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
-                    help="scans in flight: 2 overlaps a step's confirm/pack/gather with the next step's filter "
-                         "(+8..11%% throughput measured, but the per-kernel event timing then includes the overlap; "
-                         "the default keeps steps serial so that the roofline figures are those of the kernel alone)")
+    ap.add_argument("--pipeline-depth", type=int, default=0, choices=[0, 1, 2],
+                    help="scans in flight: 2 overlaps a step's record all-gather with the next step's scan; "
+                         "0 = 1 at N = 1 (the per-kernel figures are then those of the kernels alone), 2 at N > 1")
     args = ap.parse_args()
 
     import torch
@@ -367,10 +588,20 @@ def main():
 
     do_cpu = (rank == 0 and world == 1 and not args.no_cpu)
     main_res = run_workload(args.workload, args, rank, world, dist, do_cpu)
-    also = None
-    if not args.no_also:
-        other = "fdr10k" if args.workload == "teddy64" else "teddy64"
-        also = run_workload(other, args, rank, world, dist, do_cpu)
+    also = {}
+    if not args.no_also and world == 1:
+        for name in [a for a in args.also.split(",") if a]:
+            t0 = time.perf_counter()
+            try:
+                if name == "class256":
+                    also[name] = run_class256(args)
+                elif name == "rose1000":
+                    also[name] = run_rose1000(args)
+                elif name != args.workload:
+                    also[name] = run_workload(name, args, rank, world, dist, do_cpu)
+            except Exception as e:  # an extra line must not take the headline down with it
+                also[name] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"also.{name}: {time.perf_counter() - t0:.1f}s")
 
     if rank == 0:
         blocks_desc = "synthetic packets {64,128,256,576,1024,1460} B, 70% HTTP-like text / 30% random"
@@ -378,22 +609,18 @@ def main():
             "metric": "GB/s scanned (hsbench block mode)", "value": main_res["value"], "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: " + (
-                "64 literals len 4-8" if args.workload == "teddy64" else "10000 snort-like literals (8-byte suffixes)")
-                + f", {args.gib:g} GiB per GPU, block mode, {blocks_desc}",
-                "records": "16 B (block,end,id,lit)", "pipeline_depth": main_res["pipeline_depth"],
-                "sharding": f"{world} x independent shards"
-                + (", RCCL all-gather of records per step" if world > 1 else "")},
+            "config": {"workload": f"{args.workload}: {WORKLOAD_DESC[args.workload]}, {args.gib:g} GiB per GPU, block mode, {blocks_desc}",
+                       "records": "16 B (block,end,id,lit), delivery order", "pipeline_depth": main_res["pipeline_depth"],
+                       "sharding": f"{world} x independent shards"
+                       + (", RCCL all-gather of records per step" if world > 1 else "")},
             "matches_per_s": main_res["matches_per_s"], "matches_per_step": main_res["matches_per_step"],
             "roofline": main_res["roofline"], "table": main_res["table"],
         }
-        if "cpu_baseline" in main_res:
-            out["cpu_baseline"] = main_res["cpu_baseline"]
-        if "host_buffers" in main_res:
-            out["host_buffers"] = main_res["host_buffers"]
+        for k in ("cpu_baseline", "end_to_end_resident", "host_buffers", "exchange"):
+            if k in main_res:
+                out[k] = main_res[k]
         if also:
-            other = "fdr10k" if args.workload == "teddy64" else "teddy64"
-            out["also"] = {other: {k: also[k] for k in also}}
+            out["also"] = also
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -52,6 +52,9 @@ _SIGS = {
     "hsgpu_scratch_get_kernel_span": (C.c_int, [C.c_void_p, C.c_uint, C.POINTER(C.c_float)]),
     "hsgpu_scratch_get_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "hsgpu_hwlm_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, HWLM_CB, C.c_void_p, C.c_uint64]),
+    "hsgpu_hwlm_replay_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64,
+                                          C.POINTER(C.c_size_t)]),
+    "hsgpu_hwlm_count_cb": (C.c_uint64, [C.c_size_t, C.c_uint32, C.c_void_p]),
     "hsgpu_last_error": (C.c_char_p, []),
     "hsgpu_version": (C.c_char_p, []),
 }

@@ -359,11 +359,12 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     /* Few 3-byte keys beside 4-byte ones at stride 1 (a handful of short literals in a large
      * set): give each its whole filter word. The filter kernel then runs ONE class test per
      * lookup -- at stride 1 it is VALU-bound and the 3-byte test was ~30% of its instructions --
-     * and the price is a false-positive rate of keys / words <= 1% of lookups. Stride-2
-     * kernels are not VALU-bound: there the extra candidates cost more than the test
+     * and the price is a false-positive rate of keys / words <= 1% of lookups. At stride 2 only a
+     * handful of such keys are folded (<= 0.1% of the words: the 4-byte literals of a 64-literal set at
+     * their odd alignment); with hundreds of them the extra candidates cost more than the test
      * (measured, 1000 literals: 0.30 ms folded vs 0.27 ms not). */
-    if (!(tflags & (HSGPU_F_REPL | HSGPU_F_HAS_C | HSGPU_F_STRIDE2)) && (tflags & HSGPU_F_HAS_A) && (tflags & HSGPU_F_HAS_B) &&
-        !(flags & HSGPU_BUILD_NO_FOLD) && (uint64_t)keys[1].size() * 100 <= fwords)
+    if (!(tflags & (HSGPU_F_REPL | HSGPU_F_HAS_C)) && (tflags & HSGPU_F_HAS_A) && (tflags & HSGPU_F_HAS_B) &&
+        !(flags & HSGPU_BUILD_NO_FOLD) && (uint64_t)keys[1].size() * ((tflags & HSGPU_F_STRIDE2) ? 1000 : 100) <= fwords)
         tflags |= HSGPU_F_BFOLD;
     const uint32_t fshift = hsgpu_filter_shift(tflags, k);
     uint32_t ht_log2[2];

@@ -421,8 +421,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     }
     HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
     if (s->timing) s->n_timed++;
-    /* one (single-wavefront) workgroup per share of the corpus: its records sorted into place; the control block back to zero */
-    HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions), dim3(64),
+    /* one workgroup per share of the corpus: its records sorted into place; the control block back to zero */
+    HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions), dim3(256),
                             kargs, 0, stream));
     s->ctl_clean = true;
     return HSGPU_SUCCESS;
@@ -596,6 +596,31 @@ extern "C" int hsgpu_hwlm_replay(const hsgpu_hwlm_t *t, const hsgpu_match_t *rec
         if (!control) return HSGPU_HWLM_TERMINATED; /* fdr.c:719-721 */
     }
     return HSGPU_HWLM_SUCCESS;
+}
+
+/* the records of a whole batch: the sequential rules start afresh in every block (each block is a scan of
+ * its own), and a callback that returns 0 ends ITS block only */
+extern "C" int hsgpu_hwlm_replay_batch(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n, hsgpu_hwlm_cb cb,
+                                       void *ctx, uint64_t groups, size_t *n_terminated) {
+    if (!t || (n && !recs) || !cb) return HSGPU_HWLM_ERROR_UNKNOWN;
+    size_t term = 0;
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        while (j < n && recs[j].block == recs[i].block) j++;
+        const int rv = hsgpu_hwlm_replay(t, recs + i, j - i, cb, ctx, groups);
+        if (rv == HSGPU_HWLM_ERROR_UNKNOWN) return rv;
+        term += rv == HSGPU_HWLM_TERMINATED;
+        i = j;
+    }
+    if (n_terminated) *n_terminated = term;
+    return HSGPU_HWLM_SUCCESS;
+}
+
+/* hsbench's counting callback (tools/hsbench/engine_hyperscan.cpp:89-97) for the two replay functions:
+ * ctx = uint64_t counter */
+extern "C" uint64_t hsgpu_hwlm_count_cb(size_t, uint32_t, void *ctx) {
+    ++*(uint64_t *)ctx;
+    return ~0ull;
 }
 
 extern "C" int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *buf, size_t len,

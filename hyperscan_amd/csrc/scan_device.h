@@ -836,11 +836,14 @@ __device__ __forceinline__ void write_block_hints_batch(const uint64_t *off, uin
                                                         uint64_t n_hint, uint64_t b0, uint32_t lane) {
     uint64_t s[K], e[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
+    for (int k = 0; k < K; k++) { /* unconditional loads at clamped indices: one wait for all 2K of them */
         const uint64_t b = b0 + (uint64_t)k * 64 + lane;
-        s[k] = (b && b <= nblocks) ? off[b] : 0;
-        e[k] = b < nblocks ? off[b + 1] : 0;
+        s[k] = off[min(b, nblocks)];
+        e[k] = off[min(b + 1, nblocks)];
     }
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        if (b0 + (uint64_t)k * 64 + lane == 0) s[k] = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) write_block_hints_of(s[k], e[k], nblocks, hint, n_hint, b0 + (uint64_t)k * 64 + lane, lane);
 }
@@ -913,9 +916,25 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         return c;
     };
 
-    /* The first tiles are requested before anything else: the corpus stream starts while the filter image
-     * is copied into LDS and the block hints are written (with both in front, the memory pipeline idled
-     * for the first 25-30 us of every scan). */
+    /* Prologue, ordered by when each load is needed (loads of one wavefront complete in issue order): the
+     * filter image for LDS (L2 hits, wanted first), the block offsets of this wavefront's hints, then the
+     * first tiles of the corpus, which stay in flight while the image is written to LDS and the hints are
+     * stored. (With the LDS copy and the hints in front, one load and one wait at a time, the memory pipeline
+     * idled for the first 25-30 us of every scan.) */
+    constexpr int IMG = 8; /* 16-byte pieces of the image per thread in the first batch: 128 KiB / 1024 threads */
+    const uint4 *img_src = (const uint4 *)(args.blob + args.t_off_filter);
+    uint4 img[IMG];
+#pragma unroll
+    for (int u = 0; u < IMG; u++) {
+        const uint32_t i = threadIdx.x + u * blockDim.x;
+        img[u] = i < nw / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
+    }
+    const bool hints = !FUSED && args.hint_in_filter;
+    constexpr int HK = 8; /* every lane takes 8 consecutive blocks: 9 offsets, 512 blocks per wavefront and step */
+    const uint64_t hb0 = ((uint64_t)wave_global * 64 + lane) * HK;
+    uint64_t ho[HK + 1];
+#pragma unroll
+    for (int k = 0; k <= HK; k++) ho[k] = hints ? args.off[min(hb0 + k, args.nblocks)] : 0; /* clamped: no branches */
     const bool streaming = tile < tile_end;
     Chunk c0, c1, c2, c3, c4, c5, c6, c7;
     c0.d = c1.d = c2.d = c3.d = c4.d = c5.d = c6.d = c7.d = make_uint4(0, 0, 0, 0);
@@ -929,22 +948,26 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         c5 = issue(tile + 5), c6 = issue(tile + 6);
 #endif
     }
-
-    /* stage the filter(s) in LDS: once per workgroup, 16 B per lane per step */
-    {
-        const uint4 *src = (const uint4 *)(args.blob + args.t_off_filter);
-        for (uint32_t i = threadIdx.x; i < nw / 4; i += blockDim.x) ((uint4 *)filter)[i] = src[i];
-        if (HAS_C) {
-            const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
-            for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
-        }
+    /* the filter image into LDS: once per workgroup */
+#pragma unroll
+    for (int u = 0; u < IMG; u++) {
+        const uint32_t i = threadIdx.x + u * blockDim.x;
+        if (i < nw / 4) ((uint4 *)filter)[i] = img[u];
     }
-    /* two-phase: the confirm kernel's block hints are written here, 512 blocks per wavefront and step,
-     * beside the LDS copy (a hint kernel on a side stream needed a fork/join pair of cross-stream waits
-     * around the confirm launch) */
-    if (!FUSED && args.hint_in_filter)
-        for (uint64_t b0 = (uint64_t)wave_global * 512; b0 <= args.nblocks; b0 += (uint64_t)n_waves * 512)
-            write_block_hints_batch<8>(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, b0, lane);
+    for (uint32_t i = threadIdx.x + IMG * blockDim.x; i < nw / 4; i += blockDim.x) ((uint4 *)filter)[i] = img_src[i];
+    if (HAS_C) {
+        const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
+        for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
+    }
+    /* two-phase: the confirm kernel's block hints are written here (a hint kernel on a side stream needed a
+     * fork/join pair of cross-stream waits around the confirm launch) */
+    if (hints) {
+#pragma unroll
+        for (int k = 0; k < HK; k++)
+            write_block_hints_of(hb0 + k ? ho[k] : 0, ho[k + 1], args.nblocks, (uint32_t *)args.hint, args.n_hint, hb0 + k, lane);
+        for (uint64_t w0 = (uint64_t)wave_global + n_waves; w0 * (64 * HK) <= args.nblocks; w0 += n_waves)
+            write_block_hints_batch<HK>(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, w0 * (64 * HK), lane);
+    }
     __syncthreads();
 
     Tables t;
@@ -1126,12 +1149,13 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
  * the records of that share, and the shares follow each other in region order:
  *   record_scan  one workgroup: exclusive scan of the region fills (where each region's records go in the
  *                output), *count, "is the output complete"
- *   record_sort  one workgroup per share: gathers the records of its regions, sorts them (bitonic network in
- *                LDS up to SORT_LDS records, in place in the output beyond) and writes them to their place;
+ *   record_sort  one workgroup per share: gathers the records of its regions, sorts them (ranks by counting
+ *                up to 64 records, a bitonic network in LDS up to SORT_LDS, in place in the output beyond)
+ *                and writes them to their place;
  *                then every control word goes back to zero for the next scan.
  * No global atomics and no global sort: a share holds a few thousand records at most on ordinary input. */
 constexpr uint32_t SORT_LDS = 1024; /* largest share sorted in LDS (16 KiB of records) */
-constexpr uint32_t SORT_THREADS = 64;
+constexpr uint32_t SORT_THREADS = 256;
 
 __device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (block, end, literal index) */
     if (a.x != b.x) return a.x < b.x;
@@ -1139,34 +1163,33 @@ __device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (blo
     return a.w < b.w;
 }
 
-/* one workgroup: exclusive scan of the region fills IN REGION ORDER (thread t owns the run of regions
- * [t * per, (t + 1) * per)), the total into *count */
+/* one workgroup: exclusive scan of the region fills IN REGION ORDER, the total into *count. Wavefront w owns
+ * the run of regions [w * run, (w + 1) * run), run a multiple of 64, and walks it 64 regions at a time
+ * (coalesced reads, a shuffle scan per step). */
 __global__ __launch_bounds__(1024) void record_scan_kernel(HsgpuScanArgs args) {
     __shared__ unsigned long long part[32];
     __shared__ uint32_t any_overflow;
-    const uint32_t n = args.rec_regions, tid = threadIdx.x;
+    const uint32_t n = args.rec_regions, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint2 *counts = (const uint2 *)args.rec_counts;
     if (tid == 0) any_overflow = 0;
     __syncthreads();
-    const uint32_t per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
+    const uint32_t run = (((n + 15) / 16) + 63) & ~63u, lo = min(n, wv * run), hi = min(n, lo + run);
     unsigned long long sum = 0;
     bool ovf = false;
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint2 c = counts[i];
-        ovf |= (unsigned long long)c.x + c.y > args.rec_cap;
-        sum += (unsigned long long)c.x + c.y;
-    }
-    if (ovf) any_overflow = 1;
-    /* inclusive scan of the 1024 per-thread sums: shuffles inside each wavefront,
-     * then the 16 wavefront totals, two barriers in all */
-    const uint32_t lane = tid & 63, wv = tid >> 6;
-    unsigned long long incl = sum;
+    for (uint32_t i0 = lo + lane; i0 < hi; i0 += 512) { /* 8 independent loads in flight per lane */
+        uint2 c[8];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long v = __shfl_up(incl, d);
-        if (lane >= (uint32_t)d) incl += v;
+        for (int u = 0; u < 8; u++) c[u] = i0 + 64 * u < hi ? counts[i0 + 64 * u] : make_uint2(0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            ovf |= (unsigned long long)c[u].x + c[u].y > args.rec_cap;
+            sum += (unsigned long long)c[u].x + c[u].y;
+        }
     }
-    if (lane == 63) part[wv] = incl;
+    if (__ballot(ovf) && lane == 0) any_overflow = 1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) part[wv] = sum;
     __syncthreads();
     if (wv == 0) {
         unsigned long long w = lane < 16 ? part[lane] : 0;
@@ -1178,15 +1201,27 @@ __global__ __launch_bounds__(1024) void record_scan_kernel(HsgpuScanArgs args) {
         if (lane < 16) part[16 + lane] = w; /* inclusive totals of wavefronts 0..lane */
     }
     __syncthreads();
-    const unsigned long long before_wave = wv ? part[16 + wv - 1] : 0;
-    unsigned long long run = before_wave + incl - sum; /* exclusive prefix of this thread */
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint2 c = counts[i];
-        args.rec_offsets[i] = run;
-        run += (unsigned long long)c.x + c.y;
+    unsigned long long carry = wv ? part[16 + wv - 1] : 0; /* records in front of this wavefront's run */
+    for (uint32_t i0 = lo; i0 < hi; i0 += 256) { /* 4 steps' loads before the first scan */
+        uint2 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = i0 + 64 * u + lane < hi ? counts[i0 + 64 * u + lane] : make_uint2(0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + 64 * u + lane;
+            const unsigned long long mine = (unsigned long long)c[u].x + c[u].y;
+            unsigned long long incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long v = __shfl_up(incl, d);
+                if (lane >= (uint32_t)d) incl += v;
+            }
+            if (i < hi) args.rec_offsets[i] = carry + incl - mine;
+            carry += __shfl(incl, 63);
+        }
     }
-    if (tid == 1023) {
-        const unsigned long long total = before_wave + incl;
+    if (tid == 0) {
+        const unsigned long long total = part[16 + 15];
         args.rec_offsets[n] = total;
         /* a region that ran out of space lost records; its fill counters kept
          * counting, so the total is still exact: report it, but never a value
@@ -1226,19 +1261,36 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
         const uint32_t n = (uint32_t)(args.rec_offsets[last] - base);
         if (n && n <= args.cap) { /* (complete: the shares add up to at most cap) */
             const bool in_lds = n <= SORT_LDS;
-            /* gather: wavefront per region, front records then the ones spilled to its back */
-            for (uint32_t r = first + wv; r < last; r += SORT_THREADS / 64) {
-                const uint32_t f = args.rec_counts[2 * r], b = args.rec_counts[2 * r + 1];
-                const uint32_t at = (uint32_t)(args.rec_offsets[r] - base);
-                const uint4 *region = args.rec_stage + (uint64_t)r * args.rec_cap;
-                for (uint32_t i = lane; i < f + b; i += 64) {
-                    const uint4 rec = i < f ? region[i] : region[args.rec_cap - 1 - (i - f)];
-                    if (in_lds) buf[at + i] = rec;
-                    else out[base + at + i] = rec;
+            /* gather: the fills of all regions of the share at once (lane r = region first + r), then every lane
+             * walks the share's records: which region, which slot (front records, then the ones spilled to the back) */
+            const uint32_t nreg = last - first; /* <= 64 */
+            const uint2 my = lane < nreg ? ((const uint2 *)args.rec_counts)[first + lane] : make_uint2(0, 0);
+            const uint32_t my_at = lane < nreg ? (uint32_t)(args.rec_offsets[first + lane] - base) : n;
+            for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += SORT_THREADS) { /* whole wavefronts: shuffles below */
+                uint32_t r = 0;
+                for (uint32_t k = 1; k < nreg; k++) r += __shfl(my_at, k) <= i ? 1u : 0u; /* the last region starting at or before i */
+                const uint32_t f = __shfl(my.x, r), at = __shfl(my_at, r), j = i - at;
+                if (i < n) {
+                    const uint4 *region = args.rec_stage + (uint64_t)(first + r) * args.rec_cap;
+                    const uint4 rec = j < f ? region[j] : region[args.rec_cap - 1 - (j - f)];
+                    if (in_lds) buf[i] = rec;
+                    else out[base + i] = rec;
                 }
             }
             __syncthreads();
-            if (in_lds) {
+            if (n <= 64) {
+                /* rank by counting: one record per lane of the first wavefront, every lane walks the share
+                 * (all lanes read the same LDS address: a broadcast); no barriers, no compare-exchange chains */
+                if (tid < n) {
+                    const uint4 mine = buf[tid];
+                    uint32_t rank = 0;
+                    for (uint32_t q = 0; q < n; q++) { /* equal keys cannot occur; if they did, the gather order keeps ranks distinct */
+                        const uint4 o = buf[q];
+                        rank += (rec_less(o, mine) || (q < tid && !rec_less(mine, o))) ? 1u : 0u;
+                    }
+                    out[base + rank] = mine;
+                }
+            } else if (in_lds) {
                 bitonic_sort(buf, n);
                 for (uint32_t i = tid; i < n; i += SORT_THREADS) out[base + i] = buf[i];
             } else {
@@ -1255,8 +1307,8 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
         for (uint32_t i = 2 * first + tid; i < 2 * last; i += SORT_THREADS) args.rec_counts[i] = 0;
     }
     uint32_t v = 0, o = 0;
-    if (args.cand_counts) {
-        for (uint32_t i = blockIdx.x * SORT_THREADS + tid; i <= args.cand_waves; i += gridDim.x * SORT_THREADS) {
+    if (args.cand_counts) { /* 1024 counters per workgroup: only a handful of workgroups touch the statistics word */
+        for (uint32_t i = blockIdx.x * 1024 + tid; i < min(args.cand_waves + 1, (blockIdx.x + 1) * 1024); i += SORT_THREADS) {
             const uint32_t c = args.cand_counts[i];
             if (i == args.cand_waves) o = c;
             else v += c;

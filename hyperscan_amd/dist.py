@@ -64,6 +64,46 @@ def all_gather_records(records, count, block_base, dist, world, device=None):
     return torch.cat(parts, dim=0), counts
 
 
+class RecordExchange:
+    """The per-step exchange of bench.py --gpus N with nothing allocated and no host synchronisation
+    inside the step: one all-gather of {count, first global block} per rank and one all-gather of the
+    record buffers padded to `rows` rows (a fixed size agreed before the timed steps, so no rank has to
+    learn another rank's count before it can post its receive). Counts stay on the device; `compact()`
+    (which synchronises) turns the last step's buffers into the rows of all ranks with GLOBAL block
+    indices, ordered by rank -- the order of the corpus, since shards are contiguous block ranges.
+
+    Block indices are 32 bits in a record (hsgpu_match_t.block): the add of the rank's first block wraps
+    like uint32 arithmetic, so global indices are exact up to 2^32 blocks per job."""
+
+    def __init__(self, dist, world, rank, device, rows, block_base):
+        import torch
+
+        self.dist, self.world, self.rank, self.rows = dist, world, rank, int(rows)
+        self.cnt_in = torch.tensor([0, int(block_base)], dtype=torch.int64, device=device)
+        self.cnt_out = torch.zeros((world, 2), dtype=torch.int64, device=device)
+        self.rec_out = torch.zeros((world, self.rows, 4), dtype=torch.int32, device=device)
+
+    def step(self, records, d_count):
+        """records: int32 [>= rows, 4] device tensor of this rank's scan; d_count: int64 [1] device tensor
+        the scan wrote its match count to. Enqueues both collectives on the current stream."""
+        self.cnt_in[0:1].copy_(d_count[0:1], non_blocking=True)
+        self.dist.all_gather_into_tensor(self.cnt_out.view(-1), self.cnt_in)
+        self.dist.all_gather_into_tensor(self.rec_out.view(-1, 4), records[: self.rows])
+
+    def compact(self):
+        import torch
+
+        cnt = self.cnt_out.cpu()
+        counts, bases = cnt[:, 0].tolist(), cnt[:, 1].tolist()
+        assert max(counts) <= self.rows, "exchange buffer smaller than a rank's match count"
+        parts = []
+        for r in range(self.world):
+            p = self.rec_out[r, : counts[r]].clone()
+            p[:, 0] += int(bases[r]) - (1 << 32 if bases[r] >= 1 << 31 else 0)  # uint32 add in an int32 tensor
+            parts.append(p)
+        return torch.cat(parts, dim=0), counts
+
+
 def _exchange_counts(count, block_base, dist, world, device):
     import torch
 

@@ -232,6 +232,21 @@ def hwlm_exec_batch(table, scratch, base, off, start=0, cap=None):
         return out[: n.value]
 
 
+def hwlm_replay_count(table, recs, groups=HWLM_ALL_GROUPS):
+    """The sorted records of a batch (uint32 [n, 4] or MATCH_DTYPE array) through hsgpu_hwlm_replay_batch into
+    the library's native counting callback -- hsbench's delivery path (engine_hyperscan.cpp:89-97) -- and the
+    number of callbacks delivered."""
+    a = np.ascontiguousarray(recs)
+    n = a.shape[0]
+    lib = table._lib
+    cnt = C.c_uint64(0)
+    rv = lib.hsgpu_hwlm_replay_batch(table._h, a.ctypes.data, n, C.cast(lib.hsgpu_hwlm_count_cb, C.c_void_p),
+                                     C.cast(C.byref(cnt), C.c_void_p), groups, None)
+    if rv != HWLM_SUCCESS:
+        raise HsgpuError(rv, "hsgpu_hwlm_replay_batch")
+    return int(cnt.value)
+
+
 def hwlm_scan_dev(table, scratch, corpus_ptr, total_bytes, off_ptr, nblocks, out_ptr, cap, count_ptr,
                   start=0, stream=None):
     """Device-resident hot path: raw device pointers in, asynchronous."""

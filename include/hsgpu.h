@@ -185,6 +185,13 @@ void hsgpu_match_sort_host(hsgpu_match_t *recs, size_t n);
  * sequential semantics (groups gate, noruns, terminate). Host only. */
 int hsgpu_hwlm_replay(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n,
                       hsgpu_hwlm_cb cb, void *ctx, uint64_t groups);
+/* The same for the sorted records of a whole batch (hsgpu_hwlm_scan_dev / _exec_batch): the rules start
+ * afresh in every block, a callback that returns 0 ends its own block only; *n_terminated (may be NULL)
+ * counts those blocks. Returns HSGPU_HWLM_SUCCESS or HSGPU_HWLM_ERROR_UNKNOWN. */
+int hsgpu_hwlm_replay_batch(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n, hsgpu_hwlm_cb cb,
+                            void *ctx, uint64_t groups, size_t *n_terminated);
+/* hsbench's counting callback (tools/hsbench/engine_hyperscan.cpp:89-97): ctx = uint64_t counter. */
+uint64_t hsgpu_hwlm_count_cb(size_t end, uint32_t id, void *ctx);
 
 /* ---- character-class scanning ------------------------------------------------------
  * The GPU form of the reference's class accelerators: shuftiExec/rshuftiExec

@@ -381,6 +381,113 @@ int hsref_hwlm_bench_threads(void *h, const uint8_t *base, const uint64_t *off, 
     return 0;
 }
 
+static m128 ld128(const uint8_t *p) {
+    m128 v;
+    memcpy(&v, p, 16);
+    return v;
+}
+
+/* Config 4's CPU side: for every block (line) and every class, the first and the last member of the class --
+ * what the reference's accelerators are asked for (shuftiExec / rshuftiExec, truffleExec / rtruffleExec:
+ * src/nfa/shufti.c:150-199, src/nfa/truffle.c:118-165). classes: n x 33 bytes {kind 0 shufti / 1 truffle,
+ * mask lo[16] (mask1), mask hi[16] (mask2)}. Same thread model as hsref_hwlm_bench_threads. out[0] = corpus bytes
+ * walked (all threads, all passes; one pass = every class over every block), out[1] = wall seconds,
+ * out[2] = a checksum of the first/last offsets of one pass, out[3] = passes of the slowest thread. */
+struct ClassBenchArg {
+    const uint8_t *classes;
+    size_t n_classes;
+    const uint8_t *base;
+    const uint64_t *off;
+    size_t lo, hi;
+    double seconds;
+    int cpu;
+    pthread_barrier_t *bar;
+    uint64_t bytes, checksum, passes;
+    double t_begin, t_end;
+};
+static void *class_bench_thread(void *p) {
+    ClassBenchArg *a = (ClassBenchArg *)p;
+    if (a->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(a->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    pthread_barrier_wait(a->bar);
+    a->t_begin = now_s();
+    const double deadline = a->t_begin + a->seconds;
+    const uint64_t slice = a->off[a->hi] - a->off[a->lo];
+    do {
+        uint64_t sum = 0;
+        for (size_t c = 0; c < a->n_classes; c++) {
+            const uint8_t *cl = a->classes + 33 * c;
+            const m128 lo = ld128(cl + 1), hi = ld128(cl + 17);
+            for (size_t i = a->lo; i < a->hi; i++) {
+                const uint8_t *b = a->base + a->off[i], *e = a->base + a->off[i + 1];
+                const uint8_t *f = cl[0] ? truffleExec(lo, hi, b, e) : shuftiExec(lo, hi, b, e);
+                const uint8_t *l = cl[0] ? rtruffleExec(lo, hi, b, e) : rshuftiExec(lo, hi, b, e);
+                sum += (uint64_t)(f - b) + 3 * (uint64_t)(l - b + 1);
+            }
+        }
+        a->checksum = sum;
+        a->bytes += slice;
+        a->passes++;
+    } while (now_s() < deadline);
+    a->t_end = now_s();
+    return nullptr;
+}
+int hsref_class_bench_threads(const uint8_t *classes, size_t n_classes, const uint8_t *base, const uint64_t *off,
+                              size_t nblocks, int nthreads, double seconds, int pin, double out[4]) {
+    if (nthreads < 1 || nblocks == 0 || n_classes == 0) return -1;
+    if ((size_t)nthreads > nblocks) nthreads = (int)nblocks;
+    std::vector<ClassBenchArg> args((size_t)nthreads);
+    std::vector<pthread_t> th((size_t)nthreads);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, (unsigned)nthreads);
+    std::vector<int> cpus;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (pin && sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+    const uint64_t total = off[nblocks] - off[0];
+    size_t lo = 0;
+    for (int i = 0; i < nthreads; i++) {
+        const uint64_t want = off[0] + total * (uint64_t)(i + 1) / (uint64_t)nthreads;
+        size_t hi = lo;
+        while (hi < nblocks && (off[hi + 1] <= want || hi == lo)) hi++;
+        if (i == nthreads - 1) hi = nblocks;
+        args[(size_t)i] = ClassBenchArg{classes, n_classes, base, off, lo, hi, seconds,
+                                        cpus.empty() ? -1 : cpus[(size_t)i % cpus.size()], &bar, 0, 0, 0, 0.0, 0.0};
+        lo = hi;
+    }
+    int started = 0;
+    for (; started < nthreads; started++)
+        if (pthread_create(&th[(size_t)started], nullptr, class_bench_thread, &args[(size_t)started]) != 0) break;
+    if (started != nthreads) {
+        for (int i = 0; i < started; i++) pthread_cancel(th[(size_t)i]);
+        for (int i = 0; i < started; i++) pthread_join(th[(size_t)i], nullptr);
+        pthread_barrier_destroy(&bar);
+        return -1;
+    }
+    for (int i = 0; i < nthreads; i++) pthread_join(th[(size_t)i], nullptr);
+    pthread_barrier_destroy(&bar);
+    double t0 = args[0].t_begin, t1 = args[0].t_end;
+    uint64_t bytes = 0, sum = 0, min_passes = ~0ull;
+    for (const ClassBenchArg &a : args) {
+        t0 = a.t_begin < t0 ? a.t_begin : t0;
+        t1 = a.t_end > t1 ? a.t_end : t1;
+        bytes += a.bytes;
+        sum += a.checksum;
+        min_passes = a.passes < min_passes ? a.passes : min_passes;
+    }
+    out[0] = (double)bytes;
+    out[1] = t1 - t0;
+    out[2] = (double)(sum & 0xffffffffffffull);
+    out[3] = (double)min_passes;
+    return 0;
+}
+
 /* the ISA this copy of the reference was compiled for (the Teddy / FDR variants are chosen
  * at compile time, src/util/arch.h) */
 const char *hsref_build_isa(void) {
@@ -415,11 +522,6 @@ void hsref_truffle2cr(const uint8_t m1[16], const uint8_t m2[16], uint8_t bitmap
     }
 }
 
-static m128 ld128(const uint8_t *p) {
-    m128 v;
-    memcpy(&v, p, 16);
-    return v;
-}
 
 /* All exec wrappers return an offset relative to buf (len = "not found" for
  * forward scans; -1 for reverse scans), see src/nfa/shufti.h:40-52. */

@@ -59,6 +59,15 @@ def _worker(rank, world, port, out_path):
     # the exact-size exchanges deliver the same rows in the same order
     exact, counts2 = hd.all_gather_records_exact(t, recs.size, base, dist, world, rank)
     assert counts2 == counts and torch.equal(exact, allr)
+    # the bench's per-step form: fixed-size buffers, counts on the "device", two steps through the same buffers
+    rows = 4096
+    pad = torch.zeros((rows, 4), dtype=torch.int32)
+    pad[: recs.size] = t[: recs.size]
+    ex = hd.RecordExchange(dist, world, rank, torch.device("cpu"), rows, base)
+    for _ in range(2):
+        ex.step(pad, torch.tensor([recs.size], dtype=torch.int64))
+    fixed, counts4 = ex.compact()
+    assert counts4 == counts and torch.equal(fixed, allr)
     for root in range(world):
         rooted, counts3 = hd.gather_records_to_root(t, recs.size, base, dist, world, rank, root=root)
         assert counts3 == counts

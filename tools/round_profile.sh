@@ -1,16 +1,19 @@
 #!/bin/bash
-# tools/round_profile.sh <round-tag> -- on the GPU box: the driver's bench command under
-# rocprofv3 (--kernel-trace --stats), then separate PMC passes (FETCH_SIZE / WRITE_SIZE) of
-# the same command; summaries are written under gpurun_out/<tag>/ for copying to profiles/.
-TAG=${1:-r01}
+# tools/round_profile.sh <round-tag> -- on the GPU box: the driver's bench command (headline workload, no CPU
+# leg) under rocprofv3 (--kernel-trace --stats), then separate PMC passes of the same command: FETCH_SIZE,
+# WRITE_SIZE, and two sets of SQ counters for the filter kernels; summaries are written under
+# gpurun_out/<tag>/ for copying to profiles/.
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc_write.err
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --also teddy64"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc_write.err
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- $CMD > /dev/null 2> $OUT/pmc_sq1.err
+timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- $CMD > /dev/null 2> $OUT/pmc_sq2.err
 python - <<PY
 import csv, glob, collections, re, json
 out="$OUT"
@@ -18,14 +21,24 @@ lines=[]
 for f in sorted(glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True)):
     lines.append(open(f).read())
 open(out+"/kernel_stats.csv","w").write("".join(lines))
-agg=collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("pmc_fetch","pmc_write"):
-    for f in sorted(glob.glob(out+"/"+d+"/**/*counter_collection.csv", recursive=True)):
-        for r in csv.DictReader(open(f)):
-            m=re.search(r"(hwlm_\w+<[^>]*>|record_\w+|block_hint_kernel|control_reset_kernel)", r.get("Kernel_Name",""))
-            if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-summ={k:{c:{"avg_KB":sum(x)/len(x),"n":len(x)} for c,x in v.items()} for k,v in agg.items()}
+def collect(dirs):
+    agg=collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for f in sorted(glob.glob(out+"/"+d+"/**/*counter_collection.csv", recursive=True)):
+            for r in csv.DictReader(open(f)):
+                m=re.search(r"(hwlm_\w+<[^>]*>|record_\w+|block_hint_kernel)", r.get("Kernel_Name",""))
+                if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+summ={k:{c:{"avg_KB":sum(x)/len(x),"n":len(x)} for c,x in v.items()} for k,v in collect(("pmc_fetch","pmc_write")).items()}
 json.dump(summ, open(out+"/pmc_summary.json","w"), indent=1)
-print(open(out+"/kernel_stats.csv").read()[:3000])
-print(json.dumps(summ, indent=1)[:3000])
+sq={k:{c:round(sum(x)/len(x),1) for c,x in sorted(v.items())} for k,v in collect(("pmc_sq1","pmc_sq2")).items() if "filter" in k}
+for k,v in sq.items():
+    if v.get("SQ_LDS_IDX_ACTIVE"): v["lds_conflict_share_of_lds_cycles"]=round(v.get("SQ_LDS_BANK_CONFLICT",0)/v["SQ_LDS_IDX_ACTIVE"],3)
+    if v.get("SQ_WAVE_CYCLES"):
+        for c in ("SQ_ACTIVE_INST_VALU","SQ_ACTIVE_INST_LDS","SQ_WAIT_INST_ANY","SQ_WAIT_ANY"):
+            if c in v: v[c+"_share_of_wave_cycles"]=round(v[c]/v["SQ_WAVE_CYCLES"],3)
+json.dump(sq, open(out+"/filter_sq.json","w"), indent=1)
+print(open(out+"/kernel_stats.csv").read()[:2500])
+print(json.dumps(summ, indent=1)[:2500])
+print(json.dumps(sq, indent=1)[:3000])
 PY

@@ -18,12 +18,14 @@ struct ExpArgs {
     const uint32_t *table; /* 128 KiB filter image */
     uint32_t super_shift, flog2, hmask;
     unsigned long long *hits;
+    uint4 *cand; /* SPILL: candidate regions as in the product, cand_cap entries per wavefront */
+    uint32_t cand_cap;
 };
 
 // MODE 0: no lookups (xor the bytes), 1: classic stride-2 one-bit (teddy64 shape), 2: classic stride-1 two-bit
 // blind (fdr10k shape), 3: pair filter.  AUX: buffer-load cache policy bits.  EARLY: first tiles requested
 // before the filter image is staged in LDS.
-template <int STAGES, int AUX, int MODE, bool EARLY, int MAP = 0>
+template <int STAGES, int AUX, int MODE, bool EARLY, int MAP = 0, bool SPILL = false>
 __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x & 63;
@@ -86,6 +88,13 @@ __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
     f.c2base = nw * 4;
     f.hmask = args.hmask;
     uint32_t nhit = 0, x = 0;
+    HsgpuScanArgs pa;
+    pa.cand_cap = args.cand_cap;
+    pa.fold_shift = 0;
+    SpillState sp;
+    sp.region = args.cand + 2ull * (blockIdx.x * (blockDim.x >> 6) + wave) * args.cand_cap;
+    sp.written = 0;
+    sp.overflow = 0;
     while (tile < tile_end) {
 #pragma unroll
         for (int s = 0; s < STAGES; s++) {
@@ -96,17 +105,23 @@ __global__ __launch_bounds__(1024) void exp_kernel(ExpArgs args) {
             else if (MODE == 1) acc = filter_chunk<true, false, false, false, false, true, false>(cur, f);
             else if (MODE == 2) acc = filter_chunk<true, false, false, false, true, false, true>(cur, f);
             else acc = pair_filter_chunk(cur, f);
-            const unsigned long long bal = __ballot(acc != 0);
-            if (bal) nhit += __popcll(bal), x ^= acc;
+            if (SPILL) {
+                spill(pa, sp, (tile << 10) + lane * 16, acc, cur);
+            } else {
+                const unsigned long long bal = __ballot(acc != 0);
+                if (bal) nhit += __popcll(bal), x ^= acc;
+            }
             tile += step; /* tiles past the end have empty descriptors: zeros, no hits */
         }
     }
+    if (SPILL) nhit = sp.written;
     if (lane == 0 && (nhit | x)) atomicAdd(args.hits, (unsigned long long)nhit);
 }
 
 typedef void (*kfn)(ExpArgs);
 struct Variant { const char *name; kfn f; };
 #define V(S, A, M, E) {"stages=" #S " aux=" #A " mode=" #M " early=" #E, exp_kernel<S, A, M, E>}
+#define VS(S, A, M, E) {"stages=" #S " aux=" #A " mode=" #M " early=" #E " WAVE-BLOCKED SPILL", exp_kernel<S, A, M, E, 2, true>}
 #define VW(S, A, M, E) {"stages=" #S " aux=" #A " mode=" #M " early=" #E " WAVE-BLOCKED", exp_kernel<S, A, M, E, 2>}
 #define VB(S, A, M, E) {"stages=" #S " aux=" #A " mode=" #M " early=" #E " BLOCKED", exp_kernel<S, A, M, E, 1>}
 
@@ -118,6 +133,9 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&d_corpus, total + 64));
     CHECK(hipMalloc(&d_table, 131072));
     CHECK(hipMalloc(&d_hits, 8));
+    uint4 *d_cand;
+    const uint32_t cand_cap = 8192; /* per wavefront; 16384 wavefronts at most */
+    CHECK(hipMalloc(&d_cand, (size_t)16384 * cand_cap * 32));
     {   // random text-like bytes; table with ~0.05% of bits set
         std::vector<uint8_t> h(total);
         uint64_t s = 88172645463325252ull;
@@ -137,7 +155,7 @@ int main(int argc, char **argv) {
         V(8, 2, 0, false), V(8, 2, 1, false), V(8, 2, 3, false),
         V(8, 0, 1, true), V(4, 0, 1, false), V(12, 0, 1, false), V(12, 0, 0, false), V(12, 2, 1, false),
         VB(8, 0, 0, false), VB(8, 0, 1, false), VB(8, 0, 2, false), VB(8, 2, 0, false), VB(8, 2, 1, false), VB(4, 0, 1, false),
-        VW(8, 0, 0, false), VW(8, 0, 1, false), VW(8, 0, 2, false), VW(8, 2, 1, false), VW(4, 0, 1, false), VW(8, 0, 3, false), VB(8, 0, 3, false),
+        VW(8, 0, 0, false), VW(8, 0, 1, false), VW(8, 0, 2, false), VW(8, 2, 1, false), VW(4, 0, 1, false), VW(8, 0, 3, false), VB(8, 0, 3, false), VS(8, 0, 1, false), VS(8, 0, 2, false), VS(4, 0, 1, false),
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -154,7 +172,7 @@ int main(int argc, char **argv) {
         for (auto &v : vs) {
             if (one && strcmp(v.name, "stages=8 aux=0 mode=1 early=false")) continue;
             ExpArgs a;
-            a.corpus = d_corpus; a.total = total; a.table = d_table; a.hits = d_hits;
+            a.corpus = d_corpus; a.total = total; a.table = d_table; a.hits = d_hits; a.cand = d_cand; a.cand_cap = cand_cap;
             a.super_shift = g.threads == 1024 ? 14 : g.threads == 512 ? 13 : 12;
             a.flog2 = (strstr(v.name, "mode=3") ? 14 : 15); a.hmask = 0x1fdfdf;
             float best = 1e9, sum = 0;
