@@ -40,8 +40,10 @@ _SIGS = {
     "hsgpu_hwlm_deserialize": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "hsgpu_scratch_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "hsgpu_scratch_free": (None, [C.c_void_p]),
-    "hsgpu_hwlm_exec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, HWLM_CB,
-                                  C.c_void_p, C.c_uint64]),
+    "hsgpu_hwlm_exec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, HWLM_CB, C.c_void_p,
+                                  C.c_uint64]),
+    "hsgpu_scratch_set_context": (None, [C.c_void_p, C.c_void_p]),
+    "hsgpu_scratch_get_context": (C.c_void_p, [C.c_void_p]),
     "hsgpu_hwlm_exec_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsgpu_hwlm_scan_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,

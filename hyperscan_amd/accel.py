@@ -83,6 +83,10 @@ def _lib():
         lib.hsgpu_pair_scan_dev.argtypes = [C.POINTER(_Pair), C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p,
                                             C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+        lib.hsgpu_hwlm_forward_skip_dev.restype = C.c_int
+        lib.hsgpu_hwlm_forward_skip_dev.argtypes = [C.POINTER(_Accel), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                    C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p]
         lib._class_sigs = True
     return lib
 
@@ -256,6 +260,7 @@ class ForwardAccel:
     """The pre-skip scheme of a literal set (buildForwardAccel, rose_build_lit_accel.cpp:459-465)."""
 
     def __init__(self, c):
+        self._c = c
         self.type, self.offset, self.c1, self.c2 = c.type, c.offset, c.c1, c.c2
         self.mask_lo, self.mask_hi = bytes(c.mask_lo), bytes(c.mask_hi)
 
@@ -283,26 +288,26 @@ class ForwardAccel:
         return None
 
 
-def forward_skip(fa, d_corpus, total, d_off, nblocks, start=0):
-    """do_accel_block (src/hwlm/hwlm.c:48-99) for a whole batch: per block, the earliest offset at
-    which a literal of the set could start -- the accelerator's first hit minus its offset, never
-    below `start`; blocks with fewer than 16 bytes after `start` are left alone, as is everything
-    when there is no scheme. -> int64 tensor [nblocks] (block length = nothing can match)."""
+def forward_skip(fa, d_corpus, total, d_off, nblocks, start=0, stream=None):
+    """do_accel_block (src/hwlm/hwlm.c:80-99) for a whole batch, through hsgpu_hwlm_forward_skip_dev:
+    per block with at least 16 bytes after its start, max(0, hit - offset) where hit is
+    run_hwlm_accel's return value over [start, len) (the block length when nothing is found);
+    other blocks, and sets without a scheme, keep their start. `start`: one int for every block or
+    an int32/uint32 device tensor [nblocks]. -> int64 tensor [nblocks]."""
     import torch
 
-    off = d_off.to(torch.int64)
-    lens = off[1:] - off[:-1]
-    base = torch.full_like(lens, int(start))
-    sc = fa.scanner()
-    if sc is None:
-        return base
-    if sc[0] == "class":
-        _bm, first, _l = class_scan([sc[1]], d_corpus, total, d_off, nblocks, True, False)
-    else:
-        _bm, first, _l = pair_scan([sc[1]], d_corpus, total, d_off, nblocks, True, False)
-    hit = first[0].to(torch.int64) & 0xFFFFFFFF
-    # run_hwlm_accel scans [start, len); our first hit is over the whole block: hits before
-    # `start` are simply earlier than the reference would look, which only makes the skip smaller
-    skipped = torch.clamp(hit - int(fa.offset), min=int(start))
-    skipped = torch.where(hit >= lens, lens, skipped)  # no hit: nothing in this block can match
-    return torch.where(lens - int(start) >= 16, skipped, base)
+    lib = _lib()
+    dev = d_corpus.device
+    out = torch.empty(nblocks, dtype=torch.int32, device=dev)
+    bitmap = torch.empty(max(1, (total + 15) // 16) * 2, dtype=torch.uint8, device=dev)
+    work = torch.zeros(PAIR_WORK_BYTES, dtype=torch.uint8, device=dev)
+    per_block = None if isinstance(start, int) else start.to(device=dev, dtype=torch.int32).contiguous()
+    st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    rv = lib.hsgpu_hwlm_forward_skip_dev(C.byref(fa._c), d_corpus.data_ptr(), total, d_off.data_ptr(), nblocks,
+                                         per_block.data_ptr() if per_block is not None else None,
+                                         0 if per_block is not None else int(start), out.data_ptr(),
+                                         bitmap.data_ptr(), work.data_ptr(), st)
+    if rv != 0:
+        raise HsgpuError(rv, "hsgpu_hwlm_forward_skip_dev")
+    torch.cuda.current_stream().synchronize()  # `work` / `bitmap` must outlive the launch
+    return out.to(torch.int64) & 0xFFFFFFFF

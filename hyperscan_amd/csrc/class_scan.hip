@@ -492,3 +492,89 @@ extern "C" int hsgpu_pair_scan_dev(const hsgpu_pair_t *pairs, unsigned n_pairs, 
     }
     return HSGPU_SUCCESS;
 }
+
+/* ---- hwlmExec's pre-skip for a whole batch ------------------------------------------
+ * do_accel_block (src/hwlm/hwlm.c:80-99) per block: when at least 16 bytes follow `start`,
+ * start' = max(0, hit - offset) where hit = run_hwlm_accel over [start, len) (hwlm.c:48-77):
+ * the first member (class schemes) / the first pair, else len - 1 on a partial match at the
+ * last byte, else len (double vermicelli). Blocks with fewer than 16 bytes after `start`, and
+ * ACCEL_NONE, keep their start. The result may lie BEFORE the old start (hit - offset < start):
+ * that is what the reference computes, and it is what this returns. */
+__global__ void forward_skip_kernel(const uint8_t *corpus, const uint64_t *off, uint64_t nblocks,
+                                    const uint16_t *bm, const uint4 *lut, int is_pair, uint32_t offset,
+                                    const uint32_t *start_in, uint32_t start_all, uint32_t *start_out) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint64_t lo = off[b], hi = off[b + 1];
+    const uint64_t len = hi - lo;
+    const uint64_t s = start_in ? start_in[b] : start_all;
+    if (s > len || len - s < 16 || !bm) {
+        start_out[b] = (uint32_t)s;
+        return;
+    }
+    uint64_t hit;
+    if (!is_pair) {
+        const uint32_t f = first_bit(bm, lo + s, hi);
+        hit = f == 0xffffffffu ? len : s + f;
+    } else {
+        const uint32_t f = first_bit(bm, lo + s, hi - 1);
+        if (f != 0xffffffffu) {
+            hit = s + f;
+        } else {
+            const uint32_t *t1 = (const uint32_t *)&lut[2 * corpus[hi - 1]];
+            hit = (t1[0] & 0xffu) != 0xffu ? len - 1 : len;
+        }
+    }
+    start_out[b] = (uint32_t)(hit > offset ? hit - offset : 0);
+}
+
+extern "C" int hsgpu_hwlm_forward_skip_dev(const hsgpu_accel_t *aux, const void *d_corpus, uint64_t total_bytes,
+                                           const void *d_off, uint64_t nblocks, const void *d_start_in,
+                                           uint32_t start, void *d_start_out, void *d_bitmap, void *d_work,
+                                           void *stream) {
+    if (!aux || !d_off || nblocks == 0 || !d_start_out || !d_work) return HSGPU_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int is_pair = 0;
+    const uint16_t *bm = (const uint16_t *)d_bitmap;
+    void *bitmaps[1] = {d_bitmap};
+    int rv = HSGPU_SUCCESS;
+    switch (aux->type) {
+    case HSGPU_ACCEL_NONE:
+        bm = nullptr;
+        break;
+    case HSGPU_ACCEL_VERM:
+    case HSGPU_ACCEL_VERM_NOCASE:
+    case HSGPU_ACCEL_SHUFTI:
+    case HSGPU_ACCEL_TRUFFLE: {
+        hsgpu_class_t cls;
+        if (aux->type == HSGPU_ACCEL_SHUFTI)
+            rv = hsgpu_class_from_shufti(aux->mask_lo, aux->mask_hi, &cls);
+        else if (aux->type == HSGPU_ACCEL_TRUFFLE)
+            rv = hsgpu_class_from_truffle(aux->mask_lo, aux->mask_hi, &cls);
+        else
+            rv = hsgpu_class_from_verm(aux->c1, aux->type == HSGPU_ACCEL_VERM_NOCASE, 0, &cls);
+        if (rv != HSGPU_SUCCESS) return rv;
+        if (!d_bitmap) return HSGPU_INVALID;
+        rv = hsgpu_class_scan_dev(&cls, 1, d_corpus, total_bytes, nullptr, 0, bitmaps, nullptr, nullptr, d_work, stream);
+        break;
+    }
+    case HSGPU_ACCEL_DVERM:
+    case HSGPU_ACCEL_DVERM_NOCASE: {
+        hsgpu_pair_t pr;
+        rv = hsgpu_pair_from_dverm(aux->c1, aux->c2, aux->type == HSGPU_ACCEL_DVERM_NOCASE, &pr);
+        if (rv != HSGPU_SUCCESS) return rv;
+        if (!d_bitmap) return HSGPU_INVALID;
+        is_pair = 1;
+        rv = hsgpu_pair_scan_dev(&pr, 1, d_corpus, total_bytes, nullptr, 0, bitmaps, nullptr, nullptr, d_work, stream);
+        break;
+    }
+    default:
+        return HSGPU_INVALID;
+    }
+    if (rv != HSGPU_SUCCESS) return rv;
+    hipLaunchKernelGGL(forward_skip_kernel, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st,
+                       (const uint8_t *)d_corpus, (const uint64_t *)d_off, nblocks, bm, (const uint4 *)d_work, is_pair,
+                       (uint32_t)aux->offset, (const uint32_t *)d_start_in, start, (uint32_t *)d_start_out);
+    HIP_TRY(hipGetLastError());
+    return HSGPU_SUCCESS;
+}

@@ -240,16 +240,13 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     for (size_t i = 0; i < n && !blind; i++) blind = lits[i].nocase != 0;
     const uint32_t blind4 = blind ? 0x20202020u : 0u;
 
-    /* The pair filter (table.h): the layout for large sets, short literals included. Every literal is
-     * keyed at delta 0 and at delta +1 or -1, whichever needs fewer filter entries. Sets it cannot hold
-     * (a literal that needs thousands of entries, or one keyed on two bytes) stay with the layouts below. */
-    const unsigned old_layout = HSGPU_BUILD_FORCE_REPL | HSGPU_BUILD_FORCE_HASHED | HSGPU_BUILD_FORCE_K2 | HSGPU_BUILD_FORCE_K1 |
-                                HSGPU_BUILD_FORCE_STRIDE1 | HSGPU_BUILD_FORCE_STRIDE2 | HSGPU_BUILD_NO_FOLD | HSGPU_BUILD_NO_PAIR;
-    /* Not the default yet: on the 10 000-literal snort-like set the 3-byte literals (each owns whole filter
+    /* The pair filter (table.h): a stride-2 layout that holds short literals too. Every literal is keyed at
+     * delta 0 and at delta +1 or -1, whichever needs fewer filter entries. Sets it cannot hold (a literal
+     * that needs thousands of entries, or one keyed on two bytes) are refused under FORCE_PAIR.
+     * Opt-in, not the default: on the 10 000-literal snort-like set the 3-byte literals (each owns whole filter
      * planes at one parity and 32 entries at the other) leave it with about twice the candidates of the
      * stride-1 layout, which costs more in the spill and the confirm step than the halved lookups save. */
     bool pair = (flags & HSGPU_BUILD_FORCE_PAIR) != 0;
-    (void)old_layout;
     std::vector<int8_t> odd_delta(n, 1);
     uint32_t pair_hash_mask = 0;
     if (pair) {
@@ -510,6 +507,21 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     h.checksum = hsgpu_blob_checksum(blob.data(), blob.size());
     memcpy(blob.data(), &h, sizeof(h));
     return HSGPU_SUCCESS;
+}
+
+/* Was this table compiled from exactly these literals (same order)? A loader that rebuilds its own
+ * view of the literals (hs_deserialize_database) asks before trusting a stored table. */
+int hsgpu_table_agrees(const hsgpu_hwlm *t, const hsgpu_lit_t *lits, size_t n) {
+    if (!t || !lits || t->hdr()->n_lits != n) return 0;
+    const HsgpuDevLit *have = t->lits();
+    for (size_t i = 0; i < n; i++) {
+        HsgpuDevLit want;
+        if (normalise(lits[i], i, want) != HSGPU_SUCCESS) return 0;
+        if (want.v != have[i].v || want.msk != have[i].msk || want.groups != have[i].groups || want.id != have[i].id ||
+            want.size != have[i].size || want.flags != have[i].flags)
+            return 0;
+    }
+    return 1;
 }
 
 int hsgpu_validate_blob(const void *buf, size_t len) {

@@ -19,6 +19,8 @@
  * non-decreasing `to`.
  */
 #include "../../include/hs_gpu.h"
+
+#include <atomic>
 #include "hs_pattern.h"
 #include "internal.h"
 
@@ -47,7 +49,7 @@ struct hs_database {
     std::vector<unsigned> src_flags, src_ids;
     std::vector<unsigned char> src_is_lit;
     std::vector<hs_expr_ext_t> src_ext; /* flags == 0: none */
-    std::set<unsigned> single_ids;      /* report ids carrying HS_FLAG_SINGLEMATCH (built once) */
+    std::set<unsigned> single_exprs;    /* expressions carrying HS_FLAG_SINGLEMATCH (built once): the reference's exhaustion keys */
 };
 
 struct hs_scratch {
@@ -209,6 +211,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                     for (Pattern &b : parse_pattern(exprs[i], f, id)) d->pats.push_back(std::move(b));
                 }
                 for (size_t k = first_of_expr; k < d->pats.size(); k++) {
+                    d->pats[k].expr = (unsigned)i;
                     if (ext && ext[i]) apply_ext(d->pats[k], *ext[i]);
                     finish_pattern(d->pats[k]);
                 }
@@ -242,6 +245,14 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         /* a deserialised database brings its GPU table along: no literal compile on load */
         int rv = gpu_table && !gpu_table->empty() ? hsgpu_hwlm_deserialize(gpu_table->data(), gpu_table->size(), &d->hwlm)
                                                   : hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
+        /* a stored table must be the one these patterns compile to (a blob from a build whose pattern
+         * compiler chose other literals, or a spliced one, is not): otherwise compile afresh */
+        if (rv == HSGPU_SUCCESS && gpu_table && !gpu_table->empty() &&
+            !hsgpu_table_agrees(d->hwlm, lits.data(), lits.size())) {
+            hsgpu_hwlm_free(d->hwlm);
+            d->hwlm = nullptr;
+            rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
+        }
         if (rv != HSGPU_SUCCESS) {
             *error = make_error(hsgpu_last_error(), -1);
             destroy_db(d);
@@ -263,7 +274,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         d->src_ext.push_back(ext && ext[i] ? *ext[i] : none);
     }
     for (const Pattern &p : d->pats) /* (an expression may have several branches: walk the branches) */
-        if (p.single) d->single_ids.insert(p.id);
+        if (p.single) d->single_exprs.insert(p.expr);
     *db = d;
     *error = nullptr;
     return HS_SUCCESS;
@@ -290,36 +301,53 @@ bool lit_matches_at(const Pattern &p, const unsigned char *buf, size_t end /* of
     return true;
 }
 
+/* `grp`: what keeps two reports with the same id apart in the reference -- an exhaustion key of its own
+ * (SINGLEMATCH) or a start of match (SOM_LEFTMOST) make an expression's Report distinct, so those
+ * carry their expression index; plain expressions sharing an id share one Report (kNoGrp) and are
+ * reported once per offset (ReportManager::getInternalId, src/util/report_manager.cpp) */
+static const unsigned kNoGrp = 0xffffffffu;
 struct Event {
     unsigned long long to, from;
-    unsigned id;
-    bool operator<(const Event &o) const { return to != o.to ? to < o.to : (id != o.id ? id < o.id : from < o.from); }
-    bool operator==(const Event &o) const { return to == o.to && id == o.id; }
+    unsigned id, grp;
+    bool operator<(const Event &o) const {
+        if (to != o.to) return to < o.to;
+        if (id != o.id) return id < o.id;
+        return grp != o.grp ? grp < o.grp : from < o.from;
+    }
+    bool operator==(const Event &o) const { return to == o.to && id == o.id && grp == o.grp; }
 };
 
 /* turn the HWLM hits of ONE block into the user events it owes, in delivery order:
- * appended to `out` (sorted by to, one per (id, to), SINGLEMATCH ids once) */
+ * appended to `out` (sorted by to, one per (id, to), SINGLEMATCH ids once).
+ * Cost: the hits of one pattern whose report does not depend on where the match began (no
+ * start of match, no min_length, no \b layers) share ONE forward pass of the pattern's automaton
+ * over the block, with the start state injected at every hit -- O(block length) per pattern hit
+ * in the block, not O(hits x length); the other patterns run from each hit as before. */
 void collect_block_events(const hs_database *db, const unsigned char *buf, size_t len, const hsgpu_match_t *recs,
-                          size_t n, std::vector<Event> &out) {
+                          size_t n, std::vector<Event> &out, std::vector<std::pair<unsigned, size_t>> &by_pat,
+                          std::vector<size_t> &starts) {
     const size_t base = out.size();
+    const size_t n_pats = db->pats.size();
+    by_pat.clear();
     for (size_t k = 0; k < n; k++) {
+        if (recs[k].id >= n_pats) continue; /* not a record of this database's table */
         const Pattern &p = db->pats[recs[k].id];
         if (p.quiet) continue;
         const size_t lit_end = (size_t)recs[k].end + 1;
-        if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
-        unsigned long long start = lit_end - p.lit.size();
-        if (!assert_ok(p.as_lit_pre, buf, len, start) || !assert_ok(p.as_lit_post, buf, len, lit_end)) continue;
-        if (p.has_pre) { /* the part in front of the literal, backwards; `start` becomes the match start */
-            size_t f = 0;
-            if (!TailNfa::run_reverse(p, buf, len, start, p.som || (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH), f)) continue;
-            start = f;
-        } else if ((p.bol && start != 0 && !(p.bol_ml && buf[start - 1] == '\n')) || !assert_ok(p.as_start, buf, len, start)) {
-            continue;
-        }
-        const unsigned long long from = p.som ? start : 0;
+        if (lit_end > len) continue;
+        by_pat.emplace_back(recs[k].id, lit_end);
+    }
+    std::sort(by_pat.begin(), by_pat.end()); /* (pattern, lit_end) ascending */
+    for (size_t g = 0; g < by_pat.size();) {
+        size_t g_end = g;
+        while (g_end < by_pat.size() && by_pat[g_end].first == by_pat[g].first) g_end++;
+        const Pattern &p = db->pats[by_pat[g].first];
+        const bool from_matters = p.som || (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH);
+        const unsigned grp = p.single || p.som ? p.expr : kNoGrp;
+        const bool shared = !from_matters && g_end - g > 1 && (p.general ? !p.g.has_cond : !p.tail.empty());
         /* hs_expr_ext_t bounds: the job of the reference's CHECK_BOUNDS / CHECK_MIN_LENGTH
          * program instructions (src/rose/program_runtime.c) */
-        auto in_bounds = [&](unsigned long long to) {
+        auto in_bounds = [&](unsigned long long to, unsigned long long start) {
             /* `$`: at the end of the data or before its final newline; multiline: before any newline */
             if (p.eol && to != len && !(buf[to] == '\n' && (p.eol_ml || (p.eol_nl && to + 1 == len)))) return false;
             if (!assert_ok(p.as_end, buf, len, to)) return false;
@@ -328,28 +356,55 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
             if ((p.ext_flags & HS_EXT_FLAG_MIN_LENGTH) && to - start < p.min_length) return false;
             return true;
         };
-        if (p.general) {
-            TailNfa::run_general(p.g, buf, len, lit_end, [&](size_t to) {
-                if (in_bounds(to)) out.push_back(Event{to, from, p.id});
-                return true;
-            });
-        } else if (p.tail.empty()) {
-            if (in_bounds(lit_end)) out.push_back(Event{lit_end, from, p.id});
-        } else {
+        starts.clear();
+        for (size_t k = g; k < g_end; k++) {
+            const size_t lit_end = by_pat[k].second;
+            if (!lit_matches_at(p, buf, lit_end)) continue; /* long-literal check */
+            unsigned long long start = lit_end - p.lit.size();
+            if (!assert_ok(p.as_lit_pre, buf, len, start) || !assert_ok(p.as_lit_post, buf, len, lit_end)) continue;
+            if (p.has_pre) { /* the part in front of the literal, backwards; `start` becomes the match start */
+                size_t f = 0;
+                if (!TailNfa::run_reverse(p, buf, len, start, from_matters, f)) continue;
+                start = f;
+            } else if ((p.bol && start != 0 && !(p.bol_ml && buf[start - 1] == '\n')) || !assert_ok(p.as_start, buf, len, start)) {
+                continue;
+            }
+            if (shared) {
+                starts.push_back(lit_end);
+                continue;
+            }
+            const unsigned long long from = p.som ? start : 0;
             auto on_to = [&](size_t to) {
-                if (in_bounds(to)) out.push_back(Event{to, from, p.id});
+                if (in_bounds(to, start)) out.push_back(Event{to, from, p.id, grp});
                 return true;
             };
-            TailNfa::run64(p, buf, len, lit_end, on_to);
+            if (p.general) {
+                TailNfa::run_general(p.g, buf, len, lit_end, on_to);
+            } else if (p.tail.empty()) {
+                on_to(lit_end);
+            } else {
+                TailNfa::run64(p, buf, len, lit_end, on_to);
+            }
         }
+        if (shared && !starts.empty()) {
+            auto on_to = [&](size_t to) {
+                if (in_bounds(to, 0)) out.push_back(Event{to, 0, p.id, grp});
+                return true;
+            };
+            if (p.general)
+                TailNfa::run_general_multi(p.g, buf, len, starts.data(), starts.size(), on_to);
+            else
+                TailNfa::run64_multi(p, buf, len, starts.data(), starts.size(), on_to);
+        }
+        g = g_end;
     }
     std::sort(out.begin() + base, out.end());
     out.erase(std::unique(out.begin() + base, out.end()), out.end()); /* one report per (id, to) */
-    if (!db->single_ids.empty()) {
-        std::set<unsigned> exhausted; /* SINGLEMATCH ids already reported in this block */
+    if (!db->single_exprs.empty()) {
+        std::set<unsigned> exhausted; /* SINGLEMATCH expressions already reported in this block */
         size_t w = base;
         for (size_t r = base; r < out.size(); r++) {
-            if (db->single_ids.count(out[r].id) && !exhausted.insert(out[r].id).second) continue;
+            if (out[r].grp != kNoGrp && db->single_exprs.count(out[r].grp) && !exhausted.insert(out[r].grp).second) continue;
             out[w++] = out[r];
         }
         out.resize(w);
@@ -365,13 +420,15 @@ void collect_slice(const hs_database *db, const unsigned char *data, const unsig
                    const hsgpu_match_t *recs, size_t lo, size_t hi, std::vector<Event> &events,
                    std::vector<BlockRun> &runs) {
     size_t k = lo;
+    std::vector<std::pair<unsigned, size_t>> by_pat;
+    std::vector<size_t> starts;
     while (k < hi) { /* records are sorted by (block, end): one run per block */
         const unsigned long long b = recs[k].block;
         size_t e = k;
         while (e < hi && recs[e].block == b) e++;
         const size_t len = (size_t)(off[b + 1] - off[b]);
         const size_t ev0 = events.size();
-        if (len >= db->min_width) collect_block_events(db, data + off[b], len, recs + k, e - k, events);
+        if (len >= db->min_width) collect_block_events(db, data + off[b], len, recs + k, e - k, events, by_pat, starts);
         if (events.size() > ev0) runs.push_back(BlockRun{b, ev0, events.size()});
         k = e;
     }
@@ -512,28 +569,33 @@ hs_error_t hs_stream_size(const hs_database_t *db, size_t *stream_size) {
     return HS_DB_MODE_ERROR;
 }
 
-/* serialised form: magic "HSGF", CRC-32 of everything after it, count, then per pattern
+/* serialised form: magic "HSGH", CRC-32 of everything after it, count, front-end revision, then per pattern
  * (top bit: vectored mode) {is_lit, flags, id, len, ext flags, min_offset, max_offset, min_length, bytes},
  * then the GPU table section {u64 length, the hsgpu_hwlm_serialize image}. On load the host
  * automata are rebuilt from the sources (microseconds each) and the GPU table is taken from its
  * section as it is. The reference guards its bytecode with a CRC too
  * (src/database.c:119-168): a damaged blob is HS_INVALID, never a different database. */
-static const unsigned kSerialMagic = 0x48534747; /* "HSGG": version 2 = sources + GPU table section */
+static const unsigned kSerialMagic = 0x48534748; /* "HSGH": version 3 = sources + front-end revision + GPU table section */
+/* bumped whenever the pattern compiler may pick other literals / another branch order for the same
+ * sources: a blob from another revision still loads (the sources are what it stores), but its GPU
+ * table is compiled afresh instead of being trusted */
+static const unsigned kFrontEndRevision = 3;
 static const unsigned kSerialVectored = 0x80000000u; /* top bit of the count word: HS_MODE_VECTORED */
 
 static unsigned crc32_of(const unsigned char *p, size_t n) {
-    static unsigned table[256];
-    static bool ready = false;
-    if (!ready) {
-        for (unsigned i = 0; i < 256; i++) {
-            unsigned c = i;
-            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
+    struct Table {
+        unsigned v[256];
+        Table() {
+            for (unsigned i = 0; i < 256; i++) {
+                unsigned c = i;
+                for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+                v[i] = c;
+            }
         }
-        ready = true;
-    }
+    };
+    static const Table table; /* initialised once, thread-safely (C++11 function-local static) */
     unsigned c = ~0u;
-    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    for (size_t i = 0; i < n; i++) c = table.v[(c ^ p[i]) & 0xff] ^ (c >> 8);
     return ~c;
 }
 
@@ -545,6 +607,7 @@ hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *
     put32(kSerialMagic);
     put32(0); /* CRC, filled in below */
     put32((unsigned)db->sources.size() | (db->mode == HS_MODE_VECTORED ? kSerialVectored : 0));
+    put32(kFrontEndRevision);
     for (size_t i = 0; i < db->sources.size(); i++) {
         put32(db->src_is_lit[i]);
         put32(db->src_flags[i]);
@@ -612,6 +675,8 @@ hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
     if (n & kSerialVectored) out.mode = HS_MODE_VECTORED;
     n &= ~kSerialVectored;
     if (n == 0) return HS_INVALID;
+    unsigned revision = 0;
+    if (!get32(revision)) return HS_INVALID;
     for (unsigned i = 0; i < n; i++) {
         unsigned l, f, id, len;
         hs_expr_ext_t e;
@@ -628,7 +693,8 @@ hs_error_t parse_serial(const char *bytes, size_t length, Serial &out) {
     }
     unsigned long long tlen = 0;
     if (!get64(tlen) || tlen > length - off) return HS_INVALID;
-    out.table.assign((const unsigned char *)bytes + off, (const unsigned char *)bytes + off + tlen);
+    if (revision == kFrontEndRevision) /* else: compiled afresh from the sources */
+        out.table.assign((const unsigned char *)bytes + off, (const unsigned char *)bytes + off + tlen);
     off += tlen;
     return off == length ? HS_SUCCESS : HS_INVALID;
 }
@@ -814,9 +880,20 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
 
 /* The host confirm of a batch ("Rose-lite"): literal hits -> events, delivered in block order
  * on the calling thread. recs: sorted by (block, end), id = pattern index, as the literal
- * engine emits them. Returns true if some callback asked to stop (its block only). */
-static bool confirm_and_deliver(const hs_database *db, const char *data, const unsigned long long *off,
-                                const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context) {
+ * engine emits them. Returns 1 if some callback asked to stop (its block only), 0 if none did, -1
+ * when the confirm ran out of memory (nothing is delivered then). */
+static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
+                                    const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context);
+static int confirm_and_deliver(const hs_database *db, const char *data, const unsigned long long *off,
+                               const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context) {
+    try {
+        return confirm_and_deliver_impl(db, data, off, recs, n, onEvent, context);
+    } catch (...) { /* bad_alloc while sizing the per-worker vectors */
+        return -1;
+    }
+}
+static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
+                                    const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context) {
     /* host confirm: the events of different blocks are independent, so large batches are cut
      * into slices of whole blocks handled by worker threads; delivery stays on the calling
      * thread, in block order, as the callback contract requires */
@@ -833,9 +910,14 @@ static bool confirm_and_deliver(const hs_database *db, const char *data, const u
             cut[t] = c;
         }
         static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr;
+        std::atomic<bool> failed{false}; /* no exception may leave a worker thread (std::terminate) or this extern "C" path */
         auto work = [&](unsigned t) {
             const auto t0 = std::chrono::steady_clock::now();
-            collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t]);
+            try {
+                collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t]);
+            } catch (...) {
+                failed = true;
+            }
             if (timing)
                 fprintf(stderr, "  confirm worker %u: %zu hits in %.2f ms\n", t, cut[t + 1] - cut[t],
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -852,14 +934,15 @@ static bool confirm_and_deliver(const hs_database *db, const char *data, const u
             work(0);
             for (std::thread &th : pool) th.join();
         }
+        if (failed) return -1;
     }
-    bool any_terminated = false;
+    int any_terminated = 0;
     for (unsigned t = 0; t < n_thr; t++)
         for (const BlockRun &r : runs[t])
             for (size_t i = r.ev_begin; i < r.ev_end; i++) {
                 const Event &e = ev[t][i];
                 if (onEvent(r.block, e.id, e.from, e.to, 0, context) != 0) { /* stops THIS block only */
-                    any_terminated = true;
+                    any_terminated = 1;
                     break;
                 }
             }
@@ -901,7 +984,8 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
     }
     static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr; /* diagnostic: where does a batch go? */
     const auto t_scan = std::chrono::steady_clock::now();
-    const bool any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context);
+    const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context);
+    if (any_terminated < 0) return HS_NOMEM;
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "hs_scan_batch: %zu literal hits; GPU literal scan incl. copies %.2f ms, host confirm %.2f ms\n", n,
@@ -940,7 +1024,8 @@ hs_error_t hs_confirm_batch(const hs_database_t *db, const char *data, const uns
             return HS_INVALID;
         if (recs[i].end >= off[recs[i].block + 1] - off[recs[i].block]) return HS_INVALID;
     }
-    return confirm_and_deliver(db, data, off, recs, (size_t)n_records, onEvent, context) ? HS_SCAN_TERMINATED : HS_SUCCESS;
+    const int rv = confirm_and_deliver(db, data, off, recs, (size_t)n_records, onEvent, context);
+    return rv < 0 ? HS_NOMEM : (rv ? HS_SCAN_TERMINATED : HS_SUCCESS);
 }
 
 hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsigned int flags,

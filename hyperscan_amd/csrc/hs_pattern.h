@@ -74,6 +74,7 @@ struct Pattern {
      * and just after the literal, the end of the match */
     unsigned char as_start = 0, as_lit_pre = 0, as_lit_post = 0, as_end = 0;
     unsigned id = 0;
+    unsigned expr = 0;        /* index of the expression this branch belongs to */
     std::vector<Unit> tail;   /* empty: pure literal */
     bool tail_nullable = true;
     /* hs_expr_ext_t (src/hs_compile.h:244-310): bounds on `to` and on the match length */
@@ -250,6 +251,63 @@ struct TailNfa {
             step(a, cur, next);
         }
     }
+    /* The same from SEVERAL start offsets at once (ascending, duplicates allowed): the automaton is
+     * run once over the block and `first` is injected at every start, so k hits of one literal
+     * cost one pass instead of k. Reports the union of the separate runs' offsets (a position may be
+     * reported twice). Not for automata with \b / \B layers (has_cond). */
+    template <class F>
+    static void run_general_multi(const Auto &a, const unsigned char *buf, size_t len, const size_t *starts, size_t n, F report) {
+        if (!n) return;
+        const size_t W = a.W;
+        unsigned long long cur[kMaxW], next[kMaxW];
+        std::fill(next, next + W, 0ull);
+        size_t pos = starts[0], k = 0;
+        for (;;) {
+            for (; k < n && starts[k] == pos; k++) {
+                for (size_t w = 0; w < W; w++) next[w] |= a.first[w];
+                if (a.nullable) { if (!report(pos)) return; }
+            }
+            if (pos >= len) return;
+            unsigned long long any = 0;
+            for (size_t w = 0; w < W; w++) any |= next[w];
+            if (!any) { /* dead until the next start */
+                if (k >= n) return;
+                pos = starts[k];
+                continue;
+            }
+            bool acc;
+            const bool live = advance(a, buf[pos++], next, cur, &acc);
+            if (acc) { if (!report(pos)) return; }
+            if (live) step(a, cur, next);
+            else std::fill(next, next + W, 0ull);
+        }
+    }
+    template <class F>
+    static void run64_multi(const Pattern &p, const unsigned char *buf, size_t len, const size_t *starts, size_t n, F report) {
+        if (!n) return;
+        const unsigned long long accept = 1ull << p.tail.size(), init = closure64(1ull, p.opt_mask);
+        unsigned long long cur = 0;
+        size_t pos = starts[0], k = 0;
+        for (;;) {
+            bool injected = false;
+            for (; k < n && starts[k] == pos; k++) injected = true;
+            if (injected) {
+                cur |= init;
+                if (init & accept) { if (!report(pos)) return; }
+            }
+            if (pos >= len) return;
+            if (!(cur & (accept - 1))) {
+                if (k >= n) return;
+                cur = 0;
+                pos = starts[k];
+                continue;
+            }
+            const unsigned long long live = cur & p.reach[buf[pos++]];
+            cur = closure64((live << 1) | (live & p.star_mask), p.opt_mask);
+            if (cur & accept) { if (!report(pos)) return; }
+        }
+    }
+
     /* R1 backwards from the literal's first byte (the automaton is the reversed one): is there a
      * `from` with buf[from, start) in R1 (and, for `^`, a line start at `from`)? leftmost = keep
      * going for the smallest one */

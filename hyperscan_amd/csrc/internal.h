@@ -26,6 +26,7 @@ void hsgpu_set_error(const char *fmt, ...);
 int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::vector<uint8_t> &blob);
 int hsgpu_validate_blob(const void *buf, size_t len);
 uint32_t hsgpu_blob_checksum(const uint8_t *blob, size_t len);
+int hsgpu_table_agrees(const hsgpu_hwlm *t, const hsgpu_lit_t *lits, size_t n);
 
 /* runtime.hip */
 void hsgpu_release_device_copies(hsgpu_hwlm *t);

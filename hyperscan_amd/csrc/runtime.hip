@@ -66,6 +66,8 @@ struct hsgpu_scratch {
     hipStream_t side = nullptr;           /* block hints are computed beside the filter kernel */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool timing = false;                   /* hsgpu_scratch_enable_timing */
+    void *user_ctx = nullptr;              /* hsgpu_scratch_set_context: the callbacks' third argument */
+    bool has_user_ctx = false;
     /* ring of event sets {start, filter done, confirm done, packed}: one per scan */
     static const int kRing = 32;
     hipEvent_t ev_ring[kRing][4] = {};
@@ -440,6 +442,10 @@ extern "C" int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, co
         hsgpu_set_error("record buffer larger than 2^32 records");
         return HSGPU_INVALID;
     }
+    if (nblocks >= (1ull << 32)) { /* hsgpu_match_t.block is 32 bits */
+        hsgpu_set_error("more than 2^32 - 1 blocks per launch");
+        return HSGPU_INVALID;
+    }
     if (total_bytes >= (1ull << 36)) { /* chunk index is 32 bits of 16-byte chunks */
         hsgpu_set_error("corpus larger than 64 GiB per launch");
         return HSGPU_INVALID;
@@ -535,6 +541,10 @@ struct InUse {
 static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base, const uint64_t *off,
                      size_t nblocks, size_t start, std::vector<hsgpu_match_t> &recs) {
     recs.clear();
+    if ((uint64_t)nblocks >= (1ull << 32)) { /* hsgpu_match_t.block is 32 bits */
+        hsgpu_set_error("more than 2^32 - 1 blocks per call");
+        return HSGPU_INVALID;
+    }
     const uint64_t lo = off[0], total = off[nblocks] - off[0];
     if (total == 0) return HSGPU_SUCCESS;
     for (size_t i = 0; i < nblocks; i++) {
@@ -623,9 +633,23 @@ extern "C" uint64_t hsgpu_hwlm_count_cb(size_t, uint32_t, void *ctx) {
     return ~0ull;
 }
 
-extern "C" int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *buf, size_t len,
-                               size_t start, hsgpu_hwlm_cb cb, void *ctx, uint64_t groups) {
+/* what the callback receives as its third argument: the reference hands the scratch itself to
+ * HWLMCallback (src/hwlm/hwlm.h:77-93); a caller that wants its own pointer hangs it here */
+extern "C" void hsgpu_scratch_set_context(hsgpu_scratch_t *s, void *ctx) {
+    if (s) {
+        s->user_ctx = ctx;
+        s->has_user_ctx = true;
+    }
+}
+extern "C" void *hsgpu_scratch_get_context(const hsgpu_scratch_t *s) {
+    return s ? (s->has_user_ctx ? s->user_ctx : (void *)s) : nullptr;
+}
+
+/* hwlmExec's own argument order (src/hwlm/hwlm.h:120-122) */
+extern "C" int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t len, size_t start,
+                               hsgpu_hwlm_cb cb, hsgpu_scratch_t *s, uint64_t groups) {
     if (!t || !s || !cb || (len && !buf)) return HSGPU_HWLM_ERROR_UNKNOWN;
+    void *ctx = hsgpu_scratch_get_context(s);
     if (!groups) return HSGPU_HWLM_SUCCESS; /* hwlm.c:178 */
     if (len == 0 || start >= len) return HSGPU_HWLM_SUCCESS;
     InUse guard(s);

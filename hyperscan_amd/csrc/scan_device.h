@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void bitonic_sort(PTR x, uint32_t n) {
 
 __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs args) {
     __shared__ uint4 buf[SORT_LDS];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     uint4 *out = (uint4 *)args.out;
     if (args.order_state[0]) {
         const uint32_t first = blockIdx.x * args.group_regions, last = min(args.rec_regions, first + args.group_regions);

@@ -59,9 +59,17 @@ def all_gather_records(records, count, block_base, dist, world, device=None):
     parts = []
     for r in range(world):
         p = buf[r * mx:r * mx + counts[r]].clone()
-        p[:, 0] += int(bases[r])
+        p[:, 0] += _as_i32(bases[r])  # uint32 arithmetic on the int32 view: exact up to 2^32 blocks per job
         parts.append(p)
     return torch.cat(parts, dim=0), counts
+
+
+def _as_i32(v):
+    """the int32 bit pattern of a uint32 value (records travel as int32 tensors; hsgpu_match_t.block is uint32)"""
+    v = int(v)
+    if not 0 <= v < 1 << 32:
+        raise ValueError("global block index %d does not fit the record's 32-bit block field" % v)
+    return v - (1 << 32) if v >= 1 << 31 else v
 
 
 class RecordExchange:
@@ -99,7 +107,7 @@ class RecordExchange:
         parts = []
         for r in range(self.world):
             p = self.rec_out[r, : counts[r]].clone()
-            p[:, 0] += int(bases[r]) - (1 << 32 if bases[r] >= 1 << 31 else 0)  # uint32 add in an int32 tensor
+            p[:, 0] += _as_i32(bases[r])  # uint32 add in an int32 tensor
             parts.append(p)
         return torch.cat(parts, dim=0), counts
 
@@ -131,7 +139,7 @@ def all_gather_records_exact(records, count, block_base, dist, world, rank, devi
     if n:
         mine = out[starts[rank]:starts[rank] + n]
         mine.copy_(records[:n])
-        mine[:, 0] += int(block_base)
+        mine[:, 0] += _as_i32(block_base)
     pending = [dist.broadcast(out[starts[r]:starts[r + 1]], src=r, async_op=True) for r in range(world) if counts[r]]
     for h in pending:
         h.wait()
@@ -160,5 +168,5 @@ def gather_records_to_root(records, count, block_base, dist, world, rank, root=0
     for h in pending:
         h.wait()
     for r in range(world):
-        out[starts[r]:starts[r + 1], 0] += int(bases[r])
+        out[starts[r]:starts[r + 1], 0] += _as_i32(bases[r])
     return out, counts

@@ -7,6 +7,7 @@ import numpy as np
 from . import _native
 
 HS_SUCCESS, HS_INVALID, HS_NOMEM, HS_SCAN_TERMINATED, HS_COMPILER_ERROR = 0, -1, -2, -3, -4
+HS_DB_VERSION_ERROR, HS_DB_PLATFORM_ERROR = -5, -6
 HS_DB_MODE_ERROR, HS_SCRATCH_IN_USE, HS_UNKNOWN_ERROR = -7, -10, -13
 HS_FLAG_CASELESS, HS_FLAG_DOTALL, HS_FLAG_MULTILINE, HS_FLAG_SINGLEMATCH = 1, 2, 4, 8
 HS_FLAG_UTF8, HS_FLAG_SOM_LEFTMOST = 32, 256

@@ -208,7 +208,7 @@ def hwlm_exec(table, buf, start, cb, scratch, groups=HWLM_ALL_GROUPS, ctx=None):
         return int(cb(end, lit_id, ctx)) & HWLM_ALL_GROUPS
 
     ccb = HWLM_CB(tramp)
-    return table._lib.hsgpu_hwlm_exec(table._h, scratch._h, a.ctypes.data, a.size, start, ccb, None, groups)
+    return table._lib.hsgpu_hwlm_exec(table._h, a.ctypes.data, a.size, start, ccb, scratch._h, groups)
 
 
 def hwlm_exec_batch(table, scratch, base, off, start=0, cap=None):

@@ -109,8 +109,8 @@ typedef struct hsgpu_hwlm_info {
 #define HSGPU_BUILD_FORCE_MEDIUM 256u /* 64 KiB hashed filter: two 16-wavefront workgroups per CU where registers allow */
 #define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
 #define HSGPU_BUILD_NO_FOLD 512u    /* keep the separate 3-byte-key filter test even when only few such keys exist */
-#define HSGPU_BUILD_FORCE_PAIR 1024u /* the pair filter (the default from 2048 literals up) whatever the size of the set */
-#define HSGPU_BUILD_NO_PAIR 2048u    /* never the pair filter */
+#define HSGPU_BUILD_FORCE_PAIR 1024u /* the stride-2 pair filter (opt-in; an error for sets it cannot hold) */
+#define HSGPU_BUILD_NO_PAIR 2048u    /* never the pair filter (the default today) */
 
 /* ---- build side ---------------------------------------------------------- */
 
@@ -130,11 +130,15 @@ int hsgpu_hwlm_deserialize(const void *buf, size_t len, hsgpu_hwlm_t **out);
 int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device);
 void hsgpu_scratch_free(hsgpu_scratch_t *s);
 
-/* Mirror of hwlmExec: scan one host block, deliver callbacks in non-decreasing
- * `end` on the calling thread, honouring the group mask returned by the callback,
- * noruns and termination. Returns HSGPU_HWLM_*. */
-int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *buf, size_t len,
-                    size_t start, hsgpu_hwlm_cb cb, void *ctx, uint64_t groups);
+/* hwlmExec (src/hwlm/hwlm.h:120-122, src/hwlm/hwlm.c:172-199), argument for argument: scan one host
+ * block, deliver callbacks in non-decreasing `end` on the calling thread, honouring the group
+ * mask returned by the callback, noruns and termination. Returns HSGPU_HWLM_*. The callback's
+ * third argument is the scratch itself, as in the reference (HWLMCallback, src/hwlm/hwlm.h:77-93),
+ * unless the caller hung a pointer of its own on the scratch with hsgpu_scratch_set_context. */
+int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t len, size_t start,
+                    hsgpu_hwlm_cb cb, hsgpu_scratch_t *scratch, uint64_t groups);
+void hsgpu_scratch_set_context(hsgpu_scratch_t *s, void *ctx);
+void *hsgpu_scratch_get_context(const hsgpu_scratch_t *s);
 
 /* Batched host form: nblocks independent blocks, block i = base[off[i], off[i+1]).
  * Writes up to cap records sorted by (block, end, lit) and the total in *nout
@@ -288,6 +292,20 @@ int hsgpu_pair_test(const hsgpu_pair_t *p, uint8_t a, uint8_t b);
 int hsgpu_pair_scan_dev(const hsgpu_pair_t *pairs, unsigned n_pairs, const void *d_corpus, uint64_t total_bytes,
                         const void *d_off, uint64_t nblocks, void *const *d_bitmaps, void *d_first, void *d_last,
                         void *d_work, void *stream);
+
+/* ---- hwlmExec's pre-skip for a block batch ---------------------------------------------
+ * do_accel_block (src/hwlm/hwlm.c:80-99) per block, asynchronously on `stream`: where at least
+ * 16 bytes follow the block's start, start' = max(0, hit - aux->offset), hit being what
+ * run_hwlm_accel (hwlm.c:48-77) returns for [start, len): the first member of the scheme's class,
+ * or for double vermicelli the first pair, else len - 1 when the last byte alone is c1, else len.
+ * Other blocks, and HSGPU_ACCEL_NONE, keep their start. d_start_in: uint32 [nblocks] starts, or NULL
+ * for `start` everywhere; d_start_out: uint32 [nblocks]. d_bitmap: (total_bytes + 15) / 16 * 2
+ * bytes of device scratch (the scheme's membership bitmap; unused for HSGPU_ACCEL_NONE); d_work:
+ * HSGPU_PAIR_WORK_BYTES, 16-byte aligned. Feed d_start_out to nothing: the literal scan needs no
+ * pre-skip (it reads every byte at the HBM rate); this is for callers that consume `start`. */
+int hsgpu_hwlm_forward_skip_dev(const hsgpu_accel_t *aux, const void *d_corpus, uint64_t total_bytes,
+                                const void *d_off, uint64_t nblocks, const void *d_start_in, uint32_t start,
+                                void *d_start_out, void *d_bitmap, void *d_work, void *stream);
 
 const char *hsgpu_last_error(void);
 const char *hsgpu_version(void);

@@ -279,10 +279,24 @@ def test_pair_scan_tile_edges(total):
     assert int(last.cpu().numpy().view(np.uint32)[0, 0]) == (total - 1 if total > 1 else 0xFFFFFFFF)
 
 
+def _do_accel_block(L, kind, sc, offset, blk, start):
+    """do_accel_block (src/hwlm/hwlm.c:80-99) with the oracle's accelerators (pinned to the
+    compiled reference in test_oracle_accel.py) as run_hwlm_accel"""
+    n = blk.size
+    if n - start < 16:
+        return start
+    tail = np.ascontiguousarray(blk[start:])
+    if kind == "class":
+        hit = L.hso_class_fwd(sc.bitmap.ctypes.data, tail.ctypes.data, tail.size)
+    else:
+        hit = L.hso_dshufti_fwd(*sc.masks, tail.ctypes.data, tail.size)
+    return max(0, start + hit - offset)
+
+
 def test_forward_skip_is_do_accel_block_for_a_batch():
-    """forward_skip = hwlmExec's pre-skip (do_accel_block, src/hwlm/hwlm.c:48-99) per block: the
-    chosen scheme's first hit minus its offset; and the skip is SAFE: no literal of the set
-    matches with a start before it (checked with the HWLM oracle)."""
+    """hsgpu_hwlm_forward_skip_dev = hwlmExec's pre-skip (do_accel_block, src/hwlm/hwlm.c:48-99)
+    per block, value for value -- for start 0, a common start > 0 and per-block starts -- and for
+    start 0 the skip is SAFE: no literal of the set starts before it (HWLM oracle)."""
     import torch
 
     import hyperscan_amd as H
@@ -300,22 +314,33 @@ def test_forward_skip_is_do_accel_block_for_a_batch():
         lens = rng.choice([5, 16, 17, 40, 200, 1000], 300)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
         total = int(off[-1])
+        nb = off.size - 1
         text = b"".join(words[int(i)] + b"." * int(rng.integers(0, 30)) for i in rng.integers(0, len(words), total // 8))
         corpus = np.frombuffer(text[:total].ljust(total, b"."), dtype=np.uint8).copy()
+        # a block that ends in the pair's first byte alone, and blocks without any hit
+        corpus[int(off[3]):int(off[4])] = ord("~")
         d = torch.from_numpy(corpus).to("cuda:0")
         d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
-        skip = accel.forward_skip(fa, d, total, d_off, off.size - 1).cpu().numpy()
         orc = ob.Oracle(lits)
         kind, sc = fa.scanner()
-        for b in range(off.size - 1):
-            blk = np.ascontiguousarray(corpus[int(off[b]):int(off[b + 1])])
-            n = blk.size
-            if kind == "class":
-                hit = L.hso_class_fwd(sc.bitmap.ctypes.data, blk.ctypes.data, n)
-            else:
-                hit = L.hso_dshufti_fwd(*sc.masks, blk.ctypes.data, n)
-            want = 0 if n < 16 else (n if hit >= n else max(0, hit - fa.offset))
-            assert skip[b] == want, (b, n, hit, fa.offset)
-            for end, lid in orc.collect(blk):
-                size = len(lits[lid].s)
-                assert end + 1 - size >= skip[b], "a literal starts before the skip"
+        per_block = rng.integers(0, 24, nb).astype(np.int32)
+        per_block = np.minimum(per_block, lens.astype(np.int32))
+        for start in (0, 7, per_block):
+            d_start = start if isinstance(start, int) else torch.from_numpy(start).to("cuda:0")
+            skip = accel.forward_skip(fa, d, total, d_off, nb, d_start).cpu().numpy()
+            for b in range(nb):
+                blk = np.ascontiguousarray(corpus[int(off[b]):int(off[b + 1])])
+                s0 = start if isinstance(start, int) else int(start[b])
+                if s0 > blk.size:
+                    continue
+                want = _do_accel_block(L, kind, sc, fa.offset, blk, s0)
+                assert skip[b] == want, (b, blk.size, s0, fa.offset, int(skip[b]), want)
+                if s0 == 0:
+                    for end, lid in orc.collect(blk):
+                        size = len(lits[lid].s)
+                        assert end + 1 - size >= skip[b], "a literal starts before the skip"
+    # no scheme: every start is kept
+    none = accel.ForwardAccel.choose([H.HwlmLiteral(bytes([v, v ^ 0x55]), False, v) for v in range(256)])
+    if none.type == accel.ACCEL_NONE:
+        skip = accel.forward_skip(none, d, total, d_off, nb, 5).cpu().numpy()
+        assert (skip == 5).all()

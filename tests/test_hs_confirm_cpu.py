@@ -664,3 +664,100 @@ def test_repeats_unrolled_and_small_classes():
     for bad in [r"\w+", r"[^a]{2}", r"(ab)*", r"[ab]?", r"[ab]++", r"."]:
         with pytest.raises(hs.HsError):
             hs.Database.compile([bad], [0], [1])
+
+
+def test_many_hits_of_one_pattern_share_one_pass():
+    """k hits of `foo` in front of an unbounded tail (`foo.*bar`): the confirm runs the tail automaton
+    ONCE over the block with the start state injected at every hit, so a block of 20k hits takes
+    milliseconds (it was quadratic: 80 KB took 10 s), and the events are still exactly those of the
+    brute-force reading -- every `bar` end after the first `foo`."""
+    import time
+
+    for pat, flags in (("foo.*bar", hs.HS_FLAG_DOTALL), ("foo[^x]*ba?r", 0), ("foo(?:a|.)*bar", hs.HS_FLAG_DOTALL)):
+        db = hs.Database.compile_ext([pat], [flags], [7], [None])
+        n = 20_000
+        corpus = np.frombuffer(b"foo bar " * n, dtype=np.uint8).copy()
+        off = np.array([0, corpus.size], dtype=np.uint64)
+        parts = [(b"foo", "", 0, 7, {})]
+        recs = literal_hits(parts, corpus, off)
+        assert recs.size == n
+        t0 = time.time()
+        rv, ev = confirm(db, corpus, off, recs)
+        dt = time.time() - t0
+        assert rv == hs.HS_SUCCESS
+        assert [e[3] for e in ev] == [8 * k + 7 for k in range(n)], pat
+        assert all(e[1] == 7 and e[2] == 0 for e in ev)
+        assert dt < 5.0, "the confirm is no longer linear in the block length: %.1f s" % dt
+    # the short form on a small block, against re, with hits that overlap each other's tails
+    db = hs.Database.compile_ext(["ab.{0,5}c", "ab[a-c]*c"], [hs.HS_FLAG_DOTALL, 0], [1, 2], [None, None])
+    rng = np.random.default_rng(8)
+    corpus = rng.choice(np.frombuffer(b"abc.", dtype=np.uint8), 4000).copy()
+    off = np.array([0, 1000, 1003, 4000], dtype=np.uint64)
+    parts = [(b"ab", ".{0,5}c", hs.HS_FLAG_DOTALL, 1, {}), (b"ab", "[a-c]*c", 0, 2, {})]
+    recs = literal_hits(parts, corpus, off)
+    rv, ev = confirm(db, corpus, off, recs)
+    assert rv == hs.HS_SUCCESS and sorted(ev) == sorted(brute(parts, corpus, off)) and len(ev) > 300
+
+
+def test_expressions_sharing_an_id_keep_their_own_exhaustion_and_som():
+    """exhaustion (SINGLEMATCH) and start of match belong to the expression, not to the report id: a
+    plain expression that shares its id with a SINGLEMATCH one keeps reporting, and a SOM and a
+    non-SOM report at the same offset are both delivered"""
+    db = hs.Database.compile_ext(["key", "lock"], [hs.HS_FLAG_SINGLEMATCH, 0], [5, 5], [None, None])
+    corpus = np.frombuffer(b"key lock key lock lock", dtype=np.uint8).copy()
+    off = np.array([0, corpus.size], dtype=np.uint64)
+    parts = [(b"key", "", 0, 5, {}), (b"lock", "", 0, 5, {})]
+    rv, ev = confirm(db, corpus, off, literal_hits(parts, corpus, off))
+    assert rv == hs.HS_SUCCESS
+    assert [e[3] for e in ev] == [3, 8, 17, 22]  # `key` once, every `lock`
+    db = hs.Database.compile_ext(["xab", "ab"], [hs.HS_FLAG_SOM_LEFTMOST, 0], [9, 9], [None, None])
+    corpus = np.frombuffer(b"..xab..", dtype=np.uint8).copy()
+    off = np.array([0, corpus.size], dtype=np.uint64)
+    parts = [(b"xab", "", 0, 9, {}), (b"ab", "", 0, 9, {})]
+    rv, ev = confirm(db, corpus, off, literal_hits(parts, corpus, off))
+    assert rv == hs.HS_SUCCESS and sorted((e[2], e[3]) for e in ev) == [(0, 5), (2, 5)]
+    # two plain expressions with one id are one report per offset, as in the reference
+    db = hs.Database.compile_ext(["xab", "ab"], [0, 0], [9, 9], [None, None])
+    rv, ev = confirm(db, corpus, off, literal_hits(parts, corpus, off))
+    assert rv == hs.HS_SUCCESS and [(e[2], e[3]) for e in ev] == [(0, 5)]
+
+
+def test_deserialize_does_not_trust_a_table_that_is_not_its_patterns():
+    """a blob whose GPU table section belongs to another database (spliced in, CRC recomputed) still
+    loads, but the table is compiled afresh from the sources: the loaded database has its own
+    literals, and records with an id outside it are refused"""
+    import struct
+    import zlib
+
+    small = hs.Database.compile_ext(["alpha"], [0], [1], [None])
+    big = hs.Database.compile_ext(["alpha", "bravo", "charlie"], [0, 0, 0], [1, 2, 3], [None, None, None])
+
+    def split(blob):  # -> (head up to and including the table length, table)
+        n = struct.unpack_from("<I", blob, 8)[0] & 0x7FFFFFFF
+        o = 16
+        for _ in range(n):
+            ln = struct.unpack_from("<I", blob, o + 12)[0]
+            o += 16 + 32 + ln
+        tlen = struct.unpack_from("<Q", blob, o)[0]
+        assert o + 8 + tlen == len(blob)
+        return blob[:o], blob[o + 8:]
+
+    head_s, _tab_s = split(small.serialize())
+    _head_b, tab_b = split(big.serialize())
+    forged = bytearray(head_s + struct.pack("<Q", len(tab_b)) + tab_b)
+    struct.pack_into("<I", forged, 4, zlib.crc32(bytes(forged[8:])) & 0xFFFFFFFF)
+    db = hs.Database.deserialize(bytes(forged))
+    lib = hs._lib()
+    lib.hs_database_literal.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.hs_database_literal(db._h, 0, None, None, None, None) == hs.HS_SUCCESS
+    assert lib.hs_database_literal(db._h, 1, None, None, None, None) == hs.HS_INVALID  # one pattern, one literal
+    # its table is the one-literal table again: serialising it gives the small database's blob
+    assert db.serialize() == small.serialize()
+    # a blob of another format version is refused as such
+    old = bytearray(small.serialize())
+    old[0] = old[0] - 1
+    try:
+        hs.Database.deserialize(bytes(old))
+        assert False, "an older format loaded"
+    except hs.HsError as e:
+        assert e.code == hs.HS_DB_VERSION_ERROR
