@@ -452,14 +452,14 @@ def run_class256(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
-    # algorithmic bytes: every pass reads the corpus once and writes one bit per byte and class + first/last per line
-    alg = sum(total * (1 + len(p) / 8) + nb * len(p) * 8 for p in passes)
+    # algorithmic bytes: every pass reads the corpus and the block offsets once, writes one bit per byte and class + first/last per line
+    alg = sum(total * (1 + len(p) / 8) + nb * (len(p) * 8 + 8) for p in passes)
     res = {"workload": f"class256: 256 patterns -> {len(classes)} distinct classes {names} in {len(passes)} passes of <= 8, "
                        f"{total / (1 << 30):g} GiB line corpus (1 GiB of lines x {reps}), {nb} blocks",
            "value": round(total * args.steps / dt / 1e9, 2), "unit": "GB/s of corpus (all classes)", "ms_per_step": round(dt / args.steps * 1e3, 3),
            "roofline": {"bound": "hbm", "achieved": round(alg / (ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "class_bitmap_kernel + class_first_last_kernel (HIP events around all passes)",
+                        "kernel": "class_tile_fl_kernel (HIP events around all passes)",
                         "ms_all_passes": round(ms, 3), "algorithmic_bytes_per_step": int(alg)}}
     if ob.ref_available():
         R = ob.href(ob.ref_variants()[-1])

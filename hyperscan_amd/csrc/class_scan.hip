@@ -9,18 +9,12 @@
  * schemes decodes to a 256-bit class (shufti2cr, truffle2cr src/nfa/trufflecompile.cpp:77-94),
  * so the GPU takes classes as bitmaps and evaluates up to 8 of them per pass:
  *
- *   class_bitmap_kernel  streams the corpus once (16 B per lane, coalesced); per
- *       byte ONE 128-bit LDS read of a 256-entry table whose entry holds, for 8
- *       classes, a 16-bit field that is 1 when the byte value is in the class;
- *       acc |= entry << j over the lane's 16 bytes leaves the 16 membership bits
- *       of every class in its own field (no per-class work at all); each lane then
- *       stores 2 bytes per class: bit i of bitmap c <=> corpus[i] in class c.
- *       The table is replicated 16x so that the 16 lanes of every ds_read_b128
- *       lane group read 16 different 16-byte slots: conflict-free.
- *       Algorithmic bytes: 1 read + n_classes/8 written per corpus byte.
- *   class_first_last_kernel  one lane per (block, class): the accelerators' return
- *       value (first / last member offset in the block, len / -1 when none), read
- *       off the bitmaps with early exit.
+ *   class_tile_{fl,bm}_kernel  stream the corpus once: membership bitmaps (bit i of bitmap c <=>
+ *       corpus[i] in class c) and, for the blocks inside a wavefront's 4 KiB tile, the
+ *       accelerators' return value (first / last member offset in the block, len / -1 when
+ *       none) straight from the tile's bits in LDS.
+ *       Algorithmic bytes: 1 read + n_classes/8 written per corpus byte (+ 8 per block read,
+ *       8 per block and class written for first / last).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,48 +31,6 @@ namespace {
 
 constexpr int CS_THREADS = 1024;
 constexpr int CS_TILE = CS_THREADS * 16;
-
-__global__ __launch_bounds__(CS_THREADS) void class_bitmap_kernel(const uint8_t *corpus, uint64_t total,
-                                                                   const uint4 *lut /* [256] */, uint32_t n_classes,
-                                                                   uint16_t *const *bitmaps /* [8] device ptrs */) {
-    extern __shared__ __attribute__((aligned(16))) uint4 table[]; /* [256][16] */
-    for (uint32_t i = threadIdx.x; i < 256 * 16; i += CS_THREADS) table[i] = lut[i >> 4];
-    __syncthreads();
-    const uint32_t col = threadIdx.x & 15;
-    uint16_t *bm[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) bm[c] = bitmaps[c];
-    const uint64_t n_tiles = (total + CS_TILE - 1) / CS_TILE;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t off = tile * CS_TILE + (uint64_t)threadIdx.x * 16;
-        if (off >= total) continue;
-        uint32_t d[4] = {0, 0, 0, 0};
-        uint32_t valid = 16;
-        if (off + 16 <= total) {
-            const uint4 v = *(const uint4 *)(corpus + off);
-            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-        } else {
-            valid = (uint32_t)(total - off);
-            for (uint32_t i = 0; i < valid; i++) d[i >> 2] |= (uint32_t)corpus[off + i] << (8 * (i & 3));
-        }
-        uint4 acc = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t b = (d[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            const uint4 e = table[(b << 4) | col];
-            acc.x |= e.x << j;
-            acc.y |= e.y << j;
-            acc.z |= e.z << j;
-            acc.w |= e.w << j;
-        }
-        const uint32_t keep = valid >= 16 ? 0xffffu : ((1u << valid) - 1u);
-        const uint32_t f[8] = {acc.x & 0xffffu, acc.x >> 16, acc.y & 0xffffu, acc.y >> 16,
-                               acc.z & 0xffffu, acc.z >> 16, acc.w & 0xffffu, acc.w >> 16};
-#pragma unroll
-        for (int c = 0; c < 8; c++)
-            if ((uint32_t)c < n_classes) bm[c][off >> 4] = (uint16_t)(f[c] & keep);
-    }
-}
 
 /* first / last set bit of a bitmap inside [lo, hi); 0xffffffff when none */
 __device__ __forceinline__ uint32_t first_bit(const uint16_t *bm, uint64_t lo, uint64_t hi) {
@@ -129,25 +81,397 @@ __device__ __forceinline__ uint32_t last_bit64(const uint64_t *bm, uint64_t lo, 
     return 0xffffffffu;
 }
 
-/* first/last member of class c inside block b, from bitmap c. (Fusing this into the
- * classification kernel -- fields kept in LDS, a per-tile block index, atomics for blocks
- * crossing tiles -- measured 2.1 ms/GiB against 1.27 ms for these two streaming kernels: the
- * per-tile barriers and dependent offset reads cost more than re-reading the bitmaps.) */
-__global__ void class_first_last_kernel(const uint64_t *off, uint64_t nblocks, uint32_t n_classes,
-                                        uint16_t *const *bitmaps, uint64_t total, uint32_t *first, uint32_t *last) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblocks * n_classes) return;
-    const uint32_t c = (uint32_t)(i / nblocks);
-    const uint64_t b = i % nblocks;
-    const uint64_t lo = off[b], hi = off[b + 1];
-    const uint16_t *bm = bitmaps[c];
-    /* the bitmap holds (total + 15) / 16 16-bit words: whole 64-bit words only below that */
-    const bool wide = (((uintptr_t)bm & 7) == 0) && (((hi + 63) >> 6) << 2) <= ((total + 15) >> 4);
-    if (first) {
-        const uint32_t f = wide ? first_bit64((const uint64_t *)bm, lo, hi) : first_bit(bm, lo, hi);
-        first[i] = f == 0xffffffffu ? (uint32_t)(hi - lo) : f;
+/* ---- the classification kernel ------------------------------------------------------
+ * class_tile_*_kernel: every wavefront streams ONE contiguous share of the corpus in 4 KiB tiles, 64
+ * contiguous bytes per lane (the next tile's loads are issued before the current one is worked on).
+ *   classify   per byte ONE ds_read_b64 of a 256-entry table whose entry holds, for 8 classes, an
+ *              8-bit field that is 1 when the byte value is in the class; acc |= entry << j over 8
+ *              bytes leaves their 8 membership bits of every class in that class's field: no
+ *              per-class work. The table is replicated 32x (64 KiB) so that the 32 lanes of each
+ *              half of a ds_read_b64 hit 32 different bank pairs: conflict-free. Eight 4x4 byte
+ *              transposes (v_perm) turn the 8 accumulators into one 64-bit membership word per class.
+ *   store      8 bytes per lane and class: 512 contiguous bytes per wavefront and class.
+ *   first/last (FL) the same words go to a 4 KiB LDS area of the wavefront, and the blocks that lie
+ *              wholly inside the tile get their first / last member per class from there, one lane
+ *              per block -- the bitmaps are never read back from HBM. The block offsets a tile needs
+ *              are requested one tile ahead (which blocks start in a tile depends on the offsets
+ *              alone, not on the classification), so no load is waited for. Wavefront-local: no
+ *              workgroup barrier after the table is staged. A block that crosses a tile boundary stays
+ *              "open": what is known of its first / last members is carried to the next tile in
+ *              scalar registers (found with ballots over the lanes' words, no LDS); a wavefront whose
+ *              share ends inside a block reads on past its share until that block ends.
+ * HBM traffic per corpus byte: 1 read + n_classes / 8 written (+ offsets and first / last per block):
+ * the algorithmic bytes. (Round 1's two kernels re-read every bitmap and every offset per class.) */
+constexpr int CT_THREADS = 1024;
+constexpr uint32_t CT_TILE = 4096;                     /* bytes per wavefront tile */
+constexpr uint32_t CT_TABLE_BYTES = 256 * 32 * 8;       /* 64 KiB */
+constexpr uint32_t CT_PAD = 16;                         /* two zero words on either side of a class's 64 tile words */
+constexpr uint32_t CT_ROW = CT_PAD + 64 * 8 + CT_PAD;
+constexpr uint32_t CT_WAVE_LDS = 8 * CT_ROW + 64;       /* 8 classes per wavefront + the open block's {first, last} so far per class */
+constexpr uint32_t CT_LDS_BYTES = CT_TABLE_BYTES + (CT_THREADS / 64) * CT_WAVE_LDS;
+
+__device__ __forceinline__ uint2 lds_read64(uint32_t addr) {
+    const uint64_t v = *(const __attribute__((address_space(3))) uint64_t *)(uintptr_t)addr;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ uint64_t lds_word(uint32_t addr) {
+    return *(const __attribute__((address_space(3))) uint64_t *)(uintptr_t)addr;
+}
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+/* index of the lowest / number of zeros above the highest set bit; 0xffffffff for 0 */
+__device__ __forceinline__ uint32_t ffbl(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t ffbh(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+/* rows r0..r3 (4 bytes each) -> columns: o[c] = {r0.byte c, r1.byte c, r2.byte c, r3.byte c} */
+__device__ __forceinline__ void transpose4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t o[4]) {
+    const uint32_t t0 = perm(r1, r0, 0x05010400u), t1 = perm(r1, r0, 0x07030602u);
+    const uint32_t t2 = perm(r3, r2, 0x05010400u), t3 = perm(r3, r2, 0x07030602u);
+    o[0] = perm(t2, t0, 0x05040100u);
+    o[1] = perm(t2, t0, 0x07060302u);
+    o[2] = perm(t3, t1, 0x05040100u);
+    o[3] = perm(t3, t1, 0x07060302u);
+}
+
+/* 8 bytes (two dwords) -> the 8-bit membership fields of 8 classes */
+__device__ __forceinline__ uint2 classify8(uint32_t d0, uint32_t d1, uint32_t col8) {
+    uint2 acc = make_uint2(0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t d = j < 4 ? d0 : d1;
+        const int q = j & 3;
+        const uint32_t sh = q == 0 ? d << 8 : (q == 1 ? d : d >> (8 * (q - 1)));
+        const uint2 e = lds_read64((sh & 0xff00u) | col8);
+        acc.x |= e.x << j;
+        acc.y |= e.y << j;
     }
-    if (last) last[i] = wide ? last_bit64((const uint64_t *)bm, lo, hi) : last_bit(bm, lo, hi);
+    return acc;
+}
+
+/* First / last set bit of one class's tile bits inside [az, zz), zz > az, as tile bit numbers (0xffffffff:
+ * none). `row`: LDS byte address of the class's word 0. Two windows of three words, one from the block's
+ * first word up (masked below az), one from its last word down (masked above zz - 1): whatever a window finds
+ * outside the block -- bits of the neighbouring blocks, the zero padding around the row -- fails the range
+ * check, so no mask depends on how many words the block covers. Blocks of more than three words whose
+ * windows found nothing go on word by word. */
+__device__ __forceinline__ void tile_first_last(uint32_t row, uint32_t az, uint32_t zz, uint32_t &f, uint32_t &l) {
+    const uint32_t w0 = az >> 6, w1 = (zz - 1u) >> 6;
+    const uint32_t fa = row + w0 * 8u, la = row + w1 * 8u;
+    const uint64_t a0 = lds_word(fa) & (~0ull << (az & 63u)), a1 = lds_word(fa + 8u), a2 = lds_word(fa + 16u);
+    const uint64_t b0 = lds_word(la) & (~0ull >> (63u - ((zz - 1u) & 63u))), b1 = lds_word(la - 8u), b2 = lds_word(la - 16u);
+    /* v_ffbl / v_ffbh give 0xffffffff for 0: OR-ing in the dword's base keeps "none" the largest value */
+    const uint32_t fr = min(min3u(ffbl((uint32_t)a0), ffbl((uint32_t)(a0 >> 32)) | 32u, ffbl((uint32_t)a1) | 64u),
+                            min3u(ffbl((uint32_t)(a1 >> 32)) | 96u, ffbl((uint32_t)a2) | 128u, ffbl((uint32_t)(a2 >> 32)) | 160u));
+    const uint32_t lr = min(min3u(ffbh((uint32_t)(b0 >> 32)), ffbh((uint32_t)b0) | 32u, ffbh((uint32_t)(b1 >> 32)) | 64u),
+                            min3u(ffbh((uint32_t)b1) | 96u, ffbh((uint32_t)(b2 >> 32)) | 128u, ffbh((uint32_t)b2) | 160u));
+    f = w0 * 64u + fr; /* none: far beyond zz */
+    f = (fr != 0xffffffffu && f < zz) ? f : 0xffffffffu;
+    l = w1 * 64u + 63u - lr;
+    l = (lr != 0xffffffffu && (int32_t)l >= (int32_t)az) ? l : 0xffffffffu;
+    if (__any(w1 > w0 + 2 && (f == 0xffffffffu || l == 0xffffffffu))) {
+        if (w1 > w0 + 2) {
+            if (f == 0xffffffffu)
+                for (uint32_t w = w0 + 3; w <= w1; w++) {
+                    uint64_t v = lds_word(row + w * 8u);
+                    if (w == w1) v &= ~0ull >> (63u - ((zz - 1u) & 63u));
+                    if (v) {
+                        f = w * 64u + (uint32_t)__builtin_ctzll(v);
+                        break;
+                    }
+                }
+            if (l == 0xffffffffu && f != 0xffffffffu) /* (no first: no last either) */
+                for (uint32_t w = w1 - 3;; w--) {
+                    uint64_t v = lds_word(row + w * 8u);
+                    if (w == w0) v &= ~0ull << (az & 63u);
+                    if (v) {
+                        l = w * 64u + 63u - (uint32_t)__builtin_clzll(v);
+                        break;
+                    }
+                    if (w == w0) break;
+                }
+        }
+    }
+}
+
+/* number of offsets off[0 .. n) below `target` (off ascending), by the whole wavefront: 64-ary search */
+__device__ __forceinline__ uint64_t wave_lower_bound(const uint64_t *off, uint64_t n, uint64_t target, uint32_t lane) {
+    uint64_t lo = 0, hi = n; /* answer in [lo, hi] */
+    while (hi - lo > 64) {
+        const uint64_t step = (hi - lo + 63) / 64;
+        const uint64_t probe = min(lo + (uint64_t)lane * step, hi - 1);
+        const uint64_t below = __ballot(off[probe] < target); /* a prefix of the lanes */
+        const uint32_t k = (uint32_t)__popcll(below);
+        if (k == 0) return lo; /* off[lo] >= target */
+        const uint64_t nlo = min(lo + (uint64_t)(k - 1) * step, hi - 1) + 1; /* that probe is below: the answer is after it */
+        const uint64_t nhi = k < 64 ? min(lo + (uint64_t)k * step, hi - 1) : hi;
+        lo = nlo;
+        hi = nhi < lo ? lo : nhi;
+    }
+    const uint64_t idx = lo + lane;
+    const uint64_t below = __ballot(idx < hi && off[idx] < target);
+    return lo + (uint64_t)__popcll(below);
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), (int)l) << 32 |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+}
+
+template <bool FL>
+__device__ __forceinline__ void class_tile_body(const uint8_t *corpus, uint64_t total, const uint2 *lut /* [256] */,
+                                                uint32_t n_classes, uint16_t *const *bitmaps, int aligned8, const uint64_t *off,
+                                                uint64_t nblocks, uint32_t *first, uint32_t *last) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds64[]; /* [256][32] table, then [16][8][64] tile words */
+    for (uint32_t i = threadIdx.x; i < 256 * 32; i += CT_THREADS) {
+        const uint2 e = lut[i >> 5];
+        lds64[i] = (uint64_t)e.y << 32 | e.x;
+    }
+    if (FL)
+        for (uint32_t i = CT_TABLE_BYTES / 8 + threadIdx.x; i < CT_LDS_BYTES / 8; i += CT_THREADS) lds64[i] = 0; /* row padding */
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t col8 = (lane & 31u) << 3;
+    const uint32_t tb = CT_TABLE_BYTES + wave * CT_WAVE_LDS; /* this wavefront's tile words: byte address of [class][lane] */
+    /* first / last: one lane per (block, class) pair, 64 >> lg blocks at a time */
+    const uint32_t lg = n_classes > 4 ? 3u : n_classes > 2 ? 2u : n_classes > 1 ? 1u : 0u;
+    const uint32_t cls = lane & ((1u << lg) - 1u), sub = lane >> lg, per_round = 64u >> lg;
+    const uint32_t row = tb + cls * CT_ROW + CT_PAD; /* this lane's class: byte address of tile word 0 */
+    const uint32_t part = tb + 8 * CT_ROW + cls * 8u; /* the open block's {first, last} so far for this lane's class */
+    const uint64_t cls_off = (uint64_t)cls * nblocks;
+    uint16_t *bm[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) bm[c] = bitmaps[c];
+
+    const uint64_t n_tiles = (total + CT_TILE - 1) / CT_TILE;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (CT_THREADS / 64);
+    const uint64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * (CT_THREADS / 64) + wave;
+    uint64_t tile = min(n_tiles, wave_global * per_wave);
+    const uint64_t tile_end = min(n_tiles, tile + per_wave);
+    if (tile >= tile_end) return;
+
+    /* a tile's 4 loads through a buffer descriptor over the tile's whole 16-byte pieces (a ragged last
+     * piece is read byte by byte where it is used); a disabled tile gets an empty descriptor: zeros, no
+     * memory touched */
+    auto issue = [&](uint64_t t, bool enable, uint4 d[4]) {
+        const uint64_t base = enable ? t * CT_TILE : 0;
+        const uint64_t left = enable ? total - base : 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(corpus + base), 0,
+                                                                             (int)(min<uint64_t>(left, (uint64_t)CT_TILE) & ~15ull), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 64u + k * 16u, 0, 0);
+            d[k] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    /* the offsets of 64 blocks from `cur` on (lane i: block cur + i), clamped: nothing branches */
+    auto window = [&](uint64_t cur, uint64_t &s, uint64_t &e) {
+        s = off[min(cur + lane, nblocks)];
+        e = off[min(cur + lane + 1, nblocks)];
+    };
+
+    uint64_t cursor = 0, ws = 0, we = 0;
+    if (FL) {
+        cursor = wave_lower_bound(off, nblocks, tile * CT_TILE, lane); /* first block that starts in this share */
+        window(cursor, ws, we);
+    }
+    /* the block that began in an earlier tile and has not ended yet (at most one): wave-uniform; what is
+     * known of its first / last members so far (relative to its start) sits in LDS, per class */
+    bool open = false;
+    uint64_t ob = 0, os = 0, oe = 0;
+
+    /* two tiles in flight ahead of the one being worked on */
+    uint4 nxt[4], nx2[4];
+    issue(tile, true, nxt);
+    issue(tile + 1, tile + 1 < tile_end, nx2);
+    bool nx2_loaded = tile + 1 < tile_end;
+    for (;; tile++) {
+        const bool extra = tile >= tile_end; /* past the share: only to finish the open block */
+        if (extra && !open) break;
+        uint4 d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = nxt[k], nxt[k] = nx2[k];
+        const bool nxt_loaded = nx2_loaded;
+        const uint64_t lo = tile * CT_TILE, hi = lo + CT_TILE;
+        const bool last_tile = tile + 1 == n_tiles;
+
+        /* Which blocks start in this tile is known from the offsets alone: count them now and ask for the next
+         * tile's window a whole tile of work ahead of its use. The same tells whether a block will still be
+         * open after this tile, i.e. whether a tile past the share must be fetched. */
+        const uint64_t cur0 = cursor, s0 = ws, e0 = we;
+        uint32_t n0 = 0;
+        bool open_after = open && oe > hi;
+        if (FL && !extra) {
+            const bool started = cur0 + lane < nblocks && (last_tile || s0 < hi);
+            n0 = (uint32_t)__popcll(__ballot(started));
+            if (n0 < 64) {
+                cursor = cur0 + n0;
+                window(cursor, ws, we);
+            }
+            if (n0 == 64) open_after = true;
+            else if (n0) open_after = open_after || readlane64(e0, n0 - 1) > hi;
+        }
+        nx2_loaded = tile + 2 < tile_end;
+        issue(tile + 2, nx2_loaded, nx2);
+        if (tile + 1 >= tile_end && !nxt_loaded) /* a tile past the share, only when a block is still open there */
+            issue(tile + 1, tile + 1 < n_tiles && open_after, nxt);
+
+        if (last_tile && (total & 15)) { /* the ragged last piece of the corpus: one lane, byte by byte */
+            const uint32_t piece = (uint32_t)((total - lo) >> 4);
+            if (lane == piece >> 2) {
+                uint32_t r[4] = {0, 0, 0, 0};
+                const uint8_t *src = corpus + lo + (uint64_t)piece * 16;
+                for (uint32_t i = 0; i < (uint32_t)(total & 15); i++) r[i >> 2] |= (uint32_t)src[i] << (8 * (i & 3));
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((piece & 3) == (uint32_t)k) d[k] = make_uint4(r[0], r[1], r[2], r[3]);
+            }
+        }
+
+        /* classify: 8 accumulators of 8 bytes each, then one 64-bit word per class */
+        uint2 a[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            a[2 * k] = classify8(d[k].x, d[k].y, col8);
+            a[2 * k + 1] = classify8(d[k].z, d[k].w, col8);
+        }
+        uint32_t xl[4], xh[4], yl[4], yh[4];
+        transpose4(a[0].x, a[1].x, a[2].x, a[3].x, xl);
+        transpose4(a[4].x, a[5].x, a[6].x, a[7].x, xh);
+        transpose4(a[0].y, a[1].y, a[2].y, a[3].y, yl);
+        transpose4(a[4].y, a[5].y, a[6].y, a[7].y, yh);
+        uint64_t m[8];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            m[c] = (uint64_t)xh[c] << 32 | xl[c];
+            m[4 + c] = (uint64_t)yh[c] << 32 | yl[c];
+        }
+        const uint64_t lane_base = lo + lane * 64ull;
+        if (last_tile) { /* bytes past the end are not members of anything */
+            const uint64_t left = lane_base < total ? total - lane_base : 0;
+            const uint64_t keep = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+#pragma unroll
+            for (int c = 0; c < 8; c++) m[c] &= keep;
+        }
+        if (!extra) {
+            if (aligned8 && !last_tile) {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if ((uint32_t)c < n_classes) *(uint64_t *)(bm[c] + (lane_base >> 4)) = m[c];
+            } else { /* bitmaps hold (total + 15) / 16 16-bit words */
+                const uint64_t words = (total + 15) >> 4;
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if ((uint32_t)c < n_classes)
+                        for (uint32_t q = 0; q < 4; q++)
+                            if ((lane_base >> 4) + q < words) bm[c][(lane_base >> 4) + q] = (uint16_t)(m[c] >> (16 * q));
+            }
+        }
+        if (!FL) continue;
+
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            *(__attribute__((address_space(3))) uint64_t *)(uintptr_t)(tb + c * CT_ROW + CT_PAD + lane * 8u) = m[c];
+        __builtin_amdgcn_wave_barrier();
+
+        /* the open block's share of this tile, bits [0, z): lanes 0 .. classes - 1 of the first group */
+        if (open) {
+            const uint32_t z = (uint32_t)(min(oe, hi) - lo);
+            const bool mine = sub == 0 && cls < n_classes;
+            uint32_t f = 0xffffffffu, l = 0xffffffffu;
+            tile_first_last(row, 0, mine ? z : 1u, f, l);
+            if (mine) {
+                const uint2 sofar = lds_read64(part);
+                const uint32_t base = (uint32_t)(lo - os);
+                const uint32_t pf = sofar.x != 0xffffffffu ? sofar.x : (f != 0xffffffffu ? base + f : f);
+                const uint32_t pl = l != 0xffffffffu ? base + l : sofar.y;
+                if (oe <= hi) { /* it ends here */
+                    if (first) first[cls_off + ob] = pf == 0xffffffffu ? (uint32_t)(oe - os) : pf;
+                    if (last) last[cls_off + ob] = pl;
+                } else {
+                    *(__attribute__((address_space(3))) uint64_t *)(uintptr_t)part = (uint64_t)pl << 32 | pf;
+                }
+            }
+            if (oe <= hi) open = false;
+        }
+        if (extra) continue;
+
+        /* the blocks that start in the tile, 64 at a time (more than one round only for blocks under 64 bytes) */
+        uint64_t cur = cur0, s = s0, e = e0;
+        uint32_t n = n0;
+        for (;;) {
+            const bool started = cur + lane < nblocks && (last_tile || s < hi);
+            /* [s, e) in tile bits; a block that ends in a later tile takes part with what it has here */
+            const uint32_t packed = started ? (uint32_t)(s - lo) | (uint32_t)(min(e, hi) - lo) << 16 | (e > hi ? 1u << 30 : 0u)
+                                            : 0xffffffffu;
+            const uint32_t rounds = (min(n, 64u) + per_round - 1) >> (6 - lg);
+            for (uint32_t r = 0; r < rounds; r++) {
+                const uint32_t j = r * per_round + sub; /* this lane's block of the window, its class is `cls` */
+                const uint32_t pj = (uint32_t)__shfl((int)packed, (int)j);
+                const bool active = pj != 0xffffffffu && cls < n_classes;
+                const uint32_t az = active ? pj & 0xffffu : 0, zz = active ? (pj >> 16) & 0x3fffu : 0;
+                uint32_t f = 0xffffffffu, l = 0xffffffffu;
+                const bool some = zz > az;
+                tile_first_last(row, some ? az : 0, some ? zz : 1u, f, l);
+                if (!some) f = l = 0xffffffffu;
+                if (active) {
+                    if (pj >> 30) { /* the head of a block that goes on: what is known so far, relative to its start */
+                        const uint32_t pf = f == 0xffffffffu ? f : f - az, pl = l == 0xffffffffu ? l : l - az;
+                        *(__attribute__((address_space(3))) uint64_t *)(uintptr_t)part = (uint64_t)pl << 32 | pf;
+                    } else {
+                        const uint64_t at = cls_off + cur + j;
+                        if (first) first[at] = f == 0xffffffffu ? zz - az : f - az;
+                        if (last) last[at] = l == 0xffffffffu ? l : l - az;
+                    }
+                }
+            }
+            /* the one block that starts here and ends in a later tile */
+            const uint64_t over = __ballot(started && e > hi);
+            if (over) {
+                const uint32_t L = (uint32_t)__builtin_ctzll(over);
+                open = true;
+                ob = cur + L;
+                os = readlane64(s, L);
+                oe = readlane64(e, L);
+            }
+            if (n < 64) break;
+            cur += 64;
+            window(cur, s, e);
+            n = (uint32_t)__popcll(__ballot(cur + lane < nblocks && (last_tile || s < hi)));
+            if (n < 64) {
+                cursor = cur + n;
+                window(cursor, ws, we);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* with first / last: 133 KiB of LDS, one workgroup (4 wavefronts per SIMD, up to 128 VGPRs) per CU */
+__global__ __launch_bounds__(CT_THREADS) void class_tile_fl_kernel(const uint8_t *corpus, uint64_t total, const uint2 *lut,
+                                                                    uint32_t n_classes, uint16_t *const *bitmaps, int aligned8,
+                                                                    const uint64_t *off, uint64_t nblocks, uint32_t *first,
+                                                                    uint32_t *last) {
+    class_tile_body<true>(corpus, total, lut, n_classes, bitmaps, aligned8, off, nblocks, first, last);
+}
+/* bitmaps only: the 64 KiB table alone. (Two workgroups per CU, 64 VGPRs each, measured 0.52 ms/GiB against 0.45:
+ * the kernel is bound by its vector and LDS instructions, not by latency.) */
+__global__ __launch_bounds__(CT_THREADS) void class_tile_bm_kernel(const uint8_t *corpus, uint64_t total, const uint2 *lut,
+                                                                       uint32_t n_classes, uint16_t *const *bitmaps, int aligned8) {
+    class_tile_body<false>(corpus, total, lut, n_classes, bitmaps, aligned8, nullptr, 0, nullptr, nullptr);
 }
 
 /* ---- two-byte sets (double shufti / double vermicelli) --------------------------
@@ -302,45 +626,49 @@ extern "C" int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_cla
     if (((uintptr_t)d_corpus & 15) || ((uintptr_t)d_work & 15)) return HSGPU_INVALID;
     if ((d_first || d_last) && (!d_off || nblocks == 0)) return HSGPU_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    /* host-built 256-entry table: entry[v] field c (16 bits) = 1 iff v in class c */
-    uint32_t lut[256][4];
+    /* host-built 256-entry table: entry[v] field c (8 bits) = 1 iff v in class c */
+    uint32_t lut[256][2];
     memset(lut, 0, sizeof(lut));
     for (unsigned c = 0; c < n_classes; c++)
         for (unsigned v = 0; v < 256; v++)
-            if (classes[c].bitmap[v >> 3] >> (v & 7) & 1) lut[v][c >> 1] |= 1u << (16 * (c & 1));
-    /* d_work: [4096 B table][64 B pointer array] supplied by the caller (no hidden allocation) */
+            if (classes[c].bitmap[v >> 3] >> (v & 7) & 1) lut[v][c >> 2] |= 1u << (8 * (c & 3));
+    /* d_work: [2048 B table][64 B pointer array] supplied by the caller (no hidden allocation) */
     uint8_t *work = (uint8_t *)d_work;
     void *ptrs[8] = {nullptr};
+    int aligned8 = 1;
     for (unsigned c = 0; c < n_classes; c++) {
         if (!d_bitmaps[c] || ((uintptr_t)d_bitmaps[c] & 1)) return HSGPU_INVALID;
         ptrs[c] = d_bitmaps[c];
+        if ((uintptr_t)d_bitmaps[c] & 7) aligned8 = 0;
     }
+    static_assert(sizeof(lut) + sizeof(ptrs) <= HSGPU_CLASS_WORK_BYTES, "work area layout");
     HIP_TRY(hipMemcpyAsync(work, lut, sizeof(lut), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(work + sizeof(lut), ptrs, sizeof(ptrs), hipMemcpyHostToDevice, st));
     if (total_bytes == 0) return HSGPU_SUCCESS;
-    const uint4 *d_lut = (const uint4 *)work;
+    const uint2 *d_lut = (const uint2 *)work;
     uint16_t *const *d_ptrs = (uint16_t *const *)(work + sizeof(lut));
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     static bool attr_set = false;
-    const size_t lds = 256 * 16 * sizeof(uint4);
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)class_bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)class_tile_fl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)CT_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)class_tile_bm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)CT_TABLE_BYTES));
         attr_set = true;
     }
-    const uint64_t n_tiles = (total_bytes + CS_TILE - 1) / CS_TILE;
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)n_cu * 2);
+    const uint64_t n_tiles = (total_bytes + CT_TILE - 1) / CT_TILE;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 15) / 16, (uint64_t)n_cu); /* one workgroup per CU */
     const uint8_t *corpus = (const uint8_t *)d_corpus;
-    hipLaunchKernelGGL(class_bitmap_kernel, dim3(grid), dim3(CS_THREADS), lds, st, corpus, total_bytes, d_lut, n_classes,
-                       d_ptrs);
-    HIP_TRY(hipGetLastError());
     if (d_first || d_last) {
-        const uint64_t n = nblocks * n_classes;
-        hipLaunchKernelGGL(class_first_last_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const uint64_t *)d_off, nblocks, n_classes, d_ptrs, total_bytes, (uint32_t *)d_first, (uint32_t *)d_last);
+        hipLaunchKernelGGL(class_tile_fl_kernel, dim3(grid), dim3(CT_THREADS), CT_LDS_BYTES, st, corpus, total_bytes, d_lut,
+                           n_classes, d_ptrs, aligned8, (const uint64_t *)d_off, nblocks, (uint32_t *)d_first, (uint32_t *)d_last);
+        HIP_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(class_tile_bm_kernel, dim3(grid), dim3(CT_THREADS), CT_TABLE_BYTES, st, corpus, total_bytes, d_lut,
+                           n_classes, d_ptrs, aligned8);
         HIP_TRY(hipGetLastError());
     }
     return HSGPU_SUCCESS;
