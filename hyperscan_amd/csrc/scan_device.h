@@ -552,8 +552,8 @@ struct FilterCfg {
  *   prod   v_mul_u32_u24
  *   a      v_lshrrev;  addr  v_and;  word  ds_read_b32
  *   4-byte key:  t1 = word >> (a + b3)            v_add_u32_sdwa (b3 = byte select) + v_lshrrev
- *   3-byte key:  t1 = word >> a                                                      (not BFOLD)
- *   both:        t2 = word >> prod.byte1          v_lshrrev_b32_sdwa                 (K2 only)
+ *                t2 = word >> (prod.byte1 + b3)   same, both operands byte selects   (K2 only)
+ *   3-byte key:  t1 = word >> a, t2 = word >> prod.byte1                            (not BFOLD)
  *   hit = t1 & t2: only bit 0 means anything; v_alignbit shifts exactly that bit into
  *   the top of the accumulator, so no per-lookup mask / shift-into-place is needed.
  * Shifts take their amount mod 32 in hardware, which is the "& 31" of the bit index. */
@@ -570,6 +570,19 @@ template <int BYTE> __device__ __forceinline__ uint32_t add_byte(uint32_t a, uin
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(src));
     else
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(src));
+    return r;
+}
+/* byte 1 of prod + byte BYTE of src */
+template <int BYTE> __device__ __forceinline__ uint32_t add_byte1_byte(uint32_t prod, uint32_t src) {
+    uint32_t r;
+    if (BYTE == 0)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0" : "=v"(r) : "v"(prod), "v"(src));
+    else if (BYTE == 1)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(prod), "v"(src));
+    else if (BYTE == 2)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "=v"(r) : "v"(prod), "v"(src));
+    else
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3" : "=v"(r) : "v"(prod), "v"(src));
     return r;
 }
 /* word >> byte 1 of prod */
@@ -604,17 +617,16 @@ __device__ __forceinline__ void filter_test(const uint32_t (&arr)[6], const Filt
     const uint32_t b3src = arr[(Q + 1) >> 2];
     constexpr int B3 = (Q + 1) & 3;
     const uint32_t a = prod >> f.shift;
-    const uint32_t t2 = K2 && (HAS_A || HAS_B) ? shr_byte1(word, prod) : 0u; /* byte 1 of prod: the second bit index of both key kinds */
     if (HAS_A) {
         uint32_t hit = shr_lo5(word, add_byte<B3>(a, b3src));
-        if (K2) hit &= t2;
+        if (K2) hit &= shr_lo5(word, add_byte1_byte<B3>(prod, b3src)); /* byte 1 of prod: second bit index */
         acc_a = push_top(hit, acc_a, STEP);
     }
     if (HAS_B || HAS_C) {
         uint32_t hit = 0;
         if (HAS_B) {
             hit = shr_lo5(word, a);
-            if (K2) hit &= t2;
+            if (K2) hit &= shr_byte1(word, prod);
         }
         if (HAS_C) {
             constexpr int O = Q + 2;

@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 8u
+#define HSGPU_TABLE_VERSION 7u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
@@ -111,9 +111,7 @@ static_assert(sizeof(HsgpuDevLit) == 32, "DevLit is 32 bytes");
  *   a    = prod >> (32 - r);  word = a * 32 + column
  * bits tested in that word:
  *   bitA  = (a + b3) & 31              4-byte key, first bit   (v_add_u32_sdwa + v_bfe)
- *   bitA2 = (prod >> 8) & 31           4-byte key, second bit  (only with HSGPU_F_K2; byte 1 of prod as the shift
- *                                      amount is an SDWA select: no instruction. b3 enters the first bit only: one
- *                                      v_add less per lookup in a kernel bound by its vector instruction count)
+ *   bitA2 = ((prod >> 8) + b3) & 31    4-byte key, second bit  (only with HSGPU_F_K2; byte 1 of prod: an SDWA select)
  *   bitB  = a & 31                     3-byte key, first bit
  *   bitB2 = (prod >> 8) & 31           3-byte key, second bit  (only with HSGPU_F_K2)
  * With HSGPU_F_BFOLD a 3-byte key sets all 32 bits of its word instead (any b3 passes the bitA tests).
@@ -123,7 +121,7 @@ HSGPU_HD uint32_t hsgpu_filter_shift(uint32_t flags, uint32_t log2) {
     return (flags & HSGPU_F_REPL) ? 32u - log2 : 30u - log2;
 }
 HSGPU_HD uint32_t hsgpu_filter_bit_a(uint32_t b3, uint32_t a) { return (b3 + a) & 31u; }
-HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { (void)b3; return (prod >> 8) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { return (b3 + (prod >> 8)) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t a) { return a & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b2(uint32_t prod) { return (prod >> 8) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_words(uint32_t flags, uint32_t log2) {

@@ -140,7 +140,7 @@ def filter_word_and_bits(h, x24, b3):
     else:
         a = prod >> (30 - k)
         words = [int(h["filter"][a >> 2])]
-    bit_a = [(a + b3) & 31] + ([(prod >> 8) & 31] if fl & F_K2 else [])
+    bit_a = [(a + b3) & 31] + ([((prod >> 8) + b3) & 31] if fl & F_K2 else [])
     bit_b = [a & 31] + ([(prod >> 8) & 31] if fl & F_K2 else [])
     if fl & F_BFOLD:  # the filter kernel runs the 4-byte-key test only; a hit probes both exact tables
         bit_b = bit_a
