@@ -9,7 +9,8 @@ OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --also teddy64"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+# the kernel trace covers every workload of the bench line (class256 at 1 GiB, rose1000 at 0.5 GiB keep it short)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --class-gib 1 --rose-gib 0.5 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc_write.err
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- $CMD > /dev/null 2> $OUT/pmc_sq1.err
@@ -26,7 +27,7 @@ def collect(dirs):
     for d in dirs:
         for f in sorted(glob.glob(out+"/"+d+"/**/*counter_collection.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
-                m=re.search(r"(hwlm_\w+<[^>]*>|record_\w+|block_hint_kernel)", r.get("Kernel_Name",""))
+                m=re.search(r"(hwlm_\w+<[^>]*>|record_\w+|block_hint_kernel|class_\w+|pair_\w+)", r.get("Kernel_Name",""))
                 if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 summ={k:{c:{"avg_KB":sum(x)/len(x),"n":len(x)} for c,x in v.items()} for k,v in collect(("pmc_fetch","pmc_write")).items()}
