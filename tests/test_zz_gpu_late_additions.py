@@ -171,3 +171,33 @@ def test_scan_vector_behaviour_cpp():
     assert hs.scan(db2, b"needle", sc) == hs.HS_DB_MODE_ERROR
     block_db = hs.Database.compile(["needle"])
     assert hs.scan_vector(block_db, [b"needle"], sc) == hs.HS_DB_MODE_ERROR
+
+
+def test_hwlm_exec_argument_order_and_callback_context(scratch):
+    """hsgpu_hwlm_exec takes hwlmExec's arguments in hwlmExec's order (src/hwlm/hwlm.h:120-122) and
+    its callback's third argument is the scratch itself, as the reference passes its hs_scratch
+    (HWLMCallback, src/hwlm/hwlm.h:77-93), or the pointer hung on the scratch."""
+    import ctypes as C
+
+    from hyperscan_amd import _native
+
+    lib = _native.load_library()
+    t = H.hwlm_build([H.HwlmLiteral("needle", False, 7)])
+    buf = np.frombuffer(b"..needle..needle", dtype=np.uint8).copy()
+    seen = []
+
+    def cb(end, lit_id, ctx):
+        seen.append((end, lit_id, ctx))
+        return hw.HWLM_ALL_GROUPS
+
+    ccb = _native.HWLM_CB(cb)
+    rv = lib.hsgpu_hwlm_exec(t._h, buf.ctypes.data, buf.size, 0, ccb, scratch._h, hw.HWLM_ALL_GROUPS)
+    assert rv == 0 and [(e, i) for e, i, _c in seen] == [(7, 7), (15, 7)]
+    assert all(c == scratch._h.value for _e, _i, c in seen), "default context: the scratch"
+    token = C.c_uint64(0)
+    lib.hsgpu_scratch_set_context(scratch._h, C.addressof(token))
+    assert lib.hsgpu_scratch_get_context(scratch._h) == C.addressof(token)
+    del seen[:]
+    rv = lib.hsgpu_hwlm_exec(t._h, buf.ctypes.data, buf.size, 9, ccb, scratch._h, hw.HWLM_ALL_GROUPS)  # start = 9
+    assert rv == 0 and [(e, i, c) for e, i, c in seen] == [(15, 7, C.addressof(token))]
+    lib.hsgpu_scratch_set_context(scratch._h, scratch._h)  # back to the default for the tests that follow

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --also teddy64"
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --also teddy64,class256 --class-gib 1"
 # the kernel trace covers every workload of the bench line (class256 at 1 GiB, rose1000 at 0.5 GiB keep it short)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --class-gib 1 --rose-gib 0.5 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
@@ -32,7 +32,7 @@ def collect(dirs):
     return agg
 summ={k:{c:{"avg_KB":sum(x)/len(x),"n":len(x)} for c,x in v.items()} for k,v in collect(("pmc_fetch","pmc_write")).items()}
 json.dump(summ, open(out+"/pmc_summary.json","w"), indent=1)
-sq={k:{c:round(sum(x)/len(x),1) for c,x in sorted(v.items())} for k,v in collect(("pmc_sq1","pmc_sq2")).items() if "filter" in k}
+sq={k:{c:round(sum(x)/len(x),1) for c,x in sorted(v.items())} for k,v in collect(("pmc_sq1","pmc_sq2")).items() if "filter" in k or "confirm" in k or "class_" in k}
 for k,v in sq.items():
     if v.get("SQ_LDS_IDX_ACTIVE"): v["lds_conflict_share_of_lds_cycles"]=round(v.get("SQ_LDS_BANK_CONFLICT",0)/v["SQ_LDS_IDX_ACTIVE"],3)
     if v.get("SQ_WAVE_CYCLES"):
