@@ -221,7 +221,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     # second stream (its own scratch and record buffer, same table and resident corpus) while step i's
     # record all-gather runs on the first. Every step still does all of its work. N = 1 runs serial
     # steps, so that the per-kernel figures are those of the kernels alone.
-    depth = max(1, min(2, args.pipeline_depth if args.pipeline_depth else (2 if world > 1 else 1)))
+    depth = max(1, min(2, args.pipeline_depth if args.pipeline_depth else (2 if dist is not None else 1)))
     jobs = [job] + [GpuJob(None, None, None, torch.cuda.current_device(), sibling=job) for _ in range(depth - 1)]
     streams = [torch.cuda.Stream(device=job.dev) for _ in range(depth)]
 
@@ -246,7 +246,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     assert all(jb.count() == n_matches for jb in jobs)
 
     exch = None
-    if world > 1:
+    if dist is not None:
         from hyperscan_amd import dist as hd
 
         # global block indices: shards are contiguous block ranges, rank r's first block = blocks of ranks < r
@@ -277,14 +277,14 @@ def run_workload(name, args, rank, world, dist, do_cpu):
 
     # timed region: barrier + sync on both sides, exactly K steps
     ev = None
-    if world > 1:
+    if dist is not None:
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps, exch, ev)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     assert all(jb.count() == n_matches for jb in jobs), "match count changed between repeats"  # hsbench main.cpp:778-787
@@ -300,7 +300,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
             span_ms.append(jb.scratch.kernel_span(back))
     kern_avg_s = float(np.mean(filt_ms)) / 1e3
 
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=job.dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -337,7 +337,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         "records": "in delivery order (block, end, lit), sorted on the device inside the step",
     }
     res["pipeline_depth"] = depth
-    if world > 1:
+    if dist is not None:
         g = [a.elapsed_time(b) for a, b in ev]
         res["exchange"] = {"collective": "all_gather_into_tensor x2 (counts, records padded to a fixed size)",
                            "rows_per_rank": exch[0].rows, "bytes_per_rank_per_step": exch[0].rows * 16 + 16,
@@ -579,17 +579,22 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # HSGPU_BENCH_FORCE_DIST=1: take the N > 1 path (process group, exchange, two streams) at world size 1 too --
+    # the one way to run that code on a 1-GPU box
+    if world > 1 or os.environ.get("HSGPU_BENCH_FORCE_DIST"):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
-    do_cpu = (rank == 0 and world == 1 and not args.no_cpu)
+    do_cpu = (rank == 0 and dist is None and not args.no_cpu)
     main_res = run_workload(args.workload, args, rank, world, dist, do_cpu)
     also = {}
-    if not args.no_also and world == 1:
+    if not args.no_also and dist is None:
         for name in [a for a in args.also.split(",") if a]:
             t0 = time.perf_counter()
             try:
@@ -612,7 +617,7 @@ def main():
             "config": {"workload": f"{args.workload}: {WORKLOAD_DESC[args.workload]}, {args.gib:g} GiB per GPU, block mode, {blocks_desc}",
                        "records": "16 B (block,end,id,lit), delivery order", "pipeline_depth": main_res["pipeline_depth"],
                        "sharding": f"{world} x independent shards"
-                       + (", RCCL all-gather of records per step" if world > 1 else "")},
+                       + (", RCCL all-gather of records per step" if dist is not None else "")},
             "matches_per_s": main_res["matches_per_s"], "matches_per_step": main_res["matches_per_step"],
             "roofline": main_res["roofline"], "table": main_res["table"],
         }
@@ -621,9 +626,17 @@ def main():
                 out[k] = main_res[k]
         if also:
             out["also"] = also
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE line, and the last thing on stdout: RCCL writes a version banner through C stdio, which sits in
+        # libc's buffer (stdout is a pipe) until exit unless it is flushed out first
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

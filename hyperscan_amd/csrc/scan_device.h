@@ -638,14 +638,14 @@ __device__ __forceinline__ void filter_test(const uint32_t (&arr)[6], const Filt
     }
 }
 
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int... I>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int BASE, int... I>
 __device__ __forceinline__ void filter_positions(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
                                                  uint32_t &acc_o, std::integer_sequence<int, I...>) {
     constexpr int STEP = S2 ? 2 : 1;
-    const uint32_t prod[sizeof...(I)] = {filter_hash<REPL, I * STEP>(arr)...};
+    const uint32_t prod[sizeof...(I)] = {filter_hash<REPL, (BASE + I) * STEP>(arr)...};
     const uint32_t word[sizeof...(I)] = {lds_word(filter_addr<REPL>(prod[I], f))...};
     __builtin_amdgcn_sched_barrier(0);
-    (filter_test<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, I * STEP>(arr, f, prod[I], word[I], acc_a, acc_o), ...);
+    (filter_test<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, (BASE + I) * STEP>(arr, f, prod[I], word[I], acc_a, acc_o), ...);
 }
 
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND>
@@ -656,8 +656,13 @@ __device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg
         for (int i = 0; i < 5; i++) arr[i] &= 0xdfdfdfdfu; /* b3's bit 5 never reaches the 5-bit index either */
     }
     uint32_t acc_a = 0, acc_o = 0;
-    filter_positions<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(arr, f, acc_a, acc_o,
-                                                               std::make_integer_sequence<int, S2 ? 8 : 16>{});
+#ifndef HSGPU_FILTER_BATCHES
+#define HSGPU_FILTER_BATCHES 1 /* tuning builds: 2 = the chunk's lookups in two halves (half the registers held across the LDS reads) */
+#endif
+    constexpr int N_LOOK = S2 ? 8 : 16, PER = N_LOOK / HSGPU_FILTER_BATCHES;
+    filter_positions<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, 0>(arr, f, acc_a, acc_o, std::make_integer_sequence<int, PER>{});
+    if (HSGPU_FILTER_BATCHES > 1)
+        filter_positions<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, PER % N_LOOK>(arr, f, acc_a, acc_o, std::make_integer_sequence<int, PER>{});
     /* 16 / STEP pushes of STEP bits: lookup q sits at bit 16 + q (stride 2: odd bits are noise) */
     constexpr uint32_t KEEP = S2 ? 0x5555u : 0xffffu;
     return ((acc_a >> 16) & KEEP) | (acc_o & (KEEP << 16));
@@ -850,7 +855,10 @@ __device__ __forceinline__ void write_block_hints_batch(const uint64_t *off, uin
 
 /* ---- phase 1: the streaming filter (FUSED: + in-kernel confirm) ----------- */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false>
-__global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs args) {
+#ifndef HSGPU_FILTER_MIN_WAVES
+#define HSGPU_FILTER_MIN_WAVES 1 /* tuning builds: 8 caps the kernel at 64 VGPRs so that two 16-wavefront workgroups fit a CU */
+#endif
+__global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filter_kernel(HsgpuScanArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
     /* the fused kernel doubles as the overflow fallback: nothing to do unless the
@@ -921,7 +929,11 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
      * first tiles of the corpus, which stay in flight while the image is written to LDS and the hints are
      * stored. (With the LDS copy and the hints in front, one load and one wait at a time, the memory pipeline
      * idled for the first 25-30 us of every scan.) */
-    constexpr int IMG = 8; /* 16-byte pieces of the image per thread in the first batch: 128 KiB / 1024 threads */
+#ifndef HSGPU_PROLOGUE_IMG
+#define HSGPU_PROLOGUE_IMG 8
+#define HSGPU_PROLOGUE_HK 8
+#endif
+    constexpr int IMG = HSGPU_PROLOGUE_IMG; /* 16-byte pieces of the image per thread in the first batch: 128 KiB / 1024 threads */
     const uint4 *img_src = (const uint4 *)(args.blob + args.t_off_filter);
     uint4 img[IMG];
 #pragma unroll
@@ -930,7 +942,7 @@ __global__ __launch_bounds__(WG_THREADS) void hwlm_filter_kernel(HsgpuScanArgs a
         img[u] = i < nw / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
     }
     const bool hints = !FUSED && args.hint_in_filter;
-    constexpr int HK = 8; /* every lane takes 8 consecutive blocks: 9 offsets, 512 blocks per wavefront and step */
+    constexpr int HK = HSGPU_PROLOGUE_HK; /* every lane takes 8 consecutive blocks: 9 offsets, 512 blocks per wavefront and step */
     const uint64_t hb0 = ((uint64_t)wave_global * 64 + lane) * HK;
     uint64_t ho[HK + 1];
 #pragma unroll

@@ -27,3 +27,26 @@ def test_record_exchange_over_rccl_world_size_1():
                        cwd=root, env=env, capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "EXCHANGE_OK nccl 1" in r.stdout
+
+
+@pytest.mark.timeout(500)
+def test_bench_multi_gpu_path_at_world_size_1():
+    """bench.py's N > 1 code path end to end (process group, fixed-size exchange inside the timed steps, two
+    alternating streams, the all-reduced totals, the `exchange` object of the JSON line) over RCCL at world
+    size 1: HSGPU_BENCH_FORCE_DIST takes that path without a second GPU."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HSGPU_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--gib", "0.0625", "--steps", "6",
+                        "--warmup", "2", "--no-cpu", "--no-also"], cwd=root, env=env, capture_output=True, text=True, timeout=450)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert rows and rows[-1].startswith("{"), "the JSON line is not the last line of stdout: " + repr(r.stdout[-1500:])
+    assert sum(ln.startswith("{") for ln in rows) == 1, "more than one JSON line"
+    line = json.loads(rows[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
+    assert line["config"]["pipeline_depth"] == 2 and "RCCL" in line["config"]["sharding"]
+    ex = line["exchange"]
+    assert ex["rows_per_rank"] >= line["matches_per_step"] and ex["gather_ms_avg_rank0"] > 0
