@@ -627,6 +627,13 @@ def main():
         if also:
             out["also"] = also
     if dist is not None:
+        # every rank empties its C stdio buffer (RCCL's banner) before anyone can print the result line
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         # the ONE line, and the last thing on stdout: RCCL writes a version banner through C stdio, which sits in
