@@ -255,7 +255,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         dist.all_gather_into_tensor(allnb, nb)
         allnb = allnb.view(world, 2).cpu()
         base = int(allnb[:rank, 0].sum())
-        rows = min(job.cap, int(int(allnb[:, 1].max()) * 1.25) + 1024)  # every rank posts the same fixed size
+        rows = min(job.cap, int(allnb[:, 1].max()) + 1024)  # every rank posts the same fixed size: the largest count (every step scans the same shard) + slack
         exch = [hd.RecordExchange(dist, world, rank, job.dev, rows, base) for _ in jobs]
         run_steps(depth, exch)  # untimed: RCCL sets up its rings on first use
         allr, counts = exch[0].compact()
