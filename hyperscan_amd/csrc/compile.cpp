@@ -363,6 +363,12 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     if (!(tflags & (HSGPU_F_REPL | HSGPU_F_HAS_C)) && (tflags & HSGPU_F_HAS_A) && (tflags & HSGPU_F_HAS_B) &&
         !(flags & HSGPU_BUILD_NO_FOLD) && (uint64_t)keys[1].size() * ((tflags & HSGPU_F_STRIDE2) ? 1000 : 100) <= fwords)
         tflags |= HSGPU_F_BFOLD;
+    /* The key gate: while no 2-byte table and no pair gate needs the 64 Kbit section, and the set leaves it mostly
+     * empty, it says which exact-table keys exist at all (see HSGPU_F_GATE). Measured on the 10 000-literal set: 82 %
+     * fewer table probes, confirm stage 0.201 -> 0.173 ms. Small sets have few candidates and nothing to gain from it
+     * (64 literals: the 8 KiB staged per workgroup cost 3 us of a 17 us kernel). */
+    if (!pair && !(tflags & HSGPU_F_HAS_C) && !(flags & HSGPU_BUILD_NO_GATE) && entries >= 2048 && (uint64_t)entries * 2 <= 65536)
+        tflags |= HSGPU_F_GATE;
     const uint32_t fshift = hsgpu_filter_shift(tflags, k);
     uint32_t ht_log2[2];
     for (int c = 0; c < 2; c++)
@@ -430,6 +436,10 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
             uint32_t x1 = (c == 0) ? (key >> 8) : key; /* 3-byte suffix */
             uint32_t prod1 = hsgpu_filter_prod(x1);
             uint32_t a1 = prod1 >> fshift;
+            if (tflags & HSGPU_F_GATE) { /* the key gate of the confirm kernel (no 2-byte table needs the section) */
+                const uint32_t gbit = hsgpu_key_gate_bit(c == 0 ? key : (key | HSGPU_GATE_B_SALT));
+                c2bits[gbit >> 5] |= 1u << (gbit & 31);
+            }
             if (pair) {
                 /* the pair filter is filled from the literals themselves, below; a 3-byte key of either kind
                  * marks the gate bitmap the confirm step consults before it probes this table */

@@ -127,6 +127,7 @@ struct Tables {
     const uint4 *ht_a, *ht_b; /* 16-byte buckets of 4 tagged slots */
     const uint32_t *c2ref, *lists;
     const uint32_t *gate; /* pair tables: 64 Kbit "some 3-byte key has this hash" (hsgpu_gate_bit) */
+    const uint32_t *key_gate; /* confirm kernel, HSGPU_F_GATE tables: the 64 Kbit key gate staged in LDS, else nullptr */
     const HsgpuDevLit *lits;
     uint32_t ht_a_log2, ht_b_log2;
     uint32_t key_mask;    /* 0xdfdfdfdf when the exact-table keys are case-blind, else all ones */
@@ -426,6 +427,11 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
         do_a[u] = HAS_A && any && (m >> j & 1);
         do_b[u] = !PAIR && HAS_B && any && (m >> (16 + j) & 1); /* pair tables: through the gate bitmap, below */
         do_c[u] = HAS_C && any && (m >> (16 + j) & 1);
+        if (!PAIR && t.key_gate) { /* keys that no exact table holds need no probe: 14 % of them pass on a 10 000-literal set */
+            const uint32_t ga = hsgpu_key_gate_bit(w4[u]), gb = hsgpu_key_gate_bit((w4[u] >> 8) | HSGPU_GATE_B_SALT);
+            if (HAS_A) do_a[u] = do_a[u] && ((t.key_gate[ga >> 5] >> (ga & 31)) & 1u);
+            if (HAS_B) do_b[u] = do_b[u] && ((t.key_gate[gb >> 5] >> (gb & 31)) & 1u);
+        }
         const uint32_t rest = any & (any - 1);
         pend[u] = m & (rest | rest << 16);
     }
@@ -773,6 +779,7 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.ht_b = (const uint4 *)(args.blob + args.t_off_ht_b);
     t.c2ref = (const uint32_t *)(args.blob + args.t_off_c2ref);
     t.gate = (const uint32_t *)(args.blob + args.t_off_c2bits);
+    t.key_gate = nullptr;
     t.lists = (const uint32_t *)(args.blob + args.t_off_lists);
     t.lits = (const HsgpuDevLit *)(args.blob + args.t_off_lits);
     t.ht_a_log2 = args.t_ht_a_log2;
@@ -1105,7 +1112,14 @@ template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
 __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ WaveLds wave_lds[CONFIRM_THREADS / 64];
     __shared__ uint2 rest_q[CONFIRM_THREADS / 64][RQ_CAP];
+    __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
     if (args.cand_counts[args.cand_waves]) return; /* overflow: the fused fallback redoes the scan */
+    const bool gated = !PAIR && (args.t_flags & HSGPU_F_GATE);
+    if (gated) { /* the whole workgroup, before any wavefront leaves */
+        const uint4 *src = (const uint4 *)(args.blob + args.t_off_c2bits);
+        for (uint32_t i = threadIdx.x; i < 512; i += CONFIRM_THREADS) key_gate[i] = src[i];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t cw = blockIdx.x * (CONFIRM_THREADS / 64) + wave; /* confirm wavefront = record region */
@@ -1115,6 +1129,7 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     if (part * 128 >= n) return; /* nothing for this wavefront (its record counts stay zero) */
     Tables t;
     init_tables(t, args);
+    if (gated) t.key_gate = (const uint32_t *)key_gate;
     init_wave_lds(t, wave_lds + wave, lane);
     t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
     t.rec_cap = args.rec_cap;

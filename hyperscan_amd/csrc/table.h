@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 9u
+#define HSGPU_TABLE_VERSION 10u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
@@ -45,6 +45,9 @@
 #define HSGPU_F_PAIR 256u   /* pair filter (large sets, short literals included): stride 2, 64-bit entries hashed on the
                              * 3 bytes ending at the lookup position, one 32-bit plane indexed by the byte BEFORE them
                              * and one by the byte AFTER them; see "the pair filter" below */
+#define HSGPU_F_GATE 512u   /* the c2bits section holds the key gate: 64 Kbit, bit hsgpu_key_gate_bit(key) set for every
+                             * key of the two exact tables (3-byte keys salted). The confirm kernel stages it in LDS
+                             * and probes a table (one divergent 16-byte read per lane) only for keys that pass */
 
 #define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
 #define HSGPU_HT_MUL 0x9E3779B1u
@@ -156,6 +159,11 @@ HSGPU_HD uint32_t hsgpu_pair_bit_a(uint32_t nx) { return nx & 31u; }
 /* gate bitmap (64 Kbit, in the c2bits section of a pair table): is there ANY 3-byte key (of either kind)
  * with this hash? The confirm step probes the 3-byte exact table only then. */
 HSGPU_HD uint32_t hsgpu_gate_bit(uint32_t key25) { return (key25 * HSGPU_HT_MUL) >> 16; }
+
+/* key gate (HSGPU_F_GATE): the top 16 bits of the product the bucket index is taken from; 3-byte keys carry a salt
+ * in their free top byte so that they do not alias the 4-byte key with a zero first byte */
+#define HSGPU_GATE_B_SALT 0xB5000000u
+HSGPU_HD uint32_t hsgpu_key_gate_bit(uint32_t key) { return (key * HSGPU_HT_MUL) >> 16; }
 
 HSGPU_HD uint32_t hsgpu_ht_bucket(uint32_t key, uint32_t log2) { return (key * HSGPU_HT_MUL) >> (32u - log2); }
 HSGPU_HD uint32_t hsgpu_ht_tag(uint32_t key, uint32_t log2) { return ((key * HSGPU_HT_MUL) >> (26u - log2)) & HSGPU_SLOT_TAG_MASK; }

@@ -110,6 +110,7 @@ typedef struct hsgpu_hwlm_info {
 #define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
 #define HSGPU_BUILD_NO_FOLD 512u    /* keep the separate 3-byte-key filter test even when only few such keys exist */
 #define HSGPU_BUILD_FORCE_PAIR 1024u /* the stride-2 pair filter (opt-in; an error for sets it cannot hold) */
+#define HSGPU_BUILD_NO_GATE 4096u    /* no key gate in front of the exact hash tables (the confirm kernel then probes a table for every candidate) */
 #define HSGPU_BUILD_NO_PAIR 2048u    /* never the pair filter (the default today) */
 
 /* ---- build side ---------------------------------------------------------- */

@@ -20,6 +20,7 @@ from tests.util import random_literals
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 F_A, F_B, F_C, F_REPL, F_K2, F_S2, F_BLIND, F_BFOLD, F_PAIR = 1, 2, 4, 8, 16, 32, 64, 128, 256
+F_GATE = 512
 FORCE_REPL, FORCE_HASHED, FORCE_K2, FORCE_K1, FORCE_S1, FORCE_BLIND, FORCE_S2, NO_FOLD = 1, 2, 4, 8, 16, 32, 64, 512
 FORCE_PAIR, KEY_M = 1024, 0x01000000
 MUL, HT_MUL = 0x9E3779, 0x9E3779B1
@@ -177,10 +178,17 @@ def check_table_covers(lits, flags):
                 w4 = (w[0] | w[1] << 8 | w[2] << 16 | w[3] << 24) & key_mask
                 want = li | d << 30
                 found = False
-                if fl & F_A and all(all(wd >> b & 1 for b in bit_a) for wd in words):
+
+                def gate(key):  # HSGPU_F_GATE: the confirm kernel probes a table only for keys whose gate bit is set
+                    if not fl & F_GATE:
+                        return True
+                    g = ((key * HT_MUL) & 0xFFFFFFFF) >> 16
+                    return bool(h["c2bits"][g >> 5] >> (g & 31) & 1)
+
+                if fl & F_A and all(all(wd >> b & 1 for b in bit_a) for wd in words) and gate(w4):
                     ents = ht_lookup(h, h["ht_a"], h["ht_a_log2"], w4)
                     found |= ents is not None and want in ents
-                if not found and fl & F_B and all(all(wd >> b & 1 for b in bit_b) for wd in words):
+                if not found and fl & F_B and all(all(wd >> b & 1 for b in bit_b) for wd in words) and gate((w4 >> 8) | 0xB5000000):
                     ents = ht_lookup(h, h["ht_b"], h["ht_b_log2"], w4 >> 8)
                     found |= ents is not None and want in ents
                 if not found and fl & F_C:
@@ -684,3 +692,18 @@ def test_host_record_sort_matches_lexsort():
         lib.hsgpu_match_sort_host(r.ctypes.data, n)
         assert np.array_equal(r["block"], want["block"]) and np.array_equal(r["end"], want["end"])
         assert np.array_equal(r["lit"], want["lit"]) and np.array_equal(r["id"], want["id"])
+
+
+def test_key_gate_of_large_sets_admits_every_key():
+    """HSGPU_F_GATE (sets of >= 2048 keys without a 2-byte table): the confirm kernel probes an exact table only
+    for keys whose bit is set in the 64 Kbit gate, so every key of every literal, case variants included, must have
+    its bit -- check_table_covers models the gate -- and the gate must be selective (mostly empty)."""
+    rng = np.random.default_rng(77)
+    lits = random_literals(rng, 3000, 3, 8, nocase_frac=0.3)
+    h = check_table_covers(lits, 0)
+    assert h["flags"] & F_GATE and not h["flags"] & F_C
+    fill = sum(bin(int(w)).count("1") for w in h["c2bits"]) / 65536.0
+    assert 0.01 < fill < 0.2, fill
+    # NO_GATE: the section stays empty and the flag off
+    h2 = parse(H.hwlm_build(lits, 4096).serialize())
+    assert not h2["flags"] & F_GATE and not any(int(w) for w in h2["c2bits"])
