@@ -300,7 +300,7 @@ __device__ __forceinline__ void class_tile_body(const uint8_t *corpus, uint64_t 
     bool nx2_loaded = tile + 1 < tile_end;
     for (;; tile++) {
         const bool extra = tile >= tile_end; /* past the share: only to finish the open block */
-        if (extra && !open) break;
+        if ((extra && !open) || tile >= n_tiles) break; /* (offsets that run past the corpus must not keep a wavefront here) */
         uint4 d[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) d[k] = nxt[k], nxt[k] = nx2[k];
