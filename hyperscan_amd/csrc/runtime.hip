@@ -75,8 +75,9 @@ struct hsgpu_scratch {
     uint64_t n_timed = 0;       /* scans launched with timing on */
     DevBuf tstamp;              /* [kRing][4] device wall clock: filter start (min) / end (max), confirm-stage end, pipeline end */
     double wall_clock_khz = 100000.0;
-    DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, order, stats;
-    bool ctl_clean = false;                /* every control word is zero (left so by record_sort_kernel) */
+    DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats;
+    bool ctl_clean = false;                /* the control block the next scan will use is zero (left so by the scan before last) */
+    unsigned ctl_parity = 0;               /* which half of the control buffer the next scan uses */
     unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
     int n_cu = 0;
@@ -164,7 +165,6 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->off.release();
     s->out.release();
     s->count.release();
-    s->order.release();
     s->hint.release();
     s->cand.release();
     s->ctl.release();
@@ -361,26 +361,34 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.rec_regions = n_rec;
     args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
     if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
-    /* one zeroed control block: rec_counts[2 n_rec] | cand_counts[n_waves + 1] */
-    const size_t cand_ofs = (size_t)2 * n_rec, ctl_words = cand_ofs + n_waves + 1;
-    /* a reallocated control block is garbage whatever its address: hipMalloc may hand the
+    /* Two control blocks that alternate from scan to scan, each rec_counts[2 n_rec] | cand_counts[n_waves + 1] |
+     * rec_super[257] (64-bit): a scan works in one and its last kernel zeroes the other (the previous scan's), so
+     * the next scan finds its block zeroed without a memset. */
+    const size_t cand_ofs = (size_t)2 * n_rec;
+    const size_t super_ofs = (cand_ofs + n_waves + 1 + 1) & ~(size_t)1; /* 8-byte aligned */
+    const size_t blk_words = (super_ofs + 2 * 257 + 3) & ~(size_t)3;
+    /* a reallocated control buffer is garbage whatever its address: hipMalloc may hand the
      * freed range straight back, so growth is detected by capacity, never by pointer */
     const size_t ctl_cap_before = s->ctl.cap;
-    if ((rv = s->ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->ctl.ensure(2 * blk_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
     if (s->ctl.cap != ctl_cap_before) s->ctl_clean = false;
-    /* rec_offsets[n_rec + 1] | order_state */
-    if ((rv = s->order.ensure(((size_t)n_rec + 2) * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
+    const size_t half_words = (s->ctl.cap / 8) & ~(size_t)3; /* the second block starts at the same place whatever this scan's size */
+    if (!s->ctl_clean) { /* a fresh (or possibly dirty) buffer: both blocks */
+        HIP_TRY(hipMemsetAsync(s->ctl.p, 0, s->ctl.cap, stream));
+        s->ctl_parity = 0;
+    }
+    s->ctl_clean = false; /* until this scan's record_sort_kernel has been queued */
+    uint32_t *blk = (uint32_t *)s->ctl.p + (s->ctl_parity ? half_words : 0);
+    args.ctl_other = (uint32_t *)s->ctl.p + (s->ctl_parity ? 0 : half_words);
+    args.ctl_other_words = (uint32_t)half_words;
     args.rec_stage = (uint4 *)s->rec_stage.p;
-    args.rec_counts = (uint32_t *)s->ctl.p;
-    args.rec_offsets = (unsigned long long *)s->order.p;
-    args.order_state = (uint32_t *)(args.rec_offsets + n_rec + 1);
+    args.rec_counts = blk;
+    args.rec_super = (unsigned long long *)(blk + super_ofs);
+    args.super_shift = 5; /* up to 256 supers: atomics on one address serialise (~0.1 us each), 64 regions share one here */
+    while (((n_rec + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
     /* the regions fed by one filter wavefront: the records of one contiguous share of the corpus */
     args.group_regions = HSGPU_CONFIRM_SPLIT;
     args.stats = (unsigned long long *)s->stats.p;
-    /* the control words are left zeroed by the previous scan's last kernel; only a
-     * fresh (or possibly dirty) buffer needs a memset */
-    if (!s->ctl_clean) HIP_TRY(hipMemsetAsync(s->ctl.p, 0, s->ctl.cap, stream));
-    s->ctl_clean = false; /* until this scan's record_sort_kernel has been queued */
 
     void *kargs[] = {&args};
     args.tstamp = nullptr;
@@ -413,7 +421,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / cand_div + n_waves - 1) / n_waves);
         if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32)) != HSGPU_SUCCESS) return rv;
         args.cand = (uint4 *)s->cand.p;
-        args.cand_counts = (uint32_t *)s->ctl.p + cand_ofs;
+        args.cand_counts = blk + cand_ofs;
         if ((rv = set_dyn_lds(f_two, lds_two)) != HSGPU_SUCCESS) return rv;
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
@@ -421,12 +429,12 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
     }
-    HIP_TRY(hipLaunchKernel(hsgpu_record_scan_kernel(), dim3(1), dim3(1024), kargs, 0, stream));
     if (s->timing) s->n_timed++;
     /* one workgroup per share of the corpus: its records sorted into place; the control block back to zero */
     HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions), dim3(256),
                             kargs, 0, stream));
     s->ctl_clean = true;
+    s->ctl_parity ^= 1u;
     return HSGPU_SUCCESS;
 }
 

@@ -44,7 +44,7 @@
  *                       the slot names; hits are queued in LDS and resolved 64 at
  *                       a time (id/size, block lookup through the hint table, bound
  *                       checks), records stored into the wavefront's region;
- *   record_scan / record_pack / control_reset   pack the per-wavefront record regions
+ *   record_sort                                 the per-wavefront record regions into delivery order (phase 3)
  *                       into the caller's buffer, write *count, re-zero the control words.
  * A fused variant (confirm inside the streaming kernel) is kept as the
  * always-correct fallback for inputs so dense that the candidate buffer
@@ -263,9 +263,15 @@ __device__ __forceinline__ void publish_records(const Tables &t, const HsgpuScan
                                                 uint32_t region) {
     flush_records(t, lane, 1);
     if (lane == 0) {
-        args.rec_counts[2 * region] = t.wl->nfront;
-        args.rec_counts[2 * region + 1] =
-            __hip_atomic_load(&t.wl->nback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t front = t.wl->nfront,
+                       back = __hip_atomic_load(&t.wl->nback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        args.rec_counts[2 * region] = front;
+        args.rec_counts[2 * region + 1] = back;
+        /* one atomic per region (not per record): the fills of 2^super_shift consecutive regions added up, so that
+         * every sort workgroup can place its share without a scan kernel in between */
+        const unsigned long long fill = (unsigned long long)front + back;
+        if (fill) atomicAdd(&args.rec_super[region >> args.super_shift], fill);
+        if (fill > args.rec_cap) atomicAdd(&args.rec_super[256], 1ull); /* the region lost records */
     }
 }
 
@@ -1174,13 +1180,15 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
  * (block, end, literal index). Every filter wavefront streams ONE contiguous share of the corpus (see the
  * tile loop), so the staging regions fed from its candidates -- consecutive region numbers -- hold exactly
  * the records of that share, and the shares follow each other in region order:
- *   record_scan  one workgroup: exclusive scan of the region fills (where each region's records go in the
- *                output), *count, "is the output complete"
- *   record_sort  one workgroup per share: gathers the records of its regions, sorts them (ranks by counting
- *                up to 64 records, a bitonic network in LDS up to SORT_LDS, in place in the output beyond)
- *                and writes them to their place;
- *                then every control word goes back to zero for the next scan.
- * No global atomics and no global sort: a share holds a few thousand records at most on ordinary input. */
+ *   publish      every producing wavefront adds its region's fill to the sum of its "super" (2^super_shift
+ *                consecutive regions, at most 256 supers): one atomic per region, not per record
+ *   record_sort  one workgroup per share: where its records go = the supers in front of it + the fills in front
+ *                of it inside its own super (one round trip of independent loads); gathers the records of its
+ *                regions, sorts them (ranks by counting up to 64 records, a bitonic network in LDS up to SORT_LDS,
+ *                in place in the output beyond) and writes them to their place; workgroup 0 writes *count;
+ *                then the OTHER control block (the previous scan's) goes back to zero for the next scan.
+ * No atomic per record, no scan kernel and no global sort: a share holds a few thousand records at most on
+ * ordinary input. (A one-workgroup scan kernel between confirm and sort cost 11-19 us plus a launch gap.) */
 constexpr uint32_t SORT_LDS = 1024; /* largest share sorted in LDS (16 KiB of records) */
 constexpr uint32_t SORT_THREADS = 256;
 
@@ -1188,74 +1196,6 @@ __device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (blo
     if (a.x != b.x) return a.x < b.x;
     if (a.y != b.y) return a.y < b.y;
     return a.w < b.w;
-}
-
-/* one workgroup: exclusive scan of the region fills IN REGION ORDER, the total into *count. Wavefront w owns
- * the run of regions [w * run, (w + 1) * run), run a multiple of 64, and walks it 64 regions at a time
- * (coalesced reads, a shuffle scan per step). */
-__global__ __launch_bounds__(1024) void record_scan_kernel(HsgpuScanArgs args) {
-    __shared__ unsigned long long part[32];
-    __shared__ uint32_t any_overflow;
-    const uint32_t n = args.rec_regions, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint2 *counts = (const uint2 *)args.rec_counts;
-    if (tid == 0) any_overflow = 0;
-    __syncthreads();
-    const uint32_t run = (((n + 15) / 16) + 63) & ~63u, lo = min(n, wv * run), hi = min(n, lo + run);
-    unsigned long long sum = 0;
-    bool ovf = false;
-    for (uint32_t i0 = lo + lane; i0 < hi; i0 += 512) { /* 8 independent loads in flight per lane */
-        uint2 c[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) c[u] = i0 + 64 * u < hi ? counts[i0 + 64 * u] : make_uint2(0, 0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            ovf |= (unsigned long long)c[u].x + c[u].y > args.rec_cap;
-            sum += (unsigned long long)c[u].x + c[u].y;
-        }
-    }
-    if (__ballot(ovf) && lane == 0) any_overflow = 1;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    if (lane == 0) part[wv] = sum;
-    __syncthreads();
-    if (wv == 0) {
-        unsigned long long w = lane < 16 ? part[lane] : 0;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const unsigned long long v = __shfl_up(w, d);
-            if (lane >= (uint32_t)d) w += v;
-        }
-        if (lane < 16) part[16 + lane] = w; /* inclusive totals of wavefronts 0..lane */
-    }
-    __syncthreads();
-    unsigned long long carry = wv ? part[16 + wv - 1] : 0; /* records in front of this wavefront's run */
-    for (uint32_t i0 = lo; i0 < hi; i0 += 256) { /* 4 steps' loads before the first scan */
-        uint2 c[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) c[u] = i0 + 64 * u + lane < hi ? counts[i0 + 64 * u + lane] : make_uint2(0, 0);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + 64 * u + lane;
-            const unsigned long long mine = (unsigned long long)c[u].x + c[u].y;
-            unsigned long long incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned long long v = __shfl_up(incl, d);
-                if (lane >= (uint32_t)d) incl += v;
-            }
-            if (i < hi) args.rec_offsets[i] = carry + incl - mine;
-            carry += __shfl(incl, 63);
-        }
-    }
-    if (tid == 0) {
-        const unsigned long long total = part[16 + 15];
-        args.rec_offsets[n] = total;
-        /* a region that ran out of space lost records; its fill counters kept
-         * counting, so the total is still exact: report it, but never a value
-         * <= cap (that would claim the output is complete) */
-        *args.count = (any_overflow && total <= args.cap) ? args.cap + 1 : total;
-        args.order_state[0] = (!any_overflow && total <= args.cap) ? 1u : 0u; /* the output is complete */
-    }
 }
 
 /* normalized bitonic network (every comparator ascending) over n records at x; positions from n up to the
@@ -1280,19 +1220,63 @@ __device__ __forceinline__ void bitonic_sort(PTR x, uint32_t n) {
 
 __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs args) {
     __shared__ uint4 buf[SORT_LDS];
+    __shared__ unsigned long long placed[3]; /* records in front of this share, records in all, overflow flag */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     uint4 *out = (uint4 *)args.out;
-    if (args.order_state[0]) {
-        const uint32_t first = blockIdx.x * args.group_regions, last = min(args.rec_regions, first + args.group_regions);
-        const unsigned long long base = args.rec_offsets[first];
-        const uint32_t n = (uint32_t)(args.rec_offsets[last] - base);
-        if (n && n <= args.cap) { /* (complete: the shares add up to at most cap) */
+    const uint32_t first = blockIdx.x * args.group_regions, last = min(args.rec_regions, first + args.group_regions);
+    const uint2 *counts = (const uint2 *)args.rec_counts;
+    if (tid < 64) {
+        /* where this share's records go: the supers in front of its own + the regions of its own super in front of
+         * it (fewer than 2^super_shift fills, 64 at a time); all loads independent, one round trip */
+        const uint32_t n_super = (args.rec_regions + (1u << args.super_shift) - 1) >> args.super_shift; /* <= 256 */
+        const uint32_t S = first >> args.super_shift;
+        const unsigned long long flag = args.rec_super[256];
+        unsigned long long before = 0, all = 0;
+        for (uint32_t i = lane; i < n_super; i += 64) {
+            const unsigned long long sv = args.rec_super[i];
+            all += sv;
+            if (i < S) before += sv;
+        }
+        for (uint32_t i = (S << args.super_shift) + lane; i < first; i += 64) {
+            const uint2 c = counts[i];
+            before += (unsigned long long)c.x + c.y;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += __shfl_xor(before, d);
+            all += __shfl_xor(all, d);
+        }
+        if (lane == 0) {
+            placed[0] = before;
+            placed[1] = all;
+            placed[2] = flag;
+            if (blockIdx.x == 0) {
+                /* a region that ran out of space lost records; its fill counters kept counting, so the total is
+                 * still exact: report it, but never a value <= cap (that would claim the output is complete) */
+                *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long base = placed[0];
+    const bool complete = !placed[2] && placed[1] <= args.cap; /* no region overflowed, everything fits */
+    if (complete) {
+        /* the fills of all regions of the share at once (lane r = region first + r) and where each region's records
+         * start inside the share */
+        const uint32_t nreg = last - first; /* <= 64 */
+        const uint2 my = lane < nreg ? counts[first + lane] : make_uint2(0, 0);
+        uint32_t incl = my.x + my.y;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += v;
+        }
+        const uint32_t n = __shfl(incl, 63);
+        const uint32_t my_at = lane < nreg ? incl - (my.x + my.y) : n;
+        if (n) {
             const bool in_lds = n <= SORT_LDS;
-            /* gather: the fills of all regions of the share at once (lane r = region first + r), then every lane
-             * walks the share's records: which region, which slot (front records, then the ones spilled to the back) */
-            const uint32_t nreg = last - first; /* <= 64 */
-            const uint2 my = lane < nreg ? ((const uint2 *)args.rec_counts)[first + lane] : make_uint2(0, 0);
-            const uint32_t my_at = lane < nreg ? (uint32_t)(args.rec_offsets[first + lane] - base) : n;
+            /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
+             * spilled to the back) */
             for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += SORT_THREADS) { /* whole wavefronts: shuffles below */
                 uint32_t r = 0;
                 for (uint32_t k = 1; k < nreg; k++) r += __shfl(my_at, k) <= i ? 1u : 0u; /* the last region starting at or before i */
@@ -1325,13 +1309,14 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
             }
         }
     }
-    /* last kernel of a scan: every control word this scan used goes back to zero, so the next scan on
-     * this scratch needs no memset in front of it. Each workgroup zeroes what only it has read (the fill
-     * counters of its own regions); the candidate counters were last read by the confirm stage. */
-    __syncthreads();
+    /* Last kernel of a scan. The control words of THIS scan are read across workgroups (fills, sums), so nobody can
+     * zero them here; instead every workgroup zeroes its slice of the OTHER control block, the one the previous scan
+     * used and the next scan will use: no memset in front of any scan. */
     {
-        const uint32_t first = blockIdx.x * args.group_regions, last = min(args.rec_regions, first + args.group_regions);
-        for (uint32_t i = 2 * first + tid; i < 2 * last; i += SORT_THREADS) args.rec_counts[i] = 0;
+        uint4 *other = (uint4 *)args.ctl_other;
+        const uint32_t n4 = args.ctl_other_words >> 2, per = (n4 + gridDim.x - 1) / gridDim.x;
+        const uint32_t lo = blockIdx.x * per, hi = min(n4, lo + per);
+        for (uint32_t i = lo + tid; i < hi; i += SORT_THREADS) other[i] = make_uint4(0, 0, 0, 0);
     }
     uint32_t v = 0, o = 0;
     if (args.cand_counts) { /* 1024 counters per workgroup: only a handful of workgroups touch the statistics word */
@@ -1339,7 +1324,6 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
             const uint32_t c = args.cand_counts[i];
             if (i == args.cand_waves) o = c;
             else v += c;
-            args.cand_counts[i] = 0;
         }
     }
     if (blockIdx.x == 0 && tid == 0 && args.tstamp_next) {

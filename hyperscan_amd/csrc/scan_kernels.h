@@ -39,9 +39,16 @@ struct HsgpuScanArgs {
     uint32_t rec_cap;
     uint32_t rec_regions;       /* number of record regions */
     uint32_t *rec_counts;       /* [rec_regions][2]: records at the front / at the back of each region */
-    unsigned long long *rec_offsets; /* [rec_regions + 1]: exclusive scan of the region fills; [rec_regions] = the total */
+    /* sums of the region fills over "supers" of 2^super_shift consecutive regions (at most 256 of them), added up by
+     * the producing wavefronts (one atomic per region); [256] = some region overflowed. With them every sort
+     * workgroup finds where its records go from <= 256 sums + fewer than 2^super_shift fills: no scan kernel. */
+    unsigned long long *rec_super;
+    uint32_t super_shift;
     uint32_t group_regions;     /* consecutive regions that hold the records of one filter workgroup's corpus share */
-    uint32_t *order_state;      /* [0] the output is complete (no region overflowed, everything fits cap) */
+    /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
+     * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */
+    uint32_t *ctl_other;
+    uint32_t ctl_other_words;
     unsigned long long *stats;  /* [2] cumulative: candidate entries spilled, overflowed scans */
     unsigned long long *tstamp; /* timing only: [2] min start / max end of the filter kernel (device wall clock) */
     unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by record_sort_kernel */
@@ -50,7 +57,6 @@ struct HsgpuScanArgs {
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
 const void *hsgpu_confirm_kernel_for(uint32_t table_flags);
 const void *hsgpu_hint_kernel(void);
-const void *hsgpu_record_scan_kernel(void);
 const void *hsgpu_record_sort_kernel(void);
 size_t hsgpu_filter_lds_bytes(uint32_t table_flags, uint32_t filter_log2, bool fused, uint32_t wg_threads);
 

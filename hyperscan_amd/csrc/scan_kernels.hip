@@ -39,7 +39,6 @@ const void *hsgpu_confirm_kernel_for(uint32_t flags) {
 }
 
 const void *hsgpu_hint_kernel(void) { return (const void *)block_hint_kernel; }
-const void *hsgpu_record_scan_kernel(void) { return (const void *)record_scan_kernel; }
 const void *hsgpu_record_sort_kernel(void) { return (const void *)record_sort_kernel; }
 
 size_t hsgpu_filter_lds_bytes(uint32_t flags, uint32_t filter_log2, bool fused, uint32_t wg_threads) {
