@@ -201,3 +201,22 @@ def test_hwlm_exec_argument_order_and_callback_context(scratch):
     rv = lib.hsgpu_hwlm_exec(t._h, buf.ctypes.data, buf.size, 9, ccb, scratch._h, hw.HWLM_ALL_GROUPS)  # start = 9
     assert rv == 0 and [(e, i, c) for e, i, c in seen] == [(15, 7, C.addressof(token))]
     lib.hsgpu_scratch_set_context(scratch._h, scratch._h)  # back to the default for the tests that follow
+
+
+@pytest.mark.parametrize("env", [{"HSGPU_WG_PER_CU": "4", "HSGPU_WG_THREADS": "256"}, {"HSGPU_WG_PER_CU": "2"},
+                                 {"HSGPU_MODE": "fused"}])
+def test_delivery_order_under_other_geometries(env):
+    """Where a share's records go is computed from partial sums over groups of 2^k regions, k chosen from the
+    number of regions: other launch geometries (more and smaller workgroups: four times the regions; the fused
+    pipeline: a quarter of them in use) must deliver the same records in the same order."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                          "-k", "delivery_order or workload_generators or resident_and_properties or overflow",
+                          "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, env=dict(os.environ, **env), cwd=root, timeout=900)
+    assert out.returncode == 0, out.stdout[-2500:] + out.stderr[-1500:]
+    assert " passed" in out.stdout
