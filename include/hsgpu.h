@@ -158,7 +158,8 @@ int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8
  * records, or with twice the room when *d_count == cap + 1 (then the staging area of one
  * wavefront, sized from cap, was too small for a dense run of matches; in that case *d_count is a
  * lower bound). hsgpu_hwlm_exec_batch repeats the scan itself. cap < 2^32. d_corpus must be
- * 16-byte aligned. */
+ * 16-byte aligned. Successive scans on one scratch must be ordered after each other (the same stream, or
+ * synchronised): a scratch is one set of working buffers, as an hs_scratch is (one per concurrent scan). */
 int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus,
                         uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t start,
                         void *d_out, uint64_t cap, void *d_count, void *stream);
