@@ -72,9 +72,12 @@ def gen_expr(r):
     return "|".join(branches)
 
 
+MAX_PARTS = 10  # --long: 60 (many hits of one literal per block: the host confirm's shared automaton pass)
+
+
 def gen_block(r):
     parts = []
-    for _ in range(r.randint(0, 10)):
+    for _ in range(r.randint(0, MAX_PARTS)):
         parts.append(r.choice(WORDS) if r.random() < 0.6 else "".join(r.choice(ALPHA) for _ in range(r.randint(1, 4))))
     return "".join(parts).encode()
 
@@ -89,7 +92,11 @@ def main():
     ap.add_argument("--n", type=int, default=2000)
     ap.add_argument("--multi", action="store_true", help="databases of 2-6 expressions with ext bounds and SINGLEMATCH mixed in")
     ap.add_argument("--utf8", action="store_true", help="HS_FLAG_UTF8: non-ASCII characters in expressions and blocks, code-point model")
+    ap.add_argument("--long", action="store_true", help="blocks of up to 60 parts: many hits of the same literal in one block")
     a = ap.parse_args()
+    if a.long:
+        global MAX_PARTS
+        MAX_PARTS = 60
     if a.multi:
         return main_multi(a)
     if a.utf8:
