@@ -360,7 +360,7 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
      * handful of such keys are folded (<= 0.1% of the words: the 4-byte literals of a 64-literal set at
      * their odd alignment); with hundreds of them the extra candidates cost more than the test
      * (measured, 1000 literals: 0.30 ms folded vs 0.27 ms not). */
-    if (!(tflags & (HSGPU_F_REPL | HSGPU_F_HAS_C)) && (tflags & HSGPU_F_HAS_A) && (tflags & HSGPU_F_HAS_B) &&
+    if (!pair && !(tflags & (HSGPU_F_REPL | HSGPU_F_HAS_C)) && (tflags & HSGPU_F_HAS_A) && (tflags & HSGPU_F_HAS_B) && /* (a pair filter is filled from the literals: nothing to fold) */
         !(flags & HSGPU_BUILD_NO_FOLD) && (uint64_t)keys[1].size() * ((tflags & HSGPU_F_STRIDE2) ? 1000 : 100) <= fwords)
         tflags |= HSGPU_F_BFOLD;
     /* The key gate: while no 2-byte table and no pair gate needs the 64 Kbit section, and the set leaves it mostly

@@ -707,3 +707,24 @@ def test_key_gate_of_large_sets_admits_every_key():
     # NO_GATE: the section stays empty and the flag off
     h2 = parse(H.hwlm_build(lits, 4096).serialize())
     assert not h2["flags"] & F_GATE and not any(int(w) for w in h2["c2bits"])
+
+
+def test_every_built_table_reloads():
+    """hsgpu_hwlm_deserialize(hsgpu_hwlm_serialize(t)) for every layout the compiler can choose, the opt-in pair
+    filter on small sets included (found by tools/asan_table_harness.cpp: a pair table of nine literals carried
+    the folded-keys flag, which its own validation refuses)."""
+    rng = np.random.default_rng(146)
+    FORCE_PAIR, NO_GATE = 1024, 4096
+    built = 0
+    for flags in (0, FORCE_REPL, FORCE_HASHED | FORCE_K2, FORCE_S1, FORCE_S2, NO_FOLD, FORCE_PAIR, FORCE_PAIR | FORCE_BLIND, NO_GATE):
+        for n in (1, 9, 60, 700, 2500):
+            lits = random_literals(rng, n, 3 if flags & FORCE_PAIR else 1, 8, nocase_frac=0.3)
+            try:
+                t = H.hwlm_build(lits, flags)
+            except H.HsgpuError:
+                continue  # (a set the forced layout cannot hold)
+            blob = t.serialize()
+            t2 = H.HwlmTable.deserialize(blob)
+            assert t2.serialize() == blob
+            built += 1
+    assert built >= 30
