@@ -126,3 +126,18 @@ def _skew_worker(rank, world, port):
 @pytest.mark.timeout(300)
 def test_three_rank_skewed_exact_exchanges():
     mp.spawn(_skew_worker, args=(3, _free_port()), nprocs=3, join=True)
+
+
+def test_block_base_beyond_2_31_wraps_like_uint32():
+    """records travel as int32 tensors while hsgpu_match_t.block is uint32: adding a rank's first global block
+    (which passes 2^31 on big jobs) must behave as uint32 arithmetic, and a base that does not fit 32 bits at all
+    must be refused rather than wrapped silently"""
+    assert hd._as_i32(0) == 0 and hd._as_i32((1 << 31) - 1) == (1 << 31) - 1
+    assert hd._as_i32(1 << 31) == -(1 << 31) and hd._as_i32((1 << 32) - 1) == -1
+    t = torch.tensor([[5, 0, 0, 0], [7, 0, 0, 0]], dtype=torch.int32)
+    t[:, 0] += hd._as_i32(3_000_000_000)
+    assert (t[:, 0].to(torch.int64) & 0xFFFFFFFF).tolist() == [3_000_000_005, 3_000_000_007]
+    with pytest.raises(ValueError):
+        hd._as_i32(1 << 32)
+    with pytest.raises(ValueError):
+        hd._as_i32(-1)
