@@ -303,8 +303,8 @@ int hsgpu_pair_scan_dev(const hsgpu_pair_t *pairs, unsigned n_pairs, const void 
  * Other blocks, and HSGPU_ACCEL_NONE, keep their start. d_start_in: uint32 [nblocks] starts, or NULL
  * for `start` everywhere; d_start_out: uint32 [nblocks]. d_bitmap: (total_bytes + 15) / 16 * 2
  * bytes of device scratch (the scheme's membership bitmap; unused for HSGPU_ACCEL_NONE); d_work:
- * HSGPU_PAIR_WORK_BYTES, 16-byte aligned. Feed d_start_out to nothing: the literal scan needs no
- * pre-skip (it reads every byte at the HBM rate); this is for callers that consume `start`. */
+ * HSGPU_PAIR_WORK_BYTES, 16-byte aligned. The literal scan itself takes no pre-skip (it reads every
+ * byte once, at constant cost); this entry point is for callers that consume `start`. */
 int hsgpu_hwlm_forward_skip_dev(const hsgpu_accel_t *aux, const void *d_corpus, uint64_t total_bytes,
                                 const void *d_off, uint64_t nblocks, const void *d_start_in, uint32_t start,
                                 void *d_start_out, void *d_bitmap, void *d_work, void *stream);
