@@ -728,3 +728,72 @@ def test_every_built_table_reloads():
             assert t2.serialize() == blob
             built += 1
     assert built >= 30
+
+
+def test_replay_rules_equal_the_reference_under_changing_group_masks():
+    """The sequential half of hwlmExec -- group gate against the callback's last return value, noruns against the
+    last delivered id, stop on 0 (fdr_confirm_runtime.h:69-96, fdr.c:719-721) -- runs on the host in
+    hsgpu_hwlm_replay over the group-independent superset the device emits. Here the superset comes from the oracle
+    (the same literals without groups / noruns) and the result is compared with the COMPILED REFERENCE driven by the
+    same callback: masks that change at thresholds of `end`, and termination. No GPU involved."""
+    from tests import oracle_binding as ob
+    from tests.util import random_corpus, random_literals
+
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(61)
+    base = random_literals(rng, 90, 2, 8, nocase_frac=0.3)
+    lits, raw = [], []
+    for i, l in enumerate(base):  # ids = literal index, so that a record's `lit` is its id
+        groups = [H.HWLM_ALL_GROUPS, 0x1, 0x2, 0x4, 0x6][int(rng.integers(0, 5))]
+        noruns = bool(rng.random() < 0.25)
+        lits.append(H.HwlmLiteral(l.s, l.nocase, i, noruns=noruns, groups=groups))
+        raw.append(H.HwlmLiteral(l.s, l.nocase, i))
+    corpus = random_corpus(rng, 120_000, lits, plant_every=60)
+    corpus[3000:3300] = np.frombuffer(bytes(lits[1].s) * 300, dtype=np.uint8)[:300]  # a run: noruns matters
+    superset = ob.Oracle(raw).collect(corpus)
+    assert len(superset) > 1500
+    ends = sorted(e for e, _ in superset)
+    unique_ends = [e for k, e in enumerate(ends) if (k == 0 or ends[k - 1] != e) and (k + 1 == len(ends) or ends[k + 1] != e)]
+    t = H.hwlm_build(lits)
+    ref = ob.Reference(lits)
+    recs = np.zeros(len(superset), dtype=hw.MATCH_DTYPE)
+    recs["end"] = [e for e, _ in superset]
+    recs["id"] = [i for _, i in superset]
+    recs["lit"] = recs["id"]
+    order = np.lexsort((recs["lit"], recs["end"]))
+    recs = np.ascontiguousarray(recs[order])
+
+    def run_ours(policy, groups):
+        out = []
+
+        def cb(e, i, _c):
+            out.append((e, i))
+            return policy(e)
+
+        rv = t._lib.hsgpu_hwlm_replay(t._h, recs.ctypes.data, recs.size, _native.HWLM_CB(cb), None, groups)
+        return rv, out
+
+    def run_ref(policy, groups):
+        out = []
+
+        def cb(e, i):
+            out.append((e, i))
+            return policy(e)
+
+        return ref.exec(corpus, 0, cb, groups), out
+
+    # thresholds at ends that carry exactly one match: the order inside one `end` (engine specific) cannot matter
+    t1, t2, t3 = (unique_ends[len(unique_ends) * k // 4] for k in (1, 2, 3))
+    policies = [lambda e: H.HWLM_ALL_GROUPS,
+                lambda e: 0x1 if e < t1 else (0x6 if e < t2 else H.HWLM_ALL_GROUPS),
+                lambda e: 0x2 if e < t2 else 0x4,
+                lambda e: H.HWLM_ALL_GROUPS if e < t3 else 0,   # terminate at the first match from t3 on
+                lambda e: 0x4 if e < t1 else 0]
+    for pi, policy in enumerate(policies):
+        for groups in (H.HWLM_ALL_GROUPS, 0x3, 0x4):
+            rv_o, got = run_ours(policy, groups)
+            rv_r, want = run_ref(policy, groups)
+            assert rv_o == rv_r, (pi, hex(groups))
+            assert sorted(got) == sorted(want), (pi, hex(groups), len(got), len(want))
+            assert [e for e, _ in got] == sorted(e for e, _ in got)
