@@ -797,3 +797,75 @@ def test_replay_rules_equal_the_reference_under_changing_group_masks():
             assert rv_o == rv_r, (pi, hex(groups))
             assert sorted(got) == sorted(want), (pi, hex(groups), len(got), len(want))
             assert [e for e, _ in got] == sorted(e for e, _ in got)
+
+
+def test_replay_batch_restarts_the_rules_in_every_block_like_the_reference():
+    """hsgpu_hwlm_replay_batch over the records of a whole batch: the sequential rules start afresh in every block (a
+    block is one hwlmExec call), a callback that returns 0 ends its own block only. Compared block by block with the
+    compiled reference driven by the same callback; the superset comes from the oracle. No GPU involved."""
+    from tests import oracle_binding as ob
+    from tests.util import random_blocks, random_corpus, random_literals
+
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(62)
+    base = random_literals(rng, 60, 2, 8, nocase_frac=0.3)
+    lits = [H.HwlmLiteral(l.s, l.nocase, i, noruns=bool(i % 4 == 0), groups=[H.HWLM_ALL_GROUPS, 0x1, 0x2][i % 3]) for i, l in enumerate(base)]
+    raw = [H.HwlmLiteral(l.s, l.nocase, i) for i, l in enumerate(base)]
+    corpus = random_corpus(rng, 60_000, lits, plant_every=50)
+    off = random_blocks(rng, corpus.size, mean_len=900)
+    sup = ob.Oracle(raw).collect_blocks(corpus, off)
+    recs = np.zeros(sup.size, dtype=hw.MATCH_DTYPE)
+    recs["block"], recs["end"], recs["id"], recs["lit"] = sup["block"], sup["end"], sup["id"], sup["id"]
+    recs = np.ascontiguousarray(recs[np.lexsort((recs["lit"], recs["end"], recs["block"]))])
+    t = H.hwlm_build(lits)
+    ref = ob.Reference(lits)
+    # per block: switch the mask at the block's median match end if that end carries one match only, stop at 3/4
+    by_block = {}
+    for b, e in zip(recs["block"].tolist(), recs["end"].tolist()):
+        by_block.setdefault(b, []).append(e)
+    cuts = {}
+    for b, es in by_block.items():
+        uniq = [e for e in es if es.count(e) == 1]
+        if len(uniq) >= 4:
+            cuts[b] = (uniq[len(uniq) // 2], uniq[3 * len(uniq) // 4])
+    assert len(cuts) > 20
+    cur = [0]
+
+    def policy(e):
+        lo, hi = cuts.get(cur[0], (1 << 62, 1 << 62))
+        return 0x1 if e < lo else (H.HWLM_ALL_GROUPS if e < hi else 0)
+
+    # ours: one call over all records; the callback learns its block from a cursor advanced by the record order
+    delivered = []
+    blocks_in_order = recs["block"].tolist()
+    state = {"k": 0}
+
+    def cb_ours(e, i, _c):
+        # find the record this callback belongs to: the next one at or after the cursor with this (end, id)
+        k = state["k"]
+        while not (int(recs["end"][k]) == e and int(recs["id"][k]) == i):
+            k += 1
+        state["k"] = k + 1
+        cur[0] = blocks_in_order[k]
+        delivered.append((blocks_in_order[k], e, i))
+        return policy(e)
+
+    n_term = C.c_size_t(0)
+    rv = t._lib.hsgpu_hwlm_replay_batch(t._h, recs.ctypes.data, recs.size, C.cast(_native.HWLM_CB(cb_ours), C.c_void_p), None,
+                                        H.HWLM_ALL_GROUPS, C.byref(n_term))
+    assert rv == 0
+    want, want_term = [], 0
+    for b in range(off.size - 1):
+        cur[0] = b
+        blk = np.ascontiguousarray(corpus[int(off[b]):int(off[b + 1])])
+        out = []
+
+        def cb_ref(e, i):
+            out.append((b, e, i))
+            return policy(e)
+
+        want_term += 1 if ref.exec(blk, 0, cb_ref, H.HWLM_ALL_GROUPS) == 1 else 0
+        want += out
+    assert sorted(delivered) == sorted(want) and len(want) > 500
+    assert n_term.value == want_term and want_term > 10
