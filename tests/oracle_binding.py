@@ -209,6 +209,9 @@ def href(variant="avx2"):
         L.hsref_rdverm_exec.restype = C.c_int64
         L.hsref_rdverm_exec.argtypes = [C.c_uint8, C.c_uint8, C.c_int, C.c_void_p, C.c_size_t]
         L.hsref_forward_accel.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
+        if hasattr(L, "hsref_do_accel_block"):
+            L.hsref_do_accel_block.restype = C.c_size_t
+            L.hsref_do_accel_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.hsref_valid_engines.restype = C.c_size_t
         L.hsref_valid_engines.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
         _ref[variant] = L

@@ -108,3 +108,48 @@ def test_shufti_mask_builder_matches_reference():
             if got is not None:
                 assert rnb == got[2]
     assert accel.CharClass(range(8)).to_shufti() is not None  # "always able to construct masks for 8 or fewer characters"
+
+
+def test_do_accel_block_model_is_the_reference_function():
+    """The expectation used for hsgpu_hwlm_forward_skip_dev on the GPU (tests/util.do_accel_block_model: the oracle's
+    accelerators inside a restatement of do_accel_block) against the reference's OWN static do_accel_block
+    (src/hwlm/hwlm.c:80-99, exported by oracle/ref_build/accel_block_shim.c which includes hwlm.c in place): every
+    scheme, buffers of 0 .. 400 bytes, every kind of `start` (0, inside, len - 16, len - 15, len)."""
+    from tests.util import do_accel_block_model
+
+    R = ob.href()
+    if not hasattr(R, "hsref_do_accel_block"):
+        pytest.skip("oracle/_ref predates the do_accel_block shim")
+    Lo = ob.hso()
+    rng = np.random.default_rng(23)
+    sets = [[L("needle", False, 0), L("xneed", False, 1)],                       # dverm
+            [L("Hello", True, 0), L("shell", True, 1)],                          # dverm nocase
+            [L("ab", False, 0), L("cd", False, 1), L("ef", False, 2)],            # shufti
+            [L("qa", False, 0), L("zq", False, 1)],                              # verm
+            [L("Q", True, 0)],                                                   # verm nocase
+            [L(bytes([0x80 + i, 0x41]), False, i) for i in range(12)]]           # high bytes: truffle or shufti
+    seen = set()
+    for lits in sets:
+        fa = accel.ForwardAccel.choose(lits)
+        assert fa.type != accel.ACCEL_NONE
+        seen.add(fa.type)
+        arr, _keep = pack_literals(list(lits))
+        out = (C.c_uint8 * 160)()
+        R.hsref_forward_accel(arr, len(arr), 0xFFFFFFFFFFFFFFFF, out)
+        img = (C.c_uint8 * 80).from_buffer_copy(bytes(out)[80:160])  # accel0: all groups
+        assert img[0] == fa.type and img[1] == fa.offset
+        kind, sc = fa.scanner()
+        words = [l.s for l in lits] + [b"hello", b"SHELL", b"....", b"q", b"nee", b"\x80", b"A"]
+        for n in list(range(0, 40)) + [63, 64, 65, 100, 257, 400]:
+            for trial in range(6):
+                text = b"".join(words[int(i)] + b"." * int(rng.integers(0, 12)) for i in rng.integers(0, len(words), n // 3 + 1))
+                blk = np.frombuffer(text[:n].ljust(n, b"~"), dtype=np.uint8).copy()
+                if trial == 0 and n:
+                    blk[:] = ord("~")            # nothing to find
+                if trial == 1 and n:
+                    blk[-1] = lits[0].s[0]       # the last byte alone: double vermicelli's partial match
+                for start in sorted(x for x in {0, 1, n // 2, max(0, n - 17), max(0, n - 16), max(0, n - 15), n} if x <= n):  # (hwlmExec: start <= len)
+                    want = R.hsref_do_accel_block(img, blk.ctypes.data, n, start)
+                    got = do_accel_block_model(Lo, kind, sc, fa.offset, blk, start)
+                    assert got == want, (fa.type, n, start, trial, got, want)
+    assert {accel.ACCEL_DVERM, accel.ACCEL_DVERM_NOCASE, accel.ACCEL_SHUFTI, accel.ACCEL_VERM, accel.ACCEL_VERM_NOCASE} <= seen

@@ -9,6 +9,7 @@ import pytest
 from hyperscan_amd import accel
 from hyperscan_amd import corpus as cp
 from tests import oracle_binding as ob
+from tests.util import do_accel_block_model
 
 pytestmark = pytest.mark.gpu
 
@@ -279,20 +280,6 @@ def test_pair_scan_tile_edges(total):
     assert int(last.cpu().numpy().view(np.uint32)[0, 0]) == (total - 1 if total > 1 else 0xFFFFFFFF)
 
 
-def _do_accel_block(L, kind, sc, offset, blk, start):
-    """do_accel_block (src/hwlm/hwlm.c:80-99) with the oracle's accelerators (pinned to the
-    compiled reference in test_oracle_accel.py) as run_hwlm_accel"""
-    n = blk.size
-    if n - start < 16:
-        return start
-    tail = np.ascontiguousarray(blk[start:])
-    if kind == "class":
-        hit = L.hso_class_fwd(sc.bitmap.ctypes.data, tail.ctypes.data, tail.size)
-    else:
-        hit = L.hso_dshufti_fwd(*sc.masks, tail.ctypes.data, tail.size)
-    return max(0, start + hit - offset)
-
-
 def test_forward_skip_is_do_accel_block_for_a_batch():
     """hsgpu_hwlm_forward_skip_dev = hwlmExec's pre-skip (do_accel_block, src/hwlm/hwlm.c:48-99)
     per block, value for value -- for start 0, a common start > 0 and per-block starts -- and for
@@ -333,7 +320,7 @@ def test_forward_skip_is_do_accel_block_for_a_batch():
                 s0 = start if isinstance(start, int) else int(start[b])
                 if s0 > blk.size:
                     continue
-                want = _do_accel_block(L, kind, sc, fa.offset, blk, s0)
+                want = do_accel_block_model(L, kind, sc, fa.offset, blk, s0)
                 assert skip[b] == want, (b, blk.size, s0, fa.offset, int(skip[b]), want)
                 if s0 == 0:
                     for end, lid in orc.collect(blk):

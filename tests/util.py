@@ -47,3 +47,18 @@ def random_blocks(rng, total, mean_len=600, allow_empty=True):
 
 def as_set(recs):
     return sorted(zip(recs["block"].tolist(), recs["end"].tolist(), recs["id"].tolist()))
+
+
+def do_accel_block_model(L, kind, sc, offset, blk, start):
+    """do_accel_block (src/hwlm/hwlm.c:80-99) restated with the oracle's accelerators as run_hwlm_accel (`L` = the
+    oracle library, `kind` / `sc` = ForwardAccel.scanner()): the expectation of the GPU test of
+    hsgpu_hwlm_forward_skip_dev. Pinned to the reference's own do_accel_block in tests/test_accel_build.py."""
+    n = blk.size
+    if n - start < 16:
+        return start
+    tail = np.ascontiguousarray(blk[start:])
+    if kind == "class":
+        hit = L.hso_class_fwd(sc.bitmap.ctypes.data, tail.ctypes.data, tail.size)
+    else:
+        hit = L.hso_dshufti_fwd(*sc.masks, tail.ctypes.data, tail.size)
+    return max(0, start + hit - offset)
