@@ -1236,14 +1236,23 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
          * it (fewer than 2^super_shift fills, 64 at a time); all loads independent, one round trip */
         const uint32_t n_super = (args.rec_regions + (1u << args.super_shift) - 1) >> args.super_shift; /* <= 256 */
         const uint32_t S = first >> args.super_shift;
+        /* (clamped, unconditional loads, all issued before the first is used: as a loop with its bounds check
+         * this was five dependent round trips at the head of every workgroup, most of the kernel's 55 us) */
+        unsigned long long sv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sv[k] = args.rec_super[min(lane + 64u * k, 256u)];
         const unsigned long long flag = args.rec_super[256];
+        const uint32_t c0 = (S << args.super_shift) + lane;
+        const uint2 cfirst = counts[min(c0, args.rec_regions - 1)];
         unsigned long long before = 0, all = 0;
-        for (uint32_t i = lane; i < n_super; i += 64) {
-            const unsigned long long sv = args.rec_super[i];
-            all += sv;
-            if (i < S) before += sv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = lane + 64u * k;
+            if (i < n_super) all += sv[k];
+            if (i < S) before += sv[k]; /* S <= n_super */
         }
-        for (uint32_t i = (S << args.super_shift) + lane; i < first; i += 64) {
+        if (c0 < first) before += (unsigned long long)cfirst.x + cfirst.y;
+        for (uint32_t i = c0 + 64; i < first; i += 64) { /* supers of more than 64 regions: very large grids only */
             const uint2 c = counts[i];
             before += (unsigned long long)c.x + c.y;
         }
