@@ -10,7 +10,9 @@
 
 #define HSGPU_WG_THREADS 1024
 #define HSGPU_CONFIRM_THREADS 256
-#define HSGPU_CONFIRM_SPLIT 4 /* confirm wavefronts per candidate region */
+#ifndef HSGPU_CONFIRM_SPLIT
+#define HSGPU_CONFIRM_SPLIT 4 /* confirm wavefronts per candidate region (tuning builds: 2) */
+#endif
 #define HSGPU_HINT_SHIFT 10 /* one block hint per KiB of corpus */
 
 struct HsgpuScanArgs {
