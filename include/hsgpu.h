@@ -227,6 +227,34 @@ int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_classes, const
                          uint64_t total_bytes, const void *d_off, uint64_t nblocks, void *const *d_bitmaps,
                          void *d_first, void *d_last, void *d_work, void *stream);
 
+/* ---- class-sequence patterns over the class bitmaps -----------------------------------
+ * The consumer of the accelerators' answer. In the reference a literal-less pattern such as
+ * [a-z]{3,}\d+ runs in an NFA / DFA engine that idles on run_accel (src/nfa/accel.c:35-146, callers
+ * src/nfa/limex_accel.c:49-74, src/nfa/mcclellan.c:92-120) and reports every match end through its
+ * callback. With the membership bitmaps of hsgpu_class_scan_dev the pattern A{m,}B{n,} is bit-parallel
+ * (csrc/class_seq.hip): the match ends of every pattern, per block, without a host engine.
+ *   a, b   indices into the call's bitmap list; m, n in 1 .. HSGPU_SEQ_MAX_REPEAT ("+" is {1,})
+ * A pattern matches ending at byte e of a block iff some s <= e exists with bytes s..e all in B,
+ * e - s + 1 >= n, and the m bytes before s all in A, everything inside the block: the `to - 1` offsets
+ * hs_scan reports for the expression (all matches, no start of match).
+ * d_counts: uint64 [n_seqs], matches of every pattern over the whole batch (always). Records
+ * {block, end, id, lit = pattern index} are written, in no particular order, only for match ends whose
+ * corpus byte lies in [emit_lo, emit_hi): 256 class-heavy patterns report several matches per corpus
+ * byte, more than any buffer holds; *d_count = records in that range (may exceed cap: the first cap were
+ * written). d_work: hsgpu_class_seq_work_bytes(total_bytes), 16-byte aligned. Asynchronous on `stream`. */
+#define HSGPU_SEQ_MAX 1024
+#define HSGPU_SEQ_MAX_REPEAT 16
+typedef struct hsgpu_class_seq {
+    uint8_t a, b; /* class of the repeated prefix, class of the tail */
+    uint8_t m, n; /* A{m,} B{n,} */
+    uint32_t id;  /* what the records carry as id */
+} hsgpu_class_seq_t;
+size_t hsgpu_class_seq_work_bytes(uint64_t total_bytes);
+int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const void *const *d_bitmaps,
+                             unsigned n_classes, uint64_t total_bytes, const void *d_off, uint64_t nblocks,
+                             uint64_t emit_lo, uint64_t emit_hi, void *d_counts, void *d_out, uint64_t cap,
+                             void *d_count, void *d_work, size_t work_bytes, void *stream);
+
 /* ---- choosing an accelerator for a literal set (host only) ---------------------------
  * buildForwardAccel / findForwardAccelScheme (src/rose/rose_build_lit_accel.cpp:372-465): the
  * scheme hwlmExec's pre-skip uses (do_accel_block, src/hwlm/hwlm.c:48-99). `type` takes the
