@@ -33,6 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_SUMMARY = "r03_bench_pmc_summary.json"  # tools/round_profile.sh writes it from the PMC passes of this same command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REC_BYTES = 16
 WORKLOAD_DESC = {
@@ -68,7 +69,7 @@ def pmc_traffic(kernel_prefix):
     runs, tools/round_profile.sh). Units are KB; on gfx950 FETCH_SIZE counts a wide coalesced read
     stream at half its bytes (MI355X_MICROARCH.md, HBM section), hence the factor 2 on the read side.
     -> (bytes | None, source)"""
-    src = os.path.join("profiles", "r02_bench_pmc_summary.json")
+    src = os.path.join("profiles", PMC_SUMMARY)
     path = os.path.join(ROOT, src)
     if not os.path.exists(path):
         return None, None
@@ -76,6 +77,27 @@ def pmc_traffic(kernel_prefix):
         for name, e in json.load(open(path)).items():
             if name.startswith(kernel_prefix):
                 return int(e["FETCH_SIZE"]["avg_KB"] * 1024 * 2 + e["WRITE_SIZE"]["avg_KB"] * 1024), src
+    except Exception:
+        pass
+    return None, None
+
+
+def pmc_traffic_sum(kernel_prefix, launches_per_step):
+    """the same for a kernel that runs several times per step (the class passes): the average launch x launches"""
+    src = os.path.join("profiles", PMC_SUMMARY)
+    path = os.path.join(ROOT, src)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        fetch = write = n = 0.0
+        for name, e in json.load(open(path)).items():
+            if name.startswith(kernel_prefix):
+                k = e["FETCH_SIZE"]["n"]
+                fetch += e["FETCH_SIZE"]["avg_KB"] * k
+                write += e["WRITE_SIZE"]["avg_KB"] * k
+                n += k
+        if n:
+            return int((fetch * 2 + write) / n * 1024 * launches_per_step), src
     except Exception:
         pass
     return None, None
@@ -436,10 +458,12 @@ def run_class256(args):
     from tests import oracle_binding as ob
 
     rng = np.random.default_rng(5)
-    pats, used = [], set()
+    pats, used, pat_abm = [], set(), []
     for k in range(256):
         a, b = rng.choice(len(CLASS_POOL), 2, replace=False)
-        pats.append(f"{CLASS_POOL[a][0]}{{{int(rng.integers(3, 9))},}}{CLASS_POOL[b][0]}+")
+        m = int(rng.integers(3, 9))
+        pats.append(f"{CLASS_POOL[a][0]}{{{m},}}{CLASS_POOL[b][0]}+")
+        pat_abm.append((int(a), int(b), m))
         used |= {int(a), int(b)}
     classes = [accel.CharClass(CLASS_POOL[i][1]) for i in sorted(used)]
     names = [CLASS_POOL[i][0] for i in sorted(used)]
@@ -466,7 +490,28 @@ def run_class256(args):
         for ci, cls in enumerate(p):
             want = np.packbits(np.isin(corpus[:n], np.array(cls.members(), dtype=np.uint8)), bitorder="little")
             assert np.array_equal(bufs[pi][0][ci][: n // 8].cpu().numpy(), want), "class bitmap parity"
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the 256 patterns A_k{m,}B_k+ themselves: class indices into the bitmaps of the passes, in order
+    cls_index = {i: k for k, i in enumerate(sorted(used))}
+    seqs = [(cls_index[a], cls_index[b], m, 1, k) for k, (a, b, m) in enumerate(pat_abm)]
+    bitmaps = [bufs[pi][0][ci] for pi, p in enumerate(passes) for ci in range(len(p))]
+    # content gate ("final (id,to) vs a brute-force regex oracle"): the records of the first lines against
+    # a run-length restatement of the patterns (tests/class_seq_model.py, itself pinned to Python's re), every pattern
+    from tests import class_seq_model as csm
+
+    kg = 24
+    g_hi = int(off[kg])
+    counts_g, recs_g, n_emit = accel.class_seq_scan(seqs, bitmaps, total, d_off, nb, (0, g_hi), 1 << 22)
+    assert n_emit == len(recs_g), "gate slice overflowed its record buffer"
+    n_checked = 0
+    for k, (a, b, m, n_, _id) in enumerate(seqs):
+        want = csm.ends_numpy(corpus[:g_hi], off[: kg + 1], classes[a].members(), classes[b].members(), m, n_)
+        g = recs_g[recs_g[:, 3] == k]
+        g = g[np.lexsort((g[:, 1], g[:, 0]))][:, :2].astype(np.int64)
+        assert np.array_equal(g, want), f"PARITY FAILURE: pattern {k} {pats[k]}: GPU {len(g)} match ends vs model {len(want)}"
+        n_checked += len(want)
+    seq_buf = accel.class_seq_buffers(len(seqs), total, 0, dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -474,16 +519,31 @@ def run_class256(args):
         for p, b in zip(passes, bufs):
             accel.class_scan(p, d_corpus, total, d_off, nb, True, True, buffers=b)
         ev[i][1].record()
+        accel.class_seq_scan(seqs, bitmaps, total, d_off, nb, (0, 0), 0, buffers=seq_buf)  # counts only: see `matches`
+        ev[i][2].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    ms = float(np.median([a.elapsed_time(b) for a, b, _c in ev]))
+    ms_seq = float(np.median([b.elapsed_time(c) for _a, b, c in ev]))
+    n_matches = int(seq_buf[1].sum().item())
     # algorithmic bytes: every pass reads the corpus and the block offsets once, writes one bit per byte and class + first/last per line
     alg = sum(total * (1 + len(p) / 8) + nb * (len(p) * 8 + 8) for p in passes)
-    res = {"workload": f"class256: 256 patterns -> {len(classes)} distinct classes {names} in {len(passes)} passes of <= 8, "
+    traffic, traffic_src = pmc_traffic_sum("class_tile_fl_kernel", len(passes))
+    res = {"workload": f"class256: 256 patterns A{{m,}}B+ over {len(classes)} distinct classes {names}: class bitmaps + first/last in "
+                       f"{len(passes)} passes of <= 8, then every pattern's match ends from the bitmaps; "
                        f"{total / (1 << 30):g} GiB line corpus (1 GiB of lines x {reps}), {nb} blocks",
-           "value": round(total * args.steps / dt / 1e9, 2), "unit": "GB/s of corpus (all classes)", "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "value": round(total * args.steps / dt / 1e9, 2), "unit": "GB/s of corpus (bitmaps, first/last and all 256 patterns)",
+           "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "matches_per_step": n_matches, "matches_per_s": round(n_matches * args.steps / dt, 1),
+           "matches": "counted per pattern on the device over the whole corpus (several per corpus byte: no record buffer holds them); "
+                      "16-byte records are emitted for a byte range on request",
+           "parity": f"(block, end) of every one of the 256 patterns on the first {kg} lines ({n_checked} match ends) identical to the "
+                     "run-length model of tests/class_seq_model.py (pinned to Python re in the CPU suite); class bitmaps against numpy",
+           "class_stage": {"ms": round(ms, 3), "GBps_of_corpus": round(total / (ms / 1e3) / 1e9, 1)},
+           "sequence_stage": {"ms": round(ms_seq, 3), "GBps_of_corpus": round(total / (ms_seq / 1e3) / 1e9, 1),
+                              "kernel": "class_seq_kernel (one lane per pattern; instruction bound, not HBM bound)"},
            "roofline": {"bound": "hbm", "achieved": round(alg / (ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "class_tile_fl_kernel (HIP events around all passes)",
                         "ms_all_passes": round(ms, 3), "algorithmic_bytes_per_step": int(alg)}}
     if ob.ref_available():

@@ -190,12 +190,14 @@ class _Seq(C.Structure):
 SEQ_MAX, SEQ_MAX_REPEAT = 1024, 16
 
 
-def class_seq_scan(seqs, bitmaps, total, d_off, nblocks, emit=(0, 0), cap=0, stream=None):
+def class_seq_scan(seqs, bitmaps, total, d_off, nblocks, emit=(0, 0), cap=0, stream=None, buffers=None):
     """A{m,}B{n,} class-sequence patterns over the membership bitmaps of class_scan (device-resident, torch).
     seqs: iterable of (a, b, m, n, id) with a, b indices into `bitmaps` (a list of 1-D uint8 device tensors,
     one per class). emit: corpus byte range [lo, hi) whose match ends are written as records (cap of them).
     -> (counts int64 [n_seqs] on the device, records uint32 [k][4] = (block, end, id, pattern index) on the host
-    in no particular order, number of match ends in the emit range)
+    in no particular order, number of match ends in the emit range).
+    buffers = (work, counts, out, count) from class_seq_buffers: nothing is allocated and nothing waits; the
+    device tensors come back as they are (counts, out, count).
     Reference: what an accelerated NFA / DFA engine reports for such patterns (src/nfa/accel.c:35-146,
     src/nfa/limex_accel.c:49-74)."""
     import torch
@@ -203,15 +205,8 @@ def class_seq_scan(seqs, bitmaps, total, d_off, nblocks, emit=(0, 0), cap=0, str
     lib = _lib()
     seqs = list(seqs)
     arr = (_Seq * len(seqs))(*[_Seq(a, b, m, n, i) for a, b, m, n, i in seqs])
-    dev = d_off.device
     ptrs = (C.c_void_p * len(bitmaps))(*[b.data_ptr() for b in bitmaps])
-    lib.hsgpu_class_seq_work_bytes.restype = C.c_size_t
-    lib.hsgpu_class_seq_work_bytes.argtypes = [C.c_uint64]
-    wb = int(lib.hsgpu_class_seq_work_bytes(total))
-    work = torch.empty(wb + 16, dtype=torch.uint8, device=dev)
-    counts = torch.zeros(len(seqs), dtype=torch.int64, device=dev)
-    out = torch.zeros((max(1, cap), 4), dtype=torch.int32, device=dev)
-    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    work, counts, out, count = buffers if buffers is not None else class_seq_buffers(len(seqs), total, cap, d_off.device)
     st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
     lib.hsgpu_class_seq_scan_dev.restype = C.c_int
     lib.hsgpu_class_seq_scan_dev.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -219,14 +214,28 @@ def class_seq_scan(seqs, bitmaps, total, d_off, nblocks, emit=(0, 0), cap=0, str
                                              C.c_void_p, C.c_size_t, C.c_void_p]
     rv = lib.hsgpu_class_seq_scan_dev(arr, len(seqs), ptrs, len(bitmaps), total, d_off.data_ptr(), nblocks, int(emit[0]),
                                       int(emit[1]), counts.data_ptr(), out.data_ptr() if cap else None, cap, count.data_ptr(),
-                                      work.data_ptr(), wb, st)
+                                      work.data_ptr(), work.numel() - 16, st)
     if rv != 0:
         raise HsgpuError(rv, _native.load_library().hsgpu_last_error().decode())
+    if buffers is not None:
+        return counts, out, count
     if stream is not None:
         torch.cuda.synchronize()
     n_emit = int(count.item())  # synchronises the launch stream: `work` and the argument arrays may go
     recs = out[: min(n_emit, cap)].cpu().numpy().astype(np.uint32) if cap else np.zeros((0, 4), np.uint32)
     return counts, recs, n_emit
+
+
+def class_seq_buffers(n_seqs, total, cap, device):
+    """(work, counts, out, count) device tensors for class_seq_scan(buffers=...)"""
+    import torch
+
+    lib = _lib()
+    lib.hsgpu_class_seq_work_bytes.restype = C.c_size_t
+    lib.hsgpu_class_seq_work_bytes.argtypes = [C.c_uint64]
+    wb = int(lib.hsgpu_class_seq_work_bytes(total))
+    return (torch.empty(wb + 16, dtype=torch.uint8, device=device), torch.zeros(n_seqs, dtype=torch.int64, device=device),
+            torch.zeros((max(1, cap), 4), dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int64, device=device))
 
 
 class PairSet:

@@ -50,6 +50,10 @@ struct hs_database {
     std::vector<unsigned char> src_is_lit;
     std::vector<hs_expr_ext_t> src_ext; /* flags == 0: none */
     std::set<unsigned> single_exprs;    /* expressions carrying HS_FLAG_SINGLEMATCH (built once): the reference's exhaustion keys */
+    /* literal-less class sequences A{m,}B{n,}: evaluated on the GPU from the class bitmaps (csrc/class_seq.hip) */
+    std::vector<ClassSeq> cseq;
+    std::vector<hsgpu_class_t> cs_classes;   /* the distinct classes of cseq */
+    std::vector<hsgpu_class_seq_t> cs_seqs;  /* id = index into cseq */
 };
 
 struct hs_scratch {
@@ -60,6 +64,7 @@ struct hs_scratch {
      * worst-case capacity cost more than the scan) */
     hsgpu_match_t *recs = nullptr;
     size_t recs_cap = 0;
+    std::vector<hsgpu_match_t> cs_recs; /* class-sequence matches of the batch */
     ~hs_scratch() { free(recs); }
     bool reserve(size_t n) {
         if (n <= recs_cap) return true;
@@ -208,6 +213,14 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                     p.id = id;
                     d->pats.push_back(p);
                 } else {
+                    ClassSeq cs;
+                    const bool has_ext = ext && ext[i] && ext[i]->flags;
+                    if (!has_ext && parse_class_seq(exprs[i], f, cs)) { /* no literal to find: the class-sequence kernel's */
+                        cs.id = id;
+                        cs.expr = (unsigned)i;
+                        d->cseq.push_back(cs);
+                        continue;
+                    }
                     for (Pattern &b : parse_pattern(exprs[i], f, id)) d->pats.push_back(std::move(b));
                 }
                 for (size_t k = first_of_expr; k < d->pats.size(); k++) {
@@ -242,12 +255,37 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
             if (p.has_pre) w += p.pre.wmin;
             d->min_width = std::min(d->min_width, w);
         }
+        /* the class sequences: distinct classes, patterns as indices into them */
+        for (size_t k = 0; k < d->cseq.size(); k++) {
+            const ClassSeq &c = d->cseq[k];
+            auto class_index = [&](const ByteSet &bs) {
+                hsgpu_class_t hc;
+                memset(&hc, 0, sizeof(hc));
+                for (unsigned v = 0; v < 256; v++)
+                    if (bs[v]) hc.bitmap[v >> 3] |= (uint8_t)(1u << (v & 7));
+                for (size_t q = 0; q < d->cs_classes.size(); q++)
+                    if (!memcmp(&d->cs_classes[q], &hc, sizeof(hc))) return q;
+                d->cs_classes.push_back(hc);
+                return d->cs_classes.size() - 1;
+            };
+            hsgpu_class_seq_t hs;
+            const size_t ia = class_index(c.a), ib = class_index(c.b);
+            if (ia > 254 || ib > 254 || d->cseq.size() > HSGPU_SEQ_MAX) {
+                *error = make_error("Too many class-sequence patterns for one database.", (int)c.expr);
+                destroy_db(d);
+                return HS_COMPILER_ERROR;
+            }
+            hs.a = (uint8_t)ia, hs.b = (uint8_t)ib, hs.m = (uint8_t)c.m, hs.n = (uint8_t)c.n, hs.id = (uint32_t)k;
+            d->cs_seqs.push_back(hs);
+            d->min_width = std::min<size_t>(d->min_width, c.m + c.n);
+        }
         /* a deserialised database brings its GPU table along: no literal compile on load */
-        int rv = gpu_table && !gpu_table->empty() ? hsgpu_hwlm_deserialize(gpu_table->data(), gpu_table->size(), &d->hwlm)
-                                                  : hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
+        int rv = lits.empty() && !d->cseq.empty() ? HSGPU_SUCCESS /* class sequences only: no literal table */
+                 : gpu_table && !gpu_table->empty() ? hsgpu_hwlm_deserialize(gpu_table->data(), gpu_table->size(), &d->hwlm)
+                                                    : hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
         /* a stored table must be the one these patterns compile to (a blob from a build whose pattern
          * compiler chose other literals, or a spliced one, is not): otherwise compile afresh */
-        if (rv == HSGPU_SUCCESS && gpu_table && !gpu_table->empty() &&
+        if (rv == HSGPU_SUCCESS && d->hwlm && gpu_table && !gpu_table->empty() &&
             !hsgpu_table_agrees(d->hwlm, lits.data(), lits.size())) {
             hsgpu_hwlm_free(d->hwlm);
             d->hwlm = nullptr;
@@ -275,6 +313,8 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
     }
     for (const Pattern &p : d->pats) /* (an expression may have several branches: walk the branches) */
         if (p.single) d->single_exprs.insert(p.expr);
+    for (const ClassSeq &c : d->cseq)
+        if (c.single) d->single_exprs.insert(c.expr);
     *db = d;
     *error = nullptr;
     return HS_SUCCESS;
@@ -325,8 +365,15 @@ struct Event {
  * in the block, not O(hits x length); the other patterns run from each hit as before. */
 void collect_block_events(const hs_database *db, const unsigned char *buf, size_t len, const hsgpu_match_t *recs,
                           size_t n, std::vector<Event> &out, std::vector<std::pair<unsigned, size_t>> &by_pat,
-                          std::vector<size_t> &starts) {
+                          std::vector<size_t> &starts, const hsgpu_match_t *cs = nullptr, size_t n_cs = 0) {
     const size_t base = out.size();
+    /* class-sequence matches of the block (csrc/class_seq.hip): already final, `to` = end + 1 */
+    for (size_t k = 0; k < n_cs; k++) {
+        if (cs[k].id >= db->cseq.size()) continue;
+        const ClassSeq &c = db->cseq[cs[k].id];
+        if (c.quiet || (size_t)cs[k].end + 1 > len) continue;
+        out.push_back(Event{(unsigned long long)cs[k].end + 1, 0, c.id, c.single ? c.expr : kNoGrp});
+    }
     const size_t n_pats = db->pats.size();
     by_pat.clear();
     for (size_t k = 0; k < n; k++) {
@@ -418,19 +465,22 @@ struct BlockRun {
 };
 void collect_slice(const hs_database *db, const unsigned char *data, const unsigned long long *off,
                    const hsgpu_match_t *recs, size_t lo, size_t hi, std::vector<Event> &events,
-                   std::vector<BlockRun> &runs) {
-    size_t k = lo;
+                   std::vector<BlockRun> &runs, const hsgpu_match_t *cs = nullptr, size_t cs_lo = 0, size_t cs_hi = 0) {
+    size_t k = lo, c = cs_lo;
     std::vector<std::pair<unsigned, size_t>> by_pat;
     std::vector<size_t> starts;
-    while (k < hi) { /* records are sorted by (block, end): one run per block */
-        const unsigned long long b = recs[k].block;
-        size_t e = k;
+    while (k < hi || c < cs_hi) { /* both lists are sorted by (block, end): one run per block, blocks in order */
+        const unsigned long long b = std::min<unsigned long long>(k < hi ? recs[k].block : ~0ull, c < cs_hi ? cs[c].block : ~0ull);
+        size_t e = k, ce = c;
         while (e < hi && recs[e].block == b) e++;
+        while (ce < cs_hi && cs[ce].block == b) ce++;
         const size_t len = (size_t)(off[b + 1] - off[b]);
         const size_t ev0 = events.size();
-        if (len >= db->min_width) collect_block_events(db, data + off[b], len, recs + k, e - k, events, by_pat, starts);
+        if (len >= db->min_width)
+            collect_block_events(db, data + off[b], len, recs + k, e - k, events, by_pat, starts, cs ? cs + c : nullptr, ce - c);
         if (events.size() > ev0) runs.push_back(BlockRun{b, ev0, events.size()});
         k = e;
+        c = ce;
     }
 }
 
@@ -544,6 +594,7 @@ hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
     if (!db || !size || db->magic != 0x48534744) return HS_INVALID;
     size_t s = sizeof(*db) + hsgpu_hwlm_size(db->hwlm);
     for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit) + p.reach.size() * 8 + p.g.bytes() + p.pre.bytes();
+    s += db->cseq.size() * (sizeof(ClassSeq) + sizeof(hsgpu_class_seq_t)) + db->cs_classes.size() * sizeof(hsgpu_class_t);
     *size = s;
     return HS_SUCCESS;
 }
@@ -622,11 +673,15 @@ hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *
     /* the GPU literal table, as hsgpu_hwlm_serialize writes it: a deserialised database scans
      * without compiling its literals again */
     size_t tlen = 0;
-    if (hsgpu_hwlm_serialize(db->hwlm, nullptr, 0, &tlen) != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
-    std::string table(tlen, '\0');
-    if (hsgpu_hwlm_serialize(db->hwlm, &table[0], table.size(), &tlen) != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
-    put64(tlen);
-    out += table;
+    if (db->hwlm) { /* (a database of class sequences only has no literal table: an empty section) */
+        if (hsgpu_hwlm_serialize(db->hwlm, nullptr, 0, &tlen) != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
+        std::string table(tlen, '\0');
+        if (hsgpu_hwlm_serialize(db->hwlm, &table[0], table.size(), &tlen) != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
+        put64(tlen);
+        out += table;
+    } else {
+        put64(0);
+    }
     const unsigned crc = crc32_of((const unsigned char *)out.data() + 8, out.size() - 8);
     memcpy(&out[4], &crc, 4);
     *bytes = (char *)hook_alloc(g_misc, out.size());
@@ -772,6 +827,22 @@ hs_error_t hs_expression_ext_info(const char *expression, unsigned int flags, co
     *info = nullptr;
     if (!expression) { *error = make_error("Invalid parameter: expression is NULL", -1); return HS_COMPILER_ERROR; }
     std::vector<Pattern> branches;
+    ClassSeq cseq;
+    if (!(ext && ext->flags) && parse_class_seq(expression, flags, cseq)) { /* A{m,}B{n,}: at least m + n bytes, no upper bound */
+        hs_expr_info_t *out = (hs_expr_info_t *)hook_alloc(g_misc, sizeof(*out));
+        if (hs_error_t ae = check_alloc(out)) {
+            hook_free(g_misc, out);
+            *error = make_error(ae == HS_BAD_ALIGN ? "Allocator returned misaligned memory." : "Unable to allocate memory.", -1);
+            return HS_COMPILER_ERROR;
+        }
+        out->min_width = cseq.m + cseq.n;
+        out->max_width = 0xffffffffu;
+        out->unordered_matches = 0;
+        out->matches_at_eod = 0;
+        out->matches_only_at_eod = 0;
+        *info = out;
+        return HS_SUCCESS;
+    }
     try {
         branches = parse_pattern(expression, flags, 0);
         if (ext) {
@@ -883,38 +954,53 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
  * engine emits them. Returns 1 if some callback asked to stop (its block only), 0 if none did, -1
  * when the confirm ran out of memory (nothing is delivered then). */
 static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
-                                    const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context);
+                                    const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
+                                    const hsgpu_match_t *cs, size_t n_cs);
 static int confirm_and_deliver(const hs_database *db, const char *data, const unsigned long long *off,
-                               const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context) {
+                               const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
+                               const hsgpu_match_t *cs = nullptr, size_t n_cs = 0) {
     try {
-        return confirm_and_deliver_impl(db, data, off, recs, n, onEvent, context);
+        return confirm_and_deliver_impl(db, data, off, recs, n, onEvent, context, cs, n_cs);
     } catch (...) { /* bad_alloc while sizing the per-worker vectors */
         return -1;
     }
 }
 static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
-                                    const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context) {
+                                    const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
+                                    const hsgpu_match_t *cs, size_t n_cs) {
     /* host confirm: the events of different blocks are independent, so large batches are cut
      * into slices of whole blocks handled by worker threads; delivery stays on the calling
      * thread, in block order, as the callback contract requires */
     unsigned n_thr = 1;
-    if (onEvent && n >= 8192) n_thr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (onEvent && n + n_cs >= 8192) n_thr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<std::vector<Event>> ev(n_thr);
     std::vector<std::vector<BlockRun>> runs(n_thr);
     if (onEvent) {
-        std::vector<size_t> cut(n_thr + 1, n);
-        cut[0] = 0;
+        /* slices of whole blocks: cut the longer list evenly, snap to a block boundary, cut the other list at the
+         * same block */
+        std::vector<size_t> cut(n_thr + 1, n), ccut(n_thr + 1, n_cs);
+        cut[0] = ccut[0] = 0;
+        const bool by_cs = n_cs > n;
+        const hsgpu_match_t *lead = by_cs ? cs : recs, *follow = by_cs ? recs : cs;
+        const size_t n_lead = by_cs ? n_cs : n, n_follow = by_cs ? n : n_cs;
+        std::vector<size_t> &lcut = by_cs ? ccut : cut, &fcut = by_cs ? cut : ccut;
         for (unsigned t = 1; t < n_thr; t++) {
-            size_t c = std::max(cut[t - 1], n * t / n_thr);
-            while (c < n && c > 0 && recs[c].block == recs[c - 1].block) c++; /* snap to a block boundary */
-            cut[t] = c;
+            size_t c = std::max(lcut[t - 1], n_lead * t / n_thr);
+            while (c < n_lead && c > 0 && lead[c].block == lead[c - 1].block) c++; /* snap to a block boundary */
+            lcut[t] = c;
+            const unsigned long long b = c < n_lead ? lead[c].block : ~0ull;
+            size_t f = n_follow;
+            if (c < n_lead)
+                f = std::lower_bound(follow, follow + n_follow, b,
+                                     [](const hsgpu_match_t &r, unsigned long long blk) { return r.block < blk; }) - follow;
+            fcut[t] = std::max(f, fcut[t - 1]);
         }
         static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr;
         std::atomic<bool> failed{false}; /* no exception may leave a worker thread (std::terminate) or this extern "C" path */
         auto work = [&](unsigned t) {
             const auto t0 = std::chrono::steady_clock::now();
             try {
-                collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t]);
+                collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t], cs, ccut[t], ccut[t + 1]);
             } catch (...) {
                 failed = true;
             }
@@ -973,7 +1059,7 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
     if (nblocks == 0) return HS_SUCCESS;
     const auto t_begin = std::chrono::steady_clock::now();
     size_t cap = std::max<size_t>(std::max<size_t>(4096, scratch->recs_cap), (size_t)(off[nblocks] - off[0]) / 1024), n = 0;
-    for (int attempt = 0; attempt < 8; attempt++) {
+    for (int attempt = 0; db->hwlm && attempt < 8; attempt++) {
         if (!scratch->reserve(cap)) return HS_NOMEM;
         int rv = hsgpu_hwlm_exec_batch(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off,
                                        (size_t)nblocks, 0, scratch->recs, cap, &n);
@@ -982,9 +1068,30 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
         cap = n + n / 4; /* n = the exact total */
         if (attempt == 7) return HS_UNKNOWN_ERROR;
     }
+    /* literal-less class sequences: on the GPU from the class bitmaps, over the batch the literal scan left resident
+     * (or uploaded here when the database has no literal at all; a retry for room finds it resident either way) */
+    size_t n_cs = 0;
+    if (!db->cs_seqs.empty()) {
+        try {
+            if (scratch->cs_recs.size() < 4096) scratch->cs_recs.resize(4096);
+            for (int attempt = 0;; attempt++) {
+                const int resident = (db->hwlm != nullptr || attempt > 0) ? 1 : 0;
+                int rv = hsgpu_class_seq_exec_batch(db->cs_classes.data(), (unsigned)db->cs_classes.size(), db->cs_seqs.data(),
+                                                    (unsigned)db->cs_seqs.size(), scratch->gpu, (const uint8_t *)data,
+                                                    (const uint64_t *)off, (size_t)nblocks, resident, nullptr,
+                                                    scratch->cs_recs.data(), scratch->cs_recs.size(), &n_cs);
+                if (rv == HSGPU_SUCCESS) break;
+                if (rv != HSGPU_INSUFFICIENT_SPACE || attempt == 3) return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
+                scratch->cs_recs.resize(n_cs + n_cs / 8 + 16);
+            }
+        } catch (const std::bad_alloc &) {
+            return HS_NOMEM;
+        }
+    }
     static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr; /* diagnostic: where does a batch go? */
     const auto t_scan = std::chrono::steady_clock::now();
-    const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context);
+    const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context,
+                                                   n_cs ? scratch->cs_recs.data() : nullptr, n_cs);
     if (any_terminated < 0) return HS_NOMEM;
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();

@@ -1536,6 +1536,60 @@ bool rewrite_for_literal(const std::string &b, unsigned flags, unsigned id, std:
 
 /* expression := branch ('|' branch)* at the top level: every branch is its own literal-prefixed
  * pattern reporting the same id (the reference builds one graph; the reports are the same) */
+bool parse_class_seq(const std::string &expr, unsigned flags, ClassSeq &out) {
+    const unsigned ok_flags = HS_FLAG_CASELESS | HS_FLAG_DOTALL | HS_FLAG_MULTILINE | HS_FLAG_SINGLEMATCH | HS_FLAG_PREFILTER |
+                              HS_FLAG_QUIET | HS_FLAG_ALLOWEMPTY;
+    if (flags & ~ok_flags) return false;
+    const bool nocase = flags & HS_FLAG_CASELESS;
+    size_t i = 0;
+    ByteSet cls[2];
+    unsigned rep[2] = {0, 0};
+    try {
+        for (int t = 0; t < 2; t++) {
+            if (i >= expr.size()) return false;
+            if (expr[i] == '[') {
+                if (expr.find("[:", i) != std::string::npos) return false; /* POSIX names: the general parser's business */
+                cls[t] = parse_bracket_class(expr, i, nocase); /* leaves i behind the closing bracket */
+            } else if (expr[i] == '\\' && i + 1 < expr.size()) {
+                bool ok = false;
+                cls[t] = class_escape(expr[i + 1], ok);
+                if (!ok) return false;
+                i += 2;
+            } else if (expr[i] == '.') {
+                cls[t].set();
+                if (!(flags & HS_FLAG_DOTALL)) cls[t].reset('\n');
+                i++;
+            } else {
+                return false;
+            }
+            if (nocase) cls[t] = fold_case(cls[t]);
+            if (i < expr.size() && expr[i] == '+') {
+                rep[t] = 1;
+                i++;
+            } else if (i < expr.size() && expr[i] == '{') {
+                size_t j = i + 1;
+                unsigned v = 0, nd = 0;
+                for (; j < expr.size() && isdigit((unsigned char)expr[j]) && nd < 3; j++, nd++) v = v * 10 + (unsigned)(expr[j] - '0');
+                if (!nd || j + 1 >= expr.size() || expr[j] != ',' || expr[j + 1] != '}') return false;
+                rep[t] = v;
+                i = j + 2;
+            } else {
+                return false;
+            }
+            if (rep[t] < 1 || rep[t] > 16) return false;
+            if (i < expr.size() && (expr[i] == '?' || expr[i] == '+')) return false; /* lazy / possessive forms */
+        }
+    } catch (const ParseError &) {
+        return false; /* the general parser reports what is wrong with it */
+    }
+    if (i != expr.size() || cls[0].none() || cls[1].none()) return false;
+    out.a = cls[0], out.b = cls[1];
+    out.m = rep[0], out.n = rep[1];
+    out.single = flags & HS_FLAG_SINGLEMATCH;
+    out.quiet = flags & HS_FLAG_QUIET;
+    return true;
+}
+
 std::vector<Pattern> parse_pattern(const std::string &expr, unsigned flags, unsigned id) {
     check_flags(flags, false);
     /* \Q...\E quotes: rewritten as escaped characters first (also inside classes) */

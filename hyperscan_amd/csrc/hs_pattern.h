@@ -101,7 +101,21 @@ struct NoLiteral : ParseError { /* the branch is well-formed but offers no top-l
     NoLiteral() : ParseError{"Pattern has no mandatory literal at its top level (every branch needs one)."} {}
 };
 
+/* A literal-less class sequence A{m,}B{n,} ("+" is {1,}): no literal for the GPU literal matcher to find, so it is
+ * evaluated on the GPU from the class bitmaps (csrc/class_seq.hip) -- the job the reference gives to an accelerated
+ * NFA / DFA engine (src/nfa/limex_accel.c:49-74). */
+struct ClassSeq {
+    ByteSet a, b;
+    unsigned m = 1, n = 1;
+    unsigned id = 0, expr = 0;
+    bool single = false, quiet = false;
+};
+
 /* hs_pattern.cpp */
+/* true and `out` filled when the expression is exactly two classes with open repeats (classes: [...], \d \w \s
+ * and their complements, `.`; repeats: + or {k,} with k <= 16) under flags the form supports; false otherwise
+ * (the general compiler then has its say) */
+bool parse_class_seq(const std::string &expr, unsigned flags, ClassSeq &out);
 bool is_word_char(unsigned char c);
 bool is_alpha(unsigned char c);
 /* the reference's own flag rules, in its order (src/compiler/compiler.cpp:286-294,166-196) */

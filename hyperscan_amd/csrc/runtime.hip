@@ -76,6 +76,7 @@ struct hsgpu_scratch {
     DevBuf tstamp;              /* [kRing][4] device wall clock: filter start (min) / end (max), confirm-stage end, pipeline end */
     double wall_clock_khz = 100000.0;
     DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats;
+    DevBuf cs_bitmaps, cs_work, cs_counts; /* hsgpu_class_seq_exec_batch: class bitmaps, work areas, per-pattern counts */
     bool ctl_clean = false;                /* the control block the next scan will use is zero (left so by the scan before last) */
     unsigned ctl_parity = 0;               /* which half of the control buffer the next scan uses */
     unsigned long long stats_seen[2] = {0, 0};
@@ -171,6 +172,9 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->stats.release();
     s->tstamp.release();
     s->rec_stage.release();
+    s->cs_bitmaps.release();
+    s->cs_work.release();
+    s->cs_counts.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
     for (int r = 0; r < hsgpu_scratch::kRing; r++)
         for (int i = 0; i < 4; i++)
@@ -545,16 +549,14 @@ struct InUse {
     }
 };
 
-/* scan host blocks; on return recs holds ALL matches sorted by (block,end,lit) */
-static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base, const uint64_t *off,
-                     size_t nblocks, size_t start, std::vector<hsgpu_match_t> &recs) {
-    recs.clear();
+/* a host batch onto the device: corpus[off[0] .. off[nblocks]) and the offsets relative to off[0] into the scratch's
+ * buffers, asynchronously on its stream */
+static int upload_batch(hsgpu_scratch *s, const uint8_t *base, const uint64_t *off, size_t nblocks) {
     if ((uint64_t)nblocks >= (1ull << 32)) { /* hsgpu_match_t.block is 32 bits */
         hsgpu_set_error("more than 2^32 - 1 blocks per call");
         return HSGPU_INVALID;
     }
     const uint64_t lo = off[0], total = off[nblocks] - off[0];
-    if (total == 0) return HSGPU_SUCCESS;
     for (size_t i = 0; i < nblocks; i++) {
         if (off[i + 1] < off[i]) {
             hsgpu_set_error("block offsets must be ascending");
@@ -571,8 +573,20 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
     if ((rv = s->off.ensure((nblocks + 1) * sizeof(uint64_t))) != HSGPU_SUCCESS) return rv;
     std::vector<uint64_t> rel(nblocks + 1);
     for (size_t i = 0; i <= nblocks; i++) rel[i] = off[i] - lo;
-    HIP_TRY(hipMemcpyAsync(s->corpus.p, base + lo, total, hipMemcpyHostToDevice, s->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(s->corpus.p, base + lo, total, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->off.p, rel.data(), rel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream)); /* `rel` goes out of scope */
+    return HSGPU_SUCCESS;
+}
+
+/* scan host blocks; on return recs holds ALL matches sorted by (block,end,lit) */
+static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base, const uint64_t *off,
+                     size_t nblocks, size_t start, std::vector<hsgpu_match_t> &recs) {
+    recs.clear();
+    const uint64_t total = off[nblocks] - off[0];
+    if (total == 0) return HSGPU_SUCCESS;
+    int rv = upload_batch(s, base, off, nblocks);
+    if (rv != HSGPU_SUCCESS) return rv;
     uint64_t cap = std::max<uint64_t>(4096, total / 256);
     for (int attempt = 0; attempt < 8; attempt++) {
         if ((rv = s->out.ensure(cap * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return rv;
@@ -594,6 +608,61 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
         cap = std::max<uint64_t>(n + n / 4, cap * 2);
     }
     hsgpu_set_error("match buffer overflow persisted");
+    return HSGPU_UNKNOWN_ERROR;
+}
+
+/* Class-sequence patterns over a host batch (or over the batch this scratch scanned last, still resident):
+ * class bitmaps in passes of <= 8, then the sequence kernel over all of them; records of the whole batch in
+ * delivery order, counts per pattern. */
+extern "C" int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned n_classes, const hsgpu_class_seq_t *seqs,
+                                          unsigned n_seqs, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off,
+                                          size_t nblocks, int reuse_resident, uint64_t *counts, hsgpu_match_t *out,
+                                          size_t cap, size_t *nout) {
+    if (!classes || !n_classes || !seqs || !n_seqs || !s || !off || !nout || (cap && !out)) return HSGPU_INVALID;
+    *nout = 0;
+    if (counts) memset(counts, 0, (size_t)n_seqs * sizeof(uint64_t));
+    if (nblocks == 0) return HSGPU_SUCCESS;
+    const uint64_t total = off[nblocks] - off[0];
+    if (total == 0) return HSGPU_SUCCESS;
+    if (!base && !reuse_resident) return HSGPU_INVALID;
+    InUse guard(s);
+    if (!guard.ok) return HSGPU_SCRATCH_IN_USE;
+    int rv;
+    if (!reuse_resident && (rv = upload_batch(s, base, off, nblocks)) != HSGPU_SUCCESS) return rv;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t row = ((total + 15) / 16 * 2 + 15) & ~(size_t)15;
+    const size_t seq_work = hsgpu_class_seq_work_bytes(total);
+    if ((rv = s->cs_bitmaps.ensure(row * n_classes)) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->cs_work.ensure(HSGPU_CLASS_WORK_BYTES + 64 + seq_work)) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->cs_counts.ensure((size_t)n_seqs * sizeof(uint64_t))) != HSGPU_SUCCESS) return rv;
+    std::vector<void *> ptrs(n_classes);
+    for (unsigned c = 0; c < n_classes; c++) ptrs[c] = (uint8_t *)s->cs_bitmaps.p + row * c;
+    for (unsigned c = 0; c < n_classes; c += HSGPU_CLASS_MAX) {
+        const unsigned k = std::min<unsigned>(HSGPU_CLASS_MAX, n_classes - c);
+        rv = hsgpu_class_scan_dev(classes + c, k, s->corpus.p, total, s->off.p, nblocks, ptrs.data() + c, nullptr, nullptr,
+                                  s->cs_work.p, s->stream);
+        if (rv != HSGPU_SUCCESS) return rv;
+    }
+    void *work2 = (uint8_t *)s->cs_work.p + ((HSGPU_CLASS_WORK_BYTES + 63) & ~(size_t)63);
+    uint64_t dcap = std::max<uint64_t>(cap, 4096);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if ((rv = s->out.ensure(dcap * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return rv;
+        rv = hsgpu_class_seq_scan_dev(seqs, n_seqs, ptrs.data(), n_classes, total, s->off.p, nblocks, 0, total,
+                                      s->cs_counts.p, s->out.p, dcap, s->count.p, work2, seq_work, s->stream);
+        if (rv != HSGPU_SUCCESS) return rv;
+        HIP_TRY(hipMemcpyAsync(s->h_count, s->count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const uint64_t n = *s->h_count;
+        *nout = (size_t)n;
+        if (counts) HIP_TRY(hipMemcpy(counts, s->cs_counts.p, (size_t)n_seqs * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (n > cap) return HSGPU_INSUFFICIENT_SPACE; /* *nout = the room the caller needs */
+        if (n <= dcap) {
+            if (n) HIP_TRY(hipMemcpy(out, s->out.p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost));
+            hsgpu_match_sort_host(out, n); /* the kernel emits in no particular order */
+            return HSGPU_SUCCESS;
+        }
+        dcap = n;
+    }
     return HSGPU_UNKNOWN_ERROR;
 }
 

@@ -255,6 +255,16 @@ int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned n_seqs, con
                              uint64_t emit_lo, uint64_t emit_hi, void *d_counts, void *d_out, uint64_t cap,
                              void *d_count, void *d_work, size_t work_bytes, void *stream);
 
+/* The same for a batch in HOST memory (the sibling of hsgpu_hwlm_exec_batch): class bitmaps in passes of <= 8
+ * classes, then the sequence kernel; `out` receives every match of the batch in delivery order (block, end,
+ * pattern index), *nout the number there is (HSGPU_INSUFFICIENT_SPACE when more than cap: nothing is written
+ * then), counts (optional, uint64 [n_seqs]) the matches per pattern. reuse_resident != 0: the batch is the one this
+ * scratch uploaded last (hsgpu_hwlm_exec_batch / this function, same base and offsets) and is not copied again. */
+int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned n_classes, const hsgpu_class_seq_t *seqs,
+                               unsigned n_seqs, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off,
+                               size_t nblocks, int reuse_resident, uint64_t *counts, hsgpu_match_t *out, size_t cap,
+                               size_t *nout);
+
 /* ---- choosing an accelerator for a literal set (host only) ---------------------------
  * buildForwardAccel / findForwardAccelScheme (src/rose/rose_build_lit_accel.cpp:372-465): the
  * scheme hwlmExec's pre-skip uses (do_accel_block, src/hwlm/hwlm.c:48-99). `type` takes the

@@ -95,3 +95,70 @@ def test_one_block_only_and_tiny():
     off2 = np.array([0, 4, 10], dtype=np.uint64)  # "xxab" | "c123yy": the run of A is cut by the block boundary
     counts, recs, n = _run(corpus, off2, [(0, 1, 3, 1, 42), (0, 1, 1, 1, 43)], classes)
     assert counts.tolist() == [0, 3]
+
+
+# ---- through the public API: hs_compile routes literal-less class sequences to the kernel --------------------
+
+def _re_events(pats, ids, data):
+    """(id, to) of every match end of every pattern, Python re on the reversed data (all-matches semantics)"""
+    import re
+
+    rev = data[::-1]
+    out = []
+    for p, i in zip(pats, ids):
+        a, qa, b, qb = re.fullmatch(r"(\[[^\]]+\]|\\[dws]|\.)(\+|\{\d+,\})(\[[^\]]+\]|\\[dws]|\.)(\+|\{\d+,\})", p).groups()
+        rp = re.compile(("(?=%s%s%s%s)" % (b, qb.replace("+", "{1,}"), a, qa.replace("+", "{1}").replace(",}", "}"))).encode(), re.S)
+        out += [(i, len(data) - mt.start()) for mt in rp.finditer(rev)]
+    return sorted(set(out), key=lambda e: (e[1], e[0]))
+
+
+def test_hs_compile_routes_class_sequences_and_mixes_them_with_literals():
+    from hyperscan_amd import hs
+
+    pats = [r"[a-z]{3,}\d+", r"foo[0-9]+", r"\s+[A-Z]{2,}", r"[a-f0-9]{4,}[g-z]+", r"bar"]
+    ids = [10, 11, 12, 13, 14]
+    db = hs.Database.compile(pats, [hs.HS_FLAG_DOTALL] * 5, ids)
+    scratch = hs.HsScratch(db)
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"abcdefgxyz0123456789 ABC\nfoobar", np.uint8)
+    data = bytes(rng.choice(alpha, 5000))
+    got = []
+    assert hs.scan(db, data, scratch, lambda i, f, t: got.append((i, t)) and False) == hs.HS_SUCCESS
+    want = _re_events([pats[0], pats[2], pats[3]], [10, 12, 13], data)
+    import re
+
+    # foo[0-9]+ and bar by direct search: every end inside the run of digits after "foo"; every "bar"
+    for m in re.finditer(rb"foo", data):
+        k = m.end()
+        while k < len(data) and 48 <= data[k] <= 57:
+            k += 1
+            want.append((11, k))
+    want += [(14, m.start() + 3) for m in re.finditer(rb"(?=bar)", data)]
+    assert got == sorted(set(want), key=lambda e: (e[1], e[0]))
+    tos = [t for _i, t in got]
+    assert tos == sorted(tos)
+
+
+def test_hs_class_sequences_only_database_batch_singlematch_and_serialisation():
+    from hyperscan_amd import hs
+
+    pats = [r"[aeiou]{2,}[^aeiou]+", r"[A-C]+[x-z]{2,}", r".{3,}[\n]+"]
+    flags = [0, hs.HS_FLAG_SINGLEMATCH | hs.HS_FLAG_CASELESS, 0]
+    db = hs.Database.compile(pats, flags, [1, 2, 3])
+    db2 = hs.Database.deserialize(db.serialize())
+    rng = np.random.default_rng(4)
+    alpha = np.frombuffer(b"aeioubcdxyzABC\n ", np.uint8)
+    lens = rng.integers(0, 300, 40)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    data = bytes(rng.choice(alpha, int(off[-1])))
+    for d in (db, db2):
+        scratch = hs.HsScratch(d)
+        got = {}
+        hs.scan_batch(d, data, off, scratch, lambda blk, i, f, t: got.setdefault(blk, []).append((i, t)) and False)
+        for blk in range(len(lens)):
+            chunk = data[int(off[blk]):int(off[blk + 1])]
+            want = _re_events([r"[aeiou]{2,}[^aeiou]+"], [1], chunk)
+            w2 = _re_events([r"[A-Ca-c]+[x-zX-Z]{2,}"], [2], chunk)[:1]  # SINGLEMATCH: the first end only
+            w3 = _re_events([r"[^\n]{3,}[\n]+"], [3], chunk)
+            assert got.get(blk, []) == sorted(want + w2 + w3, key=lambda e: (e[1], e[0])), blk
+    assert hs.expression_info(r"[a-z]{3,}\d+") == (4, 0xffffffff)
