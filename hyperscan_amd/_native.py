@@ -57,6 +57,16 @@ _SIGS = {
     "hsgpu_hwlm_replay_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64,
                                           C.POINTER(C.c_size_t)]),
     "hsgpu_hwlm_count_cb": (C.c_uint64, [C.c_size_t, C.c_uint32, C.c_void_p]),
+    "hsgpu_hwlm_replay_batch_mt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64,
+                                             C.c_void_p]),
+    "hsgpu_hwlm_fetch_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_uint, C.c_uint64, C.POINTER(C.c_size_t), C.c_void_p]),
+    "hsgpu_class_seq_work_bytes": (C.c_size_t, [C.c_uint64]),
+    "hsgpu_class_seq_scan_dev": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_uint64, C.c_void_p, C.c_uint64,
+                                           C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]),
+    "hsgpu_class_seq_exec_batch": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsgpu_last_error": (C.c_char_p, []),
     "hsgpu_version": (C.c_char_p, []),
 }

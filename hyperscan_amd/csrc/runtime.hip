@@ -23,6 +23,9 @@
 #include <vector>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 
 #include "internal.h"
 #include "scan_kernels.h"
@@ -60,6 +63,73 @@ struct DevBuf {
     }
 };
 
+/* A few resident host threads for the consumer side of the boundary (callbacks of disjoint block ranges): threads
+ * created once per scratch, jobs handed over through one mutex; the calling thread works too. */
+class WorkerPool {
+  public:
+    explicit WorkerPool(unsigned n) {
+        for (unsigned i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    unsigned size() const { return (unsigned)th_.size(); }
+    /* f(j) for j in [0, jobs): on the pool and on the caller; returns when all are done */
+    void run(unsigned jobs, const std::function<void(unsigned)> &f) {
+        if (jobs == 0) return;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &f;
+            next_ = 0;
+            jobs_ = jobs;
+            left_ = jobs;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            unsigned j;
+            const std::function<void(unsigned)> *f;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!fn_ || next_ >= jobs_) return;
+                j = next_++;
+                f = fn_;
+            }
+            (*f)(j);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return stop_ || (fn_ && next_ < jobs_); });
+                if (stop_) return;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned next_ = 0, jobs_ = 0, left_ = 0;
+    bool stop_ = false;
+};
+
 struct hsgpu_scratch {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -81,6 +151,10 @@ struct hsgpu_scratch {
     unsigned ctl_parity = 0;               /* which half of the control buffer the next scan uses */
     unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
+    hsgpu_match_t *h_recs = nullptr;       /* pinned: hsgpu_hwlm_fetch_replay's landing area for the records */
+    size_t h_recs_cap = 0;
+    hipEvent_t ev_chunk[4] = {};           /* its D2H chunks */
+    std::unique_ptr<WorkerPool> pool;      /* its replay threads (created on first use) */
     int n_cu = 0;
     size_t lds_per_cu = 0;
     bool in_use = false;
@@ -176,6 +250,10 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->cs_work.release();
     s->cs_counts.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
+    if (s->h_recs) (void)hipHostFree(s->h_recs);
+    for (int i = 0; i < 4; i++)
+        if (s->ev_chunk[i]) (void)hipEventDestroy(s->ev_chunk[i]);
+    s->pool.reset();
     for (int r = 0; r < hsgpu_scratch::kRing; r++)
         for (int i = 0; i < 4; i++)
             if (s->ev_ring[r][i]) (void)hipEventDestroy(s->ev_ring[r][i]);
@@ -701,6 +779,118 @@ extern "C" int hsgpu_hwlm_replay_batch(const hsgpu_hwlm_t *t, const hsgpu_match_
     }
     if (n_terminated) *n_terminated = term;
     return HSGPU_HWLM_SUCCESS;
+}
+
+/* The same on several threads: the blocks are cut into n_threads contiguous ranges (whole blocks: the sequential
+ * rules restart in every block, so ranges are independent) and range i is walked in order by one thread with
+ * ctxs[i] as the callbacks' context. What hsbench's -T threads do with their own slices of the corpus
+ * (tools/hsbench/main.cpp:957-963), applied to the consumer side of the device boundary. */
+static void cut_block_ranges(const hsgpu_match_t *recs, size_t n, unsigned parts, std::vector<size_t> &cut) {
+    cut.assign(parts + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < parts; t++) {
+        size_t c = std::max(cut[t - 1], n * t / parts);
+        while (c < n && c > 0 && recs[c].block == recs[c - 1].block) c++;
+        cut[t] = c;
+    }
+}
+
+static int replay_ranges(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n, hsgpu_hwlm_cb cb, void *const *ctxs,
+                         unsigned n_threads, uint64_t groups, WorkerPool *pool, size_t *n_terminated) {
+    std::vector<size_t> cut;
+    cut_block_ranges(recs, n, n_threads, cut);
+    std::vector<size_t> term(n_threads, 0);
+    std::atomic<int> bad{0};
+    auto job = [&](unsigned i) {
+        size_t nt = 0;
+        if (cut[i + 1] > cut[i] &&
+            hsgpu_hwlm_replay_batch(t, recs + cut[i], cut[i + 1] - cut[i], cb, ctxs[i], groups, &nt) != HSGPU_HWLM_SUCCESS)
+            bad = 1;
+        term[i] = nt;
+    };
+    if (pool) {
+        pool->run(n_threads, job);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < n_threads; i++) th.emplace_back(job, i);
+        job(0);
+        for (std::thread &x : th) x.join();
+    }
+    if (n_terminated)
+        for (size_t v : term) *n_terminated += v;
+    return bad ? HSGPU_HWLM_ERROR_UNKNOWN : HSGPU_HWLM_SUCCESS;
+}
+
+extern "C" int hsgpu_hwlm_replay_batch_mt(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n, hsgpu_hwlm_cb cb,
+                                          void *const *ctxs, unsigned n_threads, uint64_t groups, size_t *n_terminated) {
+    if (!t || (n && !recs) || !cb || !ctxs || !n_threads || n_threads > 256) return HSGPU_HWLM_ERROR_UNKNOWN;
+    if (n_terminated) *n_terminated = 0;
+    try {
+        return replay_ranges(t, recs, n, cb, ctxs, n_threads, groups, nullptr, n_terminated);
+    } catch (...) {
+        return HSGPU_HWLM_ERROR_UNKNOWN;
+    }
+}
+
+/* From a device-resident scan to callbacks: the records come to the host in four chunks (pinned memory owned by
+ * the scratch) and the blocks that have arrived completely are replayed on n_threads threads while the next chunk
+ * is on the wire. The consumer side of hsgpu_hwlm_scan_dev at device speed: the single-threaded replay of 0.8 M
+ * records took five times as long as the scan that found them. */
+extern "C" int hsgpu_hwlm_fetch_replay(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_out, uint64_t cap,
+                                       const void *d_count, void *stream, hsgpu_hwlm_cb cb, void *const *ctxs,
+                                       unsigned n_threads, uint64_t groups, size_t *n_records, size_t *n_terminated) {
+    if (!t || !s || !d_count || !cb || !ctxs || !n_threads || n_threads > 256 || (cap && !d_out)) return HSGPU_INVALID;
+    if (n_records) *n_records = 0;
+    if (n_terminated) *n_terminated = 0;
+    hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(s->h_count, d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t n = *s->h_count;
+    if (n_records) *n_records = (size_t)n;
+    if (n > cap) return HSGPU_INSUFFICIENT_SPACE; /* the scan delivered nothing: rerun it with room for n */
+    if (n == 0) return HSGPU_SUCCESS;
+    if (n > s->h_recs_cap) {
+        if (s->h_recs) (void)hipHostFree(s->h_recs);
+        s->h_recs = nullptr;
+        s->h_recs_cap = 0;
+        const size_t want = (size_t)(n + n / 4 + 4096);
+        HIP_TRY(hipHostMalloc((void **)&s->h_recs, want * sizeof(hsgpu_match_t)));
+        s->h_recs_cap = want;
+    }
+    try {
+        if (!s->pool || s->pool->size() + 1 < n_threads) s->pool.reset(new WorkerPool(n_threads - 1));
+    } catch (...) {
+        return HSGPU_NOMEM;
+    }
+    const unsigned K = n >= (1u << 16) ? 4 : 1;
+    size_t edge[5];
+    for (unsigned k = 0; k <= K; k++) edge[k] = (size_t)(n * k / K);
+    for (unsigned k = 0; k < K; k++) {
+        if (!s->ev_chunk[k]) HIP_TRY(hipEventCreateWithFlags(&s->ev_chunk[k], hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(s->h_recs + edge[k], (const hsgpu_match_t *)d_out + edge[k],
+                               (edge[k + 1] - edge[k]) * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(s->ev_chunk[k], st));
+    }
+    size_t done = 0;
+    int rv = HSGPU_SUCCESS;
+    for (unsigned k = 0; k < K; k++) {
+        HIP_TRY(hipEventSynchronize(s->ev_chunk[k]));
+        size_t upto = edge[k + 1];
+        if (k + 1 < K) /* the last block of the prefix may continue in the next chunk: leave it for then */
+            while (upto > done && s->h_recs[upto - 1].block == s->h_recs[edge[k + 1] - 1].block) upto--;
+        if (upto > done) {
+            try {
+                if (replay_ranges(t, s->h_recs + done, upto - done, cb, ctxs, n_threads, groups, s->pool.get(), n_terminated) !=
+                    HSGPU_HWLM_SUCCESS)
+                    rv = HSGPU_UNKNOWN_ERROR;
+            } catch (...) {
+                rv = HSGPU_NOMEM;
+            }
+            done = upto;
+        }
+    }
+    return rv;
 }
 
 /* hsbench's counting callback (tools/hsbench/engine_hyperscan.cpp:89-97) for the two replay functions:

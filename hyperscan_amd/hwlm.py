@@ -247,6 +247,46 @@ def hwlm_replay_count(table, recs, groups=HWLM_ALL_GROUPS):
     return int(cnt.value)
 
 
+def _thread_counters(threads):
+    """one uint64 counter per thread, a cache line apart, and the array of their addresses"""
+    cnt = np.zeros(threads * 8, dtype=np.uint64)
+    ctxs = (C.c_void_p * threads)(*[cnt.ctypes.data + 64 * i for i in range(threads)])
+    return cnt, ctxs
+
+
+def hwlm_replay_count_mt(table, recs, threads, groups=HWLM_ALL_GROUPS):
+    """hwlm_replay_count on `threads` host threads (hsgpu_hwlm_replay_batch_mt: contiguous block ranges, one per
+    thread, a counter per thread) -> callbacks delivered."""
+    a = np.ascontiguousarray(recs)
+    lib = table._lib
+    cnt, ctxs = _thread_counters(threads)
+    lib.hsgpu_hwlm_replay_batch_mt.restype = C.c_int
+    lib.hsgpu_hwlm_replay_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64,
+                                               C.c_void_p]
+    rv = lib.hsgpu_hwlm_replay_batch_mt(table._h, a.ctypes.data, a.shape[0], C.cast(lib.hsgpu_hwlm_count_cb, C.c_void_p), ctxs,
+                                        threads, groups, None)
+    if rv != HWLM_SUCCESS:
+        raise HsgpuError(rv, "hsgpu_hwlm_replay_batch_mt")
+    return int(cnt.sum())
+
+
+def hwlm_fetch_replay_count(table, scratch, out_ptr, cap, count_ptr, threads, stream=None, groups=HWLM_ALL_GROUPS):
+    """hsgpu_hwlm_fetch_replay into the native counting callback: the records of a device-resident scan to pinned
+    host memory in chunks, replayed on `threads` threads while the next chunk copies.
+    -> (records the scan found, callbacks delivered)"""
+    lib = table._lib
+    cnt, ctxs = _thread_counters(threads)
+    n_rec = C.c_size_t(0)
+    lib.hsgpu_hwlm_fetch_replay.restype = C.c_int
+    lib.hsgpu_hwlm_fetch_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_uint, C.c_uint64, C.POINTER(C.c_size_t), C.c_void_p]
+    rv = lib.hsgpu_hwlm_fetch_replay(table._h, scratch._h, out_ptr, cap, count_ptr, stream,
+                                     C.cast(lib.hsgpu_hwlm_count_cb, C.c_void_p), ctxs, threads, groups, C.byref(n_rec), None)
+    if rv != 0:
+        raise HsgpuError(rv, "hsgpu_hwlm_fetch_replay")
+    return int(n_rec.value), int(cnt.sum())
+
+
 def hwlm_scan_dev(table, scratch, corpus_ptr, total_bytes, off_ptr, nblocks, out_ptr, cap, count_ptr,
                   start=0, stream=None):
     """Device-resident hot path: raw device pointers in, asynchronous."""

@@ -196,6 +196,18 @@ int hsgpu_hwlm_replay(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n
  * counts those blocks. Returns HSGPU_HWLM_SUCCESS or HSGPU_HWLM_ERROR_UNKNOWN. */
 int hsgpu_hwlm_replay_batch(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n, hsgpu_hwlm_cb cb,
                             void *ctx, uint64_t groups, size_t *n_terminated);
+/* The same on n_threads host threads: the blocks are cut into n_threads contiguous ranges and range i is walked,
+ * in order, by one thread with ctxs[i] as the callbacks' context -- callbacks of DIFFERENT blocks run
+ * concurrently (hsbench's -T model, tools/hsbench/main.cpp:957-963); within a block nothing changes. */
+int hsgpu_hwlm_replay_batch_mt(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n, hsgpu_hwlm_cb cb,
+                               void *const *ctxs, unsigned n_threads, uint64_t groups, size_t *n_terminated);
+/* From a device-resident scan (hsgpu_hwlm_scan_dev's d_out / d_count, `cap` as given there) to callbacks: waits
+ * for the scan on `stream`, brings the records to pinned host memory owned by the scratch in chunks and replays
+ * the blocks that have arrived on n_threads threads (as hsgpu_hwlm_replay_batch_mt) while the next chunk is on
+ * the wire. *n_records = the scan's count; HSGPU_INSUFFICIENT_SPACE when it exceeds cap (nothing is replayed). */
+int hsgpu_hwlm_fetch_replay(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_out, uint64_t cap,
+                            const void *d_count, void *stream, hsgpu_hwlm_cb cb, void *const *ctxs, unsigned n_threads,
+                            uint64_t groups, size_t *n_records, size_t *n_terminated);
 /* hsbench's counting callback (tools/hsbench/engine_hyperscan.cpp:89-97): ctx = uint64_t counter. */
 uint64_t hsgpu_hwlm_count_cb(size_t end, uint32_t id, void *ctx);
 

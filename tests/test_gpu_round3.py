@@ -1,0 +1,61 @@
+"""GPU tests of round 3: the consumer side of the device boundary (hsgpu_hwlm_fetch_replay), the chunked
+host-buffer pipeline, dense inputs, the run_accel-shaped entry."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hyperscan_amd as H
+from hyperscan_amd import corpus as cp
+from hyperscan_amd import hwlm as hw
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def _resident(lits, corpus, off, cap=None):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    t = H.hwlm_build(lits)
+    s = H.Scratch(0)
+    d_corpus = torch.from_numpy(np.concatenate([corpus, np.zeros(16, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.astype(np.uint64).view(np.int64)).to(dev)
+    cap = cap or max(1 << 12, corpus.size // 64)
+    d_out = torch.zeros(cap * 4, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    hw.hwlm_scan_dev(t, s, d_corpus.data_ptr(), int(corpus.size), d_off.data_ptr(), int(off.size - 1), d_out.data_ptr(), cap,
+                     d_count.data_ptr(), 0, st)
+    return t, s, d_out, d_count, cap, st, (d_corpus, d_off)
+
+
+@pytest.mark.parametrize("mib,threads", [(1, 1), (8, 4), (32, 16)])
+def test_fetch_replay_counts_what_the_reference_delivers(mib, threads):
+    lits = cp.teddy_literals(64, seed=2)
+    corpus, off = cp.packet_corpus(mib << 20, lits, seed=21, match_every=512)  # dense enough for the 4-chunk path at 32 MiB
+    t, s, d_out, d_count, cap, st, keep = _resident(lits, corpus, off)
+    n_rec, n_del = hw.hwlm_fetch_replay_count(t, s, d_out.data_ptr(), cap, d_count.data_ptr(), threads, st)
+    want = ob.Oracle(lits).count_blocks(corpus, off)
+    assert n_rec == want and n_del == want and want > 100
+    # a second call on the same scratch (pool and pinned buffer reused), other thread count
+    n_rec2, n_del2 = hw.hwlm_fetch_replay_count(t, s, d_out.data_ptr(), cap, d_count.data_ptr(), max(1, threads // 2), st)
+    assert (n_rec2, n_del2) == (want, want)
+
+
+def test_fetch_replay_sequential_rules_and_overflow():
+    """noruns literals and groups go through the same per-block rules as hsgpu_hwlm_replay_batch; a scan whose
+    records did not fit reports HSGPU_INSUFFICIENT_SPACE and delivers nothing."""
+    rng = np.random.default_rng(5)
+    base = cp.teddy_literals(40, seed=9)
+    lits = [H.HwlmLiteral(l.s, False, i, noruns=bool(i % 3 == 0), groups=[H.HWLM_ALL_GROUPS, 0x1, 0x2][i % 3]) for i, l in enumerate(base)]
+    corpus, off = cp.packet_corpus(4 << 20, lits, seed=22, match_every=256)
+    t, s, d_out, d_count, cap, st, keep = _resident(lits, corpus, off)
+    n = int(d_count.item())
+    recs = d_out[: n * 4].view(n, 4).cpu().numpy().astype(np.uint32)
+    for groups in (H.HWLM_ALL_GROUPS, 0x1, 0x2):
+        want = hw.hwlm_replay_count(t, recs, groups)
+        n_rec, n_del = hw.hwlm_fetch_replay_count(t, s, d_out.data_ptr(), cap, d_count.data_ptr(), 5, st, groups)
+        assert n_rec == n and n_del == want and 0 < want <= n
+    with pytest.raises(hw.HsgpuError):
+        hw.hwlm_fetch_replay_count(t, s, d_out.data_ptr(), 16, d_count.data_ptr(), 2, st)

@@ -869,3 +869,57 @@ def test_replay_batch_restarts_the_rules_in_every_block_like_the_reference():
         want += out
     assert sorted(delivered) == sorted(want) and len(want) > 500
     assert n_term.value == want_term and want_term > 10
+
+
+def test_replay_batch_mt_delivers_what_the_single_threaded_walk_delivers():
+    """hsgpu_hwlm_replay_batch_mt: contiguous block ranges on several threads, a context per thread. The callbacks of
+    one block stay on one thread in order (each thread checks that its blocks and, inside a block, its ends never go
+    backwards), the multiset delivered and the number of terminated blocks equal the single-threaded walk's; with
+    noruns literals, group masks that the callback changes and a stop rule inside blocks. No GPU involved."""
+    import threading
+
+    from tests import oracle_binding as ob
+    from tests.util import random_blocks, random_corpus, random_literals
+
+    rng = np.random.default_rng(63)
+    base = random_literals(rng, 40, 2, 8, nocase_frac=0.3)
+    lits = [H.HwlmLiteral(l.s, l.nocase, i, noruns=bool(i % 4 == 0), groups=[H.HWLM_ALL_GROUPS, 0x1, 0x2][i % 3]) for i, l in enumerate(base)]
+    raw = [H.HwlmLiteral(l.s, l.nocase, i) for i, l in enumerate(base)]
+    corpus = random_corpus(rng, 80_000, lits, plant_every=40)
+    off = random_blocks(rng, corpus.size, mean_len=300)
+    sup = ob.Oracle(raw).collect_blocks(corpus, off)
+    recs = np.zeros(sup.size, dtype=hw.MATCH_DTYPE)
+    recs["block"], recs["end"], recs["id"], recs["lit"] = sup["block"], sup["end"], sup["id"], sup["id"]
+    recs = np.ascontiguousarray(recs[np.lexsort((recs["lit"], recs["end"], recs["block"]))])
+    t = H.hwlm_build(lits)
+
+    def policy(e):  # depends on the end offset only: the same decision whichever thread asks
+        return 0 if e % 97 == 0 else (0x1 if e % 5 == 0 else H.HWLM_ALL_GROUPS)
+
+    single = []
+    n1 = C.c_size_t(0)
+    cb1 = _native.HWLM_CB(lambda e, i, _c: (single.append((e, i)), policy(e))[1])
+    assert t._lib.hsgpu_hwlm_replay_batch(t._h, recs.ctypes.data, recs.size, C.cast(cb1, C.c_void_p), None, H.HWLM_ALL_GROUPS,
+                                          C.byref(n1)) == 0
+    for threads in (1, 3, 8):
+        per = {}
+        lock = threading.Lock()
+
+        def cb(e, i, ctx):
+            with lock:
+                per.setdefault(ctx, []).append((e, i))
+            return policy(e)
+
+        ccb = _native.HWLM_CB(cb)
+        ctxs = (C.c_void_p * threads)(*[1000 + k for k in range(threads)])
+        nt = C.c_size_t(0)
+        t._lib.hsgpu_hwlm_replay_batch_mt.restype = C.c_int
+        t._lib.hsgpu_hwlm_replay_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64,
+                                                      C.c_void_p]
+        assert t._lib.hsgpu_hwlm_replay_batch_mt(t._h, recs.ctypes.data, recs.size, C.cast(ccb, C.c_void_p), ctxs, threads,
+                                                 H.HWLM_ALL_GROUPS, C.byref(nt)) == 0
+        # contexts 1000, 1001, ... hold consecutive pieces of the single-threaded delivery
+        joined = [x for k in range(threads) for x in per.get(1000 + k, [])]
+        assert joined == single and nt.value == n1.value and n1.value > 5
+        assert len(per) == min(threads, len(per)) and (threads == 1 or len(per) > 1)
+    assert hw.hwlm_replay_count_mt(t, recs, 4) > 0
