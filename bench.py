@@ -115,7 +115,7 @@ def filter_kernel_name(flags):
 class GpuJob:
     """One rank's resident state: table, corpus/offsets/records in HBM."""
 
-    def __init__(self, lits, corpus, off, device, sibling=None):
+    def __init__(self, lits, corpus, off, device, sibling=None, cap=None):
         import torch
 
         import hyperscan_amd as H
@@ -133,7 +133,7 @@ class GpuJob:
             self.nblocks = int(off.size - 1)
             self.d_corpus = torch.from_numpy(corpus).to(self.dev)
             self.d_off = torch.from_numpy(off.view(np.int64)).to(self.dev)
-        self.cap = max(1 << 16, self.total // 512)
+        self.cap = cap or max(1 << 16, self.total // 512)
         self.scratch.enable_timing(True)
         self.d_out = torch.zeros(self.cap * 4, dtype=torch.int32, device=self.dev)
         self.d_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -434,8 +434,16 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         t0 = time.perf_counter()
         recs_h = hw.hwlm_exec_batch(job.table, job.scratch, sample, s_off, cap=job.cap)
         dt_h = time.perf_counter() - t0
+        hw.hwlm_exec_batch_pipelined(job.table, job.scratch, sample, s_off)  # warm: the pipeline's buffers sized
+        t0 = time.perf_counter()
+        recs_p = hw.hwlm_exec_batch_pipelined(job.table, job.scratch, sample, s_off)
+        dt_p = time.perf_counter() - t0
+        assert recs_p.size == recs_h.size
         res["host_buffers"] = {"GBps": round(sample.size / dt_h / 1e9, 2), "sample_bytes": int(sample.size),
                                "matches": int(recs_h.size),
+                               "pipelined_GBps": round(sample.size / dt_p / 1e9, 2),
+                               "pipelined": "hsgpu_hwlm_exec_batch_cb: 64 MiB chunks, the copy of chunk i + 1 beside the scan of chunk i, "
+                                            "records handed over per chunk",
                                "what": "hsgpu_hwlm_exec_batch from pageable host memory: H2D of the corpus + scan + "
                                        "D2H of the records; PCIe bound, reported for completeness only"}
     if cpu:
@@ -589,6 +597,82 @@ def run_class256(args):
     return res
 
 
+# ---- flood density ("flood-density corpora must be reported separately") -------------------
+
+def run_flood(args):
+    """The reference's flood case (src/fdr/flood_runtime.h:86-335, unit/internal/fdr_flood.cpp:148-557): long runs of
+    one byte under literals made of that byte. 64 blocks of 1 MiB, block b filled with one byte value (16 values in
+    turn); for four of the values the set holds the 4-byte and the 8-byte run of that byte (two matches per corpus
+    byte in a quarter of the blocks) and a near miss; 100 ordinary literals ride along."""
+    import torch
+
+    from hyperscan_amd import corpus as cp
+    from hyperscan_amd.hwlm import HwlmLiteral
+    from tests import oracle_binding as ob
+
+    nb, blk = 64, 1 << 20
+    corpus = np.repeat((np.arange(nb) % 16 + ord("a")).astype(np.uint8), blk)
+    off = (np.arange(nb + 1, dtype=np.uint64) * np.uint64(blk))
+    lits = []
+    for c in b"abcd":
+        lits += [HwlmLiteral(bytes([c]) * 4, False, len(lits)), HwlmLiteral(bytes([c]) * 8, False, len(lits) + 1),
+                 HwlmLiteral(bytes([c]) * 3 + b"x", False, len(lits) + 2)]
+    lits += [HwlmLiteral(l.s, l.nocase, len(lits) + i) for i, l in enumerate(cp.teddy_literals(100, seed=12))]
+    want_total = 16 * ((blk - 3) + (blk - 7))
+    # the output protocol of hsgpu_hwlm_scan_dev: a count above cap (cap + 1: a staging region, sized from cap for an
+    # even spread, overflowed) means "again with more room" -- flood blocks hold four times the average density
+    cap = want_total + (1 << 20)
+    for attempt in range(4):
+        job = GpuJob(lits, corpus, off, torch.cuda.current_device(), cap=cap)
+        job.launch()
+        torch.cuda.synchronize()
+        n = job.count()
+        if n <= cap:
+            break
+        del job
+        torch.cuda.empty_cache()
+        cap *= 2
+    assert n == want_total, f"flood: {n} matches, expected {want_total}"
+    # content gate on the first block against the reference (or the restatement)
+    d_first = job.d_out[: 4 * (2 * blk)].view(-1, 4)
+    g = d_first[d_first[:, 0] == 0].cpu().numpy().astype(np.uint32)
+    ref = ob.Reference(lits, variant=ob.ref_variants()[-1]) if ob.ref_available() else ob.Oracle(lits)
+    want = ref.collect_blocks(corpus[:blk], off[:2])
+    key = (g[:, 1].astype(np.uint64) << np.uint64(32)) | g[:, 3].astype(np.uint64)
+    assert np.all(key[1:] > key[:-1]), "flood: records of block 0 not in delivery order"
+    wi = np.lexsort((want["id"], want["end"]))
+    gi = np.lexsort((g[:, 2], g[:, 1]))
+    assert len(g) == len(want) and np.array_equal(g[gi, 1], want["end"][wi]) and np.array_equal(g[gi, 2], want["id"][wi]), \
+        "PARITY FAILURE on the flood block"
+    steps = max(3, min(args.steps, 10))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.launch()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert job.count() == n
+    over = job.scratch.stats()[1]
+    f_ms, c_ms, p_ms = job.scratch.timing(0)  # filter kernel (events), filter end -> fused-kernel start, filter start -> sort start
+    res = {"workload": "flood: 64 blocks of 1 MiB, each one byte value repeated (16 values in turn); for 4 of them the set holds the "
+                       "4- and 8-byte run of that byte: 2 matches per corpus byte in a quarter of the blocks; + 100 ordinary literals",
+           "value": round(job.total / dt / 1e9, 2), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 3),
+           "matches_per_step": int(n), "matches_per_s": round(n / dt, 1), "record_bytes_per_step": int(n) * REC_BYTES,
+           "candidate_overflow_scans": int(over), "record_capacity": int(cap),
+           "stages_ms": {"filter": round(f_ms, 3), "confirm_stage": round(c_ms, 3), "filter_start_to_sort_start": round(p_ms, 3),
+                         "sort_and_gaps": round(dt * 1e3 - p_ms, 3)},
+           "parity": f"count exact ({n}); (end, id) of block 0 ({len(want)} matches) identical to the reference, delivery order checked",
+           "table": job.table.info()}
+    if ob.ref_available():
+        nbytes, secs, matches, _p = ref.bench_threads(corpus[: 4 * blk], off[:5], 4, 1.0)
+        res["cpu_baseline"] = {"value": round(nbytes / secs / 1e9, 3), "unit": "GB/s", "cores": 4, "kind": "reference",
+                               "sample": "the first 4 blocks (all four flood bytes), one pinned thread per block, ~1 s", "engine": ref.info(),
+                               "matches_per_pass": int(matches)}
+    del job
+    torch.cuda.empty_cache()
+    return res
+
+
 # ---- config 5: literal hits feeding the host-side confirm ---------------------------------------
 
 def run_rose1000(args):
@@ -666,7 +750,7 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0, help="corpus GiB per GPU")
     ap.add_argument("--workload", default="fdr10k", choices=["teddy64", "fdr10k"])
     ap.add_argument("--no-also", action="store_true", help="skip the other workloads' lines")
-    ap.add_argument("--also", default="teddy64,class256,rose1000", help="comma-separated extra workloads at N = 1")
+    ap.add_argument("--also", default="teddy64,class256,rose1000,flood", help="comma-separated extra workloads at N = 1")
     ap.add_argument("--class-gib", type=float, default=4.0)
     ap.add_argument("--rose-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
@@ -707,6 +791,8 @@ def main():
                     also[name] = run_class256(args)
                 elif name == "rose1000":
                     also[name] = run_rose1000(args)
+                elif name == "flood":
+                    also[name] = run_flood(args)
                 elif name != args.workload:
                     also[name] = run_workload(name, args, rank, world, dist, do_cpu)
             except Exception as e:  # an extra line must not take the headline down with it

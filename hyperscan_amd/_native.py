@@ -61,6 +61,8 @@ _SIGS = {
                                              C.c_void_p]),
     "hsgpu_hwlm_fetch_replay": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_uint, C.c_uint64, C.POINTER(C.c_size_t), C.c_void_p]),
+    "hsgpu_hwlm_exec_batch_cb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                           C.c_void_p, C.c_void_p]),
     "hsgpu_class_seq_work_bytes": (C.c_size_t, [C.c_uint64]),
     "hsgpu_class_seq_scan_dev": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,

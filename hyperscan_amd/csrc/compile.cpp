@@ -21,6 +21,7 @@
  * literals to confirm.
  */
 #include "internal.h"
+#include "../../include/hsgpu_tuning.h"
 
 #include <algorithm>
 #include <cstdarg>

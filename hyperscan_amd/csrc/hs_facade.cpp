@@ -1058,6 +1058,34 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
     struct Guard { hs_scratch *s; ~Guard() { s->in_use = false; } } guard{scratch};
     if (nblocks == 0) return HS_SUCCESS;
     const auto t_begin = std::chrono::steady_clock::now();
+    /* large batches of a literal-only database: the chunked pipeline (csrc/runtime.hip): the host confirm and the
+     * callbacks of chunk i run here while the chunks after it are copied and scanned */
+    if (db->hwlm && db->cs_seqs.empty() && off[nblocks] - off[0] >= ((unsigned long long)96 << 20) &&
+        hsgpu_host_is_pinned(data)) { /* (copies from pageable memory are staged by the runtime and gain nothing from chunks) */
+        struct Ctx {
+            const hs_database *db;
+            const char *data;
+            const unsigned long long *off;
+            hs_batch_event_handler onEvent;
+            void *context;
+            int terminated, failed;
+        } c{db, data, off, onEvent, context, 0, 0};
+        const int rv = hsgpu_hwlm_exec_batch_cb(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off, (size_t)nblocks, 0, 0,
+                                                [](const hsgpu_match_t *recs, size_t n, void *p) -> int {
+                                                    Ctx *c = (Ctx *)p;
+                                                    const int t = confirm_and_deliver(c->db, c->data, c->off, recs, n, c->onEvent, c->context);
+                                                    if (t < 0) {
+                                                        c->failed = 1;
+                                                        return 1;
+                                                    }
+                                                    c->terminated |= t; /* a callback's stop ends its own block only: go on */
+                                                    return 0;
+                                                },
+                                                &c);
+        if (c.failed || rv == HSGPU_NOMEM) return HS_NOMEM;
+        if (rv != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
+        return c.terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
+    }
     size_t cap = std::max<size_t>(std::max<size_t>(4096, scratch->recs_cap), (size_t)(off[nblocks] - off[0]) / 1024), n = 0;
     for (int attempt = 0; db->hwlm && attempt < 8; attempt++) {
         if (!scratch->reserve(cap)) return HS_NOMEM;

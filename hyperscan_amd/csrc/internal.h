@@ -30,5 +30,6 @@ int hsgpu_table_agrees(const hsgpu_hwlm *t, const hsgpu_lit_t *lits, size_t n);
 
 /* runtime.hip */
 void hsgpu_release_device_copies(hsgpu_hwlm *t);
+int hsgpu_host_is_pinned(const void *p);
 
 #endif

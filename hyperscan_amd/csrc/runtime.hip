@@ -29,6 +29,7 @@
 
 #include "internal.h"
 #include "scan_kernels.h"
+#include "../../include/hsgpu_tuning.h"
 
 #define HIP_TRY(expr)                                                              \
     do {                                                                           \
@@ -146,11 +147,17 @@ struct hsgpu_scratch {
     DevBuf tstamp;              /* [kRing][4] device wall clock: filter start (min) / end (max), confirm-stage end, pipeline end */
     double wall_clock_khz = 100000.0;
     DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats;
+    DevBuf pipe_corpus[2], pipe_off[2], pipe_out[2], pipe_count; /* hsgpu_hwlm_exec_batch_cb: two chunks in flight */
+    hipEvent_t ev_copied[2] = {}, ev_scanned[2] = {};
     DevBuf cs_bitmaps, cs_work, cs_counts; /* hsgpu_class_seq_exec_batch: class bitmaps, work areas, per-pattern counts */
     bool ctl_clean = false;                /* the control block the next scan will use is zero (left so by the scan before last) */
     unsigned ctl_parity = 0;               /* which half of the control buffer the next scan uses */
     unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
+    uint32_t *h_note = nullptr, *d_note = nullptr; /* mapped pinned word the fused fallback sets (see HsgpuScanArgs::overflow_note) */
+    int tune_fused = 0;                    /* hsgpu_scratch_set_tuning (tests / tuning runs) */
+    unsigned tune_wg_threads = 0, tune_wg_per_cu = 0;
+    uint64_t cand_div = 64;                /* corpus bytes per candidate entry of capacity: 16 (room for every chunk) once a scan overflowed */
     hsgpu_match_t *h_recs = nullptr;       /* pinned: hsgpu_hwlm_fetch_replay's landing area for the records */
     size_t h_recs_cap = 0;
     hipEvent_t ev_chunk[4] = {};           /* its D2H chunks */
@@ -216,10 +223,17 @@ extern "C" int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device) {
         hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void **)&s->h_count, sizeof(unsigned long long)) != hipSuccess) {
+        hipHostMalloc((void **)&s->h_count, 4 * sizeof(unsigned long long)) != hipSuccess) {
         hsgpu_set_error("scratch setup failed");
         hsgpu_scratch_free(s);
         return HSGPU_UNKNOWN_ERROR;
+    }
+    if (hipHostMalloc((void **)&s->h_note, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+        *s->h_note = 0;
+        if (hipHostGetDevicePointer((void **)&s->d_note, s->h_note, 0) != hipSuccess) s->d_note = nullptr;
+    } else {
+        (void)hipGetLastError();
+        s->h_note = nullptr;
     }
     s->n_cu = prop.multiProcessorCount;
     s->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
@@ -246,10 +260,19 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->stats.release();
     s->tstamp.release();
     s->rec_stage.release();
+    for (int i = 0; i < 2; i++) {
+        s->pipe_corpus[i].release();
+        s->pipe_off[i].release();
+        s->pipe_out[i].release();
+        if (s->ev_copied[i]) (void)hipEventDestroy(s->ev_copied[i]);
+        if (s->ev_scanned[i]) (void)hipEventDestroy(s->ev_scanned[i]);
+    }
+    s->pipe_count.release();
     s->cs_bitmaps.release();
     s->cs_work.release();
     s->cs_counts.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
+    if (s->h_note) (void)hipHostFree(s->h_note);
     if (s->h_recs) (void)hipHostFree(s->h_recs);
     for (int i = 0; i < 4; i++)
         if (s->ev_chunk[i]) (void)hipEventDestroy(s->ev_chunk[i]);
@@ -358,9 +381,12 @@ static int set_dyn_lds(const void *fn, size_t lds) {
     return HSGPU_SUCCESS;
 }
 
-static int scan_mode() { /* 0 = two-phase (default), 1 = fused only; tuning/testing knob */
-    static const char *m = getenv("HSGPU_MODE");
-    return (m && !strcmp(m, "fused")) ? 1 : 0;
+extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu) {
+    if (!s || (wg_threads && wg_threads != 256 && wg_threads != 512 && wg_threads != 1024) || wg_per_cu > 4) return HSGPU_INVALID;
+    s->tune_fused = fused_only != 0;
+    s->tune_wg_threads = wg_threads;
+    s->tune_wg_per_cu = wg_per_cu;
+    return HSGPU_SUCCESS;
 }
 
 static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArgs &a, hipStream_t stream) {
@@ -383,15 +409,14 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     const bool light = (h->flags & HSGPU_F_STRIDE2) && !(h->flags & (HSGPU_F_K2 | HSGPU_F_HAS_C | HSGPU_F_PAIR));
     unsigned wg_threads = (small || light) ? 512 : HSGPU_WG_THREADS;
     unsigned wg_per_cu = small ? 3 : 1;
-    static const char *env_wg = getenv("HSGPU_WG_THREADS"), *env_per = getenv("HSGPU_WG_PER_CU"); /* tuning knobs */
-    if (env_wg && (atoi(env_wg) == 256 || atoi(env_wg) == 512 || atoi(env_wg) == 1024)) wg_threads = (unsigned)atoi(env_wg);
+    if (s->tune_wg_threads) wg_threads = s->tune_wg_threads; /* hsgpu_scratch_set_tuning */
     if (!small) { /* a 64 KiB filter admits a second workgroup when the kernel's registers do */
         int nb = 0;
         const size_t l2 = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false, wg_threads);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f_two, (int)wg_threads, l2) == hipSuccess && nb >= 2)
             wg_per_cu = 2;
     }
-    if (env_per && atoi(env_per) >= 1 && atoi(env_per) <= 4) wg_per_cu = (unsigned)atoi(env_per);
+    if (s->tune_wg_per_cu) wg_per_cu = s->tune_wg_per_cu;
     const uint32_t super_shift = wg_threads == 256 ? 12 : wg_threads == 512 ? 13 : 14; /* 1 KiB per wavefront */
     const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads);      /* fused */
     const size_t lds_two = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false, wg_threads); /* two-phase filter */
@@ -422,7 +447,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
     if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
     args.hint = (const uint32_t *)s->hint.p;
-    const bool two_phase = scan_mode() == 0;
+    const bool two_phase = !s->tune_fused;
     /* Block hints are only needed by the confirm step. Two-phase: the filter kernel writes
      * them in its prologue (while its LDS image loads). Fused: the filter itself needs
      * them, so a hint kernel runs first on the same stream. */
@@ -471,6 +496,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     /* the regions fed by one filter wavefront: the records of one contiguous share of the corpus */
     args.group_regions = HSGPU_CONFIRM_SPLIT;
     args.stats = (unsigned long long *)s->stats.p;
+    args.overflow_note = s->d_note;
 
     void *kargs[] = {&args};
     args.tstamp = nullptr;
@@ -498,8 +524,14 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
          * owns a private region of the candidate buffer: one 32-byte entry per 64
          * corpus bytes on average, i.e. room for candidates in a quarter of all chunks. */
         args.cand_waves = n_waves;
-        static const char *env_div = getenv("HSGPU_CAND_DIV"); /* tuning knob: corpus bytes per candidate entry of capacity */
-        const uint64_t cand_div = (env_div && atoi(env_div) >= 8 && atoi(env_div) <= 4096) ? (uint64_t)atoi(env_div) : 64;
+        /* Dense input (the reference's flood case, src/fdr/flood_runtime.h:86-335): once a scan on this scratch ran out of
+         * candidate room and was redone by the fused kernel, later scans give every 16-byte chunk an entry of its own -- the
+         * two-phase path can then not overflow, at the price of a candidate buffer twice the size of the corpus. */
+        if (s->h_note && *s->h_note) {
+            *s->h_note = 0;
+            s->cand_div = 16;
+        }
+        uint64_t cand_div = s->cand_div;
         args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / cand_div + n_waves - 1) / n_waves);
         if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32)) != HSGPU_SUCCESS) return rv;
         args.cand = (uint4 *)s->cand.p;
@@ -513,8 +545,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     }
     if (s->timing) s->n_timed++;
     /* one workgroup per share of the corpus: its records sorted into place; the control block back to zero */
-    HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions), dim3(256),
-                            kargs, 0, stream));
+    HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions),
+                            dim3(s->cand_div == 16 ? 1024 : 256), kargs, 0, stream));
     s->ctl_clean = true;
     s->ctl_parity ^= 1u;
     return HSGPU_SUCCESS;
@@ -742,6 +774,192 @@ extern "C" int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned
         dcap = n;
     }
     return HSGPU_UNKNOWN_ERROR;
+}
+
+/* ---- the chunked host-buffer pipeline ---------------------------------------------------------
+ * A host batch cut into chunks of whole blocks (64 MiB by default). A producer thread drives the device: the copy
+ * of chunk i + 1 (side stream) runs beside the scan of chunk i (scratch stream), two device slots alternate; the
+ * records of every finished chunk, block indices made global, are handed IN BLOCK ORDER to the calling thread,
+ * which runs the caller's function on them while later chunks copy and scan. The reference has no device boundary
+ * (doc/dev-reference/performance.rst:56-61); for a caller whose data is in host memory this is what keeps the
+ * bus busy end to end: everything on the host side of a chunk (sorting, confirm, callbacks) hides behind the copies
+ * of the chunks after it. */
+#include <deque>
+namespace {
+struct ChunkResult {
+    std::vector<hsgpu_match_t> recs;
+    int rv = HSGPU_SUCCESS;
+    bool last = false;
+};
+} // namespace
+
+static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base, const uint64_t *off, size_t nblocks,
+                          size_t start, const std::vector<size_t> &cuts, std::mutex &mu, std::condition_variable &cv,
+                          std::deque<ChunkResult> &queue, std::atomic<bool> &abort) {
+    auto fail = [&](int rv) {
+        ChunkResult r;
+        r.rv = rv;
+        r.last = true;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            queue.push_back(std::move(r));
+        }
+        cv.notify_all();
+        return rv;
+    };
+    if (hipSetDevice(s->device) != hipSuccess) return fail(HSGPU_UNKNOWN_ERROR);
+    const size_t n_chunks = cuts.size() - 1;
+    std::vector<uint64_t> rel[2];
+    auto copy_in = [&](size_t i) -> int {
+        const int slot = (int)(i & 1);
+        const size_t b0 = cuts[i], b1 = cuts[i + 1];
+        const uint64_t lo = off[b0], bytes = off[b1] - lo;
+        int rv;
+        if ((rv = s->pipe_corpus[slot].ensure(bytes + 16)) != HSGPU_SUCCESS) return rv;
+        if ((rv = s->pipe_off[slot].ensure((b1 - b0 + 1) * sizeof(uint64_t))) != HSGPU_SUCCESS) return rv;
+        rel[slot].resize(b1 - b0 + 1);
+        for (size_t k = 0; k <= b1 - b0; k++) rel[slot][k] = off[b0 + k] - lo;
+        if (bytes) HIP_TRY(hipMemcpyAsync(s->pipe_corpus[slot].p, base + lo, bytes, hipMemcpyHostToDevice, s->side));
+        HIP_TRY(hipMemcpyAsync(s->pipe_off[slot].p, rel[slot].data(), rel[slot].size() * sizeof(uint64_t), hipMemcpyHostToDevice,
+                               s->side));
+        HIP_TRY(hipEventRecord(s->ev_copied[slot], s->side));
+        return HSGPU_SUCCESS;
+    };
+    int rv;
+    for (int i = 0; i < 2; i++) {
+        if (!s->ev_copied[i] && hipEventCreateWithFlags(&s->ev_copied[i], hipEventDisableTiming) != hipSuccess) return fail(HSGPU_UNKNOWN_ERROR);
+        if (!s->ev_scanned[i] && hipEventCreateWithFlags(&s->ev_scanned[i], hipEventDisableTiming) != hipSuccess) return fail(HSGPU_UNKNOWN_ERROR);
+    }
+    if ((rv = s->pipe_count.ensure(2 * sizeof(unsigned long long))) != HSGPU_SUCCESS) return fail(rv);
+    if ((rv = copy_in(0)) != HSGPU_SUCCESS) return fail(rv);
+    for (size_t i = 0; i < n_chunks && !abort; i++) {
+        const int slot = (int)(i & 1);
+        const size_t b0 = cuts[i], b1 = cuts[i + 1];
+        const uint64_t bytes = off[b1] - off[b0];
+        uint64_t cap = std::max<uint64_t>(4096, std::max<uint64_t>(bytes / 256, s->pipe_out[slot].cap / sizeof(hsgpu_match_t)));
+        uint64_t n = 0;
+        bool next_issued = false;
+        for (int attempt = 0;; attempt++) {
+            if ((rv = s->pipe_out[slot].ensure(cap * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return fail(rv);
+            unsigned long long *d_count = (unsigned long long *)s->pipe_count.p + slot;
+            if (hipStreamWaitEvent(s->stream, s->ev_copied[slot], 0) != hipSuccess) return fail(HSGPU_UNKNOWN_ERROR);
+            if (bytes) {
+                rv = hsgpu_hwlm_scan_dev(t, s, s->pipe_corpus[slot].p, bytes, s->pipe_off[slot].p, b1 - b0, start,
+                                         s->pipe_out[slot].p, cap, d_count, s->stream);
+                if (rv != HSGPU_SUCCESS) return fail(rv);
+            } else if (hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s->stream) != hipSuccess) {
+                return fail(HSGPU_UNKNOWN_ERROR);
+            }
+            if (hipMemcpyAsync(s->h_count + slot, d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                hipEventRecord(s->ev_scanned[slot], s->stream) != hipSuccess)
+                return fail(HSGPU_UNKNOWN_ERROR);
+            /* the next chunk's copy goes out now, beside this chunk's scan; its slot was last read by the scan of
+             * chunk i - 1, which this thread has already waited for */
+            if (!next_issued && i + 1 < n_chunks) {
+                if ((rv = copy_in(i + 1)) != HSGPU_SUCCESS) return fail(rv);
+                next_issued = true;
+            }
+            if (hipEventSynchronize(s->ev_scanned[slot]) != hipSuccess) return fail(HSGPU_UNKNOWN_ERROR);
+            n = s->h_count[slot];
+            if (n <= cap) break;
+            if (attempt == 7) return fail(HSGPU_UNKNOWN_ERROR);
+            cap = std::max<uint64_t>(n + n / 4, cap * 2); /* the count is exact: again with room (and headroom for skew) */
+        }
+        ChunkResult r;
+        try {
+            r.recs.resize(n);
+        } catch (...) {
+            return fail(HSGPU_NOMEM);
+        }
+        if (n && hipMemcpy(r.recs.data(), s->pipe_out[slot].p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(HSGPU_UNKNOWN_ERROR);
+        for (hsgpu_match_t &m : r.recs) m.block += (uint32_t)b0;
+        r.last = i + 1 == n_chunks;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            queue.push_back(std::move(r));
+        }
+        cv.notify_all();
+    }
+    if (abort) { /* the consumer stopped early: let it see an end */
+        (void)hipStreamSynchronize(s->side);
+        (void)hipStreamSynchronize(s->stream);
+        return fail(HSGPU_SUCCESS);
+    }
+    return HSGPU_SUCCESS;
+}
+
+/* is this host memory page-locked (hipHostMalloc / hipHostRegister)? Asynchronous copies from pageable memory are
+ * staged by the runtime chunk by chunk and gain nothing from being cut up further. */
+int hsgpu_host_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return a.type == hipMemoryTypeHost ? 1 : 0;
+}
+
+extern "C" int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off,
+                                        size_t nblocks, size_t start, size_t chunk_bytes, hsgpu_chunk_cb on_chunk, void *ctx) {
+    if (!t || !s || !off || !on_chunk) return HSGPU_INVALID;
+    if (nblocks == 0) return HSGPU_SUCCESS;
+    if (!base && off[nblocks] != off[0]) return HSGPU_INVALID;
+    if ((uint64_t)nblocks >= (1ull << 32)) {
+        hsgpu_set_error("more than 2^32 - 1 blocks per call");
+        return HSGPU_INVALID;
+    }
+    for (size_t i = 0; i < nblocks; i++) {
+        if (off[i + 1] < off[i]) {
+            hsgpu_set_error("block offsets must be ascending");
+            return HSGPU_INVALID;
+        }
+        if (off[i + 1] - off[i] > 0xffffffffull) {
+            hsgpu_set_error("block %zu longer than 4 GiB", i);
+            return HSGPU_INVALID;
+        }
+    }
+    InUse guard(s);
+    if (!guard.ok) return HSGPU_SCRATCH_IN_USE;
+    if (!chunk_bytes) chunk_bytes = (size_t)64 << 20;
+    std::vector<size_t> cuts; /* block indices: chunk i = blocks [cuts[i], cuts[i + 1]) */
+    try {
+        cuts.push_back(0);
+        while (cuts.back() < nblocks) {
+            const uint64_t lo = off[cuts.back()];
+            size_t b = std::upper_bound(off + cuts.back(), off + nblocks + 1, lo + chunk_bytes) - off; /* first offset past the chunk */
+            b = std::max<size_t>(b - 1, cuts.back() + 1); /* at least one block (a block larger than the chunk goes alone) */
+            cuts.push_back(std::min(b, nblocks));
+        }
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<ChunkResult> queue;
+        std::atomic<bool> abort{false};
+        std::thread producer([&] { (void)produce_chunks(t, s, base, off, nblocks, start, cuts, mu, cv, queue, abort); });
+        int rv = HSGPU_SUCCESS, stop = 0;
+        for (;;) {
+            ChunkResult r;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return !queue.empty(); });
+                r = std::move(queue.front());
+                queue.pop_front();
+            }
+            if (r.rv != HSGPU_SUCCESS) {
+                rv = r.rv;
+            } else if (!stop && !r.recs.empty() && on_chunk(r.recs.data(), r.recs.size(), ctx) != 0) {
+                stop = 1; /* the caller has seen enough: the producer winds down */
+                abort = true;
+            }
+            if (r.last) break;
+        }
+        producer.join();
+        return rv != HSGPU_SUCCESS ? rv : (stop ? HSGPU_SCAN_TERMINATED : HSGPU_SUCCESS);
+    } catch (const std::bad_alloc &) {
+        return HSGPU_NOMEM;
+    } catch (...) {
+        return HSGPU_UNKNOWN_ERROR;
+    }
 }
 
 extern "C" int hsgpu_hwlm_replay(const hsgpu_hwlm_t *t, const hsgpu_match_t *recs, size_t n, hsgpu_hwlm_cb cb,

@@ -887,6 +887,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         if (args.tstamp && blockIdx.x == 0 && threadIdx.x == 0) args.tstamp[2] = wall_clock64();
         return;
     }
+    if (FUSED && args.cand_counts && args.overflow_note && blockIdx.x == 0 && threadIdx.x == 0) *args.overflow_note = 1u;
     if (!FUSED && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
 
     const uint32_t flog2 = args.t_filter_log2;
@@ -1224,7 +1225,10 @@ __device__ __forceinline__ void bitonic_sort(PTR x, uint32_t n) {
     }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs args) {
+/* 256 threads per share; 1024 once the scratch has seen dense input (runtime.hip): a dense share holds tens of thousands of
+ * records and its sort is this one workgroup's work */
+__global__ __launch_bounds__(1024) void record_sort_kernel(HsgpuScanArgs args) {
+    const uint32_t NT = blockDim.x;
     __shared__ uint4 buf[SORT_LDS];
     __shared__ unsigned long long placed[3]; /* records in front of this share, records in all, overflow flag */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -1292,7 +1296,7 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
             const bool in_lds = n <= SORT_LDS;
             /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
              * spilled to the back) */
-            for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += SORT_THREADS) { /* whole wavefronts: shuffles below */
+            for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += NT) { /* whole wavefronts: shuffles below */
                 uint32_t r = 0;
                 for (uint32_t k = 1; k < nreg; k++) r += __shfl(my_at, k) <= i ? 1u : 0u; /* the last region starting at or before i */
                 const uint32_t f = __shfl(my.x, r), at = __shfl(my_at, r), j = i - at;
@@ -1318,9 +1322,53 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
                 }
             } else if (in_lds) {
                 bitonic_sort(buf, n);
-                for (uint32_t i = tid; i < n; i += SORT_THREADS) out[base + i] = buf[i];
+                for (uint32_t i = tid; i < n; i += NT) out[base + i] = buf[i];
             } else {
-                bitonic_sort(out + base, n);
+                /* a dense share (the reference's flood case, src/fdr/flood_runtime.h:86-335: thousands of records from a
+                 * few KiB of corpus): tiles of SORT_LDS records sorted in LDS, then merge passes between the output and
+                 * the share's own staging regions (free once gathered; together at least n records long), every thread
+                 * merging MERGE_SEG outputs from the split point its diagonal gives (merge path). The bitonic network
+                 * run in place in global memory took 28 ms for 8 192 records. */
+                uint4 *a = out + base, *b = args.rec_stage + (uint64_t)first * args.rec_cap;
+                for (uint32_t t0 = 0; t0 < n; t0 += SORT_LDS) {
+                    const uint32_t cnt = min(SORT_LDS, n - t0);
+                    for (uint32_t i = tid; i < cnt; i += NT) buf[i] = a[t0 + i];
+                    __syncthreads();
+                    bitonic_sort(buf, cnt);
+                    for (uint32_t i = tid; i < cnt; i += NT) a[t0 + i] = buf[i];
+                    __threadfence_block();
+                    __syncthreads();
+                }
+                constexpr uint32_t MERGE_SEG = 8;
+                for (uint32_t w = SORT_LDS; w < n; w <<= 1) {
+                    for (uint32_t o = tid * MERGE_SEG; o < n; o += NT * MERGE_SEG) {
+                        const uint32_t pair = o / (2 * w) * (2 * w); /* this output segment lies in the merge of runs at pair */
+                        const uint32_t la = min(w, n - pair), lb = min(w, n - min(n, pair + w));
+                        const uint4 *ra = a + pair, *rb = a + pair + la;
+                        const uint32_t d = o - pair; /* diagonal: d outputs come before this segment */
+                        /* i elements of run A and d - i of run B precede: the smallest i with A[i] > B[d - i - 1] fails */
+                        uint32_t lo = d > lb ? d - lb : 0, hi = min(d, la);
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (rec_less(rb[d - mid - 1], ra[mid])) hi = mid; /* B's element first: take fewer of A */
+                            else lo = mid + 1;
+                        }
+                        uint32_t i = lo, j = d - lo;
+                        const uint32_t stop = min(o + MERGE_SEG, min(n, pair + la + lb));
+                        for (uint32_t k = o; k < stop; k++) {
+                            const bool take_b = i >= la || (j < lb && rec_less(rb[j], ra[i]));
+                            b[k] = take_b ? rb[j++] : ra[i++];
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    uint4 *t = a;
+                    a = b;
+                    b = t;
+                }
+                if (a != out + base) { /* an odd number of passes left the result in the staging area */
+                    for (uint32_t i = tid; i < n; i += NT) out[base + i] = a[i];
+                }
             }
         }
     }
@@ -1331,11 +1379,11 @@ __global__ __launch_bounds__(SORT_THREADS) void record_sort_kernel(HsgpuScanArgs
         uint4 *other = (uint4 *)args.ctl_other;
         const uint32_t n4 = args.ctl_other_words >> 2, per = (n4 + gridDim.x - 1) / gridDim.x;
         const uint32_t lo = blockIdx.x * per, hi = min(n4, lo + per);
-        for (uint32_t i = lo + tid; i < hi; i += SORT_THREADS) other[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = lo + tid; i < hi; i += NT) other[i] = make_uint4(0, 0, 0, 0);
     }
     uint32_t v = 0, o = 0;
     if (args.cand_counts) { /* 1024 counters per workgroup: only a handful of workgroups touch the statistics word */
-        for (uint32_t i = blockIdx.x * 1024 + tid; i < min(args.cand_waves + 1, (blockIdx.x + 1) * 1024); i += SORT_THREADS) {
+        for (uint32_t i = blockIdx.x * 1024 + tid; i < min(args.cand_waves + 1, (blockIdx.x + 1) * 1024); i += NT) {
             const uint32_t c = args.cand_counts[i];
             if (i == args.cand_waves) o = c;
             else v += c;

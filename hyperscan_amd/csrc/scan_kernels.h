@@ -52,6 +52,8 @@ struct HsgpuScanArgs {
     uint32_t *ctl_other;
     uint32_t ctl_other_words;
     unsigned long long *stats;  /* [2] cumulative: candidate entries spilled, overflowed scans */
+    uint32_t *overflow_note;    /* host-visible word (mapped pinned memory): set by the fused kernel when it has to redo a scan
+                                 * whose candidate regions overflowed; the next scan on this scratch then gives every chunk room */
     unsigned long long *tstamp; /* timing only: [2] min start / max end of the filter kernel (device wall clock) */
     unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by record_sort_kernel */
 };

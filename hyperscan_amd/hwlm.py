@@ -12,6 +12,7 @@ Argument meaning, return values (HWLM_SUCCESS / HWLM_TERMINATED) and callback
 protocol (return value = live group mask, 0 terminates) are the reference's.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -142,6 +143,19 @@ class Scratch:
         if rv != 0:
             raise HsgpuError(rv, "hsgpu_scratch_alloc")
         self._h = h
+        # tests and tuning runs select another pipeline / launch geometry for a whole process through the environment
+        # (include/hsgpu_tuning.h; the C library itself reads no environment variables)
+        env = os.environ
+        if env.get("HSGPU_MODE") or env.get("HSGPU_WG_THREADS") or env.get("HSGPU_WG_PER_CU"):
+            self.set_tuning(env.get("HSGPU_MODE") == "fused", int(env.get("HSGPU_WG_THREADS", "0")),
+                            int(env.get("HSGPU_WG_PER_CU", "0")))
+
+    def set_tuning(self, fused_only=False, wg_threads=0, wg_per_cu=0):
+        self._lib.hsgpu_scratch_set_tuning.restype = C.c_int
+        self._lib.hsgpu_scratch_set_tuning.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
+        rv = self._lib.hsgpu_scratch_set_tuning(self._h, 1 if fused_only else 0, wg_threads, wg_per_cu)
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_set_tuning")
 
     def enable_timing(self, on=True):
         rv = self._lib.hsgpu_scratch_enable_timing(self._h, 1 if on else 0)
@@ -245,6 +259,38 @@ def hwlm_replay_count(table, recs, groups=HWLM_ALL_GROUPS):
     if rv != HWLM_SUCCESS:
         raise HsgpuError(rv, "hsgpu_hwlm_replay_batch")
     return int(cnt.value)
+
+
+CHUNK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def hwlm_exec_batch_pipelined(table, scratch, base, off, start=0, chunk_bytes=0, on_chunk=None):
+    """hsgpu_hwlm_exec_batch_cb: the host-buffer scan as a pipeline of chunks (copy of chunk i + 1 beside the scan
+    of chunk i; the records of each finished chunk handed over while later chunks are in flight).
+    on_chunk(records) -> truthy stops; without it the records of all chunks are returned as one MATCH_DTYPE array."""
+    a = _as_u8(base)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    got = []
+
+    def cb(ptr, n, _ctx):
+        recs = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n * 4,)).view(MATCH_DTYPE).copy() if n else \
+            np.zeros(0, dtype=MATCH_DTYPE)
+        if on_chunk is not None:
+            return 1 if on_chunk(recs) else 0
+        got.append(recs)
+        return 0
+
+    ccb = CHUNK_CB(cb)
+    lib = table._lib
+    lib.hsgpu_hwlm_exec_batch_cb.restype = C.c_int
+    lib.hsgpu_hwlm_exec_batch_cb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                             CHUNK_CB, C.c_void_p]
+    rv = lib.hsgpu_hwlm_exec_batch_cb(table._h, scratch._h, a.ctypes.data, off.ctypes.data, off.size - 1, start, chunk_bytes, ccb, None)
+    if rv not in (0, -3):
+        raise HsgpuError(rv, "hsgpu_hwlm_exec_batch_cb")
+    if on_chunk is not None:
+        return rv
+    return np.concatenate(got) if got else np.zeros(0, dtype=MATCH_DTYPE)
 
 
 def _thread_counters(threads):

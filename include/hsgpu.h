@@ -97,21 +97,9 @@ typedef struct hsgpu_hwlm_info {
     uint32_t flags;                           /* HSGPU_F_* of csrc/table.h (classes, filter layout) */
 } hsgpu_hwlm_info_t;
 
-/* hsgpu_hwlm_build flags: engine forcing for tests, like the reference's
- * fdrBuildProtoHinted hook (src/fdr/fdr_compile.cpp:900-911). 0 = automatic. */
-#define HSGPU_BUILD_FORCE_REPL 1u   /* bank-replicated ("Teddy class") filter */
-#define HSGPU_BUILD_FORCE_HASHED 2u /* hashed ("FDR class") filter */
-#define HSGPU_BUILD_FORCE_K2 4u     /* two filter bits per key */
-#define HSGPU_BUILD_FORCE_K1 8u     /* one filter bit per key */
-#define HSGPU_BUILD_FORCE_STRIDE1 16u /* look up every byte position (no stride-2 keys) */
-#define HSGPU_BUILD_FORCE_STRIDE2 64u /* stride 2 even with 2- and 3-byte literals */
-#define HSGPU_BUILD_FORCE_SMALL 128u /* 32 KiB hashed filter, run as three 8-wavefront workgroups per CU */
-#define HSGPU_BUILD_FORCE_MEDIUM 256u /* 64 KiB hashed filter: two 16-wavefront workgroups per CU where registers allow */
-#define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
-#define HSGPU_BUILD_NO_FOLD 512u    /* keep the separate 3-byte-key filter test even when only few such keys exist */
-#define HSGPU_BUILD_FORCE_PAIR 1024u /* the stride-2 pair filter (opt-in; an error for sets it cannot hold) */
-#define HSGPU_BUILD_NO_GATE 4096u    /* no key gate in front of the exact hash tables (the confirm kernel then probes a table for every candidate) */
-#define HSGPU_BUILD_NO_PAIR 2048u    /* never the pair filter (the default today) */
+/* hsgpu_hwlm_build's `flags`: 0 = the compiler chooses the layout. The engine-forcing values that tests and tuning
+ * runs pass (the role of the reference's fdrBuildProtoHinted hook, src/fdr/fdr_compile.cpp:900-911) live in
+ * hsgpu_tuning.h, with the scratch's launch-geometry override. */
 
 /* ---- build side ---------------------------------------------------------- */
 
@@ -182,6 +170,17 @@ int hsgpu_scratch_get_kernel_span(hsgpu_scratch_t *s, unsigned back, float *filt
  * filter kernel since the previous call, and how many scans since then overflowed a
  * candidate region (and were redone by the fused fallback kernel). */
 int hsgpu_scratch_get_stats(hsgpu_scratch_t *s, uint64_t *cand_entries, int *overflowed);
+
+/* The host-buffer scan as a pipeline: the batch is cut into chunks of whole blocks (chunk_bytes, 0 = 64 MiB); the
+ * copy of chunk i + 1 runs beside the scan of chunk i, and on_chunk receives the records of every finished chunk --
+ * delivery order, block indices of the whole batch, chunks in block order -- on the CALLING thread while later
+ * chunks are still being copied and scanned: whatever the caller does per chunk (confirm, callbacks) hides behind
+ * the bus. A non-zero return from on_chunk stops the scan (HSGPU_SCAN_TERMINATED). Nothing of the batch stays
+ * resident afterwards. No reference counterpart: the reference has no device boundary
+ * (doc/dev-reference/performance.rst:56-61). */
+typedef int (*hsgpu_chunk_cb)(const hsgpu_match_t *recs, size_t n, void *ctx);
+int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off,
+                             size_t nblocks, size_t start, size_t chunk_bytes, hsgpu_chunk_cb on_chunk, void *ctx);
 
 /* The delivery order (block, end, lit) for records on the host, e.g. after merging the records of
  * several scans; multi-threaded above 64 Ki records. Touches no device. */

@@ -1,0 +1,37 @@
+/* hsgpu_tuning.h -- engine forcing for tests and tuning runs. Not part of the drop-in boundary: a caller of
+ * include/hsgpu.h passes flags = 0 and never touches a scratch's geometry. */
+#ifndef HSGPU_TUNING_H
+#define HSGPU_TUNING_H
+
+#include "hsgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hsgpu_hwlm_build flags: engine forcing for tests, like the reference's
+ * fdrBuildProtoHinted hook (src/fdr/fdr_compile.cpp:900-911). 0 = automatic. */
+#define HSGPU_BUILD_FORCE_REPL 1u   /* bank-replicated ("Teddy class") filter */
+#define HSGPU_BUILD_FORCE_HASHED 2u /* hashed ("FDR class") filter */
+#define HSGPU_BUILD_FORCE_K2 4u     /* two filter bits per key */
+#define HSGPU_BUILD_FORCE_K1 8u     /* one filter bit per key */
+#define HSGPU_BUILD_FORCE_STRIDE1 16u /* look up every byte position (no stride-2 keys) */
+#define HSGPU_BUILD_FORCE_STRIDE2 64u /* stride 2 even with 2- and 3-byte literals */
+#define HSGPU_BUILD_FORCE_SMALL 128u /* 32 KiB hashed filter, run as three 8-wavefront workgroups per CU */
+#define HSGPU_BUILD_FORCE_MEDIUM 256u /* 64 KiB hashed filter: two 16-wavefront workgroups per CU where registers allow */
+#define HSGPU_BUILD_FORCE_BLIND 32u /* case-blind hash keys even without caseless literals */
+#define HSGPU_BUILD_NO_FOLD 512u    /* keep the separate 3-byte-key filter test even when only few such keys exist */
+#define HSGPU_BUILD_FORCE_PAIR 1024u /* the stride-2 pair filter (opt-in; an error for sets it cannot hold) */
+#define HSGPU_BUILD_NO_GATE 4096u    /* no key gate in front of the exact hash tables (the confirm kernel then probes a table for every candidate) */
+
+
+/* Launch geometry / pipeline of the scans on one scratch, for tests that must cover every pipeline and for tuning
+ * runs (the library reads no environment variables): fused_only != 0 runs the always-correct fused kernel alone
+ * (normally the overflow fallback); wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the
+ * workgroup size / workgroups per CU the runtime would choose (0 = its choice). */
+int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -59,3 +59,58 @@ def test_fetch_replay_sequential_rules_and_overflow():
         assert n_rec == n and n_del == want and 0 < want <= n
     with pytest.raises(hw.HsgpuError):
         hw.hwlm_fetch_replay_count(t, s, d_out.data_ptr(), 16, d_count.data_ptr(), 2, st)
+
+
+@pytest.mark.parametrize("chunk", [1 << 16, 1 << 20, 0])
+def test_chunked_host_pipeline_equals_the_one_shot_scan(chunk):
+    """hsgpu_hwlm_exec_batch_cb: the same records, in the same (delivery) order, whatever the chunk size; empty blocks,
+    a block larger than the chunk, records handed over chunk by chunk in block order."""
+    lits, _ = cp.snort_like_literals(600, seed=8)
+    corpus, off = cp.packet_corpus(6 << 20, lits, seed=23, match_every=1024)
+    off = np.sort(np.concatenate([off, off[10:14], off[-1:]]))  # empty blocks
+    off = np.concatenate([off[off < (3 << 20)], off[off >= (3 << 20) + (300 << 10)]])  # one block of >= 300 KiB
+    t = H.hwlm_build(lits)
+    s = H.Scratch(0)
+    want = hw.hwlm_exec_batch(t, s, corpus, off)
+    chunks = []
+    assert hw.hwlm_exec_batch_pipelined(t, s, corpus, off, 0, chunk, lambda r: chunks.append(r) and False) == 0
+    got = np.concatenate(chunks)
+    assert np.array_equal(got, want) and want.size > 1000
+    firsts = [int(c["block"][0]) for c in chunks if c.size]
+    assert firsts == sorted(firsts) and (chunk == 0 or len(chunks) > 3)
+    # stopping early
+    seen = []
+    assert hw.hwlm_exec_batch_pipelined(t, s, corpus, off, 0, 1 << 18, lambda r: seen.append(r) or True) == -3
+    assert len(seen) == 1
+    # the scratch is free again and scans on
+    assert np.array_equal(hw.hwlm_exec_batch(t, s, corpus, off), want)
+
+
+def test_hs_scan_batch_takes_the_pipeline_for_large_batches():
+    from hyperscan_amd import hs
+
+    rng = np.random.default_rng(9)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    lits = sorted({bytes(rng.choice(alpha, int(rng.integers(5, 9)))) for _ in range(50)})
+    pats = [l.decode() + r"[0-9]+" for l in lits]
+    db = hs.Database.compile(pats, [0] * len(pats), list(range(len(pats))))
+    scratch = hs.HsScratch(db)
+
+    class L:
+        def __init__(self, s):
+            self.s = s
+    import torch
+
+    corpus, off = cp.packet_corpus(100 << 20, [L(l + b"42") for l in lits], seed=24, match_every=8192)
+    keep = torch.from_numpy(corpus).pin_memory()  # the pipeline is taken for page-locked batches
+    corpus = keep.numpy()
+    events = []
+    assert hs.scan_batch(db, corpus, off, scratch, lambda b, i, f, t: events.append((b, i, t)) and False) == hs.HS_SUCCESS
+    # the same batch in two halves below the pipeline's threshold
+    k = int(np.searchsorted(off, 50 << 20))
+    ev2 = []
+    hs.scan_batch(db, corpus, off[: k + 1], scratch, lambda b, i, f, t: ev2.append((b, i, t)) and False)
+    hs.scan_batch(db, corpus, off[k:], scratch, lambda b, i, f, t: ev2.append((b + k, i, t)) and False)
+    assert events == ev2 and len(events) > 10000
+    blocks = [e[0] for e in events]
+    assert blocks == sorted(blocks)
