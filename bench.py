@@ -46,6 +46,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def build_shards(name, shard_bytes, shard_ids):
+    """the corpus is made of shards built with seeds 10 + shard; a rank's resident corpus is the
+    concatenation of its shards (weak scaling: one shard per rank; strong scaling: 8 / N of the same eight)"""
+    lits, parts, offs, base = None, [], [np.zeros(1, dtype=np.uint64)], 0
+    for sid in shard_ids:
+        lits, c, o = build_workload(name, shard_bytes, sid)
+        parts.append(c)
+        offs.append(o[1:] + np.uint64(base))
+        base += int(c.size)
+    return lits, (np.concatenate(parts) if len(parts) > 1 else parts[0]), np.concatenate(offs)
+
+
 def build_workload(name, total_bytes, seed_shift):
     from hyperscan_amd import corpus as cp
 
@@ -259,7 +271,16 @@ def run_workload(name, args, rank, world, dist, do_cpu):
 
     total = int(args.gib * (1 << 30))
     t0 = time.perf_counter()
-    lits, corpus, off = build_workload(name, total, seed_shift=rank)
+    if getattr(args, "shards_override", None) is not None:  # also.fdr10k_8g: all eight shards on one GPU
+        shard_ids = args.shards_override
+    elif args.scaling == "strong" and name == args.workload:
+        # the same n_shards x gib GiB whatever the rank count: rank r takes a contiguous run of the shards
+        assert args.shards % world == 0, "--shards must be a multiple of the rank count"
+        per = args.shards // world
+        shard_ids = list(range(rank * per, (rank + 1) * per))
+    else:
+        shard_ids = [rank]
+    lits, corpus, off = build_shards(name, total, shard_ids)
     log(f"[rank {rank}] {name}: generated {corpus.size} bytes / {off.size - 1} blocks in {time.perf_counter() - t0:.1f}s")
     job = GpuJob(lits, corpus, off, torch.cuda.current_device())
     info = job.table.info()
@@ -303,7 +324,16 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         allnb = allnb.view(world, 2).cpu()
         base = int(allnb[:rank, 0].sum())
         rows = min(job.cap, int(allnb[:, 1].max()) + 1024)  # every rank posts the same fixed size: the largest count (every step scans the same shard) + slack
-        exch = [hd.RecordExchange(dist, world, rank, job.dev, rows, base) for _ in jobs]
+        # padded all-gather moves world x max(count) rows per rank, the exact form sum(counts): with skewed shards (one
+        # flood-dense shard among quiet ones) the padding is most of the traffic -- choose by the skew of the warm-up counts
+        cnts = allnb[:, 1].tolist()
+        skew = max(cnts) / max(1.0, float(np.mean(cnts)))
+        exact = (args.exchange == "exact") or (args.exchange == "auto" and skew > 1.5)
+        if exact:
+            bases = np.concatenate([[0], np.cumsum(allnb[:, 0].numpy())])[:world].tolist()
+            exch = [hd.ExactExchange(dist, world, rank, job.dev, cnts, bases) for _ in jobs]
+        else:
+            exch = [hd.RecordExchange(dist, world, rank, job.dev, rows, base) for _ in jobs]
         run_steps(depth, exch)  # untimed: RCCL sets up its rings on first use
         allr, counts = exch[0].compact()
         assert counts[rank] == n_matches and allr.shape[0] == sum(counts)
@@ -386,7 +416,9 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     res["pipeline_depth"] = depth
     if dist is not None:
         g = [a.elapsed_time(b) for a, b in ev]
-        res["exchange"] = {"collective": "all_gather_into_tensor x2 (counts, records padded to a fixed size)",
+        res["exchange"] = {"collective": ("broadcast x world of exactly counts[r] rows (counts agreed before the timed steps)" if exact else
+                                          "all_gather_into_tensor x2 (counts, records padded to a fixed size)"),
+                           "count_skew_max_over_mean": round(skew, 3),
                            "rows_per_rank": exch[0].rows, "bytes_per_rank_per_step": exch[0].rows * 16 + 16,
                            "gather_ms_avg_rank0": round(float(np.mean(g)), 4), "gather_ms_max_rank0": round(float(np.max(g)), 4)}
     if do_cpu:
@@ -750,10 +782,17 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0, help="corpus GiB per GPU")
     ap.add_argument("--workload", default="fdr10k", choices=["teddy64", "fdr10k"])
     ap.add_argument("--no-also", action="store_true", help="skip the other workloads' lines")
-    ap.add_argument("--also", default="teddy64,class256,rose1000,flood", help="comma-separated extra workloads at N = 1")
+    ap.add_argument("--also", default="teddy64,class256,rose1000,flood,fdr10k_8g", help="comma-separated extra workloads at N = 1")
     ap.add_argument("--class-gib", type=float, default=4.0)
     ap.add_argument("--rose-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: one --gib shard per GPU (the default, what the driver runs); strong: the same --shards x --gib "
+                         "GiB at every GPU count, rank r scanning shards [r, r + 1) * shards / N (SURVEY 8(d) config 3: "
+                         "'also run at 1/2/4 GPUs on the same 8 GiB')")
+    ap.add_argument("--shards", type=int, default=8, help="shards of --gib GiB that make up the strong-scaling corpus")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "padded", "exact"],
+                    help="N > 1: padded all-gather, exact-size broadcasts, or by the skew of the per-rank match counts")
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=[0, 1, 2],
                     help="scans in flight: 2 overlaps a step's record all-gather with the next step's scan; "
                          "0 = 1 at N = 1 (the per-kernel figures are then those of the kernels alone), 2 at N > 1")
@@ -793,6 +832,16 @@ def main():
                     also[name] = run_rose1000(args)
                 elif name == "flood":
                     also[name] = run_flood(args)
+                elif name == "fdr10k_8g":  # config 3's whole 8 GiB on ONE GPU: the N = 1 point of the strong-scaling curve
+                    import copy
+
+                    a8 = copy.copy(args)
+                    a8.shards_override = list(range(args.shards))
+                    a8.steps, a8.warmup = max(3, min(args.steps, 10)), 2
+                    r8 = run_workload("fdr10k", a8, rank, world, None, False)
+                    also[name] = {"workload": f"fdr10k, {args.shards} shards x {args.gib:g} GiB resident on one GPU ({args.shards * args.gib:g} GiB per step)",
+                                  **{k: r8[k] for k in ("value", "ms_per_step", "matches_per_s", "matches_per_step")},
+                                  "unit": "GB/s", "roofline": r8["roofline"]}
                 elif name != args.workload:
                     also[name] = run_workload(name, args, rank, world, dist, do_cpu)
             except Exception as e:  # an extra line must not take the headline down with it
@@ -804,10 +853,11 @@ def main():
         out = {
             "metric": "GB/s scanned (hsbench block mode)", "value": main_res["value"], "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOAD_DESC[args.workload]}, {args.gib:g} GiB per GPU, block mode, {blocks_desc}",
                        "records": "16 B (block,end,id,lit), delivery order", "pipeline_depth": main_res["pipeline_depth"],
-                       "sharding": f"{world} x independent shards"
+                       "sharding": (f"{world} x independent shards" if args.scaling == "weak" else
+                                    f"strong: {args.shards} shards x {args.gib:g} GiB in all, {args.shards // world} per GPU")
                        + (", RCCL all-gather of records per step" if dist is not None else "")},
             "matches_per_s": main_res["matches_per_s"], "matches_per_step": main_res["matches_per_step"],
             "roofline": main_res["roofline"], "table": main_res["table"],

@@ -364,5 +364,57 @@ def forward_skip(fa, d_corpus, total, d_off, nblocks, start=0, stream=None):
                                          bitmap.data_ptr(), work.data_ptr(), st)
     if rv != 0:
         raise HsgpuError(rv, "hsgpu_hwlm_forward_skip_dev")
-    torch.cuda.current_stream().synchronize()  # `work` / `bitmap` must outlive the launch
+    _wait_for(stream)  # `work` / `bitmap` must outlive the launch, `out` must be complete
+    return out.to(torch.int64) & 0xFFFFFFFF
+
+
+def _wait_for(stream):
+    """wait for the stream the kernels were launched on: torch's current stream, or -- a raw stream handle torch
+    knows nothing about -- the whole device"""
+    import torch
+
+    if stream is None:
+        torch.cuda.current_stream().synchronize()
+    else:
+        torch.cuda.synchronize()
+
+
+class AccelAux(C.Structure):
+    """union AccelAux of the reference (src/nfa/accel.h:66-113), byte for byte: 80 bytes"""
+    _fields_ = [("accel_type", C.c_uint8), ("offset", C.c_uint8), ("c1", C.c_uint8), ("c2", C.c_uint8), ("m1", C.c_uint8),
+                ("m2", C.c_uint8), ("pad", C.c_uint8 * 10), ("mask", (C.c_uint8 * 16) * 4)]
+
+    @classmethod
+    def make(cls, accel_type, offset=0, c1=0, c2=0, m1=0, m2=0, masks=()):
+        a = cls()
+        a.accel_type, a.offset, a.c1, a.c2, a.m1, a.m2 = accel_type, offset, c1, c2, m1, m2
+        for k, m in enumerate(masks):
+            C.memmove(a.mask[k], bytes(m), 16)
+        return a
+
+
+ACCEL_DSHUFTI, ACCEL_RED_TAPE, ACCEL_DVERM_MASKED = 14, 16, 17
+
+
+def run_accel(aux, d_corpus, total, d_off, nblocks, start=0, stream=None):
+    """run_accel (src/nfa/accel.c:35-146) for every block of a device-resident batch through hsgpu_run_accel_dev:
+    -> int64 tensor [nblocks], run_accel(aux, buf + start, buf + len) - buf. `start`: an int or a device tensor."""
+    import torch
+
+    lib = _lib()
+    dev = d_corpus.device
+    out = torch.empty(nblocks, dtype=torch.int32, device=dev)
+    bitmap = torch.empty(max(1, (total + 15) // 16) * 2, dtype=torch.uint8, device=dev)
+    work = torch.zeros(PAIR_WORK_BYTES, dtype=torch.uint8, device=dev)
+    per_block = None if isinstance(start, int) else start.to(device=dev, dtype=torch.int32).contiguous()
+    st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    lib.hsgpu_run_accel_dev.restype = C.c_int
+    lib.hsgpu_run_accel_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rv = lib.hsgpu_run_accel_dev(C.byref(aux), d_corpus.data_ptr(), total, d_off.data_ptr(), nblocks,
+                                 per_block.data_ptr() if per_block is not None else None,
+                                 0 if per_block is not None else int(start), out.data_ptr(), bitmap.data_ptr(), work.data_ptr(), st)
+    if rv != 0:
+        raise HsgpuError(rv, _native.load_library().hsgpu_last_error().decode())
+    _wait_for(stream)
     return out.to(torch.int64) & 0xFFFFFFFF

@@ -860,7 +860,8 @@ extern "C" int hsgpu_hwlm_forward_skip_dev(const hsgpu_accel_t *aux, const void 
                                            const void *d_off, uint64_t nblocks, const void *d_start_in,
                                            uint32_t start, void *d_start_out, void *d_bitmap, void *d_work,
                                            void *stream) {
-    if (!aux || !d_off || nblocks == 0 || !d_start_out || !d_work) return HSGPU_INVALID;
+    if (!aux || !d_off || nblocks == 0 || !d_start_out) return HSGPU_INVALID;
+    if (aux->type != HSGPU_ACCEL_NONE && !d_work) return HSGPU_INVALID; /* (ACCEL_NONE uses neither the bitmap nor the work area) */
     hipStream_t st = (hipStream_t)stream;
     int is_pair = 0;
     const uint16_t *bm = (const uint16_t *)d_bitmap;
@@ -903,6 +904,111 @@ extern "C" int hsgpu_hwlm_forward_skip_dev(const hsgpu_accel_t *aux, const void 
     hipLaunchKernelGGL(forward_skip_kernel, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st,
                        (const uint8_t *)d_corpus, (const uint64_t *)d_off, nblocks, bm, (const uint4 *)d_work, is_pair,
                        (uint32_t)aux->offset, (const uint32_t *)d_start_in, start, (uint32_t *)d_start_out);
+    HIP_TRY(hipGetLastError());
+    return HSGPU_SUCCESS;
+}
+
+/* ---- run_accel for a block batch (src/nfa/accel.c:35-146) --------------------------------------
+ * out[b] = run_accel(aux, buf + start, buf + len) - buf for every block: the ten cases the reference dispatches,
+ * their "too short to bother" thresholds (c + 15 >= c_end for the one-byte schemes, c + 16 + 1 for double
+ * vermicelli, c + 15 + 1 for double shufti: the block keeps its start), the two-byte schemes searched over
+ * [c, c_end - 1) ("need to stop one early to get an accurate end state", accel.c:68,79,90,122), ACCEL_RED_TAPE = c_end,
+ * and the offset adjustment max(c + offset, rv) - offset (accel.c:138-141). */
+enum { RA_KEEP = 0, RA_SINGLE = 1, RA_PAIR = 2, RA_END = 3 };
+__global__ void run_accel_kernel(const uint8_t *corpus, const uint64_t *off, uint64_t nblocks, const uint16_t *bm,
+                                 const uint4 *lut, int kind, uint32_t min_tail, uint32_t offset, const uint32_t *start_in,
+                                 uint32_t start_all, uint32_t *out) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint64_t lo = off[b], hi = off[b + 1], len = hi - lo;
+    const uint64_t s = start_in ? start_in[b] : start_all;
+    if (kind == RA_KEEP || s > len) {
+        out[b] = (uint32_t)s;
+        return;
+    }
+    uint64_t rv;
+    if (kind == RA_END) {
+        rv = len;
+    } else {
+        if (s + min_tail >= len) { /* c + 15 (+ 1 (+ 1)) >= c_end */
+            out[b] = (uint32_t)s;
+            return;
+        }
+        if (kind == RA_SINGLE) {
+            const uint32_t f = first_bit(bm, lo + s, hi);
+            rv = f == 0xffffffffu ? len : s + f;
+        } else { /* pairs inside [s, len - 1): the second byte of a pair lies before len - 1 */
+            const uint64_t end = len - 1;
+            const uint32_t f = first_bit(bm, lo + s, lo + end - 1);
+            if (f != 0xffffffffu) {
+                rv = s + f;
+            } else { /* the last byte of the range alone passing the first-byte test: reported for re-examination */
+                const uint32_t *t1 = (const uint32_t *)&lut[2 * corpus[lo + end - 1]];
+                rv = (t1[0] & 0xffu) != 0xffu ? end - 1 : end;
+            }
+        }
+    }
+    rv = max(s + offset, rv) - offset;
+    out[b] = (uint32_t)rv;
+}
+
+extern "C" int hsgpu_run_accel_dev(const hsgpu_accel_aux_t *aux, const void *d_corpus, uint64_t total_bytes,
+                                   const void *d_off, uint64_t nblocks, const void *d_start_in, uint32_t start,
+                                   void *d_out, void *d_bitmap, void *d_work, void *stream) {
+    if (!aux || !d_off || nblocks == 0 || !d_out) return HSGPU_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int kind = RA_KEEP, rv = HSGPU_SUCCESS;
+    uint32_t min_tail = 15;
+    void *bitmaps[1] = {d_bitmap};
+    hsgpu_class_t cls;
+    hsgpu_pair_t pr;
+    switch (aux->accel_type) {
+    case HSGPU_ACCEL_NONE:
+        break;
+    case HSGPU_ACCEL_RED_TAPE:
+        kind = RA_END;
+        break;
+    case HSGPU_ACCEL_VERM:
+    case HSGPU_ACCEL_VERM_NOCASE:
+        kind = RA_SINGLE;
+        rv = hsgpu_class_from_verm(aux->c1, aux->accel_type == HSGPU_ACCEL_VERM_NOCASE, 0, &cls);
+        break;
+    case HSGPU_ACCEL_SHUFTI:
+        kind = RA_SINGLE;
+        rv = hsgpu_class_from_shufti(aux->mask[0], aux->mask[1], &cls);
+        break;
+    case HSGPU_ACCEL_TRUFFLE:
+        kind = RA_SINGLE;
+        rv = hsgpu_class_from_truffle(aux->mask[0], aux->mask[1], &cls);
+        break;
+    case HSGPU_ACCEL_DVERM:
+    case HSGPU_ACCEL_DVERM_NOCASE:
+        kind = RA_PAIR, min_tail = 17;
+        rv = hsgpu_pair_from_dverm(aux->c1, aux->c2, aux->accel_type == HSGPU_ACCEL_DVERM_NOCASE, &pr);
+        break;
+    case HSGPU_ACCEL_DVERM_MASKED:
+        kind = RA_PAIR, min_tail = 17;
+        rv = hsgpu_pair_from_dverm_masked(aux->c1, aux->c2, aux->m1, aux->m2, &pr);
+        break;
+    case HSGPU_ACCEL_DSHUFTI:
+        kind = RA_PAIR, min_tail = 16;
+        rv = hsgpu_pair_from_dshufti(aux->mask[0], aux->mask[1], aux->mask[2], aux->mask[3], &pr);
+        break;
+    default: /* the reverse and EOD types are not dispatched by run_accel either (accel.c:132-135: "not here") */
+        hsgpu_set_error("accel type %u is not one run_accel dispatches", aux->accel_type);
+        return HSGPU_INVALID;
+    }
+    if (rv != HSGPU_SUCCESS) return rv;
+    if (kind == RA_SINGLE || kind == RA_PAIR) {
+        if (!d_bitmap || !d_work || !d_corpus) return HSGPU_INVALID;
+        rv = kind == RA_SINGLE
+                 ? hsgpu_class_scan_dev(&cls, 1, d_corpus, total_bytes, nullptr, 0, bitmaps, nullptr, nullptr, d_work, stream)
+                 : hsgpu_pair_scan_dev(&pr, 1, d_corpus, total_bytes, nullptr, 0, bitmaps, nullptr, nullptr, d_work, stream);
+        if (rv != HSGPU_SUCCESS) return rv;
+    }
+    hipLaunchKernelGGL(run_accel_kernel, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, (const uint8_t *)d_corpus,
+                       (const uint64_t *)d_off, nblocks, (const uint16_t *)d_bitmap, (const uint4 *)d_work, kind, min_tail,
+                       (uint32_t)aux->offset, (const uint32_t *)d_start_in, start, (uint32_t *)d_out);
     HIP_TRY(hipGetLastError());
     return HSGPU_SUCCESS;
 }

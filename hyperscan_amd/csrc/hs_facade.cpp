@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <set>
 #include <string>
@@ -49,12 +50,28 @@ struct hs_database {
     std::vector<unsigned> src_flags, src_ids;
     std::vector<unsigned char> src_is_lit;
     std::vector<hs_expr_ext_t> src_ext; /* flags == 0: none */
-    std::set<unsigned> single_exprs;    /* expressions carrying HS_FLAG_SINGLEMATCH (built once): the reference's exhaustion keys */
+    std::set<unsigned> single_ids;      /* report ids carrying HS_FLAG_SINGLEMATCH: the reference's exhaustion keys ("all patterns
+                                         * with the same report id share an ekey", src/util/report_manager.cpp:254-257) */
     /* literal-less class sequences A{m,}B{n,}: evaluated on the GPU from the class bitmaps (csrc/class_seq.hip) */
     std::vector<ClassSeq> cseq;
     std::vector<hsgpu_class_t> cs_classes;   /* the distinct classes of cseq */
     std::vector<hsgpu_class_seq_t> cs_seqs;  /* id = index into cseq */
 };
+
+/* hs_deserialize_database_at: what the caller's memory holds. A database of this engine owns device memory (the
+ * literal table in HBM) and host containers, so it cannot live inside a caller's buffer as the reference's flat
+ * bytecode does (src/database.c:170-230); the buffer receives this header, which every entry point follows to the
+ * database proper. */
+struct hs_database_at {
+    unsigned magic; /* "HSGF" */
+    unsigned pad;
+    hs_database *real;
+};
+static const unsigned kDbMagic = 0x48534744, kDbAtMagic = 0x48534746;
+static inline const hs_database *resolve_db(const hs_database_t *db) {
+    if (db && ((const hs_database_at *)db)->magic == kDbAtMagic) return ((const hs_database_at *)db)->real;
+    return db;
+}
 
 struct hs_scratch {
     unsigned magic = 0x48534753; /* "HSGS" */
@@ -236,6 +253,35 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                 return HS_COMPILER_ERROR;
             }
         }
+        /* registerExtReport (src/util/report_manager.cpp:212-234): expressions sharing a match id must agree on
+         * HS_FLAG_SINGLEMATCH (they share one exhaustion key) */
+        {
+            std::map<unsigned, std::pair<bool, unsigned>> seen; /* id -> (single, first expression index) */
+            auto check = [&](unsigned id, bool single, unsigned expr) -> bool {
+                auto it = seen.find(id);
+                if (it == seen.end()) {
+                    seen.emplace(id, std::make_pair(single, expr));
+                    return true;
+                }
+                if (it->second.first == single || it->second.second == expr) return true;
+                char msg[256];
+                snprintf(msg, sizeof(msg),
+                         "Expression (index %u) with match ID %u %s HS_FLAG_SINGLEMATCH whereas previous expression (index %u) with the "
+                         "same match ID did%s.",
+                         expr, id, single ? "specified" : "did not specify", it->second.second, single ? " not" : "");
+                *error = make_error(msg, (int)expr);
+                return false;
+            };
+            std::vector<std::pair<unsigned, std::pair<unsigned, bool>>> all; /* (expr, (id, single)) in expression order */
+            for (const Pattern &p : d->pats) all.push_back({p.expr, {p.id, p.single}});
+            for (const ClassSeq &c : d->cseq) all.push_back({c.expr, {c.id, c.single}});
+            std::sort(all.begin(), all.end());
+            for (const auto &e : all)
+                if (!check(e.second.first, e.second.second, e.first)) {
+                    destroy_db(d);
+                    return HS_COMPILER_ERROR;
+                }
+        }
         /* one HWLM literal per pattern: the last <= 8 bytes of the literal prefix */
         std::vector<hsgpu_lit_t> lits(d->pats.size());
         hw_s.resize(d->pats.size());
@@ -312,9 +358,9 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         d->src_ext.push_back(ext && ext[i] ? *ext[i] : none);
     }
     for (const Pattern &p : d->pats) /* (an expression may have several branches: walk the branches) */
-        if (p.single) d->single_exprs.insert(p.expr);
+        if (p.single) d->single_ids.insert(p.id);
     for (const ClassSeq &c : d->cseq)
-        if (c.single) d->single_exprs.insert(c.expr);
+        if (c.single) d->single_ids.insert(c.id);
     *db = d;
     *error = nullptr;
     return HS_SUCCESS;
@@ -345,7 +391,7 @@ bool lit_matches_at(const Pattern &p, const unsigned char *buf, size_t end /* of
  * (SINGLEMATCH) or a start of match (SOM_LEFTMOST) make an expression's Report distinct, so those
  * carry their expression index; plain expressions sharing an id share one Report (kNoGrp) and are
  * reported once per offset (ReportManager::getInternalId, src/util/report_manager.cpp) */
-static const unsigned kNoGrp = 0xffffffffu;
+static const unsigned kNoGrp = 0xffffffffu, kSingleGrp = 0xfffffffeu; /* SINGLEMATCH reports: one per id (their ekey) */
 struct Event {
     unsigned long long to, from;
     unsigned id, grp;
@@ -372,7 +418,7 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
         if (cs[k].id >= db->cseq.size()) continue;
         const ClassSeq &c = db->cseq[cs[k].id];
         if (c.quiet || (size_t)cs[k].end + 1 > len) continue;
-        out.push_back(Event{(unsigned long long)cs[k].end + 1, 0, c.id, c.single ? c.expr : kNoGrp});
+        out.push_back(Event{(unsigned long long)cs[k].end + 1, 0, c.id, c.single ? kSingleGrp : kNoGrp});
     }
     const size_t n_pats = db->pats.size();
     by_pat.clear();
@@ -390,7 +436,7 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
         while (g_end < by_pat.size() && by_pat[g_end].first == by_pat[g].first) g_end++;
         const Pattern &p = db->pats[by_pat[g].first];
         const bool from_matters = p.som || (p.ext_flags & HS_EXT_FLAG_MIN_LENGTH);
-        const unsigned grp = p.single || p.som ? p.expr : kNoGrp;
+        const unsigned grp = p.single ? kSingleGrp : p.som ? p.expr : kNoGrp;
         const bool shared = !from_matters && g_end - g > 1 && (p.general ? !p.g.has_cond : !p.tail.empty());
         /* hs_expr_ext_t bounds: the job of the reference's CHECK_BOUNDS / CHECK_MIN_LENGTH
          * program instructions (src/rose/program_runtime.c) */
@@ -447,11 +493,11 @@ void collect_block_events(const hs_database *db, const unsigned char *buf, size_
     }
     std::sort(out.begin() + base, out.end());
     out.erase(std::unique(out.begin() + base, out.end()), out.end()); /* one report per (id, to) */
-    if (!db->single_exprs.empty()) {
-        std::set<unsigned> exhausted; /* SINGLEMATCH expressions already reported in this block */
+    if (!db->single_ids.empty()) {
+        std::set<unsigned> exhausted; /* SINGLEMATCH ids already reported in this block (the reference's exhaustion vector) */
         size_t w = base;
         for (size_t r = base; r < out.size(); r++) {
-            if (out[r].grp != kNoGrp && db->single_exprs.count(out[r].grp) && !exhausted.insert(out[r].grp).second) continue;
+            if (out[r].grp == kSingleGrp && !exhausted.insert(out[r].id).second) continue;
             out[w++] = out[r];
         }
         out.resize(w);
@@ -585,12 +631,20 @@ hs_error_t hs_free_compile_error(hs_compile_error_t *error) {
 
 hs_error_t hs_free_database(hs_database_t *db) {
     if (!db) return HS_SUCCESS;
+    if (((hs_database_at *)db)->magic == kDbAtMagic) { /* placed by hs_deserialize_database_at: the memory is the caller's */
+        hs_database_at *h = (hs_database_at *)db;
+        if (h->real) destroy_db(h->real);
+        h->real = nullptr;
+        h->magic = 0;
+        return HS_SUCCESS;
+    }
     if (db->magic != 0x48534744) return HS_INVALID;
     destroy_db(db);
     return HS_SUCCESS;
 }
 
 hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || !size || db->magic != 0x48534744) return HS_INVALID;
     size_t s = sizeof(*db) + hsgpu_hwlm_size(db->hwlm);
     for (const Pattern &p : db->pats) s += sizeof(p) + p.lit.size() + p.tail.size() * sizeof(Unit) + p.reach.size() * 8 + p.g.bytes() + p.pre.bytes();
@@ -600,6 +654,7 @@ hs_error_t hs_database_size(const hs_database_t *db, size_t *size) {
 }
 
 hs_error_t hs_database_info(const hs_database_t *db, char **info) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || !info || db->magic != 0x48534744) return HS_INVALID;
     char buf[160];
     snprintf(buf, sizeof(buf), "Version: %s Features: gfx950 Mode: %s", hs_version(),
@@ -616,6 +671,7 @@ hs_error_t hs_database_info(const hs_database_t *db, char **info) {
 /* src/hs_runtime.h:294 / src/runtime.c hs_stream_size: a database that was not compiled for
  * streaming answers HS_DB_MODE_ERROR (unit/hyperscan/single.cpp:72-83), and none here is. */
 hs_error_t hs_stream_size(const hs_database_t *db, size_t *stream_size) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || !stream_size || db->magic != 0x48534744) return HS_INVALID;
     return HS_DB_MODE_ERROR;
 }
@@ -651,6 +707,7 @@ static unsigned crc32_of(const unsigned char *p, size_t n) {
 }
 
 hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || !bytes || !length || db->magic != 0x48534744) return HS_INVALID;
     std::string out;
     auto put32 = [&](unsigned v) { out.append((const char *)&v, 4); };
@@ -766,6 +823,24 @@ hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_da
     hs_error_t rv = build_database(sr.ex, sr.is_lit, sr.flags.data(), sr.ids.data(), ext.data(), sr.mode, db, &err, &sr.table);
     hs_free_compile_error(err);
     return rv == HS_SUCCESS ? HS_SUCCESS : HS_INVALID;
+}
+
+/* hs_deserialize_database_at (src/hs_common.h:147-169, src/database.c:170-230): the reference rebuilds its flat
+ * bytecode inside memory the caller provides (>= hs_serialized_database_size bytes, 8-byte aligned). A database of
+ * this engine owns device memory and host containers, which no caller's buffer can hold: the buffer receives a
+ * 16-byte header that every entry point follows to the database proper. One difference follows and is documented
+ * in include/hs_gpu.h: the caller still frees its buffer itself, but calls hs_free_database(db) first to release
+ * what the database owns outside it (the reference's caller just frees the buffer). */
+hs_error_t hs_deserialize_database_at(const char *bytes, const size_t length, hs_database_t *db) {
+    if (!bytes || !db) return HS_INVALID;
+    if ((uintptr_t)db & 7) return HS_BAD_ALIGN; /* database.c:187-189 */
+    hs_database_t *real = nullptr;
+    if (hs_error_t rv = hs_deserialize_database(bytes, length, &real)) return rv;
+    hs_database_at *h = (hs_database_at *)db;
+    h->magic = kDbAtMagic;
+    h->pad = 0;
+    h->real = real;
+    return HS_SUCCESS;
 }
 
 /* src/hs_common.h:196-271: how much a deserialised database will occupy / what it is,
@@ -897,6 +972,7 @@ hs_error_t hs_expression_info(const char *expression, unsigned int flags, hs_exp
 }
 
 hs_error_t hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || !scratch || db->magic != 0x48534744) return HS_INVALID;
     if (*scratch) return (*scratch)->magic == 0x48534753 ? ((*scratch)->in_use ? HS_SCRATCH_IN_USE : HS_SUCCESS) : HS_INVALID;
     void *mem = hook_alloc(g_scratch, sizeof(hs_scratch));
@@ -1042,6 +1118,7 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
 hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
                          unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
                          hs_batch_event_handler onEvent, void *context) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     (void)flags;
     if (!scratch || !data || !off) return HS_INVALID;
     if (!db || db->magic != 0x48534744) return HS_INVALID;
@@ -1133,6 +1210,7 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
 /* the literal the GPU matcher holds for one branch (hs_gpu.h) */
 hs_error_t hs_database_literal(const hs_database_t *db, unsigned int index, const char **bytes, size_t *len,
                                int *nocase, unsigned int *id) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || db->magic != 0x48534744 || index >= db->pats.size()) return HS_INVALID;
     const Pattern &p = db->pats[index];
     const size_t n = std::min<size_t>(p.lit.size(), 8);
@@ -1150,6 +1228,7 @@ hs_error_t hs_database_literal(const hs_database_t *db, unsigned int index, cons
 hs_error_t hs_confirm_batch(const hs_database_t *db, const char *data, const unsigned long long *off,
                             unsigned long long nblocks, const void *records, unsigned long long n_records,
                             hs_batch_event_handler onEvent, void *context) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || db->magic != 0x48534744 || !data || !off || (n_records && !records)) return HS_INVALID;
     const hsgpu_match_t *recs = (const hsgpu_match_t *)records;
     for (unsigned long long i = 0; i < n_records; i++) {
@@ -1165,6 +1244,7 @@ hs_error_t hs_confirm_batch(const hs_database_t *db, const char *data, const uns
 
 hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsigned int flags,
                    hs_scratch_t *scratch, match_event_handler onEvent, void *context) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!scratch || !data) return HS_INVALID; /* src/runtime.c:320-322 */
     if (!db || db->magic != 0x48534744) return HS_INVALID;
     if (db->mode != HS_MODE_BLOCK) return HS_DB_MODE_ERROR; /* src/runtime.c:334-336 */
@@ -1187,6 +1267,7 @@ hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int lengt
 hs_error_t hs_scan_vector(const hs_database_t *db, const char *const *data, const unsigned int *length,
                           unsigned int count, unsigned int flags, hs_scratch_t *scratch, match_event_handler onEvent,
                           void *context) {
+    db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     (void)flags;
     if (!scratch || !data || !length) return HS_INVALID; /* src/runtime.c:1113-1115 */
     if (!db || db->magic != 0x48534744) return HS_INVALID;

@@ -20,9 +20,11 @@
  *   hs_serialized_database_size / _info      src/hs_common.h:196-271
  *   hs_set_allocator / hs_set_{database,misc,scratch,stream}_allocator  src/hs_common.h:273-439
  *   hs_scan_vector (HS_MODE_VECTORED)        src/hs_runtime.h:480-527, src/runtime.c:1106-1174
+ *   hs_deserialize_database_at               src/hs_common.h:147-169 (a header in the caller's memory: see there)
  * Not provided: streaming scans (the hs_open_stream family: the literal path this engine
- * replaces is block-shaped) and the in-place hs_deserialize_database_at:
- * the database object owns heap containers, so it cannot live in caller memory.
+ * replaces is block-shaped).
+ * Literal-less class sequences A{m,}B{n,} ([a-z]{3,}\d+ style) are accepted too: they are evaluated on the GPU
+ * from class bitmaps (csrc/class_seq.hip), the job the reference gives to an accelerated NFA / DFA.
  *
  * What is behind it: an expression is one or more top-level branches `b1|b2|...`, and every
  * branch must contain a mandatory literal (>= 1 byte) at its top level: R1 LIT R2, where R1 and
@@ -185,6 +187,11 @@ hs_error_t hs_stream_size(const hs_database_t *database, size_t *stream_size);
 hs_error_t hs_serialize_database(const hs_database_t *db, char **bytes, size_t *length);
 hs_error_t hs_deserialize_database(const char *bytes, const size_t length, hs_database_t **db);
 hs_error_t hs_serialized_database_size(const char *bytes, const size_t length, size_t *deserialized_size);
+/* src/hs_common.h:147-169. `db`: 8-byte aligned memory of at least hs_serialized_database_size bytes, owned and
+ * freed by the caller. A database of this engine owns device memory (its literal table in HBM), which no caller's
+ * buffer can hold: the buffer receives a header that every hs_* entry point follows. Before freeing the buffer the
+ * caller releases what lies outside it with hs_free_database(db), which leaves the buffer itself alone. */
+hs_error_t hs_deserialize_database_at(const char *bytes, const size_t length, hs_database_t *db);
 hs_error_t hs_serialized_database_info(const char *bytes, size_t length, char **info);
 
 /* Allocation hooks (src/hs_common.h:273-439): the objects handed to the caller -- databases,

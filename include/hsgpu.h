@@ -358,6 +358,31 @@ int hsgpu_hwlm_forward_skip_dev(const hsgpu_accel_t *aux, const void *d_corpus, 
                                 const void *d_off, uint64_t nblocks, const void *d_start_in, uint32_t start,
                                 void *d_start_out, void *d_bitmap, void *d_work, void *stream);
 
+/* ---- run_accel for a block batch ----------------------------------------------------------
+ * hsgpu_accel_aux_t has the layout of the reference's union AccelAux (src/nfa/accel.h:66-113: type, offset, the
+ * vermicelli bytes and masks at bytes 2..5, the 16-byte masks at 16, 32, 48, 64; 80 bytes), so an AccelAux taken
+ * from a compiled NFA / DFA can be handed over as it is. out[b] (uint32) = run_accel(aux, buf + start, buf + len) - buf
+ * for every block (src/nfa/accel.c:35-146): all ten cases it dispatches -- NONE, VERM, VERM_NOCASE, DVERM,
+ * DVERM_NOCASE, DVERM_MASKED, SHUFTI, DSHUFTI, TRUFFLE, RED_TAPE -- with their minimum-length rules, the two-byte
+ * schemes stopping one byte early, and the offset adjustment max(c + offset, rv) - offset. d_start_in: uint32
+ * [nblocks] or NULL for `start` everywhere; d_bitmap: (total_bytes + 15) / 16 * 2 bytes of device scratch and
+ * d_work: HSGPU_PAIR_WORK_BYTES, 16-byte aligned (neither is used by NONE / RED_TAPE). For double shufti the
+ * result is the exact first pair (see "two-byte accelerators" above: the reference may stop earlier at a
+ * first-byte-only hit in the last lane of one of its vectors; callers tolerate either). */
+#define HSGPU_ACCEL_DSHUFTI 14
+#define HSGPU_ACCEL_RED_TAPE 16
+#define HSGPU_ACCEL_DVERM_MASKED 17
+typedef struct hsgpu_accel_aux {
+    uint8_t accel_type, offset;
+    uint8_t c1, c2; /* verm.c = c1; dverm.c1 / c2 */
+    uint8_t m1, m2; /* dverm masked variant */
+    uint8_t pad[10];
+    uint8_t mask[4][16]; /* shufti lo, hi | dshufti lo1, hi1, lo2, hi2 | truffle mask1, mask2 */
+} hsgpu_accel_aux_t;
+int hsgpu_run_accel_dev(const hsgpu_accel_aux_t *aux, const void *d_corpus, uint64_t total_bytes, const void *d_off,
+                        uint64_t nblocks, const void *d_start_in, uint32_t start, void *d_out, void *d_bitmap,
+                        void *d_work, void *stream);
+
 const char *hsgpu_last_error(void);
 const char *hsgpu_version(void);
 

@@ -3,7 +3,9 @@ scan this rank's shard on the device with hsgpu_hwlm_scan_dev, exchange the reco
 hyperscan_amd.dist.RecordExchange over the given backend (nccl = RCCL), and check on rank 0 that the
 rows of all ranks, global block indices included, equal the oracle's scan of the whole corpus.
 
-    python tests/exchange_worker.py <backend> <rank> <world> <port>
+    python tests/exchange_worker.py <backend> <rank> <world> <port> [exact]
+
+With `exact` the step goes through hyperscan_amd.dist.ExactExchange (counts agreed once, unpadded broadcasts).
 """
 import os
 import sys
@@ -39,8 +41,18 @@ def main():
     rows = 1 << 16
     d_out = torch.zeros((rows, 4), dtype=torch.int32, device=dev)
     d_count = torch.zeros(1, dtype=torch.int64, device=dev)
-    ex = hd.RecordExchange(dist, world, rank, dev, rows, base)
+    exact = len(sys.argv) > 5 and sys.argv[5] == "exact"
     stream = torch.cuda.current_stream().cuda_stream
+    if exact:  # the counts and bases of all ranks, once, from a warm-up scan
+        hw.hwlm_scan_dev(t, s, d_corpus.data_ptr(), int(my_off[-1]), d_off.data_ptr(), my_off.size - 1,
+                         d_out.data_ptr(), rows, d_count.data_ptr(), stream=stream)
+        mine = torch.tensor([int(d_count.item()), base], dtype=torch.int64, device=dev)
+        allc = torch.empty(world * 2, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, mine)
+        allc = allc.view(world, 2).cpu()
+        ex = hd.ExactExchange(dist, world, rank, dev, allc[:, 0].tolist(), allc[:, 1].tolist())
+    else:
+        ex = hd.RecordExchange(dist, world, rank, dev, rows, base)
     for _ in range(3):  # the same buffers step after step, nothing allocated, no host sync inside
         hw.hwlm_scan_dev(t, s, d_corpus.data_ptr(), int(my_off[-1]), d_off.data_ptr(), my_off.size - 1,
                          d_out.data_ptr(), rows, d_count.data_ptr(), stream=stream)

@@ -112,6 +112,12 @@ def _skew_worker(rank, world, port):
     exact, counts2 = hd.all_gather_records_exact(t, n, base, dist, world, rank)
     assert counts == counts2 == [5, 40_000, 0]
     assert torch.equal(padded, want) and torch.equal(exact, want)
+    # the step-wise exact form (counts agreed once, as bench.py does after its warm-up): several steps, same result
+    ex = hd.ExactExchange(dist, world, rank, torch.device("cpu"), [5, 40_000, 0], [0, 100, 1000])
+    for _ in range(3):
+        ex.step(t, None)
+    stepwise, counts3 = ex.compact()
+    assert counts3 == [5, 40_000, 0] and torch.equal(stepwise, want)
     rooted, _ = hd.gather_records_to_root(t, n, base, dist, world, rank, root=2)  # the empty rank collects
     assert (rooted is None) if rank != 2 else torch.equal(rooted, want)
     # nobody has anything

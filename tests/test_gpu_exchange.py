@@ -29,6 +29,17 @@ def test_record_exchange_over_rccl_world_size_1():
     assert "EXCHANGE_OK nccl 1" in r.stdout
 
 
+@pytest.mark.timeout(400)
+def test_exact_exchange_over_rccl_world_size_1():
+    """the unpadded step (hyperscan_amd.dist.ExactExchange: broadcasts of exactly counts[r] rows) over RCCL"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "exchange_worker.py"), "nccl", "0", "1", str(_free_port()), "exact"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=360)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "EXCHANGE_OK nccl 1" in r.stdout
+
+
 @pytest.mark.timeout(500)
 def test_bench_multi_gpu_path_at_world_size_1():
     """bench.py's N > 1 code path end to end (process group, fixed-size exchange inside the timed steps, two
@@ -50,3 +61,30 @@ def test_bench_multi_gpu_path_at_world_size_1():
     assert line["config"]["pipeline_depth"] == 2 and "RCCL" in line["config"]["sharding"]
     ex = line["exchange"]
     assert ex["rows_per_rank"] >= line["matches_per_step"] and ex["gather_ms_avg_rank0"] > 0
+
+
+@pytest.mark.timeout(500)
+def test_bench_strong_scaling_mode_and_exact_exchange_at_world_size_1():
+    """bench.py --scaling strong (the rank scans its run of the fixed set of shards) with the exact-size exchange, over
+    RCCL at world size 1; and the strong corpus is the concatenation of the weak shards: twice the shard's matches."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HSGPU_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--gib", "0.03125", "--steps", "4", "--warmup", "2",
+                        "--no-cpu", "--no-also", "--scaling", "strong", "--shards", "2", "--exchange", "exact"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=450)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and "2 shards" in line["config"]["sharding"]
+    assert "exactly counts[r] rows" in line["exchange"]["collective"]
+    from bench import build_shards, build_workload
+
+    _l, c0, o0 = build_workload("fdr10k", 1 << 25, 0)
+    _l, c1, o1 = build_workload("fdr10k", 1 << 25, 1)
+    _l, c, o = build_shards("fdr10k", 1 << 25, [0, 1])
+    import numpy as np
+
+    assert np.array_equal(c, np.concatenate([c0, c1])) and o.size == o0.size + o1.size - 1 and int(o[-1]) == 1 << 26
+    assert np.array_equal(o[o0.size - 1:], o1 + np.uint64(1 << 25))

@@ -208,3 +208,29 @@ def test_simplegrep_example(tmp_path):
     offs = [int(l.rsplit(" ", 1)[1]) for l in out.stdout.splitlines() if l.startswith("Match for pattern")]
     want = sorted(set((pos + lit.size).tolist()) | {m.end() for m in re.finditer(b"hyperscan", data.tobytes())})
     assert offs == want
+
+
+def test_deserialize_database_at_places_a_header_the_api_follows():
+    """hs_deserialize_database_at (src/hs_common.h:147-169, unit/hyperscan/serialize.cpp): caller memory of
+    hs_serialized_database_size bytes, 8-byte aligned; a misaligned pointer is HS_BAD_ALIGN; the database scans, sizes,
+    serialises again and is released with hs_free_database without the buffer being freed."""
+    import ctypes as C
+
+    lits = [b"needle", b"hay"]
+    db = hs.Database.compile_lit(lits, [0, hs.HS_FLAG_CASELESS], [7, 8])
+    blob = db.serialize()
+    lib = hs._lib()
+    size = C.c_size_t(0)
+    assert lib.hs_serialized_database_size(blob, len(blob), C.byref(size)) == 0 and size.value >= 16
+    mem = (C.c_uint64 * ((size.value + 15) // 8))()
+    lib.hs_deserialize_database_at.restype = C.c_int
+    lib.hs_deserialize_database_at.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    assert lib.hs_deserialize_database_at(blob, len(blob), C.addressof(mem) + 4) == -8  # HS_BAD_ALIGN
+    assert lib.hs_deserialize_database_at(blob, len(blob), C.addressof(mem)) == 0
+    placed = hs.Database(C.c_void_p(C.addressof(mem)))
+    scratch = hs.HsScratch(placed)
+    got = collect(placed, b"a needle in the HAY, hay", scratch)
+    assert got == collect(db, b"a needle in the HAY, hay", hs.HsScratch(db)) and len(got) == 3
+    assert placed.serialize() == blob and placed.size() == db.size()
+    placed.close()  # hs_free_database: releases the database proper, leaves the caller's buffer alone
+    assert mem[0] & 0xffffffff == 0

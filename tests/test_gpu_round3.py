@@ -114,3 +114,71 @@ def test_hs_scan_batch_takes_the_pipeline_for_large_batches():
     assert events == ev2 and len(events) > 10000
     blocks = [e[0] for e in events]
     assert blocks == sorted(blocks)
+
+
+def test_run_accel_all_ten_cases_against_the_reference():
+    """hsgpu_run_accel_dev against the reference's own run_accel (src/nfa/accel.c:35-146, exported from oracle/_ref
+    by oracle/ref_build/run_accel_shim.c) on the same raw AccelAux bytes: every dispatched type, offsets, block
+    lengths around the minimum-length thresholds (15 / 16 / 17 bytes after the start), per-block starts."""
+    import torch
+
+    from hyperscan_amd import accel
+
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    R = ob.href(ob.ref_variants()[0])
+    R.hsref_run_accel.restype = C.c_size_t
+    R.hsref_run_accel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    rng = np.random.default_rng(17)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGH0123456789 \n", np.uint8)
+    lens = np.concatenate([np.arange(0, 40), rng.integers(40, 400, 400)])
+    rng.shuffle(lens)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    corpus = rng.choice(alpha, int(off[-1])).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    d_corpus = torch.from_numpy(np.concatenate([corpus, np.zeros(16, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    nb = len(lens)
+    starts = np.minimum(rng.integers(0, 12, nb), lens).astype(np.int32)
+    d_starts = torch.from_numpy(starts).to(dev)
+    shufti_cls = accel.CharClass(b"aeiou0")
+    lo, hi, _nb = shufti_cls.to_shufti()
+    t1, t2 = accel.CharClass(bytes(range(0x30, 0x3a)) + b"\n xyzXYZ").to_truffle()
+    pair = accel.PairSet.build([(b"a", b"b"), (b"q", b"u"), (b"0", b"1")], accel.CharClass(b"Z"))
+    cases = [("none", accel.AccelAux.make(accel.ACCEL_NONE)),
+             ("red_tape", accel.AccelAux.make(accel.ACCEL_RED_TAPE, 3)),
+             ("verm", accel.AccelAux.make(accel.ACCEL_VERM, 2, ord("q"))),
+             ("verm_nc", accel.AccelAux.make(accel.ACCEL_VERM_NOCASE, 0, ord("E"))),
+             ("dverm", accel.AccelAux.make(accel.ACCEL_DVERM, 1, ord("a"), ord("b"))),
+             ("dverm_nc", accel.AccelAux.make(accel.ACCEL_DVERM_NOCASE, 4, ord("A"), ord("B"))),
+             ("dverm_masked", accel.AccelAux.make(accel.ACCEL_DVERM_MASKED, 0, ord("a") & 0xdf, ord("0") & 0xf0, 0xdf, 0xf0)),
+             ("shufti", accel.AccelAux.make(accel.ACCEL_SHUFTI, 5, masks=(lo, hi))),
+             ("truffle", accel.AccelAux.make(accel.ACCEL_TRUFFLE, 1, masks=(t1, t2))),
+             ("dshufti", accel.AccelAux.make(accel.ACCEL_DSHUFTI, 2, masks=pair.masks))]
+    for name, aux in cases:
+        for st_arg, st_np in ((0, np.zeros(nb, np.int32)), (d_starts, starts)):
+            got = accel.run_accel(aux, d_corpus, int(corpus.size), d_off, nb, st_arg).cpu().numpy()
+            raw = bytes(aux)
+            want = np.array([R.hsref_run_accel(raw, corpus[int(off[b]):].ctypes.data if lens[b] else corpus.ctypes.data,
+                                               int(lens[b]), int(st_np[b])) for b in range(nb)], dtype=np.int64)
+            if name == "dshufti":
+                # the reference may stop earlier at a first-byte-only hit in the last lane of one of its vectors
+                # (include/hsgpu.h, "two-byte accelerators"); never later, and equal where it saw a real pair
+                assert np.all(got >= want), name
+                lo1, hi1, _lo2, _hi2 = pair.masks
+                exact = []
+                for b in range(nb):
+                    L, s0 = int(lens[b]), int(st_np[b])
+                    blk = corpus[int(off[b]):int(off[b]) + L]
+                    if s0 + 16 >= L:
+                        exact.append(s0)
+                        continue
+                    end = L - 1
+                    rv = next((i for i in range(s0, end - 1) if pair.test(int(blk[i]), int(blk[i + 1]))), None)
+                    if rv is None:
+                        c = int(blk[end - 1])
+                        rv = end - 1 if (lo1[c & 15] | hi1[c >> 4]) != 0xff else end
+                    exact.append(max(s0 + aux.offset, rv) - aux.offset)
+                assert np.array_equal(got, np.array(exact)), name
+            else:
+                assert np.array_equal(got, want), (name, np.nonzero(got != want)[0][:5], got[got != want][:5], want[got != want][:5])

@@ -7,6 +7,7 @@ import ctypes as C
 import re
 
 import numpy as np
+import pytest
 
 import hyperscan_amd as H
 from hyperscan_amd import hs
@@ -699,17 +700,30 @@ def test_many_hits_of_one_pattern_share_one_pass():
     assert rv == hs.HS_SUCCESS and sorted(ev) == sorted(brute(parts, corpus, off)) and len(ev) > 300
 
 
-def test_expressions_sharing_an_id_keep_their_own_exhaustion_and_som():
-    """exhaustion (SINGLEMATCH) and start of match belong to the expression, not to the report id: a
-    plain expression that shares its id with a SINGLEMATCH one keeps reporting, and a SOM and a
-    non-SOM report at the same offset are both delivered"""
-    db = hs.Database.compile_ext(["key", "lock"], [hs.HS_FLAG_SINGLEMATCH, 0], [5, 5], [None, None])
+def test_expressions_sharing_an_id_share_its_exhaustion_key_and_keep_their_som():
+    """SINGLEMATCH exhaustion belongs to the report id ("all patterns with the same report id share an ekey",
+    src/util/report_manager.cpp:254-257): two SINGLEMATCH expressions with one id deliver it once; a SINGLEMATCH
+    and a plain expression sharing an id are refused at compile time with the reference's message
+    (registerExtReport, :212-234); a SOM and a non-SOM report at the same offset are both delivered"""
+    db = hs.Database.compile_ext(["key", "lock"], [hs.HS_FLAG_SINGLEMATCH, hs.HS_FLAG_SINGLEMATCH], [5, 5], [None, None])
     corpus = np.frombuffer(b"key lock key lock lock", dtype=np.uint8).copy()
     off = np.array([0, corpus.size], dtype=np.uint64)
     parts = [(b"key", "", 0, 5, {}), (b"lock", "", 0, 5, {})]
     rv, ev = confirm(db, corpus, off, literal_hits(parts, corpus, off))
     assert rv == hs.HS_SUCCESS
-    assert [e[3] for e in ev] == [3, 8, 17, 22]  # `key` once, every `lock`
+    assert [(e[1], e[3]) for e in ev] == [(5, 3)]  # id 5 once, at its first match
+    db = hs.Database.compile_ext(["xab", "ab"], [hs.HS_FLAG_SINGLEMATCH, hs.HS_FLAG_SINGLEMATCH], [9, 9], [None, None])
+    c2 = np.frombuffer(b"..xab..", dtype=np.uint8).copy()
+    o2 = np.array([0, c2.size], dtype=np.uint64)
+    rv, ev = confirm(db, c2, o2, literal_hits([(b"xab", "", 0, 9, {}), (b"ab", "", 0, 9, {})], c2, o2))
+    assert rv == hs.HS_SUCCESS and [(e[1], e[3]) for e in ev] == [(9, 5)]  # one event for (to = 5, id = 9)
+    with pytest.raises(hs.HsError) as ei:
+        hs.Database.compile_ext(["key", "lock"], [hs.HS_FLAG_SINGLEMATCH, 0], [5, 5], [None, None])
+    assert ei.value.expression == 1
+    assert "did not specify HS_FLAG_SINGLEMATCH whereas previous expression (index 0) with the same match ID did." in str(ei.value)
+    with pytest.raises(hs.HsError) as ei:
+        hs.Database.compile_ext(["key", "lock"], [0, hs.HS_FLAG_SINGLEMATCH], [5, 5], [None, None])
+    assert "specified HS_FLAG_SINGLEMATCH whereas previous expression (index 0) with the same match ID did not." in str(ei.value)
     db = hs.Database.compile_ext(["xab", "ab"], [hs.HS_FLAG_SOM_LEFTMOST, 0], [9, 9], [None, None])
     corpus = np.frombuffer(b"..xab..", dtype=np.uint8).copy()
     off = np.array([0, corpus.size], dtype=np.uint64)
