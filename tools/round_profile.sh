@@ -3,7 +3,7 @@
 # leg) under rocprofv3 (--kernel-trace --stats), then separate PMC passes of the same command: FETCH_SIZE,
 # WRITE_SIZE, and two sets of SQ counters for the filter kernels; summaries are written under
 # gpurun_out/<tag>/ for copying to profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -27,7 +27,7 @@ def collect(dirs):
     for d in dirs:
         for f in sorted(glob.glob(out+"/"+d+"/**/*counter_collection.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
-                m=re.search(r"(hwlm_\w+<[^>]*>|record_\w+|block_hint_kernel|class_\w+|pair_\w+)", r.get("Kernel_Name",""))
+                m=re.search(r"(hwlm_\w+<[^>]*>|record_\w+|block_hint_kernel|class_\w+(?:<[^>]*>)?|pair_\w+|seq_\w+|run_accel_\w+)", r.get("Kernel_Name",""))
                 if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 summ={k:{c:{"avg_KB":sum(x)/len(x),"n":len(x)} for c,x in v.items()} for k,v in collect(("pmc_fetch","pmc_write")).items()}

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/tmp/sim'); sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'/root/repo/tools/sim'); sys.path.insert(0,'/root/repo')
 from cur import *
 def two_plane(k=14, hsh=8, offs=True):
     LO = np.zeros(1 << k, np.uint32); HI = np.zeros(1 << k, np.uint32)

@@ -6,7 +6,22 @@ from hyperscan_amd import corpus as cp
 MUL = 0x9E3779
 def is_alpha(c): return (65 <= c <= 90) or (97 <= c <= 122)
 
+def true_ends(lits, corpus, off, cache="/tmp/sim/true_ends_%d.npy"):
+    """bool per corpus byte: some literal ends there (the compiled reference, oracle/_ref)"""
+    path = cache % corpus.size
+    if os.path.exists(path):
+        return np.load(path)
+    from tests import oracle_binding as ob
+    ref = ob.Reference(lits, variant=ob.ref_variants()[-1])
+    r = ref.collect_blocks(corpus, off)
+    e = np.zeros(corpus.size, dtype=bool)
+    e[off[r["block"]].astype(np.int64) + r["end"].astype(np.int64)] = True
+    np.save(path, e)
+    return e
+
+
 def load(nbytes=64 << 20, cache="/tmp/sim/fdr10k_%d.npz"):
+    os.makedirs("/tmp/sim", exist_ok=True)
     path = cache % nbytes
     lits, _ = cp.snort_like_literals(10000, seed=4)
     if os.path.exists(path):
@@ -33,25 +48,3 @@ def padded(corpus, front=8, back=8):
     pad = np.zeros(corpus.size + front + back, dtype=np.uint32)
     pad[front:front + corpus.size] = corpus
     return pad
-
-def true_match_ends(lits, corpus):
-    """set of end positions with at least one literal matching (ignoring block boundaries): via 8-byte window compare
-    grouped by (msk) -- slow path: use hashing of last 3 bytes blind to prefilter"""
-    L = [Lit(l) for l in lits]
-    n = corpus.size
-    pad = padded(corpus)
-    ends = np.zeros(n, dtype=bool)
-    # group literals by length (<=8) and case pattern is too many; do per-literal on candidate positions of its last 2 bytes
-    b0 = pad[8:8 + n]; b1 = pad[7:7 + n]
-    key2 = (b0 & 0xdf) | ((b1 & 0xdf) << 8)
-    order = np.argsort(key2, kind="stable")
-    sk = key2[order]
-    for li in L:
-        k = (li.val[0] & 0xdf) | ((li.val[1] & 0xdf) << 8)
-        lo, hi = np.searchsorted(sk, k), np.searchsorted(sk, k, side="right")
-        pos = order[lo:hi]
-        ok = np.ones(pos.size, dtype=bool)
-        for p in range(min(li.len, 8)):
-            ok &= (pad[8 + pos - p] & li.msk[p]) == li.val[p]
-        ends[pos[ok]] = True
-    return ends

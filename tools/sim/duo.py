@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/tmp/sim'); sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'/root/repo/tools/sim'); sys.path.insert(0,'/root/repo')
 from quad4 import *
 
 def run_duo(L, log2e, b2mask, ph_in="lo", ph_k=1, name="", check=True, skipF=False, th_shift=(8, 13)):

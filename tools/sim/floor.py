@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/tmp/sim'); sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'/root/repo/tools/sim'); sys.path.insert(0,'/root/repo')
 import base
 from base import Lit
 N = 64 << 20

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/tmp/sim'); sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'/root/repo/tools/sim'); sys.path.insert(0,'/root/repo')
 from quad4 import *
 
 def run_pd(L, log2e, b2mask, sh=(8, 13), name="", check=True, use5=False):

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/tmp/sim'); sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'/root/repo/tools/sim'); sys.path.insert(0,'/root/repo')
 from quad4 import *
 MUL2 = 0x85EBCA6B
 def h2(x, variant):

@@ -1,10 +1,10 @@
 import sys, time, numpy as np
-sys.path.insert(0,'/tmp/sim'); sys.path.insert(0,'/root/repo')
+sys.path.insert(0,'/root/repo/tools/sim'); sys.path.insert(0,'/root/repo')
 import base
 from base import Lit, MUL
 N = 64 << 20
 lits, corpus, off = base.load(N)
-true_e = np.load('/tmp/sim/true_ends_64.npy')
+true_e = base.true_ends(lits, corpus, off)
 ALL = [Lit(l) for l in lits]
 pad = base.padded(corpus); n = corpus.size
 pos = np.arange(0, n, 2)
