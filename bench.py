@@ -369,7 +369,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     # steps (ring of the last 32 scans); read only now, so the timed loop itself never waited on them
     filt_ms, conf_ms, pipe_ms, span_ms = [], [], [], []
     for jb in jobs:
-        for back in range(min(args.steps // depth, 32)):
+        for back in range(min(args.steps // depth, 30)):
             f, c, t = jb.scratch.timing(back)
             filt_ms.append(f)
             conf_ms.append(c)
@@ -377,6 +377,31 @@ def run_workload(name, args, rank, world, dist, do_cpu):
             span_ms.append(jb.scratch.kernel_span(back))
     kern_avg_s = float(np.mean(filt_ms)) / 1e3
 
+    overlapped = None
+    if dist is None and depth == 1 and not getattr(args, "shards_override", None):
+        # for the record (never `value`): the same steps with two scans in flight on two streams (a second scratch over
+        # the same table and resident corpus) -- what hsbench's second thread would add; the per-kernel figures above
+        # stay those of serial steps
+        j2 = [job, GpuJob(None, None, None, torch.cuda.current_device(), sibling=job)]
+        st2 = [torch.cuda.Stream(device=job.dev) for _ in range(2)]
+
+        def run2(n):
+            for i in range(n):
+                with torch.cuda.stream(st2[i & 1]):
+                    j2[i & 1].launch()
+            for st in st2:
+                st.synchronize()
+
+        run2(4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run2(args.steps)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        assert j2[1].count() == n_matches
+        overlapped = {"ms_per_step": round(dt2 / args.steps * 1e3, 4), "GBps": round(job.total * args.steps / dt2 / 1e9, 2),
+                      "what": "the same steps, two scans in flight on two streams (second scratch, same table and corpus)"}
+        del j2[1]
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=job.dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -414,6 +439,8 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         "records": "in delivery order (block, end, lit), sorted on the device inside the step",
     }
     res["pipeline_depth"] = depth
+    if overlapped:
+        res["two_scans_in_flight"] = overlapped
     if dist is not None:
         g = [a.elapsed_time(b) for a, b in ev]
         res["exchange"] = {"collective": ("broadcast x world of exactly counts[r] rows (counts agreed before the timed steps)" if exact else
@@ -862,7 +889,7 @@ def main():
             "matches_per_s": main_res["matches_per_s"], "matches_per_step": main_res["matches_per_step"],
             "roofline": main_res["roofline"], "table": main_res["table"],
         }
-        for k in ("cpu_baseline", "end_to_end_resident", "host_buffers", "exchange"):
+        for k in ("cpu_baseline", "end_to_end_resident", "host_buffers", "exchange", "two_scans_in_flight"):
             if k in main_res:
                 out[k] = main_res[k]
         if also:
