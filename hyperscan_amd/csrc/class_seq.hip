@@ -49,7 +49,8 @@
 namespace {
 
 constexpr int SEQ_THREADS = 256;
-constexpr uint32_t SEQ_HEADER = 16384; /* work area: pattern array + bitmap pointers in front of the start bitmap */
+constexpr uint32_t SEQ_HEADER = 32768; /* work area: pattern array, bitmap pointers, (class, repeat) pairs in front of the start bitmap */
+constexpr uint32_t SEQ_BATCH = 8;     /* words per hand-over of G between the pair lanes and the pattern lanes */
 
 struct SeqArgs {
     const hsgpu_class_seq_t *seqs;
@@ -64,6 +65,11 @@ struct SeqArgs {
     hsgpu_match_t *out;
     uint64_t cap;
     unsigned long long *count;
+    /* the patterns of a workgroup (256 of them) share their distinct (A, m) pairs: G is computed once per pair */
+    const uint16_t *pair_of;   /* [n_seqs] index of the pattern's pair inside its group of 256 */
+    const uint16_t *pairs;     /* [n_wgroups][256]: class | (m - 1) << 8 */
+    const uint16_t *n_pairs;   /* [n_wgroups] */
+    uint32_t n_wgroups;
 };
 
 __global__ void seq_starts_kernel(const uint64_t *off, uint64_t nblocks, uint64_t total, uint32_t *starts32) {
@@ -197,6 +203,100 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_kernel(SeqArgs args) {
     if (active && n_match) atomicAdd(&args.counts[p], n_match);
 }
 
+/* The same with the A side shared: a workgroup of 4 wavefronts takes 256 patterns and one share of the corpus. The distinct
+ * (A, m) pairs of those patterns (72 for the bench's 256) are computed once, by the first n_pairs threads, SEQ_BATCH words at a
+ * time into LDS; then every pattern lane reads the G of its pair and does only its own B side. 1.5x fewer vector instructions
+ * than one lane per pattern doing everything (the kernel is 95 % VALU-busy, so instructions are its time). */
+__global__ __launch_bounds__(SEQ_THREADS) void class_seq_shared_kernel(SeqArgs args) {
+    __shared__ uint64_t gbuf[SEQ_BATCH][256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wg = blockIdx.x % args.n_wgroups, share = blockIdx.x / args.n_wgroups;
+    if (share >= args.n_shares) return;
+    const uint32_t p = wg * 256 + tid;
+    const bool active = p < args.n_seqs;
+    const hsgpu_class_seq_t P = args.seqs[active ? p : 0];
+    const uint32_t my_pair = active ? args.pair_of[p] : 0;
+    const uint32_t n_pairs = args.n_pairs[wg];
+    const bool pair_lane = tid < n_pairs;
+    const uint32_t pw = args.pairs[wg * 256 + (pair_lane ? tid : 0)];
+    const uint16_t *pa = args.bitmaps[pw & 0xff], *pb = args.bitmaps[P.b];
+    const uint32_t km = pw >> 8, kn = (uint32_t)P.n - 1;
+    const uint64_t n16 = (args.total + 15) / 16;
+
+    const uint64_t lo_b = (uint64_t)share * args.share_bytes, hi_b = min(args.total, lo_b + args.share_bytes);
+    const uint64_t b_lo = lower_bound_off(args.off, args.nblocks, lo_b), b_hi = lower_bound_off(args.off, args.nblocks, hi_b);
+    if (b_lo >= b_hi || b_lo >= args.nblocks) return; /* (uniform: the whole workgroup) */
+    const uint64_t s0 = args.off[b_lo], s1 = args.off[min(b_hi, args.nblocks)];
+    if (s0 >= s1) return;
+    const uint64_t w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
+
+    RunMasks ra, rb;
+    memset(&ra, 0, sizeof(ra));
+    memset(&rb, 0, sizeof(rb));
+    uint64_t prev_a = 0, prev_b = 0, prev_r = 0, prev_g = 0, cin = 0;
+    unsigned long long n_match = 0;
+    for (uint64_t wb = w0; wb <= w1; wb += SEQ_BATCH) {
+        const uint32_t nw = (uint32_t)min((uint64_t)SEQ_BATCH, w1 - wb + 1);
+        if (pair_lane) { /* G of this thread's (A, m) pair for the batch's words */
+            for (uint32_t k = 0; k < nw; k++) {
+                const uint64_t w = wb + k;
+                uint64_t a = load_word(pa, w, n16);
+                const uint64_t e = args.starts[w];
+                if ((w + 1) * 64 > args.total) a &= ~0ull >> (64 - (args.total - w * 64));
+                const uint64_t nst = ~e;
+                advance_runs(ra, a & nst);
+                const uint64_t r = shl2(a, prev_a, km) & run_of(ra, km);
+                gbuf[k][tid] = shl2(r, prev_r, 1) & nst;
+                prev_a = a, prev_r = r;
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < nw; k++) {
+            const uint64_t w = wb + k;
+            uint64_t b = load_word(pb, w, n16);
+            const uint64_t e = args.starts[w];
+            if ((w + 1) * 64 > args.total) b &= ~0ull >> (64 - (args.total - w * 64));
+            const uint64_t g = gbuf[k][my_pair];
+            const uint64_t qb = b & ~e;
+            uint64_t x;
+            if (args.any_n) {
+                advance_runs(rb, qb);
+                x = shl2(g, prev_g, kn) & shl2(b, prev_b, kn) & run_of(rb, kn);
+            } else {
+                x = g & b;
+            }
+            const uint64_t s_1 = qb + x, c1 = s_1 < qb ? 1 : 0, s_2 = s_1 + cin, c2 = s_2 < s_1 ? 1 : 0;
+            uint64_t y = ((s_2 ^ qb) & qb) | x;
+            cin = c1 | c2;
+            prev_b = b, prev_g = g;
+            if (w == w0) y &= ~0ull << (s0 & 63);
+            if (w == w1) y &= ~0ull >> (63 - ((s1 - 1) & 63));
+            if (!active) y = 0;
+            n_match += (unsigned)__popcll(y);
+            const uint64_t base = w * 64;
+            if (y && base < args.emit_hi && base + 64 > args.emit_lo) {
+                while (y) {
+                    const uint32_t j = __builtin_ctzll(y);
+                    y &= y - 1;
+                    const uint64_t pos = base + j;
+                    if (pos < args.emit_lo || pos >= args.emit_hi) continue;
+                    const unsigned long long at = atomicAdd(args.count, 1ull);
+                    if (at >= args.cap) continue;
+                    const uint64_t blk = lower_bound_off(args.off, args.nblocks, pos + 1) - 1;
+                    hsgpu_match_t rec;
+                    rec.block = (uint32_t)blk;
+                    rec.end = (uint32_t)(pos - args.off[blk]);
+                    rec.id = P.id;
+                    rec.lit = p;
+                    args.out[at] = rec;
+                }
+            }
+        }
+        __syncthreads(); /* the next batch overwrites gbuf */
+    }
+    if (active && n_match) atomicAdd(&args.counts[p], n_match);
+}
+
 } // namespace
 
 extern "C" size_t hsgpu_class_seq_work_bytes(uint64_t total_bytes) { return SEQ_HEADER + ((total_bytes + 63) / 64) * 8 + 8; }
@@ -229,13 +329,30 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)n_seqs * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
     if (!total_bytes || !nblocks) return HSGPU_SUCCESS;
-    /* work area: patterns | bitmap pointers | block-start bitmap */
+    /* work area: patterns | bitmap pointers | (class, repeat) pairs per group of 256 patterns | block-start bitmap */
     uint8_t *w = (uint8_t *)d_work;
     const size_t seq_bytes = (size_t)n_seqs * sizeof(hsgpu_class_seq_t), ptr_ofs = (seq_bytes + 15) & ~(size_t)15;
-    if (ptr_ofs + (size_t)n_classes * sizeof(void *) > SEQ_HEADER) return HSGPU_INVALID;
+    const uint32_t n_wgroups = (n_seqs + 255) / 256;
+    const size_t pairof_ofs = (ptr_ofs + (size_t)n_classes * sizeof(void *) + 15) & ~(size_t)15;
+    const size_t pairs_ofs = pairof_ofs + (((size_t)n_seqs * 2 + 15) & ~(size_t)15);
+    const size_t npairs_ofs = pairs_ofs + (size_t)n_wgroups * 256 * 2;
+    if (npairs_ofs + (size_t)n_wgroups * 2 > SEQ_HEADER) return HSGPU_INVALID;
+    std::vector<uint16_t> pair_of(n_seqs), pairs((size_t)n_wgroups * 256, 0), n_pairs(n_wgroups, 0);
+    for (unsigned i = 0; i < n_seqs; i++) {
+        const unsigned g = i / 256;
+        const uint16_t key = (uint16_t)(seqs[i].a | (unsigned)(seqs[i].m - 1) << 8);
+        unsigned k = 0;
+        while (k < n_pairs[g] && pairs[(size_t)g * 256 + k] != key) k++;
+        if (k == n_pairs[g]) pairs[(size_t)g * 256 + n_pairs[g]++] = key;
+        pair_of[i] = (uint16_t)k;
+    }
     /* (pageable sources: the runtime stages them before the call returns) */
     HIP_TRY(hipMemcpyAsync(w, seqs, seq_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(w + ptr_ofs, d_bitmaps, (size_t)n_classes * sizeof(void *), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w + pairof_ofs, pair_of.data(), pair_of.size() * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w + pairs_ofs, pairs.data(), pairs.size() * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w + npairs_ofs, n_pairs.data(), n_pairs.size() * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st)); /* the staging vectors go out of scope */
     const uint64_t n_words = (total_bytes + 63) / 64;
     uint64_t *starts = (uint64_t *)(w + SEQ_HEADER);
     HIP_TRY(hipMemsetAsync(starts, 0, n_words * 8 + 8, st));
@@ -264,9 +381,17 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
     a.out = (hsgpu_match_t *)d_out;
     a.cap = cap;
     a.count = (unsigned long long *)d_count;
-    const uint64_t waves = (uint64_t)a.n_groups * a.n_shares;
-    hipLaunchKernelGGL(class_seq_kernel, dim3((unsigned)((waves + SEQ_THREADS / 64 - 1) / (SEQ_THREADS / 64))),
-                       dim3(SEQ_THREADS), 0, st, a);
+    a.pair_of = (const uint16_t *)(w + pairof_ofs);
+    a.pairs = (const uint16_t *)(w + pairs_ofs);
+    a.n_pairs = (const uint16_t *)(w + npairs_ofs);
+    a.n_wgroups = n_wgroups;
+    if (n_seqs > 64) { /* several patterns per (A, m) pair are likely: share the A side inside a workgroup */
+        hipLaunchKernelGGL(class_seq_shared_kernel, dim3(n_wgroups * a.n_shares), dim3(SEQ_THREADS), 0, st, a);
+    } else {
+        const uint64_t waves = (uint64_t)a.n_groups * a.n_shares;
+        hipLaunchKernelGGL(class_seq_kernel, dim3((unsigned)((waves + SEQ_THREADS / 64 - 1) / (SEQ_THREADS / 64))),
+                           dim3(SEQ_THREADS), 0, st, a);
+    }
     HIP_TRY(hipGetLastError());
     return HSGPU_SUCCESS;
 }
