@@ -681,16 +681,18 @@ def run_flood(args):
     # the output protocol of hsgpu_hwlm_scan_dev: a count above cap (cap + 1: a staging region, sized from cap for an
     # even spread, overflowed) means "again with more room" -- flood blocks hold four times the average density
     cap = want_total + (1 << 20)
-    for attempt in range(4):
-        job = GpuJob(lits, corpus, off, torch.cuda.current_device(), cap=cap)
+    job = GpuJob(lits, corpus, off, torch.cuda.current_device(), cap=cap)
+    for attempt in range(5):  # the same scratch throughout: it is the scratch that remembers a dense scan
         job.launch()
         torch.cuda.synchronize()
         n = job.count()
         if n <= cap:
             break
-        del job
-        torch.cuda.empty_cache()
         cap *= 2
+        job.cap = cap
+        job.d_out = None
+        torch.cuda.empty_cache()
+        job.d_out = torch.zeros(cap * 4, dtype=torch.int32, device=job.dev)
     assert n == want_total, f"flood: {n} matches, expected {want_total}"
     # content gate on the first block against the reference (or the restatement)
     d_first = job.d_out[: 4 * (2 * blk)].view(-1, 4)

@@ -519,13 +519,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
             HIP_TRY(hipEventRecord(s->ev_t[1], stream));
         }
     } else {
-        /* phase 1 + 2, then the fused kernel as overflow fallback (returns at once
-         * unless some wavefront ran out of candidate space). Every filter wavefront
-         * owns a private region of the candidate buffer: one 32-byte entry per 64
-         * corpus bytes on average, i.e. room for candidates in a quarter of all chunks. */
+        /* phase 1 + 2. Every filter wavefront owns a private region of the candidate buffer: one 32-byte
+         * entry per 64 corpus bytes on average, i.e. room for candidates in a quarter of all chunks. */
         args.cand_waves = n_waves;
         /* Dense input (the reference's flood case, src/fdr/flood_runtime.h:86-335): once a scan on this scratch ran out of
-         * candidate room and was redone by the fused kernel, later scans give every 16-byte chunk an entry of its own -- the
+         * candidate room (and told its caller to scan again), later scans give every 16-byte chunk an entry of its own -- the
          * two-phase path can then not overflow, at the price of a candidate buffer twice the size of the corpus. */
         if (s->h_note && *s->h_note) {
             *s->h_note = 0;
@@ -541,7 +539,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
         HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
-        HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
+        /* No fused kernel behind it (it used to be launched on every scan, to return at once): a scan whose candidate regions
+         * overflowed reports count = cap + 1 like one whose staging regions did -- "again" -- and sets the scratch's note,
+         * so that the next scan has room for every chunk. Without the note (mapped host memory unavailable) the always-correct
+         * fused kernel still redoes such a scan in place. */
+        if (!s->d_note) HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
     }
     if (s->timing) s->n_timed++;
     /* one workgroup per share of the corpus: its records sorted into place; the control block back to zero */

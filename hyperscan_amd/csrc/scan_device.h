@@ -1245,7 +1245,10 @@ __global__ __launch_bounds__(1024) void record_sort_kernel(HsgpuScanArgs args) {
         unsigned long long sv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) sv[k] = args.rec_super[min(lane + 64u * k, 256u)];
-        const unsigned long long flag = args.rec_super[256];
+        /* a staging region lost records, or (two-phase pipeline) a candidate region overflowed and the confirm kernel did
+         * nothing: either way this scan delivers nothing and says so */
+        const unsigned long long flag =
+            args.rec_super[256] | ((args.cand_counts && args.overflow_note) ? args.cand_counts[args.cand_waves] : 0u);
         const uint32_t c0 = (S << args.super_shift) + lane;
         const uint2 cfirst = counts[min(c0, args.rec_regions - 1)];
         unsigned long long before = 0, all = 0;
@@ -1271,8 +1274,12 @@ __global__ __launch_bounds__(1024) void record_sort_kernel(HsgpuScanArgs args) {
             placed[2] = flag;
             if (blockIdx.x == 0) {
                 /* a region that ran out of space lost records; its fill counters kept counting, so the total is
-                 * still exact: report it, but never a value <= cap (that would claim the output is complete) */
+                 * still exact: report it, but never a value <= cap (that would claim the output is complete).
+                 * Candidate overflow: nothing was confirmed, the total is unknown: cap + 1 ("again"), and the word in
+                 * mapped host memory that makes the next scan on this scratch give every chunk an entry of its own. */
                 *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
+                if (args.cand_counts && args.cand_counts[args.cand_waves] && args.overflow_note) *args.overflow_note = 1u;
+                if (args.tstamp) args.tstamp[2] = wall_clock64(); /* the stages before the sort are done */
             }
         }
     }

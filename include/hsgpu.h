@@ -144,8 +144,10 @@ int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8
  * block by block -- and *d_count receives the TOTAL number of matches. *d_count > cap means the
  * buffer was too small and no record is delivered: scan again with room for at least *d_count
  * records, or with twice the room when *d_count == cap + 1 (then the staging area of one
- * wavefront, sized from cap, was too small for a dense run of matches; in that case *d_count is a
- * lower bound). hsgpu_hwlm_exec_batch repeats the scan itself. cap < 2^32. d_corpus must be
+ * wavefront, sized from cap, or -- the first dense scan on a scratch -- a wavefront's candidate region
+ * was too small for a dense run of matches; in that case *d_count is a lower bound, and the scratch
+ * remembers: its next scans give every 16-byte chunk candidate room of its own).
+ * hsgpu_hwlm_exec_batch repeats the scan itself. cap < 2^32. d_corpus must be
  * 16-byte aligned. Successive scans on one scratch must be ordered after each other (the same stream, or
  * synchronised): a scratch is one set of working buffers, as an hs_scratch is (one per concurrent scan). */
 int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus,
