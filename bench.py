@@ -378,7 +378,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     kern_avg_s = float(np.mean(filt_ms)) / 1e3
 
     overlapped = None
-    if dist is None and depth == 1 and not getattr(args, "shards_override", None):
+    if args.overlap_probe and dist is None and depth == 1 and not getattr(args, "shards_override", None):
         # for the record (never `value`): the same steps with two scans in flight on two streams (a second scratch over
         # the same table and resident corpus) -- what hsbench's second thread would add; the per-kernel figures above
         # stay those of serial steps
@@ -815,6 +815,9 @@ def main():
     ap.add_argument("--class-gib", type=float, default=4.0)
     ap.add_argument("--rose-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--overlap-probe", action="store_true",
+                    help="also time the steps with two scans in flight on two streams (reported as two_scans_in_flight, never "
+                         "as value; off by default so that a kernel trace of the default run holds serial launches only)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one --gib shard per GPU (the default, what the driver runs); strong: the same --shards x --gib "
                          "GiB at every GPU count, rank r scanning shards [r, r + 1) * shards / N (SURVEY 8(d) config 3: "
