@@ -118,10 +118,10 @@ def pmc_traffic_sum(kernel_prefix, launches_per_step):
 def filter_kernel_name(flags):
     b = lambda bit: "true" if flags & bit else "false"
     if flags & 256:
-        return "hwlm_filter_kernel<true, false, false, false, false, true, false, false, true>"
+        return "hwlm_filter_kernel<true, false, false, false, false, true, false, false, true, false>"
     cls = ("true, true, true" if flags & 4 else
            "true, true, false" if flags & 2 and not flags & 128 else "true, false, false")
-    return f"hwlm_filter_kernel<{cls}, {b(8)}, {b(16)}, {b(32)}, {b(64)}, false, false>"
+    return f"hwlm_filter_kernel<{cls}, {b(8)}, {b(16)}, {b(32)}, {b(64)}, false, false, {b(1024)}>"
 
 
 class GpuJob:

@@ -370,6 +370,15 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
      * (64 literals: the 8 KiB staged per workgroup cost 3 us of a 17 us kernel). */
     if (!pair && !(tflags & HSGPU_F_HAS_C) && !(flags & HSGPU_BUILD_NO_GATE) && entries >= 2048 && (uint64_t)entries * 2 <= 65536)
         tflags |= HSGPU_F_GATE;
+    /* 64-bit entries for the large stride-1 two-bit sets whose kernel runs the 4-byte-key test alone (no 3-byte keys, or
+     * folded ones): same 128 KiB, the second bit in a word of its own. Simulated on the bench's 10 000-literal set
+     * (tools/sim/b2p.py): 11.5 M -> 8.8 M candidate lanes per GiB (a folded 3-byte key no longer passes every position
+     * that hashes into its word), and the second test is one instruction (a shift by a byte of the hash) instead of two. */
+    if (!pair && !(flags & HSGPU_BUILD_NO_WIDE) && !(tflags & (HSGPU_F_REPL | HSGPU_F_HAS_C | HSGPU_F_STRIDE2)) && (tflags & HSGPU_F_K2) &&
+        (!(tflags & HSGPU_F_HAS_B) || (tflags & HSGPU_F_BFOLD)) && k == 15) {
+        tflags |= HSGPU_F_WIDE;
+        k = 14; /* entries; the same 2^15 words */
+    }
     const uint32_t fshift = hsgpu_filter_shift(tflags, k);
     uint32_t ht_log2[2];
     for (int c = 0; c < 2; c++)
@@ -445,6 +454,9 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
                 /* the pair filter is filled from the literals themselves, below; a 3-byte key of either kind
                  * marks the gate bitmap the confirm step consults before it probes this table */
                 if (c == 1) c2bits[hsgpu_gate_bit(key) >> 5] |= 1u << (hsgpu_gate_bit(key) & 31);
+            } else if (tflags & HSGPU_F_WIDE) { /* {lo, hi} at entry a1 >> 3 */
+                filter[2 * (a1 >> 3)] |= c == 0 ? 1u << hsgpu_filter_bit_lo_wide(key & 0xff) : ~0u; /* (3-byte keys are folded: any b3) */
+                filter[2 * (a1 >> 3) + 1] |= 1u << hsgpu_filter_bit_hi(prod1);
             } else if (c == 0) {
                 set_bit(a1, hsgpu_filter_bit_a(key & 0xff, a1));
                 if (tflags & HSGPU_F_K2) set_bit(a1, hsgpu_filter_bit_a2(key & 0xff, prod1));
@@ -543,6 +555,9 @@ int hsgpu_validate_blob(const void *buf, size_t len) {
     if (h.version != HSGPU_TABLE_VERSION) return HSGPU_DB_VERSION_ERROR;
     if (h.blob_bytes != len) return HSGPU_INVALID;
     if (h.filter_log2 < 4 || h.filter_log2 > 15 || ((h.flags & HSGPU_F_REPL) && h.filter_log2 > 10) ||
+        ((h.flags & HSGPU_F_WIDE) && (h.filter_log2 > 14 || !(h.flags & HSGPU_F_K2) ||
+                                      (h.flags & (HSGPU_F_REPL | HSGPU_F_HAS_C | HSGPU_F_STRIDE2 | HSGPU_F_PAIR)) ||
+                                      ((h.flags & HSGPU_F_HAS_B) && !(h.flags & HSGPU_F_BFOLD)))) ||
         ((h.flags & HSGPU_F_PAIR) && (h.filter_log2 > 14 || (h.flags & (HSGPU_F_REPL | HSGPU_F_K2 | HSGPU_F_HAS_C | HSGPU_F_BFOLD)) ||
                                       !(h.flags & HSGPU_F_STRIDE2) || !(h.hash_mask & 0xff0000u) || h.hash_mask > 0xffffffu)) ||
         h.ht_a_log2 < 2 || h.ht_a_log2 > 26 || h.ht_b_log2 < 2 || h.ht_b_log2 > 26)

@@ -620,12 +620,36 @@ template <bool REPL, int Q>
 __device__ __forceinline__ uint32_t filter_hash(const uint32_t (&arr)[6]) {
     /* 3 bytes ending at c[Q]: byte offset Q + 2 into arr */
     constexpr int O = Q + 2;
-    const uint32_t x = (O & 3) ? alignbyte(arr[(O >> 2) + 1], arr[O >> 2], O & 3) : arr[O >> 2];
+    /* byte offset 1 inside a dword: the three bytes are the dword's upper three, a plain shift (twice the issue rate of
+     * v_alignbyte); the multiply reads 24 bits, so offset 0 needs nothing */
+    const uint32_t x = (O & 3) == 0 ? arr[O >> 2] : (O & 3) == 1 ? arr[O >> 2] >> 8 : alignbyte(arr[(O >> 2) + 1], arr[O >> 2], O & 3);
     return mul_u24(x, HSGPU_FILTER_MUL);
 }
 template <bool REPL> __device__ __forceinline__ uint32_t filter_addr(uint32_t prod, const FilterCfg &f) {
     const uint32_t a = prod >> f.shift;
     return REPL ? ((a << 7) | f.lane4) : (a & f.amask);
+}
+/* word >> byte BYTE of src (the hardware reads the low five bits of the selected byte) */
+template <int BYTE> __device__ __forceinline__ uint32_t shr_byte(uint32_t word, uint32_t src) {
+    uint32_t r;
+    if (BYTE == 0) return word >> (src & 31u); /* a plain shift: its amount is the low five bits of the register */
+    else if (BYTE == 1)
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(src), "v"(word));
+    else if (BYTE == 2)
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(src), "v"(word));
+    else
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(src), "v"(word));
+    return r;
+}
+/* HSGPU_F_WIDE: 64-bit entries, the 4-byte key's first bit in lo (index = b3), its second in hi (index = the product): two
+ * shifts whose amounts the hardware takes from a byte / from the product as they are, one and, one alignbit */
+template <int Q>
+__device__ __forceinline__ void filter_test_wide(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t prod, uint2 word,
+                                                 uint32_t &acc_a) {
+    const uint32_t b3src = arr[(Q + 1) >> 2];
+    constexpr int B3 = (Q + 1) & 3;
+    const uint32_t hit = shr_byte<B3>(word.x, b3src) & shr_lo5(word.y, prod);
+    acc_a = push_top(hit, acc_a, 1);
 }
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int Q>
 __device__ __forceinline__ void filter_test(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t prod, uint32_t word,
@@ -656,6 +680,14 @@ __device__ __forceinline__ void filter_test(const uint32_t (&arr)[6], const Filt
     }
 }
 
+template <int BASE, int... I>
+__device__ __forceinline__ void filter_positions_wide(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
+                                                      std::integer_sequence<int, I...>) {
+    const uint32_t prod[sizeof...(I)] = {filter_hash<false, BASE + I>(arr)...};
+    const uint2 word[sizeof...(I)] = {lds_pair((prod[I] >> f.shift) & f.amask)...};
+    __builtin_amdgcn_sched_barrier(0);
+    (filter_test_wide<BASE + I>(arr, f, prod[I], word[I], acc_a), ...);
+}
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int BASE, int... I>
 __device__ __forceinline__ void filter_positions(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
                                                  uint32_t &acc_o, std::integer_sequence<int, I...>) {
@@ -666,7 +698,7 @@ __device__ __forceinline__ void filter_positions(const uint32_t (&arr)[6], const
     (filter_test<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, (BASE + I) * STEP>(arr, f, prod[I], word[I], acc_a, acc_o), ...);
 }
 
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool WIDE = false>
 __device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg &f) {
     uint32_t arr[6] = {c.h.y, c.d.x, c.d.y, c.d.z, c.d.w, 0u};
     if (BLIND) {
@@ -674,6 +706,10 @@ __device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg
         for (int i = 0; i < 5; i++) arr[i] &= 0xdfdfdfdfu; /* b3's bit 5 never reaches the 5-bit index either */
     }
     uint32_t acc_a = 0, acc_o = 0;
+    if (WIDE) { /* stride 1, the 4-byte-key test alone, 64-bit entries */
+        filter_positions_wide<0>(arr, f, acc_a, std::make_integer_sequence<int, 16>{});
+        return acc_a >> 16;
+    }
 #ifndef HSGPU_FILTER_BATCHES
 #define HSGPU_FILTER_BATCHES 1 /* tuning builds: 2 = the chunk's lookups in two halves (half the registers held across the LDS reads) */
 #endif
@@ -873,7 +909,7 @@ __device__ __forceinline__ void write_block_hints_batch(const uint64_t *off, uin
 }
 
 /* ---- phase 1: the streaming filter (FUSED: + in-kernel confirm) ----------- */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
 #ifndef HSGPU_FILTER_MIN_WAVES
 #define HSGPU_FILTER_MIN_WAVES 1 /* tuning builds: 8 caps the kernel at 64 VGPRs so that two 16-wavefront workgroups fit a CU */
 #endif
@@ -891,7 +927,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     if (!FUSED && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
 
     const uint32_t flog2 = args.t_filter_log2;
-    const uint32_t nw = PAIR ? (2u << flog2) : REPL ? (32u << flog2) : (1u << flog2);
+    const uint32_t nw = (PAIR || WIDE) ? (2u << flog2) : REPL ? (32u << flog2) : (1u << flog2);
     uint32_t *filter = lds;
     uint32_t *c2bits = lds + nw;
 
@@ -1018,8 +1054,8 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     }
 
     FilterCfg f;
-    f.shift = PAIR ? 29u - flog2 : REPL ? 32u - flog2 : 30u - flog2;
-    f.amask = PAIR ? ((1u << flog2) - 1u) << 3 : (nw - 1u) << 2;
+    f.shift = (PAIR || WIDE) ? 29u - flog2 : REPL ? 32u - flog2 : 30u - flog2;
+    f.amask = PAIR ? ((1u << flog2) - 1u) << 3 : WIDE ? ((1u << flog2) - 1u) << 3 : (nw - 1u) << 2;
     f.hmask = args.t_hash_mask;
     f.lane4 = (lane & 31u) << 2;
     f.c2base = nw * 4;
@@ -1028,8 +1064,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
 #define HSGPU_HANDLE(CUR, COFF)                                                                   \
     {                                                                                             \
         const uint32_t acc = PAIR ? pair_filter_chunk(CUR, f)                                     \
-                                  : filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(CUR, f); \
-        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, qcount, lane, (COFF), acc);    \
+                                  : filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, WIDE>(CUR, f); \
+        /* (WIDE: one test stands for both key classes; the in-kernel confirm looks at a class's own half of the mask) */ \
+        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, qcount, lane, (COFF), (WIDE && HAS_B) ? (acc | acc << 16) : acc); \
         else HSGPU_SPILL(args, sp, (COFF), acc, CUR);                                             \
     }
 
@@ -1095,11 +1132,11 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
             }
             if (coff) c.h = *(const uint2 *)(corpus + coff - 8);
         }
-        uint32_t acc = PAIR ? pair_filter_chunk(c, f) : filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND>(c, f);
+        uint32_t acc = PAIR ? pair_filter_chunk(c, f) : filter_chunk<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, WIDE>(c, f);
         uint32_t valid = 0;
         if (coff < total) valid = (coff + CHUNK <= total) ? 0xffffu : ((1u << (uint32_t)(total - coff)) - 1u);
         acc &= valid | valid << 16;
-        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, qcount, lane, coff, acc);
+        if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, qcount, lane, coff, (WIDE && HAS_B) ? (acc | acc << 16) : acc);
         else spill(args, sp, coff, acc, c);
     }
 #undef HSGPU_HANDLE

@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 10u
+#define HSGPU_TABLE_VERSION 11u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
@@ -48,6 +48,14 @@
 #define HSGPU_F_GATE 512u   /* the c2bits section holds the key gate: 64 Kbit, bit hsgpu_key_gate_bit(key) set for every
                              * key of the two exact tables (3-byte keys salted). The confirm kernel stages it in LDS
                              * and probes a table (one divergent 16-byte read per lane) only for keys that pass */
+
+#define HSGPU_F_WIDE 1024u  /* hashed stride-1 two-bit filter with 64-bit entries {lo, hi} (2^filter_log2 of them): a 4-byte key's
+                             * first bit -- b3 & 31, the byte in front of the hashed three -- lives in lo, its second bit in hi
+                             * and depends on the hash alone (prod & 31). A folded 3-byte key (HSGPU_F_BFOLD) then owns only the
+                             * lo half of its entry: the hi bit still discriminates. Either test is ONE shift whose amount the
+                             * hardware takes from the low five bits of a byte (an SDWA select) or of the product itself --
+                             * no index arithmetic at all (tools/sim/b2p.py: these two indices pass fewer candidates than
+                             * (a + b3) and byte 1 of the product, which cost two more instructions per lookup) */
 
 #define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
 #define HSGPU_HT_MUL 0x9E3779B1u
@@ -123,14 +131,16 @@ static_assert(sizeof(HsgpuDevLit) == 32, "DevLit is 32 bytes");
  */
 HSGPU_HD uint32_t hsgpu_filter_prod(uint32_t x24) { return (x24 & 0xffffffu) * HSGPU_FILTER_MUL; }
 HSGPU_HD uint32_t hsgpu_filter_shift(uint32_t flags, uint32_t log2) {
-    return (flags & HSGPU_F_REPL) ? 32u - log2 : 30u - log2;
+    return (flags & HSGPU_F_REPL) ? 32u - log2 : (flags & HSGPU_F_WIDE) ? 29u - log2 : 30u - log2; /* WIDE: entry = a >> 3 */
 }
 HSGPU_HD uint32_t hsgpu_filter_bit_a(uint32_t b3, uint32_t a) { return (b3 + a) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_a2(uint32_t b3, uint32_t prod) { return (b3 + (prod >> 8)) & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b(uint32_t a) { return a & 31u; }
 HSGPU_HD uint32_t hsgpu_filter_bit_b2(uint32_t prod) { return (prod >> 8) & 31u; }
+HSGPU_HD uint32_t hsgpu_filter_bit_lo_wide(uint32_t b3) { return b3 & 31u; } /* WIDE: the first bit, in the lo word */
+HSGPU_HD uint32_t hsgpu_filter_bit_hi(uint32_t prod) { return prod & 31u; }       /* WIDE: the second bit, in the hi word */
 HSGPU_HD uint32_t hsgpu_filter_words(uint32_t flags, uint32_t log2) {
-    return (flags & HSGPU_F_PAIR) ? (2u << log2) : (flags & HSGPU_F_REPL) ? (32u << log2) : (1u << log2);
+    return (flags & (HSGPU_F_PAIR | HSGPU_F_WIDE)) ? (2u << log2) : (flags & HSGPU_F_REPL) ? (32u << log2) : (1u << log2);
 }
 
 /* ---- the pair filter (HSGPU_F_PAIR) ------------------------------------------------------

@@ -182,3 +182,33 @@ def test_run_accel_all_ten_cases_against_the_reference():
                 assert np.array_equal(got, np.array(exact)), name
             else:
                 assert np.array_equal(got, want), (name, np.nonzero(got != want)[0][:5], got[got != want][:5], want[got != want][:5])
+
+
+@pytest.mark.parametrize("short", [0, 20])
+@pytest.mark.parametrize("nocase", [0.0, 0.4])
+def test_wide_filter_layout_equals_the_oracle_and_the_narrow_layout(short, nocase):
+    """HSGPU_F_WIDE (64-bit filter entries, the two bits of a 4-byte key in words of their own, tests that are plain shifts):
+    chosen for large stride-1 two-bit sets; same records as the oracle and as the 32-bit layout (HSGPU_BUILD_NO_WIDE), with and
+    without folded 3-byte keys, case-blind or not, through the two-phase pipeline and through the fused kernel."""
+    from tests.util import as_set, random_blocks, random_corpus, random_literals
+
+    FORCE_HASHED, FORCE_K2, FORCE_S1, NO_WIDE, F_WIDE, F_BFOLD = 2, 4, 16, 2048, 1024, 128
+    rng = np.random.default_rng(90 + short)
+    base = random_literals(rng, 1500, 4, 8, nocase_frac=nocase) + random_literals(rng, short, 3, 3, nocase_frac=nocase)
+    lits = [H.HwlmLiteral(l.s, nocase=l.nocase, id=i) for i, l in enumerate(base)]
+    corpus = random_corpus(rng, 700_000, lits, plant_every=150)
+    off = random_blocks(rng, corpus.size, mean_len=500)
+    want = as_set(ob.Oracle(lits).collect_blocks(corpus, off))
+    wide = H.hwlm_build(lits, FORCE_HASHED | FORCE_K2 | FORCE_S1)
+    narrow = H.hwlm_build(lits, FORCE_HASHED | FORCE_K2 | FORCE_S1 | NO_WIDE)
+    assert wide.info()["flags"] & F_WIDE and not narrow.info()["flags"] & F_WIDE
+    assert bool(wide.info()["flags"] & F_BFOLD) == bool(short)
+    s = H.Scratch(0)
+    got_w = hw.hwlm_exec_batch(wide, s, corpus, off)
+    got_n = hw.hwlm_exec_batch(narrow, s, corpus, off)
+    assert as_set(got_w) == want and as_set(got_n) == want and len(want) > 1500
+    assert np.array_equal(got_w, got_n)  # the same records in the same (delivery) order
+    assert np.array_equal(hw.hwlm_exec_batch(H.HwlmTable.deserialize(wide.serialize()), s, corpus, off), got_w)
+    f = H.Scratch(0)
+    f.set_tuning(fused_only=True)
+    assert as_set(hw.hwlm_exec_batch(wide, f, corpus, off)) == want
