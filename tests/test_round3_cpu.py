@@ -87,3 +87,44 @@ def test_bench_helpers_shards_and_quota(tmp_path):
     _l, c1, o1 = bench.build_workload("teddy64", 1 << 20, 1)
     k = int(np.searchsorted(o, 1 << 20))
     assert np.array_equal(c[1 << 20: 2 << 20], c1) and np.array_equal(o[k:k + o1.size] - np.uint64(1 << 20), o1)
+
+
+def test_wide_tables_build_reload_and_hold_every_key():
+    """HSGPU_F_WIDE (csrc/table.h): chosen for hashed stride-1 two-bit tables whose kernel runs the 4-byte-key test alone; the
+    image reloads, a damaged one is refused, NO_WIDE keeps the 32-bit layout -- and, the filter restated in numpy from table.h,
+    every literal's own bytes pass it (a filter may pass too much, never too little)."""
+    import hyperscan_amd as H
+    from tests.util import random_literals
+
+    FORCE_HASHED, FORCE_K2, FORCE_S1, NO_WIDE, F_WIDE, F_BFOLD, F_BLIND = 2, 4, 16, 2048, 1024, 128, 64
+    MUL = 0x9E3779
+    rng = np.random.default_rng(5)
+    for short in (0, 12):
+        base = random_literals(rng, 900, 4, 8, nocase_frac=0.3) + random_literals(rng, short, 3, 3, nocase_frac=0.3)
+        lits = [H.HwlmLiteral(l.s, nocase=l.nocase, id=i) for i, l in enumerate(base)]
+        t = H.hwlm_build(lits, FORCE_HASHED | FORCE_K2 | FORCE_S1)
+        info = t.info()
+        assert info["flags"] & F_WIDE and bool(info["flags"] & F_BFOLD) == bool(short) and info["filter_words"] == 32768
+        assert not H.hwlm_build(lits, FORCE_HASHED | FORCE_K2 | FORCE_S1 | NO_WIDE).info()["flags"] & F_WIDE
+        blob = bytes(t.serialize())
+        assert bytes(H.HwlmTable.deserialize(blob).serialize()) == blob
+        bad = bytearray(blob)
+        bad[len(bad) // 2] ^= 0x40
+        with pytest.raises(H.HsgpuError):
+            H.HwlmTable.deserialize(bytes(bad))
+        # the filter image: header field off_filter (word 13), 2^14 entries {lo, hi}
+        off_filter = int(np.frombuffer(blob, dtype="<u4", count=32)[13])
+        ent = np.frombuffer(blob, dtype="<u4", count=32768, offset=off_filter).reshape(-1, 2)
+        blind = 0xdf if info["flags"] & F_BLIND else 0xff
+        for l in lits:
+            s = l.s
+            b = [c & blind for c in s[-4:]] if len(s) >= 4 else [None] + [c & blind for c in s[-3:]]
+            x = b[1] | b[2] << 8 | b[3] << 16
+            prod = (x * MUL) & 0xffffffff
+            lo, hi = int(ent[prod >> 18, 0]), int(ent[prod >> 18, 1])
+            assert (hi >> (prod & 31)) & 1, l.s
+            if b[0] is None:
+                assert lo == 0xffffffff, l.s  # a folded 3-byte key: any byte in front of it
+            else:
+                for c in ({b[0], b[0] | 0x20} if l.nocase and blind == 0xdf else {b[0]}):  # every admissible b3 after blinding
+                    assert (lo >> ((c & blind) & 31)) & 1, l.s
