@@ -329,6 +329,11 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         int rv = lits.empty() && !d->cseq.empty() ? HSGPU_SUCCESS /* class sequences only: no literal table */
                  : gpu_table && !gpu_table->empty() ? hsgpu_hwlm_deserialize(gpu_table->data(), gpu_table->size(), &d->hwlm)
                                                     : hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
+        /* a stored table this library cannot load (another table version) is simply compiled again */
+        if (rv != HSGPU_SUCCESS && !lits.empty() && gpu_table && !gpu_table->empty()) {
+            d->hwlm = nullptr;
+            rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
+        }
         /* a stored table must be the one these patterns compile to (a blob from a build whose pattern
          * compiler chose other literals, or a spliced one, is not): otherwise compile afresh */
         if (rv == HSGPU_SUCCESS && d->hwlm && gpu_table && !gpu_table->empty() &&
