@@ -382,7 +382,7 @@ static int set_dyn_lds(const void *fn, size_t lds) {
 }
 
 extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu) {
-    if (!s || (wg_threads && wg_threads != 256 && wg_threads != 512 && wg_threads != 1024) || wg_per_cu > 4) return HSGPU_INVALID;
+    if (!s || (wg_threads && (wg_threads % 64 || wg_threads < 256 || wg_threads > 1024)) || wg_per_cu > 4) return HSGPU_INVALID;
     s->tune_fused = fused_only != 0;
     s->tune_wg_threads = wg_threads;
     s->tune_wg_per_cu = wg_per_cu;
