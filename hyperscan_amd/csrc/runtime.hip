@@ -538,7 +538,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
-        HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + 3) / 4), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
+        HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64)), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         /* No fused kernel behind it (it used to be launched on every scan, to return at once): a scan whose candidate regions
          * overflowed reports count = cap + 1 like one whose staging regions did -- "again" -- and sets the scratch's note,
          * so that the next scan has room for every chunk. Without the note (mapped host memory unavailable) the always-correct

@@ -9,7 +9,9 @@
 #include "../../include/hsgpu.h"
 
 #define HSGPU_WG_THREADS 1024
-#define HSGPU_CONFIRM_THREADS 256
+#ifndef HSGPU_CONFIRM_THREADS
+#define HSGPU_CONFIRM_THREADS 256 /* tuning builds: 512 (eight wavefronts share one staged key gate: 36 KiB, four workgroups per CU) */
+#endif
 #ifndef HSGPU_CONFIRM_SPLIT
 #define HSGPU_CONFIRM_SPLIT 4 /* confirm wavefronts per candidate region (tuning builds: 2) */
 #endif
