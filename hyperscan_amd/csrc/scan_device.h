@@ -643,13 +643,16 @@ template <int BYTE> __device__ __forceinline__ uint32_t shr_byte(uint32_t word, 
 }
 /* HSGPU_F_WIDE: 64-bit entries, the 4-byte key's first bit in lo (index = b3), its second in hi (index = the product): two
  * shifts whose amounts the hardware takes from a byte / from the product as they are, one and, one alignbit */
-template <int Q>
-__device__ __forceinline__ void filter_test_wide(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t prod, uint2 word,
-                                                 uint32_t &acc_a) {
-    const uint32_t b3src = arr[(Q + 1) >> 2];
-    constexpr int B3 = (Q + 1) & 3;
-    const uint32_t hit = shr_byte<B3>(word.x, b3src) & shr_lo5(word.y, prod);
+/* (b3 = c[Q-3] is byte 0 of the three hashed bytes of position Q - 1: `xprev` is that lookup's hash input, still in its register,
+ * so the first shift is a plain v_lshrrev too -- as an SDWA byte select it issued at half the rate, 12 times per tile) */
+__device__ __forceinline__ void filter_test_wide(uint32_t xprev, uint32_t prod, uint2 word, uint32_t &acc_a) {
+    const uint32_t hit = shr_lo5(word.x, xprev) & shr_lo5(word.y, prod);
     acc_a = push_top(hit, acc_a, 1);
+}
+/* the 3 bytes ending at c[Q] in the low 24 bits (what is above them is ignored by the 24-bit multiply and by a 5-bit shift amount) */
+template <int Q> __device__ __forceinline__ uint32_t filter_x(const uint32_t (&arr)[6]) {
+    constexpr int O = Q + 2;
+    return (O & 3) == 0 ? arr[O >> 2] : (O & 3) == 1 ? arr[O >> 2] >> 8 : alignbyte(arr[(O >> 2) + 1], arr[O >> 2], O & 3);
 }
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int Q>
 __device__ __forceinline__ void filter_test(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t prod, uint32_t word,
@@ -683,10 +686,11 @@ __device__ __forceinline__ void filter_test(const uint32_t (&arr)[6], const Filt
 template <int BASE, int... I>
 __device__ __forceinline__ void filter_positions_wide(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
                                                       std::integer_sequence<int, I...>) {
-    const uint32_t prod[sizeof...(I)] = {filter_hash<false, BASE + I>(arr)...};
+    const uint32_t x[sizeof...(I) + 1] = {filter_x<BASE - 1>(arr), filter_x<BASE + I>(arr)...};
+    const uint32_t prod[sizeof...(I)] = {mul_u24(x[I + 1], HSGPU_FILTER_MUL)...};
     const uint2 word[sizeof...(I)] = {lds_pair((prod[I] >> f.shift) & f.amask)...};
     __builtin_amdgcn_sched_barrier(0);
-    (filter_test_wide<BASE + I>(arr, f, prod[I], word[I], acc_a), ...);
+    (filter_test_wide(x[I], prod[I], word[I], acc_a), ...);
 }
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, int BASE, int... I>
 __device__ __forceinline__ void filter_positions(const uint32_t (&arr)[6], const FilterCfg &f, uint32_t &acc_a,
@@ -703,7 +707,12 @@ __device__ __forceinline__ uint32_t filter_chunk(const Chunk &c, const FilterCfg
     uint32_t arr[6] = {c.h.y, c.d.x, c.d.y, c.d.z, c.d.w, 0u};
     if (BLIND) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) arr[i] &= 0xdfdfdfdfu; /* b3's bit 5 never reaches the 5-bit index either */
+        for (int i = 0; i < 5; i++) {
+            arr[i] &= 0xdfdfdfdfu; /* b3's bit 5 never reaches the 5-bit index either */
+            /* (opaque from here: knowing that the multiply reads 24 bits, the compiler otherwise masks the raw dword a second
+             * time with 0xdfdfdf for every aligned lookup instead of using this value) */
+            asm("" : "+v"(arr[i]));
+        }
     }
     uint32_t acc_a = 0, acc_o = 0;
     if (WIDE) { /* stride 1, the 4-byte-key test alone, 64-bit entries */
@@ -766,33 +775,39 @@ __device__ __forceinline__ uint32_t pair_filter_chunk(const Chunk &c, const Filt
 }
 
 struct SpillState {
-    uint4 *region;     /* this wavefront's region of the candidate buffer (32-byte entries) */
-    uint32_t written;  /* entries appended so far */
-    uint32_t overflow; /* region exhausted: the scan falls back to the fused kernel */
+    __amdgpu_buffer_rsrc_t rs; /* this wavefront's region of the candidate buffer (32-byte entries), as a buffer descriptor */
+    uint32_t cap;      /* entries the region holds */
+    uint32_t written;  /* entries appended so far (wave-uniform: kept in a scalar register) */
+    uint32_t overflow; /* region exhausted: the scan reports "again" (or falls back to the fused kernel) */
 };
 
 /* two-phase: lanes with candidates append {chunk index, masks, 8-byte halo, chunk}
  * straight to this wavefront's private HBM region (ranked by ballot; no atomics,
- * no LDS staging) */
-__device__ __forceinline__ void spill(const HsgpuScanArgs &args, SpillState &sp, uint64_t coff, uint32_t acc,
-                                      const Chunk &c) {
+ * no LDS staging). Everything wave-uniform here -- the fill, the room check, the
+ * region -- lives in scalar registers (readfirstlane where the compiler would not see it):
+ * as loop-carried vector values the fill and the flag cost two v_cndmask (~9 ns each,
+ * profiles/r02_valu_lds_rates.txt), a vector compare and 64-bit vector address arithmetic
+ * on every tile. The stores take a 32-bit lane offset against the region's descriptor. */
+__device__ __forceinline__ void spill(SpillState &sp, uint32_t fold_shift, uint32_t chunk_idx, uint32_t acc, const Chunk &c) {
     const bool has = acc != 0;
     const unsigned long long bal = __ballot(has);
     if (!bal) return;
-    const uint32_t n = __popcll(bal);
-    if (sp.written + n > args.cand_cap) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(__popcll(bal));
+    if (sp.written + n > sp.cap) {
         sp.overflow = 1;
         return;
     }
     if (has) {
         const uint32_t rank =
             __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-        uint4 *e = sp.region + 2ull * (sp.written + rank);
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         /* BFOLD tables: the one class test stands for both (fold_shift = 16, else 0) */
-        e[0] = make_uint4((uint32_t)(coff >> 4), acc | acc << args.fold_shift, c.h.x, c.h.y);
-        e[1] = c.d;
+        const v4u e0 = {chunk_idx, acc | acc << fold_shift, c.h.x, c.h.y};
+        const v4u e1 = {c.d.x, c.d.y, c.d.z, c.d.w};
+        __builtin_amdgcn_raw_buffer_store_b128(e0, sp.rs, rank << 5, sp.written << 5, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(e1, sp.rs, (rank << 5) + 16u, sp.written << 5, 0);
     }
-    sp.written += n;
+    sp.written = __builtin_amdgcn_readfirstlane(sp.written + n);
 }
 
 /* fused: push into the wavefront's LDS queue; confirm 64 at a time */
@@ -945,8 +960,13 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
      * costs one small sort per share instead of a global one (phase 3). */
     const uint64_t n_full = total >> 10; /* 1 KiB tiles with every load in bounds */
     const uint64_t per_wave = (n_full + n_waves - 1) / n_waves;
-    uint64_t tile = min(n_full, (uint64_t)wave_global * per_wave);
-    const uint64_t tile_end = min(n_full, tile + per_wave);
+    /* The share as wave-uniform SCALARS: its first tile (64-bit) and the number of tiles in it (32-bit; a share of
+     * 2^32 tiles would be 4 TiB). The 64-bit division above leaves its result in vector registers; with `tile` and
+     * `tile_end` taken from there every stage of the loop below paid three 64-bit vector compares and two 64-bit moves
+     * for its "in range" and "done" tests. Now they are s_cmp on a 32-bit counter. */
+    const uint64_t tile0 = rfl64(min(n_full, (uint64_t)wave_global * per_wave));
+    const uint32_t n_own = __builtin_amdgcn_readfirstlane((uint32_t)(min(n_full, tile0 + per_wave) - tile0));
+    uint32_t tk = 0; /* tiles of the share done */
     const uint32_t lane_off = lane * CHUNK;
 
     /* Loads of one tile through a buffer descriptor built from wave-uniform values only
@@ -956,9 +976,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
      * front of the tile (halo at voffset, chunk at voffset + 8 via soffset); a tile past
      * the end of the wavefront's share gets an empty descriptor: its loads return zeros and
      * touch no memory, which replaces every bounds check. */
-    auto issue = [&](uint64_t tile) -> Chunk {
-        const uint8_t *base = corpus + (tile << 10) - 8;
-        const int records = tile < tile_end ? (int)0x7ffffff0 : 0;
+    auto issue = [&](uint32_t k) -> Chunk { /* tile k of the share */
+        const uint8_t *base = corpus + ((tile0 + k) << 10) - 8;
+        const int records = k < n_own ? (int)0x7ffffff0 : 0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, records, 0x00020000);
         Chunk c;
         const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 8, HSGPU_LOAD_AUX);
@@ -969,8 +989,8 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     };
     /* tile 0 has nothing in front of it: descriptor at the corpus itself, and the
      * first lane's halo offset wraps out of range, which reads as the zeros it needs */
-    auto issue_first = [&](uint64_t tile) -> Chunk {
-        if (tile) return issue(tile);
+    auto issue_first = [&]() -> Chunk {
+        if (tile0) return issue(0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)corpus, 0, (int)0x7ffffff0, 0x00020000);
         Chunk c;
         const auto d = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, 0, HSGPU_LOAD_AUX);
@@ -1003,17 +1023,17 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     uint64_t ho[HK + 1];
 #pragma unroll
     for (int k = 0; k <= HK; k++) ho[k] = hints ? args.off[min(hb0 + k, args.nblocks)] : 0; /* clamped: no branches */
-    const bool streaming = tile < tile_end;
+    const bool streaming = n_own != 0;
     Chunk c0, c1, c2, c3, c4, c5, c6, c7;
     c0.d = c1.d = c2.d = c3.d = c4.d = c5.d = c6.d = c7.d = make_uint4(0, 0, 0, 0);
     c0.h = c1.h = c2.h = c3.h = c4.h = c5.h = c6.h = c7.h = make_uint2(0, 0);
     if (streaming) {
-        c0 = issue_first(tile), c1 = issue(tile + 1), c2 = issue(tile + 2);
+        c0 = issue_first(), c1 = issue(1), c2 = issue(2);
 #if HSGPU_STAGES >= 6
-        c3 = issue(tile + 3), c4 = issue(tile + 4);
+        c3 = issue(3), c4 = issue(4);
 #endif
 #if HSGPU_STAGES >= 8
-        c5 = issue(tile + 5), c6 = issue(tile + 6);
+        c5 = issue(5), c6 = issue(6);
 #endif
     }
     /* the filter image into LDS: once per workgroup */
@@ -1041,7 +1061,8 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     Tables t;
     uint32_t qcount = 0;
     SpillState sp;
-    sp.region = nullptr;
+    sp.rs = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
+    sp.cap = 0;
     sp.written = 0;
     sp.overflow = 0;
     if (FUSED) {
@@ -1050,7 +1071,10 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         t.rec_region = args.rec_stage + (uint64_t)wave_global * args.rec_cap;
         t.rec_cap = args.rec_cap;
     } else {
-        sp.region = args.cand + 2ull * wave_global * args.cand_cap;
+        /* (a region is at most a few hundred MiB: cand_cap entries of 32 bytes; runtime.hip keeps it below 2 GiB) */
+        sp.rs = __builtin_amdgcn_make_buffer_rsrc((void *)(args.cand + 2ull * wave_global * args.cand_cap), 0,
+                                                  (int)min((uint64_t)args.cand_cap * 32u, (uint64_t)0x7ffffff0), 0x00020000);
+        sp.cap = args.cand_cap;
     }
 
     FilterCfg f;
@@ -1060,7 +1084,8 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     f.lane4 = (lane & 31u) << 2;
     f.c2base = nw * 4;
 
-#define HSGPU_SPILL(args, sp, coff, acc, cur) spill(args, sp, coff, acc, cur)
+/* (the chunk index of a lane in 32-bit arithmetic, as the entry holds it: corpora below 64 GiB, like everything that reads it) */
+#define HSGPU_SPILL(args, sp, coff, acc, cur) spill(sp, args.fold_shift, ((uint32_t)(tile0 + tk) << 6) | lane, acc, cur)
 #define HSGPU_HANDLE(CUR, COFF)                                                                   \
     {                                                                                             \
         const uint32_t acc = PAIR ? pair_filter_chunk(CUR, f)                                     \
@@ -1076,11 +1101,11 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
          * the only wait is for the stage about to be filtered. */
 #define HSGPU_STAGE(CUR, NEW)                                            \
     {                                                                    \
-        NEW = issue(tile + (HSGPU_STAGES - 1));                          \
-        const uint64_t coff = (tile << 10) + lane_off;                    \
+        NEW = issue(tk + (HSGPU_STAGES - 1));                            \
+        const uint64_t coff = ((tile0 + tk) << 10) | lane_off;           \
         HSGPU_HANDLE(CUR, coff)                                          \
-        tile += 1;                                                       \
-        if (tile >= tile_end) break;                                     \
+        tk += 1;                                                         \
+        if (tk >= n_own) break;                                          \
     }
 #if HSGPU_STAGES == 8
         for (;;) {
@@ -1137,7 +1162,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         if (coff < total) valid = (coff + CHUNK <= total) ? 0xffffu : ((1u << (uint32_t)(total - coff)) - 1u);
         acc &= valid | valid << 16;
         if (FUSED) enqueue_fused<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, qcount, lane, coff, (WIDE && HAS_B) ? (acc | acc << 16) : acc);
-        else spill(args, sp, coff, acc, c);
+        else spill(sp, args.fold_shift, (uint32_t)(coff >> 4), acc, c);
     }
 #undef HSGPU_HANDLE
 
