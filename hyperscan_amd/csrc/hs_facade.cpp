@@ -329,8 +329,9 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         int rv = lits.empty() && !d->cseq.empty() ? HSGPU_SUCCESS /* class sequences only: no literal table */
                  : gpu_table && !gpu_table->empty() ? hsgpu_hwlm_deserialize(gpu_table->data(), gpu_table->size(), &d->hwlm)
                                                     : hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
-        /* a stored table this library cannot load (another table version) is simply compiled again */
-        if (rv != HSGPU_SUCCESS && !lits.empty() && gpu_table && !gpu_table->empty()) {
+        /* a stored table of another table version is simply compiled again (a damaged one of this version is refused:
+         * tests/test_hs_reference_api_cpu.py::test_serialised_database_carries_the_gpu_table) */
+        if (rv == HSGPU_DB_VERSION_ERROR && !lits.empty() && gpu_table && !gpu_table->empty()) {
             d->hwlm = nullptr;
             rv = hsgpu_hwlm_build(lits.data(), lits.size(), 0, &d->hwlm);
         }

@@ -531,7 +531,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         }
         uint64_t cand_div = s->cand_div;
         args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / cand_div + n_waves - 1) / n_waves);
-        if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32)) != HSGPU_SUCCESS) return rv;
+        if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32 + 64)) != HSGPU_SUCCESS) return rv; /* + slack: the confirm kernel reads one dword past an entry */
         args.cand = (uint4 *)s->cand.p;
         args.cand_counts = blk + cand_ofs;
         if ((rv = set_dyn_lds(f_two, lds_two)) != HSGPU_SUCCESS) return rv;

@@ -516,6 +516,165 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
     }
 }
 
+/* ---- the same step for stride-1 tables without 2-byte keys, written for what the vector unit charges -----------
+ * The general step above is compiled from booleans and 64-bit values: 68 v_cndmask_b32 (a wave64 v_cndmask issues
+ * at ~1/9 of the plain VOP2 rate on gfx950, profiles/r02_valu_lds_rates.txt), 64-bit shifts for the window, 64-bit
+ * address arithmetic for every load -- ~470 vector instructions per step of 128 entries, and with them the confirm
+ * kernel is bound by vector issue, not by its dependent reads. Here every condition is a 0 / ~0 MASK made with
+ * plain arithmetic and applied with v_and / v_or; nothing on the common path selects.
+ *   entry     8 bytes {chunk, masks}; then the WINDOW itself is read: the 8 bytes ending at the candidate position
+ *             are bytes [9 + j, 16 + j] of the 32-byte entry -- three aligned dwords and two v_alignbit, instead of
+ *             six dwords in registers, two 64-bit funnel shifts and six selects
+ *   key gate  both keys' bits from LDS, unconditionally (an idle lane reads some word of the gate)
+ *   buckets   16 bytes per table at (bucket & mask): a lane with nothing to probe reads bucket 0
+ *   slots     hit_i = ~0 when slot i is in use and carries the tag; the literal a lone direct hit names is compared
+ *             in place ({v, msk}: 16 bytes); lists, several hits, full buckets: the general code (probe<true>)
+ * All loads go through buffer descriptors (32-bit lane offsets against scalar bases; out-of-range offsets read 0). */
+struct FastRs {
+    __amdgpu_buffer_rsrc_t region, ht_a, ht_b, lits;
+};
+/* (inline asm: written as C the compiler recognises each of these as a sign-extended compare and goes back to
+ * v_cmp + v_cndmask, which is exactly what this step exists to avoid) */
+__device__ __forceinline__ uint32_t m_zero31(uint32_t x) { /* x < 2^31: ~0 when x == 0 */
+    uint32_t r;
+    asm("v_add_u32_e32 %0, -1, %1\n\tv_ashrrev_i32_e32 %0, 31, %0" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t m_nonzero(uint32_t x) { /* any x: ~0 when x != 0 */
+    uint32_t r;
+    asm("v_min_u32_e32 %0, 1, %1\n\tv_sub_u32_e32 %0, 0, %0" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t m_bit(uint32_t v, uint32_t bit) { /* ~0 when bit (bit & 31) of v is set: a one-bit signed field */
+    uint32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(v), "v"(bit));
+    return r;
+}
+__device__ __forceinline__ uint32_t m_less(uint32_t a, uint32_t b) { /* ~0 when a < b, both below 2^31 */
+    uint32_t r;
+    asm("v_sub_u32_e32 %0, %1, %2\n\tv_ashrrev_i32_e32 %0, 31, %0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t slot_hit(uint32_t slot, uint32_t tag) {
+    return m_zero31(((slot >> HSGPU_SLOT_TAG_SHIFT) & HSGPU_SLOT_TAG_MASK) ^ tag) & m_nonzero(slot);
+}
+/* one bucket against one key: fast = a lone, direct, delta-0 hit in a bucket that is not full (ref names the literal);
+ * slow = anything else that needs the general code */
+__device__ __forceinline__ void bucket_masks(const uint32_t (&s)[4], uint32_t tag, uint32_t doit, uint32_t &ref, uint32_t &fast,
+                                             uint32_t &slow) {
+    const uint32_t h0 = slot_hit(s[0], tag), h1 = slot_hit(s[1], tag), h2 = slot_hit(s[2], tag), h3 = slot_hit(s[3], tag);
+    const uint32_t n = 0u - (h0 + h1 + h2 + h3); /* 0..4 hits */
+    ref = (s[0] & h0) | (s[1] & h1) | (s[2] & h2) | (s[3] & h3);
+    const uint32_t full = m_nonzero(s[3]);
+    fast = doit & m_zero31(n ^ 1u) & m_zero31((ref >> HSGPU_LIST_DELTA_SHIFT) ^ 2u) & ~full;
+    slow = doit & ~fast & (m_nonzero(n) | full);
+}
+template <bool HAS_B, bool FRESH>
+__device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs &rs, uint2 *rq, const uint32_t (&idx)[2],
+                                                  uint32_t (&pend)[2], const uint32_t (&vm)[2]) {
+    /* (Requesting the next fresh step's masks one step ahead, behind this step's last loads, was measured: 82 registers
+     * instead of 79 cost a wavefront per SIMD and the stage went 0.143 -> 0.158 ms, 0.151 with the registers capped and two
+     * spills: profiles/r03_confirm_fast_ab.txt. The stage does not wait on that hop.) */
+    uint32_t chunk[2], m[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (FRESH) {
+            const auto e = __builtin_amdgcn_raw_buffer_load_b64(rs.region, idx[u] << 5, 0, 0);
+            chunk[u] = e[0];
+            m[u] = e[1] & vm[u];
+        } else { /* an entry off the rest queue: its masks are known, the chunk index is read beside the window */
+            chunk[u] = __builtin_amdgcn_raw_buffer_load_b32(rs.region, idx[u] << 5, 0, 0);
+            m[u] = pend[u];
+        }
+    }
+    uint32_t j[2], wlo[2], whi[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t any = (m[u] | m[u] >> 16) & 0xffffu;
+        j[u] = (uint32_t)__builtin_ctz(any | 0x10000u) & 15u;
+        const uint32_t o = 9u + j[u]; /* the window ending at c[j]: entry bytes [o, o + 8) */
+        const auto d = __builtin_amdgcn_raw_buffer_load_b96(rs.region, (idx[u] << 5) + (o & ~3u), 0, 0);
+        const uint32_t sh = (o & 3u) << 3;
+        wlo[u] = __builtin_amdgcn_alignbit(d[1], d[0], sh); /* (o = 24: sh = 0, the dword past the entry is not used) */
+        whi[u] = __builtin_amdgcn_alignbit(d[2], d[1], sh);
+        const uint32_t rest = any & (any - 1u);
+        pend[u] = m[u] & (rest | rest << 16);
+    }
+    /* entries with candidate bits left: onto the rest queue */
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint64_t mask = __ballot(pend[u] != 0);
+        if (mask) {
+            const uint32_t base = __builtin_amdgcn_readfirstlane(t.wl->nrq);
+            if (pend[u]) rq[base + lane_rank(mask)] = make_uint2(idx[u], pend[u]);
+            if (lane_rank(~0ull) == 0) t.wl->nrq = base + (uint32_t)__popcll(mask);
+        }
+    }
+    uint32_t w4[2], pa[2], pb[2], do_a[2], do_b[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        w4[u] = whi[u] & t.key_mask;
+        pa[u] = w4[u] * HSGPU_HT_MUL;
+        pb[u] = (w4[u] >> 8) * HSGPU_HT_MUL;
+        do_a[u] = m_bit(m[u], j[u]); /* (no candidate bits at all: j = 0 and bit 0 is clear) */
+        do_b[u] = HAS_B ? m_bit(m[u], 16u + j[u]) : 0u;
+        if (t.key_gate) { /* keys that no exact table holds need no probe */
+            const uint32_t ga = pa[u] >> 16, gb = (pb[u] + HSGPU_GATE_B_SALT * HSGPU_HT_MUL) >> 16; /* the salt sits above the 24 key bits */
+            do_a[u] &= m_bit(t.key_gate[ga >> 5], ga);
+            if (HAS_B) do_b[u] &= m_bit(t.key_gate[gb >> 5], gb);
+        }
+    }
+    uint32_t sa[2][4], sb[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const auto a = __builtin_amdgcn_raw_buffer_load_b128(rs.ht_a, ((pa[u] >> (32u - t.ht_a_log2)) & do_a[u]) << 4, 0, 0);
+        sa[u][0] = a[0], sa[u][1] = a[1], sa[u][2] = a[2], sa[u][3] = a[3];
+        if (HAS_B) {
+            const auto b = __builtin_amdgcn_raw_buffer_load_b128(rs.ht_b, ((pb[u] >> (32u - t.ht_b_log2)) & do_b[u]) << 4, 0, 0);
+            sb[u][0] = b[0], sb[u][1] = b[1], sb[u][2] = b[2], sb[u][3] = b[3];
+        }
+    }
+    uint32_t ref_a[2], fast_a[2], slow_a[2], ref_b[2] = {0, 0}, fast_b[2] = {0, 0}, slow_b[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        bucket_masks(sa[u], (pa[u] >> (26u - t.ht_a_log2)) & HSGPU_SLOT_TAG_MASK, do_a[u], ref_a[u], fast_a[u], slow_a[u]);
+        if (HAS_B) bucket_masks(sb[u], (pb[u] >> (26u - t.ht_b_log2)) & HSGPU_SLOT_TAG_MASK, do_b[u], ref_b[u], fast_b[u], slow_b[u]);
+    }
+    /* {v, msk} of the literal the slot names (literal 0 for lanes without one). (One literal load per entry, a position
+     * whose two keys both name a literal sending its 3-byte key through the general path, brought the kernel from 79 to 69
+     * registers -- seven wavefronts per SIMD -- and was slower, 0.150 vs 0.143 ms: with BFOLD tables both keys of every
+     * candidate are tried, and the general path then runs in nearly every step.) */
+    uint32_t la[2][4], lb[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const auto a = __builtin_amdgcn_raw_buffer_load_b128(rs.lits, (ref_a[u] & HSGPU_LIST_LIT_MASK & fast_a[u]) << 5, 0, 0);
+        la[u][0] = a[0], la[u][1] = a[1], la[u][2] = a[2], la[u][3] = a[3];
+        if (HAS_B) {
+            const auto b = __builtin_amdgcn_raw_buffer_load_b128(rs.lits, (ref_b[u] & HSGPU_LIST_LIT_MASK & fast_b[u]) << 5, 0, 0);
+            lb[u][0] = b[0], lb[u][1] = b[1], lb[u][2] = b[2], lb[u][3] = b[3];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        /* (window & msk) == v, 32 bits at a time; a stride-1 table has no delta-1 entries, every g is inside the corpus */
+        const uint32_t xa = ((wlo[u] & la[u][2]) ^ la[u][0]) | ((whi[u] & la[u][3]) ^ la[u][1]);
+        if (fast_a[u] && xa == 0) push_match(t, (uint64_t)chunk[u] * CHUNK + j[u], ref_a[u] & HSGPU_LIST_LIT_MASK);
+        if (HAS_B) {
+            const uint32_t xb = ((wlo[u] & lb[u][2]) ^ lb[u][0]) | ((whi[u] & lb[u][3]) ^ lb[u][1]);
+            if (fast_b[u] && xb == 0) push_match(t, (uint64_t)chunk[u] * CHUNK + j[u], ref_b[u] & HSGPU_LIST_LIT_MASK);
+        }
+    }
+    /* everything else: the general path (behind the compares: the literals' registers are free again) */
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (slow_a[u] | slow_b[u]) {
+            const uint64_t g = (uint64_t)chunk[u] * CHUNK + j[u], w0 = (uint64_t)whi[u] << 32 | wlo[u];
+            if (slow_a[u]) probe<true>(t, t.ht_a, t.ht_a_log2, w4[u], w0, 0, g);
+            if (HAS_B && slow_b[u]) probe<true>(t, t.ht_b, t.ht_b_log2, w4[u] >> 8, w0, 0, g);
+        }
+    }
+}
+
 /* Convergent: resolve queued matches, 64 at a time with full lanes, while more than
  * `keep` are queued; records go straight to the front of the wavefront's region. */
 __device__ __forceinline__ void drain_matches(const Tables &t, uint32_t lane, uint32_t keep) {
@@ -1184,7 +1343,11 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
  * b % SPLIT), so that even a few thousand entries per region are confirmed by
  * many short dependent-read chains in parallel rather than one long one. ---- */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
-__global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScanArgs args) {
+__global__ __launch_bounds__(CONFIRM_THREADS)
+#ifdef HSGPU_CONFIRM_WAVES
+__attribute__((amdgpu_waves_per_eu(HSGPU_CONFIRM_WAVES, 8))) /* tuning builds: cap the registers for this many wavefronts per SIMD */
+#endif
+void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ WaveLds wave_lds[CONFIRM_THREADS / 64];
     __shared__ uint2 rest_q[CONFIRM_THREADS / 64][RQ_CAP];
     __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
@@ -1211,10 +1374,48 @@ __global__ __launch_bounds__(CONFIRM_THREADS) void hwlm_confirm_kernel(HsgpuScan
     const uint4 *region = args.cand + 2ull * r * args.cand_cap;
     uint2 *rq = rest_q[wave];
     uint32_t base = part * 128;
+#ifndef HSGPU_CONFIRM_FAST
+#define HSGPU_CONFIRM_FAST 1 /* tuning builds: 0 = the general step for every table */
+#endif
+    constexpr bool FAST = HSGPU_CONFIRM_FAST && HAS_A && !HAS_C && !S2 && !PAIR;
+    FastRs rs;
+    if (FAST) {
+        /* (+16: the window of a chunk's last position is read as three dwords from entry byte 24; runtime.hip allocates the slack) */
+        rs.region = __builtin_amdgcn_make_buffer_rsrc((void *)region, 0, (int)min((uint64_t)args.cand_cap * 32u + 16u, (uint64_t)0x7ffffff0), 0x00020000);
+        rs.ht_a = __builtin_amdgcn_make_buffer_rsrc((void *)t.ht_a, 0, (int)(16u << min(t.ht_a_log2, 26u)), 0x00020000);
+        rs.ht_b = __builtin_amdgcn_make_buffer_rsrc((void *)t.ht_b, 0, (int)(16u << min(t.ht_b_log2, 26u)), 0x00020000);
+        rs.lits = __builtin_amdgcn_make_buffer_rsrc((void *)t.lits, 0, (int)0x7ffffff0, 0x00020000);
+    }
     for (;;) {
         uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
         bool valid[2] = {false, false};
         bool fresh;
+        if (FAST) { /* the same schedule with masks for booleans (confirm_step_fast) */
+            const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
+            uint32_t vm[2];
+            if (base < n && nrq <= RQ_CAP - 128) {
+                const uint32_t i0 = base + lane, i1 = base + 64 + lane;
+                vm[0] = m_less(i0, n), vm[1] = m_less(i1, n); /* ~0 when i < n: past the region's fill, entry 0 without candidate bits */
+                idx[0] = i0 & vm[0], idx[1] = i1 & vm[1];
+                base += 128 * HSGPU_CONFIRM_SPLIT;
+                confirm_step_fast<HAS_B, true>(t, rs, rq, idx, pend, vm);
+            } else if (nrq) {
+                const uint32_t k = min(nrq, 128u), first = nrq - k;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    vm[u] = m_less(u * 64 + lane, k);
+                    const uint2 it = rq[(first + u * 64 + lane) & vm[u]];
+                    idx[u] = it.x & vm[u], pend[u] = it.y & vm[u];
+                }
+                if (lane == 0) t.wl->nrq = first;
+                confirm_step_fast<HAS_B, false>(t, rs, rq, idx, pend, vm);
+            } else {
+                break;
+            }
+            drain_matches(t, lane, 63);
+            flush_records(t, lane, OFLUSH);
+            continue;
+        }
         const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
         if (base < n && nrq <= RQ_CAP - 128) { /* the step may queue up to 128 more */
             fresh = true;
