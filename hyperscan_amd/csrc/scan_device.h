@@ -516,12 +516,13 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
     }
 }
 
-/* ---- the same step for stride-1 tables without 2-byte keys, written for what the vector unit charges -----------
- * The general step above is compiled from booleans and 64-bit values: 68 v_cndmask_b32 (a wave64 v_cndmask issues
- * at ~1/9 of the plain VOP2 rate on gfx950, profiles/r02_valu_lds_rates.txt), 64-bit shifts for the window, 64-bit
- * address arithmetic for every load -- ~470 vector instructions per step of 128 entries, and with them the confirm
- * kernel is bound by vector issue, not by its dependent reads. Here every condition is a 0 / ~0 MASK made with
- * plain arithmetic and applied with v_and / v_or; nothing on the common path selects.
+/* ---- the same step for stride-1 tables without 2-byte keys, in a third of the vector instructions ---------------
+ * The general step above is compiled from booleans and 64-bit values: 68 v_cndmask_b32 (most of them a boolean turned
+ * into 0 / 1 and compared again), 64-bit funnel shifts for the window, 64-bit address arithmetic for every load --
+ * ~470 vector instructions per step of 128 entries. Here every condition is a 0 / ~0 MASK made with plain
+ * arithmetic and applied with v_and / v_or; nothing on the common path selects: ~330 instructions, measured 8 %
+ * off the stage (profiles/r03_confirm_fast_ab.txt: the stage follows the number of divergent loads it issues more
+ * than its instruction count).
  *   entry     8 bytes {chunk, masks}; then the WINDOW itself is read: the 8 bytes ending at the candidate position
  *             are bytes [9 + j, 16 + j] of the 32-byte entry -- three aligned dwords and two v_alignbit, instead of
  *             six dwords in registers, two 64-bit funnel shifts and six selects
@@ -534,7 +535,7 @@ struct FastRs {
     __amdgpu_buffer_rsrc_t region, ht_a, ht_b, lits;
 };
 /* (inline asm: written as C the compiler recognises each of these as a sign-extended compare and goes back to
- * v_cmp + v_cndmask, which is exactly what this step exists to avoid) */
+ * v_cmp + v_cndmask and a boolean per condition) */
 __device__ __forceinline__ uint32_t m_zero31(uint32_t x) { /* x < 2^31: ~0 when x == 0 */
     uint32_t r;
     asm("v_add_u32_e32 %0, -1, %1\n\tv_ashrrev_i32_e32 %0, 31, %0" : "=v"(r) : "v"(x));
@@ -944,9 +945,10 @@ struct SpillState {
  * straight to this wavefront's private HBM region (ranked by ballot; no atomics,
  * no LDS staging). Everything wave-uniform here -- the fill, the room check, the
  * region -- lives in scalar registers (readfirstlane where the compiler would not see it):
- * as loop-carried vector values the fill and the flag cost two v_cndmask (~9 ns each,
- * profiles/r02_valu_lds_rates.txt), a vector compare and 64-bit vector address arithmetic
- * on every tile. The stores take a 32-bit lane offset against the region's descriptor. */
+ * as loop-carried vector values the fill and the flag cost two v_cndmask, a vector compare
+ * and 64-bit vector address arithmetic (v_lshlrev_b64, v_lshl_add_u64) on every tile of a
+ * loop that is bound by vector issue. The stores take a 32-bit lane offset against the
+ * region's descriptor. (profiles/r03_scalar_loop_ab.txt) */
 __device__ __forceinline__ void spill(SpillState &sp, uint32_t fold_shift, uint32_t chunk_idx, uint32_t acc, const Chunk &c) {
     const bool has = acc != 0;
     const unsigned long long bal = __ballot(has);
