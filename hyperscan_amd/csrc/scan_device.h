@@ -47,7 +47,11 @@
  *                       the literal the slot names; hits are queued in LDS and resolved
  *                       64 at a time (id/size, block lookup through the hint table, bound
  *                       checks), records stored into the wavefront's region, its fill
- *                       added to the partial sum of its group of regions (one atomic);
+ *                       added to the partial sum of its group of regions (one atomic).
+ *                       Stride-1 tables without 2-byte keys take confirm_step_fast: the
+ *                       window read straight from the entry, conditions as 0 / ~0 masks,
+ *                       a third of the general step's vector instructions. The stage is
+ *                       bound by the vector L1's outstanding misses;
  *   record_sort_kernel  one workgroup per share: places the share from the partial sums,
  *                       sorts its records by (block, end, literal) into the caller's
  *                       buffer (delivery order), writes *count, zeroes the control block
@@ -55,7 +59,8 @@
  * A fused variant (confirm inside the streaming kernel) is kept as the
  * always-correct fallback for inputs so dense that the candidate buffer
  * overflows (the role of the reference's flood path, flood_runtime.h:86-335);
- * it is launched after the other two and returns at once unless they overflowed.
+ * it runs alone where a scratch asks for it (tests, tuning) and behind the other two only
+ * where mapped host memory for the "again" note is unavailable.
  *
  * Block boundaries are invisible to the filter; the confirm step resolves the
  * block of a candidate and rejects matches that would start before their block
