@@ -526,8 +526,8 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
  * into 0 / 1 and compared again), 64-bit funnel shifts for the window, 64-bit address arithmetic for every load --
  * ~470 vector instructions per step of 128 entries. Here every condition is a 0 / ~0 MASK made with plain
  * arithmetic and applied with v_and / v_or; nothing on the common path selects: ~330 instructions, measured 8 %
- * off the stage (profiles/r03_confirm_fast_ab.txt: the stage follows the number of divergent loads it issues more
- * than its instruction count).
+ * off the stage (profiles/r03_confirm_fast_ab.txt). No more than that, because the stage is bound by the vector L1's
+ * outstanding misses: 10.45 M read requests per GiB at 473 cycles against 64 per CU (profiles/r03_confirm_mem.json).
  *   entry     8 bytes {chunk, masks}; then the WINDOW itself is read: the 8 bytes ending at the candidate position
  *             are bytes [9 + j, 16 + j] of the 32-byte entry -- three aligned dwords and two v_alignbit, instead of
  *             six dwords in registers, two 64-bit funnel shifts and six selects
