@@ -71,6 +71,7 @@ _SIGS = {
                                              C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "hsgpu_last_error": (C.c_char_p, []),
     "hsgpu_version": (C.c_char_p, []),
+    "hsgpu_source_hash": (C.c_char_p, []),
 }
 
 

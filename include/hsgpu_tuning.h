@@ -32,6 +32,10 @@ extern "C" {
  * workgroup size / workgroups per CU the runtime would choose (0 = its choice). */
 int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu);
 
+/* The first 32 hex digits of the sha256 over the sources this library was built from (csrc/Makefile, STAMPED): the built
+ * library is not in the repository, and a test compares this with the tree it runs in. */
+const char *hsgpu_source_hash(void);
+
 #ifdef __cplusplus
 }
 #endif
