@@ -145,6 +145,9 @@ struct hsgpu_scratch {
     hipEvent_t *ev_t = nullptr; /* the set of the scan being launched */
     uint64_t n_timed = 0;       /* scans launched with timing on */
     DevBuf tstamp;              /* [kRing][4] device wall clock: filter start (min) / end (max), confirm-stage end, pipeline end */
+    bool timing_wg = false;     /* enable == 2: per-workgroup stamps of the filter kernel too */
+    DevBuf wg_stamps;
+    unsigned wg_stamps_n = 0;   /* workgroups of the last stamped scan */
     double wall_clock_khz = 100000.0;
     DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats;
     DevBuf pipe_corpus[2], pipe_off[2], pipe_out[2], pipe_count; /* hsgpu_hwlm_exec_batch_cb: two chunks in flight */
@@ -156,8 +159,10 @@ struct hsgpu_scratch {
     unsigned long long *h_count = nullptr; /* pinned */
     uint32_t *h_note = nullptr, *d_note = nullptr; /* mapped pinned word the fused fallback sets (see HsgpuScanArgs::overflow_note) */
     int tune_fused = 0;                    /* hsgpu_scratch_set_tuning (tests / tuning runs) */
+    int tune_unfolded = 0;                 /* fused_only == 2: two-phase with record_sort_kernel behind the confirm kernel */
     unsigned tune_wg_threads = 0, tune_wg_per_cu = 0;
     uint64_t cand_div = 64;                /* corpus bytes per candidate entry of capacity: 16 (room for every chunk) once a scan overflowed */
+    unsigned dense_span = 0, dense_left = 0; /* dense mode lasts dense_span scans (doubling each time it is re-entered) */
     hsgpu_match_t *h_recs = nullptr;       /* pinned: hsgpu_hwlm_fetch_replay's landing area for the records */
     size_t h_recs_cap = 0;
     hipEvent_t ev_chunk[4] = {};           /* its D2H chunks */
@@ -259,6 +264,7 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->ctl.release();
     s->stats.release();
     s->tstamp.release();
+    s->wg_stamps.release();
     s->rec_stage.release();
     for (int i = 0; i < 2; i++) {
         s->pipe_corpus[i].release();
@@ -305,7 +311,25 @@ extern "C" int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable) {
             s->wall_clock_khz = khz;
     }
     s->timing = enable != 0;
+    s->timing_wg = enable == 2;
     s->n_timed = 0;
+    return HSGPU_SUCCESS;
+}
+
+/* tuning: the per-workgroup stamps of the last scan's filter kernel, in milliseconds relative to the earliest start:
+ * out[4 * w + {0: start, 1: prologue done, 2: wavefront 0's share done, 3: end}] (synchronises the device) */
+extern "C" int hsgpu_scratch_get_wg_stamps(hsgpu_scratch_t *s, float *out, unsigned max_wgs, unsigned *n_wgs) {
+    if (!s || !n_wgs || (max_wgs && !out)) return HSGPU_INVALID;
+    *n_wgs = s->wg_stamps_n;
+    if (!s->wg_stamps_n || !s->wg_stamps.p) return HSGPU_SUCCESS;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> v((size_t)s->wg_stamps_n * 4);
+    HIP_TRY(hipMemcpy(v.data(), s->wg_stamps.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < s->wg_stamps_n; w++) t0 = std::min(t0, v[4 * w]);
+    for (size_t w = 0; w < std::min<size_t>(s->wg_stamps_n, max_wgs); w++)
+        for (int k = 0; k < 4; k++) out[4 * w + k] = (float)((double)(v[4 * w + k] - t0) / s->wall_clock_khz);
     return HSGPU_SUCCESS;
 }
 
@@ -383,10 +407,28 @@ static int set_dyn_lds(const void *fn, size_t lds) {
 
 extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu) {
     if (!s || (wg_threads && (wg_threads % 64 || wg_threads < 256 || wg_threads > 1024)) || wg_per_cu > 4) return HSGPU_INVALID;
-    s->tune_fused = fused_only != 0;
+    s->tune_fused = fused_only == 1;
+    s->tune_unfolded = fused_only == 2;
     s->tune_wg_threads = wg_threads;
     s->tune_wg_per_cu = wg_per_cu;
     return HSGPU_SUCCESS;
+}
+
+/* how many confirm workgroups the device holds at once (per kernel instantiation: the register count differs) */
+static unsigned confirm_resident_workgroups(hsgpu_scratch *s, const void *f_conf) {
+    static std::mutex mu;
+    static std::map<const void *, int> per_cu;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = per_cu.find(f_conf);
+    if (it == per_cu.end()) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f_conf, HSGPU_CONFIRM_THREADS, 0) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 4;
+        }
+        it = per_cu.emplace(f_conf, nb).first;
+    }
+    return (unsigned)it->second * (unsigned)std::max(1, s->n_cu);
 }
 
 static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArgs &a, hipStream_t stream) {
@@ -473,7 +515,9 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * the next scan finds its block zeroed without a memset. */
     const size_t cand_ofs = (size_t)2 * n_rec;
     const size_t super_ofs = (cand_ofs + n_waves + 1 + 1) & ~(size_t)1; /* 8-byte aligned */
-    const size_t blk_words = (super_ofs + 2 * 257 + 3) & ~(size_t)3;
+    const size_t status_ofs = super_ofs + 2 * 257;                     /* folded pipeline: one status word per share, */
+    const size_t ticket_ofs = status_ofs + n_waves;                    /* and the ticket counter */
+    const size_t blk_words = (ticket_ofs + 1 + 3) & ~(size_t)3;
     /* a reallocated control buffer is garbage whatever its address: hipMalloc may hand the
      * freed range straight back, so growth is detected by capacity, never by pointer */
     const size_t ctl_cap_before = s->ctl.cap;
@@ -491,8 +535,35 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.rec_stage = (uint4 *)s->rec_stage.p;
     args.rec_counts = blk;
     args.rec_super = (unsigned long long *)(blk + super_ofs);
-    args.super_shift = 5; /* up to 256 supers: atomics on one address serialise (~0.1 us each), 64 regions share one here */
-    while (((n_rec + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
+    args.share_status = blk + status_ofs;
+    args.ticket = blk + ticket_ofs;
+    /* Dense input (the reference's flood case, src/fdr/flood_runtime.h:86-335): once a scan on this scratch ran out of
+     * candidate room (and told its caller to scan again), later scans give every 16-byte chunk an entry of its own -- the
+     * two-phase path can then not overflow, at the price of a candidate buffer twice the size of the corpus. */
+    if (two_phase) {
+        if (s->h_note && *s->h_note) {
+            /* (an overflow seen: dense mode for dense_span scans, twice as long every time it has to be re-entered) */
+            *s->h_note = 0;
+            s->cand_div = 16;
+            s->dense_span = std::min<unsigned>(s->dense_span ? s->dense_span * 2 : 16, 1u << 16);
+            s->dense_left = s->dense_span;
+        } else if (s->cand_div == 16 && s->dense_left && --s->dense_left == 0) {
+            /* Dense mode is not for ever (it costs a candidate buffer twice the size of the corpus and the unfolded pipeline):
+             * after dense_span scans without a note the scratch tries the ordinary sizing again and gives the big buffer back.
+             * If the input is still dense that scan reports "again", sets the note, and the span doubles. */
+            s->cand_div = 64;
+            s->cand.release();
+        }
+    }
+    /* The folded pipeline: the persistent confirm workgroups place and sort their shares themselves. Not for fused-only
+     * scratches, not in dense mode (a dense share is merged by a 1024-thread workgroup of record_sort_kernel), and not
+     * without the mapped "again" note (the fused kernel then has to run between confirm and sort). */
+    const bool fold = two_phase && s->cand_div != 16 && s->d_note && !s->tune_unfolded;
+    args.fold = fold ? 1u : 0u;
+    /* up to 256 supers: atomics on one address serialise (~0.1 us each). Unfolded: supers of regions (64 regions share one
+     * at 16 384 regions); folded: supers of shares */
+    args.super_shift = fold ? 3 : 5;
+    while ((((fold ? n_waves : n_rec) + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
     /* the regions fed by one filter wavefront: the records of one contiguous share of the corpus */
     args.group_regions = HSGPU_CONFIRM_SPLIT;
     args.stats = (unsigned long long *)s->stats.p;
@@ -501,6 +572,12 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     void *kargs[] = {&args};
     args.tstamp = nullptr;
     args.tstamp_next = nullptr;
+    args.wg_stamps = nullptr;
+    if (s->timing_wg && two_phase) {
+        if ((rv = s->wg_stamps.ensure((size_t)grid * 4 * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
+        args.wg_stamps = (unsigned long long *)s->wg_stamps.p;
+        s->wg_stamps_n = grid;
+    }
     if (s->timing) {
         const size_t slot = s->n_timed % hsgpu_scratch::kRing;
         s->ev_t = s->ev_ring[slot];
@@ -522,15 +599,12 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         /* phase 1 + 2. Every filter wavefront owns a private region of the candidate buffer: one 32-byte
          * entry per 64 corpus bytes on average, i.e. room for candidates in a quarter of all chunks. */
         args.cand_waves = n_waves;
-        /* Dense input (the reference's flood case, src/fdr/flood_runtime.h:86-335): once a scan on this scratch ran out of
-         * candidate room (and told its caller to scan again), later scans give every 16-byte chunk an entry of its own -- the
-         * two-phase path can then not overflow, at the price of a candidate buffer twice the size of the corpus. */
-        if (s->h_note && *s->h_note) {
-            *s->h_note = 0;
-            s->cand_div = 16;
-        }
         uint64_t cand_div = s->cand_div;
         args.cand_cap = (uint32_t)std::max<uint64_t>(256, (a.total / cand_div + n_waves - 1) / n_waves);
+        /* dense mode must not be able to overflow: sized from the kernel's own partition -- a wavefront owns
+         * ceil(tiles / wavefronts) whole 1 KiB tiles of 64 chunks, and the one that takes the partial last tile 64 more
+         * (total / 16 / n_waves rounds the other way: a fully dense share overflowed on every retry; advisor, round 3) */
+        if (cand_div == 16) args.cand_cap = (uint32_t)std::max<uint64_t>(256, (((a.total >> 10) + n_waves - 1) / n_waves + 1) * 64);
         if ((rv = s->cand.ensure((uint64_t)args.cand_cap * n_waves * 32 + 64)) != HSGPU_SUCCESS) return rv; /* + slack: the confirm kernel reads one dword past an entry */
         args.cand = (uint4 *)s->cand.p;
         args.cand_counts = blk + cand_ofs;
@@ -538,7 +612,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
-        HIP_TRY(hipLaunchKernel(f_conf, dim3((n_rec + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64)), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
+        /* persistent confirm workgroups: as many as the device holds at once, shares handed out by ticket */
+        HIP_TRY(hipLaunchKernel(f_conf, dim3(std::min<unsigned>(n_waves, confirm_resident_workgroups(s, f_conf))), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         /* No fused kernel behind it (it used to be launched on every scan, to return at once): a scan whose candidate regions
          * overflowed reports count = cap + 1 like one whose staging regions did -- "again" -- and sets the scratch's note,
          * so that the next scan has room for every chunk. Without the note (mapped host memory unavailable) the always-correct
@@ -546,9 +621,10 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if (!s->d_note) HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
     }
     if (s->timing) s->n_timed++;
-    /* one workgroup per share of the corpus: its records sorted into place; the control block back to zero */
-    HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions),
-                            dim3(s->cand_div == 16 ? 1024 : 256), kargs, 0, stream));
+    /* unfolded: one workgroup per share of the corpus: its records sorted into place; the control block back to zero */
+    if (!fold)
+        HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions),
+                                dim3(s->cand_div == 16 ? 1024 : 256), kargs, 0, stream));
     s->ctl_clean = true;
     s->ctl_parity ^= 1u;
     return HSGPU_SUCCESS;

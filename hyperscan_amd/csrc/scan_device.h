@@ -269,21 +269,25 @@ __device__ __forceinline__ void flush_records(const Tables &t, uint32_t lane, ui
     }
 }
 
-/* End of a wavefront's work: publish how much of its region is in use. */
-__device__ __forceinline__ void publish_records(const Tables &t, const HsgpuScanArgs &args, uint32_t lane,
-                                                uint32_t region) {
+/* End of a wavefront's work on one region: publish how much of the region is in use; returns the fill (wave-uniform).
+ * to_supers: the pipeline with a sort kernel of its own (fused scans, dense mode) -- the fills of 2^super_shift consecutive
+ * regions are added up here, one atomic per region, so that every sort workgroup can place its share without a scan
+ * kernel in between. The folded pipeline (hwlm_confirm_kernel) adds up per SHARE instead, after its workgroup barrier. */
+__device__ __forceinline__ uint32_t publish_records(const Tables &t, const HsgpuScanArgs &args, uint32_t lane,
+                                                    uint32_t region, bool to_supers = true) {
     flush_records(t, lane, 1);
+    uint32_t fill32 = 0;
     if (lane == 0) {
         const uint32_t front = t.wl->nfront,
                        back = __hip_atomic_load(&t.wl->nback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         args.rec_counts[2 * region] = front;
         args.rec_counts[2 * region + 1] = back;
-        /* one atomic per region (not per record): the fills of 2^super_shift consecutive regions added up, so that
-         * every sort workgroup can place its share without a scan kernel in between */
         const unsigned long long fill = (unsigned long long)front + back;
-        if (fill) atomicAdd(&args.rec_super[region >> args.super_shift], fill);
+        if (to_supers && fill) atomicAdd(&args.rec_super[region >> args.super_shift], fill);
         if (fill > args.rec_cap) atomicAdd(&args.rec_super[256], 1ull); /* the region lost records */
+        fill32 = (uint32_t)min(fill, 0x7fffffffull);
     }
+    return __builtin_amdgcn_readfirstlane(fill32);
 }
 
 template <bool DEFER = false>
@@ -1024,11 +1028,15 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
 __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t lane) {
     t.wl = wl;
     if (lane == 0) {
-        wl->nrec = 0;
-        wl->nfront = 0;
-        wl->nback = 0;
-        wl->nmq = 0;
-        wl->nrq = 0;
+        /* (an opaque zero: inside the persistent confirm loop the compiler otherwise keeps a quad of zero registers alive
+         * across the whole confirm step for these stores -- four registers of a budget that decides the occupancy) */
+        uint32_t z = 0;
+        asm volatile("" : "+v"(z));
+        wl->nrec = z;
+        wl->nfront = z;
+        wl->nback = z;
+        wl->nmq = z;
+        wl->nrq = z;
     }
 }
 
@@ -1106,6 +1114,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     }
     if (FUSED && args.cand_counts && args.overflow_note && blockIdx.x == 0 && threadIdx.x == 0) *args.overflow_note = 1u;
     if (!FUSED && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
+    if (!FUSED && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x] = wall_clock64();
 
     const uint32_t flog2 = args.t_filter_log2;
     const uint32_t nw = (PAIR || WIDE) ? (2u << flog2) : REPL ? (32u << flog2) : (1u << flog2);
@@ -1183,12 +1192,17 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         const uint32_t i = threadIdx.x + u * blockDim.x;
         img[u] = i < nw / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
     }
+#ifndef HSGPU_HINTS_LATE
+#define HSGPU_HINTS_LATE 0 /* 1: the block hints are written after the wavefront's share instead of in front of it */
+#endif
     const bool hints = !FUSED && args.hint_in_filter;
     constexpr int HK = HSGPU_PROLOGUE_HK; /* every lane takes 8 consecutive blocks: 9 offsets, 512 blocks per wavefront and step */
     const uint64_t hb0 = ((uint64_t)wave_global * 64 + lane) * HK;
+#if !HSGPU_HINTS_LATE
     uint64_t ho[HK + 1];
 #pragma unroll
     for (int k = 0; k <= HK; k++) ho[k] = hints ? args.off[min(hb0 + k, args.nblocks)] : 0; /* clamped: no branches */
+#endif
     const bool streaming = n_own != 0;
     Chunk c0, c1, c2, c3, c4, c5, c6, c7;
     c0.d = c1.d = c2.d = c3.d = c4.d = c5.d = c6.d = c7.d = make_uint4(0, 0, 0, 0);
@@ -1215,6 +1229,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     }
     /* two-phase: the confirm kernel's block hints are written here (a hint kernel on a side stream needed a
      * fork/join pair of cross-stream waits around the confirm launch) */
+#if !HSGPU_HINTS_LATE
     if (hints) {
 #pragma unroll
         for (int k = 0; k < HK; k++)
@@ -1222,7 +1237,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         for (uint64_t w0 = (uint64_t)wave_global + n_waves; w0 * (64 * HK) <= args.nblocks; w0 += n_waves)
             write_block_hints_batch<HK>(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, w0 * (64 * HK), lane);
     }
+#endif
     __syncthreads();
+    if (!FUSED && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x + 1] = wall_clock64();
 
     Tables t;
     uint32_t qcount = 0;
@@ -1339,133 +1356,32 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         args.cand_counts[wave_global] = sp.written;
         if (sp.overflow) args.cand_counts[n_waves] = 1;
     }
-    if (!FUSED && args.tstamp) {
+    if (!FUSED && args.wg_stamps && wave == 0 && lane == 0) args.wg_stamps[4 * blockIdx.x + 2] = wall_clock64(); /* (wavefront 0's share done) */
+#if HSGPU_HINTS_LATE
+    /* the hints depend on the offsets alone and only the NEXT kernel reads them: written behind the share, they cost the
+     * wavefronts that finish early nothing that anybody waits for, instead of sitting in front of every wavefront's first tile */
+    if (hints)
+        for (uint64_t w0 = (uint64_t)wave_global; w0 * (64 * HK) <= args.nblocks; w0 += n_waves)
+            write_block_hints_batch<HK>(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, w0 * (64 * HK), lane);
+#endif
+    if (!FUSED && (args.tstamp || args.wg_stamps)) {
         __syncthreads();
-        if (threadIdx.x == 0) atomicMax(&args.tstamp[1], (unsigned long long)wall_clock64());
+        if (threadIdx.x == 0) {
+            const unsigned long long now = wall_clock64();
+            if (args.tstamp) atomicMax(&args.tstamp[1], now);
+            if (args.wg_stamps) args.wg_stamps[4 * blockIdx.x + 3] = now;
+        }
     }
 }
 
-/* ---- phase 2: confirm. HSGPU_CONFIRM_SPLIT wavefronts share one filter
- * wavefront's candidate region (batch b of 64 entries goes to wavefront
- * b % SPLIT), so that even a few thousand entries per region are confirmed by
- * many short dependent-read chains in parallel rather than one long one. ---- */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
-__global__ __launch_bounds__(CONFIRM_THREADS)
-#ifdef HSGPU_CONFIRM_WAVES
-__attribute__((amdgpu_waves_per_eu(HSGPU_CONFIRM_WAVES, 8))) /* tuning builds: cap the registers for this many wavefronts per SIMD */
-#endif
-void hwlm_confirm_kernel(HsgpuScanArgs args) {
-    __shared__ WaveLds wave_lds[CONFIRM_THREADS / 64];
-    __shared__ uint2 rest_q[CONFIRM_THREADS / 64][RQ_CAP];
-    __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
-    if (args.cand_counts[args.cand_waves]) return; /* overflow: the fused fallback redoes the scan */
-    const bool gated = !PAIR && (args.t_flags & HSGPU_F_GATE);
-    if (gated) { /* the whole workgroup, before any wavefront leaves */
-        const uint4 *src = (const uint4 *)(args.blob + args.t_off_c2bits);
-        for (uint32_t i = threadIdx.x; i < 512; i += CONFIRM_THREADS) key_gate[i] = src[i];
-        __syncthreads();
-    }
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t cw = blockIdx.x * (CONFIRM_THREADS / 64) + wave; /* confirm wavefront = record region */
-    if (cw >= args.rec_regions) return;
-    const uint32_t r = cw / HSGPU_CONFIRM_SPLIT, part = cw % HSGPU_CONFIRM_SPLIT;
-    const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
-    if (part * 128 >= n) return; /* nothing for this wavefront (its record counts stay zero) */
-    Tables t;
-    init_tables(t, args);
-    if (gated) t.key_gate = (const uint32_t *)key_gate;
-    init_wave_lds(t, wave_lds + wave, lane);
-    t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
-    t.rec_cap = args.rec_cap;
-    const uint4 *region = args.cand + 2ull * r * args.cand_cap;
-    uint2 *rq = rest_q[wave];
-    uint32_t base = part * 128;
-#ifndef HSGPU_CONFIRM_FAST
-#define HSGPU_CONFIRM_FAST 1 /* tuning builds: 0 = the general step for every table */
-#endif
-    constexpr bool FAST = HSGPU_CONFIRM_FAST && HAS_A && !HAS_C && !S2 && !PAIR;
-    FastRs rs;
-    if (FAST) {
-        /* (+16: the window of a chunk's last position is read as three dwords from entry byte 24; runtime.hip allocates the slack) */
-        rs.region = __builtin_amdgcn_make_buffer_rsrc((void *)region, 0, (int)min((uint64_t)args.cand_cap * 32u + 16u, (uint64_t)0x7ffffff0), 0x00020000);
-        rs.ht_a = __builtin_amdgcn_make_buffer_rsrc((void *)t.ht_a, 0, (int)(16u << min(t.ht_a_log2, 26u)), 0x00020000);
-        rs.ht_b = __builtin_amdgcn_make_buffer_rsrc((void *)t.ht_b, 0, (int)(16u << min(t.ht_b_log2, 26u)), 0x00020000);
-        rs.lits = __builtin_amdgcn_make_buffer_rsrc((void *)t.lits, 0, (int)0x7ffffff0, 0x00020000);
-    }
-    for (;;) {
-        uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
-        bool valid[2] = {false, false};
-        bool fresh;
-        if (FAST) { /* the same schedule with masks for booleans (confirm_step_fast) */
-            const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
-            uint32_t vm[2];
-            if (base < n && nrq <= RQ_CAP - 128) {
-                const uint32_t i0 = base + lane, i1 = base + 64 + lane;
-                vm[0] = m_less(i0, n), vm[1] = m_less(i1, n); /* ~0 when i < n: past the region's fill, entry 0 without candidate bits */
-                idx[0] = i0 & vm[0], idx[1] = i1 & vm[1];
-                base += 128 * HSGPU_CONFIRM_SPLIT;
-                confirm_step_fast<HAS_B, true>(t, rs, rq, idx, pend, vm);
-            } else if (nrq) {
-                const uint32_t k = min(nrq, 128u), first = nrq - k;
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    vm[u] = m_less(u * 64 + lane, k);
-                    const uint2 it = rq[(first + u * 64 + lane) & vm[u]];
-                    idx[u] = it.x & vm[u], pend[u] = it.y & vm[u];
-                }
-                if (lane == 0) t.wl->nrq = first;
-                confirm_step_fast<HAS_B, false>(t, rs, rq, idx, pend, vm);
-            } else {
-                break;
-            }
-            drain_matches(t, lane, 63);
-            flush_records(t, lane, OFLUSH);
-            continue;
-        }
-        const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
-        if (base < n && nrq <= RQ_CAP - 128) { /* the step may queue up to 128 more */
-            fresh = true;
-            const uint32_t i0 = base + lane, i1 = base + 64 + lane;
-            valid[0] = i0 < n, valid[1] = i1 < n;
-            idx[0] = valid[0] ? i0 : 0, idx[1] = valid[1] ? i1 : 0; /* n > 0 here: entry 0 exists */
-            base += 128 * HSGPU_CONFIRM_SPLIT;
-        } else if (nrq) { /* entries with candidate bits left: same path, next bit */
-            fresh = false;
-            const uint32_t k = min(nrq, 128u), first = nrq - k;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                valid[u] = u * 64 + lane < k;
-                const uint2 it = rq[valid[u] ? first + u * 64 + lane : 0];
-                idx[u] = valid[u] ? it.x : 0, pend[u] = valid[u] ? it.y : 0;
-            }
-            if (lane == 0) t.wl->nrq = first;
-        } else {
-            break;
-        }
-        confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, fresh);
-        drain_matches(t, lane, 63);
-        flush_records(t, lane, OFLUSH);
-    }
-    drain_matches(t, lane, 0);
-    publish_records(t, args, lane, cw);
-}
-
-/* ---- phase 3: the records in delivery order ---------------------------------------------------
+/* ---- phase 3 helpers: the records in delivery order -------------------------------------------
  * hwlmExec delivers callbacks in non-decreasing `end` (src/hwlm/hwlm.h:101-118) and Rose relies on it
  * (src/rose/match.c:396-476); a batch delivers block by block. The output of a scan is therefore sorted by
  * (block, end, literal index). Every filter wavefront streams ONE contiguous share of the corpus (see the
- * tile loop), so the staging regions fed from its candidates -- consecutive region numbers -- hold exactly
- * the records of that share, and the shares follow each other in region order:
- *   publish      every producing wavefront adds its region's fill to the sum of its "super" (2^super_shift
- *                consecutive regions, at most 256 supers): one atomic per region, not per record
- *   record_sort  one workgroup per share: where its records go = the supers in front of it + the fills in front
- *                of it inside its own super (one round trip of independent loads); gathers the records of its
- *                regions, sorts them (ranks by counting up to 64 records, a bitonic network in LDS up to SORT_LDS,
- *                in place in the output beyond) and writes them to their place; workgroup 0 writes *count;
- *                then the OTHER control block (the previous scan's) goes back to zero for the next scan.
- * No atomic per record, no scan kernel and no global sort: a share holds a few thousand records at most on
- * ordinary input. (A one-workgroup scan kernel between confirm and sort cost 11-19 us plus a launch gap.) */
+ * tile loop), so the staging regions fed from its candidates -- HSGPU_CONFIRM_SPLIT consecutive region numbers --
+ * hold exactly the records of that share, and the shares follow each other in region order: delivery order is one
+ * small sort per share plus knowing how many records the shares in front of it hold. No atomic per record and no
+ * global sort: a share holds a few hundred records on ordinary input. */
 constexpr uint32_t SORT_LDS = 1024; /* largest share sorted in LDS (16 KiB of records) */
 constexpr uint32_t SORT_THREADS = 256;
 
@@ -1495,14 +1411,398 @@ __device__ __forceinline__ void bitonic_sort(PTR x, uint32_t n) {
     }
 }
 
-/* 256 threads per share; 1024 once the scratch has seen dense input (runtime.hip): a dense share holds tens of thousands of
- * records and its sort is this one workgroup's work */
+/* Workgroup-convergent: the records of the staging regions [first, last) (one share: <= 64 regions) gathered, sorted by
+ * (block, end, literal index) and written to out[base ...). buf: SORT_LDS records of LDS. A share one of whose regions
+ * lost records (its fill counter ran past its capacity: the scan reports "again") is left alone. */
+__device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf, uint32_t first, uint32_t last,
+                                           unsigned long long base) {
+    const uint32_t NT = blockDim.x, tid = threadIdx.x, lane = tid & 63;
+    uint4 *out = (uint4 *)args.out;
+    const uint2 *counts = (const uint2 *)args.rec_counts;
+    /* the fills of all regions of the share at once (lane r = region first + r) and where each region's records
+     * start inside the share */
+    const uint32_t nreg = last - first; /* <= 64 */
+    const uint2 my = lane < nreg ? counts[first + lane] : make_uint2(0, 0);
+    if (__ballot((unsigned long long)my.x + my.y > args.rec_cap)) return; /* (every wavefront holds the same fills: uniform) */
+    uint32_t incl = my.x + my.y;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += v;
+    }
+    const uint32_t n = __shfl(incl, 63);
+    const uint32_t my_at = lane < nreg ? incl - (my.x + my.y) : n;
+    if (!n) return;
+    const bool in_lds = n <= SORT_LDS;
+    /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
+     * spilled to the back) */
+    for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += NT) { /* whole wavefronts: shuffles below */
+        uint32_t r = 0;
+        for (uint32_t k = 1; k < nreg; k++) r += __shfl(my_at, k) <= i ? 1u : 0u; /* the last region starting at or before i */
+        const uint32_t f = __shfl(my.x, r), at = __shfl(my_at, r), j = i - at;
+        if (i < n) {
+            const uint4 *region = args.rec_stage + (uint64_t)(first + r) * args.rec_cap;
+            const uint4 rec = j < f ? region[j] : region[args.rec_cap - 1 - (j - f)];
+            if (in_lds) buf[i] = rec;
+            else out[base + i] = rec;
+        }
+    }
+    __syncthreads();
+    if (n <= 64) {
+        /* rank by counting: one record per lane of the first wavefront, every lane walks the share
+         * (all lanes read the same LDS address: a broadcast); no barriers, no compare-exchange chains */
+        if (tid < n) {
+            const uint4 mine = buf[tid];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < n; q++) { /* equal keys cannot occur; if they did, the gather order keeps ranks distinct */
+                const uint4 o = buf[q];
+                rank += (rec_less(o, mine) || (q < tid && !rec_less(mine, o))) ? 1u : 0u;
+            }
+            out[base + rank] = mine;
+        }
+    } else if (in_lds) {
+        bitonic_sort(buf, n);
+        for (uint32_t i = tid; i < n; i += NT) out[base + i] = buf[i];
+    } else {
+        /* a dense share (the reference's flood case, src/fdr/flood_runtime.h:86-335: thousands of records from a
+         * few KiB of corpus): tiles of SORT_LDS records sorted in LDS, then merge passes between the output and
+         * the share's own staging regions (free once gathered; together at least n records long), every thread
+         * merging MERGE_SEG outputs from the split point its diagonal gives (merge path). The bitonic network
+         * run in place in global memory took 28 ms for 8 192 records. */
+        uint4 *a = out + base, *b = args.rec_stage + (uint64_t)first * args.rec_cap;
+        for (uint32_t t0 = 0; t0 < n; t0 += SORT_LDS) {
+            const uint32_t cnt = min(SORT_LDS, n - t0);
+            for (uint32_t i = tid; i < cnt; i += NT) buf[i] = a[t0 + i];
+            __syncthreads();
+            bitonic_sort(buf, cnt);
+            for (uint32_t i = tid; i < cnt; i += NT) a[t0 + i] = buf[i];
+            __threadfence_block();
+            __syncthreads();
+        }
+        constexpr uint32_t MERGE_SEG = 8;
+        for (uint32_t w = SORT_LDS; w < n; w <<= 1) {
+            for (uint32_t o = tid * MERGE_SEG; o < n; o += NT * MERGE_SEG) {
+                const uint32_t pair = o / (2 * w) * (2 * w); /* this output segment lies in the merge of runs at pair */
+                const uint32_t la = min(w, n - pair), lb = min(w, n - min(n, pair + w));
+                const uint4 *ra = a + pair, *rb = a + pair + la;
+                const uint32_t d = o - pair; /* diagonal: d outputs come before this segment */
+                /* i elements of run A and d - i of run B precede: the smallest i with A[i] > B[d - i - 1] fails */
+                uint32_t lo = d > lb ? d - lb : 0, hi = min(d, la);
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (rec_less(rb[d - mid - 1], ra[mid])) hi = mid; /* B's element first: take fewer of A */
+                    else lo = mid + 1;
+                }
+                uint32_t i = lo, j = d - lo;
+                const uint32_t stop = min(o + MERGE_SEG, min(n, pair + la + lb));
+                for (uint32_t k = o; k < stop; k++) {
+                    const bool take_b = i >= la || (j < lb && rec_less(rb[j], ra[i]));
+                    b[k] = take_b ? rb[j++] : ra[i++];
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            uint4 *t = a;
+            a = b;
+            b = t;
+        }
+        if (a != out + base) { /* an odd number of passes left the result in the staging area */
+            for (uint32_t i = tid; i < n; i += NT) out[base + i] = a[i];
+        }
+    }
+}
+
+/* Last kernel of a scan, every workgroup. The control words of THIS scan are read across workgroups (fills, sums,
+ * tickets), so nobody can zero them here; instead every workgroup zeroes its slice of the OTHER control block, the one
+ * the previous scan used and the next scan will use: no memset in front of any scan. Plus the cumulative statistics
+ * for hsgpu_scratch_get_stats (1024 counters per workgroup: only a handful of workgroups touch the statistics word). */
+__device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
+    const uint32_t NT = blockDim.x, tid = threadIdx.x, lane = tid & 63;
+    {
+        uint4 *other = (uint4 *)args.ctl_other;
+        const uint32_t n4 = args.ctl_other_words >> 2, per = (n4 + gridDim.x - 1) / gridDim.x;
+        const uint32_t lo = blockIdx.x * per, hi = min(n4, lo + per);
+        for (uint32_t i = lo + tid; i < hi; i += NT) other[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (!args.cand_counts || blockIdx.x * 1024u > args.cand_waves) return; /* (uniform per workgroup) */
+    uint32_t v = 0, o = 0;
+    for (uint32_t i = blockIdx.x * 1024 + tid; i < min(args.cand_waves + 1, (blockIdx.x + 1) * 1024); i += NT) {
+        const uint32_t c = args.cand_counts[i];
+        if (i == args.cand_waves) o = c;
+        else v += c;
+    }
+    unsigned long long vs = v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) vs += __shfl_xor(vs, d);
+    const unsigned long long any_o = __ballot(o != 0);
+    if (lane == 0) {
+        if (vs) atomicAdd(&args.stats[0], vs);
+        if (any_o) atomicAdd(&args.stats[1], 1ull);
+    }
+}
+
+/* ---- phase 2 (+ 3): confirm, placement, sort -- one persistent kernel ------------------------------------------
+ * A workgroup of HSGPU_CONFIRM_SPLIT wavefronts takes one SHARE at a time (= one filter wavefront's candidate region;
+ * batch b of 64 entries goes to wavefront b % SPLIT, so that even a few thousand entries are confirmed by several
+ * short dependent-read chains in parallel), in ticket order, until the tickets run out. Round 3 launched one
+ * short-lived wavefront per (share, part) -- 16 384 of them for a 1 GiB scan -- and then 16 384 more for the sort
+ * kernel: the machine starts ~300 wavefronts per microsecond, so each of the two kernels had a floor of ~55 us
+ * whatever it did, and the 8 KiB key gate was staged 4 096 times. Now the grid is what the device holds at once
+ * (workgroups per CU x CUs), the gate is staged once per workgroup, and in the FOLDED pipeline (args.fold) the same
+ * workgroup also places and sorts the share's records -- there is no sort kernel behind it:
+ *   publish   after the share's barrier one thread adds {1 << 40 | records} to the sum of the share's "super"
+ *             (2^super_shift consecutive shares, at most 256 supers: one atomic per share) and stores the share's
+ *             own status word {valid | records}
+ *   place     where a share's records go = the sums of the supers in front of its own (complete once their share
+ *             count is full) + the status words of the shares in front of it inside its own super: two rounds of
+ *             independent loads by one wavefront, spinning only while a share in front is still being confirmed
+ *   deferred  the placement of share k is done AFTER the workgroup has confirmed its next share: by then the shares in
+ *             front of k (lower tickets, taken earlier) have long been published, so nobody waits. Tickets make it
+ *             deadlock-free without assuming that the whole grid is resident: a workgroup only ever waits for
+ *             lower tickets, whose holders are running and publish without waiting for anybody.
+ *   sort      sort_share above, in the LDS the confirm state occupied (dead between two shares)
+ * The workgroup that places the last share knows the total and writes *count. The unfolded pipeline (fused scans,
+ * dense mode: 1024-thread sort workgroups) keeps record_sort_kernel below. */
+struct ConfirmLds {
+    WaveLds wave[CONFIRM_THREADS / 64];
+    uint2 rest_q[CONFIRM_THREADS / 64][RQ_CAP];
+};
+static_assert(sizeof(ConfirmLds) <= SORT_LDS * sizeof(uint4), "the confirm state and the sort buffer share one LDS area");
+static_assert(CONFIRM_THREADS / 64 == HSGPU_CONFIRM_SPLIT, "one wavefront per part of a share");
+constexpr uint32_t SPIN_LIMIT = 1u << 22; /* placement: a share in front that never publishes (cannot happen) ends the wait */
+
+/* The kernel's argument block re-read from the kernarg segment at the point of use. The confirm step runs with every scalar
+ * register taken (104 of 104: table pointers, descriptors, bounds); arguments that only the per-share bookkeeping needs
+ * (tickets, sums, the sort's buffers) would otherwise be loaded at kernel entry and held -- or rather spilled into vector
+ * lanes and read back with v_readlane inside the step -- for the whole persistent loop. The empty asm hides where the
+ * pointer comes from, so the loads stay behind it. (The kernel has one by-value argument: it starts the segment.) */
+__device__ __forceinline__ const HsgpuScanArgs &cold_args() {
+    const void *p = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const HsgpuScanArgs *)p;
+}
+
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
+__global__ __launch_bounds__(CONFIRM_THREADS)
+#ifndef HSGPU_CONFIRM_WAVES
+#define HSGPU_CONFIRM_WAVES 6
+#endif
+/* Registers capped for six wavefronts per SIMD (80): what the kernel's LDS admits (six workgroups per CU). The scheduler has no
+ * occupancy target of its own here and takes 94-98 registers for the persistent loop -- five wavefronts; capped, the 4-byte-key
+ * variants keep everything in registers and the others spill a few dwords outside the confirm step (tools/kernel_regs.sh). */
+__attribute__((amdgpu_waves_per_eu(HSGPU_CONFIRM_WAVES, 8)))
+void hwlm_confirm_kernel(HsgpuScanArgs args) {
+    constexpr uint32_t W = CONFIRM_THREADS / 64;
+    __shared__ __attribute__((aligned(16))) uint4 lds_area[SORT_LDS]; /* ConfirmLds while confirming, the sort buffer while sorting */
+    __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
+    __shared__ uint32_t s_share, s_fill[W];
+    __shared__ unsigned long long s_base;
+    ConfirmLds &L = *(ConfirmLds *)lds_area;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool fold = args.fold != 0;
+    const uint32_t n_shares = args.cand_waves;
+    if (args.cand_counts[n_shares]) { /* candidate overflow: nothing was confirmed, the total is unknown */
+        if (!fold) return;             /* the kernels behind this one report (or redo the scan) */
+        if (blockIdx.x == 0 && tid == 0) {
+            /* cap + 1 ("again"), and the word in mapped host memory that makes the next scan on this scratch give every
+             * chunk an entry of its own */
+            *args.count = args.cap + 1;
+            if (args.overflow_note) *args.overflow_note = 1u;
+            if (args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64();
+            if (args.tstamp_next) args.tstamp_next[0] = ~0ull, args.tstamp_next[1] = args.tstamp_next[2] = args.tstamp_next[3] = 0;
+        }
+        scan_epilogue(args);
+        return;
+    }
+    const bool gated = !PAIR && (args.t_flags & HSGPU_F_GATE);
+    if (gated) { /* once per workgroup */
+        const uint4 *src = (const uint4 *)(args.blob + args.t_off_c2bits);
+        for (uint32_t i = tid; i < 512; i += CONFIRM_THREADS) key_gate[i] = src[i];
+    }
+    Tables t;
+    init_tables(t, args);
+    if (gated) t.key_gate = (const uint32_t *)key_gate;
+    t.rec_cap = args.rec_cap;
+    uint2 *rq = L.rest_q[wave];
+#ifndef HSGPU_CONFIRM_FAST
+#define HSGPU_CONFIRM_FAST 1 /* tuning builds: 0 = the general step for every table */
+#endif
+    constexpr bool FAST = HSGPU_CONFIRM_FAST && HAS_A && !HAS_C && !S2 && !PAIR;
+    FastRs rs;
+    if (FAST) {
+        rs.ht_a = __builtin_amdgcn_make_buffer_rsrc((void *)t.ht_a, 0, (int)(16u << min(t.ht_a_log2, 26u)), 0x00020000);
+        rs.ht_b = __builtin_amdgcn_make_buffer_rsrc((void *)t.ht_b, 0, (int)(16u << min(t.ht_b_log2, 26u)), 0x00020000);
+        rs.lits = __builtin_amdgcn_make_buffer_rsrc((void *)t.lits, 0, (int)0x7ffffff0, 0x00020000);
+    }
+
+    /* Workgroup-convergent: where share p's n_p records go (spinning on the shares in front only while they are still being
+     * confirmed), then its sort. */
+    auto place_and_sort = [&](uint32_t p, uint32_t n_p) {
+        const HsgpuScanArgs &args = cold_args(); /* (shadows the kernel's: see cold_args) */
+        if (wave == 0) {
+            const uint32_t ss = args.super_shift, S = p >> ss;
+            unsigned long long before = 0;
+            uint32_t spins = 0;
+            bool bad = false;
+            for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
+                unsigned long long v;
+                for (;;) {
+                    v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > SPIN_LIMIT) bad = true;
+                }
+                before += v & ((1ull << 40) - 1);
+            }
+            for (uint32_t i = (S << ss) + lane; i < p; i += 64) { /* the shares in front inside its own super */
+                uint32_t v;
+                for (;;) {
+                    v = __hip_atomic_load(&args.share_status[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 31) || bad) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > SPIN_LIMIT) bad = true;
+                }
+                before += v & 0x7fffffffu;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+            const bool any_bad = __ballot(bad) != 0;
+            if (lane == 0) {
+                s_base = before;
+                if (any_bad) atomicAdd(&args.rec_super[256], 1ull);
+                if (p + 1 == n_shares) {
+                    /* the last share: the total is known. A region that ran out of space lost records; its fill counter kept
+                     * counting, so the total is still exact: report it, but never a value <= cap (that would claim the
+                     * output is complete) */
+                    const unsigned long long all = before + n_p;
+                    const unsigned long long flag =
+                        __hip_atomic_load(&args.rec_super[256], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
+                    *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned long long base = rfl64(s_base);
+        if (n_p && base + n_p <= args.cap) sort_share(args, lds_area, p * W, p * W + W, base);
+        if (p + 1 == n_shares && tid == 0 && args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64(); /* (the scan is as good as done) */
+    };
+
+    uint32_t pending = ~0u, pending_n = 0;
+    for (;;) {
+        if (tid == 0) s_share = __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads(); /* (also: the gate is staged; the sort of the share before is done with the LDS area) */
+        const uint32_t r = __builtin_amdgcn_readfirstlane(s_share); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
+        if (r >= n_shares) break;
+        /* this wavefront's part of share r: batches wave, wave + W, ... of 128 candidate entries */
+        const uint32_t cw = r * W + wave; /* its record region */
+        const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
+        init_wave_lds(t, &L.wave[wave], lane);
+        uint32_t fill = 0;
+        if (wave * 128 < n) { /* else nothing for this wavefront: its record counts stay zero */
+            t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
+            const uint4 *region = args.cand + 2ull * r * args.cand_cap;
+            /* (+16: the window of a chunk's last position is read as three dwords from entry byte 24; runtime.hip allocates the slack) */
+            if (FAST) rs.region = __builtin_amdgcn_make_buffer_rsrc((void *)region, 0, (int)min((uint64_t)args.cand_cap * 32u + 16u, (uint64_t)0x7ffffff0), 0x00020000);
+            uint32_t base = wave * 128;
+            for (;;) {
+                uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
+                bool valid[2] = {false, false};
+                bool fresh;
+                if (FAST) { /* the same schedule with masks for booleans (confirm_step_fast) */
+                    const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
+                    uint32_t vm[2];
+                    if (base < n && nrq <= RQ_CAP - 128) {
+                        const uint32_t i0 = base + lane, i1 = base + 64 + lane;
+                        vm[0] = m_less(i0, n), vm[1] = m_less(i1, n); /* ~0 when i < n: past the region's fill, entry 0 without candidate bits */
+                        idx[0] = i0 & vm[0], idx[1] = i1 & vm[1];
+                        base += 128 * W;
+                        confirm_step_fast<HAS_B, true>(t, rs, rq, idx, pend, vm);
+                    } else if (nrq) {
+                        const uint32_t k = min(nrq, 128u), first = nrq - k;
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            vm[u] = m_less(u * 64 + lane, k);
+                            const uint2 it = rq[(first + u * 64 + lane) & vm[u]];
+                            idx[u] = it.x & vm[u], pend[u] = it.y & vm[u];
+                        }
+                        if (lane == 0) t.wl->nrq = first;
+                        confirm_step_fast<HAS_B, false>(t, rs, rq, idx, pend, vm);
+                    } else {
+                        break;
+                    }
+                    drain_matches(t, lane, 63);
+                    flush_records(t, lane, OFLUSH);
+                    continue;
+                }
+                const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
+                if (base < n && nrq <= RQ_CAP - 128) { /* the step may queue up to 128 more */
+                    fresh = true;
+                    const uint32_t i0 = base + lane, i1 = base + 64 + lane;
+                    valid[0] = i0 < n, valid[1] = i1 < n;
+                    idx[0] = valid[0] ? i0 : 0, idx[1] = valid[1] ? i1 : 0; /* n > 0 here: entry 0 exists */
+                    base += 128 * W;
+                } else if (nrq) { /* entries with candidate bits left: same path, next bit */
+                    fresh = false;
+                    const uint32_t k = min(nrq, 128u), first = nrq - k;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        valid[u] = u * 64 + lane < k;
+                        const uint2 it = rq[valid[u] ? first + u * 64 + lane : 0];
+                        idx[u] = valid[u] ? it.x : 0, pend[u] = valid[u] ? it.y : 0;
+                    }
+                    if (lane == 0) t.wl->nrq = first;
+                } else {
+                    break;
+                }
+                confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, fresh);
+                drain_matches(t, lane, 63);
+                flush_records(t, lane, OFLUSH);
+            }
+            drain_matches(t, lane, 0);
+            fill = publish_records(t, args, lane, cw, !fold);
+        }
+        if (lane == 0) s_fill[wave] = fill;
+        __syncthreads(); /* the share is confirmed; nobody reads s_share any more */
+        if (fold) {
+            const HsgpuScanArgs &args = cold_args();
+            uint32_t n_r = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < W; w++) n_r += min(s_fill[w], 0x1fffffffu);
+            n_r = __builtin_amdgcn_readfirstlane(n_r);
+            if (tid == 0) { /* publish: the super's sum first, then the share's own word */
+                __hip_atomic_fetch_add(&args.rec_super[r >> args.super_shift], (1ull << 40) | n_r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&args.share_status[r], 0x80000000u | n_r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (pending != ~0u) place_and_sort(pending, pending_n);
+            pending = r, pending_n = n_r;
+        }
+    }
+    if (fold) {
+        if (pending != ~0u) place_and_sort(pending, pending_n);
+        const HsgpuScanArgs &args = cold_args();
+        if (blockIdx.x == 0 && tid == 0 && args.tstamp_next) {
+            args.tstamp_next[0] = ~0ull;
+            args.tstamp_next[1] = 0;
+            args.tstamp_next[2] = 0;
+            args.tstamp_next[3] = 0;
+        }
+        scan_epilogue(args);
+    }
+}
+
+/* ---- phase 3 as a kernel of its own: fused scans and dense mode -------------------------------
+ *   publish      every producing wavefront adds its region's fill to the sum of its "super" (2^super_shift
+ *                consecutive regions, at most 256 supers): one atomic per region, not per record
+ *   record_sort  one workgroup per share: where its records go = the supers in front of it + the fills in front
+ *                of it inside its own super (one round trip of independent loads); sort_share; workgroup 0 writes
+ *                *count; then the OTHER control block (the previous scan's) goes back to zero for the next scan.
+ * 256 threads per share; 1024 once the scratch has seen dense input (runtime.hip): a dense share holds tens of
+ * thousands of records and its sort is this one workgroup's work. */
 __global__ __launch_bounds__(1024) void record_sort_kernel(HsgpuScanArgs args) {
-    const uint32_t NT = blockDim.x;
     __shared__ uint4 buf[SORT_LDS];
     __shared__ unsigned long long placed[3]; /* records in front of this share, records in all, overflow flag */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    uint4 *out = (uint4 *)args.out;
     const uint32_t first = blockIdx.x * args.group_regions, last = min(args.rec_regions, first + args.group_regions);
     const uint2 *counts = (const uint2 *)args.rec_counts;
     if (tid < 64) {
@@ -1556,132 +1856,15 @@ __global__ __launch_bounds__(1024) void record_sort_kernel(HsgpuScanArgs args) {
     __syncthreads();
     const unsigned long long base = placed[0];
     const bool complete = !placed[2] && placed[1] <= args.cap; /* no region overflowed, everything fits */
-    if (complete) {
-        /* the fills of all regions of the share at once (lane r = region first + r) and where each region's records
-         * start inside the share */
-        const uint32_t nreg = last - first; /* <= 64 */
-        const uint2 my = lane < nreg ? counts[first + lane] : make_uint2(0, 0);
-        uint32_t incl = my.x + my.y;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl, d);
-            if (lane >= (uint32_t)d) incl += v;
-        }
-        const uint32_t n = __shfl(incl, 63);
-        const uint32_t my_at = lane < nreg ? incl - (my.x + my.y) : n;
-        if (n) {
-            const bool in_lds = n <= SORT_LDS;
-            /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
-             * spilled to the back) */
-            for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += NT) { /* whole wavefronts: shuffles below */
-                uint32_t r = 0;
-                for (uint32_t k = 1; k < nreg; k++) r += __shfl(my_at, k) <= i ? 1u : 0u; /* the last region starting at or before i */
-                const uint32_t f = __shfl(my.x, r), at = __shfl(my_at, r), j = i - at;
-                if (i < n) {
-                    const uint4 *region = args.rec_stage + (uint64_t)(first + r) * args.rec_cap;
-                    const uint4 rec = j < f ? region[j] : region[args.rec_cap - 1 - (j - f)];
-                    if (in_lds) buf[i] = rec;
-                    else out[base + i] = rec;
-                }
-            }
-            __syncthreads();
-            if (n <= 64) {
-                /* rank by counting: one record per lane of the first wavefront, every lane walks the share
-                 * (all lanes read the same LDS address: a broadcast); no barriers, no compare-exchange chains */
-                if (tid < n) {
-                    const uint4 mine = buf[tid];
-                    uint32_t rank = 0;
-                    for (uint32_t q = 0; q < n; q++) { /* equal keys cannot occur; if they did, the gather order keeps ranks distinct */
-                        const uint4 o = buf[q];
-                        rank += (rec_less(o, mine) || (q < tid && !rec_less(mine, o))) ? 1u : 0u;
-                    }
-                    out[base + rank] = mine;
-                }
-            } else if (in_lds) {
-                bitonic_sort(buf, n);
-                for (uint32_t i = tid; i < n; i += NT) out[base + i] = buf[i];
-            } else {
-                /* a dense share (the reference's flood case, src/fdr/flood_runtime.h:86-335: thousands of records from a
-                 * few KiB of corpus): tiles of SORT_LDS records sorted in LDS, then merge passes between the output and
-                 * the share's own staging regions (free once gathered; together at least n records long), every thread
-                 * merging MERGE_SEG outputs from the split point its diagonal gives (merge path). The bitonic network
-                 * run in place in global memory took 28 ms for 8 192 records. */
-                uint4 *a = out + base, *b = args.rec_stage + (uint64_t)first * args.rec_cap;
-                for (uint32_t t0 = 0; t0 < n; t0 += SORT_LDS) {
-                    const uint32_t cnt = min(SORT_LDS, n - t0);
-                    for (uint32_t i = tid; i < cnt; i += NT) buf[i] = a[t0 + i];
-                    __syncthreads();
-                    bitonic_sort(buf, cnt);
-                    for (uint32_t i = tid; i < cnt; i += NT) a[t0 + i] = buf[i];
-                    __threadfence_block();
-                    __syncthreads();
-                }
-                constexpr uint32_t MERGE_SEG = 8;
-                for (uint32_t w = SORT_LDS; w < n; w <<= 1) {
-                    for (uint32_t o = tid * MERGE_SEG; o < n; o += NT * MERGE_SEG) {
-                        const uint32_t pair = o / (2 * w) * (2 * w); /* this output segment lies in the merge of runs at pair */
-                        const uint32_t la = min(w, n - pair), lb = min(w, n - min(n, pair + w));
-                        const uint4 *ra = a + pair, *rb = a + pair + la;
-                        const uint32_t d = o - pair; /* diagonal: d outputs come before this segment */
-                        /* i elements of run A and d - i of run B precede: the smallest i with A[i] > B[d - i - 1] fails */
-                        uint32_t lo = d > lb ? d - lb : 0, hi = min(d, la);
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (rec_less(rb[d - mid - 1], ra[mid])) hi = mid; /* B's element first: take fewer of A */
-                            else lo = mid + 1;
-                        }
-                        uint32_t i = lo, j = d - lo;
-                        const uint32_t stop = min(o + MERGE_SEG, min(n, pair + la + lb));
-                        for (uint32_t k = o; k < stop; k++) {
-                            const bool take_b = i >= la || (j < lb && rec_less(rb[j], ra[i]));
-                            b[k] = take_b ? rb[j++] : ra[i++];
-                        }
-                    }
-                    __threadfence_block();
-                    __syncthreads();
-                    uint4 *t = a;
-                    a = b;
-                    b = t;
-                }
-                if (a != out + base) { /* an odd number of passes left the result in the staging area */
-                    for (uint32_t i = tid; i < n; i += NT) out[base + i] = a[i];
-                }
-            }
-        }
-    }
-    /* Last kernel of a scan. The control words of THIS scan are read across workgroups (fills, sums), so nobody can
-     * zero them here; instead every workgroup zeroes its slice of the OTHER control block, the one the previous scan
-     * used and the next scan will use: no memset in front of any scan. */
-    {
-        uint4 *other = (uint4 *)args.ctl_other;
-        const uint32_t n4 = args.ctl_other_words >> 2, per = (n4 + gridDim.x - 1) / gridDim.x;
-        const uint32_t lo = blockIdx.x * per, hi = min(n4, lo + per);
-        for (uint32_t i = lo + tid; i < hi; i += NT) other[i] = make_uint4(0, 0, 0, 0);
-    }
-    uint32_t v = 0, o = 0;
-    if (args.cand_counts) { /* 1024 counters per workgroup: only a handful of workgroups touch the statistics word */
-        for (uint32_t i = blockIdx.x * 1024 + tid; i < min(args.cand_waves + 1, (blockIdx.x + 1) * 1024); i += NT) {
-            const uint32_t c = args.cand_counts[i];
-            if (i == args.cand_waves) o = c;
-            else v += c;
-        }
-    }
+    if (complete) sort_share(args, buf, first, last, base);
     if (blockIdx.x == 0 && tid == 0 && args.tstamp_next) {
-        args.tstamp[3] = wall_clock64(); /* the scan's last kernel (its start: the stages before it are done) */
+        args.tstamp[3] = wall_clock64(); /* the scan's last kernel (its first workgroup: the stages before it are done) */
         args.tstamp_next[0] = ~0ull;
         args.tstamp_next[1] = 0;
         args.tstamp_next[2] = 0;
         args.tstamp_next[3] = 0;
     }
-    /* cumulative statistics for hsgpu_scratch_get_stats: one atomic per wavefront */
-    unsigned long long vs = v;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) vs += __shfl_xor(vs, d);
-    const unsigned long long any_o = __ballot(o != 0);
-    if (lane == 0) {
-        if (vs) atomicAdd(&args.stats[0], vs);
-        if (any_o) atomicAdd(&args.stats[1], 1ull);
-    }
+    scan_epilogue(args);
 }
 
 /* ---- phase 0 (fused-only pipeline): the hints as a kernel of their own ------------ */

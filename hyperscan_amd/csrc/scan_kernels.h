@@ -49,6 +49,11 @@ struct HsgpuScanArgs {
     unsigned long long *rec_super;
     uint32_t super_shift;
     uint32_t group_regions;     /* consecutive regions that hold the records of one filter workgroup's corpus share */
+    /* the folded pipeline (hwlm_confirm_kernel places and sorts; no record_sort_kernel behind it): rec_super then counts
+     * SHARES -- word i = {shares published << 40 | their records} over 2^super_shift consecutive shares */
+    uint32_t fold;
+    uint32_t *ticket;           /* the next share to confirm (persistent confirm workgroups take shares in ticket order) */
+    uint32_t *share_status;     /* [cand_waves] {valid << 31 | records of the share}, written once the share is confirmed */
     /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
      * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */
     uint32_t *ctl_other;
@@ -57,7 +62,9 @@ struct HsgpuScanArgs {
     uint32_t *overflow_note;    /* host-visible word (mapped pinned memory): set by the fused kernel when it has to redo a scan
                                  * whose candidate regions overflowed; the next scan on this scratch then gives every chunk room */
     unsigned long long *tstamp; /* timing only: [2] min start / max end of the filter kernel (device wall clock) */
-    unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by record_sort_kernel */
+    unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by the scan's last kernel */
+    unsigned long long *wg_stamps;   /* tuning (hsgpu_scratch_enable_timing(s, 2)): [filter grid][4] device wall clock per
+                                      * workgroup: start, image staged / hints written, wavefront 0's share done, end */
 };
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);

@@ -147,20 +147,36 @@ class Scratch:
         # (include/hsgpu_tuning.h; the C library itself reads no environment variables)
         env = os.environ
         if env.get("HSGPU_MODE") or env.get("HSGPU_WG_THREADS") or env.get("HSGPU_WG_PER_CU"):
-            self.set_tuning(env.get("HSGPU_MODE") == "fused", int(env.get("HSGPU_WG_THREADS", "0")),
+            self.set_tuning({"fused": 1, "unfolded": 2}.get(env.get("HSGPU_MODE"), 0), int(env.get("HSGPU_WG_THREADS", "0")),
                             int(env.get("HSGPU_WG_PER_CU", "0")))
 
     def set_tuning(self, fused_only=False, wg_threads=0, wg_per_cu=0):
         self._lib.hsgpu_scratch_set_tuning.restype = C.c_int
         self._lib.hsgpu_scratch_set_tuning.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint]
-        rv = self._lib.hsgpu_scratch_set_tuning(self._h, 1 if fused_only else 0, wg_threads, wg_per_cu)
+        rv = self._lib.hsgpu_scratch_set_tuning(self._h, int(fused_only), wg_threads, wg_per_cu)  # 1 fused only, 2 unfolded
         if rv != 0:
             raise HsgpuError(rv, "hsgpu_scratch_set_tuning")
 
     def enable_timing(self, on=True):
-        rv = self._lib.hsgpu_scratch_enable_timing(self._h, 1 if on else 0)
+        """on = 2: also a set of device-clock stamps per workgroup of the filter kernel (wg_stamps)"""
+        rv = self._lib.hsgpu_scratch_enable_timing(self._h, int(on))
         if rv != 0:
             raise HsgpuError(rv, "hsgpu_scratch_enable_timing")
+
+    def wg_stamps(self):
+        """[workgroups][4] ms from the earliest start of the last scan's filter kernel: start, prologue done,
+        wavefront 0's share done, end (enable_timing(2))"""
+        import numpy as np
+
+        f = self._lib.hsgpu_scratch_get_wg_stamps
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_uint)]
+        n = C.c_uint(0)
+        out = np.zeros((4096, 4), dtype=np.float32)
+        rv = f(self._h, out.ctypes.data, 4096, C.byref(n))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_get_wg_stamps")
+        return out[: min(n.value, 4096)]
 
     def timing(self, back=0):
         """(filter_ms, confirm_ms, total_ms) of the hwlm_scan_dev `back` launches ago

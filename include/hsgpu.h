@@ -142,7 +142,8 @@ int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8
  * ascending uint64 offsets with d_off[nblocks] == total_bytes. The records arrive in delivery
  * order, sorted by (block, end, lit) -- hwlmExec's non-decreasing `end` (src/hwlm/hwlm.h:101-118),
  * block by block -- and *d_count receives the TOTAL number of matches. *d_count > cap means the
- * buffer was too small and no record is delivered: scan again with room for at least *d_count
+ * buffer was too small and nothing is delivered (what the buffer then holds is unspecified: the shares of the corpus that
+ * still fitted may or may not have been written; never anything past cap): scan again with room for at least *d_count
  * records, or with twice the room when *d_count == cap + 1 (then the staging area of one
  * wavefront, sized from cap, or -- the first dense scan on a scratch -- a wavefront's candidate region
  * was too small for a dense run of matches; in that case *d_count is a lower bound, and the scratch
@@ -160,7 +161,9 @@ int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d
  * hsgpu_scratch_get_timing synchronises the device and returns, for the scan `back`
  * launches ago (0 = the last), the filter kernel's duration between the two events, and --
  * from the device clock -- the confirm stage (filter end to confirm end) and the whole
- * pipeline (filter start to the end of the scan's last kernel), in milliseconds. */
+ * pipeline (filter start to the end of the scan's last kernel), in milliseconds. (Default pipeline: the confirm
+ * workgroups also place and sort, both spans end when the last share of the corpus has been sorted into the output;
+ * dense mode / fused scans, whose record sort is a kernel of its own: the spans end where that kernel starts.) */
 int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable);
 int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float *filter_ms, float *confirm_ms,
                              float *total_ms);

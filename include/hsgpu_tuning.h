@@ -27,10 +27,16 @@ extern "C" {
 
 
 /* Launch geometry / pipeline of the scans on one scratch, for tests that must cover every pipeline and for tuning
- * runs (the library reads no environment variables): fused_only != 0 runs the always-correct fused kernel alone
- * (normally the overflow fallback); wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the
+ * runs (the library reads no environment variables): fused_only == 1 runs the always-correct fused kernel alone
+ * (normally the overflow fallback), fused_only == 2 the two-phase pipeline with record_sort_kernel as a kernel of its own
+ * behind the confirm kernel (what dense mode runs; by default the confirm workgroups place and sort); wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the
  * workgroup size / workgroups per CU the runtime would choose (0 = its choice). */
 int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu);
+
+/* hsgpu_scratch_enable_timing(s, 2) also stamps every workgroup of the filter kernel (device wall clock); this returns the last
+ * scan's stamps in milliseconds from the earliest start: out[4 w + {0 start, 1 image staged and hints written, 2 wavefront 0's
+ * share streamed, 3 end}], w < min(*n_wgs, max_wgs). Synchronises the device. */
+int hsgpu_scratch_get_wg_stamps(hsgpu_scratch_t *s, float *out, unsigned max_wgs, unsigned *n_wgs);
 
 /* The first 32 hex digits of the sha256 over the sources this library was built from (csrc/Makefile, STAMPED): the built
  * library is not in the repository, and a test compares this with the tree it runs in. */

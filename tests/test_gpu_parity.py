@@ -325,7 +325,8 @@ def test_scan_dev_records_in_delivery_order(scratch, case):
     _same_records(got, want)
     # a buffer that is too small: the exact count comes back and nothing is delivered
     n2, recs2 = _scan_dev(t, scratch, corpus, off, cap=max(1, len(want) // 2))
-    assert n2 >= len(want) // 2 + 1 and (recs2 == 0xFFFFFFFF).all()
+    assert n2 >= len(want) // 2 + 1  # (what the buffer holds then is unspecified, include/hsgpu.h; nothing is written past cap:
+    # _scan_dev's buffer is exactly cap records long, and an out-of-bounds write would fault or corrupt the next tensor)
 
 
 def test_scan_dev_resident_and_properties(scratch):
@@ -377,7 +378,7 @@ def test_scan_dev_resident_and_properties(scratch):
     assert len(p1) > 1000 and n_straddling > 0
 
 
-@pytest.mark.parametrize("env", [{"HSGPU_MODE": "fused"}, {"HSGPU_WG_THREADS": "1024"}, {"HSGPU_WG_THREADS": "512"}])
+@pytest.mark.parametrize("env", [{"HSGPU_MODE": "fused"}, {"HSGPU_MODE": "unfolded"}, {"HSGPU_WG_THREADS": "1024"}, {"HSGPU_WG_THREADS": "512"}])
 def test_golden_vectors_under_alternative_pipelines(env):
     """The golden-vector suite again with the always-correct fused pipeline (normally only the
     overflow fallback) and with each workgroup geometry forced for every table."""

@@ -1,0 +1,125 @@
+"""GPU tests of round 4: the folded tail (persistent confirm workgroups that place and sort their shares), dense mode
+that can neither overflow nor last for ever, the pipelines against each other."""
+import numpy as np
+import pytest
+
+import hyperscan_amd as H
+from hyperscan_amd import corpus as cp
+from hyperscan_amd import hwlm as hw
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+class Resident:
+    def __init__(self, lits, corpus, off, cap):
+        import torch
+
+        self.torch = torch
+        dev = torch.device("cuda", 0)
+        self.t = H.hwlm_build(lits)
+        self.s = H.Scratch(0)
+        self.total, self.nblocks, self.cap = int(corpus.size), int(off.size - 1), int(cap)
+        self.d_corpus = torch.from_numpy(np.concatenate([corpus, np.zeros(16, np.uint8)])).to(dev)
+        self.d_off = torch.from_numpy(off.astype(np.uint64).view(np.int64)).to(dev)
+        self.d_out = torch.zeros(self.cap * 4, dtype=torch.int32, device=dev)
+        self.d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def scan(self):
+        st = self.torch.cuda.current_stream().cuda_stream
+        hw.hwlm_scan_dev(self.t, self.s, self.d_corpus.data_ptr(), self.total, self.d_off.data_ptr(), self.nblocks,
+                         self.d_out.data_ptr(), self.cap, self.d_count.data_ptr(), 0, st)
+        self.torch.cuda.synchronize()
+        return int(self.d_count.item())
+
+    def records(self, n):
+        return self.d_out[: n * 4].view(n, 4).cpu().numpy().astype(np.uint32)
+
+
+def _in_delivery_order(r):
+    k = (r[:, 0].astype(np.uint64) << np.uint64(32)) | r[:, 1].astype(np.uint64)
+    return bool(np.all((k[1:] > k[:-1]) | ((k[1:] == k[:-1]) & (r[1:, 3] > r[:-1, 3]))))
+
+
+@pytest.mark.parametrize("workload", ["teddy64", "fdr10k"])
+def test_folded_unfolded_and_fused_pipelines_deliver_identical_arrays(workload):
+    """The three pipelines -- confirm workgroups that place and sort (default), confirm + record_sort_kernel, the fused
+    kernel + record_sort_kernel -- write the same record array, element for element, and the oracle's multiset."""
+    if workload == "teddy64":
+        lits = cp.teddy_literals(64, seed=2)
+        corpus, off = cp.packet_corpus(48 << 20, lits, seed=33, match_every=2048)
+    else:
+        lits, _ = cp.snort_like_literals(10000, seed=4)
+        corpus, off = cp.packet_corpus(48 << 20, lits, seed=34)
+    r = Resident(lits, corpus, off, cap=1 << 20)
+    got = {}
+    for mode, code in (("folded", 0), ("unfolded", 2), ("fused", 1), ("folded again", 0)):
+        r.s.set_tuning(code)
+        n = r.scan()
+        assert 1000 < n <= r.cap
+        got[mode] = r.records(n)
+        assert _in_delivery_order(got[mode]), mode
+    for mode in ("unfolded", "fused", "folded again"):
+        assert np.array_equal(got["folded"], got[mode]), f"folded vs {mode}"
+    want = ob.Oracle(lits).collect_blocks(corpus[: 8 << 20], off[: int(np.searchsorted(off, 8 << 20, side='right'))])
+    kb = int(np.searchsorted(off, 8 << 20, side="right")) - 1
+    g = got["folded"][got["folded"][:, 0] < kb]
+    gi = np.lexsort((g[:, 2], g[:, 1], g[:, 0]))
+    wi = np.lexsort((want["id"], want["end"], want["block"]))
+    assert len(g) == len(want) and np.array_equal(g[gi, 0], want["block"][wi]) and np.array_equal(g[gi, 1], want["end"][wi]) \
+        and np.array_equal(g[gi, 2], want["id"][wi])
+
+
+@pytest.mark.parametrize("size", [(64 << 20) + 13, (64 << 20) + 1024 + 7, 5 * 1024 * 1024 + 1])
+def test_fully_dense_corpus_of_unaligned_size(size):
+    """Every chunk of the corpus holds candidates and matches ('abcd' repeated under the literal 'abcd'; a zero run under
+    four zero bytes): the first scan reports "again", the scratch goes to dense mode, and dense mode must have room for every
+    chunk whatever the size and however the tiles divide among the wavefronts (advisor, round 3: the capacity was rounded the
+    wrong way and such a scan failed on every retry)."""
+    for unit, lit in ((b"abcd", b"abcd"), (b"\0", b"\0\0\0\0")):
+        corpus = np.frombuffer((unit * (size // len(unit) + 1))[:size], dtype=np.uint8).copy()
+        off = np.array([0, size // 3, size // 3, size], dtype=np.uint64)  # an empty block in the middle
+        lits = [H.HwlmLiteral(lit, False, 5)]
+        per = len(unit)
+
+        def expect(lo, hi):  # matches of one block: ends at lo + 3, lo + 3 + per, ... (block-relative)
+            ln = hi - lo
+            if ln < 4:
+                return 0
+            first = (-lo) % per  # first occurrence start inside the block
+            return 0 if first + 4 > ln else (ln - 4 - first) // per + 1
+        want = sum(expect(int(off[i]), int(off[i + 1])) for i in range(3))
+        r = Resident(lits, corpus, off, cap=want + 4096)
+        n = r.scan()
+        tries = 0
+        while n > r.cap and tries < 4:
+            tries += 1
+            n = r.scan()
+        assert n == want, (unit, size, n, want, tries)
+        recs = r.records(n)
+        assert _in_delivery_order(recs)
+        assert (recs[:, 2] == 5).all() and set(np.unique(recs[:, 0]).tolist()) == {0, 2}
+        b0 = recs[recs[:, 0] == 0][:, 1].astype(np.int64)
+        assert b0[0] == 3 and np.all(np.diff(b0) == per)
+        # and dense mode ends: after its span the scratch is back on the ordinary sizing; a sparse corpus then scans folded
+        assert r.s.stats()[1] >= 1
+
+
+def test_dense_mode_is_left_again():
+    """A scratch that has seen one dense scan does not keep the doubled candidate buffer and the unfolded pipeline for the
+    rest of its life (advisor, round 3): after the dense span it tries the ordinary sizing again; if the input is still dense
+    that scan says "again" and the span doubles."""
+    size = 8 << 20
+    dense = np.frombuffer(b"abcd" * (size // 4), dtype=np.uint8).copy()
+    off = np.array([0, size], dtype=np.uint64)
+    lits = [H.HwlmLiteral(b"abcd", False, 1)]
+    r = Resident(lits, dense, off, cap=size // 4 + 4096)
+    again = []
+    for i in range(60):
+        n = r.scan()
+        again.append(n > r.cap)
+        assert n > r.cap or n == size // 4
+    assert again[0] and not again[1]            # the first scan overflows, the retry (dense mode) delivers
+    k = [i for i, a in enumerate(again) if a]
+    assert len(k) >= 2 and k[1] - k[0] >= 16     # ... for a span of at least 16 scans, then one probe of the ordinary sizing
+    assert len(k) < 4 and (len(k) < 3 or k[2] - k[1] >= 2 * (k[1] - k[0]) - 1)  # and the span doubles

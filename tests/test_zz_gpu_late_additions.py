@@ -204,7 +204,7 @@ def test_hwlm_exec_argument_order_and_callback_context(scratch):
 
 
 @pytest.mark.parametrize("env", [{"HSGPU_WG_PER_CU": "4", "HSGPU_WG_THREADS": "256"}, {"HSGPU_WG_PER_CU": "2"},
-                                 {"HSGPU_MODE": "fused"}])
+                                 {"HSGPU_MODE": "fused"}, {"HSGPU_MODE": "unfolded"}])
 def test_delivery_order_under_other_geometries(env):
     """Where a share's records go is computed from partial sums over groups of 2^k regions, k chosen from the
     number of regions: other launch geometries (more and smaller workgroups: four times the regions; the fused
