@@ -1193,11 +1193,15 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         img[u] = i < nw / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
     }
 #ifndef HSGPU_HINTS_LATE
-#define HSGPU_HINTS_LATE 0 /* 1: the block hints are written after the wavefront's share instead of in front of it */
+#define HSGPU_HINTS_LATE 1 /* the block hints are written after the wavefront's share, not in front of it (0: in the prologue, as in
+                            * round 3: the median workgroup then started streaming after 15.4 us instead of 7.4, the kernel took 9 us
+                            * longer: gpurun_out r4a, profiles/r04_filter_wg_stamps.txt) */
 #endif
     const bool hints = !FUSED && args.hint_in_filter;
     constexpr int HK = HSGPU_PROLOGUE_HK; /* every lane takes 8 consecutive blocks: 9 offsets, 512 blocks per wavefront and step */
+#if !HSGPU_HINTS_LATE
     const uint64_t hb0 = ((uint64_t)wave_global * 64 + lane) * HK;
+#endif
 #if !HSGPU_HINTS_LATE
     uint64_t ho[HK + 1];
 #pragma unroll
@@ -1227,6 +1231,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
         for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
     }
+    /* (two-phase: 64 bytes behind the tables hold the workgroup's progress sum, hsgpu_filter_lds_bytes) */
+    uint32_t *wg_done = lds + nw + (HAS_C ? 2048 : 0);
+    if (!FUSED && threadIdx.x == 0) *wg_done = 0;
     /* two-phase: the confirm kernel's block hints are written here (a hint kernel on a side stream needed a
      * fork/join pair of cross-stream waits around the confirm launch) */
 #if !HSGPU_HINTS_LATE
@@ -1290,8 +1297,24 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         tk += 1;                                                         \
         if (tk >= n_own) break;                                          \
     }
+#ifndef HSGPU_BALANCE
+#define HSGPU_BALANCE 0
+#endif
 #if HSGPU_STAGES == 8
         for (;;) {
+#if HSGPU_BALANCE
+            /* The wavefronts of a workgroup do not advance together: the instruction arbiter prefers the oldest, and wavefront
+             * 0 has streamed its share after 2/3 of the kernel (profiles/r04_filter_wg_stamps.txt) -- the last third runs with
+             * ever fewer wavefronts per SIMD to hide latency behind. Every eight tiles a wavefront adds its progress to the
+             * workgroup's sum in LDS and raises its priority while it is behind the mean, lowers it while ahead. */
+            if (!FUSED) {
+                uint32_t tot = 0;
+                if (lane == 0) tot = __hip_atomic_fetch_add(wg_done, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                tot = __builtin_amdgcn_readfirstlane(tot);
+                if (tk * WAVES < tot) __builtin_amdgcn_s_setprio(3);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             HSGPU_STAGE(c0, c7)
             HSGPU_STAGE(c1, c0)
             HSGPU_STAGE(c2, c1)
@@ -1648,7 +1671,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
                 unsigned long long v;
                 for (;;) {
-                    v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > SPIN_LIMIT) bad = true;
@@ -1658,7 +1681,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             for (uint32_t i = (S << ss) + lane; i < p; i += 64) { /* the shares in front inside its own super */
                 uint32_t v;
                 for (;;) {
-                    v = __hip_atomic_load(&args.share_status[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __hip_atomic_load(&args.share_status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((v >> 31) || bad) break;
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > SPIN_LIMIT) bad = true;
@@ -1677,7 +1700,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                      * output is complete) */
                     const unsigned long long all = before + n_p;
                     const unsigned long long flag =
-                        __hip_atomic_load(&args.rec_super[256], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
+                        __hip_atomic_load(&args.rec_super[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
                     *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
                 }
             }
@@ -1689,8 +1712,12 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     };
 
     uint32_t pending = ~0u, pending_n = 0;
-    for (;;) {
-        if (tid == 0) s_share = __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (bool first = true;; first = false) {
+        /* the first share is the workgroup's own index: a ticket taken by every workgroup of the grid at the same moment is
+         * 1 536 atomics on one address, ~0.1 us each one after the other. (Workgroups start in index order, so the holder of
+         * a lower first share is running whenever a higher one is.) */
+        if (tid == 0)
+            s_share = first ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads(); /* (also: the gate is staged; the sort of the share before is done with the LDS area) */
         const uint32_t r = __builtin_amdgcn_readfirstlane(s_share); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
         if (r >= n_shares) break;
@@ -1770,9 +1797,12 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
 #pragma unroll
             for (uint32_t w = 0; w < W; w++) n_r += min(s_fill[w], 0x1fffffffu);
             n_r = __builtin_amdgcn_readfirstlane(n_r);
+            /* (Relaxed device-scope atomics throughout: the words carry counts, nothing is read through them. With
+             * release / acquire semantics every publish wrote the whole L2 back (buffer_wbl2) and every poll invalidated it
+             * (buffer_inv): the stage took 0.55 ms instead of 0.16.) */
             if (tid == 0) { /* publish: the super's sum first, then the share's own word */
-                __hip_atomic_fetch_add(&args.rec_super[r >> args.super_shift], (1ull << 40) | n_r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&args.share_status[r], 0x80000000u | n_r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&args.rec_super[r >> args.super_shift], (1ull << 40) | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&args.share_status[r], 0x80000000u | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (pending != ~0u) place_and_sort(pending, pending_n);
             pending = r, pending_n = n_r;

@@ -43,5 +43,5 @@ const void *hsgpu_record_sort_kernel(void) { return (const void *)record_sort_ke
 
 size_t hsgpu_filter_lds_bytes(uint32_t flags, uint32_t filter_log2, bool fused, uint32_t wg_threads) {
     size_t words = (size_t)hsgpu_filter_words(flags, filter_log2) + ((flags & HSGPU_F_HAS_C) ? 2048 : 0);
-    return words * 4 + (fused ? (size_t)(wg_threads / 64) * sizeof(WaveLds) : 0);
+    return words * 4 + (fused ? (size_t)(wg_threads / 64) * sizeof(WaveLds) : 64 /* the workgroup's progress sum */);
 }

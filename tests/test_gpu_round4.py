@@ -92,8 +92,12 @@ def test_fully_dense_corpus_of_unaligned_size(size):
         r = Resident(lits, corpus, off, cap=want + 4096)
         n = r.scan()
         tries = 0
-        while n > r.cap and tries < 4:
+        while n > r.cap and tries < 6:  # the protocol of include/hsgpu.h: cap + 1 = "again with twice the room"
+            assert n == r.cap + 1
             tries += 1
+            if tries > 1:  # (the first "again" is the candidate overflow that sends the scratch to dense mode)
+                r.cap *= 2
+                r.d_out = r.torch.zeros(r.cap * 4, dtype=r.torch.int32, device=r.d_out.device)
             n = r.scan()
         assert n == want, (unit, size, n, want, tries)
         recs = r.records(n)
@@ -109,11 +113,11 @@ def test_dense_mode_is_left_again():
     """A scratch that has seen one dense scan does not keep the doubled candidate buffer and the unfolded pipeline for the
     rest of its life (advisor, round 3): after the dense span it tries the ordinary sizing again; if the input is still dense
     that scan says "again" and the span doubles."""
-    size = 8 << 20
+    size = 32 << 20  # (a fully dense share must exceed the 256-entry floor of a candidate region: above 16 MiB)
     dense = np.frombuffer(b"abcd" * (size // 4), dtype=np.uint8).copy()
     off = np.array([0, size], dtype=np.uint64)
     lits = [H.HwlmLiteral(b"abcd", False, 1)]
-    r = Resident(lits, dense, off, cap=size // 4 + 4096)
+    r = Resident(lits, dense, off, cap=size)  # room enough that no staging region is the reason for an "again"
     again = []
     for i in range(60):
         n = r.scan()
