@@ -1298,7 +1298,8 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         if (tk >= n_own) break;                                          \
     }
 #ifndef HSGPU_BALANCE
-#define HSGPU_BALANCE 0
+#define HSGPU_BALANCE 1 /* 0: round 3's loop (the same box, back to back: fdr10k filter 0.2998 -> 0.2855 ms, 8 GiB 2.341 -> 2.217 ms,
+                         * teddy64 0.2175 -> 0.2114; wavefront 0 done at 253 of 263 us instead of 181 of 273: profiles/r04_filter_wg_stamps.txt) */
 #endif
 #if HSGPU_STAGES == 8
         for (;;) {
@@ -1456,7 +1457,11 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
     const uint32_t n = __shfl(incl, 63);
     const uint32_t my_at = lane < nreg ? incl - (my.x + my.y) : n;
     if (!n) return;
+#ifdef HSGPU_FOLD_NOSORT /* timing experiment only: the share's records copied, not sorted */
+    const bool in_lds = false;
+#else
     const bool in_lds = n <= SORT_LDS;
+#endif
     /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
      * spilled to the back) */
     for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += NT) { /* whole wavefronts: shuffles below */
@@ -1470,6 +1475,9 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
             else out[base + i] = rec;
         }
     }
+#ifdef HSGPU_FOLD_NOSORT
+    return;
+#endif
     __syncthreads();
     if (n <= 64) {
         /* rank by counting: one record per lane of the first wavefront, every lane walks the share

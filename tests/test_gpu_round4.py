@@ -105,8 +105,8 @@ def test_fully_dense_corpus_of_unaligned_size(size):
         assert (recs[:, 2] == 5).all() and set(np.unique(recs[:, 0]).tolist()) == {0, 2}
         b0 = recs[recs[:, 0] == 0][:, 1].astype(np.int64)
         assert b0[0] == 3 and np.all(np.diff(b0) == per)
-        # and dense mode ends: after its span the scratch is back on the ordinary sizing; a sparse corpus then scans folded
-        assert r.s.stats()[1] >= 1
+        if size > (32 << 20):  # (below 16 MiB a fully dense share still fits the 256-entry floor of a candidate region)
+            assert r.s.stats()[1] >= 1, "the first scan of a dense corpus this size overflows its candidate regions"
 
 
 def test_dense_mode_is_left_again():
