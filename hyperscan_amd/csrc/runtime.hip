@@ -515,8 +515,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * the next scan finds its block zeroed without a memset. */
     const size_t cand_ofs = (size_t)2 * n_rec;
     const size_t super_ofs = (cand_ofs + n_waves + 1 + 1) & ~(size_t)1; /* 8-byte aligned */
-    const size_t status_ofs = super_ofs + 2 * 257;                     /* folded pipeline: one status word per share, */
-    const size_t ticket_ofs = status_ofs + n_waves;                    /* and the ticket counter */
+    const size_t status_ofs = super_ofs + 2 * 257;                     /* folded pipeline: one status word per region, */
+    const size_t ticket_ofs = status_ofs + n_rec;                      /* and the ticket counter */
     const size_t blk_words = (ticket_ofs + 1 + 3) & ~(size_t)3;
     /* a reallocated control buffer is garbage whatever its address: hipMalloc may hand the
      * freed range straight back, so growth is detected by capacity, never by pointer */
@@ -555,15 +555,14 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
             s->cand.release();
         }
     }
-    /* The folded pipeline: the persistent confirm workgroups place and sort their shares themselves. Not for fused-only
-     * scratches, not in dense mode (a dense share is merged by a 1024-thread workgroup of record_sort_kernel), and not
-     * without the mapped "again" note (the fused kernel then has to run between confirm and sort). */
+    /* The folded pipeline: the confirm wavefronts emit their regions in order and place them themselves. Not for fused-only
+     * scratches, not in dense mode (more matches than a wavefront's queue can order: record_sort_kernel sorts whatever it is
+     * given), and not without the mapped "again" note (the fused kernel then has to run between confirm and sort). */
     const bool fold = two_phase && s->cand_div != 16 && s->d_note && !s->tune_unfolded;
     args.fold = fold ? 1u : 0u;
-    /* up to 256 supers: atomics on one address serialise (~0.1 us each). Unfolded: supers of regions (64 regions share one
-     * at 16 384 regions); folded: supers of shares */
-    args.super_shift = fold ? 3 : 5;
-    while ((((fold ? n_waves : n_rec) + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
+    /* up to 256 supers of 2^super_shift regions: atomics on one address serialise (64 regions share one at 16 384 regions) */
+    args.super_shift = 5;
+    while (((n_rec + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
     /* the regions fed by one filter wavefront: the records of one contiguous share of the corpus */
     args.group_regions = HSGPU_CONFIRM_SPLIT;
     args.stats = (unsigned long long *)s->stats.p;

@@ -235,8 +235,12 @@ __device__ __forceinline__ void resolve_match(const Tables &t, uint64_t ge, uint
 constexpr uint32_t MQ_CAP = QCAP;
 __device__ __forceinline__ void push_match(const Tables &t, uint64_t ge, uint32_t li) {
     const uint32_t s = __hip_atomic_fetch_add(&t.wl->nmq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (s < MQ_CAP) t.wl->cand[s] = make_uint2((uint32_t)ge, li | (uint32_t)(ge >> 32) << 24);
-    else resolve_match(t, ge, li);
+    if (s < MQ_CAP) {
+        t.wl->cand[s] = make_uint2((uint32_t)ge, li | (uint32_t)(ge >> 32) << 24);
+    } else { /* (the folded pipeline emits in order: a queue that overflowed between two of its sync points did not) */
+        t.wl->pad[0] = 1u;
+        resolve_match(t, ge, li);
+    }
 }
 
 /* One list entry = literal index | delta << 30: does that literal end at g + delta?
@@ -1037,6 +1041,7 @@ __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t l
         wl->nback = z;
         wl->nmq = z;
         wl->nrq = z;
+        wl->pad[0] = z; /* "resolved a match in place" (push_match) */
     }
 }
 
@@ -1572,39 +1577,92 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
     }
 }
 
-/* ---- phase 2 (+ 3): confirm, placement, sort -- one persistent kernel ------------------------------------------
- * A workgroup of HSGPU_CONFIRM_SPLIT wavefronts takes one SHARE at a time (= one filter wavefront's candidate region;
- * batch b of 64 entries goes to wavefront b % SPLIT, so that even a few thousand entries are confirmed by several
- * short dependent-read chains in parallel), in ticket order, until the tickets run out. Round 3 launched one
- * short-lived wavefront per (share, part) -- 16 384 of them for a 1 GiB scan -- and then 16 384 more for the sort
- * kernel: the machine starts ~300 wavefronts per microsecond, so each of the two kernels had a floor of ~55 us
- * whatever it did, and the 8 KiB key gate was staged 4 096 times. Now the grid is what the device holds at once
- * (workgroups per CU x CUs), the gate is staged once per workgroup, and in the FOLDED pipeline (args.fold) the same
- * workgroup also places and sorts the share's records -- there is no sort kernel behind it:
- *   publish   after the share's barrier one thread adds {1 << 40 | records} to the sum of the share's "super"
- *             (2^super_shift consecutive shares, at most 256 supers: one atomic per share) and stores the share's
- *             own status word {valid | records}
- *   place     where a share's records go = the sums of the supers in front of its own (complete once their share
- *             count is full) + the status words of the shares in front of it inside its own super: two rounds of
- *             independent loads by one wavefront, spinning only while a share in front is still being confirmed
- *   deferred  the placement of share k is done AFTER the workgroup has confirmed its next share: by then the shares in
- *             front of k (lower tickets, taken earlier) have long been published, so nobody waits. Tickets make it
- *             deadlock-free without assuming that the whole grid is resident: a workgroup only ever waits for
- *             lower tickets, whose holders are running and publish without waiting for anybody.
- *   sort      sort_share above, in the LDS the confirm state occupied (dead between two shares)
- * The workgroup that places the last share knows the total and writes *count. The unfolded pipeline (fused scans,
- * dense mode: 1024-thread sort workgroups) keeps record_sort_kernel below. */
-struct ConfirmLds {
-    WaveLds wave[CONFIRM_THREADS / 64];
-    uint2 rest_q[CONFIRM_THREADS / 64][RQ_CAP];
-};
-static_assert(sizeof(ConfirmLds) <= SORT_LDS * sizeof(uint4), "the confirm state and the sort buffer share one LDS area");
+/* ---- phase 2 (+ 3): confirm, order, placement -- one persistent kernel ------------------------------------------
+ * A workgroup of HSGPU_CONFIRM_SPLIT wavefronts takes one SHARE at a time (= one filter wavefront's candidate region),
+ * the first one by its own index, then in ticket order, until the tickets run out; the grid is what the device holds at
+ * once (workgroups per CU x CUs), the 8 KiB key gate is staged once per workgroup. (Round 3 launched one short-lived
+ * wavefront per part of a share and 16 384 more for the sort kernel.)
+ *
+ * The FOLDED pipeline (args.fold; the default) has no sort kernel behind it, and no sort either:
+ *   parts     wavefront w of the workgroup confirms the w-th QUARTER of the share's candidate entries (whole batches of 128;
+ *             the filter appended them in corpus order), so the four staging regions of a share hold consecutive pieces of
+ *             the corpus, and so do consecutive shares
+ *   in order  matches wait in the wavefront's LDS queue until a sync point -- more than SYNC_AT queued, or the part done:
+ *             the entries with candidate bits left are confirmed first (so that no earlier position is still pending), then
+ *             the queue is sorted on 64-bit keys {position, literal} by counting ranks (<= 128 keys, one or two per lane,
+ *             every lane walks the queue through LDS broadcasts: ~1 us), resolved 64 at a time IN THAT ORDER and appended
+ *             to the region. A region is therefore sorted by (block, end, literal) as it is written, and the concatenation
+ *             of all regions is the delivery order. (A queue that overflows between two sync points -- more matches than
+ *             candidate entries: dense input -- resolves in place, out of order; the scan then reports "again" and sends
+ *             the scratch to dense mode, whose unfolded pipeline sorts whatever it is given.)
+ *   publish   the wavefront adds {1 << 40 | records} to the sum of its region's "super" (2^super_shift consecutive
+ *             regions, at most 256 supers) and stores the region's own status word {valid | records}: relaxed device-scope
+ *             atomics, the words carry counts and nothing is read through them
+ *   place     where a region's records go = the sums of the supers in front of its own (complete once their region count
+ *             is full) + the status words of the regions in front of it inside its own super: two rounds of independent
+ *             loads by the wavefront itself, then a plain copy of the region into the output. DEFERRED: a wavefront places
+ *             its region only after confirming its part of the NEXT share, when the regions in front (lower tickets, taken
+ *             earlier) have long been published -- nobody waits, and no workgroup barrier is involved (the one barrier per
+ *             share hands out the ticket). Deadlock-free without assuming a resident grid: a wavefront only waits for
+ *             lower regions, whose holders are running and publish before they wait for anybody.
+ * The wavefront that places the last region knows the total and writes *count. Measured against the same kernel followed by
+ * record_sort_kernel (profiles/r04_tail_*.txt). The unfolded pipeline (fused scans, dense mode) keeps round 3's schedule:
+ * batches of a share dealt round-robin, matches resolved as they queue up, record_sort_kernel below. */
+constexpr uint32_t SPIN_LIMIT = 1u << 22; /* placement: a region in front that never publishes (cannot happen) ends the wait */
+constexpr uint32_t SYNC_AT = 48;          /* folded: queued matches that end a group of batches (the queue holds MQ_CAP = 128) */
 static_assert(CONFIRM_THREADS / 64 == HSGPU_CONFIRM_SPLIT, "one wavefront per part of a share");
-constexpr uint32_t SPIN_LIMIT = 1u << 22; /* placement: a share in front that never publishes (cannot happen) ends the wait */
+static_assert(RQ_CAP * sizeof(uint2) >= MQ_CAP * sizeof(uint2), "the empty rest queue doubles as the sorted-key buffer");
+
+/* the 64-bit sort key of a queued match {position (< 2^36), literal index (< 2^24)}: delivery order is (block, end, literal),
+ * and (block, end) grows with the position */
+__device__ __forceinline__ uint64_t match_key(const uint2 it) {
+    return (uint64_t)(it.y >> 24) << 56 | (uint64_t)it.x << 24 | (it.y & HSGPU_LIST_LIT_MASK);
+}
+
+/* Convergent, folded pipeline: the queued matches (wl->cand[0 .. nmq), nothing pending in the rest queue `sorted`, which
+ * serves as the buffer) sorted by counting ranks, resolved in order, appended to the front of the region. */
+__device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint2 *sorted, uint32_t lane) {
+    uint32_t n = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    n = min(__builtin_amdgcn_readfirstlane(n), MQ_CAP);
+    if (n == 0) return;
+    const bool own0 = lane < n, own1 = lane + 64 < n;
+    const uint2 it0 = t.wl->cand[own0 ? lane : 0], it1 = t.wl->cand[own1 ? lane + 64 : 0];
+    if (n > 1) {
+        const uint64_t k0 = match_key(it0), k1 = match_key(it1);
+        uint32_t r0 = 0, r1 = 0;
+        for (uint32_t q = 0; q < n; q++) { /* (one LDS address for the whole wavefront: a broadcast) */
+            const uint64_t kq = match_key(t.wl->cand[q]);
+            r0 += (kq < k0 || (kq == k0 && q < lane)) ? 1u : 0u;
+            r1 += (kq < k1 || (kq == k1 && q < lane + 64)) ? 1u : 0u;
+        }
+        if (own0) sorted[r0] = it0;
+        if (own1) sorted[r1] = it1;
+    } else if (lane == 0) {
+        sorted[0] = it0;
+    }
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const bool valid = i0 + lane < n;
+        const uint2 it = sorted[valid ? i0 + lane : 0];
+        const uint32_t li = it.y & HSGPU_LIST_LIT_MASK;
+        const uint64_t ge = (uint64_t)(it.y >> 24) << 32 | it.x;
+        const uint4 l1 = ((const uint4 *)(t.lits + li))[1];
+        uint64_t bstart;
+        const uint64_t b = block_of(t, ge, bstart);
+        const uint32_t id = l1.z, size = l1.w & 0xff;
+        const uint64_t end = ge - bstart;
+        const bool ok = valid && !(end + 1 < size || end + 1 - size < t.start);
+        const uint64_t mask = __ballot(ok);
+        const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
+        const uint32_t at = f + lane_rank(mask);
+        if (ok && at < t.rec_cap) t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
+        if (lane == 0) t.wl->nfront = f + (uint32_t)__popcll(mask); /* keeps counting past the capacity: the total stays exact */
+    }
+    if (lane == 0) __hip_atomic_store(&t.wl->nmq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 
 /* The kernel's argument block re-read from the kernarg segment at the point of use. The confirm step runs with every scalar
  * register taken (104 of 104: table pointers, descriptors, bounds); arguments that only the per-share bookkeeping needs
- * (tickets, sums, the sort's buffers) would otherwise be loaded at kernel entry and held -- or rather spilled into vector
+ * (tickets, sums, the output) would otherwise be loaded at kernel entry and held -- or rather spilled into vector
  * lanes and read back with v_readlane inside the step -- for the whole persistent loop. The empty asm hides where the
  * pointer comes from, so the loads stay behind it. (The kernel has one by-value argument: it starts the segment.) */
 __device__ __forceinline__ const HsgpuScanArgs &cold_args() {
@@ -1624,11 +1682,10 @@ __global__ __launch_bounds__(CONFIRM_THREADS)
 __attribute__((amdgpu_waves_per_eu(HSGPU_CONFIRM_WAVES, 8)))
 void hwlm_confirm_kernel(HsgpuScanArgs args) {
     constexpr uint32_t W = CONFIRM_THREADS / 64;
-    __shared__ __attribute__((aligned(16))) uint4 lds_area[SORT_LDS]; /* ConfirmLds while confirming, the sort buffer while sorting */
+    __shared__ WaveLds wave_lds[W];
+    __shared__ uint2 rest_q[W][RQ_CAP];
     __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
-    __shared__ uint32_t s_share, s_fill[W];
-    __shared__ unsigned long long s_base;
-    ConfirmLds &L = *(ConfirmLds *)lds_area;
+    __shared__ uint32_t s_share;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fold = args.fold != 0;
@@ -1655,7 +1712,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     init_tables(t, args);
     if (gated) t.key_gate = (const uint32_t *)key_gate;
     t.rec_cap = args.rec_cap;
-    uint2 *rq = L.rest_q[wave];
+    uint2 *rq = rest_q[wave];
 #ifndef HSGPU_CONFIRM_FAST
 #define HSGPU_CONFIRM_FAST 1 /* tuning builds: 0 = the general step for every table */
 #endif
@@ -1667,157 +1724,159 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         rs.lits = __builtin_amdgcn_make_buffer_rsrc((void *)t.lits, 0, (int)0x7ffffff0, 0x00020000);
     }
 
-    /* Workgroup-convergent: where share p's n_p records go (spinning on the shares in front only while they are still being
-     * confirmed), then its sort. */
-    auto place_and_sort = [&](uint32_t p, uint32_t n_p) {
+    /* Wavefront-convergent, folded pipeline: where region cw's n_p sorted records go (spinning on the regions in front only
+     * while they are still being confirmed), and their copy into the output. */
+    auto place_and_copy = [&](uint32_t cw, uint32_t n_p) {
         const HsgpuScanArgs &args = cold_args(); /* (shadows the kernel's: see cold_args) */
-        if (wave == 0) {
-            const uint32_t ss = args.super_shift, S = p >> ss;
-            unsigned long long before = 0;
-            uint32_t spins = 0;
-            bool bad = false;
-            for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
-                unsigned long long v;
-                for (;;) {
-                    v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > SPIN_LIMIT) bad = true;
-                }
-                before += v & ((1ull << 40) - 1);
+        const uint32_t ss = args.super_shift, S = cw >> ss;
+        unsigned long long before = 0;
+        uint32_t spins = 0;
+        bool bad = false;
+        for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SPIN_LIMIT) bad = true;
             }
-            for (uint32_t i = (S << ss) + lane; i < p; i += 64) { /* the shares in front inside its own super */
-                uint32_t v;
-                for (;;) {
-                    v = __hip_atomic_load(&args.share_status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((v >> 31) || bad) break;
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > SPIN_LIMIT) bad = true;
-                }
-                before += v & 0x7fffffffu;
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
-            const bool any_bad = __ballot(bad) != 0;
-            if (lane == 0) {
-                s_base = before;
-                if (any_bad) atomicAdd(&args.rec_super[256], 1ull);
-                if (p + 1 == n_shares) {
-                    /* the last share: the total is known. A region that ran out of space lost records; its fill counter kept
-                     * counting, so the total is still exact: report it, but never a value <= cap (that would claim the
-                     * output is complete) */
-                    const unsigned long long all = before + n_p;
-                    const unsigned long long flag =
-                        __hip_atomic_load(&args.rec_super[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
-                    *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
-                }
-            }
+            before += v & ((1ull << 40) - 1);
         }
-        __syncthreads();
-        const unsigned long long base = rfl64(s_base);
-        if (n_p && base + n_p <= args.cap) sort_share(args, lds_area, p * W, p * W + W, base);
-        if (p + 1 == n_shares && tid == 0 && args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64(); /* (the scan is as good as done) */
+        for (uint32_t i = (S << ss) + lane; i < cw; i += 64) { /* the regions in front inside its own super */
+            uint32_t v;
+            for (;;) {
+                v = __hip_atomic_load(&args.share_status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 31) || bad) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SPIN_LIMIT) bad = true;
+            }
+            before += v & 0x7fffffffu;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+        const unsigned long long base = rfl64(before);
+        const bool any_bad = __ballot(bad) != 0;
+        if (any_bad && lane == 0) atomicAdd(&args.rec_super[256], 1ull);
+        if (n_p && n_p <= args.rec_cap && base + n_p <= args.cap) { /* (a region that lost records is left alone: the scan says "again") */
+            const uint4 *region = args.rec_stage + (uint64_t)cw * args.rec_cap;
+            uint4 *out = (uint4 *)args.out + base;
+            for (uint32_t i = lane; i < n_p; i += 64) out[i] = region[i];
+        }
+        if (cw + 1 == args.rec_regions && lane == 0) {
+            /* the last region: the total is known. A region that ran out of space lost records; its fill counter kept
+             * counting, so the total is still exact: report it, but never a value <= cap (that would claim the output is
+             * complete). The same flag says that some wavefront had to emit out of order: again, in dense mode. */
+            const unsigned long long all = base + n_p;
+            const unsigned long long flag =
+                __hip_atomic_load(&args.rec_super[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
+            *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
+            if ((flag >> 32) && args.overflow_note) *args.overflow_note = 1u; /* more matches than the queue orders: dense mode next */
+            if (args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64(); /* (the scan is as good as done) */
+        }
     };
 
     uint32_t pending = ~0u, pending_n = 0;
     for (bool first = true;; first = false) {
         /* the first share is the workgroup's own index: a ticket taken by every workgroup of the grid at the same moment is
-         * 1 536 atomics on one address, ~0.1 us each one after the other. (Workgroups start in index order, so the holder of
-         * a lower first share is running whenever a higher one is.) */
+         * 1 536 atomics on one address, one after the other. (Workgroups start in index order, so the holder of a lower
+         * first share is running whenever a higher one is.) */
         if (tid == 0)
             s_share = first ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads(); /* (also: the gate is staged; the sort of the share before is done with the LDS area) */
+        __syncthreads(); /* (also: the gate is staged) */
         const uint32_t r = __builtin_amdgcn_readfirstlane(s_share); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
         if (r >= n_shares) break;
-        /* this wavefront's part of share r: batches wave, wave + W, ... of 128 candidate entries */
-        const uint32_t cw = r * W + wave; /* its record region */
+        const uint32_t cw = r * W + wave; /* this wavefront's record region */
         const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
-        init_wave_lds(t, &L.wave[wave], lane);
+        /* this wavefront's entries [base, end) in steps of `stride`: folded -- the w-th quarter of the share's batches of 128,
+         * so that the four regions are consecutive pieces of the corpus; unfolded -- batches wave, wave + W, ... */
+        const uint32_t nb = (n + 127) >> 7;
+        uint32_t base = fold ? (wave * nb / W) << 7 : wave << 7;
+        const uint32_t end = fold ? min(n, ((wave + 1) * nb / W) << 7) : n;
+        const uint32_t stride = fold ? 128u : 128u * W;
+        init_wave_lds(t, &wave_lds[wave], lane);
         uint32_t fill = 0;
-        if (wave * 128 < n) { /* else nothing for this wavefront: its record counts stay zero */
+        if (base < end) { /* else nothing for this wavefront: its record counts stay zero */
             t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
             const uint4 *region = args.cand + 2ull * r * args.cand_cap;
             /* (+16: the window of a chunk's last position is read as three dwords from entry byte 24; runtime.hip allocates the slack) */
             if (FAST) rs.region = __builtin_amdgcn_make_buffer_rsrc((void *)region, 0, (int)min((uint64_t)args.cand_cap * 32u + 16u, (uint64_t)0x7ffffff0), 0x00020000);
-            uint32_t base = wave * 128;
+            bool syncing = false; /* folded: the rest queue is being emptied for a sorted drain */
             for (;;) {
                 uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
-                bool valid[2] = {false, false};
-                bool fresh;
-                if (FAST) { /* the same schedule with masks for booleans (confirm_step_fast) */
-                    const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
-                    uint32_t vm[2];
-                    if (base < n && nrq <= RQ_CAP - 128) {
-                        const uint32_t i0 = base + lane, i1 = base + 64 + lane;
-                        vm[0] = m_less(i0, n), vm[1] = m_less(i1, n); /* ~0 when i < n: past the region's fill, entry 0 without candidate bits */
+                const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
+                if (!syncing && base < end && nrq <= RQ_CAP - 128) { /* a fresh batch (the step may queue up to 128 more) */
+                    const uint32_t i0 = base + lane, i1 = base + 64 + lane;
+                    base += stride;
+                    if (FAST) { /* the schedule of the general step with masks for booleans (confirm_step_fast) */
+                        uint32_t vm[2];
+                        vm[0] = m_less(i0, end), vm[1] = m_less(i1, end); /* ~0 when i < end: past the fill, entry 0 without candidate bits */
                         idx[0] = i0 & vm[0], idx[1] = i1 & vm[1];
-                        base += 128 * W;
                         confirm_step_fast<HAS_B, true>(t, rs, rq, idx, pend, vm);
-                    } else if (nrq) {
-                        const uint32_t k = min(nrq, 128u), first = nrq - k;
+                    } else {
+                        const bool valid[2] = {i0 < end, i1 < end};
+                        idx[0] = valid[0] ? i0 : 0, idx[1] = valid[1] ? i1 : 0; /* end > 0 here: entry 0 exists */
+                        confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, true);
+                    }
+                } else if (nrq) { /* entries with candidate bits left: same path, next bit */
+                    const uint32_t k = min(nrq, 128u), first_q = nrq - k;
+                    if (FAST) {
+                        uint32_t vm[2];
 #pragma unroll
                         for (int u = 0; u < 2; u++) {
                             vm[u] = m_less(u * 64 + lane, k);
-                            const uint2 it = rq[(first + u * 64 + lane) & vm[u]];
+                            const uint2 it = rq[(first_q + u * 64 + lane) & vm[u]];
                             idx[u] = it.x & vm[u], pend[u] = it.y & vm[u];
                         }
-                        if (lane == 0) t.wl->nrq = first;
+                        if (lane == 0) t.wl->nrq = first_q;
                         confirm_step_fast<HAS_B, false>(t, rs, rq, idx, pend, vm);
                     } else {
-                        break;
-                    }
-                    drain_matches(t, lane, 63);
-                    flush_records(t, lane, OFLUSH);
-                    continue;
-                }
-                const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
-                if (base < n && nrq <= RQ_CAP - 128) { /* the step may queue up to 128 more */
-                    fresh = true;
-                    const uint32_t i0 = base + lane, i1 = base + 64 + lane;
-                    valid[0] = i0 < n, valid[1] = i1 < n;
-                    idx[0] = valid[0] ? i0 : 0, idx[1] = valid[1] ? i1 : 0; /* n > 0 here: entry 0 exists */
-                    base += 128 * W;
-                } else if (nrq) { /* entries with candidate bits left: same path, next bit */
-                    fresh = false;
-                    const uint32_t k = min(nrq, 128u), first = nrq - k;
+                        bool valid[2];
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        valid[u] = u * 64 + lane < k;
-                        const uint2 it = rq[valid[u] ? first + u * 64 + lane : 0];
-                        idx[u] = valid[u] ? it.x : 0, pend[u] = valid[u] ? it.y : 0;
+                        for (int u = 0; u < 2; u++) {
+                            valid[u] = u * 64 + lane < k;
+                            const uint2 it = rq[valid[u] ? first_q + u * 64 + lane : 0];
+                            idx[u] = valid[u] ? it.x : 0, pend[u] = valid[u] ? it.y : 0;
+                        }
+                        if (lane == 0) t.wl->nrq = first_q;
+                        confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, false);
                     }
-                    if (lane == 0) t.wl->nrq = first;
+                } else if (fold) { /* a sync point with nothing pending: everything queued is final; in order into the region */
+                    drain_matches_sorted(t, rq, lane);
+                    syncing = false;
+                    if (base >= end) break;
+                    continue;
                 } else {
                     break;
                 }
-                confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, fresh);
-                drain_matches(t, lane, 63);
-                flush_records(t, lane, OFLUSH);
+                if (fold) {
+                    const uint32_t nmq = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    syncing = syncing || __builtin_amdgcn_readfirstlane(nmq) > SYNC_AT || base >= end;
+                } else {
+                    drain_matches(t, lane, 63);
+                    flush_records(t, lane, OFLUSH);
+                }
             }
-            drain_matches(t, lane, 0);
+            if (!fold) drain_matches(t, lane, 0);
             fill = publish_records(t, args, lane, cw, !fold);
+            if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[256], 1ull << 32); /* emitted out of order: "again", in dense mode */
         }
-        if (lane == 0) s_fill[wave] = fill;
-        __syncthreads(); /* the share is confirmed; nobody reads s_share any more */
         if (fold) {
             const HsgpuScanArgs &args = cold_args();
-            uint32_t n_r = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < W; w++) n_r += min(s_fill[w], 0x1fffffffu);
-            n_r = __builtin_amdgcn_readfirstlane(n_r);
             /* (Relaxed device-scope atomics throughout: the words carry counts, nothing is read through them. With
              * release / acquire semantics every publish wrote the whole L2 back (buffer_wbl2) and every poll invalidated it
              * (buffer_inv): the stage took 0.55 ms instead of 0.16.) */
-            if (tid == 0) { /* publish: the super's sum first, then the share's own word */
-                __hip_atomic_fetch_add(&args.rec_super[r >> args.super_shift], (1ull << 40) | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&args.share_status[r], 0x80000000u | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t n_r = min(fill, 0x7fffffffu);
+            if (lane == 0) { /* publish: the super's sum first, then the region's own word */
+                __hip_atomic_fetch_add(&args.rec_super[cw >> args.super_shift], (1ull << 40) | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&args.share_status[cw], 0x80000000u | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (pending != ~0u) place_and_sort(pending, pending_n);
-            pending = r, pending_n = n_r;
+            if (pending != ~0u) place_and_copy(pending, pending_n);
+            pending = cw, pending_n = n_r;
         }
+        __syncthreads(); /* nobody reads s_share any more */
     }
     if (fold) {
-        if (pending != ~0u) place_and_sort(pending, pending_n);
+        if (pending != ~0u) place_and_copy(pending, pending_n);
         const HsgpuScanArgs &args = cold_args();
         if (blockIdx.x == 0 && tid == 0 && args.tstamp_next) {
             args.tstamp_next[0] = ~0ull;

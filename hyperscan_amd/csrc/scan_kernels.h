@@ -49,11 +49,12 @@ struct HsgpuScanArgs {
     unsigned long long *rec_super;
     uint32_t super_shift;
     uint32_t group_regions;     /* consecutive regions that hold the records of one filter workgroup's corpus share */
-    /* the folded pipeline (hwlm_confirm_kernel places and sorts; no record_sort_kernel behind it): rec_super then counts
-     * SHARES -- word i = {shares published << 40 | their records} over 2^super_shift consecutive shares */
+    /* the folded pipeline (hwlm_confirm_kernel emits in order and places; no record_sort_kernel behind it): a word of
+     * rec_super then is {regions published << 40 | their records} over 2^super_shift consecutive regions; [256] = regions that
+     * lost records + (regions emitted out of order) << 32 */
     uint32_t fold;
     uint32_t *ticket;           /* the next share to confirm (persistent confirm workgroups take shares in ticket order) */
-    uint32_t *share_status;     /* [cand_waves] {valid << 31 | records of the share}, written once the share is confirmed */
+    uint32_t *share_status;     /* [rec_regions] {valid << 31 | records of the region}, written once its part is confirmed */
     /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
      * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */
     uint32_t *ctl_other;
