@@ -515,7 +515,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * the next scan finds its block zeroed without a memset. */
     const size_t cand_ofs = (size_t)2 * n_rec;
     const size_t super_ofs = (cand_ofs + n_waves + 1 + 1) & ~(size_t)1; /* 8-byte aligned */
-    const size_t status_ofs = super_ofs + 2 * 257;                     /* folded pipeline: one status word per region, */
+    const size_t status_ofs = super_ofs + 2 * HSGPU_SUPER_WORDS;                     /* folded pipeline: one status word per region, */
     const size_t ticket_ofs = status_ofs + n_rec;                      /* and the ticket counter */
     const size_t blk_words = (ticket_ofs + 1 + 3) & ~(size_t)3;
     /* a reallocated control buffer is garbage whatever its address: hipMalloc may hand the

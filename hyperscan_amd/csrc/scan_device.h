@@ -1627,7 +1627,11 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint2 *sor
     if (n == 0) return;
     const bool own0 = lane < n, own1 = lane + 64 < n;
     const uint2 it0 = t.wl->cand[own0 ? lane : 0], it1 = t.wl->cand[own1 ? lane + 64 : 0];
+#ifdef HSGPU_FOLD_NORANK /* timing experiment only: the queue resolved in arrival order */
+    if (false) {
+#else
     if (n > 1) {
+#endif
         const uint64_t k0 = match_key(it0), k1 = match_key(it1);
         uint32_t r0 = 0, r1 = 0;
         for (uint32_t q = 0; q < n; q++) { /* (one LDS address for the whole wavefront: a broadcast) */
@@ -1637,8 +1641,9 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint2 *sor
         }
         if (own0) sorted[r0] = it0;
         if (own1) sorted[r1] = it1;
-    } else if (lane == 0) {
-        sorted[0] = it0;
+    } else {
+        if (own0) sorted[lane] = it0;
+        if (own1) sorted[lane + 64] = it1;
     }
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
         const bool valid = i0 + lane < n;
@@ -1685,7 +1690,8 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ WaveLds wave_lds[W];
     __shared__ uint2 rest_q[W][RQ_CAP];
     __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
-    __shared__ uint32_t s_share;
+    __shared__ uint32_t s_share[2], s_fills[2][W]; /* (the ticket alternates between two words: written for round k + 1 while a slow wavefront may not have read round k's yet) */
+    __shared__ unsigned long long s_bases[2][W];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fold = args.fold != 0;
@@ -1724,25 +1730,33 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         rs.lits = __builtin_amdgcn_make_buffer_rsrc((void *)t.lits, 0, (int)0x7ffffff0, 0x00020000);
     }
 
-    /* Wavefront-convergent, folded pipeline: where region cw's n_p sorted records go (spinning on the regions in front only
-     * while they are still being confirmed), and their copy into the output. */
-    auto place_and_copy = [&](uint32_t cw, uint32_t n_p) {
+    /* Folded pipeline, wavefront 0 of the workgroup: where share p's records go -- the hypers (16 supers each) and supers in
+     * front of its first region, then the regions in front of it inside its own super: at most 16 + 15 + 63 relaxed loads,
+     * spinning only while a region in front is still being confirmed. The four regions' own places (the fills of the share's
+     * wavefronts are in LDS) go to LDS for the copy after the next barrier. */
+    auto place_share = [&](uint32_t p, const uint32_t *fills, unsigned long long *bases) {
         const HsgpuScanArgs &args = cold_args(); /* (shadows the kernel's: see cold_args) */
-        const uint32_t ss = args.super_shift, S = cw >> ss;
+        const uint32_t ss = args.super_shift, cw0 = p * W, S = cw0 >> ss, H = S >> 4;
         unsigned long long before = 0;
         uint32_t spins = 0;
         bool bad = false;
-        for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
-            unsigned long long v;
-            for (;;) {
-                v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > SPIN_LIMIT) bad = true;
+        if (lane < 32) {
+            const bool hyper = lane < 16;
+            const uint32_t i = hyper ? lane : (H << 4) + (lane - 16);
+            if (hyper ? i < H : i < S) {
+                const unsigned long long *w = hyper ? &args.rec_super[HSGPU_SUPER_HYPER0 + i] : &args.rec_super[i];
+                const uint32_t full = hyper ? (16u << ss) : (1u << ss);
+                unsigned long long v;
+                for (;;) {
+                    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 40) == full || bad) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > SPIN_LIMIT) bad = true;
+                }
+                before += v & ((1ull << 40) - 1);
             }
-            before += v & ((1ull << 40) - 1);
         }
-        for (uint32_t i = (S << ss) + lane; i < cw; i += 64) { /* the regions in front inside its own super */
+        for (uint32_t i = (S << ss) + lane; i < cw0; i += 64) { /* the regions in front inside its own super */
             uint32_t v;
             for (;;) {
                 v = __hip_atomic_load(&args.share_status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1754,36 +1768,48 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
-        const unsigned long long base = rfl64(before);
         const bool any_bad = __ballot(bad) != 0;
-        if (any_bad && lane == 0) atomicAdd(&args.rec_super[256], 1ull);
+        if (lane == 0) {
+            if (any_bad) atomicAdd(&args.rec_super[256], 1ull);
+            unsigned long long at = before;
+            for (uint32_t w = 0; w < W; w++) bases[w] = at, at += fills[w];
+            if (cw0 + W == args.rec_regions) {
+                /* the last share: the total is known. A region that ran out of space lost records; its fill counter kept
+                 * counting, so the total is still exact: report it, but never a value <= cap (that would claim the output is
+                 * complete). The same word says that some wavefront had to emit out of order: again, in dense mode. */
+                const unsigned long long flag =
+                    __hip_atomic_load(&args.rec_super[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
+                *args.count = (flag && at <= args.cap) ? args.cap + 1 : at;
+                if ((flag >> 32) && args.overflow_note) *args.overflow_note = 1u; /* more matches than the queue orders: dense mode next */
+            }
+        }
+    };
+    /* every wavefront: its (sorted) region of a placed share into the output */
+    auto copy_region = [&](uint32_t p, uint32_t n_p, unsigned long long base) {
+        const HsgpuScanArgs &args = cold_args();
         if (n_p && n_p <= args.rec_cap && base + n_p <= args.cap) { /* (a region that lost records is left alone: the scan says "again") */
-            const uint4 *region = args.rec_stage + (uint64_t)cw * args.rec_cap;
+            const uint4 *region = args.rec_stage + (uint64_t)(p * W + wave) * args.rec_cap;
             uint4 *out = (uint4 *)args.out + base;
             for (uint32_t i = lane; i < n_p; i += 64) out[i] = region[i];
         }
-        if (cw + 1 == args.rec_regions && lane == 0) {
-            /* the last region: the total is known. A region that ran out of space lost records; its fill counter kept
-             * counting, so the total is still exact: report it, but never a value <= cap (that would claim the output is
-             * complete). The same flag says that some wavefront had to emit out of order: again, in dense mode. */
-            const unsigned long long all = base + n_p;
-            const unsigned long long flag =
-                __hip_atomic_load(&args.rec_super[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
-            *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
-            if ((flag >> 32) && args.overflow_note) *args.overflow_note = 1u; /* more matches than the queue orders: dense mode next */
-            if (args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64(); /* (the scan is as good as done) */
-        }
+        if (p + 1 == n_shares && tid == 0 && args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64(); /* (the scan is as good as done) */
     };
 
-    uint32_t pending = ~0u, pending_n = 0;
-    for (bool first = true;; first = false) {
+    /* share confirmed in the iteration before (to be placed by wavefront 0 in this one), share placed in the iteration before
+     * (its bases in s_bases[slot]: to be copied in this one); this wavefront's fills of the two */
+    uint32_t conf_p = ~0u, conf_n = 0, placed_p = ~0u, placed_n = 0, slot = 0, round = 0;
+    for (bool first = true;; first = false, round ^= 1) {
         /* the first share is the workgroup's own index: a ticket taken by every workgroup of the grid at the same moment is
          * 1 536 atomics on one address, one after the other. (Workgroups start in index order, so the holder of a lower
          * first share is running whenever a higher one is.) */
         if (tid == 0)
-            s_share = first ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads(); /* (also: the gate is staged) */
-        const uint32_t r = __builtin_amdgcn_readfirstlane(s_share); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
+            s_share[round] = first ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads(); /* (also: the gate is staged; the fills and bases of the rounds before are in LDS) */
+        const uint32_t r = __builtin_amdgcn_readfirstlane(s_share[round]); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
+        if (fold && placed_p != ~0u) { /* placed by wavefront 0 before the barrier: every wavefront copies its own region */
+            copy_region(placed_p, placed_n, rfl64(s_bases[slot ^ 1][wave]));
+            placed_p = ~0u;
+        }
         if (r >= n_shares) break;
         const uint32_t cw = r * W + wave; /* this wavefront's record region */
         const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
@@ -1866,17 +1892,28 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
              * release / acquire semantics every publish wrote the whole L2 back (buffer_wbl2) and every poll invalidated it
              * (buffer_inv): the stage took 0.55 ms instead of 0.16.) */
             const uint32_t n_r = min(fill, 0x7fffffffu);
-            if (lane == 0) { /* publish: the super's sum first, then the region's own word */
-                __hip_atomic_fetch_add(&args.rec_super[cw >> args.super_shift], (1ull << 40) | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) { /* publish: the sums of the region's super and hyper, then the region's own word */
+                const unsigned long long one = (1ull << 40) | n_r;
+                const uint32_t S = cw >> args.super_shift;
+                __hip_atomic_fetch_add(&args.rec_super[HSGPU_SUPER_HYPER0 + (S >> 4)], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&args.rec_super[S], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&args.share_status[cw], 0x80000000u | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_fills[slot][wave] = n_r;
             }
-            if (pending != ~0u) place_and_copy(pending, pending_n);
-            pending = cw, pending_n = n_r;
+            /* DEFERRED by one share: the share confirmed in the iteration before is placed now, by wavefront 0 (its fills went
+             * to LDS before this iteration's barrier), and copied by everybody after the next barrier */
+            if (conf_p != ~0u && wave == 0) place_share(conf_p, s_fills[slot ^ 1], s_bases[slot]);
+            placed_p = conf_p, placed_n = conf_n;
+            conf_p = r, conf_n = n_r;
+            slot ^= 1;
         }
-        __syncthreads(); /* nobody reads s_share any more */
     }
     if (fold) {
-        if (pending != ~0u) place_and_copy(pending, pending_n);
+        /* the tickets have run out (the barrier at the top of the last round has been passed, the share placed before it copied):
+         * place the last share confirmed, copy it */
+        if (conf_p != ~0u && wave == 0) place_share(conf_p, s_fills[slot ^ 1], s_bases[slot]);
+        __syncthreads();
+        if (conf_p != ~0u) copy_region(conf_p, conf_n, rfl64(s_bases[slot][wave]));
         const HsgpuScanArgs &args = cold_args();
         if (blockIdx.x == 0 && tid == 0 && args.tstamp_next) {
             args.tstamp_next[0] = ~0ull;

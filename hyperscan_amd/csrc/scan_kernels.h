@@ -16,6 +16,8 @@
 #define HSGPU_CONFIRM_SPLIT 4 /* confirm wavefronts per candidate region (tuning builds: 2) */
 #endif
 #define HSGPU_HINT_SHIFT 10 /* one block hint per KiB of corpus */
+#define HSGPU_SUPER_HYPER0 257 /* rec_super: [0, 256) supers, [256] flags, [257, 273) "hypers" = sums over 16 supers (folded pipeline) */
+#define HSGPU_SUPER_WORDS 273
 
 struct HsgpuScanArgs {
     const uint8_t *corpus;      /* all blocks, concatenated; 16-byte aligned */

@@ -4,7 +4,9 @@
               reversed match = every end of the forward match (all-matches semantics, as hs_scan reports `to`)
   ends_numpy  an independent restatement with run lengths (no bit tricks): per block, per position, the length of
               the run of A ending before it and the B-run reaching it
-Both return, per pattern, a sorted array of (block, end) with `end` the offset of the last byte of the match."""
+  ends_vec    the same statement without a Python loop over bytes (prefix sums over the whole batch): what bench.py gates
+              megabytes with; pinned to the two above in tests/test_class_seq_cpu.py
+All return, per pattern, a sorted array of (block, end) with `end` the offset of the last byte of the match."""
 import re
 
 import numpy as np
@@ -46,3 +48,46 @@ def ends_numpy(corpus, off, a_members, b_members, m, n):
             # earliest run broke (not B) a new one may start at a position that is both B and preceded by A's
             run_a = run_a + 1 if isa[i] else 0
     return np.array(out, dtype=np.int64).reshape(-1, 2)
+
+
+class VecModel:
+    """ends_vec over one CSR batch for many patterns: the per-class run lengths are computed once."""
+
+    def __init__(self, corpus, off):
+        self.corpus = np.ascontiguousarray(corpus)
+        self.off = np.asarray(off, dtype=np.int64)
+        N = int(self.corpus.size)
+        lens = np.diff(self.off)
+        self.blk = np.repeat(np.arange(lens.size, dtype=np.int64), lens)          # block of every byte
+        self.bstart = np.repeat(self.off[:-1], lens)                              # its block's first byte
+        self.idx = np.arange(N, dtype=np.int64)
+        self._runs = {}
+
+    def run(self, members):
+        """length of the run of class members ending at every byte, inside its block (0 where the byte is no member)"""
+        key = bytes(sorted(set(members)))
+        if key not in self._runs:
+            mem = np.isin(self.corpus, np.frombuffer(key, dtype=np.uint8))
+            last_non = np.maximum.accumulate(np.where(mem, -1, self.idx))          # last non-member at or before i (-1: none)
+            r = np.where(mem, np.minimum(self.idx - last_non, self.idx - self.bstart + 1), 0)
+            self._runs[key] = r
+        return self._runs[key]
+
+    def ends(self, a_members, b_members, m, n):
+        N = int(self.corpus.size)
+        if N == 0:
+            return np.zeros((0, 2), dtype=np.int64)
+        ra, rb = self.run(a_members), self.run(b_members)
+        # G[s]: a split may sit in front of byte s -- at least m members of A end at s - 1, in the same block as s
+        G = np.zeros(N + 1, dtype=np.int64)
+        G[1:N] = (ra[: N - 1] >= m) & (self.bstart[1:] != self.idx[1:])
+        P = np.concatenate([[0], np.cumsum(G)])                                    # P[k] = splits in front of bytes < k
+        e = np.flatnonzero(rb >= n)
+        lo, hi = e - rb[e] + 1, e - n + 1                                          # the B-run may start at any s in [lo, hi]
+        ok = P[hi + 1] - P[lo] > 0
+        e = e[ok]
+        return np.stack([self.blk[e], e - self.bstart[e]], axis=1)
+
+
+def ends_vec(corpus, off, a_members, b_members, m, n):
+    return VecModel(corpus, off).ends(a_members, b_members, m, n)
