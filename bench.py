@@ -19,7 +19,10 @@ target on:
   rose1000  config 5: 1000 literal-prefix + tail patterns through hs_scan_batch: GPU literal
             hits feeding the host-side confirm, 2 GiB of packets                  ("also", N = 1)
 
-One JSON line on stdout (rank 0).
+One JSON line on stdout (rank 0), kept under ~6 KB so that the driver's record holds all of it: the headline with its
+`roofline` and `cpu_baseline`, and under `also` one compact object per extra workload (value, roofline, cpu_baseline, parity).
+Everything else -- thread sweeps, per-stage breakdowns, table descriptions -- goes to stderr and to bench_details.json
+(beside gpurun_out/ when that exists, else beside this file); `details` in the line names it.
 """
 import argparse
 import ctypes as C
@@ -33,7 +36,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "r03_bench_pmc_summary.json"  # tools/round_profile.sh writes it from the PMC passes of this same command
+PMC_SUMMARY = "r04_bench_pmc_summary.json"  # tools/round_profile.sh writes it from the PMC passes of this same command
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REC_BYTES = 16
 WORKLOAD_DESC = {
@@ -266,6 +269,25 @@ def parity_gate(recs, gate, lits):
     return f"sorted (block,end,id) multisets identical on the first {kg} blocks ({len(want)} matches); delivery order checked"
 
 
+def gpu_vs_gpu_gate(job):
+    """The whole resident corpus, every record: the default pipeline (confirm wavefronts emit in order and place their
+    regions themselves) against the always-correct fused pipeline + record_sort_kernel on a second scratch -- the two share
+    the filter's arithmetic and nothing of what follows it. Identical arrays, element for element, or the bench stops."""
+    torch = job.torch
+    other = GpuJob(None, None, None, torch.cuda.current_device(), sibling=job, cap=job.cap)
+    other.scratch.set_tuning(1)
+    job.launch()
+    other.launch()
+    torch.cuda.synchronize()
+    n, n2 = job.count(), other.count()
+    assert n == n2 and n <= job.cap, f"PARITY FAILURE: default pipeline {n} records, fused pipeline {n2}"
+    same = bool(torch.equal(job.d_out[: n * 4], other.d_out[: n * 4]))
+    assert same, "PARITY FAILURE: the default and the fused pipeline deliver different record arrays"
+    del other
+    torch.cuda.empty_cache()
+    return f"all {n} records of the whole {job.total}-byte corpus identical, element for element, to the fused pipeline's (GPU vs GPU)"
+
+
 def run_workload(name, args, rank, world, dist, do_cpu):
     import torch
 
@@ -312,6 +334,10 @@ def run_workload(name, args, rank, world, dist, do_cpu):
     n_matches = job.count()
     assert n_matches <= job.cap, "record buffer too small"
     assert all(jb.count() == n_matches for jb in jobs)
+    whole_gate = gpu_vs_gpu_gate(job) if (dist is None and rank == 0) else None
+    if whole_gate:
+        run_steps(1)
+        torch.cuda.synchronize()
 
     exch = None
     if dist is not None:
@@ -439,6 +465,8 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         "records": "in delivery order (block, end, lit), sorted on the device inside the step",
     }
     res["pipeline_depth"] = depth
+    if whole_gate:
+        res["parity_whole_corpus"] = whole_gate
     if overlapped:
         res["two_scans_in_flight"] = overlapped
     if dist is not None:
@@ -543,10 +571,18 @@ def run_class256(args):
     names = [CLASS_POOL[i][0] for i in sorted(used)]
     total_gib = args.class_gib
     t0 = time.perf_counter()
-    unit, uoff = cp.line_corpus(1 << 30, seed=5)  # 1 GiB of lines, laid out total_gib times (offsets shifted)
+    # total_gib GiB of DISTINCT lines: one generator call per GiB, seeds 5, 6, ... (round 3 laid one GiB out four times)
     reps = max(1, int(total_gib))
-    corpus = np.tile(unit, reps)
-    off = np.concatenate([uoff[:-1] + np.uint64(r * unit.size) for r in range(reps)] + [np.array([reps * unit.size], dtype=np.uint64)])
+    parts, offs, at = [], [], 0
+    for r_ in range(reps):
+        u, uo = cp.line_corpus(int((total_gib / reps) * (1 << 30)), seed=5 + r_)
+        parts.append(u)
+        offs.append(uo[:-1] + np.uint64(at))
+        at += int(u.size)
+    unit, uoff = parts[0], np.concatenate([offs[0], [np.uint64(parts[0].size)]]).astype(np.uint64)
+    corpus = np.concatenate(parts) if reps > 1 else parts[0]
+    off = np.concatenate(offs + [np.array([at], dtype=np.uint64)]).astype(np.uint64)
+    del parts, offs
     total, nb = int(corpus.size), int(off.size - 1)
     log(f"class256: {len(classes)} distinct classes of 256 patterns, {total} bytes / {nb} lines in {time.perf_counter() - t0:.1f}s")
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -572,17 +608,26 @@ def run_class256(args):
     # a run-length restatement of the patterns (tests/class_seq_model.py, itself pinned to Python's re), every pattern
     from tests import class_seq_model as csm
 
-    kg = 24
+    # ... on >= 4 MiB of lines, in slices that fit a record buffer (0.74 match ends per corpus byte), with the vectorised model
+    kg = int(np.searchsorted(off, args.class_gate_mib << 20, side="left"))
     g_hi = int(off[kg])
-    counts_g, recs_g, n_emit = accel.class_seq_scan(seqs, bitmaps, total, d_off, nb, (0, g_hi), 1 << 22)
-    assert n_emit == len(recs_g), "gate slice overflowed its record buffer"
-    n_checked = 0
-    for k, (a, b, m, n_, _id) in enumerate(seqs):
-        want = csm.ends_numpy(corpus[:g_hi], off[: kg + 1], classes[a].members(), classes[b].members(), m, n_)
-        g = recs_g[recs_g[:, 3] == k]
-        g = g[np.lexsort((g[:, 1], g[:, 0]))][:, :2].astype(np.int64)
-        assert np.array_equal(g, want), f"PARITY FAILURE: pattern {k} {pats[k]}: GPU {len(g)} match ends vs model {len(want)}"
-        n_checked += len(want)
+    vm = csm.VecModel(corpus[:g_hi], off[: kg + 1])
+    want_all = [vm.ends(classes[a].members(), classes[b].members(), m, n_) for (a, b, m, n_, _id) in seqs]
+    n_checked, slice_blocks = 0, max(1, kg // 8)
+    for b0 in range(0, kg, slice_blocks):
+        b1 = min(kg, b0 + slice_blocks)
+        counts_g, recs_g, n_emit = accel.class_seq_scan(seqs, bitmaps, total, d_off, nb, (int(off[b0]), int(off[b1])), 1 << 24)
+        assert n_emit == len(recs_g), "gate slice overflowed its record buffer"
+        order = np.lexsort((recs_g[:, 1], recs_g[:, 0], recs_g[:, 3]))
+        recs_g = recs_g[order]
+        cuts = np.searchsorted(recs_g[:, 3], np.arange(len(seqs) + 1))
+        for k in range(len(seqs)):
+            w = want_all[k]
+            w = w[(w[:, 0] >= b0) & (w[:, 0] < b1)]
+            g = recs_g[cuts[k]:cuts[k + 1], :2].astype(np.int64)
+            assert np.array_equal(g, w), f"PARITY FAILURE: pattern {k} {pats[k]}: GPU {len(g)} match ends vs model {len(w)} in blocks [{b0}, {b1})"
+            n_checked += len(w)
+    del vm, want_all
     seq_buf = accel.class_seq_buffers(len(seqs), total, 0, dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -605,14 +650,14 @@ def run_class256(args):
     traffic, traffic_src = pmc_traffic_sum("class_tile_fl_kernel", len(passes))
     res = {"workload": f"class256: 256 patterns A{{m,}}B+ over {len(classes)} distinct classes {names}: class bitmaps + first/last in "
                        f"{len(passes)} passes of <= 8, then every pattern's match ends from the bitmaps; "
-                       f"{total / (1 << 30):g} GiB line corpus (1 GiB of lines x {reps}), {nb} blocks",
+                       f"{total / (1 << 30):g} GiB of distinct lines (seeded per GiB), {nb} blocks",
            "value": round(total * args.steps / dt / 1e9, 2), "unit": "GB/s of corpus (bitmaps, first/last and all 256 patterns)",
            "ms_per_step": round(dt / args.steps * 1e3, 3),
            "matches_per_step": n_matches, "matches_per_s": round(n_matches * args.steps / dt, 1),
            "matches": "counted per pattern on the device over the whole corpus (several per corpus byte: no record buffer holds them); "
                       "16-byte records are emitted for a byte range on request",
-           "parity": f"(block, end) of every one of the 256 patterns on the first {kg} lines ({n_checked} match ends) identical to the "
-                     "run-length model of tests/class_seq_model.py (pinned to Python re in the CPU suite); class bitmaps against numpy",
+           "parity": f"(block, end) of every one of the 256 patterns on the first {kg} lines / {g_hi} bytes ({n_checked} match ends) identical to the "
+                     "vectorised run-length model of tests/class_seq_model.py (pinned to Python re in the CPU suite); class bitmaps against numpy on 1 MiB",
            "class_stage": {"ms": round(ms, 3), "GBps_of_corpus": round(total / (ms / 1e3) / 1e9, 1)},
            "sequence_stage": {"ms": round(ms_seq, 3), "GBps_of_corpus": round(total / (ms_seq / 1e3) / 1e9, 1),
                               "kernel": "class_seq_kernel (one lane per pattern; instruction bound, not HBM bound)"},
@@ -737,17 +782,21 @@ def run_flood(args):
 # ---- config 5: literal hits feeding the host-side confirm ---------------------------------------
 
 def run_rose1000(args):
+    """Config 5 ("report GPU GB/s, host confirm hits/s, end-to-end GB/s" + a parity gate): 1000 patterns
+    LIT_k + tail. GPU literal hits feed the host-side confirm (the reference: src/rose/match.c:479-523 calling into
+    src/rose/program_runtime.c:2896-2942 per literal hit)."""
     import torch
 
     from hyperscan_amd import corpus as cp
     from hyperscan_amd import hs
+    from hyperscan_amd.hwlm import HwlmLiteral
     from tests import oracle_binding as ob
+    from tests import rose_model as RM
 
     rng = np.random.default_rng(6)
     alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ", dtype=np.uint8)
-    tails = [r"[a-z]+\d", r"\s+\w{2,8}=", r".{0,16}END"]
     lits = sorted({bytes(rng.choice(alpha, int(rng.integers(6, 13)))) for _ in range(1000)})
-    pats = [l.decode() + tails[i % 3] for i, l in enumerate(lits)]
+    pats = [l.decode() + RM.TAILS[i % 3] for i, l in enumerate(lits)]
     db = hs.Database.compile(pats, [0] * len(pats), list(range(len(pats))))
     scratch = hs.HsScratch(db)
     total = int(args.rose_gib * (1 << 30))
@@ -764,6 +813,25 @@ def run_rose1000(args):
     pinned = torch.from_numpy(corpus).pin_memory()
     buf = pinned.numpy()
     offs = np.ascontiguousarray(off, dtype=np.uint64)
+
+    # -- parity gate: (block, id, to) of a slice through hs_scan_batch against the model of tests/rose_model.py (pinned to
+    #    Python re and to hs_confirm_batch in the CPU suite); the literal occurrences of the model come from the HWLM oracle
+    kg = max(1, int(np.searchsorted(off, 8 << 20, side="right")) - 1)
+    g_off = np.ascontiguousarray(off[: kg + 1])
+    g_bytes = int(g_off[-1])
+    keyed = db.literals()
+    hl = [HwlmLiteral(k[0], k[1], i) for i, k in enumerate(keyed)]
+    hits = (ob.Reference(hl, variant=ob.ref_variants()[-1]) if ob.ref_available() else ob.Oracle(hl)).collect_blocks(corpus[:g_bytes], g_off)
+    want = RM.expected_events(corpus[:g_bytes], g_off, lits, hits)
+    got = []
+    cb = hs.BATCH_CB(lambda b, i, f, t, _fl, _c: (got.append((int(b), int(i), int(t))), 0)[1])
+    rv = lib.hs_scan_batch(db._h, buf.ctypes.data, g_off.ctypes.data, kg, 0, scratch._h, cb, None)
+    assert rv == 0
+    assert sorted(got) == want, f"PARITY FAILURE (rose1000): hs_scan_batch {len(got)} events vs model {len(want)} on the first {kg} blocks"
+    parity = (f"(block, id, to) of all 1000 patterns on the first {kg} blocks / {g_bytes} bytes ({len(want)} events) identical to the model of "
+              "tests/rose_model.py (literal occurrences from the reference's hwlmExec, tails restated; pinned to Python re in the CPU suite)")
+
+    # -- end to end from pinned host memory
     ts, n_ev = [], 0
     for _ in range(max(3, min(args.steps, 5)) + 1):
         cnt = C.c_ulonglong(0)
@@ -774,14 +842,60 @@ def run_rose1000(args):
         assert n_ev in (0, cnt.value), "match count changed between repeats"
         n_ev = cnt.value
     t = float(np.median(ts[1:]))
+
+    # -- the legs of that figure, each alone: the bus, the GPU literal stage on a resident corpus, the host confirm
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_tmp = torch.empty(total, dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h2d = []
+    for _ in range(3):
+        e0.record()
+        d_tmp.copy_(pinned, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize()
+        h2d.append(e0.elapsed_time(e1))
+    del d_tmp
+    job = GpuJob(hl, corpus, off, torch.cuda.current_device())
+    for _ in range(3):
+        job.launch()
+    torch.cuda.synchronize()
+    n_hits = job.count()
+    assert n_hits <= job.cap
+    steps = max(3, min(args.steps, 10))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.launch()
+    torch.cuda.synchronize()
+    t_gpu = (time.perf_counter() - t0) / steps
+    f_ms = float(np.mean([job.scratch.timing(b)[0] for b in range(steps)]))
+    recs = np.ascontiguousarray(job.records())
+    lib.hs_confirm_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_ulonglong, hs.BATCH_CB, C.c_void_p]
+    tc = []
+    for _ in range(3):
+        cnt = C.c_ulonglong(0)
+        t0 = time.perf_counter()
+        rv = lib.hs_confirm_batch(db._h, buf.ctypes.data, offs.ctypes.data, offs.size - 1, recs.ctypes.data, len(recs), handler, C.byref(cnt))
+        tc.append(time.perf_counter() - t0)
+        assert rv == 0 and cnt.value == n_ev, f"host confirm over the resident scan's hits: {cnt.value} events, hs_scan_batch {n_ev}"
+    t_conf = float(np.median(tc))
+    alg = total + REC_BYTES * n_hits
     res = {"workload": f"rose1000: 1000 literal-prefix + tail patterns, {args.rose_gib:g} GiB of packets through hs_scan_batch from pinned host "
                        "memory (H2D of the corpus + GPU literal scan + D2H of the records + host confirm + counting callback)",
            "value": round(total / t / 1e9, 2), "unit": "GB/s end to end", "ms": round(t * 1e3, 1), "matches": int(n_ev),
-           "matches_per_s": round(n_ev / t, 1)}
+           "matches_per_s": round(n_ev / t, 1), "parity": parity,
+           "gpu_stage": {"GBps": round(total / t_gpu / 1e9, 1), "ms": round(t_gpu * 1e3, 3), "literal_hits": int(n_hits),
+                         "what": "the database's literal table over the same corpus RESIDENT in HBM (hsgpu_hwlm_scan_dev, serial steps)"},
+           "host_confirm": {"hits_per_s": round(n_hits / t_conf, 1), "ms": round(t_conf * 1e3, 2), "events": int(n_ev),
+                            "threads": "the facade's own (hs_confirm_batch over the resident scan's hits)"},
+           "pinned_h2d_GBps": round(total / (float(np.median(h2d)) / 1e3) / 1e9, 1),
+           "bound": "the bus: end to end cannot exceed pinned_h2d_GBps; the GPU stage and the host confirm hide behind the copies",
+           "roofline": {"bound": "hbm", "achieved": round(alg / (f_ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (f_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": filter_kernel_name(job.table.info()["flags"]), "kernel_ms_avg": round(f_ms, 4),
+                        "algorithmic_bytes_per_launch": int(alg), "what": "the resident GPU stage's filter kernel (HIP events)"}}
+    del job
+    torch.cuda.empty_cache()
     if ob.ref_available():
-        from hyperscan_amd.hwlm import HwlmLiteral
-
-        hl = [HwlmLiteral(l[-8:], False, i) for i, l in enumerate(lits)]
         k = int(np.searchsorted(off, 256 << 20, side="right")) - 1
         s_off = np.ascontiguousarray(off[: k + 1])
         cpus = len(os.sched_getaffinity(0))
@@ -803,6 +917,112 @@ def run_rose1000(args):
     return res
 
 
+def run_batch_sweep(args):
+    """hsbench block mode is ONE hs_scan per block (tools/hsbench/engine_hyperscan.cpp:132-145, main.cpp:502-528): what a call
+    costs at that granularity, and how large a resident batch must be before hsgpu_hwlm_scan_dev reaches its throughput."""
+    import torch
+
+    from hyperscan_amd import hwlm as hw
+
+    lits, corpus, off = build_workload("fdr10k", 1 << 30, 0)
+    job = GpuJob(lits, corpus, off, torch.cuda.current_device())
+    for _ in range(2):
+        job.launch()
+    torch.cuda.synchronize()
+    sizes = [1460, 64 << 10, 1 << 20, 16 << 20, 256 << 20, 1 << 30]
+    curve, peak = [], 0.0
+    stream = torch.cuda.current_stream().cuda_stream
+    for sz in sizes:
+        k = max(1, int(np.searchsorted(off, sz, side="right")) - 1)
+        tot = int(off[k])
+        it = 200 if tot < (16 << 20) else 20
+        for _ in range(3):
+            hw.hwlm_scan_dev(job.table, job.scratch, job.d_corpus.data_ptr(), tot, job.d_off.data_ptr(), k, job.d_out.data_ptr(), job.cap,
+                             job.d_count.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(it):
+            hw.hwlm_scan_dev(job.table, job.scratch, job.d_corpus.data_ptr(), tot, job.d_off.data_ptr(), k, job.d_out.data_ptr(), job.cap,
+                             job.d_count.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / it
+        curve.append({"bytes": tot, "blocks": k, "us_per_scan": round(dt * 1e6, 1), "GBps": round(tot / dt / 1e9, 2)})
+        peak = max(peak, tot / dt / 1e9)
+
+    def reach(fr):
+        for a, b in zip(curve, curve[1:]):
+            if a["GBps"] < fr * peak <= b["GBps"]:  # log-linear interpolation between the two measured sizes
+                w = (fr * peak - a["GBps"]) / (b["GBps"] - a["GBps"])
+                return int(np.exp(np.log(a["bytes"]) + w * (np.log(b["bytes"]) - np.log(a["bytes"]))))
+        return curve[0]["bytes"] if curve[0]["GBps"] >= fr * peak else None
+    # one call per block, the way hsbench drives hs_scan: hsgpu_hwlm_exec on one 1460-byte packet (H2D + scan + D2H + callbacks)
+    k1 = int(np.argmax(np.diff(off.astype(np.int64)) == 1460))
+    blk = np.ascontiguousarray(corpus[int(off[k1]):int(off[k1 + 1])])
+    n_cb = [0]
+
+    def cb(end, lid, ctx):
+        n_cb[0] += 1
+        return hw.HWLM_ALL_GROUPS
+    for _ in range(5):
+        hw.hwlm_exec(job.table, blk, 0, cb, job.scratch)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        hw.hwlm_exec(job.table, blk, 0, cb, job.scratch)
+    us_exec = (time.perf_counter() - t0) / 200 * 1e6
+    res = {"workload": "fdr10k table; resident scans of the first N bytes of the 1 GiB corpus, serial launches (hsgpu_hwlm_scan_dev), and one "
+                       "hsgpu_hwlm_exec call per 1460-byte block from host memory",
+           "value": round(peak, 1), "unit": "GB/s at the largest batch",
+           "us_per_hwlm_exec_call_1460B": round(us_exec, 1), "GBps_one_block_per_call": round(1460 / us_exec / 1e3, 4),
+           "half_peak_batch_bytes": reach(0.5), "ninety_percent_batch_bytes": reach(0.9), "curve": curve}
+    del job
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---- the ONE line: compact, everything else to the details file ---------------------------------
+
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms_avg",
+                 "kernel_ms_device_clock_avg", "algorithmic_bytes_per_launch", "algorithmic_bytes_per_step", "ms_all_passes", "pipeline_ms_avg")
+CPU_KEYS = ("value", "unit", "cores", "kind", "cgroup_cpu_quota", "sample", "parity")
+
+
+def _short(v, n=200):
+    return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+
+def compact_roofline(r):
+    if not r:
+        return r
+    out = {k: r[k] for k in ROOFLINE_KEYS if k in r}
+    if isinstance(out.get("kernel"), str):
+        out["kernel"] = out["kernel"].replace("true", "1").replace("false", "0").replace(", ", ",")
+    return out
+
+
+def compact_cpu(c):
+    return {k: _short(c[k], 150) for k in CPU_KEYS if k in c} if c else c
+
+
+def compact_also(name, r):
+    if "error" in r:
+        return r
+    keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "matches_per_s", "parity", "gpu_stage", "host_confirm",
+            "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "GBps_one_block_per_call",
+            "half_peak_batch_bytes", "ninety_percent_batch_bytes", "curve", "parity_whole_corpus")
+    out = {"workload": _short(r.get("workload", name), 110)}
+    for k in keep:
+        if k in r:
+            v = r[k]
+            if isinstance(v, dict):
+                v = {kk: vv for kk, vv in v.items() if kk not in ("what", "kernel", "threads")}
+            out[k] = _short(v, 170)
+    if "roofline" in r:
+        out["roofline"] = compact_roofline(r["roofline"])
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = {k: v for k, v in compact_cpu(r["cpu_baseline"]).items() if k != "sample"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -811,8 +1031,10 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0, help="corpus GiB per GPU")
     ap.add_argument("--workload", default="fdr10k", choices=["teddy64", "fdr10k"])
     ap.add_argument("--no-also", action="store_true", help="skip the other workloads' lines")
-    ap.add_argument("--also", default="teddy64,class256,rose1000,flood,fdr10k_8g", help="comma-separated extra workloads at N = 1")
+    ap.add_argument("--also", default="teddy64,class256,rose1000,flood,fdr10k_8g,batch_sweep", help="comma-separated extra workloads at N = 1")
     ap.add_argument("--class-gib", type=float, default=4.0)
+    ap.add_argument("--class-gate-mib", type=int, default=4, help="class256: MiB of lines whose match ends are compared with the model")
+    ap.add_argument("--details", default=None, help="where the full (uncompacted) result goes; default gpurun_out/bench_details.json")
     ap.add_argument("--rose-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--overlap-probe", action="store_true",
@@ -864,6 +1086,8 @@ def main():
                     also[name] = run_rose1000(args)
                 elif name == "flood":
                     also[name] = run_flood(args)
+                elif name == "batch_sweep":
+                    also[name] = run_batch_sweep(args)
                 elif name == "fdr10k_8g":  # config 3's whole 8 GiB on ONE GPU: the N = 1 point of the strong-scaling curve
                     import copy
 
@@ -872,7 +1096,7 @@ def main():
                     a8.steps, a8.warmup = max(3, min(args.steps, 10)), 2
                     r8 = run_workload("fdr10k", a8, rank, world, None, False)
                     also[name] = {"workload": f"fdr10k, {args.shards} shards x {args.gib:g} GiB resident on one GPU ({args.shards * args.gib:g} GiB per step)",
-                                  **{k: r8[k] for k in ("value", "ms_per_step", "matches_per_s", "matches_per_step")},
+                                  **{k: r8[k] for k in ("value", "ms_per_step", "matches_per_s", "matches_per_step", "parity_whole_corpus")},
                                   "unit": "GB/s", "roofline": r8["roofline"]}
                 elif name != args.workload:
                     also[name] = run_workload(name, args, rank, world, dist, do_cpu)
@@ -882,6 +1106,7 @@ def main():
 
     if rank == 0:
         blocks_desc = "synthetic packets {64,128,256,576,1024,1460} B, 70% HTTP-like text / 30% random"
+        full = {"headline": main_res, "also": also}
         out = {
             "metric": "GB/s scanned (hsbench block mode)", "value": main_res["value"], "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
@@ -892,13 +1117,42 @@ def main():
                                     f"strong: {args.shards} shards x {args.gib:g} GiB in all, {args.shards // world} per GPU")
                        + (", RCCL all-gather of records per step" if dist is not None else "")},
             "matches_per_s": main_res["matches_per_s"], "matches_per_step": main_res["matches_per_step"],
-            "roofline": main_res["roofline"], "table": main_res["table"],
+            "roofline": compact_roofline(main_res["roofline"]),
         }
-        for k in ("cpu_baseline", "end_to_end_resident", "host_buffers", "exchange", "two_scans_in_flight"):
+        if "cpu_baseline" in main_res:
+            out["cpu_baseline"] = compact_cpu(main_res["cpu_baseline"])
+        if "parity_whole_corpus" in main_res:
+            out["parity"] = {"reference": _short(main_res.get("cpu_baseline", {}).get("parity", "no CPU leg in this run"), 170),
+                             "whole_corpus": _short(main_res["parity_whole_corpus"], 170)}
+        if "end_to_end_resident" in main_res:
+            e = main_res["end_to_end_resident"]
+            out["end_to_end_resident"] = {k: e[k] for k in ("GBps", "ms", "replay_threads", "matches_delivered")}
+        if "host_buffers" in main_res:
+            out["host_buffers"] = {k: main_res["host_buffers"][k] for k in ("GBps", "pipelined_GBps", "sample_bytes")}
+        for k in ("exchange", "two_scans_in_flight", "multi_gpu"):
             if k in main_res:
                 out[k] = main_res[k]
         if also:
-            out["also"] = also
+            out["also"] = {k: compact_also(k, v) for k, v in also.items()}
+        # the full objects: stderr and a side file
+        dpath = args.details or os.path.join(ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "", "bench_details.json")
+        try:
+            os.makedirs(os.path.dirname(dpath), exist_ok=True)
+            with open(dpath, "w") as f:
+                json.dump(full, f, indent=1)
+            out["details"] = os.path.relpath(dpath, ROOT)
+        except OSError as e:
+            out["details"] = f"not written ({e})"
+        log("bench details: " + json.dumps(full))
+        line = json.dumps(out)
+        if len(line) > 6000:  # the driver keeps an ~8.5 KB tail of stdout: shed what the details file holds anyway
+            for k in ("curve",):
+                for v in out.get("also", {}).values():
+                    v.pop(k, None)
+            for v in out.get("also", {}).values():
+                v.pop("workload", None)
+            line = json.dumps(out)
+        out_line = line
     if dist is not None:
         # every rank empties its C stdio buffer (RCCL's banner) before anyone can print the result line
         sys.stdout.flush()
@@ -916,7 +1170,7 @@ def main():
             C.CDLL(None).fflush(None)
         except OSError:
             pass
-        print(json.dumps(out), flush=True)
+        print(out_line, flush=True)
 
 
 if __name__ == "__main__":

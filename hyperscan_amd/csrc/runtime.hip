@@ -560,9 +560,10 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * given), and not without the mapped "again" note (the fused kernel then has to run between confirm and sort). */
     const bool fold = two_phase && s->cand_div != 16 && s->d_note && !s->tune_unfolded;
     args.fold = fold ? 1u : 0u;
-    /* up to 256 supers of 2^super_shift regions: atomics on one address serialise (64 regions share one at 16 384 regions) */
-    args.super_shift = 5;
-    while (((n_rec + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
+    /* up to 256 supers: atomics on one address go one after the other (~0.1 us each). Unfolded: supers of 2^super_shift regions, one
+     * atomic per region (64 regions share one at 16 384 regions); folded: supers of SHARES, one atomic per share (16 per word) */
+    args.super_shift = fold ? 3 : 5;
+    while ((((fold ? n_waves : n_rec) + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
     /* the regions fed by one filter wavefront: the records of one contiguous share of the corpus */
     args.group_regions = HSGPU_CONFIRM_SPLIT;
     args.stats = (unsigned long long *)s->stats.p;

@@ -1692,6 +1692,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
     __shared__ uint32_t s_share[2], s_fills[2][W]; /* (the ticket alternates between two words: written for round k + 1 while a slow wavefront may not have read round k's yet) */
     __shared__ unsigned long long s_bases[2][W];
+    __shared__ uint32_t s_sum[2], s_done[2]; /* the round's share: records so far, wavefronts done */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fold = args.fold != 0;
@@ -1730,33 +1731,27 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         rs.lits = __builtin_amdgcn_make_buffer_rsrc((void *)t.lits, 0, (int)0x7ffffff0, 0x00020000);
     }
 
-    /* Folded pipeline, wavefront 0 of the workgroup: where share p's records go -- the hypers (16 supers each) and supers in
-     * front of its first region, then the regions in front of it inside its own super: at most 16 + 15 + 63 relaxed loads,
-     * spinning only while a region in front is still being confirmed. The four regions' own places (the fills of the share's
-     * wavefronts are in LDS) go to LDS for the copy after the next barrier. */
+    /* Folded pipeline, wavefront 0 of the workgroup: where share p's records go -- the supers in front of its own (complete
+     * once their share count is full), then the shares in front of it inside its own super: at most 256 + 15 relaxed loads
+     * in two rounds, spinning only while a share in front is still being confirmed. The four regions' own places (the fills
+     * of the share's wavefronts are in LDS) go to LDS for the copy after the next barrier. */
     auto place_share = [&](uint32_t p, const uint32_t *fills, unsigned long long *bases) {
         const HsgpuScanArgs &args = cold_args(); /* (shadows the kernel's: see cold_args) */
-        const uint32_t ss = args.super_shift, cw0 = p * W, S = cw0 >> ss, H = S >> 4;
+        const uint32_t ss = args.super_shift, S = p >> ss;
         unsigned long long before = 0;
         uint32_t spins = 0;
         bool bad = false;
-        if (lane < 32) {
-            const bool hyper = lane < 16;
-            const uint32_t i = hyper ? lane : (H << 4) + (lane - 16);
-            if (hyper ? i < H : i < S) {
-                const unsigned long long *w = hyper ? &args.rec_super[HSGPU_SUPER_HYPER0 + i] : &args.rec_super[i];
-                const uint32_t full = hyper ? (16u << ss) : (1u << ss);
-                unsigned long long v;
-                for (;;) {
-                    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(v >> 40) == full || bad) break;
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > SPIN_LIMIT) bad = true;
-                }
-                before += v & ((1ull << 40) - 1);
+        for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SPIN_LIMIT) bad = true;
             }
+            before += v & ((1ull << 40) - 1);
         }
-        for (uint32_t i = (S << ss) + lane; i < cw0; i += 64) { /* the regions in front inside its own super */
+        for (uint32_t i = (S << ss) + lane; i < p; i += 64) { /* the shares in front inside its own super */
             uint32_t v;
             for (;;) {
                 v = __hip_atomic_load(&args.share_status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1773,7 +1768,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             if (any_bad) atomicAdd(&args.rec_super[256], 1ull);
             unsigned long long at = before;
             for (uint32_t w = 0; w < W; w++) bases[w] = at, at += fills[w];
-            if (cw0 + W == args.rec_regions) {
+            if (p + 1 == n_shares) {
                 /* the last share: the total is known. A region that ran out of space lost records; its fill counter kept
                  * counting, so the total is still exact: report it, but never a value <= cap (that would claim the output is
                  * complete). The same word says that some wavefront had to emit out of order: again, in dense mode. */
@@ -1802,8 +1797,10 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         /* the first share is the workgroup's own index: a ticket taken by every workgroup of the grid at the same moment is
          * 1 536 atomics on one address, one after the other. (Workgroups start in index order, so the holder of a lower
          * first share is running whenever a higher one is.) */
-        if (tid == 0)
+        if (tid == 0) {
             s_share[round] = first ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_sum[slot] = 0, s_done[slot] = 0; /* (this round's: last used two rounds ago) */
+        }
         __syncthreads(); /* (also: the gate is staged; the fills and bases of the rounds before are in LDS) */
         const uint32_t r = __builtin_amdgcn_readfirstlane(s_share[round]); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
         if (fold && placed_p != ~0u) { /* placed by wavefront 0 before the barrier: every wavefront copies its own region */
@@ -1891,14 +1888,19 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             /* (Relaxed device-scope atomics throughout: the words carry counts, nothing is read through them. With
              * release / acquire semantics every publish wrote the whole L2 back (buffer_wbl2) and every poll invalidated it
              * (buffer_inv): the stage took 0.55 ms instead of 0.16.) */
-            const uint32_t n_r = min(fill, 0x7fffffffu);
-            if (lane == 0) { /* publish: the sums of the region's super and hyper, then the region's own word */
-                const unsigned long long one = (1ull << 40) | n_r;
-                const uint32_t S = cw >> args.super_shift;
-                __hip_atomic_fetch_add(&args.rec_super[HSGPU_SUPER_HYPER0 + (S >> 4)], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(&args.rec_super[S], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&args.share_status[cw], 0x80000000u | n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t n_r = min(fill, 0x1fffffffu);
+            if (lane == 0) {
+                /* publish, once per SHARE: the wavefront that finishes its quarter last (a count in LDS tells it) adds the share's
+                 * records to the sum of the share's super and stores the share's own word. (Published per region, a super took 64
+                 * atomics in a burst, a hyper level above it 1 024: same-address atomics go one after the other, ~0.1 us each, and
+                 * the polls of that word queue up behind them -- the stage took 0.55 ms.) */
                 s_fills[slot][wave] = n_r;
+                __hip_atomic_fetch_add(&s_sum[slot], n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__hip_atomic_fetch_add(&s_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == W - 1) {
+                    const uint32_t tot = __hip_atomic_load(&s_sum[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&args.rec_super[r >> args.super_shift], (1ull << 40) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&args.share_status[r], 0x80000000u | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             /* DEFERRED by one share: the share confirmed in the iteration before is placed now, by wavefront 0 (its fills went
              * to LDS before this iteration's barrier), and copied by everybody after the next barrier */

@@ -16,8 +16,7 @@
 #define HSGPU_CONFIRM_SPLIT 4 /* confirm wavefronts per candidate region (tuning builds: 2) */
 #endif
 #define HSGPU_HINT_SHIFT 10 /* one block hint per KiB of corpus */
-#define HSGPU_SUPER_HYPER0 257 /* rec_super: [0, 256) supers, [256] flags, [257, 273) "hypers" = sums over 16 supers (folded pipeline) */
-#define HSGPU_SUPER_WORDS 273
+#define HSGPU_SUPER_WORDS 257 /* rec_super: [0, 256) supers, [256] flags */
 
 struct HsgpuScanArgs {
     const uint8_t *corpus;      /* all blocks, concatenated; 16-byte aligned */
@@ -52,11 +51,11 @@ struct HsgpuScanArgs {
     uint32_t super_shift;
     uint32_t group_regions;     /* consecutive regions that hold the records of one filter workgroup's corpus share */
     /* the folded pipeline (hwlm_confirm_kernel emits in order and places; no record_sort_kernel behind it): a word of
-     * rec_super then is {regions published << 40 | their records} over 2^super_shift consecutive regions; [256] = regions that
+     * rec_super then is {shares published << 40 | their records} over 2^super_shift consecutive SHARES; [256] = regions that
      * lost records + (regions emitted out of order) << 32 */
     uint32_t fold;
     uint32_t *ticket;           /* the next share to confirm (persistent confirm workgroups take shares in ticket order) */
-    uint32_t *share_status;     /* [rec_regions] {valid << 31 | records of the region}, written once its part is confirmed */
+    uint32_t *share_status;     /* [cand_waves] {valid << 31 | records of the share}, written once all its parts are confirmed */
     /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
      * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */
     uint32_t *ctl_other;
