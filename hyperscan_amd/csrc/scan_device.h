@@ -1692,7 +1692,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
     __shared__ uint32_t s_share[2], s_fills[2][W]; /* (the ticket alternates between two words: written for round k + 1 while a slow wavefront may not have read round k's yet) */
     __shared__ unsigned long long s_bases[2][W];
-    __shared__ uint32_t s_sum[2], s_done[2]; /* the round's share: records so far, wavefronts done */
+    __shared__ uint32_t s_sum[2], s_done[2], s_placer[2]; /* the round's share: records so far, wavefronts done; wavefronts past their quarter */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fold = args.fold != 0;
@@ -1741,6 +1741,23 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         unsigned long long before = 0;
         uint32_t spins = 0;
         bool bad = false;
+        /* first try: every word once, all loads in flight together (one round trip when everything in front has been published,
+         * which the deferral makes the rule) */
+        {
+            unsigned long long sv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                sv[k] = __hip_atomic_load(&args.rec_super[min(lane + 64u * k, 255u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t i0 = (S << ss) + lane;
+            const uint32_t st = __hip_atomic_load(&args.share_status[min(i0, n_shares - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = ss <= 6; /* (supers of more than 64 shares: only grids beyond 16 384 filter wavefronts) */
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (lane + 64u * k < S) ok = ok && (uint32_t)(sv[k] >> 40) == (1u << ss), before += sv[k] & ((1ull << 40) - 1);
+            if (i0 < p) ok = ok && (st >> 31), before += st & 0x7fffffffu;
+            if (__ballot(!ok)) before = 0, bad = false; /* somebody in front is still confirming: poll */
+            else goto placed;
+        }
         for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
             unsigned long long v;
             for (;;) {
@@ -1761,6 +1778,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             }
             before += v & 0x7fffffffu;
         }
+    placed:
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
         const bool any_bad = __ballot(bad) != 0;
@@ -1793,13 +1811,15 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     /* share confirmed in the iteration before (to be placed by wavefront 0 in this one), share placed in the iteration before
      * (its bases in s_bases[slot]: to be copied in this one); this wavefront's fills of the two */
     uint32_t conf_p = ~0u, conf_n = 0, placed_p = ~0u, placed_n = 0, slot = 0, round = 0;
-    for (bool first = true;; first = false, round ^= 1) {
-        /* the first share is the workgroup's own index: a ticket taken by every workgroup of the grid at the same moment is
-         * 1 536 atomics on one address, one after the other. (Workgroups start in index order, so the holder of a lower
-         * first share is running whenever a higher one is.) */
+    for (;; round ^= 1) {
+        /* Every share by ticket, the first one too. (Taking the workgroup's own index first saves the burst of 1 536 atomics on
+         * one word at the start, and deadlocks: a workgroup placing its second share waits for ALL lower shares, also the
+         * first shares of workgroups that have not been started yet -- beside another scan's filter kernel the grid is not
+         * resident as a whole -- while they wait for a slot that only an exit frees. With tickets a share has a holder only
+         * once that holder runs.) */
         if (tid == 0) {
-            s_share[round] = first ? blockIdx.x : gridDim.x + __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_sum[slot] = 0, s_done[slot] = 0; /* (this round's: last used two rounds ago) */
+            s_share[round] = __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_sum[slot] = 0, s_done[slot] = 0, s_placer[slot] = 0; /* (this round's: last used two rounds ago) */
         }
         __syncthreads(); /* (also: the gate is staged; the fills and bases of the rounds before are in LDS) */
         const uint32_t r = __builtin_amdgcn_readfirstlane(s_share[round]); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
@@ -1902,9 +1922,12 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     __hip_atomic_store(&args.share_status[r], 0x80000000u | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            /* DEFERRED by one share: the share confirmed in the iteration before is placed now, by wavefront 0 (its fills went
-             * to LDS before this iteration's barrier), and copied by everybody after the next barrier */
-            if (conf_p != ~0u && wave == 0) place_share(conf_p, s_fills[slot ^ 1], s_bases[slot]);
+            /* DEFERRED by one share: the share confirmed in the iteration before is placed now (its fills went to LDS before
+             * this iteration's barrier) -- by the wavefront that finishes its quarter FIRST, which would otherwise only wait at
+             * the barrier -- and copied by everybody after the next barrier */
+            uint32_t placer = 0;
+            if (lane == 0) placer = __hip_atomic_fetch_add(&s_placer[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (conf_p != ~0u && __builtin_amdgcn_readfirstlane(placer) == 0) place_share(conf_p, s_fills[slot ^ 1], s_bases[slot]);
             placed_p = conf_p, placed_n = conf_n;
             conf_p = r, conf_n = n_r;
             slot ^= 1;

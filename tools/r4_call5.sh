@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4f; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4g; mkdir -p $O; cd $R
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -4 $O/pytest.log
 timeout 300 python tools/ab_tail.py fdr10k --modes folded,unfolded,folded,unfolded 2>&1 | grep -v "^\[\|amdgpu.ids" | tee -a $O/ab.log
 timeout 300 python tools/ab_tail.py teddy64 --modes folded,unfolded 2>&1 | grep -v "^\[\|amdgpu.ids" | tee -a $O/ab.log
