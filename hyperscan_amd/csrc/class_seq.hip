@@ -33,6 +33,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "internal.h"
@@ -297,6 +299,233 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_shared_kernel(SeqArgs a
     if (active && n_match) atomicAdd(&args.counts[p], n_match);
 }
 
+
+/* ---- round 4: one lane per 64-byte WORD, the patterns looped in scalar registers ------------------------------------
+ * The kernels above give a lane a pattern: every shift amount, class pointer and repeat count is a per-lane value, the
+ * 64-bit shifts and the add are emulated per lane, ~130 vector instructions per word and pattern. Here a wavefront takes
+ * a TILE of 63 consecutive words (lane 0 repeats the word before the tile: its upper bits feed lane 1's shifts, nothing
+ * of it is reported) and walks a little program that the host sorted by (A, m, B, n):
+ *   class A   the run masks of qa = A & ~start by doubling (t1, t2, t4, t8) and each one's copy from the lane below
+ *             (ds_bpermute), once per distinct class
+ *   pair      R_m and G for one (A, m): the shift amounts are wave-uniform, a 64-bit funnel shift across two words is two
+ *             v_alignbit on 32-bit halves; once per distinct pair (72 of the bench's 256 patterns)
+ *   pattern   x = G & qb(B) (qb of every class sits in LDS), s = qb + x with the carry BETWEEN the words of the tile by
+ *             carry-lookahead on the wavefront: the add's carry-out mask (generate) and "s is all ones" (propagate) are
+ *             64-bit lane masks in scalar registers, one scalar add gives every lane its carry-in ((P|G) + G ^ P), one
+ *             v_addc applies it; Y = bfi(s, x, qb); the carry out of the tile's last word waits in a lane of a register
+ *             for the pattern's next tile. Two patterns' counts are packed into one DPP reduction.
+ * ~18 vector instructions per word and pattern + ~10 for the shared side, all shift amounts scalar. (profiles/r04_class_seq*.txt) */
+constexpr uint32_t TILE_WORDS = 63;
+constexpr uint32_t TILE_MAX_CLASSES = 32;
+
+enum : uint8_t { OP_CLASS = 0, OP_PAIR = 1, OP_PAT = 2 };
+struct TileOp {
+    uint8_t kind, cls, k, pad; /* OP_CLASS: cls = A | OP_PAIR: k = m - 1 | OP_PAT: cls = B, k = n - 1 */
+    uint32_t index;            /* OP_PAT: the pattern's index in the caller's list */
+};
+
+struct TileArgs {
+    const TileOp *ops;
+    uint32_t n_ops, n_pats, n_classes, n_shares;
+    const hsgpu_class_seq_t *seqs;
+    const uint64_t *const *bitmaps; /* 8-byte aligned */
+    const uint64_t *starts;
+    const uint64_t *off;
+    uint64_t nblocks, total, share_bytes, emit_lo, emit_hi, cap;
+    unsigned long long *counts, *count;
+    hsgpu_match_t *out;
+};
+
+struct W2 {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ W2 w2(uint64_t v) { return {(uint32_t)v, (uint32_t)(v >> 32)}; }
+__device__ __forceinline__ W2 operator&(W2 a, W2 b) { return {a.lo & b.lo, a.hi & b.hi}; }
+/* the value the lane below holds (lane 0: whatever; it is the halo) */
+__device__ __forceinline__ W2 from_below(W2 v, uint32_t addr_below) {
+    return {(uint32_t)__builtin_amdgcn_ds_bpermute((int)addr_below, (int)v.lo), (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr_below, (int)v.hi)};
+}
+/* (cur : prev) << k, the part that lands in cur; k wave-uniform, 0 .. 31 */
+__device__ __forceinline__ W2 shl2u(W2 cur, W2 prev, uint32_t k) {
+    if (k == 0) return cur;
+    return {__builtin_amdgcn_alignbit(cur.lo, prev.hi, 32u - k), __builtin_amdgcn_alignbit(cur.hi, cur.lo, 32u - k)};
+}
+struct Runs { /* run masks of length 1, 2, 4, 8 of this lane's word and of the lane below */
+    W2 t1, t2, t4, t8, p1, p2, p4, p8;
+};
+__device__ __forceinline__ void make_runs(Runs &r, W2 q, uint32_t below) {
+    r.t1 = q, r.p1 = from_below(r.t1, below);
+    r.t2 = r.t1 & shl2u(r.t1, r.p1, 1), r.p2 = from_below(r.t2, below);
+    r.t4 = r.t2 & shl2u(r.t2, r.p2, 2), r.p4 = from_below(r.t4, below);
+    r.t8 = r.t4 & shl2u(r.t4, r.p4, 4), r.p8 = from_below(r.t8, below);
+}
+/* q(i - k + 1 .. i) all set, k wave-uniform in 0 .. 15 */
+__device__ __forceinline__ W2 run_of_u(const Runs &r, uint32_t k) {
+    W2 acc = {~0u, ~0u};
+    uint32_t ofs = 0;
+    if (k & 1) acc = acc & r.t1, ofs = 1;
+    if (k & 2) acc = acc & shl2u(r.t2, r.p2, ofs), ofs += 2;
+    if (k & 4) acc = acc & shl2u(r.t4, r.p4, ofs), ofs += 4;
+    if (k & 8) acc = acc & shl2u(r.t8, r.p8, ofs);
+    return acc;
+}
+/* wave64 sum, the total in lane 63 (row_shr 1 2 4 8 inside the rows of 16, then row_bcast 15 and 31 across them) */
+__device__ __forceinline__ uint32_t wave_sum_to_63(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+__global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs args) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile_lds[];
+    const uint32_t lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
+    const uint32_t share = blockIdx.x * (SEQ_THREADS / 64) + wave_in_wg;
+    /* per wavefront: qb of every class for the tile's words [n_classes][64], the patterns' counts [n_pats] */
+    const size_t per_wave = (size_t)args.n_classes * 512 + (((size_t)args.n_pats * 4 + 15) & ~(size_t)15);
+    uint64_t *qb_lds = (uint64_t *)(tile_lds + wave_in_wg * per_wave);
+    uint32_t *cnt = (uint32_t *)((uint8_t *)qb_lds + (size_t)args.n_classes * 512);
+    for (uint32_t j = lane; j < args.n_pats; j += 64) cnt[j] = 0;
+    if (share >= args.n_shares) return;
+
+    /* the share: the blocks that START inside [lo_b, hi_b) (no state enters a share) */
+    const uint64_t lo_b = (uint64_t)share * args.share_bytes, hi_b = min(args.total, lo_b + args.share_bytes);
+    const uint64_t b_lo = lower_bound_off(args.off, args.nblocks, lo_b), b_hi = lower_bound_off(args.off, args.nblocks, hi_b);
+    if (b_lo >= b_hi || b_lo >= args.nblocks) return;
+    const uint64_t s0 = args.off[b_lo], s1 = args.off[min(b_hi, args.nblocks)];
+    if (s0 >= s1) return;
+    const uint64_t w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
+    const uint64_t n_words_total = (args.total + 63) >> 6;
+    const uint32_t below = ((lane + 63u) & 63u) << 2; /* ds_bpermute address of the lane below */
+
+    uint32_t cvec = 0; /* carries between tiles: pattern j's in bit j >> 6 of lane j & 63 */
+    for (uint64_t wb = w0; wb <= w1; wb += TILE_WORDS) {
+        /* this lane's word: wb + lane - 1 (lane 0 = the word before the tile) */
+        const uint64_t w = wb + lane - 1;
+        const bool have = (lane || wb > 0) && w <= w1 && w < n_words_total; /* words past the share read as zero: no runs, no carries */
+        const bool full = have && (w + 1) * 64 <= args.total;          /* the corpus' last word may be short of 8 bytes of bitmap */
+        auto load = [&](uint32_t c) -> uint64_t {
+            if (full) return args.bitmaps[c][w];
+            if (!have) return 0;
+            const uint16_t *bm = (const uint16_t *)args.bitmaps[c];
+            const uint64_t n16 = (args.total + 15) / 16;
+            uint64_t v = 0;
+            for (uint32_t k = 0; k < 4; k++)
+                if (w * 4 + k < n16) v |= (uint64_t)bm[w * 4 + k] << (16 * k);
+            return v & (~0ull >> (64 - (args.total - w * 64)));
+        };
+        const uint64_t st64 = have ? args.starts[w] : 0;
+        const W2 nst = w2(~st64);
+        /* which of this word's match ends are this share's to report */
+        uint64_t vm = 0;
+        if (lane && have && w >= w0) {
+            vm = ~0ull;
+            if (w == w0) vm &= ~0ull << (s0 & 63);
+            if (w == w1) vm &= ~0ull >> (63 - ((s1 - 1) & 63));
+        }
+        const W2 vmask = w2(vm);
+        for (uint32_t c = 0; c < args.n_classes; c++) qb_lds[c * 64 + lane] = load(c) & ~st64;
+        const uint64_t base = w * 64;
+        const bool emit_tile = wb * 64 < args.emit_hi && (wb + TILE_WORDS) * 64 > args.emit_lo; /* (uniform) */
+
+        Runs ra;
+        W2 a = {0, 0}, pa = {0, 0}, g = {0, 0}, pg = {0, 0};
+        uint32_t pj = 0;          /* patterns done in this tile (their order in the program) */
+        uint32_t packed = 0;      /* the count of an even pattern, waiting for the odd one to share a reduction */
+        for (uint32_t o = 0; o < args.n_ops; o++) {
+            const TileOp op = args.ops[o]; /* (uniform: scalar loads) */
+            if (op.kind == OP_CLASS) {
+                a = w2(load(op.cls));
+                pa = from_below(a, below);
+                make_runs(ra, a & nst, below);
+            } else if (op.kind == OP_PAIR) {
+                const W2 r = shl2u(a, pa, op.k) & run_of_u(ra, op.k); /* R_m: m members of A end here, inside one block */
+                g = shl2u(r, from_below(r, below), 1) & nst;          /* G: a match of A{m,} may end right before this byte */
+                pg = from_below(g, below);
+            } else {
+                const W2 qb = w2(qb_lds[op.cls * 64 + lane]);
+                W2 x;
+                if (op.k == 0) {
+                    x = g & qb; /* (g has no block starts: g & b = g & qb) */
+                } else { /* the mandatory B{n}: n members of B end here, the first of them anywhere in the block */
+                    Runs rb;
+                    make_runs(rb, qb, below);
+                    const W2 b = w2(load(op.cls));
+                    x = shl2u(g, pg, op.k) & shl2u(b, from_below(b, below), op.k) & run_of_u(rb, op.k);
+                }
+                /* s = qb + x, every word for itself: the carry-out mask is "generate", s == all ones is "propagate" */
+                uint32_t s_lo, s_hi, and_s;
+                unsigned long long c_lo, gmask, pmask;
+                asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s_lo), "=s"(c_lo) : "v"(qb.lo), "v"(x.lo));
+                asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s_hi), "=s"(gmask) : "v"(qb.hi), "v"(x.hi), "s"(c_lo));
+                and_s = s_lo & s_hi;
+                asm("v_cmp_eq_u32_e64 %0, -1, %1" : "=s"(pmask) : "v"(and_s));
+                /* lane 0 stands for everything below the tile: it generates exactly the carry the pattern brought along */
+                const uint32_t cword = (uint32_t)__builtin_amdgcn_readlane((int)cvec, (int)(pj & 63));
+                const unsigned long long c0 = (cword >> (pj >> 6)) & 1u;
+                gmask = (gmask & ~1ull) | c0;
+                pmask &= ~1ull;
+                const unsigned long long A = pmask | gmask, S = A + gmask, cin = S ^ pmask; /* ((P|G) + G) ^ (P|G) ^ G: the carry INTO every lane */
+                const uint32_t cout = (uint32_t)(((A & gmask) | ((A | gmask) & ~S)) >> 63); /* ... and out of lane 63 (majority: scalar) */
+                {
+                    const uint32_t nw_ = (cword & ~(1u << (pj >> 6))) | (cout << (pj >> 6)), at_ = pj & 63;
+                    cvec = lane == at_ ? nw_ : cvec; /* (v_writelane takes one scalar operand besides m0: a compare and a select instead) */
+                }
+                uint32_t t_lo, t_hi;
+                unsigned long long c2, c3;
+                asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_lo), "=s"(c2) : "v"(s_lo), "s"(cin));
+                asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_hi), "=s"(c3) : "v"(s_hi), "s"(c2));
+                /* Y = x | (qb & ~t): the run of B above x up to where the add's carry died */
+                const uint32_t y_lo = ((t_lo & x.lo) | (~t_lo & qb.lo)) & vmask.lo, y_hi = ((t_hi & x.hi) | (~t_hi & qb.hi)) & vmask.hi;
+                const uint32_t pc = __builtin_popcount(y_lo) + __builtin_popcount(y_hi);
+                if (pj & 1) { /* two patterns per reduction: no field can overflow (63 words x 64 bits) */
+                    const uint32_t tot = wave_sum_to_63(packed | pc << 16);
+                    if (lane == 63) {
+                        cnt[pj - 1] += tot & 0xffffu;
+                        cnt[pj] += tot >> 16;
+                    }
+                } else {
+                    packed = pc;
+                }
+                if (emit_tile && (y_lo | y_hi)) {
+                    uint64_t y = (uint64_t)y_hi << 32 | y_lo;
+                    while (y) {
+                        const uint32_t j = __builtin_ctzll(y);
+                        y &= y - 1;
+                        const uint64_t pos = base + j;
+                        if (pos < args.emit_lo || pos >= args.emit_hi) continue;
+                        const unsigned long long at = atomicAdd(args.count, 1ull);
+                        if (at >= args.cap) continue;
+                        const uint64_t blk = lower_bound_off(args.off, args.nblocks, pos + 1) - 1;
+                        hsgpu_match_t rec;
+                        rec.block = (uint32_t)blk;
+                        rec.end = (uint32_t)(pos - args.off[blk]);
+                        rec.id = args.seqs[op.index].id;
+                        rec.lit = op.index;
+                        args.out[at] = rec;
+                    }
+                }
+                pj++;
+            }
+        }
+        if (pj & 1) { /* an odd number of patterns: the last one reduces alone */
+            const uint32_t tot = wave_sum_to_63(packed);
+            if (lane == 63) cnt[pj - 1] += tot;
+        }
+    }
+    /* the share's counts: the program's pattern order back to the caller's */
+    uint32_t pj = 0;
+    for (uint32_t o = 0; o < args.n_ops; o++) {
+        const TileOp op = args.ops[o];
+        if (op.kind != OP_PAT) continue;
+        if (lane == 63 && cnt[pj]) atomicAdd(&args.counts[op.index], (unsigned long long)cnt[pj]);
+        pj++;
+    }
+}
+
 } // namespace
 
 extern "C" size_t hsgpu_class_seq_work_bytes(uint64_t total_bytes) { return SEQ_HEADER + ((total_bytes + 63) / 64) * 8 + 8; }
@@ -329,35 +558,115 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)n_seqs * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
     if (!total_bytes || !nblocks) return HSGPU_SUCCESS;
-    /* work area: patterns | bitmap pointers | (class, repeat) pairs per group of 256 patterns | block-start bitmap */
     uint8_t *w = (uint8_t *)d_work;
     const size_t seq_bytes = (size_t)n_seqs * sizeof(hsgpu_class_seq_t), ptr_ofs = (seq_bytes + 15) & ~(size_t)15;
+    const size_t tab_ofs = (ptr_ofs + (size_t)n_classes * sizeof(void *) + 15) & ~(size_t)15;
+    bool aligned = true;
+    for (unsigned c = 0; c < n_classes; c++) aligned = aligned && (((uintptr_t)d_bitmaps[c]) & 7) == 0;
+    const bool tiled = aligned && n_classes <= TILE_MAX_CLASSES;
+    /* the header of the work area: patterns | bitmap pointers | the kernel's tables. Built on the host, uploaded only when
+     * it differs from what this work area was given last time (the copy kept here is also what the asynchronous upload
+     * reads from: nothing on the stack goes out of scope under a DMA, and a caller that repeats a scan -- every step of a
+     * pipeline does -- neither uploads nor waits) */
+    std::vector<uint8_t> hdr(tab_ofs, 0);
+    memcpy(hdr.data(), seqs, seq_bytes);
+    memcpy(hdr.data() + ptr_ofs, d_bitmaps, (size_t)n_classes * sizeof(void *));
+    uint32_t n_ops = 0;
     const uint32_t n_wgroups = (n_seqs + 255) / 256;
-    const size_t pairof_ofs = (ptr_ofs + (size_t)n_classes * sizeof(void *) + 15) & ~(size_t)15;
-    const size_t pairs_ofs = pairof_ofs + (((size_t)n_seqs * 2 + 15) & ~(size_t)15);
-    const size_t npairs_ofs = pairs_ofs + (size_t)n_wgroups * 256 * 2;
-    if (npairs_ofs + (size_t)n_wgroups * 2 > SEQ_HEADER) return HSGPU_INVALID;
-    std::vector<uint16_t> pair_of(n_seqs), pairs((size_t)n_wgroups * 256, 0), n_pairs(n_wgroups, 0);
-    for (unsigned i = 0; i < n_seqs; i++) {
-        const unsigned g = i / 256;
-        const uint16_t key = (uint16_t)(seqs[i].a | (unsigned)(seqs[i].m - 1) << 8);
-        unsigned k = 0;
-        while (k < n_pairs[g] && pairs[(size_t)g * 256 + k] != key) k++;
-        if (k == n_pairs[g]) pairs[(size_t)g * 256 + n_pairs[g]++] = key;
-        pair_of[i] = (uint16_t)k;
+    size_t pairof_ofs = 0, pairs_ofs = 0, npairs_ofs = 0;
+    if (tiled) { /* the program of class_seq_tile_kernel: patterns sorted by (A, m, n, B) */
+        std::vector<uint32_t> order(n_seqs);
+        for (unsigned i = 0; i < n_seqs; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const hsgpu_class_seq_t &p = seqs[x], &q = seqs[y];
+            if (p.a != q.a) return p.a < q.a;
+            if (p.m != q.m) return p.m < q.m;
+            if (p.n != q.n) return p.n < q.n;
+            if (p.b != q.b) return p.b < q.b;
+            return x < y;
+        });
+        std::vector<TileOp> ops;
+        for (unsigned k = 0; k < n_seqs; k++) {
+            const hsgpu_class_seq_t &p = seqs[order[k]];
+            const bool new_a = k == 0 || seqs[order[k - 1]].a != p.a;
+            if (new_a) ops.push_back(TileOp{OP_CLASS, p.a, 0, 0, 0});
+            if (new_a || seqs[order[k - 1]].m != p.m) ops.push_back(TileOp{OP_PAIR, p.a, (uint8_t)(p.m - 1), 0, 0});
+            ops.push_back(TileOp{OP_PAT, p.b, (uint8_t)(p.n - 1), 0, order[k]});
+        }
+        n_ops = (uint32_t)ops.size();
+        hdr.resize(tab_ofs + ops.size() * sizeof(TileOp));
+        memcpy(hdr.data() + tab_ofs, ops.data(), ops.size() * sizeof(TileOp));
+    } else { /* (class, repeat) pairs per group of 256 patterns for class_seq_shared_kernel */
+        pairof_ofs = tab_ofs;
+        pairs_ofs = pairof_ofs + (((size_t)n_seqs * 2 + 15) & ~(size_t)15);
+        npairs_ofs = pairs_ofs + (size_t)n_wgroups * 256 * 2;
+        hdr.resize(npairs_ofs + (size_t)n_wgroups * 2, 0);
+        uint16_t *pair_of = (uint16_t *)(hdr.data() + pairof_ofs), *pairs = (uint16_t *)(hdr.data() + pairs_ofs),
+                 *n_pairs = (uint16_t *)(hdr.data() + npairs_ofs);
+        for (unsigned i = 0; i < n_seqs; i++) {
+            const unsigned g = i / 256;
+            const uint16_t key = (uint16_t)(seqs[i].a | (unsigned)(seqs[i].m - 1) << 8);
+            unsigned k = 0;
+            while (k < n_pairs[g] && pairs[(size_t)g * 256 + k] != key) k++;
+            if (k == n_pairs[g]) pairs[(size_t)g * 256 + n_pairs[g]++] = key;
+            pair_of[i] = (uint16_t)k;
+        }
     }
-    /* (pageable sources: the runtime stages them before the call returns) */
-    HIP_TRY(hipMemcpyAsync(w, seqs, seq_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w + ptr_ofs, d_bitmaps, (size_t)n_classes * sizeof(void *), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w + pairof_ofs, pair_of.data(), pair_of.size() * 2, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w + pairs_ofs, pairs.data(), pairs.size() * 2, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w + npairs_ofs, n_pairs.data(), n_pairs.size() * 2, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st)); /* the staging vectors go out of scope */
+    if (hdr.size() > SEQ_HEADER) return HSGPU_INVALID;
+    {
+        static std::mutex mu;
+        static std::map<void *, std::vector<uint8_t>> uploaded; /* by work area: the header it holds */
+        std::lock_guard<std::mutex> lock(mu);
+        std::vector<uint8_t> &have = uploaded[d_work];
+        if (have != hdr) {
+            if (!have.empty()) HIP_TRY(hipStreamSynchronize(st)); /* an upload from the old copy may still be on its way */
+            have = hdr;
+            HIP_TRY(hipMemcpyAsync(w, have.data(), have.size(), hipMemcpyHostToDevice, st));
+        }
+    }
     const uint64_t n_words = (total_bytes + 63) / 64;
     uint64_t *starts = (uint64_t *)(w + SEQ_HEADER);
     HIP_TRY(hipMemsetAsync(starts, 0, n_words * 8 + 8, st));
     hipLaunchKernelGGL(seq_starts_kernel, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_off,
                        nblocks, total_bytes, (uint32_t *)starts);
+    if (tiled) {
+        TileArgs t;
+        t.ops = (const TileOp *)(w + tab_ofs);
+        t.n_ops = n_ops;
+        t.n_pats = n_seqs;
+        t.n_classes = n_classes;
+        t.seqs = (const hsgpu_class_seq_t *)w;
+        t.bitmaps = (const uint64_t *const *)(w + ptr_ofs);
+        t.starts = starts;
+        t.off = (const uint64_t *)d_off;
+        t.nblocks = nblocks;
+        t.total = total_bytes;
+        /* a wavefront per share of whole blocks, every pattern: ~8 K shares, at least 16 KiB (four tiles) each */
+        uint64_t share = std::max<uint64_t>(16384, (total_bytes + 8191) / 8192);
+        share = (share + 63) & ~63ull;
+        t.share_bytes = share;
+        t.n_shares = (uint32_t)((total_bytes + share - 1) / share);
+        t.emit_lo = emit_lo;
+        t.emit_hi = std::min(emit_hi, total_bytes);
+        t.cap = cap;
+        t.counts = (unsigned long long *)d_counts;
+        t.count = (unsigned long long *)d_count;
+        t.out = (hsgpu_match_t *)d_out;
+        const size_t per_wave = (size_t)n_classes * 512 + (((size_t)n_seqs * 4 + 15) & ~(size_t)15);
+        const size_t lds = per_wave * (SEQ_THREADS / 64);
+        static std::mutex mu2;
+        static size_t lds_set = 0;
+        {
+            std::lock_guard<std::mutex> lock(mu2);
+            if (lds > lds_set) {
+                HIP_TRY(hipFuncSetAttribute((const void *)class_seq_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_set = lds;
+            }
+        }
+        hipLaunchKernelGGL(class_seq_tile_kernel, dim3((t.n_shares + SEQ_THREADS / 64 - 1) / (SEQ_THREADS / 64)), dim3(SEQ_THREADS), lds, st, t);
+        HIP_TRY(hipGetLastError());
+        return HSGPU_SUCCESS;
+    }
     SeqArgs a;
     a.seqs = (const hsgpu_class_seq_t *)w;
     a.bitmaps = (const uint16_t *const *)(w + ptr_ofs);

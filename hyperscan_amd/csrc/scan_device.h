@@ -236,7 +236,7 @@ constexpr uint32_t MQ_CAP = QCAP;
 __device__ __forceinline__ void push_match(const Tables &t, uint64_t ge, uint32_t li) {
     const uint32_t s = __hip_atomic_fetch_add(&t.wl->nmq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (s < MQ_CAP) {
-        t.wl->cand[s] = make_uint2((uint32_t)ge, li | (uint32_t)(ge >> 32) << 24);
+        t.wl->cand[s] = make_uint2(li | (uint32_t)ge << 24, (uint32_t)(ge >> 8)); /* = the 64-bit sort key {position, literal}: mq_key */
     } else { /* (the folded pipeline emits in order: a queue that overflowed between two of its sync points did not) */
         t.wl->pad[0] = 1u;
         resolve_match(t, ge, li);
@@ -689,6 +689,24 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
     }
 }
 
+/* Convergent: one queued match per lane (`valid`) resolved -- id / size, block through the hints, bounds -- and the records
+ * appended to the front of the wavefront's region in lane order. A queue entry is the 64-bit key {position << 24 | literal}. */
+__device__ __forceinline__ void resolve_queued(const Tables &t, uint32_t lane, bool valid, uint2 it) {
+    const uint32_t li = it.x & HSGPU_LIST_LIT_MASK;
+    const uint64_t ge = (uint64_t)it.y << 8 | it.x >> 24;
+    const uint4 l1 = ((const uint4 *)(t.lits + li))[1];
+    uint64_t bstart;
+    const uint64_t b = block_of(t, ge, bstart);
+    const uint32_t id = l1.z, size = l1.w & 0xff;
+    const uint64_t end = ge - bstart;
+    const bool ok = valid && !(end + 1 < size || end + 1 - size < t.start);
+    const uint64_t mask = __ballot(ok);
+    const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
+    const uint32_t at = f + lane_rank(mask);
+    if (ok && at < t.rec_cap) t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
+    if (lane == 0) t.wl->nfront = f + (uint32_t)__popcll(mask); /* keeps counting past the capacity: the total stays exact */
+}
+
 /* Convergent: resolve queued matches, 64 at a time with full lanes, while more than
  * `keep` are queued; records go straight to the front of the wavefront's region. */
 __device__ __forceinline__ void drain_matches(const Tables &t, uint32_t lane, uint32_t keep) {
@@ -703,19 +721,7 @@ __device__ __forceinline__ void drain_matches(const Tables &t, uint32_t lane, ui
         n -= k;
         const bool valid = lane < k;
         const uint2 it = t.wl->cand[valid ? n + lane : 0];
-        const uint32_t li = it.y & HSGPU_LIST_LIT_MASK;
-        const uint64_t ge = (uint64_t)(it.y >> 24) << 32 | it.x;
-        const uint4 l1 = ((const uint4 *)(t.lits + li))[1];
-        uint64_t bstart;
-        const uint64_t b = block_of(t, ge, bstart);
-        const uint32_t id = l1.z, size = l1.w & 0xff;
-        const uint64_t end = ge - bstart;
-        const bool ok = valid && !(end + 1 < size || end + 1 - size < t.start);
-        const uint64_t mask = __ballot(ok);
-        const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
-        const uint32_t at = f + lane_rank(mask);
-        if (ok && at < t.rec_cap) t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
-        if (lane == 0) t.wl->nfront = f + (uint32_t)__popcll(mask);
+        resolve_queued(t, lane, valid, it);
     }
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -1611,56 +1617,60 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
 constexpr uint32_t SPIN_LIMIT = 1u << 22; /* placement: a region in front that never publishes (cannot happen) ends the wait */
 constexpr uint32_t SYNC_AT = 48;          /* folded: queued matches that end a group of batches (the queue holds MQ_CAP = 128) */
 static_assert(CONFIRM_THREADS / 64 == HSGPU_CONFIRM_SPLIT, "one wavefront per part of a share");
-static_assert(RQ_CAP * sizeof(uint2) >= MQ_CAP * sizeof(uint2), "the empty rest queue doubles as the sorted-key buffer");
 
-/* the 64-bit sort key of a queued match {position (< 2^36), literal index (< 2^24)}: delivery order is (block, end, literal),
- * and (block, end) grows with the position */
-__device__ __forceinline__ uint64_t match_key(const uint2 it) {
-    return (uint64_t)(it.y >> 24) << 56 | (uint64_t)it.x << 24 | (it.y & HSGPU_LIST_LIT_MASK);
+/* A queued match IS its sort key: {position (< 2^36) << 24 | literal index (< 2^24)} -- delivery order is (block, end,
+ * literal), and (block, end) grows with the position. */
+__device__ __forceinline__ uint64_t mq_key(const uint2 it) { return (uint64_t)it.y << 32 | it.x; }
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, uint32_t addr) { /* the value of lane (lane ^ j): addr = (lane ^ j) * 4 */
+    return (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)(uint32_t)(v >> 32)) << 32 |
+           (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)(uint32_t)v);
 }
 
-/* Convergent, folded pipeline: the queued matches (wl->cand[0 .. nmq), nothing pending in the rest queue `sorted`, which
- * serves as the buffer) sorted by counting ranks, resolved in order, appended to the front of the region. */
-__device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint2 *sorted, uint32_t lane) {
+/* Convergent, folded pipeline: the queued matches (wl->cand[0 .. nmq)) sorted, resolved in order, appended to the front of the
+ * region. The sort is a bitonic network ACROSS THE LANES on the 64-bit keys (one key per lane, two above 64 queued; keys that
+ * are not there are all ones and sort to the end): 21 compare-exchange stages of two ds_bpermute, one compare and two
+ * selects -- ~130 vector instructions. (Ranking by counting, every lane walking the queue, was ~20 instructions per queued
+ * match and lane: 1 000 for the usual 50 matches, as much again as the confirm steps that found them; the stage took
+ * 0.19 ms instead of 0.15: profiles/r04_tail_ab.txt.) */
+__device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t lane) {
     uint32_t n = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     n = min(__builtin_amdgcn_readfirstlane(n), MQ_CAP);
     if (n == 0) return;
-    const bool own0 = lane < n, own1 = lane + 64 < n;
-    const uint2 it0 = t.wl->cand[own0 ? lane : 0], it1 = t.wl->cand[own1 ? lane + 64 : 0];
-#ifdef HSGPU_FOLD_NORANK /* timing experiment only: the queue resolved in arrival order */
-    if (false) {
-#else
-    if (n > 1) {
-#endif
-        const uint64_t k0 = match_key(it0), k1 = match_key(it1);
-        uint32_t r0 = 0, r1 = 0;
-        for (uint32_t q = 0; q < n; q++) { /* (one LDS address for the whole wavefront: a broadcast) */
-            const uint64_t kq = match_key(t.wl->cand[q]);
-            r0 += (kq < k0 || (kq == k0 && q < lane)) ? 1u : 0u;
-            r1 += (kq < k1 || (kq == k1 && q < lane + 64)) ? 1u : 0u;
+    uint64_t k0 = lane < n ? mq_key(t.wl->cand[lane]) : ~0ull;
+    if (n <= 64) {
+        if (n > 1) {
+#pragma unroll
+            for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    const uint64_t o = lane_xor64(k0, (lane ^ j) << 2);
+                    const bool up = (lane & k) == 0, low = (lane & j) == 0; /* ascending block; this lane keeps the smaller one */
+                    const bool take = (o < k0) == (up == low);
+                    k0 = take ? o : k0;
+                }
+            }
         }
-        if (own0) sorted[r0] = it0;
-        if (own1) sorted[r1] = it1;
-    } else {
-        if (own0) sorted[lane] = it0;
-        if (own1) sorted[lane + 64] = it1;
-    }
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const bool valid = i0 + lane < n;
-        const uint2 it = sorted[valid ? i0 + lane : 0];
-        const uint32_t li = it.y & HSGPU_LIST_LIT_MASK;
-        const uint64_t ge = (uint64_t)(it.y >> 24) << 32 | it.x;
-        const uint4 l1 = ((const uint4 *)(t.lits + li))[1];
-        uint64_t bstart;
-        const uint64_t b = block_of(t, ge, bstart);
-        const uint32_t id = l1.z, size = l1.w & 0xff;
-        const uint64_t end = ge - bstart;
-        const bool ok = valid && !(end + 1 < size || end + 1 - size < t.start);
-        const uint64_t mask = __ballot(ok);
-        const uint32_t f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
-        const uint32_t at = f + lane_rank(mask);
-        if (ok && at < t.rec_cap) t.rec_region[at] = make_uint4((uint32_t)b, (uint32_t)end, id, li);
-        if (lane == 0) t.wl->nfront = f + (uint32_t)__popcll(mask); /* keeps counting past the capacity: the total stays exact */
+        resolve_queued(t, lane, lane < n, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
+    } else { /* 65 .. 128 queued: two keys per lane, element i = lane + 64 r */
+        uint64_t k1 = lane + 64 < n ? mq_key(t.wl->cand[lane + 64]) : ~0ull;
+#pragma unroll
+        for (uint32_t k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                if (j == 64) { /* the partner is the lane's own other key; k = 128: ascending */
+                    const uint64_t lo = min(k0, k1), hi = max(k0, k1);
+                    k0 = lo, k1 = hi;
+                } else {
+                    const uint64_t o0 = lane_xor64(k0, (lane ^ j) << 2), o1 = lane_xor64(k1, (lane ^ j) << 2);
+                    const bool low = (lane & j) == 0;
+                    const bool up0 = (lane & k) == 0, up1 = ((lane + 64) & k) == 0;
+                    k0 = ((o0 < k0) == (up0 == low)) ? o0 : k0;
+                    k1 = ((o1 < k1) == (up1 == low)) ? o1 : k1;
+                }
+            }
+        }
+        resolve_queued(t, lane, true, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
+        resolve_queued(t, lane, lane + 64 < n, make_uint2((uint32_t)k1, (uint32_t)(k1 >> 32)));
     }
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -1884,7 +1894,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                         confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, false);
                     }
                 } else if (fold) { /* a sync point with nothing pending: everything queued is final; in order into the region */
-                    drain_matches_sorted(t, rq, lane);
+                    drain_matches_sorted(t, lane);
                     syncing = false;
                     if (base >= end) break;
                     continue;
