@@ -27,8 +27,9 @@ import numpy as np
 from . import _native
 from .hwlm import HsgpuError
 
-CLASS_MAX = 8
-WORK_BYTES = 4160
+CLASS_MAX = 8           # classes per call with first / last
+CLASS_MAX_BITMAPS = 16  # ... for the bitmaps alone: one read of the corpus
+WORK_BYTES = 8192
 PAIR_MAX = 8
 PAIR_WORK_BYTES = 8256
 
@@ -152,13 +153,14 @@ class CharClass:
 
 def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True, want_last=False, stream=None,
                buffers=None):
-    """Evaluate <= 8 classes over a device-resident block batch (torch tensors).
+    """Evaluate <= 8 classes (<= 16 when neither first nor last is asked for: one read of the corpus) over a
+    device-resident block batch (torch tensors).
     -> (bitmaps uint8 [n][ceil(total/16)*2], first int64-view uint32 [n][nblocks] | None, last | None)"""
     import torch
 
     lib = _lib()
     n = len(classes)
-    assert 1 <= n <= CLASS_MAX
+    assert 1 <= n <= (CLASS_MAX if ((want_first or want_last) and nblocks) else CLASS_MAX_BITMAPS)
     dev = d_corpus.device
     arr = (_Class * n)(*[c._to_c() for c in classes])
     words = (total + 15) // 16
@@ -178,7 +180,7 @@ def class_scan(classes, d_corpus, total, d_off=None, nblocks=0, want_first=True,
     if rv != 0:
         raise HsgpuError(rv, "hsgpu_class_scan_dev")
     if buffers is None:
-        torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
+        _wait_for(stream)  # `work` must outlive the launch (the stream it went to, not torch's current one)
         return bitmaps, first, last
     return bitmaps, first, last, work
 
@@ -307,7 +309,7 @@ def pair_scan(pairs, d_corpus, total, d_off=None, nblocks=0, want_first=True, wa
                                  last.data_ptr() if last is not None else None, work.data_ptr(), st)
     if rv != 0:
         raise HsgpuError(rv, "hsgpu_pair_scan_dev")
-    torch.cuda.current_stream().synchronize()  # `work` must outlive the launch
+    _wait_for(stream)  # `work` must outlive the launch (the stream it went to, not torch's current one)
     return bitmaps, first, last
 
 

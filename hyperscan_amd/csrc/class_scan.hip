@@ -474,6 +474,122 @@ __global__ __launch_bounds__(CT_THREADS) void class_tile_bm_kernel(const uint8_t
     class_tile_body<false>(corpus, total, lut, n_classes, bitmaps, aligned8, nullptr, 0, nullptr, nullptr);
 }
 
+/* ---- up to 16 classes, membership bitmaps only, ONE read of the corpus (round 4) -----------------------------------
+ * The tile kernels above hold 8 classes per pass, and their instruction count is dominated by what first / last need
+ * (block windows, open blocks, scalar state that no longer fits the scalar registers: 311 v_readlane in the bitmaps-only
+ * instantiation). A caller that wants the bitmaps alone -- the class-sequence patterns of config 4 do -- gets this
+ * kernel: the table entry of a byte value is 128 bits, an 8-bit field per class (1 = member), read with ONE ds_read_b128;
+ * acc[q] |= entry[q] << j over the 8 bytes of a group leaves every class's 8 membership bits in its field (four
+ * v_lshl_or per byte for 16 classes), and 4 x 4 byte transposes (v_perm) turn the eight groups of a lane's 64 bytes into
+ * one 64-bit word per class. The table is replicated 8 times (32 KiB): the 8 lanes that share a cycle of a 128-bit LDS
+ * read hit 8 different quadruples of banks. Per corpus byte: 1 B read, n_classes / 8 B written, nothing else. */
+/* The 16 8-bit fields of 8 corpus bytes: eight ds_read_b128 of the replicated table, 32 shift-ors. A function of its own,
+ * NOT inlined: inlined four times into the tile loop, the scheduler moves all 32 reads of a tile (128 result registers) to the
+ * front and the kernel spills ~70 dwords per tile whatever the barriers between the groups. */
+__device__ __attribute__((noinline)) uint4 b16_classify8(uint32_t d0, uint32_t d1, uint32_t rep) {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t d = j < 4 ? d0 : d1;
+        const int q = j & 3;
+        /* byte q of d, times 128 (8 replicas of 16 bytes), + this lane's replica */
+        const uint32_t sh = q == 0 ? d << 7 : d >> (8 * q - 7);
+        const v4u e = *(const __attribute__((address_space(3))) v4u *)(uintptr_t)((sh & 0x7f80u) | rep); /* one ds_read_b128 */
+        acc[0] |= e[0] << j, acc[1] |= e[1] << j, acc[2] |= e[2] << j, acc[3] |= e[3] << j;
+    }
+    return make_uint4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+constexpr int B16_THREADS = 256;
+constexpr uint32_t B16_TABLE_BYTES = 256 * 8 * 16;
+constexpr uint32_t B16_TILE = 2048; /* bytes per wavefront tile: 32 per lane -> one dword of every class's bitmap per lane */
+
+/* (five wavefronts per SIMD = five 32 KiB workgroups per CU. A 4 KiB tile -- 64 bytes and a 64-bit word per class and lane --
+ * needs ~110 registers and spilled a hundred dwords at 96; 32 bytes per lane need 60.) */
+__global__ __launch_bounds__(B16_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void class_bitmap16_kernel(
+    const uint8_t *corpus, uint64_t total, const uint4 *lut /* [256] */, uint32_t n_classes, uint16_t *const *bitmaps) {
+    extern __shared__ __attribute__((aligned(16))) uint4 b16_tab[]; /* [256][8] */
+    for (uint32_t i = threadIdx.x; i < 256 * 8; i += B16_THREADS) b16_tab[i] = lut[i >> 3];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rep = (lane & 7u) << 4;
+    const uint64_t n_tiles = (total + B16_TILE - 1) / B16_TILE;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (B16_THREADS / 64);
+    const uint64_t per_wave = (n_tiles + n_waves - 1) / n_waves;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * (B16_THREADS / 64) + wave;
+    uint64_t tile = min(n_tiles, wave_global * per_wave);
+    const uint64_t tile_end = min(n_tiles, tile + per_wave);
+    if (tile >= tile_end) return;
+    const uint64_t words16 = (total + 15) >> 4; /* what a bitmap holds */
+
+    auto issue = [&](uint64_t t, bool enable, uint4 d[2]) { /* (a disabled tile gets an empty descriptor: zeros, no memory touched) */
+        const uint64_t base = enable ? t * B16_TILE : 0;
+        const uint64_t left = enable ? total - base : 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(corpus + base), 0,
+                                                                             (int)(min<uint64_t>(left, (uint64_t)B16_TILE) & ~15ull), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 32u + k * 16u, 0, 0);
+            d[k] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto classify = [&](uint32_t d0, uint32_t d1, uint32_t acc[4]) {
+        const uint4 r = b16_classify8(d0, d1, rep);
+        acc[0] = r.x, acc[1] = r.y, acc[2] = r.z, acc[3] = r.w;
+    };
+    uint4 nxt[2]; /* (one tile ahead; five wavefronts per SIMD cover the rest of the latency) */
+    issue(tile, true, nxt);
+    for (; tile < tile_end; tile++) {
+        uint4 d[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) d[k] = nxt[k];
+        issue(tile + 1, tile + 1 < tile_end, nxt);
+        const uint64_t lo = tile * B16_TILE;
+        const bool last_tile = tile + 1 == n_tiles;
+        if (last_tile && (total & 15)) { /* the ragged last piece of the corpus: one lane, byte by byte */
+            const uint32_t piece = (uint32_t)((total - lo) >> 4);
+            if (lane == piece >> 1) {
+                uint32_t r[4] = {0, 0, 0, 0};
+                const uint8_t *src = corpus + lo + (uint64_t)piece * 16;
+                for (uint32_t i = 0; i < (uint32_t)(total & 15); i++) r[i >> 2] |= (uint32_t)src[i] << (8 * (i & 3));
+                if (piece & 1) d[1] = make_uint4(r[0], r[1], r[2], r[3]);
+                else d[0] = make_uint4(r[0], r[1], r[2], r[3]);
+            }
+        }
+        uint32_t A[4][4];
+        classify(d[0].x, d[0].y, A[0]);
+        classify(d[0].z, d[0].w, A[1]);
+        classify(d[1].x, d[1].y, A[2]);
+        classify(d[1].z, d[1].w, A[3]);
+        const uint64_t lane_base = lo + lane * 32ull;
+        uint32_t keep = ~0u;
+        if (last_tile) { /* bytes past the end are not members of anything */
+            const uint64_t left = lane_base < total ? total - lane_base : 0;
+            keep = left >= 32 ? ~0u : ((1u << left) - 1u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { /* four classes at a time: transposed and stored (their words do not wait for the others') */
+            uint32_t w[4];
+            transpose4(A[0][q], A[1][q], A[2][q], A[3][q], w);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int c = 4 * q + r;
+                if ((uint32_t)c >= n_classes) continue;
+                const uint32_t m = w[r] & keep;
+                uint16_t *bm = bitmaps[c];
+                if (!last_tile) {
+                    *(uint32_t *)(bm + (lane_base >> 4)) = m;
+                } else {
+                    for (uint32_t k = 0; k < 2; k++)
+                        if ((lane_base >> 4) + k < words16) bm[(lane_base >> 4) + k] = (uint16_t)(m >> (16 * k));
+                }
+            }
+        }
+    }
+}
+
 /* ---- two-byte sets (double shufti / double vermicelli) --------------------------
  * Table entry v: T1 (first uint4) field k (16 bits) = t_k(v), T2 (second uint4) field k =
  * u_k(v); unused fields 0xff. A pair matches set k iff (t_k | u_k) != 0xff. */
@@ -622,10 +738,47 @@ extern "C" int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_cla
                                     uint64_t total_bytes, const void *d_off, uint64_t nblocks,
                                     void *const *d_bitmaps, void *d_first, void *d_last, void *d_work,
                                     void *stream) {
-    if (!classes || n_classes == 0 || n_classes > HSGPU_CLASS_MAX || !d_bitmaps || !d_work) return HSGPU_INVALID;
+    /* (first / last: 8 classes per call; bitmaps alone: 16) */
+    if (!classes || n_classes == 0 || n_classes > ((d_first || d_last) ? HSGPU_CLASS_MAX : HSGPU_CLASS_MAX_BITMAPS) || !d_bitmaps || !d_work)
+        return HSGPU_INVALID;
     if (((uintptr_t)d_corpus & 15) || ((uintptr_t)d_work & 15)) return HSGPU_INVALID;
     if ((d_first || d_last) && (!d_off || nblocks == 0)) return HSGPU_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    bool all_aligned8 = true;
+    for (unsigned c = 0; c < n_classes; c++) {
+        if (!d_bitmaps[c] || ((uintptr_t)d_bitmaps[c] & 1)) return HSGPU_INVALID;
+        all_aligned8 = all_aligned8 && !((uintptr_t)d_bitmaps[c] & 7);
+    }
+    if (!d_first && !d_last && (n_classes > HSGPU_CLASS_MAX || all_aligned8)) {
+        /* bitmaps alone: the 16-class kernel, one read of the corpus whatever the number of classes */
+        if (!all_aligned8) {
+            hsgpu_set_error("more than %d class bitmaps per call need 8-byte aligned bitmaps", HSGPU_CLASS_MAX);
+            return HSGPU_INVALID;
+        }
+        uint32_t lut16[256][4];
+        memset(lut16, 0, sizeof(lut16));
+        for (unsigned c = 0; c < n_classes; c++)
+            for (unsigned v = 0; v < 256; v++)
+                if (classes[c].bitmap[v >> 3] >> (v & 7) & 1) lut16[v][c >> 2] |= 1u << (8 * (c & 3));
+        uint8_t *work = (uint8_t *)d_work;
+        void *ptrs16[HSGPU_CLASS_MAX_BITMAPS] = {nullptr};
+        for (unsigned c = 0; c < n_classes; c++) ptrs16[c] = d_bitmaps[c];
+        static_assert(sizeof(lut16) + sizeof(ptrs16) <= HSGPU_CLASS_WORK_BYTES, "work area layout");
+        HIP_TRY(hipMemcpyAsync(work, lut16, sizeof(lut16), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(work + sizeof(lut16), ptrs16, sizeof(ptrs16), hipMemcpyHostToDevice, st));
+        if (total_bytes == 0) return HSGPU_SUCCESS;
+        int dev = 0, n_cu = 256;
+        HIP_TRY(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        const uint64_t n_tiles = (total_bytes + B16_TILE - 1) / B16_TILE;
+        /* five 32 KiB workgroups of four wavefronts per CU */
+        const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 3) / 4, (uint64_t)n_cu * 5);
+        hipLaunchKernelGGL(class_bitmap16_kernel, dim3(grid), dim3(B16_THREADS), B16_TABLE_BYTES, st, (const uint8_t *)d_corpus, total_bytes,
+                           (const uint4 *)work, n_classes, (uint16_t *const *)(work + sizeof(lut16)));
+        HIP_TRY(hipGetLastError());
+        return HSGPU_SUCCESS;
+    }
     /* host-built 256-entry table: entry[v] field c (8 bits) = 1 iff v in class c */
     uint32_t lut[256][2];
     memset(lut, 0, sizeof(lut));

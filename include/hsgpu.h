@@ -220,8 +220,9 @@ uint64_t hsgpu_hwlm_count_cb(size_t end, uint32_t id, void *ctx);
  * (src/nfa/shufti.h:46-52), truffleExec/rtruffleExec (src/nfa/truffle.h:45-50),
  * vermicelliExec/nvermicelliExec/rvermicelliExec (src/nfa/vermicelli.h:42-518), dispatched
  * by run_accel (src/nfa/accel.c:35-146). Every scheme decodes to a 256-bit class. */
-#define HSGPU_CLASS_MAX 8
-#define HSGPU_CLASS_WORK_BYTES 4160 /* device work area for hsgpu_class_scan_dev */
+#define HSGPU_CLASS_MAX 8          /* classes per call when first / last are asked for */
+#define HSGPU_CLASS_MAX_BITMAPS 16 /* ... for the membership bitmaps alone (d_first == d_last == NULL): one read of the corpus */
+#define HSGPU_CLASS_WORK_BYTES 8192 /* device work area for hsgpu_class_scan_dev */
 
 typedef struct hsgpu_class {
     uint8_t bitmap[32]; /* bit v (LSB first) set <=> byte value v is a member */

@@ -127,3 +127,27 @@ def test_dense_mode_is_left_again():
     k = [i for i, a in enumerate(again) if a]
     assert len(k) >= 2 and k[1] - k[0] >= 16     # ... for a span of at least 16 scans, then one probe of the ordinary sizing
     assert len(k) < 4 and (len(k) < 3 or k[2] - k[1] >= 2 * (k[1] - k[0]) - 1)  # and the span doubles
+
+
+@pytest.mark.parametrize("n_classes,total", [(16, (3 << 20) + 5), (12, 4099), (9, 2048), (16, 31), (1, 1 << 16), (8, (1 << 20) + 17)])
+def test_sixteen_class_bitmaps_in_one_read(n_classes, total):
+    """hsgpu_class_scan_dev without first / last takes up to 16 classes in one pass (class_bitmap16_kernel): every bitmap
+    against numpy, ragged sizes (the last tile, the last 16-byte piece, the last 16-bit word of the bitmap)."""
+    import torch
+
+    from hyperscan_amd import accel
+
+    rng = np.random.default_rng(100 + n_classes + total % 97)
+    corpus = rng.integers(0, 256, total, dtype=np.uint8)
+    classes = []
+    for c in range(n_classes):
+        k = int(rng.integers(1, 200))
+        classes.append(accel.CharClass(sorted(set(rng.integers(0, 256, k).tolist()))))
+    dev = torch.device("cuda", 0)
+    d_corpus = torch.from_numpy(np.concatenate([corpus, np.zeros(16, np.uint8)])).to(dev)
+    bitmaps, first, last = accel.class_scan(classes, d_corpus, total, None, 0, False, False)
+    assert first is None and last is None
+    for c, cls in enumerate(classes):
+        want = np.packbits(np.isin(corpus, np.array(cls.members(), dtype=np.uint8)), bitorder="little")
+        got = bitmaps[c][: want.size].cpu().numpy()
+        assert np.array_equal(got, want), (c, n_classes, total)
