@@ -1651,7 +1651,10 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t l
             }
         }
         /* (a lane without a match resolves the smallest key again -- its all-ones filler names no literal and no position) */
-        const uint64_t safe = rfl64(k0);
+        /* (v_readlane of lane 0, not readfirstlane: the compiler sank one half of a readfirstlane into the `lane >= n` side of
+         * the select, where the first active lane is a filler) */
+        const uint64_t safe = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k0 >> 32), 0) << 32 |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k0, 0);
         if (lane >= n) k0 = safe;
         resolve_queued(t, lane, lane < n, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
     } else { /* 65 .. 128 queued: two keys per lane, element i = lane + 64 r */
@@ -1673,7 +1676,9 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t l
             }
         }
         resolve_queued(t, lane, true, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
-        if (lane + 64 >= n) k1 = rfl64(k0);
+        const uint64_t safe = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k0 >> 32), 0) << 32 |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k0, 0);
+        if (lane + 64 >= n) k1 = safe;
         resolve_queued(t, lane, lane + 64 < n, make_uint2((uint32_t)k1, (uint32_t)(k1 >> 32)));
     }
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
