@@ -274,7 +274,7 @@ def gpu_vs_gpu_gate(job):
     regions themselves) against the always-correct fused pipeline + record_sort_kernel on a second scratch -- the two share
     the filter's arithmetic and nothing of what follows it. Identical arrays, element for element, or the bench stops."""
     torch = job.torch
-    other = GpuJob(None, None, None, torch.cuda.current_device(), sibling=job, cap=job.cap)
+    other = GpuJob(None, None, None, torch.cuda.current_device(), sibling=job, cap=4 * job.cap)  # (the fused kernel stages per filter wavefront: a quarter of the regions)
     other.scratch.set_tuning(1)
     job.launch()
     other.launch()

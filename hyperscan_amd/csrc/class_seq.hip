@@ -564,10 +564,11 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
     bool aligned = true;
     for (unsigned c = 0; c < n_classes; c++) aligned = aligned && (((uintptr_t)d_bitmaps[c]) & 7) == 0;
     const bool tiled = aligned && n_classes <= TILE_MAX_CLASSES;
-    /* the header of the work area: patterns | bitmap pointers | the kernel's tables. Built on the host, uploaded only when
-     * it differs from what this work area was given last time (the copy kept here is also what the asynchronous upload
-     * reads from: nothing on the stack goes out of scope under a DMA, and a caller that repeats a scan -- every step of a
-     * pipeline does -- neither uploads nor waits) */
+    /* the header of the work area: patterns | bitmap pointers | the kernel's tables. Built on the host and uploaded on every
+     * call (the work area is the caller's: it may have been freed, reused and zeroed since the last call), asynchronously, from
+     * a copy kept per work area -- nothing on the stack goes out of scope under the DMA, and the call does not wait for the
+     * stream (round 3 synchronised it on every call). Only a call whose header differs from the kept copy waits, for the
+     * upload that may still be reading the old one. */
     std::vector<uint8_t> hdr(tab_ofs, 0);
     memcpy(hdr.data(), seqs, seq_bytes);
     memcpy(hdr.data() + ptr_ofs, d_bitmaps, (size_t)n_classes * sizeof(void *));
@@ -619,10 +620,10 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
         std::lock_guard<std::mutex> lock(mu);
         std::vector<uint8_t> &have = uploaded[d_work];
         if (have != hdr) {
-            if (!have.empty()) HIP_TRY(hipStreamSynchronize(st)); /* an upload from the old copy may still be on its way */
+            if (!have.empty()) HIP_TRY(hipDeviceSynchronize()); /* an upload from the old copy may still be on its way (on any stream) */
             have = hdr;
-            HIP_TRY(hipMemcpyAsync(w, have.data(), have.size(), hipMemcpyHostToDevice, st));
         }
+        HIP_TRY(hipMemcpyAsync(w, have.data(), have.size(), hipMemcpyHostToDevice, st));
     }
     const uint64_t n_words = (total_bytes + 63) / 64;
     uint64_t *starts = (uint64_t *)(w + SEQ_HEADER);

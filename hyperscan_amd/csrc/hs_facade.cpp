@@ -27,7 +27,6 @@
 #include <algorithm>
 #include <bitset>
 #include <cctype>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1077,18 +1076,13 @@ static int confirm_and_deliver_impl(const hs_database *db, const char *data, con
                                      [](const hsgpu_match_t &r, unsigned long long blk) { return r.block < blk; }) - follow;
             fcut[t] = std::max(f, fcut[t - 1]);
         }
-        static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr;
         std::atomic<bool> failed{false}; /* no exception may leave a worker thread (std::terminate) or this extern "C" path */
         auto work = [&](unsigned t) {
-            const auto t0 = std::chrono::steady_clock::now();
             try {
                 collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t], cs, ccut[t], ccut[t + 1]);
             } catch (...) {
                 failed = true;
             }
-            if (timing)
-                fprintf(stderr, "  confirm worker %u: %zu hits in %.2f ms\n", t, cut[t + 1] - cut[t],
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         };
         if (n_thr == 1) {
             work(0);
@@ -1140,7 +1134,6 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
     scratch->in_use = true;
     struct Guard { hs_scratch *s; ~Guard() { s->in_use = false; } } guard{scratch};
     if (nblocks == 0) return HS_SUCCESS;
-    const auto t_begin = std::chrono::steady_clock::now();
     /* large batches of a literal-only database: the chunked pipeline (csrc/runtime.hip): the host confirm and the
      * callbacks of chunk i run here while the chunks after it are copied and scanned */
     if (db->hwlm && db->cs_seqs.empty() && off[nblocks] - off[0] >= ((unsigned long long)96 << 20) &&
@@ -1199,17 +1192,9 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
             return HS_NOMEM;
         }
     }
-    static const bool timing = getenv("HSGPU_FACADE_TIMING") != nullptr; /* diagnostic: where does a batch go? */
-    const auto t_scan = std::chrono::steady_clock::now();
     const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context,
                                                    n_cs ? scratch->cs_recs.data() : nullptr, n_cs);
     if (any_terminated < 0) return HS_NOMEM;
-    if (timing) {
-        const auto t_end = std::chrono::steady_clock::now();
-        fprintf(stderr, "hs_scan_batch: %zu literal hits; GPU literal scan incl. copies %.2f ms, host confirm %.2f ms\n", n,
-                std::chrono::duration<double, std::milli>(t_scan - t_begin).count(),
-                std::chrono::duration<double, std::milli>(t_end - t_scan).count());
-    }
     return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
 }
 

@@ -1760,6 +1760,9 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         unsigned long long before = 0;
         uint32_t spins = 0;
         bool bad = false;
+#ifdef HSGPU_X_NOPLACE
+        goto placed;
+#endif
         /* first try: every word once, all loads in flight together (one round trip when everything in front has been published,
          * which the deferral makes the rule) */
         {
@@ -1819,7 +1822,11 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     /* every wavefront: its (sorted) region of a placed share into the output */
     auto copy_region = [&](uint32_t p, uint32_t n_p, unsigned long long base) {
         const HsgpuScanArgs &args = cold_args();
+#ifdef HSGPU_X_NOCOPY
+        if (false) {
+#else
         if (n_p && n_p <= args.rec_cap && base + n_p <= args.cap) { /* (a region that lost records is left alone: the scan says "again") */
+#endif
             const uint4 *region = args.rec_stage + (uint64_t)(p * W + wave) * args.rec_cap;
             uint4 *out = (uint4 *)args.out + base;
             for (uint32_t i = lane; i < n_p; i += 64) out[i] = region[i];
@@ -1852,9 +1859,15 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         /* this wavefront's entries [base, end) in steps of `stride`: folded -- the w-th quarter of the share's batches of 128,
          * so that the four regions are consecutive pieces of the corpus; unfolded -- batches wave, wave + W, ... */
         const uint32_t nb = (n + 127) >> 7;
+#ifdef HSGPU_X_RR /* timing experiments only (results out of order) */
+        uint32_t base = wave << 7;
+        const uint32_t end = n;
+        const uint32_t stride = 128u * W;
+#else
         uint32_t base = fold ? (wave * nb / W) << 7 : wave << 7;
         const uint32_t end = fold ? min(n, ((wave + 1) * nb / W) << 7) : n;
         const uint32_t stride = fold ? 128u : 128u * W;
+#endif
         init_wave_lds(t, &wave_lds[wave], lane);
         uint32_t fill = 0;
         if (base < end) { /* else nothing for this wavefront: its record counts stay zero */
@@ -1903,7 +1916,11 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                         confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, false);
                     }
                 } else if (fold) { /* a sync point with nothing pending: everything queued is final; in order into the region */
+#ifdef HSGPU_X_PLAINDRAIN
+                    drain_matches(t, lane, 0);
+#else
                     drain_matches_sorted(t, lane);
+#endif
                     syncing = false;
                     if (base >= end) break;
                     continue;
