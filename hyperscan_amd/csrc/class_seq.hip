@@ -435,8 +435,15 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
         W2 a = {0, 0}, pa = {0, 0}, g = {0, 0}, pg = {0, 0};
         uint32_t pj = 0;          /* patterns done in this tile (their order in the program) */
         uint32_t packed = 0;      /* the count of an even pattern, waiting for the odd one to share a reduction */
+        /* the program is read one operation ahead (a scalar load and its wait at the head of every iteration were most of an
+         * iteration's time), and so is the next pattern's qb from LDS */
+        TileOp nxt_op = args.ops[0];
+        W2 qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]);
         for (uint32_t o = 0; o < args.n_ops; o++) {
-            const TileOp op = args.ops[o]; /* (uniform: scalar loads) */
+            const TileOp op = nxt_op;
+            const W2 qb_cur = qb_nxt;
+            nxt_op = args.ops[min(o + 1, args.n_ops - 1)];
+            qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]);
             if (op.kind == OP_CLASS) {
                 a = w2(load(op.cls));
                 pa = from_below(a, below);
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
                 g = shl2u(r, from_below(r, below), 1) & nst;          /* G: a match of A{m,} may end right before this byte */
                 pg = from_below(g, below);
             } else {
-                const W2 qb = w2(qb_lds[op.cls * 64 + lane]);
+                const W2 qb = qb_cur;
                 W2 x;
                 if (op.k == 0) {
                     x = g & qb; /* (g has no block starts: g & b = g & qb) */
@@ -483,14 +490,14 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
                 const uint32_t pc = __builtin_popcount(y_lo) + __builtin_popcount(y_hi);
                 if (pj & 1) { /* two patterns per reduction: no field can overflow (63 words x 64 bits) */
                     const uint32_t tot = wave_sum_to_63(packed | pc << 16);
-                    if (lane == 63) {
-                        cnt[pj - 1] += tot & 0xffffu;
-                        cnt[pj] += tot >> 16;
+                    if (lane == 63) { /* (ds_add without return: nothing waits for LDS here) */
+                        __hip_atomic_fetch_add(&cnt[pj - 1], tot & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        __hip_atomic_fetch_add(&cnt[pj], tot >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                 } else {
                     packed = pc;
                 }
-                if (emit_tile && (y_lo | y_hi)) {
+                if (emit_tile) { /* (uniform, and rare: a caller asked for the records of a byte range) */
                     uint64_t y = (uint64_t)y_hi << 32 | y_lo;
                     while (y) {
                         const uint32_t j = __builtin_ctzll(y);
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
         }
         if (pj & 1) { /* an odd number of patterns: the last one reduces alone */
             const uint32_t tot = wave_sum_to_63(packed);
-            if (lane == 63) cnt[pj - 1] += tot;
+            if (lane == 63) __hip_atomic_fetch_add(&cnt[pj - 1], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     }
     /* the share's counts: the program's pattern order back to the caller's */

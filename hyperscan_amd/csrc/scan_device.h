@@ -287,8 +287,8 @@ __device__ __forceinline__ uint32_t publish_records(const Tables &t, const Hsgpu
         args.rec_counts[2 * region] = front;
         args.rec_counts[2 * region + 1] = back;
         const unsigned long long fill = (unsigned long long)front + back;
-        if (to_supers && fill) atomicAdd(&args.rec_super[region >> args.super_shift], fill);
-        if (fill > args.rec_cap) atomicAdd(&args.rec_super[256], 1ull); /* the region lost records */
+        if (to_supers && fill) atomicAdd(&args.rec_super[HSGPU_SUPER(region >> args.super_shift)], fill);
+        if (fill > args.rec_cap) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull); /* the region lost records */
         fill32 = (uint32_t)min(fill, 0x7fffffffull);
     }
     return __builtin_amdgcn_readfirstlane(fill32);
@@ -1711,6 +1711,8 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
     __shared__ uint32_t s_share[2], s_fills[2][W]; /* (the ticket alternates between two words: written for round k + 1 while a slow wavefront may not have read round k's yet) */
     __shared__ unsigned long long s_bases[2][W];
+    __shared__ uint32_t s_sup_n;            /* placement: the supers [0, s_sup_n) are complete and add up to s_sup_sum */
+    __shared__ unsigned long long s_sup_sum;
     __shared__ uint32_t s_sum[2], s_done[2], s_placer[2]; /* the round's share: records so far, wavefronts done; wavefronts past their quarter */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1729,6 +1731,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         scan_epilogue(args);
         return;
     }
+    if (tid == 0) s_sup_n = 0, s_sup_sum = 0;
     const bool gated = !PAIR && (args.t_flags & HSGPU_F_GATE);
     if (gated) { /* once per workgroup */
         const uint4 *src = (const uint4 *)(args.blob + args.t_off_c2bits);
@@ -1760,30 +1763,45 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         unsigned long long before = 0;
         uint32_t spins = 0;
         bool bad = false;
-#ifdef HSGPU_X_NOPLACE
-        goto placed;
-#endif
-        /* first try: every word once, all loads in flight together (one round trip when everything in front has been published,
-         * which the deferral makes the rule) */
+        /* The sums of the supers in front: a super that is complete never changes, so the workgroup keeps in LDS how many of them
+         * it has added up already and their sum (s_sup_n, s_sup_sum; one placer per round, the round's barrier in between) and
+         * reads only the new ones -- ~96 per placement instead of all S: with every placement reading all of them, 1.3 M polls
+         * of the same 2 KiB took 65 us of the stage (profiles/r04_tail_fold_components_ab.txt). The super words are 64 bytes
+         * apart for the same reason. First try: every word once, all loads in flight together (one round trip when everything
+         * in front has been published, which the deferral makes the rule). */
+        const uint32_t S0 = min(s_sup_n, S);
+        unsigned long long cached = s_sup_sum;
         {
             unsigned long long sv[4];
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                sv[k] = __hip_atomic_load(&args.rec_super[min(lane + 64u * k, 255u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sv[k] = __hip_atomic_load(&args.rec_super[HSGPU_SUPER(min(S0 + lane + 64u * k, 255u))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t i0 = (S << ss) + lane;
             const uint32_t st = __hip_atomic_load(&args.share_status[min(i0, n_shares - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool ok = ss <= 6; /* (supers of more than 64 shares: only grids beyond 16 384 filter wavefronts) */
+            unsigned long long fresh = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (lane + 64u * k < S) ok = ok && (uint32_t)(sv[k] >> 40) == (1u << ss), before += sv[k] & ((1ull << 40) - 1);
-            if (i0 < p) ok = ok && (st >> 31), before += st & 0x7fffffffu;
-            if (__ballot(!ok)) before = 0, bad = false; /* somebody in front is still confirming: poll */
-            else goto placed;
+                if (S0 + lane + 64u * k < S) ok = ok && (uint32_t)(sv[k] >> 40) == (1u << ss), fresh += sv[k] & ((1ull << 40) - 1);
+            if (__ballot(!ok) == 0) {
+                if (i0 < p) ok = (st >> 31) != 0, before = st & 0x7fffffffu;
+                if (__ballot(!ok) == 0) {
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) fresh += __shfl_xor(fresh, d);
+                    cached += fresh;
+                    if (lane == 0) s_sup_n = S, s_sup_sum = cached; /* all of [0, S) complete and added up */
+                    if (lane == 0) before += cached;
+                    goto placed;
+                }
+            }
+            before = 0;
         }
-        for (uint32_t i = lane; i < S; i += 64) { /* the supers in front: all of them full ones */
+        /* somebody in front is still confirming: poll, word by word */
+        if (lane == 0) before = cached;
+        for (uint32_t i = S0 + lane; i < S; i += 64) { /* the supers in front not added up yet: all of them full ones */
             unsigned long long v;
             for (;;) {
-                v = __hip_atomic_load(&args.rec_super[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = __hip_atomic_load(&args.rec_super[HSGPU_SUPER(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > SPIN_LIMIT) bad = true;
@@ -1805,7 +1823,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
         const bool any_bad = __ballot(bad) != 0;
         if (lane == 0) {
-            if (any_bad) atomicAdd(&args.rec_super[256], 1ull);
+            if (any_bad) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull);
             unsigned long long at = before;
             for (uint32_t w = 0; w < W; w++) bases[w] = at, at += fills[w];
             if (p + 1 == n_shares) {
@@ -1813,7 +1831,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                  * counting, so the total is still exact: report it, but never a value <= cap (that would claim the output is
                  * complete). The same word says that some wavefront had to emit out of order: again, in dense mode. */
                 const unsigned long long flag =
-                    __hip_atomic_load(&args.rec_super[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
+                    __hip_atomic_load(&args.rec_super[HSGPU_SUPER_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
                 *args.count = (flag && at <= args.cap) ? args.cap + 1 : at;
                 if ((flag >> 32) && args.overflow_note) *args.overflow_note = 1u; /* more matches than the queue orders: dense mode next */
             }
@@ -1937,7 +1955,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             }
             if (!fold) drain_matches(t, lane, 0);
             fill = publish_records(t, args, lane, cw, !fold);
-            if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[256], 1ull << 32); /* emitted out of order: "again", in dense mode */
+            if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32); /* emitted out of order: "again", in dense mode */
         }
         if (fold) {
             const HsgpuScanArgs &args = cold_args();
@@ -1954,7 +1972,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                 __hip_atomic_fetch_add(&s_sum[slot], n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__hip_atomic_fetch_add(&s_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == W - 1) {
                     const uint32_t tot = __hip_atomic_load(&s_sum[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&args.rec_super[r >> args.super_shift], (1ull << 40) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&args.rec_super[HSGPU_SUPER(r >> args.super_shift)], (1ull << 40) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&args.share_status[r], 0x80000000u | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -2009,11 +2027,11 @@ __global__ __launch_bounds__(1024) void record_sort_kernel(HsgpuScanArgs args) {
          * this was five dependent round trips at the head of every workgroup, most of the kernel's 55 us) */
         unsigned long long sv[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) sv[k] = args.rec_super[min(lane + 64u * k, 256u)];
+        for (int k = 0; k < 4; k++) sv[k] = args.rec_super[HSGPU_SUPER(min(lane + 64u * k, 255u))]; /* (the flags word is read below) */
         /* a staging region lost records, or (two-phase pipeline) a candidate region overflowed and the confirm kernel did
          * nothing: either way this scan delivers nothing and says so */
         const unsigned long long flag =
-            args.rec_super[256] | ((args.cand_counts && args.overflow_note) ? args.cand_counts[args.cand_waves] : 0u);
+            args.rec_super[HSGPU_SUPER_FLAGS] | ((args.cand_counts && args.overflow_note) ? args.cand_counts[args.cand_waves] : 0u);
         const uint32_t c0 = (S << args.super_shift) + lane;
         const uint2 cfirst = counts[min(c0, args.rec_regions - 1)];
         unsigned long long before = 0, all = 0;

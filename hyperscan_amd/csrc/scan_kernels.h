@@ -16,7 +16,11 @@
 #define HSGPU_CONFIRM_SPLIT 4 /* confirm wavefronts per candidate region (tuning builds: 2) */
 #endif
 #define HSGPU_HINT_SHIFT 10 /* one block hint per KiB of corpus */
-#define HSGPU_SUPER_WORDS 257 /* rec_super: [0, 256) supers, [256] flags */
+/* rec_super: 256 supers and a flags word, each on a 64-byte line of its own (thousands of wavefronts poll and add to them:
+ * side by side in 2 KiB they were one hot spot in one memory channel) */
+#define HSGPU_SUPER(i) ((i) << 3)
+#define HSGPU_SUPER_FLAGS HSGPU_SUPER(256)
+#define HSGPU_SUPER_WORDS (257 * 8)
 
 struct HsgpuScanArgs {
     const uint8_t *corpus;      /* all blocks, concatenated; 16-byte aligned */
