@@ -203,3 +203,104 @@ def gather_records_to_root(records, count, block_base, dist, world, rank, root=0
     for r in range(world):
         out[starts[r]:starts[r + 1], 0] += _as_i32(bases[r])
     return out, counts
+
+
+class NativeExchange:
+    """Mirror of the C ABI's exchange (include/hsgpu.h, hsgpu_exchange_*; csrc/exchange.hip): RCCL directly, 12-byte wire
+    records {global block, end, id}, to the root (default: one host delivers the callbacks) or to every rank.
+
+    The 128-byte RCCL id travels from rank 0 to the others over the process group the job already has (`dist`, any backend);
+    world == 1 needs no group. step() takes the scan's device buffers as they are (nothing allocated, no host sync);
+    compact() synchronises and returns (int32 tensor [total, 3] of the ranks' records in corpus order -- empty where nothing
+    arrives --, counts per rank)."""
+
+    TO_ROOT, ALL_GATHER = 0, 1
+
+    def __init__(self, dist, world, rank, device, rows, block_base, mode=TO_ROOT, root=0, with_comm=None):
+        import ctypes as C
+
+        import torch
+
+        from . import _native
+
+        self._lib = lib = _native.load_library()
+        self.world, self.rank, self.rows, self.base, self.mode, self.root = world, rank, int(rows), int(block_base), mode, root
+        self.device = device
+        lib.hsgpu_exchange_create.restype = C.c_int
+        lib.hsgpu_exchange_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint, C.c_int]
+        lib.hsgpu_exchange_step.restype = C.c_int
+        lib.hsgpu_exchange_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.hsgpu_exchange_compact.restype = C.c_int
+        lib.hsgpu_exchange_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+        lib.hsgpu_exchange_set_counts.restype = C.c_int
+        lib.hsgpu_exchange_set_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.hsgpu_exchange_wire_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.hsgpu_exchange_free.argtypes = [C.c_void_p]
+        want_comm = world > 1 if with_comm is None else with_comm
+        idbuf = None
+        if want_comm:
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_uint8 * 128)()
+                rv = lib.hsgpu_exchange_unique_id(raw)
+                if rv != 0:
+                    raise RuntimeError("hsgpu_exchange_unique_id: " + lib.hsgpu_last_error().decode())
+                idt = torch.tensor(list(raw), dtype=torch.uint8)
+            if world > 1:
+                on = idt.to(device) if dist.get_backend() == "nccl" else idt
+                dist.broadcast(on, src=0)
+                idt = on.cpu()
+            idbuf = (C.c_uint8 * 128)(*idt.tolist())
+        h = C.c_void_p()
+        rv = lib.hsgpu_exchange_create(C.byref(h), idbuf, world, rank, device.index if device.index is not None else 0, self.rows, mode, root)
+        if rv != 0:
+            raise RuntimeError("hsgpu_exchange_create: " + lib.hsgpu_last_error().decode())
+        self._h = h
+        self.out = torch.zeros((max(1, world * self.rows), 3), dtype=torch.int32, device=device)
+
+    def set_counts(self, counts):
+        import ctypes as C
+
+        arr = (C.c_uint64 * self.world)(*[int(c) for c in counts]) if counts is not None else None
+        rv = self._lib.hsgpu_exchange_set_counts(self._h, arr, self.world)
+        if rv != 0:
+            raise RuntimeError("hsgpu_exchange_set_counts: " + self._lib.hsgpu_last_error().decode())
+
+    def wire_bytes(self):
+        import ctypes as C
+
+        s, r = C.c_uint64(), C.c_uint64()
+        self._lib.hsgpu_exchange_wire_bytes(self._h, C.byref(s), C.byref(r))
+        return s.value, r.value
+
+    def step(self, records, d_count):
+        """records: the scan's int32 [cap, 4] device tensor, d_count its int64 [1] counter; on torch's current stream"""
+        import torch
+
+        rv = self._lib.hsgpu_exchange_step(self._h, records.data_ptr(), d_count.data_ptr(), self.base, torch.cuda.current_stream().cuda_stream)
+        if rv != 0:
+            raise RuntimeError("hsgpu_exchange_step: " + self._lib.hsgpu_last_error().decode())
+
+    def compact(self):
+        import ctypes as C
+
+        import torch
+
+        counts = (C.c_uint64 * self.world)()
+        total = C.c_uint64()
+        rv = self._lib.hsgpu_exchange_compact(self._h, self.out.data_ptr(), self.out.shape[0], counts, C.byref(total),
+                                              torch.cuda.current_stream().cuda_stream)
+        if rv != 0:
+            raise RuntimeError(f"hsgpu_exchange_compact: rc {rv} (counts {list(counts)}, slot {self.rows} rows) " + self._lib.hsgpu_last_error().decode())
+        return self.out[: total.value], [int(c) for c in counts]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hsgpu_exchange_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -215,6 +215,43 @@ int hsgpu_hwlm_fetch_replay(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const voi
 /* hsbench's counting callback (tools/hsbench/engine_hyperscan.cpp:89-97): ctx = uint64_t counter. */
 uint64_t hsgpu_hwlm_count_cb(size_t end, uint32_t id, void *ctx);
 
+/* ---- the exchange step of a multi-GPU job (csrc/exchange.hip) ------------------------------------
+ * Blocks are independent scans: a job over N GPUs (one process per GPU) shards the corpus by contiguous block ranges, every
+ * rank scans its shard with hsgpu_hwlm_scan_dev, and ONE collective per step brings the match records together -- at the
+ * rank whose host delivers the callbacks (HSGPU_XCHG_TO_ROOT: what hsbench's threads do with their result table,
+ * tools/hsbench/main.cpp:957-963, 990-1030; on xGMI every peer has a link of its own to the root), or at every rank
+ * (HSGPU_XCHG_ALL_GATHER). RCCL directly (loaded at run time); no reference counterpart: the reference has no device boundary.
+ *   wire record   12 bytes {GLOBAL block index, end, id}
+ *   unique_id     rank 0 obtains 128 bytes and hands them to the other ranks by whatever means the job has (MPI, a file, a
+ *                 torch.distributed broadcast); world == 1 may pass NULL (no communicator is made)
+ *   create        collective over all ranks. rows_per_rank: the records a rank's slot holds (agree on the largest expected
+ *                 count + slack); a slot travels whole unless set_counts told every rank the exact rows of every rank
+ *                 (steps that repeat a scan: the counts are known from the first one)
+ *   step          packs the records of the scan that wrote d_records / d_count (hsgpu_hwlm_scan_dev's buffers, still on the
+ *                 device; first_block = the global index of this rank's block 0) and posts the transfers, all on `stream`:
+ *                 no host synchronisation, nothing allocated
+ *   compact       (synchronises) the records of the last step in rank order = corpus order into d_out (device, hsgpu_wire_t
+ *                 [cap]), counts[r] = what rank r's scan found, *total = records delivered; HSGPU_INSUFFICIENT_SPACE when
+ *                 a scan found more than its slot (or cap) holds. On ranks that receive nothing (TO_ROOT, not the root)
+ *                 *total = 0. */
+#define HSGPU_XCHG_ID_BYTES 128
+#define HSGPU_XCHG_TO_ROOT 0u
+#define HSGPU_XCHG_ALL_GATHER 1u
+typedef struct hsgpu_exchange hsgpu_exchange_t;
+typedef struct hsgpu_wire {
+    uint32_t block, end, id;
+} hsgpu_wire_t;
+int hsgpu_exchange_unique_id(void *id /* HSGPU_XCHG_ID_BYTES */);
+int hsgpu_exchange_create(hsgpu_exchange_t **x, const void *id, int world, int rank, int device, uint64_t rows_per_rank,
+                          unsigned mode, int root);
+int hsgpu_exchange_set_counts(hsgpu_exchange_t *x, const uint64_t *rows /* [world], NULL = fixed slots again */, int world);
+int hsgpu_exchange_step(hsgpu_exchange_t *x, const void *d_records, const void *d_count, uint64_t first_block, void *stream);
+int hsgpu_exchange_compact(hsgpu_exchange_t *x, void *d_out, uint64_t cap, uint64_t *counts /* [world], host */, uint64_t *total,
+                           void *stream);
+/* bytes this rank sends / receives in one step (the figure a link budget needs) */
+int hsgpu_exchange_wire_bytes(const hsgpu_exchange_t *x, uint64_t *sent, uint64_t *received);
+void hsgpu_exchange_free(hsgpu_exchange_t *x);
+
 /* ---- character-class scanning ------------------------------------------------------
  * The GPU form of the reference's class accelerators: shuftiExec/rshuftiExec
  * (src/nfa/shufti.h:46-52), truffleExec/rtruffleExec (src/nfa/truffle.h:45-50),

@@ -151,3 +151,39 @@ def test_sixteen_class_bitmaps_in_one_read(n_classes, total):
         want = np.packbits(np.isin(corpus, np.array(cls.members(), dtype=np.uint8)), bitorder="little")
         got = bitmaps[c][: want.size].cpu().numpy()
         assert np.array_equal(got, want), (c, n_classes, total)
+
+
+@pytest.mark.parametrize("mode,with_comm", [(0, True), (1, True), (0, False)])
+def test_native_exchange_world_size_1(mode, with_comm):
+    """hsgpu_exchange_* (csrc/exchange.hip, RCCL loaded at run time) at world size 1: the scan's records packed to 12-byte
+    wire records with global block indices, through an RCCL communicator of one rank (to-root and all-gather forms), compacted:
+    the oracle's (block + base, end, id) in delivery order; a slot that is too small says so; exact counts."""
+    import torch
+
+    from hyperscan_amd import dist as hd
+
+    lits = cp.teddy_literals(64, seed=2)
+    corpus, off = cp.packet_corpus(8 << 20, lits, seed=44, match_every=1024)
+    r = Resident(lits, corpus, off, cap=1 << 16)
+    n = r.scan()
+    assert 1000 < n <= r.cap
+    want = r.records(n)
+    dev = torch.device("cuda", 0)
+    base = 123456
+    x = hd.NativeExchange(None, 1, 0, dev, n + 100, base, mode=mode, with_comm=with_comm)
+    x.step(r.d_out.view(-1, 4), r.d_count)
+    out, counts = x.compact()
+    assert counts == [n] and out.shape == (n, 3)
+    g = out.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(g[:, 0], want[:, 0] + np.uint32(base)) and np.array_equal(g[:, 1], want[:, 1]) and np.array_equal(g[:, 2], want[:, 2])
+    assert x.wire_bytes() == (0, 0)
+    x.set_counts([n])
+    x.step(r.d_out.view(-1, 4), r.d_count)
+    out2, _ = x.compact()
+    assert torch.equal(out, out2)
+    x.close()
+    small = hd.NativeExchange(None, 1, 0, dev, n // 2, base, mode=mode, with_comm=False)
+    small.step(r.d_out.view(-1, 4), r.d_count)
+    with pytest.raises(RuntimeError):
+        small.compact()
+    small.close()
