@@ -355,16 +355,40 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         cnts = allnb[:, 1].tolist()
         skew = max(cnts) / max(1.0, float(np.mean(cnts)))
         exact = (args.exchange == "exact") or (args.exchange == "auto" and skew > 1.5)
-        if exact:
+        native = None
+        if args.exchange in ("auto", "native", "native_all"):
+            # the C ABI's exchange (hsgpu_exchange_*: RCCL directly, 12-byte wire records): to the root -- the rank whose host
+            # would deliver the callbacks -- unless all-gather is asked for; the rows every rank sends are the warm-up's
+            # counts (every step scans the same shard). Every rank must have it, or none uses it.
+            try:
+                native = [hd.NativeExchange(dist, world, rank, job.dev, rows, base,
+                                            mode=hd.NativeExchange.ALL_GATHER if args.exchange == "native_all" else hd.NativeExchange.TO_ROOT)
+                          for _ in jobs]
+                for x in native:
+                    x.set_counts(cnts)
+                ok = 1
+            except Exception as e:  # noqa: BLE001 -- any failure means the torch.distributed form for everybody
+                log(f"[rank {rank}] native exchange unavailable: {e}")
+                native, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int64, device=job.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                native = None
+                assert args.exchange == "auto", "--exchange native: hsgpu_exchange_create failed on some rank"
+        if native is not None:
+            exch = native
+        elif exact:
             bases = np.concatenate([[0], np.cumsum(allnb[:, 0].numpy())])[:world].tolist()
             exch = [hd.ExactExchange(dist, world, rank, job.dev, cnts, bases) for _ in jobs]
         else:
             exch = [hd.RecordExchange(dist, world, rank, job.dev, rows, base) for _ in jobs]
         run_steps(depth, exch)  # untimed: RCCL sets up its rings on first use
         allr, counts = exch[0].compact()
-        assert counts[rank] == n_matches and allr.shape[0] == sum(counts)
-        assert bool((allr[1:, 0].to(torch.int64) & 0xFFFFFFFF >= allr[:-1, 0].to(torch.int64) & 0xFFFFFFFF).all()), \
-            "gathered records are not in global block order"
+        assert counts[rank] == n_matches
+        if native is None or rank == 0 or args.exchange == "native_all":
+            assert allr.shape[0] == sum(counts)
+            assert bool((allr[1:, 0].to(torch.int64) & 0xFFFFFFFF >= allr[:-1, 0].to(torch.int64) & 0xFFFFFFFF).all()), \
+                "gathered records are not in global block order"
 
     # parity gate on the first blocks (bounded CPU time) + the CPU baseline
     cpu = None
@@ -465,13 +489,30 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         "records": "in delivery order (block, end, lit), sorted on the device inside the step",
     }
     res["pipeline_depth"] = depth
+    if dist is None:
+        # what an 8-GPU step would be made of (NOT measured here: one GPU): the scan as measured, the records of one rank on the
+        # wire, over xGMI's point-to-point links at 153 GB/s x 0.8 each (MI355X_MICROARCH.md)
+        wire = 16 + 12 * n_matches
+        link = 153e9 * 0.8
+        res["multi_gpu"] = {"predicted_for_n_gpus": 8, "measured": False, "scan_ms": round(dt / args.steps * 1e3, 4), "wire_bytes_per_rank": wire,
+                            "to_root_ms": round(wire / link * 1e3, 4), "ring_all_gather_ms": round(7 * wire / link * 1e3, 4),
+                            "step_ms_exchange_overlapped_with_next_scan": round(max(dt / args.steps, wire / link) * 1e3, 4),
+                            "assumes": "every peer sends its records to rank 0 over its own xGMI link (7 transfers side by side); "
+                                       "a ring all-gather carries 7 ranks' records over every link"}
     if whole_gate:
         res["parity_whole_corpus"] = whole_gate
     if overlapped:
         res["two_scans_in_flight"] = overlapped
     if dist is not None:
         g = [a.elapsed_time(b) for a, b in ev]
-        res["exchange"] = {"collective": ("broadcast x world of exactly counts[r] rows (counts agreed before the timed steps)" if exact else
+        if native is not None:
+            sent, rcvd = exch[0].wire_bytes()
+            res["exchange"] = {"collective": ("hsgpu_exchange_step (C ABI, RCCL): grouped ncclSend / ncclRecv of exactly the agreed rows, 12-byte wire "
+                                              "records, " + ("every rank to every rank" if args.exchange == "native_all" else "every rank to rank 0")),
+                               "count_skew_max_over_mean": round(skew, 3), "wire_bytes_sent_rank0": sent, "wire_bytes_received_rank0": rcvd,
+                               "gather_ms_avg_rank0": round(float(np.mean(g)), 4), "gather_ms_max_rank0": round(float(np.max(g)), 4)}
+        else:
+          res["exchange"] = {"collective": ("broadcast x world of exactly counts[r] rows (counts agreed before the timed steps)" if exact else
                                           "all_gather_into_tensor x2 (counts, records padded to a fixed size)"),
                            "count_skew_max_over_mean": round(skew, 3),
                            "rows_per_rank": exch[0].rows, "bytes_per_rank_per_step": exch[0].rows * 16 + 16,
@@ -1056,8 +1097,10 @@ def main():
                          "GiB at every GPU count, rank r scanning shards [r, r + 1) * shards / N (SURVEY 8(d) config 3: "
                          "'also run at 1/2/4 GPUs on the same 8 GiB')")
     ap.add_argument("--shards", type=int, default=8, help="shards of --gib GiB that make up the strong-scaling corpus")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "padded", "exact"],
-                    help="N > 1: padded all-gather, exact-size broadcasts, or by the skew of the per-rank match counts")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "native", "native_all", "padded", "exact"],
+                    help="N > 1: auto = the C ABI's exchange over RCCL, records to rank 0 (12-byte wire records), falling back to "
+                         "torch.distributed (padded all-gather, or exact-size broadcasts when the per-rank counts are skewed) when it "
+                         "cannot be created; native_all = the same to every rank; padded / exact = the torch.distributed forms")
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=[0, 1, 2],
                     help="scans in flight: 2 overlaps a step's record all-gather with the next step's scan; "
                          "0 = 1 at N = 1 (the per-kernel figures are then those of the kernels alone), 2 at N > 1")

@@ -318,11 +318,18 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_shared_kernel(SeqArgs a
 constexpr uint32_t TILE_WORDS = 63;
 constexpr uint32_t TILE_MAX_CLASSES = 32;
 
-enum : uint8_t { OP_CLASS = 0, OP_PAIR = 1, OP_PAT = 2 };
+enum : uint8_t { OP_CLASS = 0, OP_PAIR = 1, OP_PAT = 2, OP_PAT2 = 3 };
 struct TileOp {
-    uint8_t kind, cls, k, pad; /* OP_CLASS: cls = A | OP_PAIR: k = m - 1 | OP_PAT: cls = B, k = n - 1 */
-    uint32_t index;            /* OP_PAT: the pattern's index in the caller's list */
+    uint8_t kind, cls, k, pad; /* OP_CLASS: cls = A | OP_PAIR: k = m - 1 | OP_PAT: cls = B, k = n - 1 | OP_PAT2: cls, pad = the two B */
+    uint32_t index;            /* OP_PAT: the pattern's index in the caller's list; OP_PAT2: two of them, 16 bits each */
 };
+__host__ __device__ inline size_t tile_lds_per_wave(uint32_t n_classes, uint32_t n_pats) { /* qb words | carries | counts */
+    return (size_t)n_classes * 512 + (size_t)(n_pats / 64 + 2) * 8 + ((((size_t)n_pats + 1) * 4 + 15) & ~(size_t)15);
+}
+__device__ __forceinline__ unsigned long long rfl64u(unsigned long long v) {
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 
 struct TileArgs {
     const TileOp *ops;
@@ -385,10 +392,12 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
     const uint32_t lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
     const uint32_t share = blockIdx.x * (SEQ_THREADS / 64) + wave_in_wg;
     /* per wavefront: qb of every class for the tile's words [n_classes][64], the patterns' counts [n_pats] */
-    const size_t per_wave = (size_t)args.n_classes * 512 + (((size_t)args.n_pats * 4 + 15) & ~(size_t)15);
+    const size_t per_wave = tile_lds_per_wave(args.n_classes, args.n_pats);
     uint64_t *qb_lds = (uint64_t *)(tile_lds + wave_in_wg * per_wave);
-    uint32_t *cnt = (uint32_t *)((uint8_t *)qb_lds + (size_t)args.n_classes * 512);
-    for (uint32_t j = lane; j < args.n_pats; j += 64) cnt[j] = 0;
+    unsigned long long *carry_lds = (unsigned long long *)((uint8_t *)qb_lds + (size_t)args.n_classes * 512); /* [n_pats / 64 + 1] */
+    uint32_t *cnt = (uint32_t *)(carry_lds + (args.n_pats / 64 + 2));
+    for (uint32_t j = lane; j < args.n_pats + 1; j += 64) cnt[j] = 0;
+    for (uint32_t j = lane; j < args.n_pats / 64 + 2; j += 64) carry_lds[j] = 0;
     if (share >= args.n_shares) return;
 
     /* the share: the blocks that START inside [lo_b, hi_b) (no state enters a share) */
@@ -401,7 +410,6 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
     const uint64_t n_words_total = (args.total + 63) >> 6;
     const uint32_t below = ((lane + 63u) & 63u) << 2; /* ds_bpermute address of the lane below */
 
-    uint32_t cvec = 0; /* carries between tiles: pattern j's in bit j >> 6 of lane j & 63 */
     for (uint64_t wb = w0; wb <= w1; wb += TILE_WORDS) {
         /* this lane's word: wb + lane - 1 (lane 0 = the word before the tile) */
         const uint64_t w = wb + lane - 1;
@@ -433,17 +441,64 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
 
         Runs ra;
         W2 a = {0, 0}, pa = {0, 0}, g = {0, 0}, pg = {0, 0};
-        uint32_t pj = 0;          /* patterns done in this tile (their order in the program) */
-        uint32_t packed = 0;      /* the count of an even pattern, waiting for the odd one to share a reduction */
+        uint32_t pj = 0; /* patterns done in this tile (their order in the program) */
+        /* the carries the patterns bring along from the tile before: 64 patterns' worth in a scalar register pair, the rest in LDS */
+        unsigned long long cb = rfl64u(carry_lds[0]);
+        /* one pattern with n = 1 on this lane's word: s = qb + x word for word, the carry BETWEEN the words of the tile by
+         * carry-lookahead on the wavefront; -> the match ends of the word (masked to what this share reports) */
+        auto core = [&](W2 qb, W2 x, uint32_t bit, uint32_t &y_lo, uint32_t &y_hi) {
+            uint32_t s_lo, s_hi, and_s;
+            unsigned long long c_lo, gmask, pmask;
+            asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s_lo), "=s"(c_lo) : "v"(qb.lo), "v"(x.lo));
+            asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s_hi), "=s"(gmask) : "v"(qb.hi), "v"(x.hi), "s"(c_lo));
+            and_s = s_lo & s_hi;
+            asm("v_cmp_eq_u32_e64 %0, -1, %1" : "=s"(pmask) : "v"(and_s));
+            /* lane 0 stands for everything below the tile: it generates exactly the carry the pattern brought along */
+            gmask = (gmask & ~1ull) | ((cb >> bit) & 1ull);
+            pmask &= ~1ull;
+            const unsigned long long A = pmask | gmask, S = A + gmask, cin = S ^ pmask; /* ((P|G) + G) ^ (P|G) ^ G: the carry INTO every lane */
+            const unsigned long long cout = ((A & gmask) | ((A | gmask) & ~S)) >> 63;   /* ... and out of lane 63 (majority: scalar) */
+            cb = (cb & ~(1ull << bit)) | (cout << bit);
+            uint32_t t_lo, t_hi;
+            unsigned long long c2, c3;
+            asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_lo), "=s"(c2) : "v"(s_lo), "s"(cin));
+            asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_hi), "=s"(c3) : "v"(s_hi), "s"(c2));
+            /* Y = x | (qb & ~t): the run of B above x up to where the add's carry died */
+            y_lo = ((t_lo & x.lo) | (~t_lo & qb.lo)) & vmask.lo, y_hi = ((t_hi & x.hi) | (~t_hi & qb.hi)) & vmask.hi;
+        };
+        auto emit = [&](uint32_t y_lo, uint32_t y_hi, uint32_t index) { /* (rare: a caller asked for the records of a byte range) */
+            uint64_t y = (uint64_t)y_hi << 32 | y_lo;
+            while (y) {
+                const uint32_t j = __builtin_ctzll(y);
+                y &= y - 1;
+                const uint64_t pos = base + j;
+                if (pos < args.emit_lo || pos >= args.emit_hi) continue;
+                const unsigned long long at = atomicAdd(args.count, 1ull);
+                if (at >= args.cap) continue;
+                const uint64_t blk = lower_bound_off(args.off, args.nblocks, pos + 1) - 1;
+                hsgpu_match_t rec;
+                rec.block = (uint32_t)blk;
+                rec.end = (uint32_t)(pos - args.off[blk]);
+                rec.id = args.seqs[index].id;
+                rec.lit = index;
+                args.out[at] = rec;
+            }
+        };
+        auto next_group = [&]() { /* 64 patterns done: their carries to LDS, the next 64 patterns' from there */
+            if ((pj & 63) == 0) {
+                if (lane == 0) carry_lds[(pj >> 6) - 1] = cb;
+                cb = rfl64u(carry_lds[pj >> 6]);
+            }
+        };
         /* the program is read one operation ahead (a scalar load and its wait at the head of every iteration were most of an
-         * iteration's time), and so is the next pattern's qb from LDS */
+         * iteration's time), and so are the next operation's qb words from LDS */
         TileOp nxt_op = args.ops[0];
-        W2 qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]);
+        W2 qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]), qb2_nxt = w2(qb_lds[nxt_op.pad * 64 + lane]);
         for (uint32_t o = 0; o < args.n_ops; o++) {
             const TileOp op = nxt_op;
-            const W2 qb_cur = qb_nxt;
+            const W2 qb = qb_nxt, qb2 = qb2_nxt;
             nxt_op = args.ops[min(o + 1, args.n_ops - 1)];
-            qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]);
+            qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]), qb2_nxt = w2(qb_lds[nxt_op.pad * 64 + lane]);
             if (op.kind == OP_CLASS) {
                 a = w2(load(op.cls));
                 pa = from_below(a, below);
@@ -452,84 +507,54 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
                 const W2 r = shl2u(a, pa, op.k) & run_of_u(ra, op.k); /* R_m: m members of A end here, inside one block */
                 g = shl2u(r, from_below(r, below), 1) & nst;          /* G: a match of A{m,} may end right before this byte */
                 pg = from_below(g, below);
+            } else if (op.kind == OP_PAT2) {
+                /* two patterns of the pair with n = 1 (g has no block starts: g & b = g & qb), their two carry chains side by
+                 * side in one instruction stream, their counts in one reduction */
+                uint32_t y0l, y0h, y1l, y1h;
+                core(qb, g & qb, pj & 63, y0l, y0h);
+                core(qb2, g & qb2, (pj + 1) & 63, y1l, y1h);
+                const uint32_t pc0 = __builtin_popcount(y0l) + __builtin_popcount(y0h), pc1 = __builtin_popcount(y1l) + __builtin_popcount(y1h);
+                const uint32_t tot = wave_sum_to_63(pc0 | pc1 << 16); /* (no field can overflow: 63 words x 64 bits) */
+                if (lane == 63) { /* (ds_add without return: nothing waits for LDS here) */
+                    __hip_atomic_fetch_add(&cnt[pj], tot & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(&cnt[pj + 1], tot >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+                if (emit_tile) emit(y0l, y0h, op.index & 0xffffu), emit(y1l, y1h, op.index >> 16);
+                pj += 2; /* (the host pairs patterns at even positions: both in one group of 64) */
+                next_group();
             } else {
-                const W2 qb = qb_cur;
                 W2 x;
                 if (op.k == 0) {
-                    x = g & qb; /* (g has no block starts: g & b = g & qb) */
+                    x = g & qb;
                 } else { /* the mandatory B{n}: n members of B end here, the first of them anywhere in the block */
                     Runs rb;
                     make_runs(rb, qb, below);
                     const W2 b = w2(load(op.cls));
                     x = shl2u(g, pg, op.k) & shl2u(b, from_below(b, below), op.k) & run_of_u(rb, op.k);
                 }
-                /* s = qb + x, every word for itself: the carry-out mask is "generate", s == all ones is "propagate" */
-                uint32_t s_lo, s_hi, and_s;
-                unsigned long long c_lo, gmask, pmask;
-                asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s_lo), "=s"(c_lo) : "v"(qb.lo), "v"(x.lo));
-                asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s_hi), "=s"(gmask) : "v"(qb.hi), "v"(x.hi), "s"(c_lo));
-                and_s = s_lo & s_hi;
-                asm("v_cmp_eq_u32_e64 %0, -1, %1" : "=s"(pmask) : "v"(and_s));
-                /* lane 0 stands for everything below the tile: it generates exactly the carry the pattern brought along */
-                const uint32_t cword = (uint32_t)__builtin_amdgcn_readlane((int)cvec, (int)(pj & 63));
-                const unsigned long long c0 = (cword >> (pj >> 6)) & 1u;
-                gmask = (gmask & ~1ull) | c0;
-                pmask &= ~1ull;
-                const unsigned long long A = pmask | gmask, S = A + gmask, cin = S ^ pmask; /* ((P|G) + G) ^ (P|G) ^ G: the carry INTO every lane */
-                const uint32_t cout = (uint32_t)(((A & gmask) | ((A | gmask) & ~S)) >> 63); /* ... and out of lane 63 (majority: scalar) */
-                {
-                    const uint32_t nw_ = (cword & ~(1u << (pj >> 6))) | (cout << (pj >> 6)), at_ = pj & 63;
-                    cvec = lane == at_ ? nw_ : cvec; /* (v_writelane takes one scalar operand besides m0: a compare and a select instead) */
-                }
-                uint32_t t_lo, t_hi;
-                unsigned long long c2, c3;
-                asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_lo), "=s"(c2) : "v"(s_lo), "s"(cin));
-                asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_hi), "=s"(c3) : "v"(s_hi), "s"(c2));
-                /* Y = x | (qb & ~t): the run of B above x up to where the add's carry died */
-                const uint32_t y_lo = ((t_lo & x.lo) | (~t_lo & qb.lo)) & vmask.lo, y_hi = ((t_hi & x.hi) | (~t_hi & qb.hi)) & vmask.hi;
-                const uint32_t pc = __builtin_popcount(y_lo) + __builtin_popcount(y_hi);
-                if (pj & 1) { /* two patterns per reduction: no field can overflow (63 words x 64 bits) */
-                    const uint32_t tot = wave_sum_to_63(packed | pc << 16);
-                    if (lane == 63) { /* (ds_add without return: nothing waits for LDS here) */
-                        __hip_atomic_fetch_add(&cnt[pj - 1], tot & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        __hip_atomic_fetch_add(&cnt[pj], tot >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    }
-                } else {
-                    packed = pc;
-                }
-                if (emit_tile) { /* (uniform, and rare: a caller asked for the records of a byte range) */
-                    uint64_t y = (uint64_t)y_hi << 32 | y_lo;
-                    while (y) {
-                        const uint32_t j = __builtin_ctzll(y);
-                        y &= y - 1;
-                        const uint64_t pos = base + j;
-                        if (pos < args.emit_lo || pos >= args.emit_hi) continue;
-                        const unsigned long long at = atomicAdd(args.count, 1ull);
-                        if (at >= args.cap) continue;
-                        const uint64_t blk = lower_bound_off(args.off, args.nblocks, pos + 1) - 1;
-                        hsgpu_match_t rec;
-                        rec.block = (uint32_t)blk;
-                        rec.end = (uint32_t)(pos - args.off[blk]);
-                        rec.id = args.seqs[op.index].id;
-                        rec.lit = op.index;
-                        args.out[at] = rec;
-                    }
-                }
+                uint32_t y_lo, y_hi;
+                core(qb, x, pj & 63, y_lo, y_hi);
+                const uint32_t tot = wave_sum_to_63(__builtin_popcount(y_lo) + __builtin_popcount(y_hi));
+                if (lane == 63) __hip_atomic_fetch_add(&cnt[pj], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (emit_tile) emit(y_lo, y_hi, op.index);
                 pj++;
+                next_group();
             }
         }
-        if (pj & 1) { /* an odd number of patterns: the last one reduces alone */
-            const uint32_t tot = wave_sum_to_63(packed);
-            if (lane == 63) __hip_atomic_fetch_add(&cnt[pj - 1], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
+        if ((pj & 63) && lane == 0) carry_lds[pj >> 6] = cb;
     }
     /* the share's counts: the program's pattern order back to the caller's */
     uint32_t pj = 0;
     for (uint32_t o = 0; o < args.n_ops; o++) {
         const TileOp op = args.ops[o];
-        if (op.kind != OP_PAT) continue;
-        if (lane == 63 && cnt[pj]) atomicAdd(&args.counts[op.index], (unsigned long long)cnt[pj]);
-        pj++;
+        if (op.kind == OP_PAT2) {
+            if (lane == 63 && cnt[pj]) atomicAdd(&args.counts[op.index & 0xffffu], (unsigned long long)cnt[pj]);
+            if (lane == 63 && cnt[pj + 1]) atomicAdd(&args.counts[op.index >> 16], (unsigned long long)cnt[pj + 1]);
+            pj += 2;
+        } else if (op.kind == OP_PAT) {
+            if (lane == 63 && cnt[pj]) atomicAdd(&args.counts[op.index], (unsigned long long)cnt[pj]);
+            pj++;
+        }
     }
 }
 
@@ -594,12 +619,24 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
             return x < y;
         });
         std::vector<TileOp> ops;
+        unsigned n_pat_done = 0;
         for (unsigned k = 0; k < n_seqs; k++) {
             const hsgpu_class_seq_t &p = seqs[order[k]];
             const bool new_a = k == 0 || seqs[order[k - 1]].a != p.a;
             if (new_a) ops.push_back(TileOp{OP_CLASS, p.a, 0, 0, 0});
             if (new_a || seqs[order[k - 1]].m != p.m) ops.push_back(TileOp{OP_PAIR, p.a, (uint8_t)(p.m - 1), 0, 0});
-            ops.push_back(TileOp{OP_PAT, p.b, (uint8_t)(p.n - 1), 0, order[k]});
+            /* two patterns of the same (A, m) with n = 1 become one operation -- at an even position of the program, so that
+             * both carries sit in the same group of 64 */
+            const bool pairable = p.n == 1 && k + 1 < n_seqs && seqs[order[k + 1]].a == p.a && seqs[order[k + 1]].m == p.m &&
+                                  seqs[order[k + 1]].n == 1 && (n_pat_done & 1) == 0;
+            if (pairable) {
+                ops.push_back(TileOp{OP_PAT2, p.b, 0, seqs[order[k + 1]].b, order[k] | order[k + 1] << 16});
+                n_pat_done += 2;
+                k++;
+            } else {
+                ops.push_back(TileOp{OP_PAT, p.b, (uint8_t)(p.n - 1), 0, order[k]});
+                n_pat_done += 1;
+            }
         }
         n_ops = (uint32_t)ops.size();
         hdr.resize(tab_ofs + ops.size() * sizeof(TileOp));
@@ -660,8 +697,7 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
         t.counts = (unsigned long long *)d_counts;
         t.count = (unsigned long long *)d_count;
         t.out = (hsgpu_match_t *)d_out;
-        const size_t per_wave = (size_t)n_classes * 512 + (((size_t)n_seqs * 4 + 15) & ~(size_t)15);
-        const size_t lds = per_wave * (SEQ_THREADS / 64);
+        const size_t lds = tile_lds_per_wave(n_classes, n_seqs) * (SEQ_THREADS / 64);
         static std::mutex mu2;
         static size_t lds_set = 0;
         {
