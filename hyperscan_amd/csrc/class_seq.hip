@@ -686,17 +686,6 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
         t.off = (const uint64_t *)d_off;
         t.nblocks = nblocks;
         t.total = total_bytes;
-        /* a wavefront per share of whole blocks, every pattern: ~8 K shares, at least 16 KiB (four tiles) each */
-        uint64_t share = std::max<uint64_t>(16384, (total_bytes + 8191) / 8192);
-        share = (share + 63) & ~63ull;
-        t.share_bytes = share;
-        t.n_shares = (uint32_t)((total_bytes + share - 1) / share);
-        t.emit_lo = emit_lo;
-        t.emit_hi = std::min(emit_hi, total_bytes);
-        t.cap = cap;
-        t.counts = (unsigned long long *)d_counts;
-        t.count = (unsigned long long *)d_count;
-        t.out = (hsgpu_match_t *)d_out;
         const size_t lds = tile_lds_per_wave(n_classes, n_seqs) * (SEQ_THREADS / 64);
         static std::mutex mu2;
         static size_t lds_set = 0;
@@ -707,6 +696,27 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
                 lds_set = lds;
             }
         }
+        /* a wavefront per share of whole blocks, every pattern. As many shares as the device holds wavefronts of this kernel at
+         * once, times two (8 192 shares on 5 120 slots were 1.6 rounds: the second one 60 % full), at least 16 KiB (four tiles) each */
+        int dev = 0, n_cu = 256, per_cu = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)class_seq_tile_kernel, SEQ_THREADS, lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 4;
+        }
+        const uint64_t slots = (uint64_t)n_cu * per_cu * (SEQ_THREADS / 64) * 2;
+        uint64_t share = std::max<uint64_t>(16384, (total_bytes + slots - 1) / slots);
+        share = (share + 63) & ~63ull;
+        t.share_bytes = share;
+        t.n_shares = (uint32_t)((total_bytes + share - 1) / share);
+        t.emit_lo = emit_lo;
+        t.emit_hi = std::min(emit_hi, total_bytes);
+        t.cap = cap;
+        t.counts = (unsigned long long *)d_counts;
+        t.count = (unsigned long long *)d_count;
+        t.out = (hsgpu_match_t *)d_out;
         hipLaunchKernelGGL(class_seq_tile_kernel, dim3((t.n_shares + SEQ_THREADS / 64 - 1) / (SEQ_THREADS / 64)), dim3(SEQ_THREADS), lds, st, t);
         HIP_TRY(hipGetLastError());
         return HSGPU_SUCCESS;

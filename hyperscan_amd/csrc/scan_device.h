@@ -147,6 +147,10 @@ struct Tables {
     WaveLds *wl;       /* this wavefront's LDS area */
     uint4 *rec_region; /* this wavefront's private region of the staged-record buffer */
     uint32_t rec_cap;  /* its capacity in records */
+    /* pair tables: the first corpus byte of the share being confirmed. A literal keyed one byte LATE is found at the lookup
+     * position behind its end; at a share's first position that end lies in the share before -- whose records have been (or
+     * are being) ordered without it. The share that owns the end looks for it instead (pair_edge_probe). */
+    uint64_t share_start;
 };
 
 /* the 8 bytes ending at g, little-endian, bytes before the corpus read as 0
@@ -363,8 +367,18 @@ __device__ __forceinline__ void confirm_pos_pair(const Tables &t, uint64_t wm, u
     if (HAS_B) {
         const uint32_t kb = w4 >> 8, km = (((uint32_t)(wm >> 32) & t.key_mask) >> 8) | HSGPU_KEY_M;
         if (gate_hit(t, kb)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, kb, w0, w1, g);
-        if (g && gate_hit(t, km)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, km, wm, 0, g - 1);
+        if (g && g != t.share_start && gate_hit(t, km)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, km, wm, 0, g - 1);
     }
+}
+
+/* One lane, pair tables: the late-keyed literals that end at g - 1, the last byte of a share -- asked for by that share, since
+ * the lookup position g that would find them is the NEXT share's first (see Tables::share_start). The exact tables are the
+ * authority: no filter bit is needed. */
+template <bool DEFER>
+__device__ __forceinline__ void pair_edge_probe(const Tables &t, uint64_t g) {
+    const uint64_t wm = window8(t.corpus, g - 1);
+    const uint32_t km = (((uint32_t)(wm >> 32) & t.key_mask) >> 8) | HSGPU_KEY_M;
+    if (gate_hit(t, km)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, km, wm, 0, g - 1);
 }
 
 /* fused kernel: {chunk, masks} entry, windows re-read from the corpus (L2 hits) */
@@ -523,7 +537,7 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
         if (HAS_C && ref_c[u] && !fast_c[u]) walk_ref<true>(t, ref_c[u], w0[u], w1[u], g[u]);
         if (PAIR && HAS_B && cnd[u]) { /* rare: a few percent of the candidates have a 3-byte key with their hash */
             if ((gb[u] >> (hsgpu_gate_bit(kb[u]) & 31)) & 1u) probe<true>(t, t.ht_b, t.ht_b_log2, kb[u], w0[u], w1[u], g[u]);
-            if (g[u] && ((gm[u] >> (hsgpu_gate_bit(km[u]) & 31)) & 1u))
+            if (g[u] && g[u] != t.share_start && ((gm[u] >> (hsgpu_gate_bit(km[u]) & 31)) & 1u))
                 probe<true>(t, t.ht_b, t.ht_b_log2, km[u], wm[u], 0, g[u] - 1);
         }
     }
@@ -1033,6 +1047,7 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.wl = nullptr;
     t.rec_region = nullptr;
     t.rec_cap = 0;
+    t.share_start = 0;
 }
 
 __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t lane) {
@@ -1268,6 +1283,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     sp.overflow = 0;
     if (FUSED) {
         init_tables(t, args);
+        t.share_start = tile0 << 10;
         init_wave_lds(t, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)) + wave, lane);
         t.rec_region = args.rec_stage + (uint64_t)wave_global * args.rec_cap;
         t.rec_cap = args.rec_cap;
@@ -1386,6 +1402,8 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
 
     if (FUSED) {
         if (lane < qcount) drain_entry<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, t.wl->cand[lane]);
+        /* pair tables: the late-keyed literals ending at this share's last byte (the next share's first lookup would find them) */
+        if (PAIR && HAS_B && lane == 0 && n_own && tile0 + n_own < n_full) pair_edge_probe<false>(t, (tile0 + n_own) << 10);
         publish_records(t, args, lane, wave_global);
     } else if (lane == 0) {
         args.cand_counts[wave_global] = sp.written;
@@ -1888,8 +1906,16 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
 #endif
         init_wave_lds(t, &wave_lds[wave], lane);
         uint32_t fill = 0;
-        if (base < end) { /* else nothing for this wavefront: its record counts stay zero */
+        uint64_t edge = 0; /* pair tables, the share's last wavefront: the next share's first byte, when that share exists */
+        if (PAIR && HAS_B) {
+            const uint64_t n_full = args.total >> 10, per = (n_full + n_shares - 1) / n_shares;
+            t.share_start = min(n_full, (uint64_t)r * per) << 10;
+            const uint64_t next = min(n_full, ((uint64_t)r + 1) * per);
+            if (wave == W - 1 && next < n_full && next > (t.share_start >> 10)) edge = next << 10;
+        }
+        if (base < end || edge) { /* else nothing for this wavefront: its record counts stay zero */
             t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
+            if (PAIR && HAS_B && edge && lane == 0) pair_edge_probe<true>(t, edge); /* (queued: ordered and resolved with the rest) */
             const uint4 *region = args.cand + 2ull * r * args.cand_cap;
             /* (+16: the window of a chunk's last position is read as three dwords from entry byte 24; runtime.hip allocates the slack) */
             if (FAST) rs.region = __builtin_amdgcn_make_buffer_rsrc((void *)region, 0, (int)min((uint64_t)args.cand_cap * 32u + 16u, (uint64_t)0x7ffffff0), 0x00020000);

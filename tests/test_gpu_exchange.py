@@ -59,8 +59,15 @@ def test_bench_multi_gpu_path_at_world_size_1():
     line = json.loads(rows[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
     assert line["config"]["pipeline_depth"] == 2 and "RCCL" in line["config"]["sharding"]
-    ex = line["exchange"]
-    assert ex["rows_per_rank"] >= line["matches_per_step"] and ex["gather_ms_avg_rank0"] > 0
+    ex = line["exchange"]  # (default: the C ABI's exchange, hsgpu_exchange_step, records to rank 0)
+    assert "hsgpu_exchange_step" in ex["collective"] and ex["gather_ms_avg_rank0"] > 0 and ex["wire_bytes_received_rank0"] == 0
+    # and the torch.distributed form it falls back to
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--gib", "0.0625", "--steps", "4", "--warmup", "2",
+                        "--no-cpu", "--no-also", "--exchange", "padded"], cwd=root, env=dict(env, MASTER_PORT=str(_free_port())),
+                       capture_output=True, text=True, timeout=450)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["exchange"]["rows_per_rank"] >= line["matches_per_step"] and line["exchange"]["gather_ms_avg_rank0"] > 0
 
 
 @pytest.mark.timeout(500)
