@@ -334,6 +334,7 @@ __device__ __forceinline__ unsigned long long rfl64u(unsigned long long v) {
 struct TileArgs {
     const TileOp *ops;
     uint32_t n_ops, n_pats, n_classes, n_shares;
+    uint32_t only_emit; /* hsgpu_class_seq_emit_dev: only the shares whose blocks can end in [emit_lo, emit_hi) are walked (no counts) */
     const hsgpu_class_seq_t *seqs;
     const uint64_t *const *bitmaps; /* 8-byte aligned */
     const uint64_t *starts;
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
 
     /* the share: the blocks that START inside [lo_b, hi_b) (no state enters a share) */
     const uint64_t lo_b = (uint64_t)share * args.share_bytes, hi_b = min(args.total, lo_b + args.share_bytes);
+    /* (an emit range is made of whole blocks: the blocks that START in it, i.e. in the shares it touches) */
+    if (args.only_emit && (hi_b <= args.emit_lo || lo_b >= args.emit_hi)) return;
     const uint64_t b_lo = lower_bound_off(args.off, args.nblocks, lo_b), b_hi = lower_bound_off(args.off, args.nblocks, hi_b);
     if (b_lo >= b_hi || b_lo >= args.nblocks) return;
     const uint64_t s0 = args.off[b_lo], s1 = args.off[min(b_hi, args.nblocks)];
@@ -544,6 +547,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
         if ((pj & 63) && lane == 0) carry_lds[pj >> 6] = cb;
     }
     /* the share's counts: the program's pattern order back to the caller's */
+    if (!args.counts) return;
     uint32_t pj = 0;
     for (uint32_t o = 0; o < args.n_ops; o++) {
         const TileOp op = args.ops[o];
@@ -562,11 +566,32 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
 
 extern "C" size_t hsgpu_class_seq_work_bytes(uint64_t total_bytes) { return SEQ_HEADER + ((total_bytes + 63) / 64) * 8 + 8; }
 
+static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const void *const *d_bitmaps, unsigned n_classes,
+                          uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t emit_lo, uint64_t emit_hi, void *d_counts,
+                          void *d_out, uint64_t cap, void *d_count, void *d_work, size_t work_bytes, void *stream, bool only_emit);
+
 extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const void *const *d_bitmaps,
                                         unsigned n_classes, uint64_t total_bytes, const void *d_off, uint64_t nblocks,
                                         uint64_t emit_lo, uint64_t emit_hi, void *d_counts, void *d_out, uint64_t cap,
                                         void *d_count, void *d_work, size_t work_bytes, void *stream) {
-    if (!seqs || !n_seqs || !d_bitmaps || !n_classes || !d_off || !d_counts || !d_count || !d_work || (cap && !d_out))
+    if (!d_counts) return HSGPU_INVALID;
+    return class_seq_scan(seqs, n_seqs, d_bitmaps, n_classes, total_bytes, d_off, nblocks, emit_lo, emit_hi, d_counts, d_out, cap, d_count,
+                          d_work, work_bytes, stream, false);
+}
+
+/* the records of a range of whole blocks only: the shares outside it are not walked, nothing is counted */
+extern "C" int hsgpu_class_seq_emit_dev(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const void *const *d_bitmaps,
+                                        unsigned n_classes, uint64_t total_bytes, const void *d_off, uint64_t nblocks,
+                                        uint64_t emit_lo, uint64_t emit_hi, void *d_out, uint64_t cap, void *d_count, void *d_work,
+                                        size_t work_bytes, void *stream) {
+    return class_seq_scan(seqs, n_seqs, d_bitmaps, n_classes, total_bytes, d_off, nblocks, emit_lo, emit_hi, nullptr, d_out, cap, d_count,
+                          d_work, work_bytes, stream, true);
+}
+
+static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const void *const *d_bitmaps, unsigned n_classes,
+                          uint64_t total_bytes, const void *d_off, uint64_t nblocks, uint64_t emit_lo, uint64_t emit_hi, void *d_counts,
+                          void *d_out, uint64_t cap, void *d_count, void *d_work, size_t work_bytes, void *stream, bool only_emit) {
+    if (!seqs || !n_seqs || !d_bitmaps || !n_classes || !d_off || !d_count || !d_work || (cap && !d_out))
         return HSGPU_INVALID;
     if (n_seqs > HSGPU_SEQ_MAX || n_classes > 255) {
         hsgpu_set_error("at most %u class sequences and 255 classes per call", HSGPU_SEQ_MAX);
@@ -587,7 +612,7 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
         any_n |= seqs[i].n > 1;
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)n_seqs * sizeof(unsigned long long), st));
+    if (d_counts) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)n_seqs * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
     if (!total_bytes || !nblocks) return HSGPU_SUCCESS;
     uint8_t *w = (uint8_t *)d_work;
@@ -596,6 +621,10 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
     bool aligned = true;
     for (unsigned c = 0; c < n_classes; c++) aligned = aligned && (((uintptr_t)d_bitmaps[c]) & 7) == 0;
     const bool tiled = aligned && n_classes <= TILE_MAX_CLASSES;
+    if (!tiled && !d_counts) { /* (the lane-per-pattern kernels always count) */
+        hsgpu_set_error("hsgpu_class_seq_emit_dev needs 8-byte aligned bitmaps and at most %u classes", TILE_MAX_CLASSES);
+        return HSGPU_INVALID;
+    }
     /* the header of the work area: patterns | bitmap pointers | the kernel's tables. Built on the host and uploaded on every
      * call (the work area is the caller's: it may have been freed, reused and zeroed since the last call), asynchronously, from
      * a copy kept per work area -- nothing on the stack goes out of scope under the DMA, and the call does not wait for the
@@ -711,6 +740,7 @@ extern "C" int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned 
         share = (share + 63) & ~63ull;
         t.share_bytes = share;
         t.n_shares = (uint32_t)((total_bytes + share - 1) / share);
+        t.only_emit = only_emit ? 1u : 0u;
         t.emit_lo = emit_lo;
         t.emit_hi = std::min(emit_hi, total_bytes);
         t.cap = cap;

@@ -1172,29 +1172,55 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
         cap = n + n / 4; /* n = the exact total */
         if (attempt == 7) return HS_UNKNOWN_ERROR;
     }
-    /* literal-less class sequences: on the GPU from the class bitmaps, over the batch the literal scan left resident
-     * (or uploaded here when the database has no literal at all; a retry for room finds it resident either way) */
-    size_t n_cs = 0;
-    if (!db->cs_seqs.empty()) {
-        try {
-            if (scratch->cs_recs.size() < 4096) scratch->cs_recs.resize(4096);
-            for (int attempt = 0;; attempt++) {
-                const int resident = (db->hwlm != nullptr || attempt > 0) ? 1 : 0;
-                int rv = hsgpu_class_seq_exec_batch(db->cs_classes.data(), (unsigned)db->cs_classes.size(), db->cs_seqs.data(),
-                                                    (unsigned)db->cs_seqs.size(), scratch->gpu, (const uint8_t *)data,
-                                                    (const uint64_t *)off, (size_t)nblocks, resident, nullptr,
-                                                    scratch->cs_recs.data(), scratch->cs_recs.size(), &n_cs);
-                if (rv == HSGPU_SUCCESS) break;
-                if (rv != HSGPU_INSUFFICIENT_SPACE || attempt == 3) return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
-                scratch->cs_recs.resize(n_cs + n_cs / 8 + 16);
-            }
-        } catch (const std::bad_alloc &) {
-            return HS_NOMEM;
-        }
+    if (db->cs_seqs.empty()) {
+        const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context);
+        if (any_terminated < 0) return HS_NOMEM;
+        return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
     }
-    const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context,
-                                                   n_cs ? scratch->cs_recs.data() : nullptr, n_cs);
-    if (any_terminated < 0) return HS_NOMEM;
+    /* Literal-less class sequences: on the GPU from the class bitmaps, over the batch the literal scan left resident (or
+     * uploaded here when the database has no literal at all). Such patterns match about once per byte ("[a-z]{3,}\d+",
+     * "\w+\w+"): the records of a whole batch are K x 16 bytes per corpus byte, so the batch is delivered in RANGES of whole
+     * blocks through a record buffer of bounded size -- the bitmaps are computed once, every range is one launch over its own
+     * part of the corpus, its events (merged with the literal path's of the same blocks, in delivery order) go out before the
+     * next range is asked for. A range that does not fit is halved. (Round 3 materialised the whole batch: advisor.) */
+    int any_terminated = 0;
+    try {
+        const size_t room = (size_t)1 << 20; /* records per range: 16 MiB of host buffer */
+        if (scratch->cs_recs.size() < room) scratch->cs_recs.resize(room);
+        const hsgpu_match_t *lit = scratch->recs;
+        size_t li = 0; /* literal records delivered so far (they are sorted by block) */
+        unsigned long long span = std::max<unsigned long long>(1, nblocks / 64); /* blocks per range: adapts to what fits */
+        int resident = db->hwlm != nullptr ? 1 : 0, have_bitmaps = 0;
+        for (unsigned long long b0 = 0; b0 < nblocks;) {
+            const unsigned long long b1 = std::min<unsigned long long>(nblocks, b0 + span);
+            size_t n_cs = 0;
+            const int rv = hsgpu_class_seq_exec_blocks(db->cs_classes.data(), (unsigned)db->cs_classes.size(), db->cs_seqs.data(),
+                                                       (unsigned)db->cs_seqs.size(), scratch->gpu, (const uint8_t *)data, (const uint64_t *)off,
+                                                       (size_t)nblocks, resident, have_bitmaps, (size_t)b0, (size_t)b1,
+                                                       scratch->cs_recs.data(), scratch->cs_recs.size(), &n_cs);
+            if (rv == HSGPU_INSUFFICIENT_SPACE) {
+                resident = have_bitmaps = 1; /* (the batch and its bitmaps are on the device now whatever else happened) */
+                if (b1 - b0 > 1) {
+                    span = (b1 - b0) / 2;
+                    continue;
+                }
+                scratch->cs_recs.resize(n_cs + n_cs / 8 + 16); /* one block alone holds more: it gets the room it needs */
+                continue;
+            }
+            if (rv != HSGPU_SUCCESS) return rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
+            resident = have_bitmaps = 1;
+            size_t lj = li;
+            while (lj < n && lit[lj].block < b1) lj++;
+            const int t = confirm_and_deliver(db, data, off, lit + li, lj - li, onEvent, context, n_cs ? scratch->cs_recs.data() : nullptr, n_cs);
+            if (t < 0) return HS_NOMEM;
+            any_terminated |= t;
+            li = lj;
+            b0 = b1;
+            if (n_cs * 4 < scratch->cs_recs.size() && span < nblocks) span *= 2; /* plenty of room: larger ranges */
+        }
+    } catch (const std::bad_alloc &) {
+        return HS_NOMEM;
+    }
     return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
 }
 

@@ -825,8 +825,8 @@ extern "C" int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned
     if ((rv = s->cs_counts.ensure((size_t)n_seqs * sizeof(uint64_t))) != HSGPU_SUCCESS) return rv;
     std::vector<void *> ptrs(n_classes);
     for (unsigned c = 0; c < n_classes; c++) ptrs[c] = (uint8_t *)s->cs_bitmaps.p + row * c;
-    for (unsigned c = 0; c < n_classes; c += HSGPU_CLASS_MAX) {
-        const unsigned k = std::min<unsigned>(HSGPU_CLASS_MAX, n_classes - c);
+    for (unsigned c = 0; c < n_classes; c += HSGPU_CLASS_MAX_BITMAPS) { /* bitmaps alone: 16 classes per read of the corpus */
+        const unsigned k = std::min<unsigned>(HSGPU_CLASS_MAX_BITMAPS, n_classes - c);
         rv = hsgpu_class_scan_dev(classes + c, k, s->corpus.p, total, s->off.p, nblocks, ptrs.data() + c, nullptr, nullptr,
                                   s->cs_work.p, s->stream);
         if (rv != HSGPU_SUCCESS) return rv;
@@ -852,6 +852,53 @@ extern "C" int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned
         dcap = n;
     }
     return HSGPU_UNKNOWN_ERROR;
+}
+
+/* The same for the blocks [block_lo, block_hi) only (include/hsgpu.h): a batch whose patterns match several times per byte holds
+ * more records than any buffer -- 256 class-heavy patterns over 1 GiB are 16 bytes x 800 M -- and the reference delivers such
+ * matches through callbacks in O(1) memory; the facade walks the batch range by range through this (advisor, round 3). */
+extern "C" int hsgpu_class_seq_exec_blocks(const hsgpu_class_t *classes, unsigned n_classes, const hsgpu_class_seq_t *seqs,
+                                           unsigned n_seqs, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off, size_t nblocks,
+                                           int reuse_resident, int reuse_bitmaps, size_t block_lo, size_t block_hi, hsgpu_match_t *out,
+                                           size_t cap, size_t *nout) {
+    if (!classes || !n_classes || !seqs || !n_seqs || !s || !off || !nout || (cap && !out) || block_lo > block_hi || block_hi > nblocks)
+        return HSGPU_INVALID;
+    *nout = 0;
+    if (block_lo == block_hi) return HSGPU_SUCCESS;
+    const uint64_t total = off[nblocks] - off[0];
+    if (total == 0) return HSGPU_SUCCESS;
+    if (!base && !reuse_resident) return HSGPU_INVALID;
+    InUse guard(s);
+    if (!guard.ok) return HSGPU_SCRATCH_IN_USE;
+    int rv;
+    if (!reuse_resident && (rv = upload_batch(s, base, off, nblocks)) != HSGPU_SUCCESS) return rv;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t row = ((total + 15) / 16 * 2 + 15) & ~(size_t)15;
+    const size_t seq_work = hsgpu_class_seq_work_bytes(total);
+    if (reuse_bitmaps && (s->cs_bitmaps.cap < row * n_classes || s->cs_work.cap < HSGPU_CLASS_WORK_BYTES + 64 + seq_work)) return HSGPU_INVALID;
+    if ((rv = s->cs_bitmaps.ensure(row * n_classes)) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->cs_work.ensure(HSGPU_CLASS_WORK_BYTES + 64 + seq_work)) != HSGPU_SUCCESS) return rv;
+    std::vector<void *> ptrs(n_classes);
+    for (unsigned c = 0; c < n_classes; c++) ptrs[c] = (uint8_t *)s->cs_bitmaps.p + row * c;
+    for (unsigned c = 0; !reuse_bitmaps && c < n_classes; c += HSGPU_CLASS_MAX_BITMAPS) {
+        const unsigned k = std::min<unsigned>(HSGPU_CLASS_MAX_BITMAPS, n_classes - c);
+        rv = hsgpu_class_scan_dev(classes + c, k, s->corpus.p, total, s->off.p, nblocks, ptrs.data() + c, nullptr, nullptr,
+                                  s->cs_work.p, s->stream);
+        if (rv != HSGPU_SUCCESS) return rv;
+    }
+    void *work2 = (uint8_t *)s->cs_work.p + ((HSGPU_CLASS_WORK_BYTES + 63) & ~(size_t)63);
+    if ((rv = s->out.ensure(std::max<size_t>(cap, 4096) * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return rv;
+    rv = hsgpu_class_seq_emit_dev(seqs, n_seqs, ptrs.data(), n_classes, total, s->off.p, nblocks, off[block_lo] - off[0], off[block_hi] - off[0],
+                                  s->out.p, cap, s->count.p, work2, seq_work, s->stream);
+    if (rv != HSGPU_SUCCESS) return rv;
+    HIP_TRY(hipMemcpyAsync(s->h_count, s->count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const uint64_t n = *s->h_count;
+    *nout = (size_t)n;
+    if (n > cap) return HSGPU_INSUFFICIENT_SPACE;
+    if (n) HIP_TRY(hipMemcpy(out, s->out.p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost));
+    hsgpu_match_sort_host(out, n); /* the kernel emits in no particular order */
+    return HSGPU_SUCCESS;
 }
 
 /* ---- the chunked host-buffer pipeline ---------------------------------------------------------

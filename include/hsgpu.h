@@ -309,6 +309,14 @@ int hsgpu_class_seq_scan_dev(const hsgpu_class_seq_t *seqs, unsigned n_seqs, con
                              uint64_t emit_lo, uint64_t emit_hi, void *d_counts, void *d_out, uint64_t cap,
                              void *d_count, void *d_work, size_t work_bytes, void *stream);
 
+/* The records of a byte range made of WHOLE blocks only (emit_lo / emit_hi = offsets of two block starts): the parts of the
+ * corpus that hold no block of the range are not walked and nothing is counted -- what a caller uses that delivers a
+ * match-dense batch range by range through a bounded record buffer. Needs 8-byte aligned bitmaps, at most 32 classes. */
+int hsgpu_class_seq_emit_dev(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const void *const *d_bitmaps,
+                             unsigned n_classes, uint64_t total_bytes, const void *d_off, uint64_t nblocks,
+                             uint64_t emit_lo, uint64_t emit_hi, void *d_out, uint64_t cap, void *d_count, void *d_work,
+                             size_t work_bytes, void *stream);
+
 /* The same for a batch in HOST memory (the sibling of hsgpu_hwlm_exec_batch): class bitmaps in passes of <= 8
  * classes, then the sequence kernel; `out` receives every match of the batch in delivery order (block, end,
  * pattern index), *nout the number there is (HSGPU_INSUFFICIENT_SPACE when more than cap: nothing is written
@@ -318,6 +326,14 @@ int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned n_classes,
                                unsigned n_seqs, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off,
                                size_t nblocks, int reuse_resident, uint64_t *counts, hsgpu_match_t *out, size_t cap,
                                size_t *nout);
+/* ... for the blocks [block_lo, block_hi) of the batch only, in delivery order: a batch whose patterns match several times per
+ * byte is delivered range by range through a buffer of bounded size (HSGPU_INSUFFICIENT_SPACE, *nout = the room needed: ask for
+ * fewer blocks). reuse_resident as above; reuse_bitmaps != 0: the class bitmaps of the previous call on this scratch (same batch,
+ * same classes) are still there and are not computed again. */
+int hsgpu_class_seq_exec_blocks(const hsgpu_class_t *classes, unsigned n_classes, const hsgpu_class_seq_t *seqs,
+                                unsigned n_seqs, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off, size_t nblocks,
+                                int reuse_resident, int reuse_bitmaps, size_t block_lo, size_t block_hi, hsgpu_match_t *out,
+                                size_t cap, size_t *nout);
 
 /* ---- choosing an accelerator for a literal set (host only) ---------------------------
  * buildForwardAccel / findForwardAccelScheme (src/rose/rose_build_lit_accel.cpp:372-465): the

@@ -3,14 +3,14 @@
 # leg) under rocprofv3 (--kernel-trace --stats), then separate PMC passes of the same command: FETCH_SIZE,
 # WRITE_SIZE, and two sets of SQ counters for the filter kernels; summaries are written under
 # gpurun_out/<tag>/ for copying to profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --also teddy64,class256 --class-gib 1"
 # the kernel trace covers every workload of the bench line (class256 at 1 GiB, rose1000 at 0.5 GiB keep it short)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --class-gib 1 --rose-gib 0.5 --also teddy64,class256,rose1000,flood > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --class-gib 1 --rose-gib 0.5 --also teddy64,class256,rose1000,flood,batch_sweep > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc_write.err
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- $CMD > /dev/null 2> $OUT/pmc_sq1.err
