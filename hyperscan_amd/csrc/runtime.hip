@@ -922,16 +922,26 @@ static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *
                           size_t start, const std::vector<size_t> &cuts, std::mutex &mu, std::condition_variable &cv,
                           std::deque<ChunkResult> &queue, std::atomic<bool> &abort) {
     auto fail = [&](int rv) {
-        ChunkResult r;
-        r.rv = rv;
-        r.last = true;
-        {
+        /* a copy from the caller's buffer may still be on its way: the caller is free to release that buffer once the call
+         * has returned, so nothing of it may be in flight by then (advisor, round 3) */
+        (void)hipStreamSynchronize(s->side);
+        (void)hipStreamSynchronize(s->stream);
+        try {
+            ChunkResult r;
+            r.rv = rv;
+            r.last = true;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                queue.push_back(std::move(r));
+            }
+        } catch (...) { /* not even the end marker could be queued: the consumer watches this flag too */
             std::lock_guard<std::mutex> g(mu);
-            queue.push_back(std::move(r));
+            abort = true;
         }
         cv.notify_all();
         return rv;
     };
+    try {
     if (hipSetDevice(s->device) != hipSuccess) return fail(HSGPU_UNKNOWN_ERROR);
     const size_t n_chunks = cuts.size() - 1;
     std::vector<uint64_t> rel[2];
@@ -1007,11 +1017,12 @@ static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *
         cv.notify_all();
     }
     if (abort) { /* the consumer stopped early: let it see an end */
-        (void)hipStreamSynchronize(s->side);
-        (void)hipStreamSynchronize(s->stream);
         return fail(HSGPU_SUCCESS);
     }
     return HSGPU_SUCCESS;
+    } catch (...) { /* std::bad_alloc from a vector on this thread: no exception may leave it (std::terminate) */
+        return fail(HSGPU_NOMEM);
+    }
 }
 
 /* is this host memory page-locked (hipHostMalloc / hipHostRegister)? Asynchronous copies from pageable memory are
@@ -1061,12 +1072,24 @@ extern "C" int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *
         std::deque<ChunkResult> queue;
         std::atomic<bool> abort{false};
         std::thread producer([&] { (void)produce_chunks(t, s, base, off, nblocks, start, cuts, mu, cv, queue, abort); });
+        struct Join { /* whatever happens below (the caller's function may throw): the producer winds down and is joined */
+            std::thread &th;
+            std::atomic<bool> &abort;
+            ~Join() {
+                abort = true;
+                if (th.joinable()) th.join();
+            }
+        } join{producer, abort};
         int rv = HSGPU_SUCCESS, stop = 0;
         for (;;) {
             ChunkResult r;
             {
                 std::unique_lock<std::mutex> g(mu);
-                cv.wait(g, [&] { return !queue.empty(); });
+                cv.wait(g, [&] { return !queue.empty() || (abort && !stop); });
+                if (queue.empty()) { /* the producer failed without being able to say so */
+                    rv = HSGPU_NOMEM;
+                    break;
+                }
                 r = std::move(queue.front());
                 queue.pop_front();
             }
@@ -1078,7 +1101,6 @@ extern "C" int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *
             }
             if (r.last) break;
         }
-        producer.join();
         return rv != HSGPU_SUCCESS ? rv : (stop ? HSGPU_SCAN_TERMINATED : HSGPU_SUCCESS);
     } catch (const std::bad_alloc &) {
         return HSGPU_NOMEM;
