@@ -317,14 +317,16 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_shared_kernel(SeqArgs a
  * ~18 vector instructions per word and pattern + ~10 for the shared side, all shift amounts scalar. (profiles/r04_class_seq*.txt) */
 constexpr uint32_t TILE_WORDS = 63;
 constexpr uint32_t TILE_MAX_CLASSES = 32;
+constexpr uint32_t QB_STRIDE = 65; /* a class' qb words in LDS: [0] = 0 (the halo lane adds nothing to a carry chain), [1..63] the tile's words, [64] the halo's true word */
 
-enum : uint8_t { OP_CLASS = 0, OP_PAIR = 1, OP_PAT = 2, OP_PAT2 = 3 };
-struct TileOp {
-    uint8_t kind, cls, k, pad; /* OP_CLASS: cls = A | OP_PAIR: k = m - 1 | OP_PAT: cls = B, k = n - 1 | OP_PAT2: cls, pad = the two B */
-    uint32_t index;            /* OP_PAT: the pattern's index in the caller's list; OP_PAT2: two of them, 16 bits each */
+enum : uint8_t { OP_CLASS = 0, OP_PAIR = 1, OP_PAT = 2, OP_PAT2 = 3, OP_NOP = 4, OP_COUNT0 = 5 };
+struct TileOp { /* 8 bytes, read with one scalar load */
+    uint8_t kind, k;    /* OP_PAIR: k = m - 1 | OP_PAT: k = n - 1 */
+    uint16_t ofs1, ofs2; /* OP_PAT, OP_PAT2: the byte offsets of the B classes' qb words in the wavefront's LDS (class * QB_STRIDE * 8) */
+    uint16_t cls;        /* OP_CLASS: A | OP_PAT: B */
 };
 __host__ __device__ inline size_t tile_lds_per_wave(uint32_t n_classes, uint32_t n_pats) { /* qb words | carries | counts */
-    return (size_t)n_classes * 512 + (size_t)(n_pats / 64 + 2) * 8 + ((((size_t)n_pats + 1) * 4 + 15) & ~(size_t)15);
+    return (size_t)n_classes * (QB_STRIDE * 8) + (size_t)(n_pats / 64 + 2) * 8 + ((((size_t)n_pats + 2) * 4 + 15) & ~(size_t)15);
 }
 __device__ __forceinline__ unsigned long long rfl64u(unsigned long long v) {
     return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 |
@@ -333,6 +335,7 @@ __device__ __forceinline__ unsigned long long rfl64u(unsigned long long v) {
 
 struct TileArgs {
     const TileOp *ops;
+    const uint16_t *order; /* [n_pats]: the caller's index of the program's j-th pattern */
     uint32_t n_ops, n_pats, n_classes, n_shares;
     uint32_t only_emit; /* hsgpu_class_seq_emit_dev: only the shares whose blocks can end in [emit_lo, emit_hi) are walked (no counts) */
     const hsgpu_class_seq_t *seqs;
@@ -395,9 +398,9 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
     /* per wavefront: qb of every class for the tile's words [n_classes][64], the patterns' counts [n_pats] */
     const size_t per_wave = tile_lds_per_wave(args.n_classes, args.n_pats);
     uint64_t *qb_lds = (uint64_t *)(tile_lds + wave_in_wg * per_wave);
-    unsigned long long *carry_lds = (unsigned long long *)((uint8_t *)qb_lds + (size_t)args.n_classes * 512); /* [n_pats / 64 + 1] */
+    unsigned long long *carry_lds = (unsigned long long *)((uint8_t *)qb_lds + (size_t)args.n_classes * (QB_STRIDE * 8)); /* [n_pats / 64 + 1] */
     uint32_t *cnt = (uint32_t *)(carry_lds + (args.n_pats / 64 + 2));
-    for (uint32_t j = lane; j < args.n_pats + 1; j += 64) cnt[j] = 0;
+    for (uint32_t j = lane; j < args.n_pats + 2; j += 64) cnt[j] = 0;
     for (uint32_t j = lane; j < args.n_pats / 64 + 2; j += 64) carry_lds[j] = 0;
     if (share >= args.n_shares) return;
 
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
     const uint64_t w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
     const uint64_t n_words_total = (args.total + 63) >> 6;
     const uint32_t below = ((lane + 63u) & 63u) << 2; /* ds_bpermute address of the lane below */
+    const uint32_t row_shift = (0x00201030u >> ((lane >> 4) * 8)) & 0xffu; /* rows 0 1 2 3 hold the sums of operations 0 2 1 3 */
 
     for (uint64_t wb = w0; wb <= w1; wb += TILE_WORDS) {
         /* this lane's word: wb + lane - 1 (lane 0 = the word before the tile) */
@@ -437,37 +441,47 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
             if (w == w0) vm &= ~0ull << (s0 & 63);
             if (w == w1) vm &= ~0ull >> (63 - ((s1 - 1) & 63));
         }
-        const W2 vmask = w2(vm);
-        for (uint32_t c = 0; c < args.n_classes; c++) qb_lds[c * 64 + lane] = load(c) & ~st64;
+        /* (the mask goes into the qb words: a match end is a bit of qb, and what lies outside the share starts or ends at a block
+         * start, where runs and carries stop anyway; the halo's true word keeps its bits for the runs that reach into lane 1) */
+        for (uint32_t c = 0; c < args.n_classes; c++) {
+            const uint64_t q = load(c) & ~st64;
+            qb_lds[c * QB_STRIDE + lane] = q & vm;
+            if (!lane) qb_lds[c * QB_STRIDE + 64] = q;
+        }
         const uint64_t base = w * 64;
         const bool emit_tile = wb * 64 < args.emit_hi && (wb + TILE_WORDS) * 64 > args.emit_lo; /* (uniform) */
 
         Runs ra;
-        W2 a = {0, 0}, pa = {0, 0}, g = {0, 0}, pg = {0, 0};
+        W2 a = {0, 0}, pa = {0, 0}, g = {0, 0};
         uint32_t pj = 0; /* patterns done in this tile (their order in the program) */
         /* the carries the patterns bring along from the tile before: 64 patterns' worth in a scalar register pair, the rest in LDS */
         unsigned long long cb = rfl64u(carry_lds[0]);
         /* one pattern with n = 1 on this lane's word: s = qb + x word for word, the carry BETWEEN the words of the tile by
          * carry-lookahead on the wavefront; -> the match ends of the word (masked to what this share reports) */
-        auto core = [&](W2 qb, W2 x, uint32_t bit, uint32_t &y_lo, uint32_t &y_hi) {
+        auto core = [&](W2 qb, W2 x, uint32_t &y_lo, uint32_t &y_hi) {
             uint32_t s_lo, s_hi, and_s;
             unsigned long long c_lo, gmask, pmask;
             asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s_lo), "=s"(c_lo) : "v"(qb.lo), "v"(x.lo));
             asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s_hi), "=s"(gmask) : "v"(qb.hi), "v"(x.hi), "s"(c_lo));
             and_s = s_lo & s_hi;
             asm("v_cmp_eq_u32_e64 %0, -1, %1" : "=s"(pmask) : "v"(and_s));
-            /* lane 0 stands for everything below the tile: it generates exactly the carry the pattern brought along */
-            gmask = (gmask & ~1ull) | ((cb >> bit) & 1ull);
-            pmask &= ~1ull;
-            const unsigned long long A = pmask | gmask, S = A + gmask, cin = S ^ pmask; /* ((P|G) + G) ^ (P|G) ^ G: the carry INTO every lane */
-            const unsigned long long cout = ((A & gmask) | ((A | gmask) & ~S)) >> 63;   /* ... and out of lane 63 (majority: scalar) */
-            cb = (cb & ~(1ull << bit)) | (cout << bit);
+            /* lane 0 stands for everything below the tile: its own word is zero (no generate, no propagate), it generates
+             * exactly the carry the pattern brought along: bit 0 of cb, a shift register of the group's 64 carries */
+            const uint32_t g_lo = (uint32_t)gmask | ((uint32_t)cb & 1u), g_hi = (uint32_t)(gmask >> 32);
+            const uint32_t a_lo = (uint32_t)pmask | g_lo, a_hi = (uint32_t)(pmask >> 32) | g_hi;
+            uint32_t sum_lo, sum_hi, cout31; /* S = (P|G) + G; the carry INTO every lane is S ^ P, the one out of lane 63 the add's own */
+            asm("s_add_u32 %0, %3, %5\n\ts_addc_u32 %1, %4, %6\n\ts_cselect_b32 %2, 0x80000000, 0"
+                : "=&s"(sum_lo), "=&s"(sum_hi), "=s"(cout31)
+                : "s"(a_lo), "s"(a_hi), "s"(g_lo), "s"(g_hi)
+                : "scc");
+            const unsigned long long cin = ((unsigned long long)sum_hi << 32 | sum_lo) ^ pmask;
+            cb = (cb >> 1) | (unsigned long long)cout31 << 32;
             uint32_t t_lo, t_hi;
             unsigned long long c2, c3;
             asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_lo), "=s"(c2) : "v"(s_lo), "s"(cin));
             asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(t_hi), "=s"(c3) : "v"(s_hi), "s"(c2));
             /* Y = x | (qb & ~t): the run of B above x up to where the add's carry died */
-            y_lo = ((t_lo & x.lo) | (~t_lo & qb.lo)) & vmask.lo, y_hi = ((t_hi & x.hi) | (~t_hi & qb.hi)) & vmask.hi;
+            y_lo = (t_lo & x.lo) | (~t_lo & qb.lo), y_hi = (t_hi & x.hi) | (~t_hi & qb.hi);
         };
         auto emit = [&](uint32_t y_lo, uint32_t y_hi, uint32_t index) { /* (rare: a caller asked for the records of a byte range) */
             uint64_t y = (uint64_t)y_hi << 32 | y_lo;
@@ -495,71 +509,99 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
         };
         /* the program is read one operation ahead (a scalar load and its wait at the head of every iteration were most of an
          * iteration's time), and so are the next operation's qb words from LDS */
-        TileOp nxt_op = args.ops[0];
-        W2 qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]), qb2_nxt = w2(qb_lds[nxt_op.pad * 64 + lane]);
+        /* (two OP_NOP behind the program: reading ahead needs no bound; the constant address space: scalar loads) */
+        const __attribute__((address_space(4))) uint64_t *ops = (const __attribute__((address_space(4))) uint64_t *)(uintptr_t)args.ops;
+        const uint8_t *qb_lane = (const uint8_t *)(qb_lds + lane);
+        auto qb_at = [&](uint32_t ofs) { return w2(*(const uint64_t *)(qb_lane + ofs)); };
+        TileOp op1 = __builtin_bit_cast(TileOp, ops[0]);
+        uint64_t raw2 = ops[1];
+        W2 qb_nxt = qb_at(op1.ofs1), qb2_nxt = qb_at(op1.ofs2);
+        /* the counts: a lane's two popcounts are one packed word (16 bits each: 63 words x 64 bits fit); FOUR operations' words
+         * are summed over the wavefront together -- v_permlane32_swap + add folds two words into the halves of one, then
+         * v_permlane16_swap + add folds two of those into the four rows of one, four DPP steps finish the rows, and the last lane
+         * of every row adds its two sums to the counts of ITS operation (the host numbers the counting operations 0 1 2 3 in
+         * k's top bits and pads their number to a multiple of four with OP_COUNT0: nothing is pending at the end of a tile).
+         * One reduction per operation was 6 DPP steps, each waiting on the one before: a third of the loop's issue slots. */
+        uint32_t stash = 0, x1 = 0;
+        unsigned long long slots = 0; /* the four operations' first count slots, 16 bits each, the oldest on top */
+        auto account = [&](uint32_t v, uint32_t slot, uint32_t q) {
+            slots = slots << 16 | slot;
+            if (!(q & 1)) {
+                stash = v;
+            } else {
+                const auto r = __builtin_amdgcn_permlane32_swap(stash, v, false, false);
+                const uint32_t x = r[0] + r[1]; /* lanes 0..31: the even operation's, 32..63: the odd one's */
+                if (q == 1) {
+                    x1 = x;
+                } else {
+                    const auto r2 = __builtin_amdgcn_permlane16_swap(x1, x, false, false);
+                    uint32_t t = r2[0] + r2[1]; /* rows: operations 0, 2, 1, 3 */
+                    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xf, 0xf, false);
+                    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xf, 0xf, false);
+                    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xf, false);
+                    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xf, 0xf, false);
+                    if ((lane & 15) == 15) { /* (ds_add without return: nothing waits for LDS here) */
+                        const uint32_t at = (uint32_t)(slots >> row_shift) & 0xffffu;
+                        __hip_atomic_fetch_add(&cnt[at], t & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        __hip_atomic_fetch_add(&cnt[at + 1], t >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+            }
+        };
         for (uint32_t o = 0; o < args.n_ops; o++) {
-            const TileOp op = nxt_op;
+            /* what the iteration before asked for is waited for HERE, before this iteration's loads are issued: scalar and LDS
+             * loads share one counter that can only be waited to zero, a wait further down would wait for the new ones too */
+            asm volatile("" : "+v"(qb_nxt.lo), "+v"(qb_nxt.hi), "+v"(qb2_nxt.lo), "+v"(qb2_nxt.hi), "+s"(raw2) : : "memory");
+            const TileOp op = op1;
             const W2 qb = qb_nxt, qb2 = qb2_nxt;
-            nxt_op = args.ops[min(o + 1, args.n_ops - 1)];
-            qb_nxt = w2(qb_lds[nxt_op.cls * 64 + lane]), qb2_nxt = w2(qb_lds[nxt_op.pad * 64 + lane]);
-            if (op.kind == OP_CLASS) {
+            op1 = __builtin_bit_cast(TileOp, raw2);
+            raw2 = ops[o + 2];
+            qb_nxt = qb_at(op1.ofs1), qb2_nxt = qb_at(op1.ofs2);
+            if (__builtin_expect(op.kind == OP_PAT2, 1)) {
+                /* two patterns of the pair with n = 1 (g has no block starts: g & b = g & qb), their two carry chains side by
+                 * side in one instruction stream, their counts in one reduction */
+                uint32_t y0l, y0h, y1l, y1h;
+                core(qb, g & qb, y0l, y0h);
+                core(qb2, g & qb2, y1l, y1h);
+                const uint32_t pc0 = __builtin_popcount(y0l) + __builtin_popcount(y0h), pc1 = __builtin_popcount(y1l) + __builtin_popcount(y1h);
+                account(pc0 | pc1 << 16, pj, op.k >> 6);
+                if (emit_tile) emit(y0l, y0h, args.order[pj]), emit(y1l, y1h, args.order[pj + 1]);
+                pj += 2; /* (the host pairs patterns at even positions: both in one group of 64) */
+                next_group();
+            } else if (op.kind == OP_CLASS) {
                 a = w2(load(op.cls));
                 pa = from_below(a, below);
                 make_runs(ra, a & nst, below);
             } else if (op.kind == OP_PAIR) {
                 const W2 r = shl2u(a, pa, op.k) & run_of_u(ra, op.k); /* R_m: m members of A end here, inside one block */
                 g = shl2u(r, from_below(r, below), 1) & nst;          /* G: a match of A{m,} may end right before this byte */
-                pg = from_below(g, below);
-            } else if (op.kind == OP_PAT2) {
-                /* two patterns of the pair with n = 1 (g has no block starts: g & b = g & qb), their two carry chains side by
-                 * side in one instruction stream, their counts in one reduction */
-                uint32_t y0l, y0h, y1l, y1h;
-                core(qb, g & qb, pj & 63, y0l, y0h);
-                core(qb2, g & qb2, (pj + 1) & 63, y1l, y1h);
-                const uint32_t pc0 = __builtin_popcount(y0l) + __builtin_popcount(y0h), pc1 = __builtin_popcount(y1l) + __builtin_popcount(y1h);
-                const uint32_t tot = wave_sum_to_63(pc0 | pc1 << 16); /* (no field can overflow: 63 words x 64 bits) */
-                if (lane == 63) { /* (ds_add without return: nothing waits for LDS here) */
-                    __hip_atomic_fetch_add(&cnt[pj], tot & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(&cnt[pj + 1], tot >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-                if (emit_tile) emit(y0l, y0h, op.index & 0xffffu), emit(y1l, y1h, op.index >> 16);
-                pj += 2; /* (the host pairs patterns at even positions: both in one group of 64) */
-                next_group();
-            } else {
+            } else if (op.kind == OP_COUNT0) {
+                account(0, args.n_pats, op.k >> 6);
+            } else if (op.kind == OP_PAT) {
+                const uint32_t k = op.k & 63u;
                 W2 x;
-                if (op.k == 0) {
+                if (k == 0) {
                     x = g & qb;
                 } else { /* the mandatory B{n}: n members of B end here, the first of them anywhere in the block */
                     Runs rb;
-                    make_runs(rb, qb, below);
+                    make_runs(rb, w2(qb_lds[op.cls * QB_STRIDE + (lane ? lane : 64)]), below);
                     const W2 b = w2(load(op.cls));
-                    x = shl2u(g, pg, op.k) & shl2u(b, from_below(b, below), op.k) & run_of_u(rb, op.k);
+                    x = shl2u(g, from_below(g, below), k) & shl2u(b, from_below(b, below), k) & run_of_u(rb, k) & qb; /* (& qb: nothing on the halo lane, nothing outside the share) */
                 }
                 uint32_t y_lo, y_hi;
-                core(qb, x, pj & 63, y_lo, y_hi);
-                const uint32_t tot = wave_sum_to_63(__builtin_popcount(y_lo) + __builtin_popcount(y_hi));
-                if (lane == 63) __hip_atomic_fetch_add(&cnt[pj], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (emit_tile) emit(y_lo, y_hi, op.index);
+                core(qb, x, y_lo, y_hi);
+                account(__builtin_popcount(y_lo) + __builtin_popcount(y_hi), pj, op.k >> 6);
+                if (emit_tile) emit(y_lo, y_hi, args.order[pj]);
                 pj++;
                 next_group();
             }
         }
-        if ((pj & 63) && lane == 0) carry_lds[pj >> 6] = cb;
+        if ((pj & 63) && lane == 0) carry_lds[pj >> 6] = cb >> (64 - (pj & 63)); /* (the shift register, part of the way round) */
     }
     /* the share's counts: the program's pattern order back to the caller's */
     if (!args.counts) return;
-    uint32_t pj = 0;
-    for (uint32_t o = 0; o < args.n_ops; o++) {
-        const TileOp op = args.ops[o];
-        if (op.kind == OP_PAT2) {
-            if (lane == 63 && cnt[pj]) atomicAdd(&args.counts[op.index & 0xffffu], (unsigned long long)cnt[pj]);
-            if (lane == 63 && cnt[pj + 1]) atomicAdd(&args.counts[op.index >> 16], (unsigned long long)cnt[pj + 1]);
-            pj += 2;
-        } else if (op.kind == OP_PAT) {
-            if (lane == 63 && cnt[pj]) atomicAdd(&args.counts[op.index], (unsigned long long)cnt[pj]);
-            pj++;
-        }
-    }
+    for (uint32_t j = lane; j < args.n_pats; j += 64)
+        if (cnt[j]) atomicAdd(&args.counts[args.order[j]], (unsigned long long)cnt[j]);
 }
 
 } // namespace
@@ -635,7 +677,7 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
     memcpy(hdr.data() + ptr_ofs, d_bitmaps, (size_t)n_classes * sizeof(void *));
     uint32_t n_ops = 0;
     const uint32_t n_wgroups = (n_seqs + 255) / 256;
-    size_t pairof_ofs = 0, pairs_ofs = 0, npairs_ofs = 0;
+    size_t pairof_ofs = 0, pairs_ofs = 0, npairs_ofs = 0, order_ofs = 0;
     if (tiled) { /* the program of class_seq_tile_kernel: patterns sorted by (A, m, n, B) */
         std::vector<uint32_t> order(n_seqs);
         for (unsigned i = 0; i < n_seqs; i++) order[i] = i;
@@ -648,28 +690,35 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
             return x < y;
         });
         std::vector<TileOp> ops;
-        unsigned n_pat_done = 0;
+        std::vector<uint16_t> prog_order;
+        unsigned n_pat_done = 0, n_count_ops = 0;
         for (unsigned k = 0; k < n_seqs; k++) {
             const hsgpu_class_seq_t &p = seqs[order[k]];
             const bool new_a = k == 0 || seqs[order[k - 1]].a != p.a;
-            if (new_a) ops.push_back(TileOp{OP_CLASS, p.a, 0, 0, 0});
-            if (new_a || seqs[order[k - 1]].m != p.m) ops.push_back(TileOp{OP_PAIR, p.a, (uint8_t)(p.m - 1), 0, 0});
+            if (new_a) ops.push_back(TileOp{OP_CLASS, 0, 0, 0, p.a});
+            if (new_a || seqs[order[k - 1]].m != p.m) ops.push_back(TileOp{OP_PAIR, (uint8_t)(p.m - 1), 0, 0, p.a});
             /* two patterns of the same (A, m) with n = 1 become one operation -- at an even position of the program, so that
              * both carries sit in the same group of 64 */
             const bool pairable = p.n == 1 && k + 1 < n_seqs && seqs[order[k + 1]].a == p.a && seqs[order[k + 1]].m == p.m &&
                                   seqs[order[k + 1]].n == 1 && (n_pat_done & 1) == 0;
             if (pairable) {
-                ops.push_back(TileOp{OP_PAT2, p.b, 0, seqs[order[k + 1]].b, order[k] | order[k + 1] << 16});
+                ops.push_back(TileOp{OP_PAT2, (uint8_t)((n_count_ops++ & 3) << 6), (uint16_t)(p.b * QB_STRIDE * 8), (uint16_t)(seqs[order[k + 1]].b * QB_STRIDE * 8), 0});
+                prog_order.push_back((uint16_t)order[k]), prog_order.push_back((uint16_t)order[k + 1]);
                 n_pat_done += 2;
                 k++;
             } else {
-                ops.push_back(TileOp{OP_PAT, p.b, (uint8_t)(p.n - 1), 0, order[k]});
+                ops.push_back(TileOp{OP_PAT, (uint8_t)((p.n - 1) | (n_count_ops++ & 3) << 6), (uint16_t)(p.b * QB_STRIDE * 8), 0, p.b});
+                prog_order.push_back((uint16_t)order[k]);
                 n_pat_done += 1;
             }
         }
+        while (n_count_ops & 3) ops.push_back(TileOp{OP_COUNT0, (uint8_t)((n_count_ops++ & 3) << 6), 0, 0, 0});
         n_ops = (uint32_t)ops.size();
-        hdr.resize(tab_ofs + ops.size() * sizeof(TileOp));
+        ops.push_back(TileOp{OP_NOP, 0, 0, 0, 0}), ops.push_back(TileOp{OP_NOP, 0, 0, 0, 0}); /* (the kernel reads two ahead) */
+        order_ofs = tab_ofs + ops.size() * sizeof(TileOp);
+        hdr.resize(order_ofs + prog_order.size() * sizeof(uint16_t));
         memcpy(hdr.data() + tab_ofs, ops.data(), ops.size() * sizeof(TileOp));
+        memcpy(hdr.data() + order_ofs, prog_order.data(), prog_order.size() * sizeof(uint16_t));
     } else { /* (class, repeat) pairs per group of 256 patterns for class_seq_shared_kernel */
         pairof_ofs = tab_ofs;
         pairs_ofs = pairof_ofs + (((size_t)n_seqs * 2 + 15) & ~(size_t)15);
@@ -706,6 +755,7 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
     if (tiled) {
         TileArgs t;
         t.ops = (const TileOp *)(w + tab_ofs);
+        t.order = (const uint16_t *)(w + order_ofs);
         t.n_ops = n_ops;
         t.n_pats = n_seqs;
         t.n_classes = n_classes;
