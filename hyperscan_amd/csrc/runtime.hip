@@ -163,6 +163,7 @@ struct hsgpu_scratch {
     unsigned tune_wg_threads = 0, tune_wg_per_cu = 0;
     uint64_t cand_div = 64;                /* corpus bytes per candidate entry of capacity: 16 (room for every chunk) once a scan overflowed */
     unsigned dense_span = 0, dense_left = 0; /* dense mode lasts dense_span scans (doubling each time it is re-entered) */
+    bool dense_unfolded = false;             /* a dense scan of the folded pipeline asked for "again" (more matches per position than its queue orders) */
     hsgpu_match_t *h_recs = nullptr;       /* pinned: hsgpu_hwlm_fetch_replay's landing area for the records */
     size_t h_recs_cap = 0;
     hipEvent_t ev_chunk[4] = {};           /* its D2H chunks */
@@ -435,7 +436,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     const HsgpuTableHeader *h = t->hdr();
     const void *f_two = hsgpu_filter_kernel_for(h->flags, false);
     const void *f_fused = hsgpu_filter_kernel_for(h->flags, true);
-    const void *f_conf = hsgpu_confirm_kernel_for(h->flags);
+    const void *f_conf = hsgpu_confirm_kernel_for(h->flags, false);
     if (!f_two || !f_fused || !f_conf) {
         hsgpu_set_error("no kernel for table flags %u", h->flags);
         return HSGPU_UNKNOWN_ERROR;
@@ -544,6 +545,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if (s->h_note && *s->h_note) {
             /* (an overflow seen: dense mode for dense_span scans, twice as long every time it has to be re-entered) */
             *s->h_note = 0;
+            if (s->cand_div == 16) s->dense_unfolded = true; /* candidates cannot overflow in dense mode: the folded confirm kernel emitted out of order */
             s->cand_div = 16;
             s->dense_span = std::min<unsigned>(s->dense_span ? s->dense_span * 2 : 16, 1u << 16);
             s->dense_left = s->dense_span;
@@ -552,14 +554,18 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
              * after dense_span scans without a note the scratch tries the ordinary sizing again and gives the big buffer back.
              * If the input is still dense that scan reports "again", sets the note, and the span doubles. */
             s->cand_div = 64;
+            s->dense_unfolded = false;
             s->cand.release();
         }
     }
     /* The folded pipeline: the confirm wavefronts emit their regions in order and place them themselves. Not for fused-only
-     * scratches, not in dense mode (more matches than a wavefront's queue can order: record_sort_kernel sorts whatever it is
-     * given), and not without the mapped "again" note (the fused kernel then has to run between confirm and sort). */
-    const bool fold = two_phase && s->cand_div != 16 && s->d_note && !s->tune_unfolded;
-    args.fold = fold ? 1u : 0u;
+     * scratches and not without the mapped "again" note (the fused kernel then has to run between confirm and sort). In dense
+     * mode (fold = 2) dense batches are confirmed position by position; a set with more matches per position than the queue
+     * orders that way makes the scan say "again" once more, and the scratch goes on with record_sort_kernel, which sorts
+     * whatever it is given. */
+    const bool fold = two_phase && s->d_note && !s->tune_unfolded && !(s->cand_div == 16 && s->dense_unfolded);
+    args.fold = fold ? (s->cand_div == 16 ? 2u : 1u) : 0u;
+    if (args.fold == 2 && !(f_conf = hsgpu_confirm_kernel_for(h->flags, true))) return HSGPU_INVALID;
     /* up to 256 supers: atomics on one address go one after the other (~0.1 us each). Unfolded: supers of 2^super_shift regions, one
      * atomic per region (64 regions share one at 16 384 regions); folded: supers of SHARES, one atomic per share (16 per word) */
     args.super_shift = fold ? 3 : 5;

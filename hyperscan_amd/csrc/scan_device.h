@@ -151,6 +151,10 @@ struct Tables {
      * position behind its end; at a share's first position that end lies in the share before -- whose records have been (or
      * are being) ordered without it. The share that owns the end looks for it instead (pair_edge_probe). */
     uint64_t share_start;
+    /* ... and the folded pipeline's frontier: the first position behind what a wavefront has drained in order. The late-keyed
+     * literals that end right in front of it were asked for before that drain (pair_edge_probe); the lookup at the frontier
+     * itself leaves them alone. */
+    uint64_t late_skip;
 };
 
 /* the 8 bytes ending at g, little-endian, bytes before the corpus read as 0
@@ -367,7 +371,7 @@ __device__ __forceinline__ void confirm_pos_pair(const Tables &t, uint64_t wm, u
     if (HAS_B) {
         const uint32_t kb = w4 >> 8, km = (((uint32_t)(wm >> 32) & t.key_mask) >> 8) | HSGPU_KEY_M;
         if (gate_hit(t, kb)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, kb, w0, w1, g);
-        if (g && g != t.share_start && gate_hit(t, km)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, km, wm, 0, g - 1);
+        if (g && g != t.share_start && g != t.late_skip && gate_hit(t, km)) probe<DEFER>(t, t.ht_b, t.ht_b_log2, km, wm, 0, g - 1);
     }
 }
 
@@ -537,7 +541,7 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
         if (HAS_C && ref_c[u] && !fast_c[u]) walk_ref<true>(t, ref_c[u], w0[u], w1[u], g[u]);
         if (PAIR && HAS_B && cnd[u]) { /* rare: a few percent of the candidates have a 3-byte key with their hash */
             if ((gb[u] >> (hsgpu_gate_bit(kb[u]) & 31)) & 1u) probe<true>(t, t.ht_b, t.ht_b_log2, kb[u], w0[u], w1[u], g[u]);
-            if (g[u] && g[u] != t.share_start && ((gm[u] >> (hsgpu_gate_bit(km[u]) & 31)) & 1u))
+            if (g[u] && g[u] != t.share_start && g[u] != t.late_skip && ((gm[u] >> (hsgpu_gate_bit(km[u]) & 31)) & 1u))
                 probe<true>(t, t.ht_b, t.ht_b_log2, km[u], wm[u], 0, g[u] - 1);
         }
     }
@@ -1048,6 +1052,7 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.rec_region = nullptr;
     t.rec_cap = 0;
     t.share_start = 0;
+    t.late_skip = ~0ull;
 }
 
 __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t lane) {
@@ -1633,6 +1638,8 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
  * record_sort_kernel (profiles/r04_tail_*.txt). The unfolded pipeline (fused scans, dense mode) keeps round 3's schedule:
  * batches of a share dealt round-robin, matches resolved as they queue up, record_sort_kernel below. */
 constexpr uint32_t SPIN_LIMIT = 1u << 22; /* placement: a region in front that never publishes (cannot happen) ends the wait */
+constexpr uint32_t DENSE_AT = 48;    /* dense scans: candidate positions in a batch of 128 entries from which the batch goes position by position */
+constexpr uint32_t DENSE_STEPS = 64; /* ... two entries of the batch per step */
 constexpr uint32_t SYNC_AT = 48;          /* folded: queued matches that end a group of batches (the queue holds MQ_CAP = 128) */
 static_assert(CONFIRM_THREADS / 64 == HSGPU_CONFIRM_SPLIT, "one wavefront per part of a share");
 
@@ -1713,7 +1720,7 @@ __device__ __forceinline__ const HsgpuScanArgs &cold_args() {
     return *(const HsgpuScanArgs *)p;
 }
 
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false>
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false, bool DENSE = false>
 __global__ __launch_bounds__(CONFIRM_THREADS)
 #ifndef HSGPU_CONFIRM_WAVES
 #define HSGPU_CONFIRM_WAVES 6
@@ -1735,6 +1742,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fold = args.fold != 0;
+    constexpr bool dense = DENSE; /* (an instantiation of its own, scan_inst_dense.hip: the position-parallel path costs the ordinary kernel registers it does not have) */
     const uint32_t n_shares = args.cand_waves;
     if (args.cand_counts[n_shares]) { /* candidate overflow: nothing was confirmed, the total is unknown */
         if (!fold) return;             /* the kernels behind this one report (or redo the scan) */
@@ -1911,20 +1919,61 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             const uint64_t n_full = args.total >> 10, per = (n_full + n_shares - 1) / n_shares;
             t.share_start = min(n_full, (uint64_t)r * per) << 10;
             const uint64_t next = min(n_full, ((uint64_t)r + 1) * per);
-            if (wave == W - 1 && next < n_full && next > (t.share_start >> 10)) edge = next << 10;
+            /* (the wavefront that holds the share's last entries -- the ends in question sort among its records; a share without
+             * entries: the last wavefront) */
+            const bool owner = n ? (base < end && end == n) : wave == W - 1;
+            if (owner && next < n_full && next > (t.share_start >> 10)) edge = next << 10;
+            t.late_skip = ~0ull;
         }
         if (base < end || edge) { /* else nothing for this wavefront: its record counts stay zero */
             t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
-            if (PAIR && HAS_B && edge && lane == 0) pair_edge_probe<true>(t, edge); /* (queued: ordered and resolved with the rest) */
             const uint4 *region = args.cand + 2ull * r * args.cand_cap;
+            if (PAIR && HAS_B) {
+                /* unfolded: queued here, sorted with everything else by record_sort_kernel. Folded: before the drain that the end in
+                 * question sorts into (below); a quarter that does not start the share starts behind somebody's frontier */
+                if (!fold && edge && lane == 0) pair_edge_probe<true>(t, edge);
+                if (fold && base && base < end) t.late_skip = (uint64_t)((const uint32_t *)region)[8ull * base] * CHUNK;
+            }
             /* (+16: the window of a chunk's last position is read as three dwords from entry byte 24; runtime.hip allocates the slack) */
             if (FAST) rs.region = __builtin_amdgcn_make_buffer_rsrc((void *)region, 0, (int)min((uint64_t)args.cand_cap * 32u + 16u, (uint64_t)0x7ffffff0), 0x00020000);
             bool syncing = false; /* folded: the rest queue is being emptied for a sorted drain */
+            /* Dense scans (args.fold == 2: the scratch gives every chunk an entry, the reference's flood case): a batch with more
+             * candidate positions than a step and the queue can order is confirmed POSITION-parallel -- two entries at a time,
+             * one lane per position, a sorted drain after every such step (up to four matches per position fit the queue) -- so that
+             * the records still leave the wavefront in delivery order and nothing has to be sorted afterwards. (Dense mode used to mean
+             * record_sort_kernel: 10.4 ms for the bench's 33.5 M flood records, profiles/r04_flood.txt.) */
+            uint32_t dense_s = DENSE_STEPS, dense_base = 0, dm[2] = {0, 0};
             for (;;) {
                 uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
                 const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
-                if (!syncing && base < end && nrq <= RQ_CAP - 128) { /* a fresh batch (the step may queue up to 128 more) */
+                bool again = false; /* a step on (idx, pend) that somebody queued: the rest queue's entries, a dense batch's positions */
+                if (DENSE && dense_s < DENSE_STEPS && !syncing) {
+                    const uint32_t k = 2 * dense_s + ((lane >> 4) & 1u); /* lanes 0 .. 31: entry k of the batch, position lane & 15 */
+                    const uint32_t m_e = (uint32_t)__shfl((int)(dense_s < DENSE_STEPS / 2 ? dm[0] : dm[1]), (int)(k & 63u));
+                    dense_s++;
+                    pend[0] = lane < 32 ? m_e & (0x10001u << (lane & 15u)) : 0u;
+                    if (__ballot(pend[0] != 0) == 0) continue;
+                    idx[0] = pend[0] ? dense_base + k : 0u;
+                    again = true;
+                } else if (!syncing && base < end && nrq <= RQ_CAP - 128) { /* a fresh batch (the step may queue up to 128 more) */
                     const uint32_t i0 = base + lane, i1 = base + 64 + lane;
+                    if (dense) {
+                        const uint32_t *rw = (const uint32_t *)region;
+                        const uint32_t m0 = i0 < end ? rw[8ull * i0 + 1] : 0u, m1 = i1 < end ? rw[8ull * i1 + 1] : 0u;
+                        uint32_t cnt = __popc((m0 | m0 >> 16) & 0xffffu) + __popc((m1 | m1 >> 16) & 0xffffu);
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+                        if (cnt > DENSE_AT) {
+                            const uint32_t nmq = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            if (nrq || __builtin_amdgcn_readfirstlane(nmq)) { /* what is queued lies in front of this batch: out first */
+                                syncing = true;
+                                continue;
+                            }
+                            dm[0] = m0, dm[1] = m1, dense_base = base, dense_s = 0;
+                            base += stride;
+                            continue;
+                        }
+                    }
                     base += stride;
                     if (FAST) { /* the schedule of the general step with masks for booleans (confirm_step_fast) */
                         uint32_t vm[2];
@@ -1938,42 +1987,56 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     }
                 } else if (nrq) { /* entries with candidate bits left: same path, next bit */
                     const uint32_t k = min(nrq, 128u), first_q = nrq - k;
-                    if (FAST) {
-                        uint32_t vm[2];
 #pragma unroll
-                        for (int u = 0; u < 2; u++) {
-                            vm[u] = m_less(u * 64 + lane, k);
-                            const uint2 it = rq[(first_q + u * 64 + lane) & vm[u]];
-                            idx[u] = it.x & vm[u], pend[u] = it.y & vm[u];
+                    for (int u = 0; u < 2; u++) {
+                        if (FAST) {
+                            const uint32_t vq = m_less(u * 64 + lane, k);
+                            const uint2 it = rq[(first_q + u * 64 + lane) & vq];
+                            idx[u] = it.x & vq, pend[u] = it.y & vq;
+                        } else {
+                            const bool v = u * 64 + lane < k;
+                            const uint2 it = rq[v ? first_q + u * 64 + lane : 0];
+                            idx[u] = v ? it.x : 0, pend[u] = v ? it.y : 0;
                         }
-                        if (lane == 0) t.wl->nrq = first_q;
-                        confirm_step_fast<HAS_B, false>(t, rs, rq, idx, pend, vm);
-                    } else {
-                        bool valid[2];
-#pragma unroll
-                        for (int u = 0; u < 2; u++) {
-                            valid[u] = u * 64 + lane < k;
-                            const uint2 it = rq[valid[u] ? first_q + u * 64 + lane : 0];
-                            idx[u] = valid[u] ? it.x : 0, pend[u] = valid[u] ? it.y : 0;
-                        }
-                        if (lane == 0) t.wl->nrq = first_q;
-                        confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, false);
                     }
+                    if (lane == 0) t.wl->nrq = first_q;
+                    again = true;
                 } else if (fold) { /* a sync point with nothing pending: everything queued is final; in order into the region */
+                    if (PAIR && HAS_B) {
+                        /* the frontier: the entry that is confirmed next (by this wavefront, or by the one with the next quarter); the
+                         * late-keyed literals ending right in front of its chunk belong into THIS drain */
+                        const uint32_t nxt = (DENSE && dense_s < DENSE_STEPS) ? dense_base + 2 * dense_s : min(base, end);
+                        uint64_t gf = 0;
+                        if (nxt < n) gf = (uint64_t)((const uint32_t *)region)[8ull * nxt] * CHUNK;
+                        else if (base >= end) gf = edge;
+                        if (gf && gf != t.late_skip && gf != t.share_start) {
+                            if (lane == 0) pair_edge_probe<true>(t, gf);
+                            t.late_skip = gf;
+                        }
+                    }
 #ifdef HSGPU_X_PLAINDRAIN
                     drain_matches(t, lane, 0);
 #else
                     drain_matches_sorted(t, lane);
 #endif
                     syncing = false;
-                    if (base >= end) break;
+                    if (base >= end && dense_s >= DENSE_STEPS) break;
                     continue;
                 } else {
                     break;
                 }
+                if (again) { /* (a lane with nothing to do: entry 0, no candidate bits) */
+                    if (FAST) {
+                        const uint32_t vm[2] = {0, 0}; /* (only a fresh step masks with it) */
+                        confirm_step_fast<HAS_B, false>(t, rs, rq, idx, pend, vm);
+                    } else {
+                        const bool valid[2] = {pend[0] != 0, pend[1] != 0};
+                        confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, false);
+                    }
+                }
                 if (fold) {
                     const uint32_t nmq = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    syncing = syncing || __builtin_amdgcn_readfirstlane(nmq) > SYNC_AT || base >= end;
+                    syncing = syncing || __builtin_amdgcn_readfirstlane(nmq) > SYNC_AT || base >= end || dense_s < DENSE_STEPS;
                 } else {
                     drain_matches(t, lane, 63);
                     flush_records(t, lane, OFLUSH);

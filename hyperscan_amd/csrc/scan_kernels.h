@@ -74,7 +74,7 @@ struct HsgpuScanArgs {
 };
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
-const void *hsgpu_confirm_kernel_for(uint32_t table_flags);
+const void *hsgpu_confirm_kernel_for(uint32_t table_flags, bool dense); /* dense: the folded pipeline's kernel for dense scans (fold == 2) */
 const void *hsgpu_hint_kernel(void);
 const void *hsgpu_record_sort_kernel(void);
 size_t hsgpu_filter_lds_bytes(uint32_t table_flags, uint32_t filter_log2, bool fused, uint32_t wg_threads);

@@ -33,7 +33,9 @@ template <bool S2> static const void *pick_confirm(uint32_t flags) {
     if (flags & HSGPU_F_HAS_B) return (const void *)hwlm_confirm_kernel<true, true, false, S2>;
     return (const void *)hwlm_confirm_kernel<true, false, false, S2>;
 }
-const void *hsgpu_confirm_kernel_for(uint32_t flags) {
+const void *hsgpu_dense_confirm_kernel(uint32_t flags); /* scan_inst_dense.hip */
+const void *hsgpu_confirm_kernel_for(uint32_t flags, bool dense) {
+    if (dense) return hsgpu_dense_confirm_kernel(flags);
     if (flags & HSGPU_F_PAIR) return hsgpu_pair_confirm_kernel(flags);
     return (flags & HSGPU_F_STRIDE2) ? pick_confirm<true>(flags) : pick_confirm<false>(flags);
 }

@@ -109,6 +109,41 @@ def test_fully_dense_corpus_of_unaligned_size(size):
             assert r.s.stats()[1] >= 1, "the first scan of a dense corpus this size overflows its candidate regions"
 
 
+@pytest.mark.parametrize("n_lits", [2, 5])
+def test_flood_blocks_in_delivery_order_without_a_sort(n_lits):
+    """The reference's flood case (unit/internal/fdr_flood.cpp:148-557): runs of one byte under literals made of that byte.
+    Dense scans stay on the folded pipeline -- a dense batch is confirmed position by position, two entries per step, and
+    leaves the wavefront in delivery order (2 literals: two matches per position). With 5 literals a step's 32 positions hold
+    more matches than the queue orders: that scan says "again" once more and the scratch goes on with record_sort_kernel.
+    Either way: the exact count, delivery order, block 0 identical to the oracle."""
+    nb, blk = 8, 1 << 20
+    corpus = np.repeat((np.arange(nb) % 4 + ord("a")).astype(np.uint8), blk)
+    off = np.arange(nb + 1, dtype=np.uint64) * np.uint64(blk)
+    lits = [H.HwlmLiteral(b"a" * (4 + k), False, 10 + k) for k in range(n_lits)] + [H.HwlmLiteral(b"aaax", False, 3)]
+    lits += [H.HwlmLiteral(l.s, l.nocase, 100 + i) for i, l in enumerate(cp.teddy_literals(40, seed=12))]
+    want_total = 2 * sum(blk - 3 - k for k in range(n_lits))
+    r = Resident(lits, corpus, off, cap=want_total + (1 << 18))
+    n, tries = r.scan(), 0
+    while n > r.cap and tries < 8:
+        assert n == r.cap + 1
+        tries += 1
+        if tries > (1 if n_lits == 2 else 2):  # (the candidate overflow first; with 5 literals the queue's "again" second)
+            r.cap *= 2
+            r.d_out = r.torch.zeros(r.cap * 4, dtype=r.torch.int32, device=r.d_out.device)
+        n = r.scan()
+    assert n == want_total, (n, want_total, tries)
+    recs = r.records(n)
+    assert _in_delivery_order(recs)
+    assert set(np.unique(recs[:, 0]).tolist()) == {0, 4}
+    want = ob.Oracle(lits).collect_blocks(corpus[:blk], off[:2])
+    g = recs[recs[:, 0] == 0]
+    wi = np.lexsort((want["id"], want["end"]))
+    gi = np.lexsort((g[:, 2], g[:, 1]))
+    assert len(g) == len(want) and np.array_equal(g[gi, 1], want["end"][wi]) and np.array_equal(g[gi, 2], want["id"][wi])
+    n2 = r.scan()  # and again on the same scratch, whatever mode it is in now
+    assert n2 == want_total and np.array_equal(r.records(n2), recs)
+
+
 def test_dense_mode_is_left_again():
     """A scratch that has seen one dense scan does not keep the doubled candidate buffer and the unfolded pipeline for the
     rest of its life (advisor, round 3): after the dense span it tries the ordinary sizing again; if the input is still dense
