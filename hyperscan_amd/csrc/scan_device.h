@@ -155,6 +155,7 @@ struct Tables {
      * literals that end right in front of it were asked for before that drain (pair_edge_probe); the lookup at the frontier
      * itself leaves them alone. */
     uint64_t late_skip;
+    uint32_t mq_redo; /* dense steps: a match the queue has no room for is only counted (the step is done again on fewer positions) */
 };
 
 /* the 8 bytes ending at g, little-endian, bytes before the corpus read as 0
@@ -245,7 +246,7 @@ __device__ __forceinline__ void push_match(const Tables &t, uint64_t ge, uint32_
     const uint32_t s = __hip_atomic_fetch_add(&t.wl->nmq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     if (s < MQ_CAP) {
         t.wl->cand[s] = make_uint2(li | (uint32_t)ge << 24, (uint32_t)(ge >> 8)); /* = the 64-bit sort key {position, literal}: mq_key */
-    } else { /* (the folded pipeline emits in order: a queue that overflowed between two of its sync points did not) */
+    } else if (!t.mq_redo) { /* (the folded pipeline emits in order: a queue that overflowed between two of its sync points did not) */
         t.wl->pad[0] = 1u;
         resolve_match(t, ge, li);
     }
@@ -1053,6 +1054,7 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.rec_cap = 0;
     t.share_start = 0;
     t.late_skip = ~0ull;
+    t.mq_redo = 0;
 }
 
 __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t lane) {
@@ -1639,7 +1641,7 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
  * batches of a share dealt round-robin, matches resolved as they queue up, record_sort_kernel below. */
 constexpr uint32_t SPIN_LIMIT = 1u << 22; /* placement: a region in front that never publishes (cannot happen) ends the wait */
 constexpr uint32_t DENSE_AT = 48;    /* dense scans: candidate positions in a batch of 128 entries from which the batch goes position by position */
-constexpr uint32_t DENSE_STEPS = 64; /* ... two entries of the batch per step */
+constexpr uint32_t DENSE_POS = 128 * 16; /* ... the positions of a batch */
 constexpr uint32_t SYNC_AT = 48;          /* folded: queued matches that end a group of batches (the queue holds MQ_CAP = 128) */
 static_assert(CONFIRM_THREADS / 64 == HSGPU_CONFIRM_SPLIT, "one wavefront per part of a share");
 
@@ -1938,22 +1940,32 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             if (FAST) rs.region = __builtin_amdgcn_make_buffer_rsrc((void *)region, 0, (int)min((uint64_t)args.cand_cap * 32u + 16u, (uint64_t)0x7ffffff0), 0x00020000);
             bool syncing = false; /* folded: the rest queue is being emptied for a sorted drain */
             /* Dense scans (args.fold == 2: the scratch gives every chunk an entry, the reference's flood case): a batch with more
-             * candidate positions than a step and the queue can order is confirmed POSITION-parallel -- two entries at a time,
-             * one lane per position, a sorted drain after every such step (up to four matches per position fit the queue) -- so that
-             * the records still leave the wavefront in delivery order and nothing has to be sorted afterwards. (Dense mode used to mean
-             * record_sort_kernel: 10.4 ms for the bench's 33.5 M flood records, profiles/r04_flood.txt.) */
-            uint32_t dense_s = DENSE_STEPS, dense_base = 0, dm[2] = {0, 0};
+             * candidate positions than a step and the queue can order is confirmed POSITION-parallel -- dP consecutive positions of the
+             * batch at a time, one per lane slot, a sorted drain after every such step -- so that the records still leave the wavefront
+             * in delivery order and nothing has to be sorted afterwards. dP adapts: a step that found more matches than the queue holds
+             * is taken back (the surplus was only counted) and done again on half the positions; one that filled less than half
+             * the queue doubles it (flood: 64 positions, two matches each). (Dense mode used to mean record_sort_kernel: 10.4 ms for
+             * the bench's 33.5 M flood records, profiles/r04_flood.txt.) */
+            uint32_t dq = DENSE_POS, dP = 32, dense_base = 0, dm[2] = {0, 0}; /* the batch's next position, positions per step */
             for (;;) {
                 uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
                 const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
                 bool again = false; /* a step on (idx, pend) that somebody queued: the rest queue's entries, a dense batch's positions */
-                if (DENSE && dense_s < DENSE_STEPS && !syncing) {
-                    const uint32_t k = 2 * dense_s + ((lane >> 4) & 1u); /* lanes 0 .. 31: entry k of the batch, position lane & 15 */
-                    const uint32_t m_e = (uint32_t)__shfl((int)(dense_s < DENSE_STEPS / 2 ? dm[0] : dm[1]), (int)(k & 63u));
-                    dense_s++;
-                    pend[0] = lane < 32 ? m_e & (0x10001u << (lane & 15u)) : 0u;
-                    if (__ballot(pend[0] != 0) == 0) continue;
-                    idx[0] = pend[0] ? dense_base + k : 0u;
+                if (DENSE && dq < DENSE_POS && !syncing) {
+                    /* positions [dq, dq + dP) of the batch, one per lane slot: entry (position >> 4), its candidate bits of that position */
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t sigma = u * 64 + lane, a = dq + sigma, k = a >> 4;
+                        const uint32_t lo = (uint32_t)__shfl((int)dm[0], (int)(k & 63u)), hi = (uint32_t)__shfl((int)dm[1], (int)(k & 63u));
+                        const uint32_t m_e = k < 64 ? lo : hi;
+                        pend[u] = (sigma < dP && k < 128) ? m_e & (0x10001u << (a & 15u)) : 0u;
+                        idx[u] = pend[u] ? dense_base + k : 0u;
+                    }
+                    if (__ballot((pend[0] | pend[1]) != 0) == 0) { /* nothing there: on */
+                        dq += dP;
+                        continue;
+                    }
+                    t.mq_redo = dP > 1; /* a step that finds more than the queue holds is taken back and done again on half the positions */
                     again = true;
                 } else if (!syncing && base < end && nrq <= RQ_CAP - 128) { /* a fresh batch (the step may queue up to 128 more) */
                     const uint32_t i0 = base + lane, i1 = base + 64 + lane;
@@ -1969,7 +1981,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                                 syncing = true;
                                 continue;
                             }
-                            dm[0] = m0, dm[1] = m1, dense_base = base, dense_s = 0;
+                            dm[0] = m0, dm[1] = m1, dense_base = base, dq = 0;
                             base += stride;
                             continue;
                         }
@@ -2005,9 +2017,10 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     if (PAIR && HAS_B) {
                         /* the frontier: the entry that is confirmed next (by this wavefront, or by the one with the next quarter); the
                          * late-keyed literals ending right in front of its chunk belong into THIS drain */
-                        const uint32_t nxt = (DENSE && dense_s < DENSE_STEPS) ? dense_base + 2 * dense_s : min(base, end);
+                        const bool mid = DENSE && dq < DENSE_POS && dense_base + (dq >> 4) < n; /* inside a dense batch: position by position */
+                        const uint32_t nxt = mid ? dense_base + (dq >> 4) : min(base, end);
                         uint64_t gf = 0;
-                        if (nxt < n) gf = (uint64_t)((const uint32_t *)region)[8ull * nxt] * CHUNK;
+                        if (nxt < n) gf = (uint64_t)((const uint32_t *)region)[8ull * nxt] * CHUNK + (mid ? dq & 15u : 0u);
                         else if (base >= end) gf = edge;
                         if (gf && gf != t.late_skip && gf != t.share_start) {
                             if (lane == 0) pair_edge_probe<true>(t, gf);
@@ -2020,7 +2033,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     drain_matches_sorted(t, lane);
 #endif
                     syncing = false;
-                    if (base >= end && dense_s >= DENSE_STEPS) break;
+                    if (base >= end && dq >= DENSE_POS) break;
                     continue;
                 } else {
                     break;
@@ -2035,8 +2048,22 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     }
                 }
                 if (fold) {
-                    const uint32_t nmq = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    syncing = syncing || __builtin_amdgcn_readfirstlane(nmq) > SYNC_AT || base >= end || dense_s < DENSE_STEPS;
+                    const uint32_t nmq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+                    if (DENSE && t.mq_redo) { /* a dense step */
+                        t.mq_redo = 0;
+                        if (nmq > MQ_CAP) { /* (the matches past the queue were not resolved: nothing of this step has left the wavefront) */
+                            if (lane == 0) __hip_atomic_store(&t.wl->nmq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            dP >>= 1;
+                            continue;
+                        }
+                        dq += dP;
+                        if (2 * nmq <= MQ_CAP && dP < 128) dP <<= 1;
+                        syncing = true;
+                    } else if (DENSE && dq < DENSE_POS) { /* (a single position, resolved in place past the queue's capacity) */
+                        dq += dP;
+                        syncing = true;
+                    }
+                    syncing = syncing || nmq > SYNC_AT || base >= end;
                 } else {
                     drain_matches(t, lane, 63);
                     flush_records(t, lane, OFLUSH);

@@ -112,10 +112,10 @@ def test_fully_dense_corpus_of_unaligned_size(size):
 @pytest.mark.parametrize("n_lits", [2, 5])
 def test_flood_blocks_in_delivery_order_without_a_sort(n_lits):
     """The reference's flood case (unit/internal/fdr_flood.cpp:148-557): runs of one byte under literals made of that byte.
-    Dense scans stay on the folded pipeline -- a dense batch is confirmed position by position, two entries per step, and
-    leaves the wavefront in delivery order (2 literals: two matches per position). With 5 literals a step's 32 positions hold
-    more matches than the queue orders: that scan says "again" once more and the scratch goes on with record_sort_kernel.
-    Either way: the exact count, delivery order, block 0 identical to the oracle."""
+    Dense scans stay on the folded pipeline -- a dense batch is confirmed position by position, a sorted drain after every
+    step, and leaves the wavefront in delivery order. How many positions a step takes adapts to what the queue can order
+    (2 literals: two matches per position, 64 positions; 5 literals: steps that overflow are taken back and redone on
+    half). Either way: the exact count, delivery order, block 0 identical to the oracle, the same array on the next scan."""
     nb, blk = 8, 1 << 20
     corpus = np.repeat((np.arange(nb) % 4 + ord("a")).astype(np.uint8), blk)
     off = np.arange(nb + 1, dtype=np.uint64) * np.uint64(blk)
@@ -127,7 +127,7 @@ def test_flood_blocks_in_delivery_order_without_a_sort(n_lits):
     while n > r.cap and tries < 8:
         assert n == r.cap + 1
         tries += 1
-        if tries > (1 if n_lits == 2 else 2):  # (the candidate overflow first; with 5 literals the queue's "again" second)
+        if tries > 1:  # (the first "again" is the candidate overflow that sends the scratch to dense mode)
             r.cap *= 2
             r.d_out = r.torch.zeros(r.cap * 4, dtype=r.torch.int32, device=r.d_out.device)
         n = r.scan()
