@@ -9,8 +9,12 @@ OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --also teddy64,class256 --class-gib 1"
-# the kernel trace covers every workload of the bench line (class256 at 1 GiB, rose1000 at 0.5 GiB keep it short)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --class-gib 1 --rose-gib 0.5 --also teddy64,class256,rose1000,flood,batch_sweep > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+# 1. the headline workload alone (the driver's command without the other workloads and the CPU leg): kernel_stats.csv is
+#    what roofline.achieved's launch duration has to agree with
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-also > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+# 2. the same with teddy64 and class256 (1 GiB) behind it: their kernels are other instantiations (kernel_stats_also.csv);
+#    flood has a trace of its own (tools/flood_prof.py), rose1000's GPU stage is teddy64's kernel, batch_sweep is 1 000 small launches
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_also -- $CMD > $OUT/bench_also_under_rocprof.json 2> $OUT/trace_also.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > /dev/null 2> $OUT/pmc_write.err
 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- $CMD > /dev/null 2> $OUT/pmc_sq1.err
@@ -22,6 +26,7 @@ lines=[]
 for f in sorted(glob.glob(out+"/trace/**/*kernel_stats.csv", recursive=True)):
     lines.append(open(f).read())
 open(out+"/kernel_stats.csv","w").write("".join(lines))
+open(out+"/kernel_stats_also.csv","w").write("".join(open(f).read() for f in sorted(glob.glob(out+"/trace_also/**/*kernel_stats.csv", recursive=True))))
 def collect(dirs):
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
