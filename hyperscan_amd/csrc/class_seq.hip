@@ -319,14 +319,14 @@ constexpr uint32_t TILE_WORDS = 63;
 constexpr uint32_t TILE_MAX_CLASSES = 32;
 constexpr uint32_t QB_STRIDE = 65; /* a class' qb words in LDS: [0] = 0 (the halo lane adds nothing to a carry chain), [1..63] the tile's words, [64] the halo's true word */
 
-enum : uint8_t { OP_CLASS = 0, OP_PAIR = 1, OP_PAT = 2, OP_PAT2 = 3, OP_NOP = 4, OP_COUNT0 = 5 };
+enum : uint8_t { OP_PAT2 = 0, OP_CLASS = 1, OP_PAIR = 2, OP_PAT = 3, OP_NOP = 4, OP_COUNT0 = 5 }; /* (the common one first: one compare) */
 struct TileOp { /* 8 bytes, read with one scalar load */
     uint8_t kind, k;    /* OP_PAIR: k = m - 1 | OP_PAT: k = n - 1 */
     uint16_t ofs1, ofs2; /* OP_PAT, OP_PAT2: the byte offsets of the B classes' qb words in the wavefront's LDS (class * QB_STRIDE * 8) */
     uint16_t cls;        /* OP_CLASS: A | OP_PAT: B */
 };
 __host__ __device__ inline size_t tile_lds_per_wave(uint32_t n_classes, uint32_t n_pats) { /* qb words | carries | counts */
-    return (size_t)n_classes * (QB_STRIDE * 8) + (size_t)(n_pats / 64 + 2) * 8 + ((((size_t)n_pats + 2) * 4 + 15) & ~(size_t)15);
+    return (size_t)n_classes * (QB_STRIDE * 8) + (size_t)(n_pats / 64 + 2) * 8 + (((((size_t)n_pats + 3) / 2) * 4 + 15) & ~(size_t)15); /* counts: two 16-bit fields per word */
 }
 __device__ __forceinline__ unsigned long long rfl64u(unsigned long long v) {
     return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32 |
@@ -391,7 +391,7 @@ __device__ __forceinline__ uint32_t wave_sum_to_63(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs args) {
+__global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void class_seq_tile_kernel(TileArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile_lds[];
     const uint32_t lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
     const uint32_t share = blockIdx.x * (SEQ_THREADS / 64) + wave_in_wg;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
     uint64_t *qb_lds = (uint64_t *)(tile_lds + wave_in_wg * per_wave);
     unsigned long long *carry_lds = (unsigned long long *)((uint8_t *)qb_lds + (size_t)args.n_classes * (QB_STRIDE * 8)); /* [n_pats / 64 + 1] */
     uint32_t *cnt = (uint32_t *)(carry_lds + (args.n_pats / 64 + 2));
-    for (uint32_t j = lane; j < args.n_pats + 2; j += 64) cnt[j] = 0;
+    for (uint32_t j = lane; j < (args.n_pats + 3) / 2; j += 64) cnt[j] = 0;
     for (uint32_t j = lane; j < args.n_pats / 64 + 2; j += 64) carry_lds[j] = 0;
     if (share >= args.n_shares) return;
 
@@ -417,7 +417,20 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
     const uint32_t below = ((lane + 63u) & 63u) << 2; /* ds_bpermute address of the lane below */
     const uint32_t row_shift = (0x00201030u >> ((lane >> 4) * 8)) & 0xffu; /* rows 0 1 2 3 hold the sums of operations 0 2 1 3 */
 
+    /* the counts live in LDS as 16-bit fields (63 words x 64 bits per tile: 16 tiles fit) and go to the caller's counters,
+     * the program's pattern order back to the caller's, every 16 tiles and at the end */
+    auto flush_counts = [&]() {
+        if (!args.counts) return;
+        for (uint32_t wd = lane; wd < (args.n_pats + 1) / 2; wd += 64) {
+            const uint32_t v = cnt[wd];
+            cnt[wd] = 0;
+            if (v & 0xffffu) atomicAdd(&args.counts[args.order[2 * wd]], (unsigned long long)(v & 0xffffu));
+            if ((v >> 16) && 2 * wd + 1 < args.n_pats) atomicAdd(&args.counts[args.order[2 * wd + 1]], (unsigned long long)(v >> 16));
+        }
+    };
+    uint32_t tiles_counted = 0;
     for (uint64_t wb = w0; wb <= w1; wb += TILE_WORDS) {
+        if (++tiles_counted > 16) flush_counts(), tiles_counted = 1;
         /* this lane's word: wb + lane - 1 (lane 0 = the word before the tile) */
         const uint64_t w = wb + lane - 1;
         const bool have = (lane || wb > 0) && w <= w1 && w < n_words_total; /* words past the share read as zero: no runs, no carries */
@@ -515,6 +528,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
         auto qb_at = [&](uint32_t ofs) { return w2(*(const uint64_t *)(qb_lane + ofs)); };
         TileOp op1 = __builtin_bit_cast(TileOp, ops[0]);
         uint64_t raw2 = ops[1];
+        const __attribute__((address_space(4))) uint64_t *ops_ahead = ops + 1;
         W2 qb_nxt = qb_at(op1.ofs1), qb2_nxt = qb_at(op1.ofs2);
         /* the counts: a lane's two popcounts are one packed word (16 bits each: 63 words x 64 bits fit); FOUR operations' words
          * are summed over the wavefront together -- v_permlane32_swap + add folds two words into the halves of one, then
@@ -542,8 +556,8 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
                     t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xf, 0xf, false);
                     if ((lane & 15) == 15) { /* (ds_add without return: nothing waits for LDS here) */
                         const uint32_t at = (uint32_t)(slots >> row_shift) & 0xffffu;
-                        __hip_atomic_fetch_add(&cnt[at], t & 0xffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        __hip_atomic_fetch_add(&cnt[at + 1], t >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        /* (slots 2i and 2i + 1 share a word; a pair of patterns sits at an even slot: its packed sums go in as they are) */
+                        __hip_atomic_fetch_add(&cnt[at >> 1], (at & 1u) ? t << 16 : t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
                 }
             }
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
             const TileOp op = op1;
             const W2 qb = qb_nxt, qb2 = qb2_nxt;
             op1 = __builtin_bit_cast(TileOp, raw2);
-            raw2 = ops[o + 2];
+            raw2 = *++ops_ahead; /* (a running pointer: two scalar instructions instead of five for base + (o + 2) * 8) */
             qb_nxt = qb_at(op1.ofs1), qb2_nxt = qb_at(op1.ofs2);
             if (__builtin_expect(op.kind == OP_PAT2, 1)) {
                 /* two patterns of the pair with n = 1 (g has no block starts: g & b = g & qb), their two carry chains side by
@@ -600,8 +614,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void class_seq_tile_kernel(TileArgs ar
     }
     /* the share's counts: the program's pattern order back to the caller's */
     if (!args.counts) return;
-    for (uint32_t j = lane; j < args.n_pats; j += 64)
-        if (cnt[j]) atomicAdd(&args.counts[args.order[j]], (unsigned long long)cnt[j]);
+    flush_counts();
 }
 
 } // namespace
