@@ -1493,11 +1493,7 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
     const uint32_t n = __shfl(incl, 63);
     const uint32_t my_at = lane < nreg ? incl - (my.x + my.y) : n;
     if (!n) return;
-#ifdef HSGPU_FOLD_NOSORT /* timing experiment only: the share's records copied, not sorted */
-    const bool in_lds = false;
-#else
     const bool in_lds = n <= SORT_LDS;
-#endif
     /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
      * spilled to the back) */
     for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += NT) { /* whole wavefronts: shuffles below */
@@ -1511,9 +1507,6 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
             else out[base + i] = rec;
         }
     }
-#ifdef HSGPU_FOLD_NOSORT
-    return;
-#endif
     __syncthreads();
     if (n <= 64) {
         /* rank by counting: one record per lane of the first wavefront, every lane walks the share
@@ -1868,11 +1861,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     /* every wavefront: its (sorted) region of a placed share into the output */
     auto copy_region = [&](uint32_t p, uint32_t n_p, unsigned long long base) {
         const HsgpuScanArgs &args = cold_args();
-#ifdef HSGPU_X_NOCOPY
-        if (false) {
-#else
         if (n_p && n_p <= args.rec_cap && base + n_p <= args.cap) { /* (a region that lost records is left alone: the scan says "again") */
-#endif
             const uint4 *region = args.rec_stage + (uint64_t)(p * W + wave) * args.rec_cap;
             uint4 *out = (uint4 *)args.out + base;
             for (uint32_t i = lane; i < n_p; i += 64) out[i] = region[i];
@@ -1905,15 +1894,9 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         /* this wavefront's entries [base, end) in steps of `stride`: folded -- the w-th quarter of the share's batches of 128,
          * so that the four regions are consecutive pieces of the corpus; unfolded -- batches wave, wave + W, ... */
         const uint32_t nb = (n + 127) >> 7;
-#ifdef HSGPU_X_RR /* timing experiments only (results out of order) */
-        uint32_t base = wave << 7;
-        const uint32_t end = n;
-        const uint32_t stride = 128u * W;
-#else
         uint32_t base = fold ? (wave * nb / W) << 7 : wave << 7;
         const uint32_t end = fold ? min(n, ((wave + 1) * nb / W) << 7) : n;
         const uint32_t stride = fold ? 128u : 128u * W;
-#endif
         init_wave_lds(t, &wave_lds[wave], lane);
         uint32_t fill = 0;
         uint64_t edge = 0; /* pair tables, the share's last wavefront: the next share's first byte, when that share exists */
@@ -2027,11 +2010,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                             t.late_skip = gf;
                         }
                     }
-#ifdef HSGPU_X_PLAINDRAIN
-                    drain_matches(t, lane, 0);
-#else
                     drain_matches_sorted(t, lane);
-#endif
                     syncing = false;
                     if (base >= end && dq >= DENSE_POS) break;
                     continue;
