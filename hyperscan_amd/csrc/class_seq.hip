@@ -319,11 +319,11 @@ constexpr uint32_t TILE_WORDS = 63;
 constexpr uint32_t TILE_MAX_CLASSES = 32;
 constexpr uint32_t QB_STRIDE = 65; /* a class' qb words in LDS: [0] = 0 (the halo lane adds nothing to a carry chain), [1..63] the tile's words, [64] the halo's true word */
 
-enum : uint8_t { OP_PAT2 = 0, OP_CLASS = 1, OP_PAIR = 2, OP_PAT = 3, OP_NOP = 4, OP_COUNT0 = 5 }; /* (the common one first: one compare) */
-struct TileOp { /* 8 bytes, read with one scalar load */
-    uint8_t kind, k;    /* OP_PAIR: k = m - 1 | OP_PAT: k = n - 1 */
-    uint16_t ofs1, ofs2; /* OP_PAT, OP_PAT2: the byte offsets of the B classes' qb words in the wavefront's LDS (class * QB_STRIDE * 8) */
-    uint16_t cls;        /* OP_CLASS: A | OP_PAT: B */
+enum : uint8_t { ENTRY_ONE = 0, ENTRY_TWO = 1 }; /* an entry's kind bit */
+struct TileOp { /* a word of the program: 8 bytes, read with one scalar load */
+    uint8_t kind, k;     /* class header: k = its pairs | pair header: k = m - 1 | entry: kind = ENTRY_ONE / ENTRY_TWO, k = n - 1 (ENTRY_ONE) */
+    uint16_t ofs1, ofs2; /* entries: the byte offsets of the B classes' qb words in the wavefront's LDS (class * QB_STRIDE * 8); headers: 0 */
+    uint16_t cls;        /* class header: A | pair header: its entries | ENTRY_ONE: B */
 };
 __host__ __device__ inline size_t tile_lds_per_wave(uint32_t n_classes, uint32_t n_pats) { /* qb words | carries | counts */
     return (size_t)n_classes * (QB_STRIDE * 8) + (size_t)(n_pats / 64 + 2) * 8 + (((((size_t)n_pats + 3) / 2) * 4 + 15) & ~(size_t)15); /* counts: two 16-bit fields per word */
@@ -336,7 +336,7 @@ __device__ __forceinline__ unsigned long long rfl64u(unsigned long long v) {
 struct TileArgs {
     const TileOp *ops;
     const uint16_t *order; /* [n_pats]: the caller's index of the program's j-th pattern */
-    uint32_t n_ops, n_pats, n_classes, n_shares;
+    uint32_t n_groups, n_pats, n_classes, n_shares; /* n_groups: class headers in the program */
     uint32_t only_emit; /* hsgpu_class_seq_emit_dev: only the shares whose blocks can end in [emit_lo, emit_hi) are walked (no counts) */
     const hsgpu_class_seq_t *seqs;
     const uint64_t *const *bitmaps; /* 8-byte aligned */
@@ -562,54 +562,66 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
                 }
             }
         };
-        for (uint32_t o = 0; o < args.n_ops; o++) {
-            /* what the iteration before asked for is waited for HERE, before this iteration's loads are issued: scalar and LDS
-             * loads share one counter that can only be waited to zero, a wait further down would wait for the new ones too */
+        /* The program is nested, not dispatched: class header {cls, pairs}, per pair a header {m - 1, entries}, per entry one bit
+         * (two patterns with n = 1 | one pattern, any n). Three counted loops; an operation kind is never decoded. (With one flat
+         * list and a switch on the kind, the loop around the carry chains was three quarters of the kernel's instructions:
+         * profiles/r04_class_seq_v2.txt.) Words are still read two ahead, their qb words one ahead. */
+        W2 qb = {0, 0}, qb2 = {0, 0};
+        auto next_word = [&]() -> TileOp {
+            /* what the word before asked for is waited for HERE, before this word's loads are issued: scalar and LDS loads share
+             * one counter that can only be waited to zero, a wait further down would wait for the new ones too */
             asm volatile("" : "+v"(qb_nxt.lo), "+v"(qb_nxt.hi), "+v"(qb2_nxt.lo), "+v"(qb2_nxt.hi), "+s"(raw2) : : "memory");
             const TileOp op = op1;
-            const W2 qb = qb_nxt, qb2 = qb2_nxt;
+            qb = qb_nxt, qb2 = qb2_nxt;
             op1 = __builtin_bit_cast(TileOp, raw2);
-            raw2 = *++ops_ahead; /* (a running pointer: two scalar instructions instead of five for base + (o + 2) * 8) */
-            qb_nxt = qb_at(op1.ofs1), qb2_nxt = qb_at(op1.ofs2);
-            if (__builtin_expect(op.kind == OP_PAT2, 1)) {
-                /* two patterns of the pair with n = 1 (g has no block starts: g & b = g & qb), their two carry chains side by
-                 * side in one instruction stream, their counts in one reduction */
-                uint32_t y0l, y0h, y1l, y1h;
-                core(qb, g & qb, y0l, y0h);
-                core(qb2, g & qb2, y1l, y1h);
-                const uint32_t pc0 = __builtin_popcount(y0l) + __builtin_popcount(y0h), pc1 = __builtin_popcount(y1l) + __builtin_popcount(y1h);
-                account(pc0 | pc1 << 16, pj, op.k >> 6);
-                if (emit_tile) emit(y0l, y0h, args.order[pj]), emit(y1l, y1h, args.order[pj + 1]);
-                pj += 2; /* (the host pairs patterns at even positions: both in one group of 64) */
-                next_group();
-            } else if (op.kind == OP_CLASS) {
-                a = w2(load(op.cls));
-                pa = from_below(a, below);
-                make_runs(ra, a & nst, below);
-            } else if (op.kind == OP_PAIR) {
-                const W2 r = shl2u(a, pa, op.k) & run_of_u(ra, op.k); /* R_m: m members of A end here, inside one block */
+            raw2 = *++ops_ahead;
+            qb_nxt = qb_at(op1.ofs1), qb2_nxt = qb_at(op1.ofs2); /* (headers carry offset 0) */
+            return op;
+        };
+        uint32_t nq = 0; /* counting operations so far: four of them share a reduction */
+        for (uint32_t c = 0; c < args.n_groups; c++) {
+            const TileOp ch = next_word(); /* class A: cls, k = its pairs */
+            a = w2(load(ch.cls));
+            pa = from_below(a, below);
+            make_runs(ra, a & nst, below);
+            for (uint32_t p = 0; p < ch.k; p++) {
+                const TileOp ph = next_word(); /* pair (A, m): k = m - 1, cls = its entries */
+                const W2 r = shl2u(a, pa, ph.k) & run_of_u(ra, ph.k); /* R_m: m members of A end here, inside one block */
                 g = shl2u(r, from_below(r, below), 1) & nst;          /* G: a match of A{m,} may end right before this byte */
-            } else if (op.kind == OP_COUNT0) {
-                account(0, args.n_pats, op.k >> 6);
-            } else if (op.kind == OP_PAT) {
-                const uint32_t k = op.k & 63u;
-                W2 x;
-                if (k == 0) {
-                    x = g & qb;
-                } else { /* the mandatory B{n}: n members of B end here, the first of them anywhere in the block */
-                    Runs rb;
-                    make_runs(rb, w2(qb_lds[op.cls * QB_STRIDE + (lane ? lane : 64)]), below);
-                    const W2 b = w2(load(op.cls));
-                    x = shl2u(g, from_below(g, below), k) & shl2u(b, from_below(b, below), k) & run_of_u(rb, k) & qb; /* (& qb: nothing on the halo lane, nothing outside the share) */
+                for (uint32_t e = 0; e < ph.cls; e++) {
+                    const TileOp op = next_word();
+                    if (op.kind & 1) {
+                        /* two patterns of the pair with n = 1 (g has no block starts: g & b = g & qb), their two carry chains side by
+                         * side in one instruction stream, their counts in one reduction */
+                        uint32_t y0l, y0h, y1l, y1h;
+                        core(qb, g & qb, y0l, y0h);
+                        core(qb2, g & qb2, y1l, y1h);
+                        const uint32_t pc0 = __builtin_popcount(y0l) + __builtin_popcount(y0h), pc1 = __builtin_popcount(y1l) + __builtin_popcount(y1h);
+                        account(pc0 | pc1 << 16, pj, nq++ & 3u);
+                        if (emit_tile) emit(y0l, y0h, args.order[pj]), emit(y1l, y1h, args.order[pj + 1]);
+                        pj += 2; /* (the host pairs patterns at even positions: both in one group of 64) */
+                    } else {
+                        const uint32_t k = op.k;
+                        W2 x;
+                        if (k == 0) {
+                            x = g & qb;
+                        } else { /* the mandatory B{n}: n members of B end here, the first of them anywhere in the block */
+                            Runs rb;
+                            make_runs(rb, w2(qb_lds[op.cls * QB_STRIDE + (lane ? lane : 64)]), below);
+                            const W2 b = w2(load(op.cls));
+                            x = shl2u(g, from_below(g, below), k) & shl2u(b, from_below(b, below), k) & run_of_u(rb, k) & qb; /* (& qb: nothing on the halo lane, nothing outside the share) */
+                        }
+                        uint32_t y_lo, y_hi;
+                        core(qb, x, y_lo, y_hi);
+                        account(__builtin_popcount(y_lo) + __builtin_popcount(y_hi), pj, nq++ & 3u);
+                        if (emit_tile) emit(y_lo, y_hi, args.order[pj]);
+                        pj++;
+                    }
+                    next_group();
                 }
-                uint32_t y_lo, y_hi;
-                core(qb, x, y_lo, y_hi);
-                account(__builtin_popcount(y_lo) + __builtin_popcount(y_hi), pj, op.k >> 6);
-                if (emit_tile) emit(y_lo, y_hi, args.order[pj]);
-                pj++;
-                next_group();
             }
         }
+        while (nq & 3u) account(0, args.n_pats, nq++ & 3u); /* (the last reduction's missing operations: nobody's counts) */
         if ((pj & 63) && lane == 0) carry_lds[pj >> 6] = cb >> (64 - (pj & 63)); /* (the shift register, part of the way round) */
     }
     /* the share's counts: the program's pattern order back to the caller's */
@@ -688,7 +700,7 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
     std::vector<uint8_t> hdr(tab_ofs, 0);
     memcpy(hdr.data(), seqs, seq_bytes);
     memcpy(hdr.data() + ptr_ofs, d_bitmaps, (size_t)n_classes * sizeof(void *));
-    uint32_t n_ops = 0;
+    uint32_t n_groups = 0;
     const uint32_t n_wgroups = (n_seqs + 255) / 256;
     size_t pairof_ofs = 0, pairs_ofs = 0, npairs_ofs = 0, order_ofs = 0;
     if (tiled) { /* the program of class_seq_tile_kernel: patterns sorted by (A, m, n, B) */
@@ -704,30 +716,38 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
         });
         std::vector<TileOp> ops;
         std::vector<uint16_t> prog_order;
-        unsigned n_pat_done = 0, n_count_ops = 0;
+        unsigned n_pat_done = 0;
+        size_t class_at = 0, pair_at = 0; /* the open headers: their counts are filled in as the program grows */
         for (unsigned k = 0; k < n_seqs; k++) {
             const hsgpu_class_seq_t &p = seqs[order[k]];
             const bool new_a = k == 0 || seqs[order[k - 1]].a != p.a;
-            if (new_a) ops.push_back(TileOp{OP_CLASS, 0, 0, 0, p.a});
-            if (new_a || seqs[order[k - 1]].m != p.m) ops.push_back(TileOp{OP_PAIR, (uint8_t)(p.m - 1), 0, 0, p.a});
-            /* two patterns of the same (A, m) with n = 1 become one operation -- at an even position of the program, so that
+            if (new_a) {
+                class_at = ops.size();
+                ops.push_back(TileOp{0, 0, 0, 0, p.a}); /* class header: k = pairs */
+                n_groups++;
+            }
+            if (new_a || seqs[order[k - 1]].m != p.m) {
+                pair_at = ops.size();
+                ops.push_back(TileOp{0, (uint8_t)(p.m - 1), 0, 0, 0}); /* pair header: cls = entries */
+                ops[class_at].k++; /* (at most 16 repeat counts per class) */
+            }
+            /* two patterns of the same (A, m) with n = 1 become one entry -- at an even position of the program, so that
              * both carries sit in the same group of 64 */
             const bool pairable = p.n == 1 && k + 1 < n_seqs && seqs[order[k + 1]].a == p.a && seqs[order[k + 1]].m == p.m &&
                                   seqs[order[k + 1]].n == 1 && (n_pat_done & 1) == 0;
             if (pairable) {
-                ops.push_back(TileOp{OP_PAT2, (uint8_t)((n_count_ops++ & 3) << 6), (uint16_t)(p.b * QB_STRIDE * 8), (uint16_t)(seqs[order[k + 1]].b * QB_STRIDE * 8), 0});
+                ops.push_back(TileOp{ENTRY_TWO, 0, (uint16_t)(p.b * QB_STRIDE * 8), (uint16_t)(seqs[order[k + 1]].b * QB_STRIDE * 8), 0});
                 prog_order.push_back((uint16_t)order[k]), prog_order.push_back((uint16_t)order[k + 1]);
                 n_pat_done += 2;
                 k++;
             } else {
-                ops.push_back(TileOp{OP_PAT, (uint8_t)((p.n - 1) | (n_count_ops++ & 3) << 6), (uint16_t)(p.b * QB_STRIDE * 8), 0, p.b});
+                ops.push_back(TileOp{ENTRY_ONE, (uint8_t)(p.n - 1), (uint16_t)(p.b * QB_STRIDE * 8), 0, p.b});
                 prog_order.push_back((uint16_t)order[k]);
                 n_pat_done += 1;
             }
+            ops[pair_at].cls++;
         }
-        while (n_count_ops & 3) ops.push_back(TileOp{OP_COUNT0, (uint8_t)((n_count_ops++ & 3) << 6), 0, 0, 0});
-        n_ops = (uint32_t)ops.size();
-        ops.push_back(TileOp{OP_NOP, 0, 0, 0, 0}), ops.push_back(TileOp{OP_NOP, 0, 0, 0, 0}); /* (the kernel reads two ahead) */
+        ops.push_back(TileOp{0, 0, 0, 0, 0}), ops.push_back(TileOp{0, 0, 0, 0, 0}); /* (the kernel reads two ahead) */
         order_ofs = tab_ofs + ops.size() * sizeof(TileOp);
         hdr.resize(order_ofs + prog_order.size() * sizeof(uint16_t));
         memcpy(hdr.data() + tab_ofs, ops.data(), ops.size() * sizeof(TileOp));
@@ -769,7 +789,7 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
         TileArgs t;
         t.ops = (const TileOp *)(w + tab_ofs);
         t.order = (const uint16_t *)(w + order_ofs);
-        t.n_ops = n_ops;
+        t.n_groups = n_groups;
         t.n_pats = n_seqs;
         t.n_classes = n_classes;
         t.seqs = (const hsgpu_class_seq_t *)w;
