@@ -35,6 +35,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "internal.h"
@@ -391,6 +392,8 @@ __device__ __forceinline__ uint32_t wave_sum_to_63(uint32_t v) {
     return v;
 }
 
+/* EMIT = false: the counting pass (no record can be asked for: the emit range is empty) without the record path's registers and branches */
+template <bool EMIT>
 __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void class_seq_tile_kernel(TileArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile_lds[];
     const uint32_t lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     /* the share: the blocks that START inside [lo_b, hi_b) (no state enters a share) */
     const uint64_t lo_b = (uint64_t)share * args.share_bytes, hi_b = min(args.total, lo_b + args.share_bytes);
     /* (an emit range is made of whole blocks: the blocks that START in it, i.e. in the shares it touches) */
-    if (args.only_emit && (hi_b <= args.emit_lo || lo_b >= args.emit_hi)) return;
+    if (EMIT && args.only_emit && (hi_b <= args.emit_lo || lo_b >= args.emit_hi)) return;
     const uint64_t b_lo = lower_bound_off(args.off, args.nblocks, lo_b), b_hi = lower_bound_off(args.off, args.nblocks, hi_b);
     if (b_lo >= b_hi || b_lo >= args.nblocks) return;
     const uint64_t s0 = args.off[b_lo], s1 = args.off[min(b_hi, args.nblocks)];
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             if (!lane) qb_lds[c * QB_STRIDE + 64] = q;
         }
         const uint64_t base = w * 64;
-        const bool emit_tile = wb * 64 < args.emit_hi && (wb + TILE_WORDS) * 64 > args.emit_lo; /* (uniform) */
+        const bool emit_tile = EMIT && wb * 64 < args.emit_hi && (wb + TILE_WORDS) * 64 > args.emit_lo; /* (uniform) */
 
         Runs ra;
         W2 a = {0, 0}, pa = {0, 0}, g = {0, 0};
@@ -480,6 +483,7 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             asm("v_cmp_eq_u32_e64 %0, -1, %1" : "=s"(pmask) : "v"(and_s));
             /* lane 0 stands for everything below the tile: its own word is zero (no generate, no propagate), it generates
              * exactly the carry the pattern brought along: bit 0 of cb, a shift register of the group's 64 carries */
+            cb = rfl64u(cb); /* (wave-uniform by construction; said again, because an "s" operand the compiler holds in a vector register is an assembler error, not a copy) */
             const uint32_t g_lo = (uint32_t)gmask | ((uint32_t)cb & 1u), g_hi = (uint32_t)(gmask >> 32);
             const uint32_t a_lo = (uint32_t)pmask | g_lo, a_hi = (uint32_t)(pmask >> 32) | g_hi;
             uint32_t sum_lo, sum_hi, cout31; /* S = (P|G) + G; the carry INTO every lane is S ^ P, the one out of lane 63 the add's own */
@@ -799,24 +803,35 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
         t.nblocks = nblocks;
         t.total = total_bytes;
         const size_t lds = tile_lds_per_wave(n_classes, n_seqs) * (SEQ_THREADS / 64);
-        static std::mutex mu2;
-        static size_t lds_set = 0;
-        {
-            std::lock_guard<std::mutex> lock(mu2);
-            if (lds > lds_set) {
-                HIP_TRY(hipFuncSetAttribute((const void *)class_seq_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                lds_set = lds;
-            }
-        }
+        /* the counting pass (empty emit range) has an instantiation without the record path */
+        const bool emits = std::min(emit_hi, total_bytes) > emit_lo;
+        const void *kfn = emits ? (const void *)class_seq_tile_kernel<true> : (const void *)class_seq_tile_kernel<false>;
         /* a wavefront per share of whole blocks, every pattern. As many shares as the device holds wavefronts of this kernel at
-         * once, times two (8 192 shares on 5 120 slots were 1.6 rounds: the second one 60 % full), at least 16 KiB (four tiles) each */
+         * once, times two (8 192 shares on 5 120 slots were 1.6 rounds: the second one 60 % full), at least 16 KiB (four tiles) each.
+         * (The device's answers are kept: asking on every call was a visible part of a small scan.) */
         int dev = 0, n_cu = 256, per_cu = 0;
         HIP_TRY(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)class_seq_tile_kernel, SEQ_THREADS, lds) != hipSuccess || per_cu < 1) {
-            (void)hipGetLastError();
-            per_cu = 4;
+        {
+            static std::mutex mu2;
+            static std::map<std::pair<const void *, int>, size_t> lds_set;      /* (kernel, device) -> dynamic LDS allowed so far */
+            static std::map<std::tuple<const void *, int, size_t>, std::pair<int, int>> geo; /* -> (CUs, workgroups per CU) */
+            std::lock_guard<std::mutex> lock(mu2);
+            size_t &have = lds_set[{kfn, dev}];
+            if (lds > have) {
+                HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                have = lds;
+            }
+            auto it = geo.find({kfn, dev, lds});
+            if (it == geo.end()) {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SEQ_THREADS, lds) != hipSuccess || per_cu < 1) {
+                    (void)hipGetLastError();
+                    per_cu = 4;
+                }
+                it = geo.emplace(std::make_tuple(kfn, dev, lds), std::make_pair(n_cu, per_cu)).first;
+            }
+            n_cu = it->second.first, per_cu = it->second.second;
         }
         const uint64_t slots = (uint64_t)n_cu * per_cu * (SEQ_THREADS / 64) * 2;
         uint64_t share = std::max<uint64_t>(16384, (total_bytes + slots - 1) / slots);
@@ -830,7 +845,8 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
         t.counts = (unsigned long long *)d_counts;
         t.count = (unsigned long long *)d_count;
         t.out = (hsgpu_match_t *)d_out;
-        hipLaunchKernelGGL(class_seq_tile_kernel, dim3((t.n_shares + SEQ_THREADS / 64 - 1) / (SEQ_THREADS / 64)), dim3(SEQ_THREADS), lds, st, t);
+        void *kargs[] = {&t};
+        HIP_TRY(hipLaunchKernel(kfn, dim3((t.n_shares + SEQ_THREADS / 64 - 1) / (SEQ_THREADS / 64)), dim3(SEQ_THREADS), kargs, lds, st));
         HIP_TRY(hipGetLastError());
         return HSGPU_SUCCESS;
     }
