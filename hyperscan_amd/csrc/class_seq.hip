@@ -351,6 +351,14 @@ struct TileArgs {
 struct W2 {
     uint32_t lo, hi;
 };
+/* a wave-uniform 64-bit value for a vector use, through an explicit move: a scalar value carried round a loop that has ONE vector user
+ * (a store, a per-lane shift) is otherwise kept in vector registers altogether and read back with v_readfirstlane at every scalar use */
+__device__ __forceinline__ unsigned long long to_vector(unsigned long long v) {
+    uint32_t lo, hi;
+    asm("v_mov_b32 %0, %1" : "=v"(lo) : "s"((uint32_t)v));
+    asm("v_mov_b32 %0, %1" : "=v"(hi) : "s"((uint32_t)(v >> 32)));
+    return (unsigned long long)hi << 32 | lo;
+}
 __device__ __forceinline__ W2 w2(uint64_t v) { return {(uint32_t)v, (uint32_t)(v >> 32)}; }
 __device__ __forceinline__ W2 operator&(W2 a, W2 b) { return {a.lo & b.lo, a.hi & b.hi}; }
 /* the value the lane below holds (lane 0: whatever; it is the halo) */
@@ -483,15 +491,27 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             asm("v_cmp_eq_u32_e64 %0, -1, %1" : "=s"(pmask) : "v"(and_s));
             /* lane 0 stands for everything below the tile: its own word is zero (no generate, no propagate), it generates
              * exactly the carry the pattern brought along: bit 0 of cb, a shift register of the group's 64 carries */
-            cb = rfl64u(cb); /* (wave-uniform by construction; said again, because an "s" operand the compiler holds in a vector register is an assembler error, not a copy) */
-            const uint32_t g_lo = (uint32_t)gmask | ((uint32_t)cb & 1u), g_hi = (uint32_t)(gmask >> 32);
-            const uint32_t a_lo = (uint32_t)pmask | g_lo, a_hi = (uint32_t)(pmask >> 32) | g_hi;
-            uint32_t sum_lo, sum_hi, cout31; /* S = (P|G) + G; the carry INTO every lane is S ^ P, the one out of lane 63 the add's own */
-            asm("s_add_u32 %0, %3, %5\n\ts_addc_u32 %1, %4, %6\n\ts_cselect_b32 %2, 0x80000000, 0"
-                : "=&s"(sum_lo), "=&s"(sum_hi), "=s"(cout31)
-                : "s"(a_lo), "s"(a_hi), "s"(g_lo), "s"(g_hi)
+            /* The scalar side in ONE statement whose operands are all scalar. (gmask / pmask come out of statements that also have a
+             * vector output, which makes them divergent to the compiler: plain C on them may be selected as vector instructions,
+             * and an "s" operand held in a vector register is an assembler error, not a copy. Their halves are passed as they are.)
+             * G = generate | the carry the pattern brought along (bit 0 of cb, a shift register of the group's 64 carries: lane 0 stands
+             * for everything below the tile; its own word is zero); S = (P|G) + G; the carry INTO every lane is S ^ P, the one out of
+             * lane 63 the add's own carry. */
+            /* (readfirstlane: in one of the two instantiations the compiler carries cb round the loops in vector registers) */
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)cb & 1u));
+            uint32_t cin_lo, cin_hi, cout31, t0, t1, t2;
+            asm("s_or_b32 %3, %6, %10\n\t"   /* t0 = G.lo */
+                "s_or_b32 %4, %8, %3\n\t"    /* t1 = A.lo = P.lo | G.lo */
+                "s_or_b32 %5, %9, %7\n\t"    /* t2 = A.hi */
+                "s_add_u32 %4, %4, %3\n\t"   /* S.lo */
+                "s_addc_u32 %5, %5, %7\n\t"  /* S.hi */
+                "s_cselect_b32 %2, 0x80000000, 0\n\t"
+                "s_xor_b32 %0, %4, %8\n\t"
+                "s_xor_b32 %1, %5, %9"
+                : "=&s"(cin_lo), "=&s"(cin_hi), "=&s"(cout31), "=&s"(t0), "=&s"(t1), "=&s"(t2)
+                : "s"((uint32_t)gmask), "s"((uint32_t)(gmask >> 32)), "s"((uint32_t)pmask), "s"((uint32_t)(pmask >> 32)), "s"(c0)
                 : "scc");
-            const unsigned long long cin = ((unsigned long long)sum_hi << 32 | sum_lo) ^ pmask;
+            const unsigned long long cin = (unsigned long long)cin_hi << 32 | cin_lo;
             cb = (cb >> 1) | (unsigned long long)cout31 << 32;
             uint32_t t_lo, t_hi;
             unsigned long long c2, c3;
@@ -520,7 +540,7 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
         };
         auto next_group = [&]() { /* 64 patterns done: their carries to LDS, the next 64 patterns' from there */
             if ((pj & 63) == 0) {
-                if (lane == 0) carry_lds[(pj >> 6) - 1] = cb;
+                if (lane == 0) carry_lds[(pj >> 6) - 1] = to_vector(cb);
                 cb = rfl64u(carry_lds[pj >> 6]);
             }
         };
@@ -559,7 +579,7 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
                     t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xf, false);
                     t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xf, 0xf, false);
                     if ((lane & 15) == 15) { /* (ds_add without return: nothing waits for LDS here) */
-                        const uint32_t at = (uint32_t)(slots >> row_shift) & 0xffffu;
+                        const uint32_t at = (uint32_t)(to_vector(slots) >> row_shift) & 0xffffu;
                         /* (slots 2i and 2i + 1 share a word; a pair of patterns sits at an even slot: its packed sums go in as they are) */
                         __hip_atomic_fetch_add(&cnt[at >> 1], (at & 1u) ? t << 16 : t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
@@ -574,7 +594,10 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
         auto next_word = [&]() -> TileOp {
             /* what the word before asked for is waited for HERE, before this word's loads are issued: scalar and LDS loads share
              * one counter that can only be waited to zero, a wait further down would wait for the new ones too */
-            asm volatile("" : "+v"(qb_nxt.lo), "+v"(qb_nxt.hi), "+v"(qb2_nxt.lo), "+v"(qb2_nxt.hi), "+s"(raw2) : : "memory");
+            /* (two statements: an asm with ANY vector output makes all its outputs divergent to the compiler -- the program word, and with
+             * it every loop bound and everything carried round the loops, ended up in vector registers behind v_readfirstlane) */
+            asm volatile("" : "+s"(raw2) : : "memory");
+            asm volatile("" : "+v"(qb_nxt.lo), "+v"(qb_nxt.hi), "+v"(qb2_nxt.lo), "+v"(qb2_nxt.hi) : : "memory");
             const TileOp op = op1;
             qb = qb_nxt, qb2 = qb2_nxt;
             op1 = __builtin_bit_cast(TileOp, raw2);
@@ -626,7 +649,7 @@ __global__ __launch_bounds__(SEQ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             }
         }
         while (nq & 3u) account(0, args.n_pats, nq++ & 3u); /* (the last reduction's missing operations: nobody's counts) */
-        if ((pj & 63) && lane == 0) carry_lds[pj >> 6] = cb >> (64 - (pj & 63)); /* (the shift register, part of the way round) */
+        if ((pj & 63) && lane == 0) carry_lds[pj >> 6] = to_vector(cb >> (64 - (pj & 63))); /* (the shift register, part of the way round) */
     }
     /* the share's counts: the program's pattern order back to the caller's */
     if (!args.counts) return;
