@@ -504,40 +504,6 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     };
     args.hint_in_filter = two_phase ? 1u : 0u;
     if (!two_phase && (rv = launch_hints(stream)) != HSGPU_SUCCESS) return rv;
-    /* staged match records: one region per producing wavefront, packed into the
-     * caller's buffer by the last two kernels. 2x headroom over an even split. */
-    const uint32_t n_waves = grid * (wg_threads / 64);
-    const uint32_t n_rec = n_waves * HSGPU_CONFIRM_SPLIT; /* the fused kernel uses the first n_waves of them */
-    args.rec_regions = n_rec;
-    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
-    if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
-    /* Two control blocks that alternate from scan to scan, each rec_counts[2 n_rec] | cand_counts[n_waves + 1] |
-     * rec_super[257] (64-bit): a scan works in one and its last kernel zeroes the other (the previous scan's), so
-     * the next scan finds its block zeroed without a memset. */
-    const size_t cand_ofs = (size_t)2 * n_rec;
-    const size_t super_ofs = (cand_ofs + n_waves + 1 + 1) & ~(size_t)1; /* 8-byte aligned */
-    const size_t status_ofs = super_ofs + 2 * HSGPU_SUPER_WORDS;                     /* folded pipeline: one status word per region, */
-    const size_t ticket_ofs = status_ofs + n_rec;                      /* and the ticket counter */
-    const size_t blk_words = (ticket_ofs + 1 + 3) & ~(size_t)3;
-    /* a reallocated control buffer is garbage whatever its address: hipMalloc may hand the
-     * freed range straight back, so growth is detected by capacity, never by pointer */
-    const size_t ctl_cap_before = s->ctl.cap;
-    if ((rv = s->ctl.ensure(2 * blk_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
-    if (s->ctl.cap != ctl_cap_before) s->ctl_clean = false;
-    const size_t half_words = (s->ctl.cap / 8) & ~(size_t)3; /* the second block starts at the same place whatever this scan's size */
-    if (!s->ctl_clean) { /* a fresh (or possibly dirty) buffer: both blocks */
-        HIP_TRY(hipMemsetAsync(s->ctl.p, 0, s->ctl.cap, stream));
-        s->ctl_parity = 0;
-    }
-    s->ctl_clean = false; /* until this scan's record_sort_kernel has been queued */
-    uint32_t *blk = (uint32_t *)s->ctl.p + (s->ctl_parity ? half_words : 0);
-    args.ctl_other = (uint32_t *)s->ctl.p + (s->ctl_parity ? 0 : half_words);
-    args.ctl_other_words = (uint32_t)half_words;
-    args.rec_stage = (uint4 *)s->rec_stage.p;
-    args.rec_counts = blk;
-    args.rec_super = (unsigned long long *)(blk + super_ofs);
-    args.share_status = blk + status_ofs;
-    args.ticket = blk + ticket_ofs;
     /* Dense input (the reference's flood case, src/fdr/flood_runtime.h:86-335): once a scan on this scratch ran out of
      * candidate room (and told its caller to scan again), later scans give every 16-byte chunk an entry of its own -- the
      * two-phase path can then not overflow, at the price of a candidate buffer twice the size of the corpus. */
@@ -566,11 +532,58 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     const bool fold = two_phase && s->d_note && !s->tune_unfolded && !(s->cand_div == 16 && s->dense_unfolded);
     args.fold = fold ? (s->cand_div == 16 ? 2u : 1u) : 0u;
     if (args.fold == 2 && !(f_conf = hsgpu_confirm_kernel_for(h->flags, true))) return HSGPU_INVALID;
-    /* up to 256 supers: atomics on one address go one after the other (~0.1 us each). Unfolded: supers of 2^super_shift regions, one
-     * atomic per region (64 regions share one at 16 384 regions); folded: supers of SHARES, one atomic per share (16 per word) */
-    args.super_shift = fold ? 3 : 5;
-    while ((((fold ? n_waves : n_rec) + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
-    /* the regions fed by one filter wavefront: the records of one contiguous share of the corpus */
+    /* staged match records: one region per producing wavefront -- the confirm kernel's workers (two-phase) or the filter
+     * wavefronts (fused) --, packed into the caller's buffer in delivery order. 2x headroom over an even split. */
+    const uint32_t n_waves = grid * (wg_threads / 64);
+    uint32_t n_rec = n_waves * HSGPU_CONFIRM_SPLIT; /* the fused kernel uses the first n_waves of them */
+    unsigned conf_grid = 0;
+    args.conf_q = args.conf_k = 1;
+    if (two_phase) {
+        /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
+         * worker wavefront, so that the parts go round the workers the device holds at once as evenly as whole numbers allow
+         * (4 096 shares on 6 144 workers: Q = 3, K = 2). */
+        const uint64_t w_max = (uint64_t)confirm_resident_workgroups(s, f_conf) * (HSGPU_CONFIRM_THREADS / 64);
+        double best = -1;
+        for (uint32_t q = 1; q <= 8; q++) {
+            const uint64_t parts = (uint64_t)n_waves * q, k = (parts + w_max - 1) / w_max;
+            const double eff = (double)parts / (double)(k * w_max) - 1e-3 * q; /* the slots busy in steady state; ties: fewer parts */
+            if (eff > best) best = eff, args.conf_q = q, args.conf_k = (uint32_t)k;
+        }
+        const uint64_t workers = ((uint64_t)n_waves * args.conf_q + args.conf_k - 1) / args.conf_k;
+        conf_grid = (unsigned)((workers + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64));
+        n_rec = conf_grid * (HSGPU_CONFIRM_THREADS / 64);
+        if (!s->d_note) n_rec = std::max(n_rec, n_waves); /* (the fused kernel behind the confirm kernel writes one region per filter wavefront) */
+    }
+    args.rec_regions = n_rec;
+    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
+    if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
+    /* Two control blocks that alternate from scan to scan, each rec_counts[2 n_rec] | cand_counts[n_waves + 1] |
+     * rec_super[257] (64-bit): a scan works in one and its last kernel zeroes the other (the previous scan's), so
+     * the next scan finds its block zeroed without a memset. */
+    const size_t cand_ofs = (size_t)2 * n_rec;
+    const size_t super_ofs = (cand_ofs + n_waves + 1 + 1) & ~(size_t)1; /* 8-byte aligned */
+    const size_t blk_words = (super_ofs + 2 * HSGPU_SUPER_WORDS + 3) & ~(size_t)3;
+    /* a reallocated control buffer is garbage whatever its address: hipMalloc may hand the
+     * freed range straight back, so growth is detected by capacity, never by pointer */
+    const size_t ctl_cap_before = s->ctl.cap;
+    if ((rv = s->ctl.ensure(2 * blk_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    if (s->ctl.cap != ctl_cap_before) s->ctl_clean = false;
+    const size_t half_words = (s->ctl.cap / 8) & ~(size_t)3; /* the second block starts at the same place whatever this scan's size */
+    if (!s->ctl_clean) { /* a fresh (or possibly dirty) buffer: both blocks */
+        HIP_TRY(hipMemsetAsync(s->ctl.p, 0, s->ctl.cap, stream));
+        s->ctl_parity = 0;
+    }
+    s->ctl_clean = false; /* until this scan's record_sort_kernel has been queued */
+    uint32_t *blk = (uint32_t *)s->ctl.p + (s->ctl_parity ? half_words : 0);
+    args.ctl_other = (uint32_t *)s->ctl.p + (s->ctl_parity ? 0 : half_words);
+    args.ctl_other_words = (uint32_t)half_words;
+    args.rec_stage = (uint4 *)s->rec_stage.p;
+    args.rec_counts = blk;
+    args.rec_super = (unsigned long long *)(blk + super_ofs);
+    /* up to 256 supers of 2^super_shift regions, one atomic per region (atomics on one address go one after the other) */
+    args.super_shift = 5;
+    while (((n_rec + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
+    /* consecutive regions that one record_sort_kernel workgroup places (consecutive pieces of the corpus) */
     args.group_regions = HSGPU_CONFIRM_SPLIT;
     args.stats = (unsigned long long *)s->stats.p;
     args.overflow_note = s->d_note;
@@ -618,8 +631,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
-        /* persistent confirm workgroups: as many as the device holds at once, shares handed out by ticket */
-        HIP_TRY(hipLaunchKernel(f_conf, dim3(std::min<unsigned>(n_waves, confirm_resident_workgroups(s, f_conf))), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
+        /* the confirm kernel's workers: at most as many as the device holds at once */
+        HIP_TRY(hipLaunchKernel(f_conf, dim3(conf_grid), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
         /* No fused kernel behind it (it used to be launched on every scan, to return at once): a scan whose candidate regions
          * overflowed reports count = cap + 1 like one whose staging regions did -- "again" -- and sets the scratch's note,
          * so that the next scan has room for every chunk. Without the note (mapped host memory unavailable) the always-correct
@@ -627,10 +640,10 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if (!s->d_note) HIP_TRY(hipLaunchKernel(f_fused, dim3(grid), dim3(wg_threads), kargs, lds, stream));
     }
     if (s->timing) s->n_timed++;
-    /* unfolded: one workgroup per share of the corpus: its records sorted into place; the control block back to zero */
-    if (!fold)
-        HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions),
-                                dim3(s->cand_div == 16 ? 1024 : 256), kargs, 0, stream));
+    /* one workgroup per group of regions: its records into place (folded: gathered, the regions are sorted runs; else
+     * sorted); the control block back to zero */
+    HIP_TRY(hipLaunchKernel(hsgpu_record_sort_kernel(), dim3((n_rec + args.group_regions - 1) / args.group_regions),
+                            dim3(!fold && s->cand_div == 16 ? 1024 : 256), kargs, 0, stream));
     s->ctl_clean = true;
     s->ctl_parity ^= 1u;
     return HSGPU_SUCCESS;

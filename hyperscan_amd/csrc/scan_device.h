@@ -1493,7 +1493,8 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
     const uint32_t n = __shfl(incl, 63);
     const uint32_t my_at = lane < nreg ? incl - (my.x + my.y) : n;
     if (!n) return;
-    const bool in_lds = n <= SORT_LDS;
+    /* folded pipeline: the regions are consecutive sorted runs of the corpus -- gathered straight into place */
+    const bool in_lds = !args.fold && n <= SORT_LDS;
     /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
      * spilled to the back) */
     for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += NT) { /* whole wavefronts: shuffles below */
@@ -1507,6 +1508,7 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
             else out[base + i] = rec;
         }
     }
+    if (args.fold) return; /* (uniform) */
     __syncthreads();
     if (n <= 64) {
         /* rank by counting: one record per lane of the first wavefront, every lane walks the share
@@ -1573,7 +1575,7 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
 }
 
 /* Last kernel of a scan, every workgroup. The control words of THIS scan are read across workgroups (fills, sums,
- * tickets), so nobody can zero them here; instead every workgroup zeroes its slice of the OTHER control block, the one
+ * counts), so nobody can zero them here; instead every workgroup zeroes its slice of the OTHER control block, the one
  * the previous scan used and the next scan will use: no memset in front of any scan. Plus the cumulative statistics
  * for hsgpu_scratch_get_stats (1024 counters per workgroup: only a handful of workgroups touch the statistics word). */
 __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
@@ -1601,38 +1603,29 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
     }
 }
 
-/* ---- phase 2 (+ 3): confirm, order, placement -- one persistent kernel ------------------------------------------
- * A workgroup of HSGPU_CONFIRM_SPLIT wavefronts takes one SHARE at a time (= one filter wavefront's candidate region),
- * the first one by its own index, then in ticket order, until the tickets run out; the grid is what the device holds at
- * once (workgroups per CU x CUs), the 8 KiB key gate is staged once per workgroup. (Round 3 launched one short-lived
- * wavefront per part of a share and 16 384 more for the sort kernel.)
- *
- * The FOLDED pipeline (args.fold; the default) has no sort kernel behind it, and no sort either:
- *   parts     wavefront w of the workgroup confirms the w-th QUARTER of the share's candidate entries (whole batches of 128;
- *             the filter appended them in corpus order), so the four staging regions of a share hold consecutive pieces of
- *             the corpus, and so do consecutive shares
- *   in order  matches wait in the wavefront's LDS queue until a sync point -- more than SYNC_AT queued, or the part done:
- *             the entries with candidate bits left are confirmed first (so that no earlier position is still pending), then
- *             the queue is sorted on 64-bit keys {position, literal} by counting ranks (<= 128 keys, one or two per lane,
- *             every lane walks the queue through LDS broadcasts: ~1 us), resolved 64 at a time IN THAT ORDER and appended
- *             to the region. A region is therefore sorted by (block, end, literal) as it is written, and the concatenation
- *             of all regions is the delivery order. (A queue that overflows between two sync points -- more matches than
- *             candidate entries: dense input -- resolves in place, out of order; the scan then reports "again" and sends
- *             the scratch to dense mode, whose unfolded pipeline sorts whatever it is given.)
- *   publish   the wavefront adds {1 << 40 | records} to the sum of its region's "super" (2^super_shift consecutive
- *             regions, at most 256 supers) and stores the region's own status word {valid | records}: relaxed device-scope
- *             atomics, the words carry counts and nothing is read through them
- *   place     where a region's records go = the sums of the supers in front of its own (complete once their region count
- *             is full) + the status words of the regions in front of it inside its own super: two rounds of independent
- *             loads by the wavefront itself, then a plain copy of the region into the output. DEFERRED: a wavefront places
- *             its region only after confirming its part of the NEXT share, when the regions in front (lower tickets, taken
- *             earlier) have long been published -- nobody waits, and no workgroup barrier is involved (the one barrier per
- *             share hands out the ticket). Deadlock-free without assuming a resident grid: a wavefront only waits for
- *             lower regions, whose holders are running and publish before they wait for anybody.
- * The wavefront that places the last region knows the total and writes *count. Measured against the same kernel followed by
- * record_sort_kernel (profiles/r04_tail_*.txt). The unfolded pipeline (fused scans, dense mode) keeps round 3's schedule:
- * batches of a share dealt round-robin, matches resolved as they queue up, record_sort_kernel below. */
-constexpr uint32_t SPIN_LIMIT = 1u << 22; /* placement: a region in front that never publishes (cannot happen) ends the wait */
+/* ---- phase 2: confirm, in order -- one resident grid of worker wavefronts ------------------------------------------
+ * The grid is what the device holds at once (workgroups per CU x CUs); the 8 KiB key gate is staged once per workgroup, behind
+ * the kernel's only barrier. Every wavefront is a WORKER with conf_k consecutive PARTS of the corpus -- a share (= one filter
+ * wavefront's candidate region) cut into conf_q pieces of whole batches of 128 entries; runtime.hip picks the two numbers so
+ * that the parts go round the workers evenly (4 096 shares x 3 = 2 per worker on 6 144). Its records go to ONE staging region.
+ *   in order  (args.fold; the default) matches wait in the wavefront's LDS queue until a sync point -- more than SYNC_AT queued, or
+ *             the part done: the entries with candidate bits left are confirmed first (so that no earlier position is still
+ *             pending), then the queue is sorted on 64-bit keys {position, literal} by a bitonic network across the lanes,
+ *             resolved 64 at a time IN THAT ORDER and appended to the region. A region is therefore sorted by (block, end,
+ *             literal) as it is written, and the concatenation of all regions is the delivery order: record_sort_kernel
+ *             behind this kernel only gathers them into place. (A queue that overflows between two sync points resolves in
+ *             place, out of order; the scan then reports "again" and sends the scratch to dense mode.)
+ *   publish   the wavefront adds its fill to the sum of its region's "super" (2^super_shift consecutive regions, at most 256
+ *             supers): one relaxed atomic per worker; record_sort_kernel finds every group's place from <= 256 sums + the fills
+ *             in front of it inside its own super.
+ * History, all measured (profiles/r04_tail_*.txt, r04_confirm_fixed_cost.txt): round 3 launched one short-lived wavefront per
+ * part of a share. Round 4 first made the workgroups persistent with shares handed out by ticket, quarters per wavefront, and
+ * the placement done by the wavefronts themselves, deferred by one share so that nobody polled: equal to confirm + sort at
+ * 1 GiB, better at 8 GiB -- but a line fitted through 16 MiB .. 1 GiB showed 93 us of the 200 us stage there before the first
+ * candidate (2.67 rounds of ticket, barrier, final drain, publish, placement, copy per workgroup). Static parts per worker
+ * remove the rounds; placing in the same kernel then means every worker polling the sums until everybody in front has
+ * published (0.30 ms: 6 144 wavefronts on a few hundred words), so the placement went back to a kernel of its own, which for
+ * sorted regions is a plain gather: 16 MiB 118 -> 49 us, 1 GiB 0.512 -> 0.491 ms, teddy64 0.320 -> 0.281 ms. */
 constexpr uint32_t DENSE_AT = 48;    /* dense scans: candidate positions in a batch of 128 entries from which the batch goes position by position */
 constexpr uint32_t DENSE_POS = 128 * 16; /* ... the positions of a batch */
 constexpr uint32_t SYNC_AT = 48;          /* folded: queued matches that end a group of batches (the queue holds MQ_CAP = 128) */
@@ -1704,17 +1697,6 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t l
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-/* The kernel's argument block re-read from the kernarg segment at the point of use. The confirm step runs with every scalar
- * register taken (104 of 104: table pointers, descriptors, bounds); arguments that only the per-share bookkeeping needs
- * (tickets, sums, the output) would otherwise be loaded at kernel entry and held -- or rather spilled into vector
- * lanes and read back with v_readlane inside the step -- for the whole persistent loop. The empty asm hides where the
- * pointer comes from, so the loads stay behind it. (The kernel has one by-value argument: it starts the segment.) */
-__device__ __forceinline__ const HsgpuScanArgs &cold_args() {
-    const void *p = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return *(const HsgpuScanArgs *)p;
-}
-
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false, bool DENSE = false>
 __global__ __launch_bounds__(CONFIRM_THREADS)
 #ifndef HSGPU_CONFIRM_WAVES
@@ -1729,30 +1711,12 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __shared__ WaveLds wave_lds[W];
     __shared__ uint2 rest_q[W][RQ_CAP];
     __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
-    __shared__ uint32_t s_share[2], s_fills[2][W]; /* (the ticket alternates between two words: written for round k + 1 while a slow wavefront may not have read round k's yet) */
-    __shared__ unsigned long long s_bases[2][W];
-    __shared__ uint32_t s_sup_n;            /* placement: the supers [0, s_sup_n) are complete and add up to s_sup_sum */
-    __shared__ unsigned long long s_sup_sum;
-    __shared__ uint32_t s_sum[2], s_done[2], s_placer[2]; /* the round's share: records so far, wavefronts done; wavefronts past their quarter */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fold = args.fold != 0;
     constexpr bool dense = DENSE; /* (an instantiation of its own, scan_inst_dense.hip: the position-parallel path costs the ordinary kernel registers it does not have) */
     const uint32_t n_shares = args.cand_waves;
-    if (args.cand_counts[n_shares]) { /* candidate overflow: nothing was confirmed, the total is unknown */
-        if (!fold) return;             /* the kernels behind this one report (or redo the scan) */
-        if (blockIdx.x == 0 && tid == 0) {
-            /* cap + 1 ("again"), and the word in mapped host memory that makes the next scan on this scratch give every
-             * chunk an entry of its own */
-            *args.count = args.cap + 1;
-            if (args.overflow_note) *args.overflow_note = 1u;
-            if (args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64();
-            if (args.tstamp_next) args.tstamp_next[0] = ~0ull, args.tstamp_next[1] = args.tstamp_next[2] = args.tstamp_next[3] = 0;
-        }
-        scan_epilogue(args);
-        return;
-    }
-    if (tid == 0) s_sup_n = 0, s_sup_sum = 0;
+    if (args.cand_counts[n_shares]) return; /* candidate overflow: nothing is confirmed, the total is unknown; record_sort_kernel reports ("again") */
     const bool gated = !PAIR && (args.t_flags & HSGPU_F_GATE);
     if (gated) { /* once per workgroup */
         const uint4 *src = (const uint4 *)(args.blob + args.t_off_c2bits);
@@ -1774,144 +1738,38 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         rs.lits = __builtin_amdgcn_make_buffer_rsrc((void *)t.lits, 0, (int)0x7ffffff0, 0x00020000);
     }
 
-    /* Folded pipeline, wavefront 0 of the workgroup: where share p's records go -- the supers in front of its own (complete
-     * once their share count is full), then the shares in front of it inside its own super: at most 256 + 15 relaxed loads
-     * in two rounds, spinning only while a share in front is still being confirmed. The four regions' own places (the fills
-     * of the share's wavefronts are in LDS) go to LDS for the copy after the next barrier. */
-    auto place_share = [&](uint32_t p, const uint32_t *fills, unsigned long long *bases) {
-        const HsgpuScanArgs &args = cold_args(); /* (shadows the kernel's: see cold_args) */
-        const uint32_t ss = args.super_shift, S = p >> ss;
-        unsigned long long before = 0;
-        uint32_t spins = 0;
-        bool bad = false;
-        /* The sums of the supers in front: a super that is complete never changes, so the workgroup keeps in LDS how many of them
-         * it has added up already and their sum (s_sup_n, s_sup_sum; one placer per round, the round's barrier in between) and
-         * reads only the new ones -- ~96 per placement instead of all S: with every placement reading all of them, 1.3 M polls
-         * of the same 2 KiB took 65 us of the stage (profiles/r04_tail_fold_components_ab.txt). The super words are 64 bytes
-         * apart for the same reason. First try: every word once, all loads in flight together (one round trip when everything
-         * in front has been published, which the deferral makes the rule). */
-        const uint32_t S0 = min(s_sup_n, S);
-        unsigned long long cached = s_sup_sum;
-        {
-            unsigned long long sv[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                sv[k] = __hip_atomic_load(&args.rec_super[HSGPU_SUPER(min(S0 + lane + 64u * k, 255u))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t i0 = (S << ss) + lane;
-            const uint32_t st = __hip_atomic_load(&args.share_status[min(i0, n_shares - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool ok = ss <= 6; /* (supers of more than 64 shares: only grids beyond 16 384 filter wavefronts) */
-            unsigned long long fresh = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (S0 + lane + 64u * k < S) ok = ok && (uint32_t)(sv[k] >> 40) == (1u << ss), fresh += sv[k] & ((1ull << 40) - 1);
-            if (__ballot(!ok) == 0) {
-                if (i0 < p) ok = (st >> 31) != 0, before = st & 0x7fffffffu;
-                if (__ballot(!ok) == 0) {
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) fresh += __shfl_xor(fresh, d);
-                    cached += fresh;
-                    if (lane == 0) s_sup_n = S, s_sup_sum = cached; /* all of [0, S) complete and added up */
-                    if (lane == 0) before += cached;
-                    goto placed;
-                }
-            }
-            before = 0;
-        }
-        /* somebody in front is still confirming: poll, word by word */
-        if (lane == 0) before = cached;
-        for (uint32_t i = S0 + lane; i < S; i += 64) { /* the supers in front not added up yet: all of them full ones */
-            unsigned long long v;
-            for (;;) {
-                v = __hip_atomic_load(&args.rec_super[HSGPU_SUPER(i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(v >> 40) == (1u << ss) || bad) break;
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > SPIN_LIMIT) bad = true;
-            }
-            before += v & ((1ull << 40) - 1);
-        }
-        for (uint32_t i = (S << ss) + lane; i < p; i += 64) { /* the shares in front inside its own super */
-            uint32_t v;
-            for (;;) {
-                v = __hip_atomic_load(&args.share_status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 31) || bad) break;
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > SPIN_LIMIT) bad = true;
-            }
-            before += v & 0x7fffffffu;
-        }
-    placed:
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
-        const bool any_bad = __ballot(bad) != 0;
-        if (lane == 0) {
-            if (any_bad) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull);
-            unsigned long long at = before;
-            for (uint32_t w = 0; w < W; w++) bases[w] = at, at += fills[w];
-            if (p + 1 == n_shares) {
-                /* the last share: the total is known. A region that ran out of space lost records; its fill counter kept
-                 * counting, so the total is still exact: report it, but never a value <= cap (that would claim the output is
-                 * complete). The same word says that some wavefront had to emit out of order: again, in dense mode. */
-                const unsigned long long flag =
-                    __hip_atomic_load(&args.rec_super[HSGPU_SUPER_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (any_bad ? 1ull : 0ull);
-                *args.count = (flag && at <= args.cap) ? args.cap + 1 : at;
-                if ((flag >> 32) && args.overflow_note) *args.overflow_note = 1u; /* more matches than the queue orders: dense mode next */
-            }
-        }
-    };
-    /* every wavefront: its (sorted) region of a placed share into the output */
-    auto copy_region = [&](uint32_t p, uint32_t n_p, unsigned long long base) {
-        const HsgpuScanArgs &args = cold_args();
-        if (n_p && n_p <= args.rec_cap && base + n_p <= args.cap) { /* (a region that lost records is left alone: the scan says "again") */
-            const uint4 *region = args.rec_stage + (uint64_t)(p * W + wave) * args.rec_cap;
-            uint4 *out = (uint4 *)args.out + base;
-            for (uint32_t i = lane; i < n_p; i += 64) out[i] = region[i];
-        }
-        if (p + 1 == n_shares && tid == 0 && args.tstamp) args.tstamp[2] = args.tstamp[3] = wall_clock64(); /* (the scan is as good as done) */
-    };
-
-    /* share confirmed in the iteration before (to be placed by wavefront 0 in this one), share placed in the iteration before
-     * (its bases in s_bases[slot]: to be copied in this one); this wavefront's fills of the two */
-    uint32_t conf_p = ~0u, conf_n = 0, placed_p = ~0u, placed_n = 0, slot = 0, round = 0;
-    for (;; round ^= 1) {
-        /* Every share by ticket, the first one too. (Taking the workgroup's own index first saves the burst of 1 536 atomics on
-         * one word at the start, and deadlocks: a workgroup placing its second share waits for ALL lower shares, also the
-         * first shares of workgroups that have not been started yet -- beside another scan's filter kernel the grid is not
-         * resident as a whole -- while they wait for a slot that only an exit frees. With tickets a share has a holder only
-         * once that holder runs.) */
-        if (tid == 0) {
-            s_share[round] = __hip_atomic_fetch_add(cold_args().ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_sum[slot] = 0, s_done[slot] = 0, s_placer[slot] = 0; /* (this round's: last used two rounds ago) */
-        }
-        __syncthreads(); /* (also: the gate is staged; the fills and bases of the rounds before are in LDS) */
-        const uint32_t r = __builtin_amdgcn_readfirstlane(s_share[round]); /* (an LDS read is a vector value to the compiler: everything derived from it would be) */
-        if (fold && placed_p != ~0u) { /* placed by wavefront 0 before the barrier: every wavefront copies its own region */
-            copy_region(placed_p, placed_n, rfl64(s_bases[slot ^ 1][wave]));
-            placed_p = ~0u;
-        }
-        if (r >= n_shares) break;
-        const uint32_t cw = r * W + wave; /* this wavefront's record region */
+    __syncthreads(); /* the gate is staged: the only barrier of the kernel */
+    /* Every wavefront is a WORKER with K consecutive parts of the corpus: share r = one filter wavefront's candidates, cut into Q
+     * parts of whole batches (runtime.hip picks Q and K so that the parts go round the workers the device holds: 4 096 shares x 3
+     * = 2 per worker on 6 144). No tickets, no barrier per share, ONE publish / place / copy per worker: with shares handed out by
+     * ticket to workgroups (quarters per wavefront, a barrier, a publish and a placement per share, 2.67 rounds of them) the stage
+     * cost 93 us before the first candidate -- 96 us for 16 MiB, 200 for 1 GiB (profiles/r04_confirm_fixed_cost.txt). Workers are
+     * numbered by blockIdx: a worker waits only for LOWER workers, which were dispatched before it (in order per XCD), so
+     * nobody waits for a workgroup that needs somebody's exit to start. */
+    const uint32_t worker = blockIdx.x * W + wave;
+    const uint32_t Q = args.conf_q, K = args.conf_k, n_parts = n_shares * Q;
+    init_wave_lds(t, &wave_lds[wave], lane);
+    t.rec_region = args.rec_stage + (uint64_t)worker * args.rec_cap;
+    for (uint32_t part = worker * K; part < min(n_parts, worker * K + K); part++) {
+        const uint32_t r = part / Q, q = part - r * Q;
         const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
-        /* this wavefront's entries [base, end) in steps of `stride`: folded -- the w-th quarter of the share's batches of 128,
-         * so that the four regions are consecutive pieces of the corpus; unfolded -- batches wave, wave + W, ... */
+        /* this part's entries [base, end): the q-th of Q pieces of the share's batches of 128, consecutive pieces of the corpus */
         const uint32_t nb = (n + 127) >> 7;
-        uint32_t base = fold ? (wave * nb / W) << 7 : wave << 7;
-        const uint32_t end = fold ? min(n, ((wave + 1) * nb / W) << 7) : n;
-        const uint32_t stride = fold ? 128u : 128u * W;
-        init_wave_lds(t, &wave_lds[wave], lane);
-        uint32_t fill = 0;
-        uint64_t edge = 0; /* pair tables, the share's last wavefront: the next share's first byte, when that share exists */
+        uint32_t base = (q * nb / Q) << 7;
+        const uint32_t end = min(n, ((q + 1) * nb / Q) << 7);
+        const uint32_t stride = 128u;
+        uint64_t edge = 0; /* pair tables, the share's last part: the next share's first byte, when that share exists */
         if (PAIR && HAS_B) {
             const uint64_t n_full = args.total >> 10, per = (n_full + n_shares - 1) / n_shares;
             t.share_start = min(n_full, (uint64_t)r * per) << 10;
             const uint64_t next = min(n_full, ((uint64_t)r + 1) * per);
-            /* (the wavefront that holds the share's last entries -- the ends in question sort among its records; a share without
-             * entries: the last wavefront) */
-            const bool owner = n ? (base < end && end == n) : wave == W - 1;
+            /* (the part that holds the share's last entries -- the ends in question sort among its records; a share without
+             * entries: its last part) */
+            const bool owner = n ? (base < end && end == n) : q == Q - 1;
             if (owner && next < n_full && next > (t.share_start >> 10)) edge = next << 10;
             t.late_skip = ~0ull;
         }
-        if (base < end || edge) { /* else nothing for this wavefront: its record counts stay zero */
-            t.rec_region = args.rec_stage + (uint64_t)cw * args.rec_cap;
+        if (base < end || edge) { /* else nothing in this part */
             const uint4 *region = args.cand + 2ull * r * args.cand_cap;
             if (PAIR && HAS_B) {
                 /* unfolded: queued here, sorted with everything else by record_sort_kernel. Folded: before the drain that the end in
@@ -2049,54 +1907,14 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                 }
             }
             if (!fold) drain_matches(t, lane, 0);
-            fill = publish_records(t, args, lane, cw, !fold);
-            if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32); /* emitted out of order: "again", in dense mode */
-        }
-        if (fold) {
-            const HsgpuScanArgs &args = cold_args();
-            /* (Relaxed device-scope atomics throughout: the words carry counts, nothing is read through them. With
-             * release / acquire semantics every publish wrote the whole L2 back (buffer_wbl2) and every poll invalidated it
-             * (buffer_inv): the stage took 0.55 ms instead of 0.16.) */
-            const uint32_t n_r = min(fill, 0x1fffffffu);
-            if (lane == 0) {
-                /* publish, once per SHARE: the wavefront that finishes its quarter last (a count in LDS tells it) adds the share's
-                 * records to the sum of the share's super and stores the share's own word. (Published per region, a super took 64
-                 * atomics in a burst, a hyper level above it 1 024: same-address atomics go one after the other, ~0.1 us each, and
-                 * the polls of that word queue up behind them -- the stage took 0.55 ms.) */
-                s_fills[slot][wave] = n_r;
-                __hip_atomic_fetch_add(&s_sum[slot], n_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__hip_atomic_fetch_add(&s_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == W - 1) {
-                    const uint32_t tot = __hip_atomic_load(&s_sum[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&args.rec_super[HSGPU_SUPER(r >> args.super_shift)], (1ull << 40) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&args.share_status[r], 0x80000000u | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            /* DEFERRED by one share: the share confirmed in the iteration before is placed now (its fills went to LDS before
-             * this iteration's barrier) -- by the wavefront that finishes its quarter FIRST, which would otherwise only wait at
-             * the barrier -- and copied by everybody after the next barrier */
-            uint32_t placer = 0;
-            if (lane == 0) placer = __hip_atomic_fetch_add(&s_placer[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (conf_p != ~0u && __builtin_amdgcn_readfirstlane(placer) == 0) place_share(conf_p, s_fills[slot ^ 1], s_bases[slot]);
-            placed_p = conf_p, placed_n = conf_n;
-            conf_p = r, conf_n = n_r;
-            slot ^= 1;
         }
     }
-    if (fold) {
-        /* the tickets have run out (the barrier at the top of the last round has been passed, the share placed before it copied):
-         * place the last share confirmed, copy it */
-        if (conf_p != ~0u && wave == 0) place_share(conf_p, s_fills[slot ^ 1], s_bases[slot]);
-        __syncthreads();
-        if (conf_p != ~0u) copy_region(conf_p, conf_n, rfl64(s_bases[slot][wave]));
-        const HsgpuScanArgs &args = cold_args();
-        if (blockIdx.x == 0 && tid == 0 && args.tstamp_next) {
-            args.tstamp_next[0] = ~0ull;
-            args.tstamp_next[1] = 0;
-            args.tstamp_next[2] = 0;
-            args.tstamp_next[3] = 0;
-        }
-        scan_epilogue(args);
-    }
+    /* the worker's region is complete (in delivery order when folded): its fill, once, added to the sum of its super. Placing
+     * the regions is record_sort_kernel's (folded: a gather, the regions are consecutive sorted runs). (Placed by the workers
+     * themselves -- every worker polling the sums until everybody in front had published -- the stage took 0.30 ms instead of
+     * 0.15: 6 144 wavefronts polling the same few hundred words, the publishing atomics queued behind the polls.) */
+    publish_records(t, args, lane, worker, true);
+    if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32); /* emitted out of order: "again", in dense mode */
 }
 
 /* ---- phase 3 as a kernel of its own: fused scans and dense mode -------------------------------
@@ -2156,7 +1974,8 @@ __global__ __launch_bounds__(1024) void record_sort_kernel(HsgpuScanArgs args) {
                  * Candidate overflow: nothing was confirmed, the total is unknown: cap + 1 ("again"), and the word in
                  * mapped host memory that makes the next scan on this scratch give every chunk an entry of its own. */
                 *args.count = (flag && all <= args.cap) ? args.cap + 1 : all;
-                if (args.cand_counts && args.cand_counts[args.cand_waves] && args.overflow_note) *args.overflow_note = 1u;
+                /* ... and so does the folded pipeline when a wavefront had to emit out of order (bits 32+ of the flags word): dense mode next */
+                if (args.overflow_note && ((args.cand_counts && args.cand_counts[args.cand_waves]) || (flag >> 32))) *args.overflow_note = 1u;
                 if (args.tstamp) args.tstamp[2] = wall_clock64(); /* the stages before the sort are done */
             }
         }

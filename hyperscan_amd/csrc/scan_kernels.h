@@ -54,12 +54,13 @@ struct HsgpuScanArgs {
     unsigned long long *rec_super;
     uint32_t super_shift;
     uint32_t group_regions;     /* consecutive regions that hold the records of one filter workgroup's corpus share */
-    /* the folded pipeline (hwlm_confirm_kernel emits in order and places; no record_sort_kernel behind it): a word of
-     * rec_super then is {shares published << 40 | their records} over 2^super_shift consecutive SHARES; [256] = regions that
-     * lost records + (regions emitted out of order) << 32 */
+    /* the folded pipeline: hwlm_confirm_kernel emits every region in delivery order (sorted drains) and record_sort_kernel only
+     * gathers them (1; 2 = dense scan: dense batches position by position); 0 = regions in any order, sorted by record_sort_kernel.
+     * rec_super[256] = regions that lost records + (regions emitted out of order) << 32 */
     uint32_t fold;
-    uint32_t *ticket;           /* the next share to confirm (persistent confirm workgroups take shares in ticket order) */
-    uint32_t *share_status;     /* [cand_waves] {valid << 31 | records of the share}, written once all its parts are confirmed */
+    /* the confirm kernel's partition: every share (= one filter wavefront's candidates) in conf_q parts of whole batches, conf_k
+     * consecutive parts per worker wavefront; rec_regions = its workers */
+    uint32_t conf_q, conf_k;
     /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
      * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */
     uint32_t *ctl_other;
