@@ -415,6 +415,20 @@ extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsi
     return HSGPU_SUCCESS;
 }
 
+extern "C" unsigned hsgpu_confirm_partition(unsigned n_shares, unsigned max_workers, unsigned *q_out, unsigned *k_out) {
+    if (!n_shares || !max_workers) return 0;
+    double best = -1;
+    unsigned bq = 1, bk = 1;
+    for (unsigned q = 1; q <= 8; q++) {
+        const uint64_t parts = (uint64_t)n_shares * q, k = (parts + max_workers - 1) / max_workers;
+        const double eff = (double)parts / (double)(k * max_workers) - 1e-3 * q; /* the slots busy in steady state; ties: fewer parts */
+        if (eff > best) best = eff, bq = q, bk = (unsigned)k;
+    }
+    if (q_out) *q_out = bq;
+    if (k_out) *k_out = bk;
+    return (unsigned)(((uint64_t)n_shares * bq + bk - 1) / bk);
+}
+
 /* how many confirm workgroups the device holds at once (per kernel instantiation: the register count differs) */
 static unsigned confirm_resident_workgroups(hsgpu_scratch *s, const void *f_conf) {
     static std::mutex mu;
@@ -542,14 +556,10 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
          * worker wavefront, so that the parts go round the workers the device holds at once as evenly as whole numbers allow
          * (4 096 shares on 6 144 workers: Q = 3, K = 2). */
-        const uint64_t w_max = (uint64_t)confirm_resident_workgroups(s, f_conf) * (HSGPU_CONFIRM_THREADS / 64);
-        double best = -1;
-        for (uint32_t q = 1; q <= 8; q++) {
-            const uint64_t parts = (uint64_t)n_waves * q, k = (parts + w_max - 1) / w_max;
-            const double eff = (double)parts / (double)(k * w_max) - 1e-3 * q; /* the slots busy in steady state; ties: fewer parts */
-            if (eff > best) best = eff, args.conf_q = q, args.conf_k = (uint32_t)k;
-        }
-        const uint64_t workers = ((uint64_t)n_waves * args.conf_q + args.conf_k - 1) / args.conf_k;
+        const unsigned w_max = confirm_resident_workgroups(s, f_conf) * (HSGPU_CONFIRM_THREADS / 64);
+        unsigned q = 1, k = 1;
+        const unsigned workers = hsgpu_confirm_partition(n_waves, w_max, &q, &k);
+        args.conf_q = q, args.conf_k = k;
         conf_grid = (unsigned)((workers + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64));
         n_rec = conf_grid * (HSGPU_CONFIRM_THREADS / 64);
         if (!s->d_note) n_rec = std::max(n_rec, n_waves); /* (the fused kernel behind the confirm kernel writes one region per filter wavefront) */

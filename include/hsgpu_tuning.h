@@ -29,7 +29,8 @@ extern "C" {
 /* Launch geometry / pipeline of the scans on one scratch, for tests that must cover every pipeline and for tuning
  * runs (the library reads no environment variables): fused_only == 1 runs the always-correct fused kernel alone
  * (normally the overflow fallback), fused_only == 2 the two-phase pipeline with record_sort_kernel as a kernel of its own
- * behind the confirm kernel (what dense mode runs; by default the confirm workgroups place and sort); wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the
+ * sorting behind the confirm kernel (regions in any order, sorted there; by default the confirm workers emit in delivery order and the
+ * kernel behind them only gathers); wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the
  * workgroup size / workgroups per CU the runtime would choose (0 = its choice). */
 int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu);
 
@@ -37,6 +38,11 @@ int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_thr
  * scan's stamps in milliseconds from the earliest start: out[4 w + {0 start, 1 image staged and hints written, 2 wavefront 0's
  * share streamed, 3 end}], w < min(*n_wgs, max_wgs). Synchronises the device. */
 int hsgpu_scratch_get_wg_stamps(hsgpu_scratch_t *s, float *out, unsigned max_wgs, unsigned *n_wgs);
+
+/* The confirm kernel's partition (csrc/runtime.hip): n_shares candidate regions (one per filter wavefront), each cut into *q parts
+ * of whole batches, *k consecutive parts per worker wavefront, for a device that holds max_workers of them at once: the pair that
+ * keeps most worker slots busy with every worker getting the same number of parts. Returns the workers used. Host arithmetic only. */
+unsigned hsgpu_confirm_partition(unsigned n_shares, unsigned max_workers, unsigned *q, unsigned *k);
 
 /* The first 32 hex digits of the sha256 over the sources this library was built from (csrc/Makefile, STAMPED): the built
  * library is not in the repository, and a test compares this with the tree it runs in. */

@@ -44,6 +44,27 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/hs_gpu.h but not exported"
 
 
+def test_confirm_partition_covers_every_part_and_fits_the_device():
+    """hsgpu_confirm_partition (the confirm kernel's static parts per worker, csrc/runtime.hip): every part has a worker, no
+    more workers than the device holds, and the common geometries get what DESIGN 4.7 says."""
+    import ctypes as C
+    lib = _native.load_library()
+    f = lib.hsgpu_confirm_partition
+    f.restype = C.c_uint
+    f.argtypes = [C.c_uint, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    q, k = C.c_uint(), C.c_uint()
+    for shares in [1, 3, 16, 255, 1024, 4096, 6144, 8192, 16384, 65536, 100003]:
+        for w_max in [4, 1024, 4096, 6144, 8192]:
+            workers = f(shares, w_max, C.byref(q), C.byref(k))
+            parts = shares * q.value
+            assert 1 <= q.value <= 8 and k.value >= 1
+            assert workers <= w_max, (shares, w_max, workers)
+            assert workers * k.value >= parts > (workers - 1) * k.value, (shares, w_max, q.value, k.value, workers)
+    assert (f(4096, 6144, C.byref(q), C.byref(k)), q.value, k.value) == (6144, 3, 2)
+    assert (f(6144, 6144, C.byref(q), C.byref(k)), q.value, k.value) == (6144, 1, 1)
+    assert f(0, 6144, C.byref(q), C.byref(k)) == 0
+
+
 def test_hs_compile_errors_without_gpu():
     """Compile-side argument and syntax checks of the hs_* facade need no GPU."""
     from hyperscan_amd import hs
