@@ -1703,7 +1703,7 @@ __global__ __launch_bounds__(CONFIRM_THREADS)
 #define HSGPU_CONFIRM_WAVES 6
 #endif
 /* Registers capped for six wavefronts per SIMD (80): what the kernel's LDS admits (six workgroups per CU). The scheduler has no
- * occupancy target of its own here and takes 94-98 registers for the persistent loop -- five wavefronts; capped, the 4-byte-key
+ * occupancy target of its own here and takes 94-98 registers for the worker's loop -- five wavefronts; capped, the 4-byte-key
  * variants keep everything in registers and the others spill a few dwords outside the confirm step (tools/kernel_regs.sh). */
 __attribute__((amdgpu_waves_per_eu(HSGPU_CONFIRM_WAVES, 8)))
 void hwlm_confirm_kernel(HsgpuScanArgs args) {
@@ -1741,11 +1741,9 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     __syncthreads(); /* the gate is staged: the only barrier of the kernel */
     /* Every wavefront is a WORKER with K consecutive parts of the corpus: share r = one filter wavefront's candidates, cut into Q
      * parts of whole batches (runtime.hip picks Q and K so that the parts go round the workers the device holds: 4 096 shares x 3
-     * = 2 per worker on 6 144). No tickets, no barrier per share, ONE publish / place / copy per worker: with shares handed out by
-     * ticket to workgroups (quarters per wavefront, a barrier, a publish and a placement per share, 2.67 rounds of them) the stage
-     * cost 93 us before the first candidate -- 96 us for 16 MiB, 200 for 1 GiB (profiles/r04_confirm_fixed_cost.txt). Workers are
-     * numbered by blockIdx: a worker waits only for LOWER workers, which were dispatched before it (in order per XCD), so
-     * nobody waits for a workgroup that needs somebody's exit to start. */
+     * = 2 per worker on 6 144). No tickets, no barrier per share, ONE publish per worker, and nobody waits for anybody: with shares
+     * handed out by ticket to workgroups (quarters per wavefront, a barrier, a publish and a placement per share, 2.67 rounds of
+     * them) the stage cost 93 us before the first candidate -- 96 us for 16 MiB, 200 for 1 GiB (profiles/r04_confirm_fixed_cost.txt). */
     const uint32_t worker = blockIdx.x * W + wave;
     const uint32_t Q = args.conf_q, K = args.conf_k, n_parts = n_shares * Q;
     init_wave_lds(t, &wave_lds[wave], lane);
@@ -1773,7 +1771,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             const uint4 *region = args.cand + 2ull * r * args.cand_cap;
             if (PAIR && HAS_B) {
                 /* unfolded: queued here, sorted with everything else by record_sort_kernel. Folded: before the drain that the end in
-                 * question sorts into (below); a quarter that does not start the share starts behind somebody's frontier */
+                 * question sorts into (below); a part that does not start the share starts behind somebody's frontier */
                 if (!fold && edge && lane == 0) pair_edge_probe<true>(t, edge);
                 if (fold && base && base < end) t.late_skip = (uint64_t)((const uint32_t *)region)[8ull * base] * CHUNK;
             }
