@@ -1628,7 +1628,10 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
  * sorted regions is a plain gather: 16 MiB 118 -> 49 us, 1 GiB 0.512 -> 0.491 ms, teddy64 0.320 -> 0.281 ms. */
 constexpr uint32_t DENSE_AT = 48;    /* dense scans: candidate positions in a batch of 128 entries from which the batch goes position by position */
 constexpr uint32_t DENSE_POS = 128 * 16; /* ... the positions of a batch */
-constexpr uint32_t SYNC_AT = 48;          /* folded: queued matches that end a group of batches (the queue holds MQ_CAP = 128) */
+#ifndef HSGPU_SYNC_AT
+#define HSGPU_SYNC_AT 48 /* tuning builds */
+#endif
+constexpr uint32_t SYNC_AT = HSGPU_SYNC_AT;          /* folded: queued matches that end a group of batches (the queue holds MQ_CAP = 128) */
 static_assert(CONFIRM_THREADS / 64 == HSGPU_CONFIRM_SPLIT, "one wavefront per part of a share");
 
 /* A queued match IS its sort key: {position (< 2^36) << 24 | literal index (< 2^24)} -- delivery order is (block, end,
