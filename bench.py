@@ -270,8 +270,8 @@ def parity_gate(recs, gate, lits):
 
 
 def gpu_vs_gpu_gate(job):
-    """The whole resident corpus, every record: the default pipeline (confirm wavefronts emit in order and place their
-    regions themselves) against the always-correct fused pipeline + record_sort_kernel on a second scratch -- the two share
+    """The whole resident corpus, every record: the default pipeline (confirm workers emit their regions in delivery order,
+    a gather kernel places them) against the always-correct fused pipeline + record_sort_kernel on a second scratch -- the two share
     the filter's arithmetic and nothing of what follows it. Identical arrays, element for element, or the bench stops."""
     torch = job.torch
     other = GpuJob(None, None, None, torch.cuda.current_device(), sibling=job, cap=4 * job.cap)  # (the fused kernel stages per filter wavefront: a quarter of the regions)

@@ -161,9 +161,9 @@ int hsgpu_hwlm_scan_dev(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d
  * hsgpu_scratch_get_timing synchronises the device and returns, for the scan `back`
  * launches ago (0 = the last), the filter kernel's duration between the two events, and --
  * from the device clock -- the confirm stage (filter end to confirm end) and the whole
- * pipeline (filter start to the end of the scan's last kernel), in milliseconds. (Default pipeline: the confirm
- * workgroups also place and sort, both spans end when the last share of the corpus has been sorted into the output;
- * dense mode / fused scans, whose record sort is a kernel of its own: the spans end where that kernel starts.) */
+ * pipeline (filter start to the end of the scan's last kernel), in milliseconds. (The confirm stage's span ends where the
+ * kernel that places the records starts -- a gather behind the default pipeline, whose confirm workers emit in delivery
+ * order; a sort behind fused scans -- the pipeline's where that kernel's first workgroup ends.) */
 int hsgpu_scratch_enable_timing(hsgpu_scratch_t *s, int enable);
 int hsgpu_scratch_get_timing(hsgpu_scratch_t *s, unsigned back, float *filter_ms, float *confirm_ms,
                              float *total_ms);
