@@ -303,6 +303,7 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
         /* the class sequences: distinct classes, patterns as indices into them */
         for (size_t k = 0; k < d->cseq.size(); k++) {
             const ClassSeq &c = d->cseq[k];
+            if (c.quiet) continue; /* (reports nothing: not evaluated at all -- advisor, round 3) */
             auto class_index = [&](const ByteSet &bs) {
                 hsgpu_class_t hc;
                 memset(&hc, 0, sizeof(hc));

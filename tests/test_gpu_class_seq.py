@@ -162,3 +162,23 @@ def test_hs_class_sequences_only_database_batch_singlematch_and_serialisation():
             w3 = _re_events([r"[^\n]{3,}[\n]+"], [3], chunk)
             assert got.get(blk, []) == sorted(want + w2 + w3, key=lambda e: (e[1], e[0])), blk
     assert hs.expression_info(r"[a-z]{3,}\d+") == (4, 0xffffffff)
+
+
+def test_hs_quiet_class_sequence_is_not_evaluated_and_reports_nothing():
+    """HS_FLAG_QUIET on a class sequence: no event for it (src/hs.h: "ignore match reporting for this expression"), the
+    other patterns unaffected; a database whose class sequences are all quiet scans with its literals alone."""
+    from hyperscan_amd import hs
+
+    pats = [r"[a-z]{3,}\d+", r"\s+[A-Z]{2,}", r"bar"]
+    rng = np.random.default_rng(8)
+    data = bytes(rng.choice(np.frombuffer(b"abcxyz0123 ABC\nbar", np.uint8), 4000))
+    import re
+
+    bars = [(3, m.start() + 3) for m in re.finditer(rb"(?=bar)", data)]
+    for flags, want in (([hs.HS_FLAG_QUIET, 0, 0], sorted(set(_re_events([pats[1]], [2], data) + bars), key=lambda e: (e[1], e[0]))),
+                        ([hs.HS_FLAG_QUIET, hs.HS_FLAG_QUIET, 0], bars)):
+        db = hs.Database.compile(pats, flags, [1, 2, 3])
+        scratch = hs.HsScratch(db)
+        got = []
+        assert hs.scan(db, data, scratch, lambda i, f, t: got.append((i, t)) and False) == hs.HS_SUCCESS
+        assert got == want
