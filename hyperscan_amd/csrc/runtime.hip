@@ -1086,7 +1086,10 @@ extern "C" int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *
     }
     InUse guard(s);
     if (!guard.ok) return HSGPU_SCRATCH_IN_USE;
-    if (!chunk_bytes) chunk_bytes = (size_t)64 << 20;
+#ifndef HSGPU_CHUNK_MIB
+#define HSGPU_CHUNK_MIB 64 /* tuning builds */
+#endif
+    if (!chunk_bytes) chunk_bytes = (size_t)HSGPU_CHUNK_MIB << 20;
     std::vector<size_t> cuts; /* block indices: chunk i = blocks [cuts[i], cuts[i + 1]) */
     try {
         cuts.push_back(0);
