@@ -21,6 +21,9 @@
 #include "../../include/hs_gpu.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include "hs_pattern.h"
 #include "internal.h"
 
@@ -72,8 +75,81 @@ static inline const hs_database *resolve_db(const hs_database_t *db) {
     return db;
 }
 
+/* The host confirm's worker threads, kept for the life of a scratch: hs_scan_batch's chunked pipeline confirms one chunk of the
+ * batch after the other, and starting (and joining) the threads for every chunk was ~0.4 ms of each chunk's budget -- with
+ * chunks smaller than 64 MiB the confirm stopped hiding behind the next chunk's copy. run(jobs, f): f(0 .. jobs - 1)
+ * on the workers and the calling thread; returns when all are done. f must not throw. */
+class WorkerPool {
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_idle_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned jobs_ = 0, active_ = 0;
+    unsigned long long run_ = 0;
+    std::atomic<unsigned> next_{0};
+    bool stop_ = false;
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *f;
+            unsigned jobs;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return stop_ || run_ != seen; });
+                if (stop_) return;
+                seen = run_;
+                f = fn_, jobs = jobs_;
+                active_++;
+            }
+            for (unsigned j; (j = next_.fetch_add(1, std::memory_order_relaxed)) < jobs;) (*f)(j);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--active_ == 0) cv_idle_.notify_all();
+            }
+        }
+    }
+
+public:
+    size_t size() const { return threads_.size(); }
+    void ensure(unsigned n) { /* (a thread that cannot be started is done without) */
+        try {
+            while (threads_.size() < n) threads_.emplace_back([this] { loop(); });
+        } catch (...) {
+        }
+    }
+    void run(unsigned jobs, const std::function<void(unsigned)> &f) {
+        if (threads_.empty() || jobs <= 1) {
+            for (unsigned j = 0; j < jobs; j++) f(j);
+            return;
+        }
+        {
+            /* (a worker that woke up late for the run before still holds that run's function and job count: the job counter
+             * goes back to zero only when nobody is looking at it) */
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_idle_.wait(lk, [&] { return active_ == 0; });
+            fn_ = &f, jobs_ = jobs;
+            next_.store(0, std::memory_order_relaxed);
+            run_++;
+        }
+        cv_work_.notify_all();
+        for (unsigned j; (j = next_.fetch_add(1, std::memory_order_relaxed)) < jobs;) f(j);
+        /* every job has been TAKEN; wait for the workers that are still inside one (a worker that wakes up late finds none) */
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_idle_.wait(lk, [&] { return active_ == 0; });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+};
+
 struct hs_scratch {
     unsigned magic = 0x48534753; /* "HSGS" */
+    WorkerPool pool; /* the host confirm's threads (started with the first large batch) */
     hsgpu_scratch_t *gpu = nullptr;
     bool in_use = false;
     /* record buffer: grown on demand, never value-initialised (a std::vector::resize of the
@@ -1037,19 +1113,19 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
  * when the confirm ran out of memory (nothing is delivered then). */
 static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
                                     const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
-                                    const hsgpu_match_t *cs, size_t n_cs);
+                                    const hsgpu_match_t *cs, size_t n_cs, WorkerPool *pool);
 static int confirm_and_deliver(const hs_database *db, const char *data, const unsigned long long *off,
                                const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
-                               const hsgpu_match_t *cs = nullptr, size_t n_cs = 0) {
+                               const hsgpu_match_t *cs = nullptr, size_t n_cs = 0, WorkerPool *pool = nullptr) {
     try {
-        return confirm_and_deliver_impl(db, data, off, recs, n, onEvent, context, cs, n_cs);
+        return confirm_and_deliver_impl(db, data, off, recs, n, onEvent, context, cs, n_cs, pool);
     } catch (...) { /* bad_alloc while sizing the per-worker vectors */
         return -1;
     }
 }
 static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
                                     const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
-                                    const hsgpu_match_t *cs, size_t n_cs) {
+                                    const hsgpu_match_t *cs, size_t n_cs, WorkerPool *pool) {
     /* host confirm: the events of different blocks are independent, so large batches are cut
      * into slices of whole blocks handled by worker threads; delivery stays on the calling
      * thread, in block order, as the callback contract requires */
@@ -1087,15 +1163,11 @@ static int confirm_and_deliver_impl(const hs_database *db, const char *data, con
         };
         if (n_thr == 1) {
             work(0);
-        } else {
-            std::vector<std::thread> pool;
-            try {
-                for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(work, t);
-            } catch (...) { /* could not start every worker: the caller's thread does the rest */
-                for (unsigned t = (unsigned)pool.size() + 1; t < n_thr; t++) work(t);
-            }
-            work(0);
-            for (std::thread &th : pool) th.join();
+        } else { /* the scratch's own threads and this one; without a scratch (hs_confirm_batch): threads for this call */
+            WorkerPool local;
+            WorkerPool *p = pool ? pool : &local;
+            p->ensure(n_thr - 1);
+            p->run(n_thr, work);
         }
         if (failed) return -1;
     }
@@ -1145,12 +1217,13 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
             const unsigned long long *off;
             hs_batch_event_handler onEvent;
             void *context;
+            WorkerPool *pool;
             int terminated, failed;
-        } c{db, data, off, onEvent, context, 0, 0};
+        } c{db, data, off, onEvent, context, &scratch->pool, 0, 0};
         const int rv = hsgpu_hwlm_exec_batch_cb(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off, (size_t)nblocks, 0, 0,
                                                 [](const hsgpu_match_t *recs, size_t n, void *p) -> int {
                                                     Ctx *c = (Ctx *)p;
-                                                    const int t = confirm_and_deliver(c->db, c->data, c->off, recs, n, c->onEvent, c->context);
+                                                    const int t = confirm_and_deliver(c->db, c->data, c->off, recs, n, c->onEvent, c->context, nullptr, 0, c->pool);
                                                     if (t < 0) {
                                                         c->failed = 1;
                                                         return 1;
@@ -1174,7 +1247,7 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
         if (attempt == 7) return HS_UNKNOWN_ERROR;
     }
     if (db->cs_seqs.empty()) {
-        const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context);
+        const int any_terminated = confirm_and_deliver(db, data, off, scratch->recs, n, onEvent, context, nullptr, 0, &scratch->pool);
         if (any_terminated < 0) return HS_NOMEM;
         return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
     }
@@ -1212,7 +1285,7 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
             resident = have_bitmaps = 1;
             size_t lj = li;
             while (lj < n && lit[lj].block < b1) lj++;
-            const int t = confirm_and_deliver(db, data, off, lit + li, lj - li, onEvent, context, n_cs ? scratch->cs_recs.data() : nullptr, n_cs);
+            const int t = confirm_and_deliver(db, data, off, lit + li, lj - li, onEvent, context, n_cs ? scratch->cs_recs.data() : nullptr, n_cs, &scratch->pool);
             if (t < 0) return HS_NOMEM;
             any_terminated |= t;
             li = lj;
