@@ -79,7 +79,7 @@ static inline const hs_database *resolve_db(const hs_database_t *db) {
  * batch after the other, and starting (and joining) the threads for every chunk was ~0.4 ms of each chunk's budget -- with
  * chunks smaller than 64 MiB the confirm stopped hiding behind the next chunk's copy. run(jobs, f): f(0 .. jobs - 1)
  * on the workers and the calling thread; returns when all are done. f must not throw. */
-class WorkerPool {
+class HsConfirmPool {
     std::vector<std::thread> threads_;
     std::mutex mu_;
     std::condition_variable cv_work_, cv_idle_;
@@ -137,7 +137,7 @@ public:
         std::unique_lock<std::mutex> lk(mu_);
         cv_idle_.wait(lk, [&] { return active_ == 0; });
     }
-    ~WorkerPool() {
+    ~HsConfirmPool() {
         {
             std::lock_guard<std::mutex> lk(mu_);
             stop_ = true;
@@ -149,7 +149,7 @@ public:
 
 struct hs_scratch {
     unsigned magic = 0x48534753; /* "HSGS" */
-    WorkerPool pool; /* the host confirm's threads (started with the first large batch) */
+    HsConfirmPool pool; /* the host confirm's threads (started with the first large batch) */
     hsgpu_scratch_t *gpu = nullptr;
     bool in_use = false;
     /* record buffer: grown on demand, never value-initialised (a std::vector::resize of the
@@ -1113,10 +1113,10 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
  * when the confirm ran out of memory (nothing is delivered then). */
 static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
                                     const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
-                                    const hsgpu_match_t *cs, size_t n_cs, WorkerPool *pool);
+                                    const hsgpu_match_t *cs, size_t n_cs, HsConfirmPool *pool);
 static int confirm_and_deliver(const hs_database *db, const char *data, const unsigned long long *off,
                                const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
-                               const hsgpu_match_t *cs = nullptr, size_t n_cs = 0, WorkerPool *pool = nullptr) {
+                               const hsgpu_match_t *cs = nullptr, size_t n_cs = 0, HsConfirmPool *pool = nullptr) {
     try {
         return confirm_and_deliver_impl(db, data, off, recs, n, onEvent, context, cs, n_cs, pool);
     } catch (...) { /* bad_alloc while sizing the per-worker vectors */
@@ -1125,7 +1125,7 @@ static int confirm_and_deliver(const hs_database *db, const char *data, const un
 }
 static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
                                     const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
-                                    const hsgpu_match_t *cs, size_t n_cs, WorkerPool *pool) {
+                                    const hsgpu_match_t *cs, size_t n_cs, HsConfirmPool *pool) {
     /* host confirm: the events of different blocks are independent, so large batches are cut
      * into slices of whole blocks handled by worker threads; delivery stays on the calling
      * thread, in block order, as the callback contract requires */
@@ -1164,8 +1164,8 @@ static int confirm_and_deliver_impl(const hs_database *db, const char *data, con
         if (n_thr == 1) {
             work(0);
         } else { /* the scratch's own threads and this one; without a scratch (hs_confirm_batch): threads for this call */
-            WorkerPool local;
-            WorkerPool *p = pool ? pool : &local;
+            HsConfirmPool local;
+            HsConfirmPool *p = pool ? pool : &local;
             p->ensure(n_thr - 1);
             p->run(n_thr, work);
         }
@@ -1217,7 +1217,7 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
             const unsigned long long *off;
             hs_batch_event_handler onEvent;
             void *context;
-            WorkerPool *pool;
+            HsConfirmPool *pool;
             int terminated, failed;
         } c{db, data, off, onEvent, context, &scratch->pool, 0, 0};
         const int rv = hsgpu_hwlm_exec_batch_cb(db->hwlm, scratch->gpu, (const uint8_t *)data, (const uint64_t *)off, (size_t)nblocks, 0, 0,
