@@ -1298,7 +1298,7 @@ extern "C" uint64_t hsgpu_hwlm_count_cb(size_t, uint32_t, void *ctx) {
 }
 
 /* what the callback receives as its third argument: the reference hands the scratch itself to
- * HWLMCallback (src/hwlm/hwlm.h:77-93); a caller that wants its own pointer hangs it here */
+ * HWLMCallback (src/hwlm/hwlm.h:80-99); a caller that wants its own pointer hangs it here */
 extern "C" void hsgpu_scratch_set_context(hsgpu_scratch_t *s, void *ctx) {
     if (s) {
         s->user_ctx = ctx;
@@ -1309,7 +1309,7 @@ extern "C" void *hsgpu_scratch_get_context(const hsgpu_scratch_t *s) {
     return s ? (s->has_user_ctx ? s->user_ctx : (void *)s) : nullptr;
 }
 
-/* hwlmExec's own argument order (src/hwlm/hwlm.h:120-122) */
+/* hwlmExec's own argument order (src/hwlm/hwlm.h:116-118) */
 extern "C" int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t len, size_t start,
                                hsgpu_hwlm_cb cb, hsgpu_scratch_t *s, uint64_t groups) {
     if (!t || !s || !cb || (len && !buf)) return HSGPU_HWLM_ERROR_UNKNOWN;

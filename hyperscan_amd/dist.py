@@ -216,7 +216,7 @@ class NativeExchange:
 
     TO_ROOT, ALL_GATHER = 0, 1
 
-    def __init__(self, dist, world, rank, device, rows, block_base, mode=TO_ROOT, root=0, with_comm=None):
+    def __init__(self, dist, world, rank, device, rows, block_base, mode=TO_ROOT, root=0, with_comm=None, id_bytes=None):
         import ctypes as C
 
         import torch
@@ -229,7 +229,7 @@ class NativeExchange:
         lib.hsgpu_exchange_create.restype = C.c_int
         lib.hsgpu_exchange_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint, C.c_int]
         lib.hsgpu_exchange_step.restype = C.c_int
-        lib.hsgpu_exchange_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.hsgpu_exchange_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
         lib.hsgpu_exchange_compact.restype = C.c_int
         lib.hsgpu_exchange_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
         lib.hsgpu_exchange_set_counts.restype = C.c_int
@@ -238,7 +238,9 @@ class NativeExchange:
         lib.hsgpu_exchange_free.argtypes = [C.c_void_p]
         want_comm = world > 1 if with_comm is None else with_comm
         idbuf = None
-        if want_comm:
+        if id_bytes is not None:  # the caller brought the id (loopback_id(): virtual ranks of one process)
+            idbuf = (C.c_uint8 * 128)(*bytes(id_bytes))
+        elif want_comm:
             idt = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 raw = (C.c_uint8 * 128)()
@@ -273,11 +275,26 @@ class NativeExchange:
         self._lib.hsgpu_exchange_wire_bytes(self._h, C.byref(s), C.byref(r))
         return s.value, r.value
 
-    def step(self, records, d_count):
+    @staticmethod
+    def loopback_id():
+        """an id for VIRTUAL ranks: `world` NativeExchange objects of this process made with it (id_bytes=) exchange by device
+        copies instead of RCCL -- the N > 1 step's own logic on a 1-GPU box (include/hsgpu.h, hsgpu_exchange_loopback_id)"""
+        import ctypes as C
+
+        from . import _native
+
+        raw = (C.c_uint8 * 128)()
+        lib = _native.load_library()
+        lib.hsgpu_exchange_loopback_id.restype = C.c_int
+        assert lib.hsgpu_exchange_loopback_id(raw) == 0
+        return bytes(raw)
+
+    def step(self, records, d_count, cap=None):
         """records: the scan's int32 [cap, 4] device tensor, d_count its int64 [1] counter; on torch's current stream"""
         import torch
 
-        rv = self._lib.hsgpu_exchange_step(self._h, records.data_ptr(), d_count.data_ptr(), self.base, torch.cuda.current_stream().cuda_stream)
+        rv = self._lib.hsgpu_exchange_step(self._h, records.data_ptr(), records.shape[0] if cap is None else cap, d_count.data_ptr(), self.base,
+                                           torch.cuda.current_stream().cuda_stream)
         if rv != 0:
             raise RuntimeError("hsgpu_exchange_step: " + self._lib.hsgpu_last_error().decode())
 

@@ -65,6 +65,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden and an export list (csrc/Makefile: libhsgpu.map, made from these headers):
+ * what is declared between here and the pop is the whole exported surface, as hs.def / hs_runtime.def are the reference's */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef int hs_error_t;
 struct hs_database;
@@ -252,6 +257,9 @@ int hs_batch_count_handler(unsigned long long block, unsigned int id, unsigned l
 const char *hs_version(void);
 hs_error_t hs_valid_platform(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden and an export list (csrc/Makefile: libhsgpu.map, made from these headers):
+ * what is declared between here and the pop is the whole exported surface, as hs.def / hs_runtime.def are the reference's */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* hs_error_t mirror (src/hs_common.h:478-588) */
 #define HSGPU_SUCCESS 0
@@ -119,10 +124,10 @@ int hsgpu_hwlm_deserialize(const void *buf, size_t len, hsgpu_hwlm_t **out);
 int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device);
 void hsgpu_scratch_free(hsgpu_scratch_t *s);
 
-/* hwlmExec (src/hwlm/hwlm.h:120-122, src/hwlm/hwlm.c:172-199), argument for argument: scan one host
+/* hwlmExec (src/hwlm/hwlm.h:116-118, src/hwlm/hwlm.c:172-199), argument for argument: scan one host
  * block, deliver callbacks in non-decreasing `end` on the calling thread, honouring the group
  * mask returned by the callback, noruns and termination. Returns HSGPU_HWLM_*. The callback's
- * third argument is the scratch itself, as in the reference (HWLMCallback, src/hwlm/hwlm.h:77-93),
+ * third argument is the scratch itself, as in the reference (HWLMCallback, src/hwlm/hwlm.h:80-99),
  * unless the caller hung a pointer of its own on the scratch with hsgpu_scratch_set_context. */
 int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t len, size_t start,
                     hsgpu_hwlm_cb cb, hsgpu_scratch_t *scratch, uint64_t groups);
@@ -228,8 +233,9 @@ uint64_t hsgpu_hwlm_count_cb(size_t end, uint32_t id, void *ctx);
  *                 count + slack); a slot travels whole unless set_counts told every rank the exact rows of every rank
  *                 (steps that repeat a scan: the counts are known from the first one)
  *   step          packs the records of the scan that wrote d_records / d_count (hsgpu_hwlm_scan_dev's buffers, still on the
- *                 device; first_block = the global index of this rank's block 0) and posts the transfers, all on `stream`:
- *                 no host synchronisation, nothing allocated
+ *                 device; record_cap = the `cap` that scan was given: a scan that found more wrote nothing usable, its slot
+ *                 then travels with no rows and compact reports HSGPU_INSUFFICIENT_SPACE; first_block = the global index of
+ *                 this rank's block 0) and posts the transfers, all on `stream`: no host synchronisation, nothing allocated
  *   compact       (synchronises) the records of the last step in rank order = corpus order into d_out (device, hsgpu_wire_t
  *                 [cap]), counts[r] = what rank r's scan found, *total = records delivered; HSGPU_INSUFFICIENT_SPACE when
  *                 a scan found more than its slot (or cap) holds. On ranks that receive nothing (TO_ROOT, not the root)
@@ -245,7 +251,13 @@ int hsgpu_exchange_unique_id(void *id /* HSGPU_XCHG_ID_BYTES */);
 int hsgpu_exchange_create(hsgpu_exchange_t **x, const void *id, int world, int rank, int device, uint64_t rows_per_rank,
                           unsigned mode, int root);
 int hsgpu_exchange_set_counts(hsgpu_exchange_t *x, const uint64_t *rows /* [world], NULL = fixed slots again */, int world);
-int hsgpu_exchange_step(hsgpu_exchange_t *x, const void *d_records, const void *d_count, uint64_t first_block, void *stream);
+int hsgpu_exchange_step(hsgpu_exchange_t *x, const void *d_records, uint64_t record_cap, const void *d_count, uint64_t first_block,
+                        void *stream);
+/* An id for VIRTUAL ranks: `world` exchanges created with it in ONE process on one device talk to each other by device copies
+ * instead of RCCL (a Send meeting its Recv = one hipMemcpyAsync, ordered by events; the ranks may be driven from one thread in
+ * any order, each on a stream of its own or all on one). Everything else -- who sends what to whom, slot sizes, agreed
+ * counts, compact -- is the code the RCCL transport runs: the way to run an N > 1 job's exchange on a 1-GPU box. */
+int hsgpu_exchange_loopback_id(void *id /* HSGPU_XCHG_ID_BYTES */);
 int hsgpu_exchange_compact(hsgpu_exchange_t *x, void *d_out, uint64_t cap, uint64_t *counts /* [world], host */, uint64_t *total,
                            void *stream);
 /* bytes this rank sends / receives in one step (the figure a link budget needs) */
@@ -445,6 +457,9 @@ int hsgpu_run_accel_dev(const hsgpu_accel_aux_t *aux, const void *d_corpus, uint
 const char *hsgpu_last_error(void);
 const char *hsgpu_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

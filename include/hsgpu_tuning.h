@@ -8,6 +8,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden and an export list (csrc/Makefile: libhsgpu.map, made from these headers):
+ * what is declared between here and the pop is the whole exported surface, as hs.def / hs_runtime.def are the reference's */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* hsgpu_hwlm_build flags: engine forcing for tests, like the reference's
  * fdrBuildProtoHinted hook (src/fdr/fdr_compile.cpp:900-911). 0 = automatic. */
@@ -48,6 +53,9 @@ unsigned hsgpu_confirm_partition(unsigned n_shares, unsigned max_workers, unsign
  * library is not in the repository, and a test compares this with the tree it runs in. */
 const char *hsgpu_source_hash(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -174,9 +174,9 @@ def test_scan_vector_behaviour_cpp():
 
 
 def test_hwlm_exec_argument_order_and_callback_context(scratch):
-    """hsgpu_hwlm_exec takes hwlmExec's arguments in hwlmExec's order (src/hwlm/hwlm.h:120-122) and
+    """hsgpu_hwlm_exec takes hwlmExec's arguments in hwlmExec's order (src/hwlm/hwlm.h:116-118) and
     its callback's third argument is the scratch itself, as the reference passes its hs_scratch
-    (HWLMCallback, src/hwlm/hwlm.h:77-93), or the pointer hung on the scratch."""
+    (HWLMCallback, src/hwlm/hwlm.h:80-99), or the pointer hung on the scratch."""
     import ctypes as C
 
     from hyperscan_amd import _native
