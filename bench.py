@@ -36,7 +36,36 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "r04_bench_pmc_summary.json"  # tools/round_profile.sh writes it from the PMC passes of this same command
+# tools/round_profile.sh writes these from rocprofv3 passes of this same command (the newest committed round wins)
+PMC_SUMMARIES = ("r05_bench_pmc_summary.json", "r04_bench_pmc_summary.json")
+KERNEL_STATS = ("r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv")
+
+
+def _first_profile(names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return n
+    return names[0]
+
+
+PMC_SUMMARY = _first_profile(PMC_SUMMARIES)
+
+
+def kernel_ms_trace(kernel_prefix):
+    """the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this same command
+    (profiles/rNN_bench_kernel_stats.csv): what roofline.kernel_ms_avg, measured live with HIP events, has to agree with.
+    -> (ms | None, source)"""
+    import csv
+
+    src = os.path.join("profiles", _first_profile(KERNEL_STATS))
+    try:
+        best = None
+        for r in csv.DictReader(open(os.path.join(ROOT, src))):
+            if kernel_prefix in r["Name"] and (best is None or int(r["Calls"]) > best[0]):
+                best = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
+        return (round(best[1], 4), src) if best else (None, None)
+    except (OSError, KeyError, ValueError):
+        return None, None
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REC_BYTES = 16
 WORKLOAD_DESC = {
@@ -223,7 +252,7 @@ def cpu_baseline(lits, corpus, off, want_seconds=14.0, sample_bytes=256 << 20):
         dt = time.perf_counter() - t0
         return ({"value": round(s_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
                  "sample": f"first {s_bytes} bytes / {k} blocks of the same corpus, oracle/hwlm_oracle.c, 1 thread",
-                 "matches_in_sample": int(n)}, (k, o.collect_blocks(sample, s_off)))
+                 "matches_in_sample": int(n)}, None)
     runs, best = {}, None
     quota, quota_src = cgroup_cpu_quota()
     # hsbench -T sweep: 1, 2, 4, ... up to every CPU this process may run on (a cgroup quota below that count shows as
@@ -241,8 +270,6 @@ def cpu_baseline(lits, corpus, off, want_seconds=14.0, sample_bytes=256 << 20):
                                        "matches_per_pass": matches}
             if best is None or gbs > best[0]:
                 best = (gbs, T, variant, matches)
-        # parity gate: the reference's records over the WHOLE sample it was timed on
-        gate = (k, ref.collect_blocks(sample, s_off))
     t1 = max(v["GBps"] for kk, v in runs.items() if v["threads"] == 1)
     return ({"value": round(best[0], 3), "unit": "GB/s", "cores": best[1], "kind": "reference",
              "sample": f"first {s_bytes} bytes / {k} blocks of the same corpus; hwlmExec per block, T pinned pthreads x own "
@@ -250,23 +277,68 @@ def cpu_baseline(lits, corpus, off, want_seconds=14.0, sample_bytes=256 << 20):
              "engine": engine, "cpu": host_cpu_desc(), "cpus_visible": cpus, "cgroup_cpu_quota": quota,
              "cgroup_cpu_quota_source": quota_src,
              "effective_cores_by_scaling": round(best[0] / t1, 1) if t1 > 0 else None,
-             "runs": runs, "matches_in_sample": int(best[3])}, gate)
+             "runs": runs, "matches_in_sample": int(best[3])}, None)
 
 
-def parity_gate(recs, gate, lits):
-    """Content-level parity on the first blocks: the sorted (block, end, id) multisets of the GPU and of
-    the reference are identical (unit/internal/fdr.cpp:185-188 compares (end, id) lists the same way),
+def compare_records(g, want, what):
+    """g: GPU records [n, 4] (block, end, id, lit) of some block range, want: the reference's (block, end, id) of the same range.
+    The sorted (block, end, id) multisets are identical (unit/internal/fdr.cpp:185-188 compares (end, id) lists the same way)
     and the GPU's records arrive in delivery order."""
-    kg, want = gate
-    g = recs[recs[:, 0] < kg]
     key = (g[:, 0].astype(np.uint64) << np.uint64(32)) | g[:, 1].astype(np.uint64)
-    assert np.all((key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (g[1:, 3] > g[:-1, 3]))), "records not in delivery order"
+    assert np.all((key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (g[1:, 3] > g[:-1, 3]))), f"records not in delivery order ({what})"
     gi = np.lexsort((g[:, 2], g[:, 1], g[:, 0]))
     wi = np.lexsort((want["id"], want["end"], want["block"]))
     ok = (len(g) == len(want) and np.array_equal(g[gi, 0], want["block"][wi]) and np.array_equal(g[gi, 1], want["end"][wi])
           and np.array_equal(g[gi, 2], want["id"][wi]))
-    assert ok, f"PARITY FAILURE on the first {kg} blocks: GPU {len(g)} records vs CPU {len(want)}"
+    assert ok, f"PARITY FAILURE on {what}: GPU {len(g)} records vs CPU {len(want)}"
+
+
+def parity_gate(recs, gate, lits):
+    """Content-level parity on the first blocks (the bounded form; reference_gate_full is what the bench runs since round 5)."""
+    kg, want = gate
+    compare_records(recs[recs[:, 0] < kg], want, f"the first {kg} blocks")
     return f"sorted (block,end,id) multisets identical on the first {kg} blocks ({len(want)} matches); delivery order checked"
+
+
+def reference_gate_full(lits, corpus, off, recs, what):
+    """The WHOLE corpus against the reference (round 4's verdict: the gate covered a quarter of the headline GiB and none of the
+    8 GiB): the compiled reference's hwlmExec per block over every block (unit/internal/fdr.cpp:185-188 compares full lists;
+    hsbench checks the count per repeat, tools/hsbench/main.cpp:778-787), collected on every host thread at once -- ranges of
+    blocks balanced by bytes, each range's (block, end, id) multiset compared with the GPU's records of the same blocks, and the
+    GPU's delivery order checked across the whole array. Byte offsets beyond 2^32 are ordinary here (the 8 GiB corpus).
+    -> prose for the bench line"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests import oracle_binding as ob
+
+    t0 = time.perf_counter()
+    real = ob.ref_available()
+    ref = ob.Reference(lits, variant=ob.ref_variants()[-1]) if real else ob.Oracle(lits)
+    nblocks = int(off.size - 1)
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    parts = max(1, min(nblocks, threads * 4))
+    cuts = np.searchsorted(off, np.linspace(0, int(off[-1]), parts + 1)[1:-1].astype(np.uint64), side="left")
+    cuts = np.unique(np.concatenate([[0], cuts, [nblocks]]))
+    assert np.all(recs[1:, 0] >= recs[:-1, 0]), "records not in block order"
+    idx = np.searchsorted(recs[:, 0], cuts, side="left")
+
+    def one(i):
+        lo, hi = int(cuts[i]), int(cuts[i + 1])
+        g = recs[int(idx[i]):int(idx[i + 1])]
+        if real:
+            want = ref.collect_blocks(corpus, off[lo:hi + 1], cap=len(g) + 4096)
+        else:
+            want = ref.collect_blocks(corpus[int(off[lo]):int(off[hi])], off[lo:hi + 1] - off[lo])
+        want["block"] += np.uint32(lo)
+        compare_records(g, want, f"blocks [{lo}, {hi}) of {what}")
+        return len(want)
+
+    with ThreadPoolExecutor(threads) as ex:
+        n = sum(ex.map(one, range(len(cuts) - 1)))
+    assert n == len(recs)
+    src = "the compiled reference's hwlmExec (oracle/_ref)" if real else "oracle/hwlm_oracle.c"
+    return (f"ALL {nblocks} blocks / {n} matches / {int(off[-1])} bytes: sorted (block,end,id) multisets identical to {src}, "
+            f"delivery order checked ({time.perf_counter() - t0:.1f}s on {threads} threads)")
 
 
 def gpu_vs_gpu_gate(job):
@@ -339,7 +411,7 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         run_steps(1)
         torch.cuda.synchronize()
 
-    exch = None
+    exch, second, native, exact, skew, kind = None, None, None, False, 1.0, None
     if dist is not None:
         from hyperscan_amd import dist as hd
 
@@ -354,51 +426,74 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         # flood-dense shard among quiet ones) the padding is most of the traffic -- choose by the skew of the warm-up counts
         cnts = allnb[:, 1].tolist()
         skew = max(cnts) / max(1.0, float(np.mean(cnts)))
-        exact = (args.exchange == "exact") or (args.exchange == "auto" and skew > 1.5)
-        native = None
-        if args.exchange in ("auto", "native", "native_all"):
-            # the C ABI's exchange (hsgpu_exchange_*: RCCL directly, 12-byte wire records): to the root -- the rank whose host
-            # would deliver the callbacks -- unless all-gather is asked for; the rows every rank sends are the warm-up's
-            # counts (every step scans the same shard). Every rank must have it, or none uses it.
-            try:
-                native = [hd.NativeExchange(dist, world, rank, job.dev, rows, base,
-                                            mode=hd.NativeExchange.ALL_GATHER if args.exchange == "native_all" else hd.NativeExchange.TO_ROOT)
-                          for _ in jobs]
-                for x in native:
-                    x.set_counts(cnts)
-                ok = 1
-            except Exception as e:  # noqa: BLE001 -- any failure means the torch.distributed form for everybody
-                log(f"[rank {rank}] native exchange unavailable: {e}")
-                native, ok = None, 0
-            flag = torch.tensor([ok], dtype=torch.int64, device=job.dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                native = None
-                assert args.exchange == "auto", "--exchange native: hsgpu_exchange_create failed on some rank"
-        if native is not None:
-            exch = native
-        elif exact:
-            bases = np.concatenate([[0], np.cumsum(allnb[:, 0].numpy())])[:world].tolist()
-            exch = [hd.ExactExchange(dist, world, rank, job.dev, cnts, bases) for _ in jobs]
-        else:
-            exch = [hd.RecordExchange(dist, world, rank, job.dev, rows, base) for _ in jobs]
-        run_steps(depth, exch)  # untimed: RCCL sets up its rings on first use
-        allr, counts = exch[0].compact()
-        assert counts[rank] == n_matches
-        if native is None or rank == 0 or args.exchange == "native_all":
-            assert allr.shape[0] == sum(counts)
-            assert bool((allr[1:, 0].to(torch.int64) & 0xFFFFFFFF >= allr[:-1, 0].to(torch.int64) & 0xFFFFFFFF).all()), \
-                "gathered records are not in global block order"
 
-    # parity gate on the first blocks (bounded CPU time) + the CPU baseline
-    cpu = None
+        def make_exchange(which):
+            """one exchange object per scan in flight, or None when the C ABI's exchange cannot be created on some rank"""
+            if which in ("native", "native_all"):
+                # the C ABI's exchange (hsgpu_exchange_*: RCCL directly, 12-byte wire records, exactly the rows every rank found in
+                # the warm-up -- every step scans the same shard): to every rank (the all-gather BASELINE.json names), or to the
+                # root -- the rank whose host would deliver the callbacks. Every rank must have it, or none uses it.
+                try:
+                    objs = [hd.NativeExchange(dist, world, rank, job.dev, rows, base,
+                                              mode=hd.NativeExchange.ALL_GATHER if which == "native_all" else hd.NativeExchange.TO_ROOT)
+                            for _ in jobs]
+                    for x in objs:
+                        x.set_counts(cnts)
+                    ok = 1
+                except Exception as e:  # noqa: BLE001 -- any failure means the torch.distributed form for everybody
+                    log(f"[rank {rank}] native exchange unavailable: {e}")
+                    objs, ok = None, 0
+                flag = torch.tensor([ok], dtype=torch.int64, device=job.dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return objs if int(flag.item()) == 1 else None
+            if which == "exact":
+                bases = np.concatenate([[0], np.cumsum(allnb[:, 0].numpy())])[:world].tolist()
+                return [hd.ExactExchange(dist, world, rank, job.dev, cnts, bases) for _ in jobs]
+            return [hd.RecordExchange(dist, world, rank, job.dev, rows, base) for _ in jobs]
+
+        def check_gathered(objs, which):
+            allr, counts = objs[0].compact()
+            assert counts[rank] == n_matches
+            if which != "native" or rank == 0:
+                assert allr.shape[0] == sum(counts)
+                assert bool((allr[1:, 0].to(torch.int64) & 0xFFFFFFFF >= allr[:-1, 0].to(torch.int64) & 0xFFFFFFFF).all()), \
+                    "gathered records are not in global block order"
+
+        # `value`'s collective is the all-gather north_star names (auto = native_all); the to-root form -- 1/world of the traffic,
+        # what a job whose rank 0 delivers the callbacks needs -- is timed right after it over the same steps, beside it
+        kind = "native_all" if args.exchange == "auto" else args.exchange
+        exch = make_exchange(kind)
+        if exch is None:
+            assert args.exchange == "auto", f"--exchange {args.exchange}: hsgpu_exchange_create failed on some rank"
+            kind = "exact" if skew > 1.5 else "padded"
+            exch = make_exchange(kind)
+        native = exch if kind in ("native", "native_all") else None
+        exact = kind == "exact"
+        run_steps(depth, exch)  # untimed: RCCL sets up its rings on first use
+        check_gathered(exch, kind)
+        if native is not None:
+            kind2 = "native" if kind == "native_all" else "native_all"
+            second = make_exchange(kind2)
+            if second is not None:
+                run_steps(depth, second)
+                check_gathered(second, kind2)
+
+    # parity gate against the reference over the WHOLE corpus + the CPU baseline
+    cpu, ref_parity = None, None
     if do_cpu:
         # records first: on this stack the scans that directly follow a large D2H copy run ~3x
         # slower for tens of ms (measured: 1.9 vs 0.66 ms per scan, host launch time unchanged);
         # the CPU baseline's seconds in between and one untimed scan keep that out of the timed region
         recs = job.records()
-        cpu, gate = cpu_baseline(lits, corpus, off)
-        cpu["parity"] = parity_gate(recs, gate, lits)
+        cpu, _ = cpu_baseline(lits, corpus, off)
+        ref_parity = cpu["parity"] = reference_gate_full(lits, corpus, off, recs, name)
+        del recs
+        run_steps(1)
+        torch.cuda.synchronize()
+    elif getattr(args, "reference_gate", False):  # also.fdr10k_8g: no CPU timing leg, but the same whole-corpus gate
+        recs = job.records()
+        ref_parity = reference_gate_full(lits, corpus, off, recs, name)
+        del recs
         run_steps(1)
         torch.cuda.synchronize()
 
@@ -415,6 +510,22 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         dist.barrier()
     dt = time.perf_counter() - t0
     assert all(jb.count() == n_matches for jb in jobs), "match count changed between repeats"  # hsbench main.cpp:778-787
+    dt_local, second_res = dt, None
+    if second is not None:  # the other collective over the same K steps, same protocol (never `value`)
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.steps, second, ev2)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt2 = time.perf_counter() - t1
+        tt2 = torch.tensor([dt2], dtype=torch.float64, device=job.dev)
+        dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+        g2 = [a.elapsed_time(b) for a, b in ev2]
+        s2, r2 = second[0].wire_bytes()
+        second_res = {"ms_per_step": round(float(tt2.item()) / args.steps * 1e3, 4), "gather_ms_avg_rank0": round(float(np.mean(g2)), 4),
+                      "wire_bytes_sent_rank0": s2, "wire_bytes_received_rank0": r2}
     # HIP events the library recorded on the launch stream around its filter kernel during the timed
     # steps (ring of the last 32 scans); read only now, so the timed loop itself never waited on them
     filt_ms, conf_ms, pipe_ms, span_ms = [], [], [], []
@@ -459,14 +570,26 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         tot = torch.tensor([job.total, n_matches], dtype=torch.int64, device=job.dev)
         dist.all_reduce(tot)
         all_bytes, all_matches = int(tot[0].item()), int(tot[1].item())
+        # every rank's own clock around the same K steps: the per-rank rates (hsbench prints one line per scan thread too)
+        mine = torch.tensor([dt_local, float(job.total)], dtype=torch.float64, device=job.dev)
+        every = torch.empty(world * 2, dtype=torch.float64, device=job.dev)
+        dist.all_gather_into_tensor(every, mine)
+        every = every.view(world, 2).cpu().numpy()
+        per_rank_gbps = [round(float(b * args.steps / t / 1e9), 2) for t, b in every]
     else:
         all_bytes, all_matches = job.total, n_matches
 
+    # algorithmic bytes: 1 B read per corpus byte -- the filter kernel's -- + 16 B written per match record -- the
+    # confirm stage's (its workers stage and place the records; the filter writes none). The dominant kernel is priced on its own
+    # bytes, the step on all of them.
     alg_bytes = job.total + REC_BYTES * n_matches
+    filter_bytes = job.total
     kname = filter_kernel_name(info["flags"])
+    trace_ms, trace_src = kernel_ms_trace(kname) if abs(job.total - (1 << 30)) < (1 << 20) else (None, None)
+    step_s = dt / args.steps  # (N > 1: per-rank bytes over the max-over-ranks step time)
     # (the committed PMC passes ran this command at 1 GiB per launch: no figure for any other size)
     traffic, traffic_src = pmc_traffic(kname) if abs(job.total - (1 << 30)) < (1 << 20) else (None, None)
-    achieved = alg_bytes / kern_avg_s / 1e9
+    achieved = filter_bytes / kern_avg_s / 1e9
     res = {
         "value": round(all_bytes * args.steps / dt / 1e9, 3),
         "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -477,11 +600,16 @@ def run_workload(name, args, rank, world, dist, do_cpu):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": kname, "kernel_ms_avg": round(kern_avg_s * 1e3, 4),
             "kernel_ms_best": round(float(np.min(filt_ms)), 4),
-            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms_trace": trace_ms, "kernel_ms_trace_source": trace_src,
+            "algorithmic_bytes_per_launch": filter_bytes,
+            "algorithmic_bytes_per_step": alg_bytes,
+            # the WHOLE step against the roofline: what `value` is made of (filter + confirm stage + gather + gaps)
+            "step_achieved": round(alg_bytes / step_s / 1e9, 2), "step_frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+            "record_bytes_per_step": REC_BYTES * n_matches,
             # the kernel's own execution span from the device wall clock (what rocprofv3's kernel
             # trace reports); the HIP-event interval above also contains the dispatch gaps
             "kernel_ms_device_clock_avg": round(float(np.mean(span_ms)), 4),
-            "achieved_device_clock": round(alg_bytes / (float(np.mean(span_ms)) / 1e3) / 1e9, 2),
+            "achieved_device_clock": round(filter_bytes / (float(np.mean(span_ms)) / 1e3) / 1e9, 2),
             "confirm_stage_ms_avg": round(float(np.mean(conf_ms)), 4),
             "pipeline_ms_avg": round(float(np.mean(pipe_ms)), 4),
             "pipeline_GBps": round(alg_bytes / (float(np.mean(pipe_ms)) / 1e3) / 1e9, 2),
@@ -500,24 +628,41 @@ def run_workload(name, args, rank, world, dist, do_cpu):
                             "step_ms_exchange_overlapped_with_next_scan": round(max(dt / args.steps, wire / link) * 1e3, 4),
                             "assumes": "every peer sends its records to rank 0 over its own xGMI link (7 transfers side by side); "
                                        "a ring all-gather carries 7 ranks' records over every link"}
+    if dist is not None:
+        wire = 16 + 12 * max(cnts)
+        link = 153e9 * 0.8
+        res["multi_gpu"] = {"measured": True, "n_gpus": world, "per_rank_GBps": per_rank_gbps, "per_rank_matches": cnts,
+                            "step_ms": round(dt / args.steps * 1e3, 4),
+                            "predicted": {"to_root_ms": round(wire / link * 1e3, 4), "ring_all_gather_ms": round((world - 1) * wire / link * 1e3, 4),
+                                          "point_to_point_all_gather_ms": round(wire / link * 1e3, 4),
+                                          "assumes": "153 GB/s x 0.8 per xGMI link; to-root / point-to-point: every peer over its own link"}}
     if whole_gate:
         res["parity_whole_corpus"] = whole_gate
+    if ref_parity:
+        res["parity_reference"] = ref_parity
     if overlapped:
         res["two_scans_in_flight"] = overlapped
     if dist is not None:
         g = [a.elapsed_time(b) for a, b in ev]
         if native is not None:
             sent, rcvd = exch[0].wire_bytes()
-            res["exchange"] = {"collective": ("hsgpu_exchange_step (C ABI, RCCL): grouped ncclSend / ncclRecv of exactly the agreed rows, 12-byte wire "
-                                              "records, " + ("every rank to every rank" if args.exchange == "native_all" else "every rank to rank 0")),
-                               "count_skew_max_over_mean": round(skew, 3), "wire_bytes_sent_rank0": sent, "wire_bytes_received_rank0": rcvd,
-                               "gather_ms_avg_rank0": round(float(np.mean(g)), 4), "gather_ms_max_rank0": round(float(np.max(g)), 4)}
+            names = {"native_all": "all_gather", "native": "to_root"}
+            res["exchange"] = {"value_uses": names[kind],
+                               "collective": ("hsgpu_exchange_step (C ABI, RCCL): grouped ncclSend / ncclRecv of exactly the agreed rows, 12-byte wire "
+                                              "records, " + ("every rank to every rank" if kind == "native_all" else "every rank to rank 0")),
+                               "count_skew_max_over_mean": round(skew, 3),
+                               names[kind]: {"ms_per_step": round(dt / args.steps * 1e3, 4), "gather_ms_avg_rank0": round(float(np.mean(g)), 4),
+                                             "gather_ms_max_rank0": round(float(np.max(g)), 4), "wire_bytes_sent_rank0": sent,
+                                             "wire_bytes_received_rank0": rcvd}}
+            if second_res is not None:
+                res["exchange"][names["native" if kind == "native_all" else "native_all"]] = second_res
         else:
-          res["exchange"] = {"collective": ("broadcast x world of exactly counts[r] rows (counts agreed before the timed steps)" if exact else
-                                          "all_gather_into_tensor x2 (counts, records padded to a fixed size)"),
-                           "count_skew_max_over_mean": round(skew, 3),
-                           "rows_per_rank": exch[0].rows, "bytes_per_rank_per_step": exch[0].rows * 16 + 16,
-                           "gather_ms_avg_rank0": round(float(np.mean(g)), 4), "gather_ms_max_rank0": round(float(np.max(g)), 4)}
+            res["exchange"] = {"value_uses": "exact" if exact else "padded",
+                               "collective": ("broadcast x world of exactly counts[r] rows (counts agreed before the timed steps)" if exact else
+                                              "all_gather_into_tensor x2 (counts, records padded to a fixed size)"),
+                               "count_skew_max_over_mean": round(skew, 3),
+                               "rows_per_rank": exch[0].rows, "bytes_per_rank_per_step": exch[0].rows * 16 + 16,
+                               "gather_ms_avg_rank0": round(float(np.mean(g)), 4), "gather_ms_max_rank0": round(float(np.max(g)), 4)}
     if do_cpu:
         from hyperscan_amd import hwlm as hw
 
@@ -635,12 +780,16 @@ def run_class256(args):
     assert len(classes) <= accel.CLASS_MAX_BITMAPS
     bm_all, _f, _l = accel.class_scan(classes, d_corpus, total, d_off, nb, False, False)
     cls_buf = (bm_all, None, None, torch.zeros(accel.WORK_BYTES, dtype=torch.uint8, device=dev))
-    # parity on a slice: membership bit i <=> corpus[i] in class
+    # parity of the bitmaps, membership bit i <=> corpus[i] in class: 1 MiB at the head of EVERY GiB and the corpus' last MiB
+    # (round 4 checked the first MiB of four GiB)
     n = 1 << 20
     cpu = None
-    for ci, cls in enumerate(classes):
-        want = np.packbits(np.isin(corpus[:n], np.array(cls.members(), dtype=np.uint8)), bitorder="little")
-        assert np.array_equal(bm_all[ci][: n // 8].cpu().numpy(), want), "class bitmap parity"
+    bm_at = sorted({min(g << 30, max(0, total - n)) & ~7 for g in range(int(np.ceil(total / (1 << 30))))} | {max(0, total - n) & ~7})
+    for lo8 in bm_at:
+        hi8 = min(total, lo8 + n) & ~7
+        for ci, cls in enumerate(classes):
+            want = np.packbits(np.isin(corpus[lo8:hi8], np.array(cls.members(), dtype=np.uint8)), bitorder="little")
+            assert np.array_equal(bm_all[ci][lo8 // 8: hi8 // 8].cpu().numpy(), want), f"class bitmap parity at byte {lo8}"
     # the accelerators' own answer (first / last member per block, shufti.h:40-52), 8 classes per pass: timed beside the
     # patterns' path, which does not need it
     fl = accel.class_scan(classes[:8], d_corpus, total, d_off, nb, True, True)
@@ -660,26 +809,52 @@ def run_class256(args):
     # a run-length restatement of the patterns (tests/class_seq_model.py, itself pinned to Python's re), every pattern
     from tests import class_seq_model as csm
 
-    # ... on >= 4 MiB of lines, in slices that fit a record buffer (0.74 match ends per corpus byte), with the vectorised model
-    kg = int(np.searchsorted(off, args.class_gate_mib << 20, side="left"))
-    g_hi = int(off[kg])
-    vm = csm.VecModel(corpus[:g_hi], off[: kg + 1])
-    want_all = [vm.ends(classes[a].members(), classes[b].members(), m, n_) for (a, b, m, n_, _id) in seqs]
-    n_checked, slice_blocks = 0, max(1, kg // 8)
-    for b0 in range(0, kg, slice_blocks):
-        b1 = min(kg, b0 + slice_blocks)
-        counts_g, recs_g, n_emit = accel.class_seq_scan(seqs, bitmaps, total, d_off, nb, (int(off[b0]), int(off[b1])), 1 << 24)
+    # ... on `--class-gate-mib` MiB of lines (0.74 match ends per corpus byte) with the vectorised model: the first MiB of lines
+    # of EVERY GiB and the last MiB of the corpus (round 4: the first 4 MiB of 4 GiB), each slice emitted as one byte range
+    per = max(1, args.class_gate_mib) << 20
+    starts = sorted({min(g << 30, max(0, total - per)) for g in range(int(np.ceil(total / (1 << 30))))} | {max(0, total - per)})
+    n_checked, gate_slices = 0, []
+    for lo_byte in starts:
+        b0 = int(np.searchsorted(off, lo_byte, side="left"))
+        b1 = int(np.searchsorted(off, min(total, int(off[b0]) + per), side="right")) - 1
+        if b1 <= b0:
+            continue
+        g_lo, g_hi = int(off[b0]), int(off[b1])
+        vm = csm.VecModel(corpus[g_lo:g_hi], off[b0: b1 + 1] - off[b0])
+        counts_g, recs_g, n_emit = accel.class_seq_scan(seqs, bitmaps, total, d_off, nb, (g_lo, g_hi), 1 << 24)
         assert n_emit == len(recs_g), "gate slice overflowed its record buffer"
         order = np.lexsort((recs_g[:, 1], recs_g[:, 0], recs_g[:, 3]))
         recs_g = recs_g[order]
         cuts = np.searchsorted(recs_g[:, 3], np.arange(len(seqs) + 1))
-        for k in range(len(seqs)):
-            w = want_all[k]
-            w = w[(w[:, 0] >= b0) & (w[:, 0] < b1)]
+        for k, (a, b, m, n_, _id) in enumerate(seqs):
+            w = vm.ends(classes[a].members(), classes[b].members(), m, n_)
             g = recs_g[cuts[k]:cuts[k + 1], :2].astype(np.int64)
-            assert np.array_equal(g, w), f"PARITY FAILURE: pattern {k} {pats[k]}: GPU {len(g)} match ends vs model {len(w)} in blocks [{b0}, {b1})"
+            g[:, 0] -= b0
+            assert np.array_equal(g, w), (f"PARITY FAILURE: pattern {k} {pats[k]}: GPU {len(g)} match ends vs model {len(w)} in blocks "
+                                          f"[{b0}, {b1}) (bytes [{g_lo}, {g_hi}))")
             n_checked += len(w)
-    del vm, want_all
+        gate_slices.append((b0, b1, g_lo, g_hi))
+        del vm
+    kg, g_hi = sum(b1 - b0 for b0, b1, _l, _h in gate_slices), sum(h - l for _b0, _b1, l, h in gate_slices)
+    # ... and additivity over the GiB parts (lines never cross them: one generator call per GiB): the per-pattern counts of the
+    # whole scan equal the sum of the counts of every part scanned ALONE (its own class scan, its own offsets)
+    whole_counts, _r, _n = accel.class_seq_scan(seqs, bitmaps, total, d_off, nb, (0, 0), 0)
+    whole_counts = whole_counts.cpu().numpy().astype(np.int64)
+    part_sum, part_at, n_parts = np.zeros(len(seqs), dtype=np.int64), 0, 0
+    bounds = [int(np.searchsorted(off, min(total, (g + 1) << 30), side="left")) for g in range(int(np.ceil(total / (1 << 30))))]
+    if len(bounds) > 1 and all(int(off[b]) % 16 == 0 for b in bounds[:-1]) and all(int(off[b]) == min(total, (g + 1) << 30) for g, b in enumerate(bounds)):
+        b_lo = 0
+        for b_hi in bounds:
+            lo_b, hi_b = int(off[b_lo]), int(off[b_hi])
+            d_sub_off = torch.from_numpy((off[b_lo: b_hi + 1] - off[b_lo]).view(np.int64)).to(dev)
+            sub_bm, _f2, _l2 = accel.class_scan(classes, d_corpus[lo_b:hi_b], hi_b - lo_b, d_sub_off, b_hi - b_lo, False, False)
+            c_sub, _r, _n = accel.class_seq_scan(seqs, [sub_bm[ci] for ci in range(len(classes))], hi_b - lo_b, d_sub_off, b_hi - b_lo, (0, 0), 0)
+            part_sum += c_sub.cpu().numpy().astype(np.int64)
+            n_parts += 1
+            b_lo = b_hi
+            del sub_bm, d_sub_off
+        assert np.array_equal(part_sum, whole_counts), "PARITY FAILURE: per-pattern counts of the whole corpus differ from the sum over its GiB parts"
+        torch.cuda.empty_cache()
     seq_buf = accel.class_seq_buffers(len(seqs), total, 0, dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -709,8 +884,10 @@ def run_class256(args):
            "matches_per_step": n_matches, "matches_per_s": round(n_matches * args.steps / dt, 1),
            "matches": "counted per pattern on the device over the whole corpus (several per corpus byte: no record buffer holds them); "
                       "16-byte records are emitted for a byte range on request",
-           "parity": f"(block, end) of every one of the 256 patterns on the first {kg} lines / {g_hi} bytes ({n_checked} match ends) identical to the "
-                     "vectorised run-length model of tests/class_seq_model.py (pinned to Python re in the CPU suite); class bitmaps against numpy on 1 MiB",
+           "parity": f"(block, end) of all 256 patterns on {len(gate_slices)} slices ({kg} lines / {g_hi} bytes, {n_checked} match ends: the head of every GiB "
+                     f"and the corpus' tail) identical to the run-length model of tests/class_seq_model.py (pinned to Python re in the CPU suite); "
+                     f"per-pattern counts of the whole corpus = the sum over its {n_parts} GiB parts scanned alone; class bitmaps against numpy on "
+                     f"{len(bm_at)} x 1 MiB (every GiB and the tail)",
            "class_stage": {"ms": round(ms, 3), "GBps_of_corpus": round(total / (ms / 1e3) / 1e9, 1)},
            "sequence_stage": {"ms": round(ms_seq, 3), "GBps_of_corpus": round(total / (ms_seq / 1e3) / 1e9, 1),
                               "kernel": "class_seq_tile_kernel (one lane per 64-byte word, patterns looped in scalar registers; instruction bound)"},
@@ -872,20 +1049,31 @@ def run_rose1000(args):
 
     # -- parity gate: (block, id, to) of a slice through hs_scan_batch against the model of tests/rose_model.py (pinned to
     #    Python re and to hs_confirm_batch in the CPU suite); the literal occurrences of the model come from the HWLM oracle
-    kg = max(1, int(np.searchsorted(off, 8 << 20, side="right")) - 1)
-    g_off = np.ascontiguousarray(off[: kg + 1])
-    g_bytes = int(g_off[-1])
+    #    ... on 4 slices of `--rose-gate-mib` / 4 MiB each (round 4: the first 8 MiB): the head, two inside and the tail of the corpus
     keyed = db.literals()
     hl = [HwlmLiteral(k[0], k[1], i) for i, k in enumerate(keyed)]
-    hits = (ob.Reference(hl, variant=ob.ref_variants()[-1]) if ob.ref_available() else ob.Oracle(hl)).collect_blocks(corpus[:g_bytes], g_off)
-    want = RM.expected_events(corpus[:g_bytes], g_off, lits, hits)
-    got = []
-    cb = hs.BATCH_CB(lambda b, i, f, t, _fl, _c: (got.append((int(b), int(i), int(t))), 0)[1])
-    rv = lib.hs_scan_batch(db._h, buf.ctypes.data, g_off.ctypes.data, kg, 0, scratch._h, cb, None)
-    assert rv == 0
-    assert sorted(got) == want, f"PARITY FAILURE (rose1000): hs_scan_batch {len(got)} events vs model {len(want)} on the first {kg} blocks"
-    parity = (f"(block, id, to) of all 1000 patterns on the first {kg} blocks / {g_bytes} bytes ({len(want)} events) identical to the model of "
-              "tests/rose_model.py (literal occurrences from the reference's hwlmExec, tails restated; pinned to Python re in the CPU suite)")
+    href_ = ob.Reference(hl, variant=ob.ref_variants()[-1]) if ob.ref_available() else ob.Oracle(hl)
+    per = max(1, args.rose_gate_mib // 4) << 20
+    n_gate_ev, n_gate_blocks, n_gate_bytes, n_slices = 0, 0, 0, 0
+    c_total = int(off[-1])
+    for lo_byte in sorted({0, c_total // 3, 2 * c_total // 3, max(0, c_total - per)}):
+        b0 = min(int(np.searchsorted(off, lo_byte, side="left")), int(off.size - 2))
+        b1 = max(b0 + 1, int(np.searchsorted(off, min(c_total, int(off[b0]) + per), side="right")) - 1)
+        b1 = min(b1, int(off.size - 1))
+        g_lo, g_hi = int(off[b0]), int(off[b1])
+        g_off = np.ascontiguousarray(off[b0: b1 + 1] - off[b0])
+        hits = href_.collect_blocks(corpus[g_lo:g_hi], g_off)
+        want = RM.expected_events(corpus[g_lo:g_hi], g_off, lits, hits)
+        got = []
+        cb = hs.BATCH_CB(lambda b, i, f, t, _fl, _c: (got.append((int(b), int(i), int(t))), 0)[1])
+        rv = lib.hs_scan_batch(db._h, buf.ctypes.data + g_lo, g_off.ctypes.data, b1 - b0, 0, scratch._h, cb, None)
+        assert rv == 0
+        assert sorted(got) == want, (f"PARITY FAILURE (rose1000): hs_scan_batch {len(got)} events vs model {len(want)} on blocks [{b0}, {b1}) "
+                                     f"(bytes [{g_lo}, {g_hi}))")
+        n_gate_ev, n_gate_blocks, n_gate_bytes, n_slices = n_gate_ev + len(want), n_gate_blocks + b1 - b0, n_gate_bytes + g_hi - g_lo, n_slices + 1
+    parity = (f"(block, id, to) of all 1000 patterns on {n_slices} slices (head, two inside, tail: {n_gate_blocks} blocks / {n_gate_bytes} bytes, "
+              f"{n_gate_ev} events) identical to the model of tests/rose_model.py (literal occurrences from the reference's hwlmExec, tails restated; "
+              "pinned to Python re in the CPU suite)")
 
     # -- end to end from pinned host memory
     ts, n_ev = [], 0
@@ -1037,9 +1225,10 @@ def run_batch_sweep(args):
 
 # ---- the ONE line: compact, everything else to the details file ---------------------------------
 
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms_avg",
-                 "kernel_ms_device_clock_avg", "algorithmic_bytes_per_launch", "algorithmic_bytes_per_step", "ms_all_passes", "pipeline_ms_avg")
-CPU_KEYS = ("value", "unit", "cores", "kind", "cgroup_cpu_quota", "sample", "parity")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "step_frac", "step_achieved", "traffic", "traffic_source", "kernel", "kernel_ms_avg",
+                 "kernel_ms_trace", "kernel_ms_device_clock_avg", "confirm_stage_ms_avg", "algorithmic_bytes_per_launch", "algorithmic_bytes_per_step",
+                 "ms_all_passes", "pipeline_ms_avg")
+CPU_KEYS = ("value", "unit", "cores", "kind", "cgroup_cpu_quota", "sample")
 
 
 def _short(v, n=200):
@@ -1064,7 +1253,7 @@ def compact_also(name, r):
         return r
     keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "matches_per_s", "parity", "gpu_stage", "host_confirm",
             "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "GBps_one_block_per_call",
-            "half_peak_batch_bytes", "ninety_percent_batch_bytes", "curve", "parity_whole_corpus")
+            "half_peak_batch_bytes", "ninety_percent_batch_bytes", "curve", "parity_whole_corpus", "parity_reference")
     out = {"workload": _short(r.get("workload", name), 110)}
     for k in keep:
         if k in r:
@@ -1079,6 +1268,29 @@ def compact_also(name, r):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N ranks through torch.distributed.run on this node, the same command the
+    driver's contract uses. Fewer than N devices is an error, not a smaller run."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        log(f"bench.py: --gpus {n} asked for, this box shows {have} GPU(s): refusing to run a smaller job under that label")
+        return 3
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1089,9 +1301,10 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other workloads' lines")
     ap.add_argument("--also", default="teddy64,class256,rose1000,flood,fdr10k_8g,batch_sweep", help="comma-separated extra workloads at N = 1")
     ap.add_argument("--class-gib", type=float, default=4.0)
-    ap.add_argument("--class-gate-mib", type=int, default=4, help="class256: MiB of lines whose match ends are compared with the model")
+    ap.add_argument("--class-gate-mib", type=int, default=1, help="class256: MiB of lines PER SLICE (the head of every GiB + the tail) whose match ends are compared with the model")
     ap.add_argument("--details", default=None, help="where the full (uncompacted) result goes; default gpurun_out/bench_details.json")
     ap.add_argument("--rose-gib", type=float, default=2.0)
+    ap.add_argument("--rose-gate-mib", type=int, default=64, help="rose1000: MiB of packets (in 4 slices across the corpus) whose events are compared with the model")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--overlap-probe", action="store_true",
                     help="also time the steps with two scans in flight on two streams (reported as two_scans_in_flight, never "
@@ -1104,7 +1317,8 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "native", "native_all", "padded", "exact"],
                     help="N > 1: auto = the C ABI's exchange over RCCL, records to rank 0 (12-byte wire records), falling back to "
                          "torch.distributed (padded all-gather, or exact-size broadcasts when the per-rank counts are skewed) when it "
-                         "cannot be created; native_all = the same to every rank; padded / exact = the torch.distributed forms")
+                         "cannot be created; native_all = the same to every rank; padded / exact = the torch.distributed forms. "
+                         "(round 5: auto = native_all, the all-gather BASELINE.json names, with the to-root form timed beside it)")
     ap.add_argument("--pipeline-depth", type=int, default=0, choices=[0, 1, 2],
                     help="scans in flight: 2 overlaps a step's record all-gather with the next step's scan; "
                          "0 = 1 at N = 1 (the per-kernel figures are then those of the kernels alone), 2 at N > 1")
@@ -1112,11 +1326,20 @@ def main():
 
     import torch
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: the N ranks are launched from here (one process per GPU over RCCL, as the
+        # contract's torch.distributed.run line does), never a silent one-GPU run with n_gpus: 1 in the line
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or run `python bench.py --gpus "
+                         f"{args.gpus}` without WORLD_SIZE set: it starts them itself)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants device {local}, this box shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dist = None
     # HSGPU_BENCH_FORCE_DIST=1: take the N > 1 path (process group, exchange, two streams) at world size 1 too --
@@ -1129,7 +1352,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+        formed = dist.get_world_size()  # the ranks RCCL actually formed: what n_gpus reports
+        assert formed == world, f"process group of {formed} ranks, WORLD_SIZE {world}"
 
     do_cpu = (rank == 0 and dist is None and not args.no_cpu)
     main_res = run_workload(args.workload, args, rank, world, dist, do_cpu)
@@ -1151,10 +1375,11 @@ def main():
 
                     a8 = copy.copy(args)
                     a8.shards_override = list(range(args.shards))
+                    a8.reference_gate = not args.no_cpu
                     a8.steps, a8.warmup = max(3, min(args.steps, 10)), 2
                     r8 = run_workload("fdr10k", a8, rank, world, None, False)
                     also[name] = {"workload": f"fdr10k, {args.shards} shards x {args.gib:g} GiB resident on one GPU ({args.shards * args.gib:g} GiB per step)",
-                                  **{k: r8[k] for k in ("value", "ms_per_step", "matches_per_s", "matches_per_step", "parity_whole_corpus")},
+                                  **{k: r8[k] for k in ("value", "ms_per_step", "matches_per_s", "matches_per_step", "parity_whole_corpus", "parity_reference") if k in r8},
                                   "unit": "GB/s", "roofline": r8["roofline"]}
                 elif name != args.workload:
                     also[name] = run_workload(name, args, rank, world, dist, do_cpu)
@@ -1173,14 +1398,21 @@ def main():
                        "records": "16 B (block,end,id,lit), delivery order", "pipeline_depth": main_res["pipeline_depth"],
                        "sharding": (f"{world} x independent shards" if args.scaling == "weak" else
                                     f"strong: {args.shards} shards x {args.gib:g} GiB in all, {args.shards // world} per GPU")
-                       + (", RCCL all-gather of records per step" if dist is not None else "")},
+                       + ({"all_gather": ", RCCL all-gather of the match records per step (value); to-root timed beside it",
+                           "to_root": ", RCCL gather of the match records to rank 0 per step (value); all-gather timed beside it",
+                           "exact": ", torch.distributed broadcasts of exactly the records per step (value)",
+                           "padded": ", torch.distributed padded all-gather of the records per step (value)"}[main_res["exchange"]["value_uses"]]
+                          if dist is not None else "")},
             "matches_per_s": main_res["matches_per_s"], "matches_per_step": main_res["matches_per_step"],
             "roofline": compact_roofline(main_res["roofline"]),
         }
+        knobs = {k: os.environ[k] for k in ("HSGPU_LIB_VARIANT", "HSGPU_BUILD_FLAGS", "HSGPU_BENCH_FORCE_DIST") if os.environ.get(k)}
+        if knobs:  # a tuning build or forced table flags under the headline must be visible in the record
+            out["env_knobs"] = knobs
         if "cpu_baseline" in main_res:
             out["cpu_baseline"] = compact_cpu(main_res["cpu_baseline"])
         if "parity_whole_corpus" in main_res:
-            out["parity"] = {"reference": _short(main_res.get("cpu_baseline", {}).get("parity", "no CPU leg in this run"), 170),
+            out["parity"] = {"reference": _short(main_res.get("parity_reference", "no CPU leg in this run"), 200),
                              "whole_corpus": _short(main_res["parity_whole_corpus"], 170)}
         if "end_to_end_resident" in main_res:
             e = main_res["end_to_end_resident"]

@@ -192,7 +192,7 @@ class _Seq(C.Structure):
 SEQ_MAX, SEQ_MAX_REPEAT = 1024, 16
 
 
-def class_seq_scan(seqs, bitmaps, total, d_off, nblocks, emit=(0, 0), cap=0, stream=None, buffers=None):
+def class_seq_scan(seqs, bitmaps, total, d_off, nblocks, emit=(0, 0), cap=0, stream=None, buffers=None, emit_only=False):
     """A{m,}B{n,} class-sequence patterns over the membership bitmaps of class_scan (device-resident, torch).
     seqs: iterable of (a, b, m, n, id) with a, b indices into `bitmaps` (a list of 1-D uint8 device tensors,
     one per class). emit: corpus byte range [lo, hi) whose match ends are written as records (cap of them).
@@ -214,9 +214,17 @@ def class_seq_scan(seqs, bitmaps, total, d_off, nblocks, emit=(0, 0), cap=0, str
     lib.hsgpu_class_seq_scan_dev.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_uint64, C.c_void_p, C.c_uint64,
                                              C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]
-    rv = lib.hsgpu_class_seq_scan_dev(arr, len(seqs), ptrs, len(bitmaps), total, d_off.data_ptr(), nblocks, int(emit[0]),
-                                      int(emit[1]), counts.data_ptr(), out.data_ptr() if cap else None, cap, count.data_ptr(),
-                                      work.data_ptr(), work.numel() - 16, st)
+    if emit_only:  # hsgpu_class_seq_emit_dev: the records of a range of whole blocks, nothing counted, only that range walked
+        lib.hsgpu_class_seq_emit_dev.restype = C.c_int
+        lib.hsgpu_class_seq_emit_dev.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                 C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p]
+        rv = lib.hsgpu_class_seq_emit_dev(arr, len(seqs), ptrs, len(bitmaps), total, d_off.data_ptr(), nblocks, int(emit[0]), int(emit[1]),
+                                          out.data_ptr(), cap, count.data_ptr(), work.data_ptr(), work.numel() - 16, st)
+    else:
+        rv = lib.hsgpu_class_seq_scan_dev(arr, len(seqs), ptrs, len(bitmaps), total, d_off.data_ptr(), nblocks, int(emit[0]),
+                                          int(emit[1]), counts.data_ptr(), out.data_ptr() if cap else None, cap, count.data_ptr(),
+                                          work.data_ptr(), work.numel() - 16, st)
     if rv != 0:
         raise HsgpuError(rv, _native.load_library().hsgpu_last_error().decode())
     if buffers is not None:

@@ -241,11 +241,13 @@ class Reference:
     def info(self):
         return self.L.hsref_hwlm_info(self.h).decode() + " isa=" + self.L.hsref_build_isa().decode()
 
-    def collect_blocks(self, base, off, start=0, groups=HWLM_ALL_GROUPS):
-        """Every match as (block, end, id), in the reference's own delivery order."""
+    def collect_blocks(self, base, off, start=0, groups=HWLM_ALL_GROUPS, cap=1 << 16):
+        """Every match as (block, end, id), in the reference's own delivery order. `off` may be a slice of a larger
+        offset array (absolute offsets into `base`): block indices then count from the slice's first block. Thread safe
+        (the collecting context is thread local in oracle/ref_build/ref_driver.cpp), and the GIL is released while it runs."""
         a = _u8(base)
         off = np.ascontiguousarray(off, dtype=np.uint64)
-        cap = 1 << 16
+        cap = max(16, int(cap))
         while True:
             b = np.zeros(cap, dtype=np.uint32)
             e = np.zeros(cap, dtype=np.uint32)

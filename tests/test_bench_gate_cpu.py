@@ -55,3 +55,25 @@ def test_parity_gate_accepts_the_truth_and_refuses_everything_else():
     tail = recs.copy()
     tail[recs[:, 0] >= kg, 2] ^= 7
     assert "identical" in bench.parity_gate(tail, gate, lits)
+
+
+def test_whole_corpus_reference_gate_accepts_the_truth_and_refuses_a_single_wrong_record():
+    """reference_gate_full (round 5: every block of the corpus against the compiled reference, on all host threads, range by
+    range) -- the same refusals as the bounded gate, wherever in the corpus the damage sits"""
+    lits = cp.teddy_literals(64, seed=2)
+    corpus, off = cp.packet_corpus(4 << 20, lits, seed=5, match_every=2048)
+    recs, want = _records(lits, corpus, off)
+    msg = bench.reference_gate_full(lits, corpus, off, recs, "test")
+    assert f"ALL {off.size - 1} blocks / {len(want)} matches" in msg
+    for where in (0, len(recs) // 2, len(recs) - 1):
+        bad = recs.copy()
+        bad[where, 2] ^= 1
+        with pytest.raises(AssertionError, match="PARITY FAILURE"):
+            bench.reference_gate_full(lits, corpus, off, bad, "test")
+        with pytest.raises(AssertionError):
+            bench.reference_gate_full(lits, corpus, off, np.delete(recs, where, axis=0), "test")
+    bad = recs.copy()
+    a = len(recs) // 3
+    bad[[a, a + 1]] = bad[[a + 1, a]]
+    with pytest.raises(AssertionError):
+        bench.reference_gate_full(lits, corpus, off, bad, "test")

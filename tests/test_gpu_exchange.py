@@ -59,8 +59,13 @@ def test_bench_multi_gpu_path_at_world_size_1():
     line = json.loads(rows[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
     assert line["config"]["pipeline_depth"] == 2 and "RCCL" in line["config"]["sharding"]
-    ex = line["exchange"]  # (default: the C ABI's exchange, hsgpu_exchange_step, records to rank 0)
-    assert "hsgpu_exchange_step" in ex["collective"] and ex["gather_ms_avg_rank0"] > 0 and ex["wire_bytes_received_rank0"] == 0
+    ex = line["exchange"]  # (default: the C ABI's exchange, hsgpu_exchange_step; round 5: `value` over the all-gather, to-root timed beside it)
+    assert "hsgpu_exchange_step" in ex["collective"] and ex["value_uses"] == "all_gather" and "all-gather" in line["config"]["sharding"]
+    assert ex["all_gather"]["gather_ms_avg_rank0"] > 0 and ex["all_gather"]["wire_bytes_received_rank0"] == 0
+    assert ex["to_root"]["ms_per_step"] > 0
+    mg = line["multi_gpu"]
+    assert mg["measured"] is True and mg["n_gpus"] == 1 and len(mg["per_rank_GBps"]) == 1 and mg["per_rank_GBps"][0] > 0
+    assert line["env_knobs"] == {"HSGPU_BENCH_FORCE_DIST": "1"}
     # and the torch.distributed form it falls back to
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--gib", "0.0625", "--steps", "4", "--warmup", "2",
                         "--no-cpu", "--no-also", "--exchange", "padded"], cwd=root, env=dict(env, MASTER_PORT=str(_free_port())),
@@ -95,3 +100,21 @@ def test_bench_strong_scaling_mode_and_exact_exchange_at_world_size_1():
 
     assert np.array_equal(c, np.concatenate([c0, c1])) and o.size == o0.size + o1.size - 1 and int(o[-1]) == 1 << 26
     assert np.array_equal(o[o0.size - 1:], o1 + np.uint64(1 << 25))
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_to_run_fewer_gpus_than_asked_for():
+    """`python bench.py --gpus 2` with no launcher starts its ranks itself (torch.distributed.run); on a box with one GPU it
+    must fail loudly -- round 4's bench ran ONE GPU there and printed n_gpus: 1. The same under a launcher whose WORLD_SIZE
+    does not match --gpus."""
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 1), "--gib", "0.03125", "--steps", "2", "--no-cpu",
+                        "--no-also"], cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "refusing" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--gib", "0.03125", "--steps", "2", "--no-cpu", "--no-also"],
+                       cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
