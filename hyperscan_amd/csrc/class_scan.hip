@@ -27,6 +27,19 @@
 
 #include "internal.h"
 
+/* the CU count of a device, asked once (hipGetDeviceProperties on every call was a visible part of a small scan: advisor, round 4) */
+static int cached_cu_count(int dev) {
+    static std::mutex mu;
+    static std::map<int, int> known;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = known.find(dev);
+    if (it != known.end()) return it->second;
+    hipDeviceProp_t prop;
+    const int n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    known[dev] = n;
+    return n;
+}
+
 namespace {
 
 constexpr int CS_THREADS = 1024;
@@ -769,8 +782,7 @@ extern "C" int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_cla
         if (total_bytes == 0) return HSGPU_SUCCESS;
         int dev = 0, n_cu = 256;
         HIP_TRY(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        n_cu = cached_cu_count(dev);
         const uint64_t n_tiles = (total_bytes + B16_TILE - 1) / B16_TILE;
         /* five 32 KiB workgroups of four wavefronts per CU */
         const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 3) / 4, (uint64_t)n_cu * 5);
@@ -802,8 +814,7 @@ extern "C" int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_cla
     uint16_t *const *d_ptrs = (uint16_t *const *)(work + sizeof(lut));
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    n_cu = cached_cu_count(dev);
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void *)class_tile_fl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -957,8 +968,7 @@ extern "C" int hsgpu_pair_scan_dev(const hsgpu_pair_t *pairs, unsigned n_pairs, 
     uint16_t *const *d_ptrs = (uint16_t *const *)(work + sizeof(lut));
     int dev = 0, n_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    n_cu = cached_cu_count(dev);
     const uint64_t n_tiles = (total_bytes + CS_TILE - 1) / CS_TILE;
     const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)n_cu * 2);
     const uint8_t *corpus = (const uint8_t *)d_corpus;

@@ -797,15 +797,32 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
     }
     if (hdr.size() > SEQ_HEADER) return HSGPU_INVALID;
     {
+        /* the header goes up from page-locked memory, a ring of four staging areas each with an event: a copy out of one is
+         * awaited (that copy alone) before the area is written again. Round 4 kept a host copy per work-area pointer in a static
+         * map -- never erased, and a changed header meant hipDeviceSynchronize(): a device-wide stall on a no-wait path (advisor). */
+        struct Stage {
+            uint8_t *p = nullptr;
+            hipEvent_t ev = nullptr;
+            bool used = false;
+        };
         static std::mutex mu;
-        static std::map<void *, std::vector<uint8_t>> uploaded; /* by work area: the header it holds */
+        static std::map<int, std::vector<Stage>> rings; /* per device */
+        static std::map<int, unsigned> next;
+        int dev_now = 0;
+        HIP_TRY(hipGetDevice(&dev_now));
         std::lock_guard<std::mutex> lock(mu);
-        std::vector<uint8_t> &have = uploaded[d_work];
-        if (have != hdr) {
-            if (!have.empty()) HIP_TRY(hipDeviceSynchronize()); /* an upload from the old copy may still be on its way (on any stream) */
-            have = hdr;
+        std::vector<Stage> &ring = rings[dev_now];
+        if (ring.empty()) ring.resize(4);
+        Stage &sg = ring[next[dev_now]++ % ring.size()];
+        if (!sg.p) {
+            HIP_TRY(hipHostMalloc((void **)&sg.p, SEQ_HEADER));
+            HIP_TRY(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));
         }
-        HIP_TRY(hipMemcpyAsync(w, have.data(), have.size(), hipMemcpyHostToDevice, st));
+        if (sg.used) HIP_TRY(hipEventSynchronize(sg.ev));
+        memcpy(sg.p, hdr.data(), hdr.size());
+        HIP_TRY(hipMemcpyAsync(w, sg.p, hdr.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(sg.ev, st));
+        sg.used = true;
     }
     const uint64_t n_words = (total_bytes + 63) / 64;
     uint64_t *starts = (uint64_t *)(w + SEQ_HEADER);

@@ -370,6 +370,15 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
      * (64 literals: the 8 KiB staged per workgroup cost 3 us of a 17 us kernel). */
     if (!pair && !(tflags & HSGPU_F_HAS_C) && !(flags & HSGPU_BUILD_NO_GATE) && entries >= 2048 && (uint64_t)entries * 2 <= 65536)
         tflags |= HSGPU_F_GATE;
+    /* Round 5, opt-in: at stride 1 (every key is a delta-0 key) the gate can be a Bloom filter over the FULL-window keys instead
+     * -- table.h, HSGPU_F_BLOOM; it takes the gate's place (12 KiB of LDS instead of 8). Built because the verdict of round 4 asked
+     * for it and the simulator promised 70 % fewer bucket reads (tools/sim/bloomgate.py: A probes 3.64 M -> 0.69 M per GiB, which
+     * the device confirms by delivering identical records); not the default because the stage is no faster for it: 0.1747 ms against
+     * 0.1667 with the key gate, three alternating runs on one box (profiles/r05_bloom_gate_ab.txt). The stage is bound by the
+     * length of a step's dependent chain at six wavefronts per SIMD, not by its L2 requests; three more LDS round trips per
+     * candidate lengthen the chain. */
+    if ((tflags & HSGPU_F_GATE) && !stride2 && (flags & HSGPU_BUILD_FORCE_BLOOM)) tflags = (tflags & ~HSGPU_F_GATE) | HSGPU_F_BLOOM;
+    const size_t c2words = (tflags & HSGPU_F_BLOOM) ? HSGPU_BLOOM_WORDS : 2048;
     /* 64-bit entries for the large stride-1 two-bit sets whose kernel runs the 4-byte-key test alone (no 3-byte keys, or
      * folded ones): same 128 KiB, the second bit in a word of its own. Simulated on the bench's 10 000-literal set
      * (tools/sim/b2p.py): 11.5 M -> 8.8 M candidate lanes per GiB (a folded 3-byte key no longer passes every position
@@ -415,7 +424,7 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     h.off_filter = (uint32_t)off;
     off += (size_t)4 * fwords;
     h.off_c2bits = (uint32_t)off;
-    off += 2048 * 4;
+    off += c2words * 4;
     h.off_ht_a = (uint32_t)off;
     off += (sizeof(HsgpuHtSlot) * HSGPU_BUCKET_SLOTS) << ht_log2[0];
     h.off_ht_b = (uint32_t)off;
@@ -423,7 +432,28 @@ int hsgpu_compile_table(const hsgpu_lit_t *lits, size_t n, unsigned flags, std::
     h.off_c2ref = (uint32_t)off;
     off += (tflags & HSGPU_F_HAS_C) ? 65536 * 4 : 16;
 
-    std::vector<uint32_t> filter(fwords, 0), c2bits(2048, 0);
+    std::vector<uint32_t> filter(fwords, 0), c2bits(c2words, 0);
+    auto bloom_add = [&](uint32_t hi, uint32_t lo, uint32_t group) {
+        uint32_t idx[3];
+        hsgpu_bloom_idx(hi, lo, group, idx);
+        for (uint32_t j = 0; j < 3; j++) c2bits[(j << (HSGPU_BLOOM_PLANE_LOG2 - 5)) + (idx[j] >> 5)] |= 1u << (idx[j] & 31);
+    };
+    if (tflags & HSGPU_F_BLOOM) {
+        /* group 3: the keys of table B; groups 4 / 5: every class-A literal by its five last bytes when they are all given (no
+         * wildcard beyond the case bit of a case-blind table), else by each of its 4-byte key variants */
+        for (auto &kv : keys[1]) bloom_add(kv.first << 8, 0, 3);
+        const uint32_t blind1 = blind ? 0x20u : 0u;
+        for (size_t i = 0; i < n; i++) {
+            HsgpuDevLit l = dl[i];
+            l.msk |= (uint64_t)blind4 << 32;
+            l.v &= ~((uint64_t)blind4 << 32);
+            if (choose_class(l).cls != 0) continue;
+            const uint32_t m4 = (uint32_t)(l.msk >> 32), v4 = (uint32_t)(l.v >> 32);
+            const uint32_t m5 = (uint32_t)(dl[i].msk >> 24) & 0xffu, v5 = (uint32_t)(dl[i].v >> 24) & 0xffu;
+            if (m4 == 0xffffffffu && (m5 | blind1) == 0xffu) bloom_add(v4, (v5 & ~blind1) << 24, 5);
+            else for_each_variant(v4, ~m4, [&](uint32_t key) { bloom_add(key, 0, 4); });
+        }
+    }
     std::vector<HsgpuHtSlot> ht[2];
     for (int c = 0; c < 2; c++) ht[c].assign((size_t)HSGPU_BUCKET_SLOTS << ht_log2[c], 0u);
     std::vector<uint32_t> c2ref((tflags & HSGPU_F_HAS_C) ? 65536 : 4, 0);
@@ -563,7 +593,9 @@ int hsgpu_validate_blob(const void *buf, size_t len) {
         h.ht_a_log2 < 2 || h.ht_a_log2 > 26 || h.ht_b_log2 < 2 || h.ht_b_log2 > 26)
         return HSGPU_INVALID;
     auto in = [&](uint64_t off, uint64_t bytes) { return off >= sizeof(h) && off + bytes <= len; };
-    if (!in(h.off_filter, 4ull * hsgpu_filter_words(h.flags, h.filter_log2)) || !in(h.off_c2bits, 8192) ||
+    if (((h.flags & HSGPU_F_BLOOM) && (h.flags & (HSGPU_F_GATE | HSGPU_F_STRIDE2 | HSGPU_F_PAIR | HSGPU_F_HAS_C))) ||
+        !in(h.off_filter, 4ull * hsgpu_filter_words(h.flags, h.filter_log2)) ||
+        !in(h.off_c2bits, (h.flags & HSGPU_F_BLOOM) ? 4ull * HSGPU_BLOOM_WORDS : 8192) ||
         !in(h.off_ht_a, 16ull << h.ht_a_log2) || !in(h.off_ht_b, 16ull << h.ht_b_log2) ||
         !in(h.off_c2ref, (h.flags & HSGPU_F_HAS_C) ? 262144 : 16) || !in(h.off_lists, 4ull * h.n_lists) ||
         !in(h.off_lits, 32ull * h.n_lits))

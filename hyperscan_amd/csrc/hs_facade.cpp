@@ -1275,7 +1275,10 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
             if (rv == HSGPU_INSUFFICIENT_SPACE) {
                 resident = have_bitmaps = 1; /* (the batch and its bitmaps are on the device now whatever else happened) */
                 if (b1 - b0 > 1) {
-                    span = (b1 - b0) / 2;
+                    /* n_cs = the room this range needs: the next one is sized from the density it has just shown (three quarters of
+                     * the buffer), not by blind halving -- every failed attempt is a discarded launch (advisor, round 4) */
+                    const unsigned long long fit = (unsigned long long)((double)(b1 - b0) * 0.75 * (double)scratch->cs_recs.size() / (double)std::max<size_t>(1, n_cs));
+                    span = std::max<unsigned long long>(1, std::min<unsigned long long>((b1 - b0) / 2, fit));
                     continue;
                 }
                 scratch->cs_recs.resize(n_cs + n_cs / 8 + 16); /* one block alone holds more: it gets the room it needs */
@@ -1290,7 +1293,10 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
             any_terminated |= t;
             li = lj;
             b0 = b1;
-            if (n_cs * 4 < scratch->cs_recs.size() && span < nblocks) span *= 2; /* plenty of room: larger ranges */
+            /* the next range from this one's density: three quarters of the buffer, at most twice this span (a sparse range says
+             * little about the next one), never doubled blindly after one sparse range into a span that has just failed */
+            const unsigned long long fit = n_cs ? (unsigned long long)((double)(b1 - b0 ? b1 - b0 : 1) * 0.75 * (double)scratch->cs_recs.size() / (double)n_cs) : 2 * span;
+            span = std::max<unsigned long long>(1, std::min<unsigned long long>(std::min<unsigned long long>(2 * span, fit), nblocks));
         }
     } catch (const std::bad_alloc &) {
         return HS_NOMEM;

@@ -152,6 +152,14 @@ struct hsgpu_scratch {
     DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats;
     DevBuf pipe_corpus[2], pipe_off[2], pipe_out[2], pipe_count; /* hsgpu_hwlm_exec_batch_cb: two chunks in flight */
     hipEvent_t ev_copied[2] = {}, ev_scanned[2] = {};
+    /* ... its page-locked staging: the chunk's relative offsets on their way in, its records on their way out. (Round 4 copied
+     * both through pageable vectors: a pageable copy is staged by the runtime and synchronises, and the offsets' copy sat in the
+     * copy stream BETWEEN two chunks' corpus copies -- 0.1-0.2 ms of idle bus per chunk, the "0.2-0.6 ms per chunk that no copy
+     * hides" of DESIGN 6.) */
+    uint64_t *h_rel[2] = {nullptr, nullptr};
+    size_t h_rel_cap[2] = {0, 0};
+    hsgpu_match_t *h_prec[2] = {nullptr, nullptr};
+    size_t h_prec_cap[2] = {0, 0};
     DevBuf cs_bitmaps, cs_work, cs_counts; /* hsgpu_class_seq_exec_batch: class bitmaps, work areas, per-pattern counts */
     bool ctl_clean = false;                /* the control block the next scan will use is zero (left so by the scan before last) */
     unsigned ctl_parity = 0;               /* which half of the control buffer the next scan uses */
@@ -159,6 +167,11 @@ struct hsgpu_scratch {
     unsigned long long *h_count = nullptr; /* pinned */
     uint32_t *h_note = nullptr, *d_note = nullptr; /* mapped pinned word the fused fallback sets (see HsgpuScanArgs::overflow_note) */
     int tune_fused = 0;                    /* hsgpu_scratch_set_tuning (tests / tuning runs) */
+    int tune_solo = 0;                     /* fused_only == 3: never the single-launch path for small batches; 4: whenever the geometry allows */
+    DevBuf solo_ctl;                       /* solo scans: rec_counts | rec_super | ticket, left zeroed by the scan itself */
+    const void *res_corpus = nullptr, *res_off = nullptr; /* where the batch this scratch took in last lives (reuse_resident): its device buffers, or the mapped small-batch area */
+    uint8_t *h_small = nullptr, *d_small = nullptr; /* small host batches: mapped pinned {count | offsets | corpus | records}, read and written by the kernel itself */
+    bool solo_ctl_clean = false;
     int tune_unfolded = 0;                 /* fused_only == 2: two-phase with record_sort_kernel behind the confirm kernel */
     unsigned tune_wg_threads = 0, tune_wg_per_cu = 0;
     uint64_t cand_div = 64;                /* corpus bytes per candidate entry of capacity: 16 (room for every chunk) once a scan overflowed */
@@ -267,10 +280,13 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->tstamp.release();
     s->wg_stamps.release();
     s->rec_stage.release();
+    s->solo_ctl.release();
     for (int i = 0; i < 2; i++) {
         s->pipe_corpus[i].release();
         s->pipe_off[i].release();
         s->pipe_out[i].release();
+        if (s->h_rel[i]) (void)hipHostFree(s->h_rel[i]);
+        if (s->h_prec[i]) (void)hipHostFree(s->h_prec[i]);
         if (s->ev_copied[i]) (void)hipEventDestroy(s->ev_copied[i]);
         if (s->ev_scanned[i]) (void)hipEventDestroy(s->ev_scanned[i]);
     }
@@ -280,6 +296,7 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->cs_counts.release();
     if (s->h_count) (void)hipHostFree(s->h_count);
     if (s->h_note) (void)hipHostFree(s->h_note);
+    if (s->h_small) (void)hipHostFree(s->h_small);
     if (s->h_recs) (void)hipHostFree(s->h_recs);
     for (int i = 0; i < 4; i++)
         if (s->ev_chunk[i]) (void)hipEventDestroy(s->ev_chunk[i]);
@@ -410,6 +427,7 @@ extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsi
     if (!s || (wg_threads && (wg_threads % 64 || wg_threads < 256 || wg_threads > 1024)) || wg_per_cu > 4) return HSGPU_INVALID;
     s->tune_fused = fused_only == 1;
     s->tune_unfolded = fused_only == 2;
+    s->tune_solo = fused_only == 3 ? 1 : fused_only == 4 ? 2 : 0;
     s->tune_wg_threads = wg_threads;
     s->tune_wg_per_cu = wg_per_cu;
     return HSGPU_SUCCESS;
@@ -430,18 +448,19 @@ extern "C" unsigned hsgpu_confirm_partition(unsigned n_shares, unsigned max_work
 }
 
 /* how many confirm workgroups the device holds at once (per kernel instantiation: the register count differs) */
-static unsigned confirm_resident_workgroups(hsgpu_scratch *s, const void *f_conf) {
+static unsigned confirm_resident_workgroups(hsgpu_scratch *s, const void *f_conf, size_t gate_lds) {
     static std::mutex mu;
-    static std::map<const void *, int> per_cu;
+    static std::map<std::pair<const void *, size_t>, int> per_cu;
     std::lock_guard<std::mutex> g(mu);
-    auto it = per_cu.find(f_conf);
+    const std::pair<const void *, size_t> key(f_conf, gate_lds);
+    auto it = per_cu.find(key);
     if (it == per_cu.end()) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f_conf, HSGPU_CONFIRM_THREADS, 0) != hipSuccess || nb < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f_conf, HSGPU_CONFIRM_THREADS, gate_lds) != hipSuccess || nb < 1) {
             (void)hipGetLastError();
             nb = 4;
         }
-        it = per_cu.emplace(f_conf, nb).first;
+        it = per_cu.emplace(key, nb).first;
     }
     return (unsigned)it->second * (unsigned)std::max(1, s->n_cu);
 }
@@ -486,6 +505,9 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)s->n_cu * wg_per_cu);
 
     HsgpuScanArgs args = a;
+    args.solo = 0;
+    args.solo_ctl_words = 0;
+    args.solo_ticket = nullptr;
     args.t_flags = h->flags;
     args.fold_shift = (h->flags & (HSGPU_F_BFOLD | HSGPU_F_PAIR)) ? 16u : 0u; /* one filter test stands for every key class */
     args.t_hash_mask = h->hash_mask;
@@ -500,6 +522,69 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.t_off_lists = h->off_lists;
     args.t_off_lits = h->off_lits;
     int rv;
+    /* Small batches: ONE launch (the fused kernel with the placement in its last workgroup; scan_device.h, solo_tail). The
+     * reference serves short blocks from dedicated small matchers (src/rose/block.c:382-391, src/runtime.c:401-413); here
+     * three launches were ~20 us of fixed cost per scan whatever its size. Up to SOLO_BYTES by default (beyond that the
+     * two-phase pipeline's throughput wins), the default pipeline only, not in dense mode. */
+    constexpr uint64_t SOLO_BYTES = 1ull << 20;
+    const bool solo_ok = !s->tune_fused && !s->tune_unfolded && s->tune_solo != 1 && s->cand_div == 64 && !(s->h_note && *s->h_note) &&
+                         (size_t)hsgpu_filter_words(h->flags, h->filter_log2) * 4 >= 28 * 1024;
+    if (solo_ok && (a.total <= SOLO_BYTES || s->tune_solo == 2)) {
+        /* 16 KiB (8 KiB for 512-thread workgroups) per workgroup up to 32 workgroups, then larger shares; forced on big
+         * corpora (tests): at most 64 workgroups = 1024 regions */
+        const unsigned solo_grid = (unsigned)std::min<uint64_t>(n_tiles, a.total <= SOLO_BYTES ? 32 : 1024 / (wg_threads / 64));
+        const uint32_t n_reg = solo_grid * (wg_threads / 64);
+        /* (the hints: every wavefront writes those of its own tiles in the kernel's prologue) */
+        args.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
+        if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+        args.hint = (const uint32_t *)s->hint.p;
+        args.hint_in_filter = 0;
+        args.fold = 0;
+        args.conf_q = args.conf_k = 1;
+        args.cand = nullptr;
+        args.cand_cap = 0;
+        args.cand_waves = 0;
+        args.cand_counts = nullptr;
+        args.rec_regions = n_reg;
+        args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_reg + 1)));
+        if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_reg * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
+        args.rec_stage = (uint4 *)s->rec_stage.p;
+        const size_t super_ofs = ((size_t)2 * 1024 + 1) & ~(size_t)1, ticket_ofs = super_ofs + 2 * HSGPU_SUPER_WORDS;
+        const size_t ctl_words = (ticket_ofs + 4) & ~(size_t)3;
+        const size_t cap_before = s->solo_ctl.cap;
+        if ((rv = s->solo_ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+        if (s->solo_ctl.cap != cap_before || !s->solo_ctl_clean) HIP_TRY(hipMemsetAsync(s->solo_ctl.p, 0, s->solo_ctl.cap, stream));
+        s->solo_ctl_clean = true; /* (the scan's last workgroup leaves it zeroed) */
+        args.rec_counts = (uint32_t *)s->solo_ctl.p;
+        args.rec_super = (unsigned long long *)((uint32_t *)s->solo_ctl.p + super_ofs);
+        args.solo_ticket = (uint32_t *)s->solo_ctl.p + ticket_ofs;
+        args.solo_ctl_words = (uint32_t)ctl_words;
+        args.super_shift = 5;
+        args.group_regions = 1;
+        args.ctl_other = nullptr;
+        args.ctl_other_words = 0;
+        args.stats = (unsigned long long *)s->stats.p;
+        args.overflow_note = s->d_note;
+        args.solo = 1;
+        args.tstamp = nullptr;
+        args.tstamp_next = nullptr;
+        args.wg_stamps = nullptr;
+        if (s->timing) {
+            const size_t slot = s->n_timed % hsgpu_scratch::kRing;
+            s->ev_t = s->ev_ring[slot];
+            args.tstamp = (unsigned long long *)s->tstamp.p + 4 * slot;
+            args.tstamp_next = (unsigned long long *)s->tstamp.p + 4 * ((slot + 1) % hsgpu_scratch::kRing);
+            HIP_TRY(hipEventRecord(s->ev_t[0], stream));
+        }
+        void *skargs[] = {&args};
+        if ((rv = set_dyn_lds(f_fused, lds)) != HSGPU_SUCCESS) return rv;
+        HIP_TRY(hipLaunchKernel(f_fused, dim3(solo_grid), dim3(wg_threads), skargs, lds, stream));
+        if (s->timing) {
+            HIP_TRY(hipEventRecord(s->ev_t[1], stream));
+            s->n_timed++;
+        }
+        return HSGPU_SUCCESS;
+    }
     /* phase 0: per-KiB block hints */
     args.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
     if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
@@ -543,6 +628,8 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * mode (fold = 2) dense batches are confirmed position by position; a set with more matches per position than the queue
      * orders that way makes the scan say "again" once more, and the scratch goes on with record_sort_kernel, which sorts
      * whatever it is given. */
+    /* the confirm kernel's gate in dynamic LDS: the 64 Kbit key gate, or the opt-in Bloom gate's three planes (table.h) */
+    const size_t gate_lds = (h->flags & HSGPU_F_PAIR) ? 16 : (h->flags & HSGPU_F_BLOOM) ? (size_t)HSGPU_BLOOM_WORDS * 4 : 8192;
     const bool fold = two_phase && s->d_note && !s->tune_unfolded && !(s->cand_div == 16 && s->dense_unfolded);
     args.fold = fold ? (s->cand_div == 16 ? 2u : 1u) : 0u;
     if (args.fold == 2 && !(f_conf = hsgpu_confirm_kernel_for(h->flags, true))) return HSGPU_INVALID;
@@ -556,7 +643,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
          * worker wavefront, so that the parts go round the workers the device holds at once as evenly as whole numbers allow
          * (4 096 shares on 6 144 workers: Q = 3, K = 2). */
-        const unsigned w_max = confirm_resident_workgroups(s, f_conf) * (HSGPU_CONFIRM_THREADS / 64);
+        const unsigned w_max = confirm_resident_workgroups(s, f_conf, gate_lds) * (HSGPU_CONFIRM_THREADS / 64);
         unsigned q = 1, k = 1;
         const unsigned workers = hsgpu_confirm_partition(n_waves, w_max, &q, &k);
         args.conf_q = q, args.conf_k = k;
@@ -642,7 +729,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         HIP_TRY(hipLaunchKernel(f_two, dim3(grid), dim3(wg_threads), kargs, lds_two, stream));
         if (s->timing) HIP_TRY(hipEventRecord(s->ev_t[1], stream));
         /* the confirm kernel's workers: at most as many as the device holds at once */
-        HIP_TRY(hipLaunchKernel(f_conf, dim3(conf_grid), dim3(HSGPU_CONFIRM_THREADS), kargs, 0, stream));
+        HIP_TRY(hipLaunchKernel(f_conf, dim3(conf_grid), dim3(HSGPU_CONFIRM_THREADS), kargs, gate_lds, stream));
         /* No fused kernel behind it (it used to be launched on every scan, to return at once): a scan whose candidate regions
          * overflowed reports count = cap + 1 like one whose staging regions did -- "again" -- and sets the scratch's note,
          * so that the next scan has room for every chunk. Without the note (mapped host memory unavailable) the always-correct
@@ -793,6 +880,50 @@ static int upload_batch(hsgpu_scratch *s, const uint8_t *base, const uint64_t *o
     if (total) HIP_TRY(hipMemcpyAsync(s->corpus.p, base + lo, total, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->off.p, rel.data(), rel.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream)); /* `rel` goes out of scope */
+    s->res_corpus = s->corpus.p, s->res_off = s->off.p;
+    return HSGPU_SUCCESS;
+}
+
+/* Small host batches (one packet per hwlmExec call is the reference's normal diet: src/rose/block.c:382-391,
+ * tools/hsbench/engine_hyperscan.cpp:132-145): no copy commands at all. The batch is laid out in mapped pinned memory owned by
+ * the scratch -- {count | offsets | corpus | records} -- and the scan kernel reads it over the bus and writes records and count
+ * back into it: ONE kernel launch (a solo scan, launch_scan) and one stream synchronisation per call. Round 4: an H2D copy, a
+ * synchronisation, a memset, three launches, a D2H of the count, a synchronisation and a blocking D2H of the records --
+ * 68-72 us per 1 460-byte call. -> HSGPU_SUCCESS, or 1 when the batch does not fit this path (the caller takes the general one). */
+constexpr size_t SMALL_BYTES = 256 << 10, SMALL_BLOCKS = 4096, SMALL_RECS = 4096;
+constexpr size_t SMALL_OFF_AT = 64, SMALL_CORPUS_AT = SMALL_OFF_AT + (SMALL_BLOCKS + 1) * 8 + 56 /* -> a multiple of 64 */,
+                 SMALL_RECS_AT = SMALL_CORPUS_AT + SMALL_BYTES + 64, SMALL_TOTAL = SMALL_RECS_AT + SMALL_RECS * sizeof(hsgpu_match_t);
+static_assert(SMALL_CORPUS_AT % 64 == 0 && SMALL_RECS_AT % 64 == 0, "aligned sections");
+static int scan_host_small(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base, const uint64_t *off, size_t nblocks,
+                           size_t start, std::vector<hsgpu_match_t> &recs) {
+    const uint64_t lo = off[0], total = off[nblocks] - off[0];
+    if (total > SMALL_BYTES || nblocks > SMALL_BLOCKS) return 1;
+    for (size_t i = 0; i < nblocks; i++)
+        if (off[i + 1] < off[i]) return 1; /* (the general path reports it) */
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->h_small) {
+        if (hipHostMalloc((void **)&s->h_small, SMALL_TOTAL, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&s->d_small, s->h_small, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (s->h_small) (void)hipHostFree(s->h_small);
+            s->h_small = s->d_small = nullptr;
+            return 1;
+        }
+    }
+    uint64_t *h_off = (uint64_t *)(s->h_small + SMALL_OFF_AT);
+    for (size_t i = 0; i <= nblocks; i++) h_off[i] = off[i] - lo;
+    memcpy(s->h_small + SMALL_CORPUS_AT, base + lo, total);
+    memset(s->h_small + SMALL_CORPUS_AT + total, 0, 16);
+    *(volatile unsigned long long *)s->h_small = ~0ull;
+    s->res_corpus = s->d_small + SMALL_CORPUS_AT, s->res_off = s->d_small + SMALL_OFF_AT;
+    int rv = hsgpu_hwlm_scan_dev(t, s, s->d_small + SMALL_CORPUS_AT, total, s->d_small + SMALL_OFF_AT, nblocks, start,
+                                 s->d_small + SMALL_RECS_AT, SMALL_RECS, s->d_small, s->stream);
+    if (rv != HSGPU_SUCCESS) return rv;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const uint64_t n = *(volatile unsigned long long *)s->h_small;
+    if (n > SMALL_RECS) return 1; /* more matches than this path's buffer holds (or "again"): the general path */
+    recs.resize(n);
+    if (n) memcpy(recs.data(), s->h_small + SMALL_RECS_AT, n * sizeof(hsgpu_match_t));
     return HSGPU_SUCCESS;
 }
 
@@ -802,7 +933,10 @@ static int scan_host(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base,
     recs.clear();
     const uint64_t total = off[nblocks] - off[0];
     if (total == 0) return HSGPU_SUCCESS;
-    int rv = upload_batch(s, base, off, nblocks);
+    int rv = scan_host_small(t, s, base, off, nblocks, start, recs);
+    if (rv != 1) return rv;
+    recs.clear();
+    rv = upload_batch(s, base, off, nblocks);
     if (rv != HSGPU_SUCCESS) return rv;
     uint64_t cap = std::max<uint64_t>(4096, total / 256);
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -856,7 +990,7 @@ extern "C" int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned
     for (unsigned c = 0; c < n_classes; c++) ptrs[c] = (uint8_t *)s->cs_bitmaps.p + row * c;
     for (unsigned c = 0; c < n_classes; c += HSGPU_CLASS_MAX_BITMAPS) { /* bitmaps alone: 16 classes per read of the corpus */
         const unsigned k = std::min<unsigned>(HSGPU_CLASS_MAX_BITMAPS, n_classes - c);
-        rv = hsgpu_class_scan_dev(classes + c, k, s->corpus.p, total, s->off.p, nblocks, ptrs.data() + c, nullptr, nullptr,
+        rv = hsgpu_class_scan_dev(classes + c, k, s->res_corpus, total, s->res_off, nblocks, ptrs.data() + c, nullptr, nullptr,
                                   s->cs_work.p, s->stream);
         if (rv != HSGPU_SUCCESS) return rv;
     }
@@ -864,7 +998,7 @@ extern "C" int hsgpu_class_seq_exec_batch(const hsgpu_class_t *classes, unsigned
     uint64_t dcap = std::max<uint64_t>(cap, 4096);
     for (int attempt = 0; attempt < 3; attempt++) {
         if ((rv = s->out.ensure(dcap * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return rv;
-        rv = hsgpu_class_seq_scan_dev(seqs, n_seqs, ptrs.data(), n_classes, total, s->off.p, nblocks, 0, total,
+        rv = hsgpu_class_seq_scan_dev(seqs, n_seqs, ptrs.data(), n_classes, total, s->res_off, nblocks, 0, total,
                                       s->cs_counts.p, s->out.p, dcap, s->count.p, work2, seq_work, s->stream);
         if (rv != HSGPU_SUCCESS) return rv;
         HIP_TRY(hipMemcpyAsync(s->h_count, s->count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
@@ -896,6 +1030,10 @@ extern "C" int hsgpu_class_seq_exec_blocks(const hsgpu_class_t *classes, unsigne
     if (block_lo == block_hi) return HSGPU_SUCCESS;
     const uint64_t total = off[nblocks] - off[0];
     if (total == 0) return HSGPU_SUCCESS;
+    /* a range of empty blocks with batch and bitmaps already in place: nothing to emit (an empty emit range would select the
+     * counting kernel and walk the corpus for nothing; advisor, round 4). A first call still uploads and classifies: its caller
+     * goes on with reuse_resident / reuse_bitmaps. */
+    if (off[block_lo] == off[block_hi] && reuse_resident && reuse_bitmaps) return HSGPU_SUCCESS;
     if (!base && !reuse_resident) return HSGPU_INVALID;
     InUse guard(s);
     if (!guard.ok) return HSGPU_SCRATCH_IN_USE;
@@ -911,13 +1049,13 @@ extern "C" int hsgpu_class_seq_exec_blocks(const hsgpu_class_t *classes, unsigne
     for (unsigned c = 0; c < n_classes; c++) ptrs[c] = (uint8_t *)s->cs_bitmaps.p + row * c;
     for (unsigned c = 0; !reuse_bitmaps && c < n_classes; c += HSGPU_CLASS_MAX_BITMAPS) {
         const unsigned k = std::min<unsigned>(HSGPU_CLASS_MAX_BITMAPS, n_classes - c);
-        rv = hsgpu_class_scan_dev(classes + c, k, s->corpus.p, total, s->off.p, nblocks, ptrs.data() + c, nullptr, nullptr,
+        rv = hsgpu_class_scan_dev(classes + c, k, s->res_corpus, total, s->res_off, nblocks, ptrs.data() + c, nullptr, nullptr,
                                   s->cs_work.p, s->stream);
         if (rv != HSGPU_SUCCESS) return rv;
     }
     void *work2 = (uint8_t *)s->cs_work.p + ((HSGPU_CLASS_WORK_BYTES + 63) & ~(size_t)63);
     if ((rv = s->out.ensure(std::max<size_t>(cap, 4096) * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return rv;
-    rv = hsgpu_class_seq_emit_dev(seqs, n_seqs, ptrs.data(), n_classes, total, s->off.p, nblocks, off[block_lo] - off[0], off[block_hi] - off[0],
+    rv = hsgpu_class_seq_emit_dev(seqs, n_seqs, ptrs.data(), n_classes, total, s->res_off, nblocks, off[block_lo] - off[0], off[block_hi] - off[0],
                                   s->out.p, cap, s->count.p, work2, seq_work, s->stream);
     if (rv != HSGPU_SUCCESS) return rv;
     HIP_TRY(hipMemcpyAsync(s->h_count, s->count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
@@ -949,7 +1087,7 @@ struct ChunkResult {
 
 static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base, const uint64_t *off, size_t nblocks,
                           size_t start, const std::vector<size_t> &cuts, std::mutex &mu, std::condition_variable &cv,
-                          std::deque<ChunkResult> &queue, std::atomic<bool> &abort) {
+                          std::deque<ChunkResult> &queue, std::atomic<bool> &abort, std::atomic<bool> &producer_dead) {
     auto fail = [&](int rv) {
         /* a copy from the caller's buffer may still be on its way: the caller is free to release that buffer once the call
          * has returned, so nothing of it may be in flight by then (advisor, round 3) */
@@ -963,9 +1101,11 @@ static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *
                 std::lock_guard<std::mutex> g(mu);
                 queue.push_back(std::move(r));
             }
-        } catch (...) { /* not even the end marker could be queued: the consumer watches this flag too */
+        } catch (...) { /* not even the end marker could be queued: the consumer watches this flag of its own (advisor, round 4:
+                         * `abort` also means "the caller asked to stop", and a consumer that had asked waited for ever) */
             std::lock_guard<std::mutex> g(mu);
             abort = true;
+            producer_dead = true;
         }
         cv.notify_all();
         return rv;
@@ -973,7 +1113,20 @@ static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *
     try {
     if (hipSetDevice(s->device) != hipSuccess) return fail(HSGPU_UNKNOWN_ERROR);
     const size_t n_chunks = cuts.size() - 1;
-    std::vector<uint64_t> rel[2];
+    /* page-locked memory that grows on demand (freed with the scratch) */
+    auto pinned = [&](void **p, size_t *cap, size_t bytes) -> int {
+        if (*cap >= bytes) return HSGPU_SUCCESS;
+        if (*p) (void)hipHostFree(*p);
+        *p = nullptr, *cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            *p = nullptr;
+            return HSGPU_NOMEM;
+        }
+        *cap = want;
+        return HSGPU_SUCCESS;
+    };
     auto copy_in = [&](size_t i) -> int {
         const int slot = (int)(i & 1);
         const size_t b0 = cuts[i], b1 = cuts[i + 1];
@@ -981,11 +1134,13 @@ static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *
         int rv;
         if ((rv = s->pipe_corpus[slot].ensure(bytes + 16)) != HSGPU_SUCCESS) return rv;
         if ((rv = s->pipe_off[slot].ensure((b1 - b0 + 1) * sizeof(uint64_t))) != HSGPU_SUCCESS) return rv;
-        rel[slot].resize(b1 - b0 + 1);
-        for (size_t k = 0; k <= b1 - b0; k++) rel[slot][k] = off[b0 + k] - lo;
+        /* (the slot's last copy out of this staging area belonged to chunk i - 2, whose scan this thread has waited for) */
+        if ((rv = pinned((void **)&s->h_rel[slot], &s->h_rel_cap[slot], (b1 - b0 + 1) * sizeof(uint64_t))) != HSGPU_SUCCESS) return rv;
+        uint64_t *rel = s->h_rel[slot];
+        for (size_t k = 0; k <= b1 - b0; k++) rel[k] = off[b0 + k] - lo;
+        /* the small copy FIRST: behind the corpus it would wait for it, and the scan for both */
+        HIP_TRY(hipMemcpyAsync(s->pipe_off[slot].p, rel, (b1 - b0 + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s->side));
         if (bytes) HIP_TRY(hipMemcpyAsync(s->pipe_corpus[slot].p, base + lo, bytes, hipMemcpyHostToDevice, s->side));
-        HIP_TRY(hipMemcpyAsync(s->pipe_off[slot].p, rel[slot].data(), rel[slot].size() * sizeof(uint64_t), hipMemcpyHostToDevice,
-                               s->side));
         HIP_TRY(hipEventRecord(s->ev_copied[slot], s->side));
         return HSGPU_SUCCESS;
     };
@@ -1030,13 +1185,17 @@ static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *
             cap = std::max<uint64_t>(n + n / 4, cap * 2); /* the count is exact: again with room (and headroom for skew) */
         }
         ChunkResult r;
-        try {
-            r.recs.resize(n);
-        } catch (...) {
-            return fail(HSGPU_NOMEM);
+        if (n) { /* the records: to page-locked memory on the scan's own stream (no default-stream copy, nothing staged), then into the chunk's vector */
+            if ((rv = pinned((void **)&s->h_prec[slot], &s->h_prec_cap[slot], n * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return fail(rv);
+            if (hipMemcpyAsync(s->h_prec[slot], s->pipe_out[slot].p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+                hipStreamSynchronize(s->stream) != hipSuccess)
+                return fail(HSGPU_UNKNOWN_ERROR);
+            try {
+                r.recs.assign(s->h_prec[slot], s->h_prec[slot] + n);
+            } catch (...) {
+                return fail(HSGPU_NOMEM);
+            }
         }
-        if (n && hipMemcpy(r.recs.data(), s->pipe_out[slot].p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost) != hipSuccess)
-            return fail(HSGPU_UNKNOWN_ERROR);
         for (hsgpu_match_t &m : r.recs) m.block += (uint32_t)b0;
         r.last = i + 1 == n_chunks;
         {
@@ -1089,21 +1248,26 @@ extern "C" int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *
 #ifndef HSGPU_CHUNK_MIB
 #define HSGPU_CHUNK_MIB 64 /* tuning builds */
 #endif
+    /* the caller's chunk size as it is; the default ramps up -- 8, 16, 32, then 64 MiB -- so that the pipeline's fill (nothing is
+     * scanned before the first chunk has arrived: 1.2 ms for 64 MiB at 57 GB/s) costs an eighth of that */
+    const bool ramp = chunk_bytes == 0;
     if (!chunk_bytes) chunk_bytes = (size_t)HSGPU_CHUNK_MIB << 20;
     std::vector<size_t> cuts; /* block indices: chunk i = blocks [cuts[i], cuts[i + 1]) */
     try {
         cuts.push_back(0);
         while (cuts.back() < nblocks) {
             const uint64_t lo = off[cuts.back()];
-            size_t b = std::upper_bound(off + cuts.back(), off + nblocks + 1, lo + chunk_bytes) - off; /* first offset past the chunk */
+            const size_t k = cuts.size() - 1;
+            const size_t this_chunk = (ramp && k < 3) ? std::max<size_t>(chunk_bytes >> (3 - k), 1 << 20) : chunk_bytes;
+            size_t b = std::upper_bound(off + cuts.back(), off + nblocks + 1, lo + this_chunk) - off; /* first offset past the chunk */
             b = std::max<size_t>(b - 1, cuts.back() + 1); /* at least one block (a block larger than the chunk goes alone) */
             cuts.push_back(std::min(b, nblocks));
         }
         std::mutex mu;
         std::condition_variable cv;
         std::deque<ChunkResult> queue;
-        std::atomic<bool> abort{false};
-        std::thread producer([&] { (void)produce_chunks(t, s, base, off, nblocks, start, cuts, mu, cv, queue, abort); });
+        std::atomic<bool> abort{false}, producer_dead{false};
+        std::thread producer([&] { (void)produce_chunks(t, s, base, off, nblocks, start, cuts, mu, cv, queue, abort, producer_dead); });
         struct Join { /* whatever happens below (the caller's function may throw): the producer winds down and is joined */
             std::thread &th;
             std::atomic<bool> &abort;
@@ -1117,7 +1281,7 @@ extern "C" int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *
             ChunkResult r;
             {
                 std::unique_lock<std::mutex> g(mu);
-                cv.wait(g, [&] { return !queue.empty() || (abort && !stop); });
+                cv.wait(g, [&] { return !queue.empty() || producer_dead; });
                 if (queue.empty()) { /* the producer failed without being able to say so */
                     rv = HSGPU_NOMEM;
                     break;

@@ -139,6 +139,7 @@ struct Tables {
     const uint32_t *c2ref, *lists;
     const uint32_t *gate; /* pair tables: 64 Kbit "some 3-byte key has this hash" (hsgpu_gate_bit) */
     const uint32_t *key_gate; /* confirm kernel, HSGPU_F_GATE tables: the 64 Kbit key gate staged in LDS, else nullptr */
+    const uint32_t *bloom;    /* confirm kernel, HSGPU_F_BLOOM tables: the full-window Bloom gate (three planes of 2^15 bits) in LDS */
     const HsgpuDevLit *lits;
     uint32_t ht_a_log2, ht_b_log2;
     uint32_t key_mask;    /* 0xdfdfdfdf when the exact-table keys are case-blind, else all ones */
@@ -189,10 +190,33 @@ __device__ __forceinline__ uint64_t find_block(const uint64_t *off, uint64_t lo,
     return lo;
 }
 
+/* The same by a whole wavefront for a wave-uniform g: 64 probes per round (every lane one offset of an evenly spaced grid, a
+ * ballot picks the segment) -- two dependent rounds for 4 096 blocks instead of twelve. Searches [0, nblocks]: index nblocks
+ * stands for "at or behind the last offset", as the block hints use it. */
+__device__ __forceinline__ uint64_t find_block_wave(const uint64_t *off, uint64_t nblocks, uint64_t g, uint32_t lane) {
+    uint64_t lo = 0, n = nblocks + 1; /* invariant: off[lo] <= g; the answer lies in [lo, lo + n) */
+    while (n > 1) {
+        const uint64_t step = (n + 63) >> 6;
+        const uint64_t at = (uint64_t)lane * step;
+        const uint64_t v = off[min(lo + at, nblocks)];
+        const uint64_t mask = __ballot(at < n && v <= g); /* monotone: lanes 0 .. k - 1 */
+        const uint64_t k = (uint64_t)__popcll(mask);
+        const uint64_t adv = (k ? k - 1 : 0) * step;
+        lo += adv;
+        n = min(step, n - adv);
+    }
+    return lo;
+}
+
 /* Block of corpus offset g and that block's start. Two dependent reads in the
  * common case: the hint pair, then the next three offsets after off[lo] all at
  * once; only tiles cut into more than three blocks fall back to bisection. */
 __device__ __forceinline__ uint64_t block_of(const Tables &t, uint64_t g, uint64_t &block_start) {
+    if (!t.hint) { /* solo scans (small batches, one launch): no hints were written; a few thousand blocks at most */
+        const uint64_t b = find_block(t.off, 0, t.nblocks - 1, g);
+        block_start = t.off[b];
+        return b;
+    }
     const uint64_t tile = g >> HSGPU_HINT_SHIFT;
     const uint64_t lo = t.hint[tile];
     const uint64_t hi = (tile + 1 < t.n_hint) ? t.hint[tile + 1] : t.nblocks - 1;
@@ -441,6 +465,27 @@ __device__ __forceinline__ void check_lit_loaded(const Tables &t, uint32_t ent, 
     push_match(t, ge, ent & HSGPU_LIST_LIT_MASK);
 }
 
+/* The Bloom gate (table.h, HSGPU_F_BLOOM) for one masked window {hi, lo} of group `salt`: ~0 when all three planes have the
+ * key's bit, else 0. Three LDS reads; v_bfe_i32 takes the bit index from the low five bits of its operand. */
+__device__ __forceinline__ uint32_t bloom_pass(const uint32_t *bl, uint32_t hi, uint32_t lo, uint32_t salt) {
+    uint32_t idx[3];
+    hsgpu_bloom_idx(hi, lo, salt, idx);
+    constexpr uint32_t PW = 1u << (HSGPU_BLOOM_PLANE_LOG2 - 5);
+    const uint32_t w0 = bl[idx[0] >> 5], w1 = bl[PW + (idx[1] >> 5)], w2 = bl[2 * PW + (idx[2] >> 5)];
+    uint32_t r0, r1, r2;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r0) : "v"(w0), "v"(idx[0]));
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r1) : "v"(w1), "v"(idx[1]));
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r2) : "v"(w2), "v"(idx[2]));
+    return r0 & r1 & r2;
+}
+/* -> which exact tables a position with this (case-blinded where the table is) window has to be probed in */
+template <bool HAS_B>
+__device__ __forceinline__ void bloom_gate(const Tables &t, uint32_t whi, uint32_t wlo, uint32_t &pass_a, uint32_t &pass_b) {
+    const uint32_t hb = whi & t.key_mask, lb = wlo & t.key_mask & 0xff000000u;
+    pass_a = bloom_pass(t.bloom, hb, lb, 5) | bloom_pass(t.bloom, hb, 0, 4);
+    pass_b = HAS_B ? bloom_pass(t.bloom, hb & 0xffffff00u, 0, 3) : 0u;
+}
+
 /* Convergent. idx[u] / pend[u]: entry index in `region` and its candidate masks still
  * to do (0 = idle lane, reads entry 0). `fresh`: take the masks from the entry itself. */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR>
@@ -471,7 +516,12 @@ __device__ __forceinline__ void confirm_step(const Tables &t, const uint4 *regio
         do_a[u] = HAS_A && any && (m >> j & 1);
         do_b[u] = !PAIR && HAS_B && any && (m >> (16 + j) & 1); /* pair tables: through the gate bitmap, below */
         do_c[u] = HAS_C && any && (m >> (16 + j) & 1);
-        if (!PAIR && t.key_gate) { /* keys that no exact table holds need no probe: 14 % of them pass on a 10 000-literal set */
+        if (!PAIR && !S2 && t.bloom) { /* windows that no literal's full key matches need no probe (HSGPU_F_BLOOM) */
+            uint32_t pa, pb;
+            bloom_gate<HAS_B>(t, (uint32_t)(w0[u] >> 32), (uint32_t)w0[u], pa, pb);
+            do_a[u] = do_a[u] && pa;
+            do_b[u] = do_b[u] && pb;
+        } else if (!PAIR && t.key_gate) { /* keys that no exact table holds need no probe: 14 % of them pass on a 10 000-literal set */
             const uint32_t ga = hsgpu_key_gate_bit(w4[u]), gb = hsgpu_key_gate_bit((w4[u] >> 8) | HSGPU_GATE_B_SALT);
             if (HAS_A) do_a[u] = do_a[u] && ((t.key_gate[ga >> 5] >> (ga & 31)) & 1u);
             if (HAS_B) do_b[u] = do_b[u] && ((t.key_gate[gb >> 5] >> (gb & 31)) & 1u);
@@ -651,7 +701,12 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
         pb[u] = (w4[u] >> 8) * HSGPU_HT_MUL;
         do_a[u] = m_bit(m[u], j[u]); /* (no candidate bits at all: j = 0 and bit 0 is clear) */
         do_b[u] = HAS_B ? m_bit(m[u], 16u + j[u]) : 0u;
-        if (t.key_gate) { /* keys that no exact table holds need no probe */
+        if (t.bloom) { /* windows that no literal's full key matches need no probe (HSGPU_F_BLOOM) */
+            uint32_t ga, gb;
+            bloom_gate<HAS_B>(t, whi[u], wlo[u], ga, gb);
+            do_a[u] &= ga;
+            do_b[u] &= gb;
+        } else if (t.key_gate) { /* keys that no exact table holds need no probe */
             const uint32_t ga = pa[u] >> 16, gb = (pb[u] + HSGPU_GATE_B_SALT * HSGPU_HT_MUL) >> 16; /* the salt sits above the 24 key bits */
             do_a[u] &= m_bit(t.key_gate[ga >> 5], ga);
             if (HAS_B) do_b[u] &= m_bit(t.key_gate[gb >> 5], gb);
@@ -1042,6 +1097,7 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.c2ref = (const uint32_t *)(args.blob + args.t_off_c2ref);
     t.gate = (const uint32_t *)(args.blob + args.t_off_c2bits);
     t.key_gate = nullptr;
+    t.bloom = nullptr;
     t.lists = (const uint32_t *)(args.blob + args.t_off_lists);
     t.lits = (const HsgpuDevLit *)(args.blob + args.t_off_lits);
     t.ht_a_log2 = args.t_ht_a_log2;
@@ -1130,6 +1186,10 @@ __device__ __forceinline__ void write_block_hints_batch(const uint64_t *off, uin
     for (int k = 0; k < K; k++) write_block_hints_of(s[k], e[k], nblocks, hint, n_hint, b0 + (uint64_t)k * 64 + lane, lane);
 }
 
+
+
+__device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *lds, uint32_t n_reg); /* below, behind sort_share */
+
 /* ---- phase 1: the streaming filter (FUSED: + in-kernel confirm) ----------- */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
 #ifndef HSGPU_FILTER_MIN_WAVES
@@ -1146,7 +1206,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         return;
     }
     if (FUSED && args.cand_counts && args.overflow_note && blockIdx.x == 0 && threadIdx.x == 0) *args.overflow_note = 1u;
-    if (!FUSED && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
+    if ((!FUSED || args.solo) && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
     if (!FUSED && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x] = wall_clock64();
 
     const uint32_t flog2 = args.t_filter_log2;
@@ -1252,6 +1312,20 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
 #if HSGPU_STAGES >= 8
         c5 = issue(5), c6 = issue(6);
 #endif
+    }
+    if (FUSED && args.solo) {
+        /* solo scans: no kernel ran in front of this one, so every wavefront writes the block hints of its OWN tiles (and of the
+         * boundary behind them: block_of reads hint[tile] and hint[tile + 1]) before it needs them -- a wave-wide search each, two
+         * dependent rounds, behind the image and corpus loads already in flight. (Resolving matches by plain bisection was 11
+         * dependent loads per match: a 1 MiB solo scan took 61 us against the three kernels' 33.) */
+        const bool owns_tail = (total & 1023) && wave_global == (per_wave ? min((uint64_t)n_waves - 1, n_full / per_wave) : 0);
+        if (n_own || owns_tail) {
+            const uint64_t t_last = min(tile0 + n_own, args.n_hint - 1);
+            for (uint64_t tt = tile0; tt <= t_last; tt++) {
+                const uint64_t b = find_block_wave(args.off, args.nblocks, tt << HSGPU_HINT_SHIFT, lane);
+                if (lane == 0) ((uint32_t *)args.hint)[tt] = (uint32_t)b;
+            }
+        }
     }
     /* the filter image into LDS: once per workgroup */
 #pragma unroll
@@ -1412,6 +1486,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
         /* pair tables: the late-keyed literals ending at this share's last byte (the next share's first lookup would find them) */
         if (PAIR && HAS_B && lane == 0 && n_own && tile0 + n_own < n_full) pair_edge_probe<false>(t, (tile0 + n_own) << 10);
         publish_records(t, args, lane, wave_global);
+        if (args.solo) solo_tail(args, lds, n_waves);
     } else if (lane == 0) {
         args.cand_counts[wave_global] = sp.written;
         if (sp.overflow) args.cand_counts[n_waves] = 1;
@@ -1574,6 +1649,123 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
     }
 }
 
+
+/* ---- solo scans: the placement inside the (fused) scan kernel -------------------------------------------------
+ * hsbench block mode is one hs_scan per block (tools/hsbench/engine_hyperscan.cpp:132-145) and the reference serves short blocks
+ * from dedicated small matchers (src/rose/block.c:382-391, src/runtime.c:401-413); three launches per scan -- filter, confirm,
+ * placement -- are ~20 us of fixed cost whatever the batch holds (also.batch_sweep, round 4). A batch of up to ~1 MiB takes ONE:
+ * the fused kernel (filter + confirm inline, one staging region per wavefront = one contiguous piece of the corpus), and the
+ * workgroup that finishes LAST does what record_sort_kernel does for the others. "Last" is a ticket: every workgroup releases
+ * its stores at agent scope (L2 write-back: the XCDs' L2s are not coherent with each other inside a kernel) and takes a number;
+ * whoever draws grid - 1 acquires and sees everybody's regions. Nobody waits for anybody.
+ *   placement   fills -> exclusive prefix (<= 1024 regions, one wavefront); a region of <= 64 records is ranked by counting by
+ *               ONE wavefront (its records in that wavefront's 1 KiB of LDS, every lane walks them: broadcast reads), 16
+ *               regions at a time; larger regions go through sort_share one after the other (LDS bitonic, merge path beyond)
+ *   count       as record_sort_kernel: the exact total; cap + 1 ("again") when a region lost records
+ *   control     the scan's own block (fills, sums, ticket) is zeroed by the same workgroup: the next solo scan finds it clean
+ * LDS: the filter image is dead by then; its first 28 KiB serve as sort buffer, prefix array and list of large regions. */
+constexpr uint32_t SOLO_MAX_REGIONS = 1024;
+__device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *lds, uint32_t n_reg) {
+    const uint32_t NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
+    __syncthreads(); /* every wavefront of this workgroup has published (its stores have left for L2: the barrier's release) */
+    uint32_t *flagw = lds; /* [0] = last, [1] = total (low), [2] = total (high), [3] = flag, [4] = number of large regions, [5] = a region lost records */
+    if (tid == 0) {
+        const uint32_t ticket = __hip_atomic_fetch_add(args.solo_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        flagw[0] = ticket == gridDim.x - 1;
+        flagw[5] = 0;
+    }
+    __syncthreads();
+    if (!flagw[0]) return; /* (uniform) */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* every wavefront, before it reads what other workgroups wrote */
+    uint4 *buf = (uint4 *)(lds + 64);                       /* SORT_LDS records: 16 KiB */
+    uint32_t *start = lds + 64 + SORT_LDS * 4;              /* [SOLO_MAX_REGIONS + 1] fills, then exclusive prefix */
+    uint32_t *large = start + SOLO_MAX_REGIONS + 64;        /* regions of more than 64 records */
+    const uint2 *counts = (const uint2 *)args.rec_counts;
+    uint32_t over = 0;
+    for (uint32_t i = tid; i < SOLO_MAX_REGIONS; i += NT) {
+        uint32_t f = 0;
+        if (i < n_reg) {
+            const uint2 c = counts[i];
+            const unsigned long long fill = (unsigned long long)c.x + c.y;
+            over |= fill > args.rec_cap;
+            f = (uint32_t)min(fill, 0xffffffffull);
+        }
+        start[i] = f;
+    }
+    /* (not __syncthreads_or: the device library's workgroup reduction owns a static LDS word, and a kernel with static LDS no
+     * longer has its dynamic LDS at address 0, which every filter kernel's absolute LDS addressing relies on -- they trap) */
+    if (over) flagw[5] = 1;
+    __syncthreads();
+    const uint32_t any_over = flagw[5];
+    if (wave == 0) { /* exclusive prefix over 1024 fills: 16 per lane */
+        uint32_t v[16];
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = start[lane * 16 + k], sum += v[k];
+        unsigned long long incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += o;
+        }
+        unsigned long long at = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            start[lane * 16 + k] = (uint32_t)min(at, 0xffffffffull);
+            at += v[k];
+        }
+        if (lane == 63) {
+            const unsigned long long all = incl;
+            const unsigned long long flag = args.rec_super[HSGPU_SUPER_FLAGS] | any_over;
+            flagw[1] = (uint32_t)all, flagw[2] = (uint32_t)(all >> 32), flagw[3] = (flag != 0) || all > args.cap, flagw[4] = 0;
+            *args.count = (flag && all <= args.cap) ? args.cap + 1 : all; /* as record_sort_kernel: never a value <= cap for an incomplete output */
+            start[SOLO_MAX_REGIONS] = (uint32_t)min(all, 0xffffffffull);
+        }
+    }
+    __syncthreads();
+    if (!flagw[3]) {
+        uint4 *out = (uint4 *)args.out;
+        for (uint32_t r0 = 0; r0 < n_reg; r0 += NW) { /* (uniform trip count) */
+            const uint32_t r = r0 + wave;
+            const uint2 c = r < n_reg ? counts[r] : make_uint2(0, 0);
+            const uint32_t n = c.x + c.y;
+            if (n > 64) {
+                if (lane == 0) large[atomicAdd(&flagw[4], 1u)] = r;
+            } else if (n) {
+                const uint4 *region = args.rec_stage + (uint64_t)r * args.rec_cap;
+                uint4 *mine = buf + wave * 64;
+                uint4 rec = make_uint4(0, 0, 0, 0);
+                if (lane < n) {
+                    rec = lane < c.x ? region[lane] : region[args.rec_cap - 1 - (lane - c.x)];
+                    mine[lane] = rec;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint32_t rank = 0;
+                for (uint32_t q = 0; q < n; q++) {
+                    const uint4 o = mine[q];
+                    rank += (rec_less(o, rec) || (q < lane && !rec_less(rec, o))) ? 1u : 0u;
+                }
+                if (lane < n) out[(uint64_t)start[r] + rank] = rec;
+            }
+        }
+        __syncthreads();
+        const uint32_t n_large = flagw[4];
+        for (uint32_t k = 0; k < n_large; k++) { /* rare: dense pieces of the corpus */
+            const uint32_t r = large[k];
+            sort_share(args, buf, r, r + 1, start[r]);
+            __syncthreads();
+        }
+    }
+    /* the control block back to zero (nobody else is left); the timing slots */
+    for (uint32_t i = tid; i < args.solo_ctl_words; i += NT) args.rec_counts[i] = 0;
+    if (tid == 0 && args.tstamp) {
+        const unsigned long long now = wall_clock64();
+        args.tstamp[1] = now, args.tstamp[2] = now, args.tstamp[3] = now;
+        if (args.tstamp_next) args.tstamp_next[0] = ~0ull, args.tstamp_next[1] = 0, args.tstamp_next[2] = 0, args.tstamp_next[3] = 0;
+    }
+}
+
 /* Last kernel of a scan, every workgroup. The control words of THIS scan are read across workgroups (fills, sums,
  * counts), so nobody can zero them here; instead every workgroup zeroes its slice of the OTHER control block, the one
  * the previous scan used and the next scan will use: no memset in front of any scan. Plus the cumulative statistics
@@ -1713,7 +1905,9 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     constexpr uint32_t W = CONFIRM_THREADS / 64;
     __shared__ WaveLds wave_lds[W];
     __shared__ uint2 rest_q[W][RQ_CAP];
-    __shared__ uint4 key_gate[PAIR ? 1 : 512]; /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all" */
+    /* HSGPU_F_GATE: 64 Kbit, "is there an exact-table key with this hash at all"; HSGPU_F_BLOOM (opt-in, stride-1 tables): 96 Kbit,
+     * "is there a literal whose full key this window has" -- one or the other, in dynamic LDS (runtime.hip asks for 8 or 12 KiB) */
+    extern __shared__ __attribute__((aligned(16))) uint4 key_gate[];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool fold = args.fold != 0;
@@ -1721,13 +1915,15 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     const uint32_t n_shares = args.cand_waves;
     if (args.cand_counts[n_shares]) return; /* candidate overflow: nothing is confirmed, the total is unknown; record_sort_kernel reports ("again") */
     const bool gated = !PAIR && (args.t_flags & HSGPU_F_GATE);
-    if (gated) { /* once per workgroup */
+    const bool bloomed = !PAIR && !S2 && (args.t_flags & HSGPU_F_BLOOM);
+    if (gated || bloomed) { /* once per workgroup */
         const uint4 *src = (const uint4 *)(args.blob + args.t_off_c2bits);
-        for (uint32_t i = tid; i < 512; i += CONFIRM_THREADS) key_gate[i] = src[i];
+        for (uint32_t i = tid; i < (bloomed ? HSGPU_BLOOM_WORDS / 4 : 512u); i += CONFIRM_THREADS) key_gate[i] = src[i];
     }
     Tables t;
     init_tables(t, args);
     if (gated) t.key_gate = (const uint32_t *)key_gate;
+    if (bloomed) t.bloom = (const uint32_t *)key_gate;
     t.rec_cap = args.rec_cap;
     uint2 *rq = rest_q[wave];
 #ifndef HSGPU_CONFIRM_FAST

@@ -70,6 +70,12 @@ struct HsgpuScanArgs {
                                  * whose candidate regions overflowed; the next scan on this scratch then gives every chunk room */
     unsigned long long *tstamp; /* timing only: [2] min start / max end of the filter kernel (device wall clock) */
     unsigned long long *tstamp_next; /* slot the next scan will use: re-armed by the scan's last kernel */
+    /* SOLO scans (round 5: batches up to ~1 MiB in ONE launch): the fused kernel with the placement inside -- the workgroup that
+     * finishes last (a ticket in solo_ticket) orders and places every region's records itself, writes the count and leaves the
+     * scan's own small control block zeroed. No hint kernel (hint == nullptr: block_of bisects the offsets), no sort kernel. */
+    uint32_t solo;
+    uint32_t solo_ctl_words;    /* words of the control block that starts at rec_counts (rec_counts | rec_super | ticket) */
+    uint32_t *solo_ticket;
     unsigned long long *wg_stamps;   /* tuning (hsgpu_scratch_enable_timing(s, 2)): [filter grid][4] device wall clock per
                                       * workgroup: start, image staged / hints written, wavefront 0's share done, end */
 };

@@ -31,7 +31,7 @@
 #endif
 
 #define HSGPU_TABLE_MAGIC 0x54475348u /* "HSGT" */
-#define HSGPU_TABLE_VERSION 11u
+#define HSGPU_TABLE_VERSION 12u
 
 #define HSGPU_F_HAS_A 1u /* literals keyed on their last 4 bytes */
 #define HSGPU_F_HAS_B 2u /* literals keyed on their last 3 bytes */
@@ -56,6 +56,18 @@
                              * hardware takes from the low five bits of a byte (an SDWA select) or of the product itself --
                              * no index arithmetic at all (tools/sim/b2p.py: these two indices pass fewer candidates than
                              * (a + b3) and byte 1 of the product, which cost two more instructions per lookup) */
+
+#define HSGPU_F_BLOOM 2048u /* opt-in (HSGPU_BUILD_FORCE_BLOOM), stride-1 tables that would carry the key gate: the c2bits section is 12 KiB,
+                             * three planes of 2^15 bits -- a Bloom filter over the FULL-window keys of the literals, probed by the
+                             * confirm kernel in LDS before it reads an exact-table bucket. The key gate tests the four bytes the
+                             * filter kernel already tested, so 3.6 M of 9.5 M candidate positions per GiB of the bench corpus
+                             * fetch a bucket from L2 (and 2.8 M of them a literal) only for the 8-byte compare to fail; keyed
+                             * on five bytes where the literal has them, 0.7 M do (tools/sim/bloomgate.py). Groups:
+                             *   3  every 3-byte key of table B                      hi = key << 8,            lo = 0
+                             *   4  the 4-byte keys of literals that are not in 5    hi = key,                 lo = 0
+                             *   5  literals whose last FIVE bytes are fully given   hi = last four bytes,     lo = fifth << 24
+                             *      (up to the case bit of a case-blind table)       (DevLit.v's alignment: last byte on top)
+                             * A position is probed in table A when group 4 or group 5 passes, in table B when group 3 does. */
 
 #define HSGPU_FILTER_MUL 0x9E3779u /* 24-bit odd multiplier (golden ratio) */
 #define HSGPU_HT_MUL 0x9E3779B1u
@@ -174,6 +186,23 @@ HSGPU_HD uint32_t hsgpu_gate_bit(uint32_t key25) { return (key25 * HSGPU_HT_MUL)
  * in their free top byte so that they do not alias the 4-byte key with a zero first byte */
 #define HSGPU_GATE_B_SALT 0xB5000000u
 HSGPU_HD uint32_t hsgpu_key_gate_bit(uint32_t key) { return (key * HSGPU_HT_MUL) >> 16; }
+
+/* the Bloom gate's three bit indices, one per plane of 2^15 bits, for a masked window {hi, lo} of group `salt` */
+#define HSGPU_BLOOM_PLANE_LOG2 15u
+#define HSGPU_BLOOM_WORDS (3u << (HSGPU_BLOOM_PLANE_LOG2 - 5)) /* 3072 words = 12 KiB */
+#define HSGPU_BLOOM_M1 0x9E3779B1u
+#define HSGPU_BLOOM_M2 0x85EBCA6Bu
+#define HSGPU_BLOOM_M3 0xC2B2AE35u
+#define HSGPU_BLOOM_M4 0x27D4EB2Fu
+#define HSGPU_BLOOM_M5 0x632BE5ABu
+HSGPU_HD void hsgpu_bloom_idx(uint32_t hi, uint32_t lo, uint32_t salt, uint32_t (&idx)[3]) {
+    uint32_t h = (hi * HSGPU_BLOOM_M1) ^ (lo * HSGPU_BLOOM_M2 + salt * HSGPU_BLOOM_M5);
+    h ^= h >> 15;
+    const uint32_t p1 = h * HSGPU_BLOOM_M3, p2 = h * HSGPU_BLOOM_M4;
+    idx[0] = p1 >> (32u - HSGPU_BLOOM_PLANE_LOG2); /* indices from the TOP bits of a product: its low bits depend on few key bits */
+    idx[1] = p2 >> (32u - HSGPU_BLOOM_PLANE_LOG2);
+    idx[2] = (p1 >> 2) & ((1u << HSGPU_BLOOM_PLANE_LOG2) - 1u);
+}
 
 HSGPU_HD uint32_t hsgpu_ht_bucket(uint32_t key, uint32_t log2) { return (key * HSGPU_HT_MUL) >> (32u - log2); }
 HSGPU_HD uint32_t hsgpu_ht_tag(uint32_t key, uint32_t log2) { return ((key * HSGPU_HT_MUL) >> (26u - log2)) & HSGPU_SLOT_TAG_MASK; }

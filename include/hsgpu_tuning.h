@@ -28,6 +28,8 @@ extern "C" {
 #define HSGPU_BUILD_NO_FOLD 512u    /* keep the separate 3-byte-key filter test even when only few such keys exist */
 #define HSGPU_BUILD_FORCE_PAIR 1024u /* the stride-2 pair filter (opt-in; an error for sets it cannot hold) */
 #define HSGPU_BUILD_NO_WIDE 2048u    /* 32-bit filter words even where 64-bit entries {lo, hi} would be chosen (HSGPU_F_WIDE) */
+#define HSGPU_BUILD_FORCE_BLOOM 8192u /* the full-window Bloom gate (HSGPU_F_BLOOM, csrc/table.h) in place of the 4-byte key gate on stride-1 sets: opt-in --
+                                      * it stops 70 % of the exact-table probes and the confirm stage is 5 % SLOWER with it (profiles/r05_bloom_gate_ab.txt) */
 #define HSGPU_BUILD_NO_GATE 4096u    /* no key gate in front of the exact hash tables (the confirm kernel then probes a table for every candidate) */
 
 

@@ -20,7 +20,8 @@ from tests.util import random_literals
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 F_A, F_B, F_C, F_REPL, F_K2, F_S2, F_BLIND, F_BFOLD, F_PAIR = 1, 2, 4, 8, 16, 32, 64, 128, 256
-F_GATE = 512
+F_GATE, F_WIDE, F_BLOOM = 512, 1024, 2048
+NO_GATE, FORCE_BLOOM = 4096, 8192
 FORCE_REPL, FORCE_HASHED, FORCE_K2, FORCE_K1, FORCE_S1, FORCE_BLIND, FORCE_S2, NO_FOLD = 1, 2, 4, 8, 16, 32, 64, 512
 FORCE_PAIR, KEY_M = 1024, 0x01000000
 MUL, HT_MUL = 0x9E3779, 0x9E3779B1
@@ -111,9 +112,9 @@ def parse(blob):
              "off_c2ref", "off_lists", "n_lists", "off_lits", "checksum"]
     h = dict(zip(names, f))
     fl = h["flags"]
-    nw = (2 << h["filter_log2"]) if fl & F_PAIR else (32 << h["filter_log2"]) if fl & F_REPL else (1 << h["filter_log2"])
+    nw = (2 << h["filter_log2"]) if fl & (F_PAIR | F_WIDE) else (32 << h["filter_log2"]) if fl & F_REPL else (1 << h["filter_log2"])
     h["filter"] = np.frombuffer(blob, "<u4", nw, h["off_filter"])
-    h["c2bits"] = np.frombuffer(blob, "<u4", 2048, h["off_c2bits"])
+    h["c2bits"] = np.frombuffer(blob, "<u4", 3072 if fl & F_BLOOM else 2048, h["off_c2bits"])
     # 16-byte buckets of 4 tagged slots: DIRECT(31) | delta(30) | tag6(29..24) | index24
     h["ht_a"] = np.frombuffer(blob, "<u4", 4 << h["ht_a_log2"], h["off_ht_a"]).reshape(-1, 4)
     h["ht_b"] = np.frombuffer(blob, "<u4", 4 << h["ht_b_log2"], h["off_ht_b"]).reshape(-1, 4)
@@ -153,6 +154,19 @@ def ht_lookup(h, tab, log2, key):
         b = (b + 1) & ((1 << log2) - 1)
 
 
+def bloom_idx(hi, lo, salt):
+    """table.h hsgpu_bloom_idx: one bit index per plane of 2^15 bits"""
+    M = 0xFFFFFFFF
+    h = ((hi * 0x9E3779B1) & M) ^ ((lo * 0x85EBCA6B + salt * 0x632BE5AB) & M)
+    h ^= h >> 15
+    p1, p2 = (h * 0xC2B2AE35) & M, (h * 0x27D4EB2F) & M
+    return [p1 >> 17, p2 >> 17, (p1 >> 2) & 0x7FFF]
+
+
+def bloom_pass(h, hi, lo, salt):
+    return all(int(h["c2bits"][j * 1024 + (i >> 5)]) >> (i & 31) & 1 for j, i in enumerate(bloom_idx(hi, lo, salt)))
+
+
 def filter_word_and_bits(h, x24, b3):
     fl, k = h["flags"], h["filter_log2"]
     prod = (x24 * MUL) & 0xFFFFFFFF
@@ -187,7 +201,11 @@ def check_table_covers(lits, flags):
                 for i, c in enumerate(s):
                     if chr(c).isalpha() and c < 128 and (variant >> (i & 1)) & 1:
                         s[i] = c ^ 0x20
-            ctx = bytes(rng.integers(0, 256, 8, dtype=np.uint8)) + bytes(s)  # random bytes in front
+            ctx = bytearray(bytes(rng.integers(0, 256, 8, dtype=np.uint8)) + bytes(s))  # random bytes in front ...
+            for k in range(1, len(lit.msk) + 1):  # ... that satisfy the literal's msk / cmp where it reaches in front of the string
+                if k > len(s):
+                    ctx[-k] = (ctx[-k] & ~lit.msk[-k] & 0xFF) | (lit.cmp[-k] & lit.msk[-k])
+            ctx = bytes(ctx)
             for d in deltas:
                 if len(s) - d < 1:
                     continue
@@ -201,6 +219,12 @@ def check_table_covers(lits, flags):
                 found = False
 
                 def gate(key):  # HSGPU_F_GATE: the confirm kernel probes a table only for keys whose gate bit is set
+                    if fl & F_BLOOM:  # ... HSGPU_F_BLOOM: only for windows some literal's FULL key matches (groups 3, 4, 5 of table.h)
+                        assert d == 0
+                        if key >> 24 == 0xB5:
+                            return bloom_pass(h, (w4 & 0xFFFFFF00), 0, 3)
+                        w5 = (ctx[-5] & (key_mask & 0xFF)) << 24
+                        return bloom_pass(h, w4, w5, 5) or bloom_pass(h, w4, 0, 4)
                     if not fl & F_GATE:
                         return True
                     g = ((key * HT_MUL) & 0xFFFFFFFF) >> 16
@@ -722,12 +746,38 @@ def test_key_gate_of_large_sets_admits_every_key():
     rng = np.random.default_rng(77)
     lits = random_literals(rng, 3000, 3, 8, nocase_frac=0.3)
     h = check_table_covers(lits, 0)
-    assert h["flags"] & F_GATE and not h["flags"] & F_C
+    assert h["flags"] & F_GATE and not h["flags"] & (F_C | F_BLOOM)
     fill = sum(bin(int(w)).count("1") for w in h["c2bits"]) / 65536.0
     assert 0.01 < fill < 0.2, fill
     # NO_GATE: the section stays empty and the flag off
-    h2 = parse(H.hwlm_build(lits, 4096).serialize())
-    assert not h2["flags"] & F_GATE and not any(int(w) for w in h2["c2bits"])
+    h2 = parse(H.hwlm_build(lits, NO_GATE).serialize())
+    assert not h2["flags"] & (F_GATE | F_BLOOM) and not any(int(w) for w in h2["c2bits"])
+
+
+def test_bloom_gate_of_large_stride_1_sets_admits_every_window():
+    """HSGPU_F_BLOOM (round 5, opt-in: HSGPU_BUILD_FORCE_BLOOM; stride-1 sets of >= 2048 keys without a 2-byte table): in place of the key gate the confirm kernel
+    probes a Bloom filter over the literals' FULL-window keys -- five bytes where a literal has them -- so every window a literal
+    can match, case variants and msk / cmp wildcards included, must pass its group (check_table_covers models the three groups),
+    the planes must be selective, and stride-2 tables keep the key gate."""
+    rng = np.random.default_rng(78)
+    lits = random_literals(rng, 3000, 3, 8, nocase_frac=0.3)
+    n0 = len(lits)
+    # wildcards inside the last five bytes and in front of them; a mask longer than the string
+    lits += [H.HwlmLiteral("abcde", False, n0, msk=b"\xff\xf0\xff\xff\xff", cmp=b"a\x60cde"),
+             H.HwlmLiteral("qrstuv", True, n0 + 1, msk=b"\x00\xff\xff\xff\xff\xff", cmp=b"\x00RSTUV"),
+             H.HwlmLiteral("wxyz", False, n0 + 2, msk=b"\x0f\xff\xff\xff\xff", cmp=b"\x01wxyz"),
+             H.HwlmLiteral("mnop", False, n0 + 3, msk=b"\xff\xff\xff\xff\xff", cmp=b"Zmnop")]
+    h = check_table_covers(lits, FORCE_BLOOM)
+    assert h["flags"] & F_BLOOM and not h["flags"] & (F_GATE | F_C | F_S2)
+    fills = [sum(bin(int(w)).count("1") for w in h["c2bits"][j * 1024:(j + 1) * 1024]) / 32768.0 for j in range(3)]
+    assert all(0.02 < f < 0.3 for f in fills), fills
+    # case-blind and not: the same with no caseless literal in the set
+    caseful = random_literals(rng, 2500, 3, 8, nocase_frac=0)
+    h2 = check_table_covers(caseful, FORCE_BLOOM)
+    assert h2["flags"] & F_BLOOM and not h2["flags"] & F_BLIND
+    # literals of >= 4 bytes: stride 2, and the key gate stays
+    h3 = check_table_covers(random_literals(rng, 3000, 4, 8, nocase_frac=0.3), FORCE_BLOOM)
+    assert h3["flags"] & F_S2 and h3["flags"] & F_GATE and not h3["flags"] & F_BLOOM
 
 
 def test_every_built_table_reloads():
@@ -735,9 +785,9 @@ def test_every_built_table_reloads():
     filter on small sets included (found by tools/asan_table_harness.cpp: a pair table of nine literals carried
     the folded-keys flag, which its own validation refuses)."""
     rng = np.random.default_rng(146)
-    FORCE_PAIR, NO_GATE = 1024, 4096
+    FORCE_PAIR = 1024
     built = 0
-    for flags in (0, FORCE_REPL, FORCE_HASHED | FORCE_K2, FORCE_S1, FORCE_S2, NO_FOLD, FORCE_PAIR, FORCE_PAIR | FORCE_BLIND, NO_GATE):
+    for flags in (0, FORCE_REPL, FORCE_HASHED | FORCE_K2, FORCE_S1, FORCE_S2, NO_FOLD, FORCE_PAIR, FORCE_PAIR | FORCE_BLIND, NO_GATE, FORCE_BLOOM):
         for n in (1, 9, 60, 700, 2500):
             lits = random_literals(rng, n, 3 if flags & FORCE_PAIR else 1, 8, nocase_frac=0.3)
             try:

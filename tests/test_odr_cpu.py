@@ -37,3 +37,39 @@ def test_no_weak_symbol_of_ours_differs_between_objects():
             continue
         ours[dem] = by_obj
     assert not ours, "inline functions of one name and different bodies in different translation units: %r" % ours
+
+
+def test_filter_kernels_own_no_static_lds():
+    """Every hwlm_filter_kernel addresses its dynamic LDS absolutely (the filter image starts at LDS address 0; the kernel traps
+    when it does not). Anything that gives such a kernel a STATIC LDS variable moves the dynamic part behind it: round 5's solo
+    tail called __syncthreads_or, whose device-library reduction owns an LDS word -- every fused kernel trapped on the GPU
+    (HSA_STATUS_ERROR_EXCEPTION), found only there. The objects' metadata says it here: group_segment_fixed_size must be 0."""
+    import shutil
+    import tempfile
+
+    objs = sorted(glob.glob(os.path.join(OBJ, "scan_*.hip.o")))
+    tools = "/opt/rocm/lib/llvm/bin"
+    if len(objs) < 5 or not os.path.exists(os.path.join(tools, "llvm-readelf")):
+        pytest.skip("the library's objects (or the LLVM tools) are not here")
+    seen = 0
+    for o in objs:
+        d = tempfile.mkdtemp()
+        try:
+            shutil.copy(o, os.path.join(d, "x.o"))
+            subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", "x.o"], cwd=d, capture_output=True)
+            cos = [f for f in os.listdir(d) if "gfx950" in f]
+            if not cos:
+                continue
+            notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", os.path.join(d, cos[0])], capture_output=True, text=True).stdout
+            lds = None
+            for line in notes.splitlines():
+                m = re.search(r"\.group_segment_fixed_size:\s*(\d+)", line)
+                if m:
+                    lds = int(m.group(1))
+                m = re.search(r"\.name:\s*(\S+)", line)
+                if m and "hwlm_filter_kernel" in m.group(1) and lds is not None:
+                    seen += 1
+                    assert lds == 0, f"{os.path.basename(o)}: {m.group(1)} has {lds} bytes of static LDS"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    assert seen >= 20
