@@ -524,15 +524,16 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     int rv;
     /* Small batches: ONE launch (the fused kernel with the placement in its last workgroup; scan_device.h, solo_tail). The
      * reference serves short blocks from dedicated small matchers (src/rose/block.c:382-391, src/runtime.c:401-413); here
-     * three launches were ~20 us of fixed cost per scan whatever its size. Up to SOLO_BYTES by default (beyond that the
-     * two-phase pipeline's throughput wins), the default pipeline only, not in dense mode. */
-    constexpr uint64_t SOLO_BYTES = 1ull << 20;
+     * three launches were ~20 us of fixed cost per scan whatever its size. Up to SOLO_BYTES by default -- measured, resident
+     * scans without timing events, solo vs three kernels: 1 460 B 10.4 vs 15.6 us, 16 KiB 17.0 vs 20.9, 64 KiB 20.2 vs 21.2,
+     * 256 KiB 28.9 vs 22.1 (the in-kernel confirm's dependent reads and a placement by one workgroup stop paying) --, the default
+     * pipeline only, not in dense mode. */
+    constexpr uint64_t SOLO_BYTES = 64ull << 10;
     const bool solo_ok = !s->tune_fused && !s->tune_unfolded && s->tune_solo != 1 && s->cand_div == 64 && !(s->h_note && *s->h_note) &&
                          (size_t)hsgpu_filter_words(h->flags, h->filter_log2) * 4 >= 28 * 1024;
     if (solo_ok && (a.total <= SOLO_BYTES || s->tune_solo == 2)) {
-        /* 16 KiB (8 KiB for 512-thread workgroups) per workgroup up to 32 workgroups, then larger shares; forced on big
-         * corpora (tests): at most 64 workgroups = 1024 regions */
-        const unsigned solo_grid = (unsigned)std::min<uint64_t>(n_tiles, a.total <= SOLO_BYTES ? 32 : 1024 / (wg_threads / 64));
+        /* 16 KiB (8 KiB for 512-thread workgroups) per workgroup; forced on big corpora (tests): at most 1024 regions */
+        const unsigned solo_grid = (unsigned)std::min<uint64_t>(n_tiles, 1024 / (wg_threads / 64));
         const uint32_t n_reg = solo_grid * (wg_threads / 64);
         /* (the hints: every wavefront writes those of its own tiles in the kernel's prologue) */
         args.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
@@ -1137,7 +1138,17 @@ static int produce_chunks(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *
         /* (the slot's last copy out of this staging area belonged to chunk i - 2, whose scan this thread has waited for) */
         if ((rv = pinned((void **)&s->h_rel[slot], &s->h_rel_cap[slot], (b1 - b0 + 1) * sizeof(uint64_t))) != HSGPU_SUCCESS) return rv;
         uint64_t *rel = s->h_rel[slot];
-        for (size_t k = 0; k <= b1 - b0; k++) rel[k] = off[b0 + k] - lo;
+        uint64_t bad = 0; /* (branch-free: the loop vectorises) */
+        for (size_t k = 0; k < b1 - b0; k++) {
+            const uint64_t a = off[b0 + k], b = off[b0 + k + 1];
+            rel[k] = a - lo;
+            bad |= (uint64_t)(b < a) | ((b - a) >> 32);
+        }
+        rel[b1 - b0] = off[b1] - lo;
+        if (bad) {
+            hsgpu_set_error("block offsets must be ascending and blocks shorter than 4 GiB (blocks %zu .. %zu)", b0, b1);
+            return HSGPU_INVALID;
+        }
         /* the small copy FIRST: behind the corpus it would wait for it, and the scan for both */
         HIP_TRY(hipMemcpyAsync(s->pipe_off[slot].p, rel, (b1 - b0 + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s->side));
         if (bytes) HIP_TRY(hipMemcpyAsync(s->pipe_corpus[slot].p, base + lo, bytes, hipMemcpyHostToDevice, s->side));
@@ -1233,15 +1244,13 @@ extern "C" int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *
         hsgpu_set_error("more than 2^32 - 1 blocks per call");
         return HSGPU_INVALID;
     }
-    for (size_t i = 0; i < nblocks; i++) {
-        if (off[i + 1] < off[i]) {
-            hsgpu_set_error("block offsets must be ascending");
-            return HSGPU_INVALID;
-        }
-        if (off[i + 1] - off[i] > 0xffffffffull) {
-            hsgpu_set_error("block %zu longer than 4 GiB", i);
-            return HSGPU_INVALID;
-        }
+    /* The offsets are checked chunk by chunk by the producer, beside the copies (a chunk whose offsets are not ascending ends the
+     * call with HSGPU_INVALID before it is copied; the chunks in front of it have been delivered). Walking all of them first --
+     * 28 MB for the 3.5 M packets of 2 GiB -- was 3 ms of a 40 ms call in which nothing else happened (round 5,
+     * tools/chunk_sweep.py: every chunk size lost the same 7 % of the bus). The first and last offset, which cut the chunks, here: */
+    if (off[nblocks] < off[0]) {
+        hsgpu_set_error("block offsets must be ascending");
+        return HSGPU_INVALID;
     }
     InUse guard(s);
     if (!guard.ok) return HSGPU_SCRATCH_IN_USE;

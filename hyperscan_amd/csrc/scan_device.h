@@ -1666,7 +1666,7 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
  * LDS: the filter image is dead by then; its first 28 KiB serve as sort buffer, prefix array and list of large regions. */
 constexpr uint32_t SOLO_MAX_REGIONS = 1024;
 __device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *lds, uint32_t n_reg) {
-    const uint32_t NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT >> 6;
+    const uint32_t NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __syncthreads(); /* every wavefront of this workgroup has published (its stores have left for L2: the barrier's release) */
     uint32_t *flagw = lds; /* [0] = last, [1] = total (low), [2] = total (high), [3] = flag, [4] = number of large regions, [5] = a region lost records */
     if (tid == 0) {
@@ -1725,28 +1725,35 @@ __device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *l
     __syncthreads();
     if (!flagw[3]) {
         uint4 *out = (uint4 *)args.out;
-        for (uint32_t r0 = 0; r0 < n_reg; r0 += NW) { /* (uniform trip count) */
-            const uint32_t r = r0 + wave;
-            const uint2 c = r < n_reg ? counts[r] : make_uint2(0, 0);
-            const uint32_t n = c.x + c.y;
-            if (n > 64) {
-                if (lane == 0) large[atomicAdd(&flagw[4], 1u)] = r;
-            } else if (n) {
-                const uint4 *region = args.rec_stage + (uint64_t)r * args.rec_cap;
-                uint4 *mine = buf + wave * 64;
-                uint4 rec = make_uint4(0, 0, 0, 0);
-                if (lane < n) {
-                    rec = lane < c.x ? region[lane] : region[args.rec_cap - 1 - (lane - c.x)];
-                    mine[lane] = rec;
+        /* regions of up to 64 records (nearly all): ONE pass over the record slots, a thread per record -- its region by bisection
+         * of the prefix array in LDS, its rank by counting against the region's other records (a handful; read from L2), its place
+         * start[region] + rank. (A wavefront per region, regions one after the other, was 32 dependent rounds for the 512 regions of
+         * a 1 MiB scan: 30 of its 50 us.) Larger regions are listed for sort_share. */
+        const uint32_t all = flagw[1]; /* (complete: all <= cap < 2^32) */
+        for (uint32_t i0 = 0; i0 < all; i0 += NT) {
+            const uint32_t i = i0 + tid;
+            if (i < all) {
+                uint32_t lo_r = 0, hi_r = n_reg; /* the last region with start <= i */
+                while (hi_r - lo_r > 1) {
+                    const uint32_t mid = (lo_r + hi_r) >> 1;
+                    if (start[mid] <= i) lo_r = mid;
+                    else hi_r = mid;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                uint32_t rank = 0;
-                for (uint32_t q = 0; q < n; q++) {
-                    const uint4 o = mine[q];
-                    rank += (rec_less(o, rec) || (q < lane && !rec_less(rec, o))) ? 1u : 0u;
+                const uint32_t r = lo_r, j = i - start[r];
+                const uint2 c = counts[r];
+                const uint32_t n = c.x + c.y;
+                if (n > 64) {
+                    if (j == 0) large[atomicAdd(&flagw[4], 1u)] = r;
+                } else {
+                    const uint4 *region = args.rec_stage + (uint64_t)r * args.rec_cap;
+                    const uint4 rec = j < c.x ? region[j] : region[args.rec_cap - 1 - (j - c.x)];
+                    uint32_t rank = 0;
+                    for (uint32_t q = 0; q < n; q++) {
+                        const uint4 o = q < c.x ? region[q] : region[args.rec_cap - 1 - (q - c.x)];
+                        rank += (rec_less(o, rec) || (q < j && !rec_less(rec, o))) ? 1u : 0u;
+                    }
+                    out[(uint64_t)start[r] + rank] = rec;
                 }
-                if (lane < n) out[(uint64_t)start[r] + rank] = rec;
             }
         }
         __syncthreads();

@@ -109,11 +109,11 @@ SOLO_OFF, SOLO_ALWAYS = 3, 4  # hsgpu_scratch_set_tuning: never the single launc
 
 @pytest.mark.parametrize("workload", ["teddy64", "fdr10k", "mixed3000"])
 def test_solo_scans_equal_the_three_kernel_pipeline_at_every_small_size(workload):
-    """A resident batch of up to 1 MiB takes ONE launch (the fused kernel, its last workgroup placing the records). The same
+    """A resident batch of up to 64 KiB takes ONE launch (the fused kernel, its last workgroup placing the records). The same
     record array, element for element, as the three-kernel pipeline on the same scratch (set_tuning(3) switches the single
     launch off), and the oracle's multiset, at sizes around every edge: one byte, less than a chunk, a packet, tile and
-    workgroup-share boundaries, exactly 1 MiB, and one byte more (no longer solo). The scans alternate on ONE scratch, so
-    each path must leave the other's control words as it found them."""
+    workgroup-share boundaries, exactly 64 KiB, one byte more (no longer solo), and on to 1 MiB. The scans alternate on ONE
+    scratch, so each path must leave the other's control words as it found them."""
     rng = np.random.default_rng(77)
     if workload == "teddy64":
         lits = cp.teddy_literals(64, seed=2)
@@ -129,7 +129,7 @@ def test_solo_scans_equal_the_three_kernel_pipeline_at_every_small_size(workload
     table = H.hwlm_build(lits)
     oracle = ob.Oracle(lits)
     r = _Resident(table, corpus, off, cap=1 << 18, timing=True)
-    sizes = [1, 7, 15, 16, 17, 1023, 1024, 1025, 1460, 16383, 16384, 16385, 65536, 300001, (1 << 20) - 1, 1 << 20, (1 << 20) + 1]
+    sizes = [1, 7, 15, 16, 17, 1023, 1024, 1025, 1460, 9000, 16383, 16384, 16385, 40000, 65535, 65536, 65537, 300001, 1 << 20, (1 << 20) + 1]
     for sz in sizes:
         k = int(np.searchsorted(off, sz, side="right")) - 1
         if k < 1:  # the first block alone, cut to sz bytes
