@@ -3,7 +3,7 @@
 # leg) under rocprofv3 (--kernel-trace --stats), then separate PMC passes of the same command: FETCH_SIZE,
 # WRITE_SIZE, and two sets of SQ counters for the filter kernels; summaries are written under
 # gpurun_out/<tag>/ for copying to profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
