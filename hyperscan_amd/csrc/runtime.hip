@@ -148,6 +148,8 @@ struct hsgpu_scratch {
     bool timing_wg = false;     /* enable == 2: per-workgroup stamps of the filter kernel too */
     DevBuf wg_stamps;
     unsigned wg_stamps_n = 0;   /* workgroups of the last stamped scan */
+    DevBuf conf_stamps;
+    unsigned conf_stamps_n = 0; /* confirm workers of the last stamped scan */
     double wall_clock_khz = 100000.0;
     DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats;
     DevBuf pipe_corpus[2], pipe_off[2], pipe_out[2], pipe_count; /* hsgpu_hwlm_exec_batch_cb: two chunks in flight */
@@ -279,6 +281,7 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->stats.release();
     s->tstamp.release();
     s->wg_stamps.release();
+    s->conf_stamps.release();
     s->rec_stage.release();
     s->solo_ctl.release();
     for (int i = 0; i < 2; i++) {
@@ -348,6 +351,30 @@ extern "C" int hsgpu_scratch_get_wg_stamps(hsgpu_scratch_t *s, float *out, unsig
     for (size_t w = 0; w < s->wg_stamps_n; w++) t0 = std::min(t0, v[4 * w]);
     for (size_t w = 0; w < std::min<size_t>(s->wg_stamps_n, max_wgs); w++)
         for (int k = 0; k < 4; k++) out[4 * w + k] = (float)((double)(v[4 * w + k] - t0) / s->wall_clock_khz);
+    return HSGPU_SUCCESS;
+}
+
+/* tuning builds (HSGPU_CONFIRM_STAMPS=1): the confirm kernel's per-worker stamps of the last scan:
+ * out[6 * w + {0: start, 1: end (ms from the earliest start), 2: fresh steps, 3: steps on the rest queue, 4: sorted drains, 5: entries}] */
+extern "C" int hsgpu_scratch_get_conf_stamps(hsgpu_scratch_t *s, float *out, unsigned max_workers, unsigned *n_workers) {
+    if (!s || !n_workers || (max_workers && !out)) return HSGPU_INVALID;
+    *n_workers = s->conf_stamps_n;
+    if (!s->conf_stamps_n || !s->conf_stamps.p) return HSGPU_SUCCESS;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> v((size_t)s->conf_stamps_n * 4);
+    HIP_TRY(hipMemcpy(v.data(), s->conf_stamps.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < s->conf_stamps_n; w++)
+        if (v[4 * w]) t0 = std::min(t0, v[4 * w]);
+    for (size_t w = 0; w < std::min<size_t>(s->conf_stamps_n, max_workers); w++) {
+        out[6 * w] = v[4 * w] ? (float)((double)(v[4 * w] - t0) / s->wall_clock_khz) : -1.f;
+        out[6 * w + 1] = v[4 * w + 3] ? (float)((double)(v[4 * w + 3] - t0) / s->wall_clock_khz) : -1.f;
+        out[6 * w + 2] = (float)(v[4 * w + 1] & 0xffff);
+        out[6 * w + 3] = (float)(v[4 * w + 1] >> 16 & 0xffff);
+        out[6 * w + 4] = (float)(v[4 * w + 1] >> 32);
+        out[6 * w + 5] = (float)v[4 * w + 2];
+    }
     return HSGPU_SUCCESS;
 }
 
@@ -542,6 +569,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.hint_in_filter = 0;
         args.fold = 0;
         args.conf_q = args.conf_k = 1;
+    args.conf_cus = (uint32_t)std::max(1, s->n_cu);
         args.cand = nullptr;
         args.cand_cap = 0;
         args.cand_waves = 0;
@@ -570,6 +598,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.tstamp = nullptr;
         args.tstamp_next = nullptr;
         args.wg_stamps = nullptr;
+        args.conf_stamps = nullptr;
         if (s->timing) {
             const size_t slot = s->n_timed % hsgpu_scratch::kRing;
             s->ev_t = s->ev_ring[slot];
@@ -640,6 +669,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     uint32_t n_rec = n_waves * HSGPU_CONFIRM_SPLIT; /* the fused kernel uses the first n_waves of them */
     unsigned conf_grid = 0;
     args.conf_q = args.conf_k = 1;
+    args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     if (two_phase) {
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
          * worker wavefront, so that the parts go round the workers the device holds at once as evenly as whole numbers allow
@@ -648,6 +678,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         unsigned q = 1, k = 1;
         const unsigned workers = hsgpu_confirm_partition(n_waves, w_max, &q, &k);
         args.conf_q = q, args.conf_k = k;
+        args.conf_cus = (uint32_t)std::max(1, s->n_cu);
         conf_grid = (unsigned)((workers + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64));
         n_rec = conf_grid * (HSGPU_CONFIRM_THREADS / 64);
         if (!s->d_note) n_rec = std::max(n_rec, n_waves); /* (the fused kernel behind the confirm kernel writes one region per filter wavefront) */
@@ -690,10 +721,15 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.tstamp = nullptr;
     args.tstamp_next = nullptr;
     args.wg_stamps = nullptr;
+    args.conf_stamps = nullptr;
     if (s->timing_wg && two_phase) {
         if ((rv = s->wg_stamps.ensure((size_t)grid * 4 * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
         args.wg_stamps = (unsigned long long *)s->wg_stamps.p;
         s->wg_stamps_n = grid;
+        if ((rv = s->conf_stamps.ensure((size_t)n_rec * 4 * sizeof(unsigned long long))) != HSGPU_SUCCESS) return rv;
+        HIP_TRY(hipMemsetAsync(s->conf_stamps.p, 0, (size_t)n_rec * 4 * sizeof(unsigned long long), stream));
+        args.conf_stamps = (unsigned long long *)s->conf_stamps.p;
+        s->conf_stamps_n = n_rec;
     }
     if (s->timing) {
         const size_t slot = s->n_timed % hsgpu_scratch::kRing;

@@ -447,7 +447,33 @@ __device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t 
  * speculatively for every candidate was slower still.)
  * Several tag matches in one bucket, literal lists and displaced keys (full buckets)
  * go through the general code, which queues its matches the same way. */
-constexpr uint32_t RQ_CAP = 256; /* rest queue: {entry index, masks still to do} */
+#ifndef HSGPU_CONFIRM_BLOOM
+#define HSGPU_CONFIRM_BLOOM 1 /* tuning builds: 0 compiles the opt-in Bloom gate out of the fast step (what it costs the default in registers) */
+#endif
+/* Candidate entries per lane and confirm step, and the wavefronts per SIMD the kernel's registers are capped for -- per
+ * instantiation (confirm_shape). The fast step (stride-1 tables without 2-byte keys: the headline's) takes ONE entry per lane at
+ * EIGHT wavefronts per SIMD: ~60 registers, 18 KiB of LDS per workgroup, eight workgroups per CU. Measured on one MI355X, the
+ * headline workload, alternating libraries (profiles/r05_confirm_shape_ab.txt): two entries at six wavefronts (rounds 3-5) 0.1625-
+ * 0.1655 ms, two at five (89 registers, nothing spilled) the same, three at five 0.223, four at four 0.213-0.216 (both spill),
+ * one at eight 0.153-0.156. The stage is not short of entries in flight per lane; its SIMDs are ~50 % busy issuing vector
+ * instructions (48.9 M per GiB x 4 cycles over 1 024 SIMDs = 0.08 of its 0.165 ms) and wait on dependent reads the rest of the
+ * time: more wavefronts cover more of that, more entries per wavefront only lengthen a step. The general step keeps two entries
+ * at six wavefronts (its 85-92 registers do not fit eight). */
+#ifndef HSGPU_CONFIRM_U
+#define HSGPU_CONFIRM_U 1 /* the fast step's entries per lane (tuning builds: 2 with HSGPU_CONFIRM_WAVES=6 is rounds 3-5) */
+#endif
+#ifndef HSGPU_CONFIRM_WAVES
+#define HSGPU_CONFIRM_WAVES 8 /* ... and its wavefronts per SIMD */
+#endif
+#ifndef HSGPU_CONFIRM_FAST
+#define HSGPU_CONFIRM_FAST 1 /* tuning builds: 0 = the general step for every table */
+#endif
+template <bool HAS_A, bool HAS_C, bool S2, bool PAIR, bool DENSE> struct confirm_shape {
+    static constexpr bool FAST = HSGPU_CONFIRM_FAST && HAS_A && !HAS_C && !S2 && !PAIR;
+    static constexpr int U = (FAST && !DENSE) ? HSGPU_CONFIRM_U : 2;
+    static constexpr int WAVES = (FAST && !DENSE) ? HSGPU_CONFIRM_WAVES : 6;
+    static constexpr uint32_t RQ_CAP = 128u * U; /* rest queue: {entry index, masks still to do}; a step may queue 64 * U more */
+};
 
 __device__ __forceinline__ uint32_t pick_slot(const uint4 s, uint32_t m) {
     return (m & 1) ? s.x : (m & 2) ? s.y : (m & 4) ? s.z : s.w;
@@ -652,15 +678,15 @@ __device__ __forceinline__ void bucket_masks(const uint32_t (&s)[4], uint32_t ta
     fast = doit & m_zero31(n ^ 1u) & m_zero31((ref >> HSGPU_LIST_DELTA_SHIFT) ^ 2u) & ~full;
     slow = doit & ~fast & (m_nonzero(n) | full);
 }
-template <bool HAS_B, bool FRESH>
-__device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs &rs, uint2 *rq, const uint32_t (&idx)[2],
-                                                  uint32_t (&pend)[2], const uint32_t (&vm)[2]) {
+template <bool HAS_B, bool FRESH, int U = 2>
+__device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs &rs, uint2 *rq, const uint32_t (&idx)[U],
+                                                  uint32_t (&pend)[U], const uint32_t (&vm)[U]) {
     /* (Requesting the next fresh step's masks one step ahead, behind this step's last loads, was measured: 82 registers
      * instead of 79 cost a wavefront per SIMD and the stage went 0.143 -> 0.158 ms, 0.151 with the registers capped and two
      * spills: profiles/r03_confirm_fast_ab.txt. The stage does not wait on that hop.) */
-    uint32_t chunk[2], m[2];
+    uint32_t chunk[U], m[U];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         if (FRESH) {
             const auto e = __builtin_amdgcn_raw_buffer_load_b64(rs.region, idx[u] << 5, 0, 0);
             chunk[u] = e[0];
@@ -670,9 +696,9 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
             m[u] = pend[u];
         }
     }
-    uint32_t j[2], wlo[2], whi[2];
+    uint32_t j[U], wlo[U], whi[U];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         const uint32_t any = (m[u] | m[u] >> 16) & 0xffffu;
         j[u] = (uint32_t)__builtin_ctz(any | 0x10000u) & 15u;
         const uint32_t o = 9u + j[u]; /* the window ending at c[j]: entry bytes [o, o + 8) */
@@ -685,7 +711,7 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
     }
     /* entries with candidate bits left: onto the rest queue */
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         const uint64_t mask = __ballot(pend[u] != 0);
         if (mask) {
             const uint32_t base = __builtin_amdgcn_readfirstlane(t.wl->nrq);
@@ -693,15 +719,15 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
             if (lane_rank(~0ull) == 0) t.wl->nrq = base + (uint32_t)__popcll(mask);
         }
     }
-    uint32_t w4[2], pa[2], pb[2], do_a[2], do_b[2];
+    uint32_t w4[U], pa[U], pb[U], do_a[U], do_b[U];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         w4[u] = whi[u] & t.key_mask;
         pa[u] = w4[u] * HSGPU_HT_MUL;
         pb[u] = (w4[u] >> 8) * HSGPU_HT_MUL;
         do_a[u] = m_bit(m[u], j[u]); /* (no candidate bits at all: j = 0 and bit 0 is clear) */
         do_b[u] = HAS_B ? m_bit(m[u], 16u + j[u]) : 0u;
-        if (t.bloom) { /* windows that no literal's full key matches need no probe (HSGPU_F_BLOOM) */
+        if (HSGPU_CONFIRM_BLOOM && t.bloom) { /* windows that no literal's full key matches need no probe (HSGPU_F_BLOOM) */
             uint32_t ga, gb;
             bloom_gate<HAS_B>(t, whi[u], wlo[u], ga, gb);
             do_a[u] &= ga;
@@ -712,9 +738,9 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
             if (HAS_B) do_b[u] &= m_bit(t.key_gate[gb >> 5], gb);
         }
     }
-    uint32_t sa[2][4], sb[2][4];
+    uint32_t sa[U][4], sb[U][4];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         const auto a = __builtin_amdgcn_raw_buffer_load_b128(rs.ht_a, ((pa[u] >> (32u - t.ht_a_log2)) & do_a[u]) << 4, 0, 0);
         sa[u][0] = a[0], sa[u][1] = a[1], sa[u][2] = a[2], sa[u][3] = a[3];
         if (HAS_B) {
@@ -722,9 +748,12 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
             sb[u][0] = b[0], sb[u][1] = b[1], sb[u][2] = b[2], sb[u][3] = b[3];
         }
     }
-    uint32_t ref_a[2], fast_a[2], slow_a[2], ref_b[2] = {0, 0}, fast_b[2] = {0, 0}, slow_b[2] = {0, 0};
+    /* (all bucket reads issued before the first is looked at: with one entry per lane and 64 registers the scheduler otherwise
+     * waited for table A's bucket and worked on it before it asked for table B's -- two round trips for one) */
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t ref_a[U], fast_a[U], slow_a[U], ref_b[U] = {}, fast_b[U] = {}, slow_b[U] = {};
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         bucket_masks(sa[u], (pa[u] >> (26u - t.ht_a_log2)) & HSGPU_SLOT_TAG_MASK, do_a[u], ref_a[u], fast_a[u], slow_a[u]);
         if (HAS_B) bucket_masks(sb[u], (pb[u] >> (26u - t.ht_b_log2)) & HSGPU_SLOT_TAG_MASK, do_b[u], ref_b[u], fast_b[u], slow_b[u]);
     }
@@ -732,9 +761,9 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
      * whose two keys both name a literal sending its 3-byte key through the general path, brought the kernel from 79 to 69
      * registers -- seven wavefronts per SIMD -- and was slower, 0.150 vs 0.143 ms: with BFOLD tables both keys of every
      * candidate are tried, and the general path then runs in nearly every step.) */
-    uint32_t la[2][4], lb[2][4];
+    uint32_t la[U][4], lb[U][4];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         const auto a = __builtin_amdgcn_raw_buffer_load_b128(rs.lits, (ref_a[u] & HSGPU_LIST_LIT_MASK & fast_a[u]) << 5, 0, 0);
         la[u][0] = a[0], la[u][1] = a[1], la[u][2] = a[2], la[u][3] = a[3];
         if (HAS_B) {
@@ -743,7 +772,7 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
         }
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         /* (window & msk) == v, 32 bits at a time; a stride-1 table has no delta-1 entries, every g is inside the corpus */
         const uint32_t xa = ((wlo[u] & la[u][2]) ^ la[u][0]) | ((whi[u] & la[u][3]) ^ la[u][1]);
         if (fast_a[u] && xa == 0) push_match(t, (uint64_t)chunk[u] * CHUNK + j[u], ref_a[u] & HSGPU_LIST_LIT_MASK);
@@ -754,7 +783,7 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
     }
     /* everything else: the general path (behind the compares: the literals' registers are free again) */
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < U; u++) {
         if (slow_a[u] | slow_b[u]) {
             const uint64_t g = (uint64_t)chunk[u] * CHUNK + j[u], w0 = (uint64_t)whi[u] << 32 | wlo[u];
             if (slow_a[u]) probe<true>(t, t.ht_a, t.ht_a_log2, w4[u], w0, 0, g);
@@ -1899,16 +1928,21 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t l
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+#ifndef HSGPU_CONFIRM_SGPR_ATTR
+#define HSGPU_CONFIRM_SGPR_ATTR
+#endif
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool S2, bool PAIR = false, bool DENSE = false>
 __global__ __launch_bounds__(CONFIRM_THREADS)
-#ifndef HSGPU_CONFIRM_WAVES
-#define HSGPU_CONFIRM_WAVES 6
-#endif
-/* Registers capped for six wavefronts per SIMD (80): what the kernel's LDS admits (six workgroups per CU). The scheduler has no
- * occupancy target of its own here and takes 94-98 registers for the worker's loop -- five wavefronts; capped, the 4-byte-key
- * variants keep everything in registers and the others spill a few dwords outside the confirm step (tools/kernel_regs.sh). */
-__attribute__((amdgpu_waves_per_eu(HSGPU_CONFIRM_WAVES, 8)))
+/* Registers capped for the wavefronts per SIMD that the kernel's LDS admits (confirm_shape: eight workgroups per CU for the fast
+ * step, six otherwise). The scheduler has no occupancy target of its own here and takes 94-98 registers for the general worker's
+ * loop -- five wavefronts; capped, the 4-byte-key variants keep everything in registers and the others spill a few dwords outside
+ * the confirm step (tools/kernel_regs.sh). */
+__attribute__((amdgpu_waves_per_eu(confirm_shape<HAS_A, HAS_C, S2, PAIR, DENSE>::WAVES, 8))) HSGPU_CONFIRM_SGPR_ATTR
 void hwlm_confirm_kernel(HsgpuScanArgs args) {
+    using shape = confirm_shape<HAS_A, HAS_C, S2, PAIR, DENSE>;
+    constexpr bool FAST = shape::FAST;
+    constexpr int CU = shape::U; /* entries per lane and step */
+    constexpr uint32_t RQ_CAP = shape::RQ_CAP;
     constexpr uint32_t W = CONFIRM_THREADS / 64;
     __shared__ WaveLds wave_lds[W];
     __shared__ uint2 rest_q[W][RQ_CAP];
@@ -1933,10 +1967,6 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     if (bloomed) t.bloom = (const uint32_t *)key_gate;
     t.rec_cap = args.rec_cap;
     uint2 *rq = rest_q[wave];
-#ifndef HSGPU_CONFIRM_FAST
-#define HSGPU_CONFIRM_FAST 1 /* tuning builds: 0 = the general step for every table */
-#endif
-    constexpr bool FAST = HSGPU_CONFIRM_FAST && HAS_A && !HAS_C && !S2 && !PAIR;
     FastRs rs;
     if (FAST) {
         rs.ht_a = __builtin_amdgcn_make_buffer_rsrc((void *)t.ht_a, 0, (int)(16u << min(t.ht_a_log2, 26u)), 0x00020000);
@@ -1953,6 +1983,30 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     const uint32_t worker = blockIdx.x * W + wave;
     const uint32_t Q = args.conf_q, K = args.conf_k, n_parts = n_shares * Q;
     init_wave_lds(t, &wave_lds[wave], lane);
+    /* The instruction arbiter prefers the oldest wavefront of a SIMD, and the workgroups of this resident grid reach a CU in index
+     * order: with equal work the workers of the first 256 workgroups finish first and those of the last 256 last (two entries per
+     * lane, six per SIMD: 137 .. 164 us; one entry, eight per SIMD: 97 .. 121 us; the kernel ends 20 % behind its mean worker:
+     * profiles/r05_confirm_workers.txt). Tuning builds, HSGPU_CONFIRM_ROTPRIO=1: every step a worker takes the next of the four
+     * priorities, starting from its workgroup's rank on its CU -- the spread narrows (p10 .. p90 of the lifetimes 104 .. 120 us
+     * instead of 96 .. 123) and the stage gains 1.5 % (0.1475 vs 0.150 ms); "through all eight ranks" and "the youngest first"
+     * gained nothing. Not in the product build: 1.5 % does not pay for a dependence on the dispatch order. */
+#ifndef HSGPU_CONFIRM_ROTPRIO
+#define HSGPU_CONFIRM_ROTPRIO 0
+#endif
+#if HSGPU_CONFIRM_ROTPRIO
+    const uint32_t prio_rank = __builtin_amdgcn_readfirstlane(blockIdx.x / max(args.conf_cus, 1u));
+    uint32_t prio_step = 0;
+#endif
+#ifndef HSGPU_CONFIRM_STAMPS
+#define HSGPU_CONFIRM_STAMPS 0 /* tuning builds: 1 = per-worker stamps and step counts (hsgpu_scratch_get_conf_stamps) */
+#endif
+#if HSGPU_CONFIRM_STAMPS
+    uint32_t st_fresh = 0, st_rest = 0, st_drains = 0, st_entries = 0;
+    if (args.conf_stamps && lane == 0) args.conf_stamps[4 * worker] = wall_clock64();
+#define HSGPU_ST(x) x
+#else
+#define HSGPU_ST(x)
+#endif
     t.rec_region = args.rec_stage + (uint64_t)worker * args.rec_cap;
     for (uint32_t part = worker * K; part < min(n_parts, worker * K + K); part++) {
         const uint32_t r = part / Q, q = part - r * Q;
@@ -1973,6 +2027,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             if (owner && next < n_full && next > (t.share_start >> 10)) edge = next << 10;
             t.late_skip = ~0ull;
         }
+        HSGPU_ST(st_entries += end > base ? end - base : 0;)
         if (base < end || edge) { /* else nothing in this part */
             const uint4 *region = args.cand + 2ull * r * args.cand_cap;
             if (PAIR && HAS_B) {
@@ -1993,7 +2048,15 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
              * the bench's 33.5 M flood records, profiles/r04_flood.txt.) */
             uint32_t dq = DENSE_POS, dP = 32, dense_base = 0, dm[2] = {0, 0}; /* the batch's next position, positions per step */
             for (;;) {
-                uint32_t idx[2] = {0, 0}, pend[2] = {0, 0};
+#if HSGPU_CONFIRM_ROTPRIO
+                switch ((prio_rank + prio_step++) & 3u) { /* (the argument of s_setprio is an immediate) */
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+                }
+#endif
+                uint32_t idx[CU] = {}, pend[CU] = {};
                 const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
                 bool again = false; /* a step on (idx, pend) that somebody queued: the rest queue's entries, a dense batch's positions */
                 if (DENSE && dq < DENSE_POS && !syncing) {
@@ -2012,7 +2075,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     }
                     t.mq_redo = dP > 1; /* a step that finds more than the queue holds is taken back and done again on half the positions */
                     again = true;
-                } else if (!syncing && base < end && nrq <= RQ_CAP - 128) { /* a fresh batch (the step may queue up to 128 more) */
+                } else if (!syncing && base < end && nrq <= RQ_CAP - 64 * CU) { /* a fresh batch (the step may queue up to 64 * CU more) */
                     const uint32_t i0 = base + lane, i1 = base + 64 + lane;
                     if (dense) {
                         const uint32_t *rw = (const uint32_t *)region;
@@ -2031,21 +2094,26 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                             continue;
                         }
                     }
-                    base += stride;
-                    if (FAST) { /* the schedule of the general step with masks for booleans (confirm_step_fast) */
-                        uint32_t vm[2];
-                        vm[0] = m_less(i0, end), vm[1] = m_less(i1, end); /* ~0 when i < end: past the fill, entry 0 without candidate bits */
-                        idx[0] = i0 & vm[0], idx[1] = i1 & vm[1];
-                        confirm_step_fast<HAS_B, true>(t, rs, rq, idx, pend, vm);
+                    base += FAST ? 64u * CU : stride;
+                    HSGPU_ST(st_fresh++;)
+                    if constexpr (FAST) { /* the schedule of the general step with masks for booleans (confirm_step_fast) */
+                        uint32_t vm[CU];
+#pragma unroll
+                        for (int u = 0; u < CU; u++) {
+                            const uint32_t iu = i0 + 64u * u;
+                            vm[u] = m_less(iu, end); /* ~0 when i < end: past the fill, entry 0 without candidate bits */
+                            idx[u] = iu & vm[u];
+                        }
+                        confirm_step_fast<HAS_B, true, CU>(t, rs, rq, idx, pend, vm);
                     } else {
                         const bool valid[2] = {i0 < end, i1 < end};
                         idx[0] = valid[0] ? i0 : 0, idx[1] = valid[1] ? i1 : 0; /* end > 0 here: entry 0 exists */
                         confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, true);
                     }
                 } else if (nrq) { /* entries with candidate bits left: same path, next bit */
-                    const uint32_t k = min(nrq, 128u), first_q = nrq - k;
+                    const uint32_t k = min(nrq, 64u * CU), first_q = nrq - k;
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
+                    for (int u = 0; u < CU; u++) {
                         if (FAST) {
                             const uint32_t vq = m_less(u * 64 + lane, k);
                             const uint2 it = rq[(first_q + u * 64 + lane) & vq];
@@ -2058,6 +2126,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     }
                     if (lane == 0) t.wl->nrq = first_q;
                     again = true;
+                    HSGPU_ST(st_rest++;)
                 } else if (fold) { /* a sync point with nothing pending: everything queued is final; in order into the region */
                     if (PAIR && HAS_B) {
                         /* the frontier: the entry that is confirmed next (by this wavefront, or by the one with the next quarter); the
@@ -2074,15 +2143,16 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     }
                     drain_matches_sorted(t, lane);
                     syncing = false;
+                    HSGPU_ST(st_drains++;)
                     if (base >= end && dq >= DENSE_POS) break;
                     continue;
                 } else {
                     break;
                 }
                 if (again) { /* (a lane with nothing to do: entry 0, no candidate bits) */
-                    if (FAST) {
-                        const uint32_t vm[2] = {0, 0}; /* (only a fresh step masks with it) */
-                        confirm_step_fast<HAS_B, false>(t, rs, rq, idx, pend, vm);
+                    if constexpr (FAST) {
+                        const uint32_t vm[CU] = {}; /* (only a fresh step masks with it) */
+                        confirm_step_fast<HAS_B, false, CU>(t, rs, rq, idx, pend, vm);
                     } else {
                         const bool valid[2] = {pend[0] != 0, pend[1] != 0};
                         confirm_step<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, region, rq, idx, pend, valid, false);
@@ -2117,6 +2187,14 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
      * the regions is record_sort_kernel's (folded: a gather, the regions are consecutive sorted runs). (Placed by the workers
      * themselves -- every worker polling the sums until everybody in front had published -- the stage took 0.30 ms instead of
      * 0.15: 6 144 wavefronts polling the same few hundred words, the publishing atomics queued behind the polls.) */
+#if HSGPU_CONFIRM_STAMPS
+    if (args.conf_stamps && lane == 0) {
+        args.conf_stamps[4 * worker + 1] = (unsigned long long)st_fresh | (unsigned long long)st_rest << 16 | (unsigned long long)st_drains << 32;
+        args.conf_stamps[4 * worker + 2] = st_entries;
+        args.conf_stamps[4 * worker + 3] = wall_clock64();
+    }
+#endif
+#undef HSGPU_ST
     publish_records(t, args, lane, worker, true);
     if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32); /* emitted out of order: "again", in dense mode */
 }

@@ -61,6 +61,7 @@ struct HsgpuScanArgs {
     /* the confirm kernel's partition: every share (= one filter wavefront's candidates) in conf_q parts of whole batches, conf_k
      * consecutive parts per worker wavefront; rec_regions = its workers */
     uint32_t conf_q, conf_k;
+    uint32_t conf_cus;          /* the device's CUs: workgroup index / conf_cus = the workgroup's rank among those resident on its CU */
     /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
      * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */
     uint32_t *ctl_other;
@@ -78,6 +79,8 @@ struct HsgpuScanArgs {
     uint32_t *solo_ticket;
     unsigned long long *wg_stamps;   /* tuning (hsgpu_scratch_enable_timing(s, 2)): [filter grid][4] device wall clock per
                                       * workgroup: start, image staged / hints written, wavefront 0's share done, end */
+    unsigned long long *conf_stamps; /* the same for the confirm kernel's workers (tuning builds, HSGPU_CONFIRM_STAMPS=1):
+                                      * [worker][4]: start, fresh steps | rest steps << 16 | sorted drains << 32, entries, end */
 };
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);

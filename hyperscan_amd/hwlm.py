@@ -178,6 +178,21 @@ class Scratch:
             raise HsgpuError(rv, "hsgpu_scratch_get_wg_stamps")
         return out[: min(n.value, 4096)]
 
+    def conf_stamps(self):
+        """[confirm workers][6]: start ms, end ms, fresh steps, rest steps, sorted drains, entries (enable_timing(2), a library
+        built with -DHSGPU_CONFIRM_STAMPS=1)"""
+        import numpy as np
+
+        f = self._lib.hsgpu_scratch_get_conf_stamps
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(C.c_uint)]
+        n = C.c_uint(0)
+        out = np.zeros((16384, 6), dtype=np.float32)
+        rv = f(self._h, out.ctypes.data, 16384, C.byref(n))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_get_conf_stamps")
+        return out[: min(n.value, 16384)]
+
     def timing(self, back=0):
         """(filter_ms, confirm_ms, total_ms) of the hwlm_scan_dev `back` launches ago
         on this scratch (0 = the last one; a ring of 32 is kept)."""

@@ -37,14 +37,20 @@ extern "C" {
  * runs (the library reads no environment variables): fused_only == 1 runs the always-correct fused kernel alone
  * (normally the overflow fallback), fused_only == 2 the two-phase pipeline with record_sort_kernel as a kernel of its own
  * sorting behind the confirm kernel (regions in any order, sorted there; by default the confirm workers emit in delivery order and the
- * kernel behind them only gathers); wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the
- * workgroup size / workgroups per CU the runtime would choose (0 = its choice). */
+ * kernel behind them only gathers); fused_only == 3 / 4 switch the one-launch path of small batches off / force it at any size;
+ * wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the workgroup size / workgroups per CU the runtime would
+ * choose (0 = its choice). */
 int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu);
 
 /* hsgpu_scratch_enable_timing(s, 2) also stamps every workgroup of the filter kernel (device wall clock); this returns the last
  * scan's stamps in milliseconds from the earliest start: out[4 w + {0 start, 1 image staged and hints written, 2 wavefront 0's
  * share streamed, 3 end}], w < min(*n_wgs, max_wgs). Synchronises the device. */
 int hsgpu_scratch_get_wg_stamps(hsgpu_scratch_t *s, float *out, unsigned max_wgs, unsigned *n_wgs);
+
+/* The same for the confirm kernel's worker wavefronts, from a tuning build of the library (-DHSGPU_CONFIRM_STAMPS=1; the product
+ * build writes no stamps and this returns zeros): out[6 w + {0 start, 1 end (ms from the earliest start), 2 fresh steps, 3 steps
+ * on the rest queue, 4 sorted drains, 5 candidate entries}]. Synchronises the device. */
+int hsgpu_scratch_get_conf_stamps(hsgpu_scratch_t *s, float *out, unsigned max_workers, unsigned *n_workers);
 
 /* The confirm kernel's partition (csrc/runtime.hip): n_shares candidate regions (one per filter wavefront), each cut into *q parts
  * of whole batches, *k consecutive parts per worker wavefront, for a device that holds max_workers of them at once: the pair that
