@@ -569,6 +569,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.hint_in_filter = 0;
         args.fold = 0;
         args.conf_q = args.conf_k = 1;
+        args.conf_spread = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
         args.cand = nullptr;
         args.cand_cap = 0;
@@ -669,6 +670,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     uint32_t n_rec = n_waves * HSGPU_CONFIRM_SPLIT; /* the fused kernel uses the first n_waves of them */
     unsigned conf_grid = 0;
     args.conf_q = args.conf_k = 1;
+    args.conf_spread = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     if (two_phase) {
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
@@ -681,6 +683,23 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.conf_cus = (uint32_t)std::max(1, s->n_cu);
         conf_grid = (unsigned)((workers + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64));
         n_rec = conf_grid * (HSGPU_CONFIRM_THREADS / 64);
+        if (args.fold == 2 && !(h->flags & HSGPU_F_PAIR)) {
+            /* Dense scans: parts of half a batch or a few (a dense half batch is 1 024 lookup positions, each of which may match), a
+             * region per part, the parts of a worker spread over the corpus (hwlm_confirm_kernel). */
+            const uint64_t share_entries = ((a.total >> 10) + n_waves - 1) / n_waves * 64 + 64; /* = cand_cap below */
+            const unsigned nb = (unsigned)std::min<uint64_t>((share_entries + 63) / 64, 1u << 20); /* half batches */
+            q = std::max(1u, std::min(nb, 32u));
+            const uint64_t parts = (uint64_t)n_waves * q;
+            if (parts < (1u << 24)) {
+                const unsigned w_use = (unsigned)std::min<uint64_t>(w_max, parts);
+                k = (unsigned)((parts + w_use - 1) / w_use);
+                const unsigned wk = (unsigned)((parts + k - 1) / k);
+                conf_grid = (wk + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64);
+                n_rec = (uint32_t)parts;
+                args.conf_q = q, args.conf_k = k;
+                args.conf_spread = 1;
+            }
+        }
         if (!s->d_note) n_rec = std::max(n_rec, n_waves); /* (the fused kernel behind the confirm kernel writes one region per filter wavefront) */
     }
     args.rec_regions = n_rec;

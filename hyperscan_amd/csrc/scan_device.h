@@ -157,6 +157,9 @@ struct Tables {
      * itself leaves them alone. */
     uint64_t late_skip;
     uint32_t mq_redo; /* dense steps: a match the queue has no room for is only counted (the step is done again on fewer positions) */
+    /* dense scans: the block of the last drain, [cb_start, cb_end) = block cb (wave-uniform; cb_end = 0: none yet). A dense step's
+     * matches are a few dozen consecutive positions: while they stay inside that block nobody looks a block up (resolve_queued) */
+    uint64_t cb, cb_start, cb_end;
 };
 
 /* the 8 bytes ending at g, little-endian, bytes before the corpus read as 0
@@ -471,7 +474,10 @@ __device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t 
 template <bool HAS_A, bool HAS_C, bool S2, bool PAIR, bool DENSE> struct confirm_shape {
     static constexpr bool FAST = HSGPU_CONFIRM_FAST && HAS_A && !HAS_C && !S2 && !PAIR;
     static constexpr int U = (FAST && !DENSE) ? HSGPU_CONFIRM_U : 2;
-    static constexpr int WAVES = (FAST && !DENSE) ? HSGPU_CONFIRM_WAVES : 6;
+#ifndef HSGPU_CONFIRM_DENSE_WAVES
+#define HSGPU_CONFIRM_DENSE_WAVES 5 /* the dense kernels' position-parallel path on top of the general step: 96 registers (at 80 they spill 33-73) */
+#endif
+    static constexpr int WAVES = (FAST && !DENSE) ? HSGPU_CONFIRM_WAVES : DENSE ? HSGPU_CONFIRM_DENSE_WAVES : 6;
     static constexpr uint32_t RQ_CAP = 128u * U; /* rest queue: {entry index, masks still to do}; a step may queue 64 * U more */
 };
 
@@ -794,12 +800,31 @@ __device__ __forceinline__ void confirm_step_fast(const Tables &t, const FastRs 
 
 /* Convergent: one queued match per lane (`valid`) resolved -- id / size, block through the hints, bounds -- and the records
  * appended to the front of the wavefront's region in lane order. A queue entry is the 64-bit key {position << 24 | literal}. */
-__device__ __forceinline__ void resolve_queued(const Tables &t, uint32_t lane, bool valid, uint2 it) {
+template <bool CACHE = false, class TABLES>
+__device__ __forceinline__ void resolve_queued(TABLES &t, uint32_t lane, bool valid, uint2 it) {
     const uint32_t li = it.x & HSGPU_LIST_LIT_MASK;
     const uint64_t ge = (uint64_t)it.y << 8 | it.x >> 24;
     const uint4 l1 = ((const uint4 *)(t.lits + li))[1];
-    uint64_t bstart;
-    const uint64_t b = block_of(t, ge, bstart);
+    uint64_t bstart, b;
+    bool cached = false;
+    if constexpr (CACHE) {
+        /* every queued match inside the block of the last drain: no lookup (the reference's flood case is one block for millions
+         * of matches; block_of is five dependent reads) */
+        if (__ballot(valid && !(ge >= t.cb_start && ge < t.cb_end)) == 0) b = t.cb, bstart = t.cb_start, cached = true;
+    }
+    if (!cached) {
+        b = block_of(t, ge, bstart);
+        if constexpr (CACHE) { /* the block of the last valid lane (the keys are sorted: the largest position) is the next drain's guess */
+            const uint64_t vm = __ballot(valid);
+            if (vm) {
+                const int last = 63 - __builtin_clzll(vm);
+                const uint64_t bend = t.off[min(b + 1, t.nblocks)];
+                t.cb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), last) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, last);
+                t.cb_start = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bstart >> 32), last) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bstart, last);
+                t.cb_end = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bend >> 32), last) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bend, last);
+            }
+        }
+    }
     const uint32_t id = l1.z, size = l1.w & 0xff;
     const uint64_t end = ge - bstart;
     const bool ok = valid && !(end + 1 < size || end + 1 - size < t.start);
@@ -1140,6 +1165,7 @@ __device__ __forceinline__ void init_tables(Tables &t, const HsgpuScanArgs &args
     t.share_start = 0;
     t.late_skip = ~0ull;
     t.mq_redo = 0;
+    t.cb = t.cb_start = t.cb_end = 0;
 }
 
 __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t lane) {
@@ -1876,7 +1902,8 @@ __device__ __forceinline__ uint64_t lane_xor64(uint64_t v, uint32_t addr) { /* t
  * selects -- ~130 vector instructions. (Ranking by counting, every lane walking the queue, was ~20 instructions per queued
  * match and lane: 1 000 for the usual 50 matches, as much again as the confirm steps that found them; the stage took
  * 0.19 ms instead of 0.15: profiles/r04_tail_ab.txt.) */
-__device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t lane) {
+template <bool CACHE = false, class TABLES>
+__device__ __forceinline__ void drain_matches_sorted(TABLES &t, uint32_t lane) {
     uint32_t n = __hip_atomic_load(&t.wl->nmq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     n = min(__builtin_amdgcn_readfirstlane(n), MQ_CAP);
     if (n == 0) return;
@@ -1900,7 +1927,7 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t l
         const uint64_t safe = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k0 >> 32), 0) << 32 |
                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k0, 0);
         if (lane >= n) k0 = safe;
-        resolve_queued(t, lane, lane < n, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
+        resolve_queued<CACHE>(t, lane, lane < n, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
     } else { /* 65 .. 128 queued: two keys per lane, element i = lane + 64 r */
         uint64_t k1 = lane + 64 < n ? mq_key(t.wl->cand[lane + 64]) : ~0ull;
 #pragma unroll
@@ -1919,11 +1946,11 @@ __device__ __forceinline__ void drain_matches_sorted(const Tables &t, uint32_t l
                 }
             }
         }
-        resolve_queued(t, lane, true, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
+        resolve_queued<CACHE>(t, lane, true, make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)));
         const uint64_t safe = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k0 >> 32), 0) << 32 |
                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k0, 0);
         if (lane + 64 >= n) k1 = safe;
-        resolve_queued(t, lane, lane + 64 < n, make_uint2((uint32_t)k1, (uint32_t)(k1 >> 32)));
+        resolve_queued<CACHE>(t, lane, lane + 64 < n, make_uint2((uint32_t)k1, (uint32_t)(k1 >> 32)));
     }
     if (lane == 0) __hip_atomic_store(&t.wl->nmq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -2008,13 +2035,30 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
 #define HSGPU_ST(x)
 #endif
     t.rec_region = args.rec_stage + (uint64_t)worker * args.rec_cap;
-    for (uint32_t part = worker * K; part < min(n_parts, worker * K + K); part++) {
+    /* Dense scans (args.conf_spread, runtime.hip): a region per PART, and a worker's K parts are not neighbours but spread over the
+     * corpus -- its j-th part is part j x workers + (worker + 2 731 j) mod workers: consecutive parts go to consecutive workers, so
+     * a dense run of L parts gives every worker L / workers of them, give or take one (a multiplicative shuffle of the parts was
+     * measured first: Poisson, the busiest worker had twice the mean); the rotation per row keeps a corpus whose dense runs
+     * repeat with a period of `workers` parts from landing on the same workers every time. Dense input
+     * comes in runs (the reference's flood case: whole blocks of one byte), a dense part is hundreds of times the work of a quiet
+     * one, and with K consecutive parts per worker the bench's flood corpus kept a quarter of the workers busy for 1.65 ms while the
+     * others had finished after 0.1 (profiles/r05_flood.txt). A dense step ends in a sorted drain anyway, so small parts cost
+     * nothing here (on ordinary input every part end is a sync point: the 10 000-literal stage is 20 % slower with four parts
+     * per worker than with one). */
+    const bool spread = DENSE && !PAIR && args.conf_spread;
+    const uint32_t n_workers = gridDim.x * W;
+    for (uint32_t slot = worker * K; slot < (spread ? worker * K + K : min(n_parts, worker * K + K)); slot++) {
+        const uint32_t row = slot - worker * K;
+        const uint32_t part = spread ? row * n_workers + (worker + 2731u * row) % n_workers : slot;
+        if (part >= n_parts) continue; /* (spread: the last row is not full) */
         const uint32_t r = part / Q, q = part - r * Q;
+        if (spread) t.rec_region = args.rec_stage + (uint64_t)part * args.rec_cap;
         const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
         /* this part's entries [base, end): the q-th of Q pieces of the share's batches of 128, consecutive pieces of the corpus */
-        const uint32_t nb = (n + 127) >> 7;
-        uint32_t base = (q * nb / Q) << 7;
-        const uint32_t end = min(n, ((q + 1) * nb / Q) << 7);
+        /* (spread parts: pieces of whole half batches -- a dense half batch is 1 024 lookup positions) */
+        const uint32_t gshift = spread ? 6u : 7u, nb = (n + (1u << gshift) - 1u) >> gshift;
+        uint32_t base = (q * nb / Q) << gshift;
+        const uint32_t end = min(n, ((q + 1) * nb / Q) << gshift);
         const uint32_t stride = 128u;
         uint64_t edge = 0; /* pair tables, the share's last part: the next share's first byte, when that share exists */
         if (PAIR && HAS_B) {
@@ -2141,7 +2185,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                             t.late_skip = gf;
                         }
                     }
-                    drain_matches_sorted(t, lane);
+                    drain_matches_sorted<DENSE && !PAIR>(t, lane);
                     syncing = false;
                     HSGPU_ST(st_drains++;)
                     if (base >= end && dq >= DENSE_POS) break;
@@ -2182,6 +2226,11 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             }
             if (!fold) drain_matches(t, lane, 0);
         }
+        if (spread) { /* this part's region is complete: published on its own, the wavefront's counters start over */
+            publish_records(t, args, lane, part, true);
+            if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32);
+            init_wave_lds(t, &wave_lds[wave], lane);
+        }
     }
     /* the worker's region is complete (in delivery order when folded): its fill, once, added to the sum of its super. Placing
      * the regions is record_sort_kernel's (folded: a gather, the regions are consecutive sorted runs). (Placed by the workers
@@ -2195,6 +2244,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
     }
 #endif
 #undef HSGPU_ST
+    if (spread) return;
     publish_records(t, args, lane, worker, true);
     if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32); /* emitted out of order: "again", in dense mode */
 }

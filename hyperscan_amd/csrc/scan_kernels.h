@@ -61,6 +61,9 @@ struct HsgpuScanArgs {
     /* the confirm kernel's partition: every share (= one filter wavefront's candidates) in conf_q parts of whole batches, conf_k
      * consecutive parts per worker wavefront; rec_regions = its workers */
     uint32_t conf_q, conf_k;
+    /* dense scans: conf_spread = 1: a record region per part (rec_regions = shares x conf_q), and the conf_k parts of a worker
+     * are spread over the corpus row by row (hwlm_confirm_kernel) -- runs of dense input go round all workers */
+    uint32_t conf_spread;
     uint32_t conf_cus;          /* the device's CUs: workgroup index / conf_cus = the workgroup's rank among those resident on its CU */
     /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
      * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */
