@@ -243,3 +243,62 @@ def test_small_host_batches_take_no_copy_commands_and_return_the_same_records():
     fl = [H.HwlmLiteral(b"aaaa", False, 0), H.HwlmLiteral(b"aa", False, 1)]
     got = hw.hwlm_exec_batch(H.hwlm_build(fl), s1, flood, np.array([0, 20_000], dtype=np.uint64))
     assert len(got) == (20_000 - 3) + (20_000 - 1)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_dense_runs_of_any_length_among_quiet_blocks_spread_parts(seed):
+    """Dense scans since round 5: a record region per PART (half batches), and a worker's parts spread over the corpus row by row
+    (csrc/runtime.hip, hwlm_confirm_kernel: conf_spread), the block of the last drain cached (resolve_queued). Flood runs of
+    uneven length (the reference's flood case, unit/internal/fdr_flood.cpp:148-557) between ordinary packets, sizes chosen so that
+    the part count is no multiple of the worker count and the last row of parts is not full; runs that end inside a half batch;
+    a run cut into many small blocks (the cached block changes inside a drain). Every record against the oracle, in delivery
+    order, twice (the second scan is the dense one's repeat)."""
+    rng = np.random.default_rng(seed)
+    lits = [H.HwlmLiteral(b"aaaa", False, 7), H.HwlmLiteral(b"aaaaaaaa", False, 8), H.HwlmLiteral(b"aaax", False, 9)]
+    lits += [H.HwlmLiteral(l.s, l.nocase, 100 + i) for i, l in enumerate(cp.teddy_literals(40, seed=12))]
+    pieces, sizes = [], []
+    quiet, qoff = cp.packet_corpus(6 << 20, lits[3:], seed=40 + seed, match_every=4096)
+    qb = 0
+    for run in (300 * 1024 + 5, 1300 * 1024 + 777, 77 * 1024, 33, 512 * 1024 + 1):
+        take = int(rng.integers(200, 900))  # quiet blocks in front of the run
+        for b in range(qb, min(qb + take, qoff.size - 1)):
+            pieces.append(quiet[int(qoff[b]):int(qoff[b + 1])])
+            sizes.append(pieces[-1].size)
+        qb += take
+        if run > 400 * 1024:  # one run as many small blocks of uneven size
+            left = run
+            while left:
+                n = int(min(left, rng.integers(40, 1500)))
+                pieces.append(np.full(n, ord("a"), np.uint8))
+                sizes.append(n)
+                left -= n
+        else:
+            pieces.append(np.full(run, ord("a"), np.uint8))
+            sizes.append(run)
+    corpus = np.concatenate(pieces)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    oracle = ob.Oracle(lits)
+    want = []
+    for b in range(off.size - 1):
+        for e, i in oracle.collect(corpus[int(off[b]):int(off[b + 1])]):
+            want.append((b, e, i))
+    want = np.array(sorted(want), dtype=np.int64)
+    from tests.test_gpu_round4 import Resident, _in_delivery_order
+
+    r = Resident(lits, corpus, off, cap=want.shape[0] + (1 << 16))
+    n, tries = r.scan(), 0
+    while n > r.cap and tries < 8:
+        tries += 1
+        if tries > 1:
+            r.cap *= 2
+            r.d_out = r.torch.zeros(r.cap * 4, dtype=r.torch.int32, device=r.d_out.device)
+        n = r.scan()
+    assert tries >= 1, "the runs were meant to send the scratch to dense mode"
+    for again in range(2):
+        assert n == want.shape[0], (n, want.shape[0], tries)
+        got = r.records(n)
+        assert _in_delivery_order(got)
+        a = np.stack([got[:, 0].astype(np.int64), got[:, 1].astype(np.int64), got[:, 2].astype(np.int64)], axis=1)
+        a = a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        assert np.array_equal(a, want)
+        n = r.scan()
