@@ -675,7 +675,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     if (two_phase) {
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
          * worker wavefront, so that the parts go round the workers the device holds at once as evenly as whole numbers allow
-         * (4 096 shares on 6 144 workers: Q = 3, K = 2). */
+         * (4 096 shares on 8 192 workers: Q = 2, K = 1; on 6 144: Q = 3, K = 2). */
         const unsigned w_max = confirm_resident_workgroups(s, f_conf, gate_lds) * (HSGPU_CONFIRM_THREADS / 64);
         unsigned q = 1, k = 1;
         const unsigned workers = hsgpu_confirm_partition(n_waves, w_max, &q, &k);

@@ -1861,7 +1861,7 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
  * The grid is what the device holds at once (workgroups per CU x CUs); the 8 KiB key gate is staged once per workgroup, behind
  * the kernel's only barrier. Every wavefront is a WORKER with conf_k consecutive PARTS of the corpus -- a share (= one filter
  * wavefront's candidate region) cut into conf_q pieces of whole batches of 128 entries; runtime.hip picks the two numbers so
- * that the parts go round the workers evenly (4 096 shares x 3 = 2 per worker on 6 144). Its records go to ONE staging region.
+ * that the parts go round the workers evenly (4 096 shares x 2 = 1 per worker on the fast step's 8 192; x 3 = 2 per worker on the general step's 6 144). Its records go to ONE staging region.
  *   in order  (args.fold; the default) matches wait in the wavefront's LDS queue until a sync point -- more than SYNC_AT queued, or
  *             the part done: the entries with candidate bits left are confirmed first (so that no earlier position is still
  *             pending), then the queue is sorted on 64-bit keys {position, literal} by a bitonic network across the lanes,
@@ -2003,8 +2003,8 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
 
     __syncthreads(); /* the gate is staged: the only barrier of the kernel */
     /* Every wavefront is a WORKER with K consecutive parts of the corpus: share r = one filter wavefront's candidates, cut into Q
-     * parts of whole batches (runtime.hip picks Q and K so that the parts go round the workers the device holds: 4 096 shares x 3
-     * = 2 per worker on 6 144). No tickets, no barrier per share, ONE publish per worker, and nobody waits for anybody: with shares
+     * parts of whole batches (runtime.hip picks Q and K so that the parts go round the workers the device holds: 4 096 shares x 2
+     * = 1 per worker on 8 192; x 3 = 2 per worker on 6 144). No tickets, no barrier per share, ONE publish per worker, and nobody waits for anybody: with shares
      * handed out by ticket to workgroups (quarters per wavefront, a barrier, a publish and a placement per share, 2.67 rounds of
      * them) the stage cost 93 us before the first candidate -- 96 us for 16 MiB, 200 for 1 GiB (profiles/r04_confirm_fixed_cost.txt). */
     const uint32_t worker = blockIdx.x * W + wave;

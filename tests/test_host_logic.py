@@ -62,6 +62,7 @@ def test_confirm_partition_covers_every_part_and_fits_the_device():
             assert workers <= w_max, (shares, w_max, workers)
             assert workers * k.value >= parts > (workers - 1) * k.value, (shares, w_max, q.value, k.value, workers)
     assert (f(4096, 6144, C.byref(q), C.byref(k)), q.value, k.value) == (6144, 3, 2)
+    assert (f(4096, 8192, C.byref(q), C.byref(k)), q.value, k.value) == (8192, 2, 1)  # the fast step's eight workgroups per CU
     assert (f(6144, 6144, C.byref(q), C.byref(k)), q.value, k.value) == (6144, 1, 1)
     assert f(0, 6144, C.byref(q), C.byref(k)) == 0
 
