@@ -510,7 +510,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
      * than 16 (teddy64: 0.269 vs 0.288 ms; 1000 literals: 0.269 vs 0.309 ms); the VALU-bound
      * variants (stride 1, two filter bits) want all 16 (fdr10k: 0.39 vs 0.45 ms). */
     const bool light = (h->flags & HSGPU_F_STRIDE2) && !(h->flags & (HSGPU_F_K2 | HSGPU_F_HAS_C | HSGPU_F_PAIR));
-    unsigned wg_threads = (small || light) ? 512 : HSGPU_WG_THREADS;
+    /* Round 5: the light filters run TWELVE wavefronts per CU, three per SIMD -- the sizes in between had never been tried.
+     * teddy64, 1 GiB, one box (tools/kbench.py, HSGPU_WG_THREADS): 384 threads 0.2676 ms, 512 0.2528, 640 0.2430, 704 0.2141,
+     * 768 0.2062, 832 0.2212, 896 0.2412, 960 0.2389, 1024 0.2641; the 10 000-literal filter: 704 0.3139, 768 0.3088, 832
+     * 0.3320, 896 0.3174, 960 0.3050, 1024 0.2919 (profiles/r05_wg_threads_sweep.txt). */
+    unsigned wg_threads = small ? 512 : light ? 768 : HSGPU_WG_THREADS;
     unsigned wg_per_cu = small ? 3 : 1;
     if (s->tune_wg_threads) wg_threads = s->tune_wg_threads; /* hsgpu_scratch_set_tuning */
     if (!small) { /* a 64 KiB filter admits a second workgroup when the kernel's registers do */
@@ -520,7 +524,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
             wg_per_cu = 2;
     }
     if (s->tune_wg_per_cu) wg_per_cu = s->tune_wg_per_cu;
-    const uint32_t super_shift = wg_threads == 256 ? 12 : wg_threads == 512 ? 13 : 14; /* 1 KiB per wavefront */
+    const uint32_t super_shift = wg_threads <= 256 ? 12 : wg_threads <= 512 ? 13 : 14; /* >= 1 KiB per wavefront: the grid of a small corpus */
     const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads);      /* fused */
     const size_t lds_two = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, false, wg_threads); /* two-phase filter */
     if (lds > s->lds_per_cu) {
