@@ -784,8 +784,12 @@ extern "C" int hsgpu_class_scan_dev(const hsgpu_class_t *classes, unsigned n_cla
         HIP_TRY(hipGetDevice(&dev));
         n_cu = cached_cu_count(dev);
         const uint64_t n_tiles = (total_bytes + B16_TILE - 1) / B16_TILE;
-        /* five 32 KiB workgroups of four wavefronts per CU */
-        const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 3) / 4, (uint64_t)n_cu * 5);
+        /* four 32 KiB workgroups of four wavefronts per CU (five fit) */
+#ifndef HSGPU_B16_WG_PER_CU
+#define HSGPU_B16_WG_PER_CU 4 /* 12 classes, bitmaps only, one box: 2 workgroups per CU 0.729 ms per GiB, 3 0.590, 4 0.554, 5 (rounds 4-5: what the LDS holds) 0.659;
+                                * 4 GiB: 5 2.451 ms, 4 1.992 (0.674 of the roofline), 3 2.088: profiles/r05_wg_threads_sweep.txt */
+#endif
+        const unsigned grid = (unsigned)std::min<uint64_t>((n_tiles + 3) / 4, (uint64_t)n_cu * HSGPU_B16_WG_PER_CU);
         hipLaunchKernelGGL(class_bitmap16_kernel, dim3(grid), dim3(B16_THREADS), B16_TABLE_BYTES, st, (const uint8_t *)d_corpus, total_bytes,
                            (const uint4 *)work, n_classes, (uint16_t *const *)(work + sizeof(lut16)));
         HIP_TRY(hipGetLastError());

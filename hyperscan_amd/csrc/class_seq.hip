@@ -842,12 +842,16 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
         t.off = (const uint64_t *)d_off;
         t.nblocks = nblocks;
         t.total = total_bytes;
-        const size_t lds = tile_lds_per_wave(n_classes, n_seqs) * (SEQ_THREADS / 64);
+#ifndef HSGPU_SEQ_WG_PER_CU
+#define HSGPU_SEQ_WG_PER_CU 0 /* tuning builds: workgroups per CU (the dynamic LDS is padded so that no more fit; 0: what the device holds) */
+#endif
+        size_t lds = tile_lds_per_wave(n_classes, n_seqs) * (SEQ_THREADS / 64);
+        if (HSGPU_SEQ_WG_PER_CU) lds = std::max<size_t>(lds, ((160u << 10) / HSGPU_SEQ_WG_PER_CU) & ~(size_t)255);
         /* the counting pass (empty emit range) has an instantiation without the record path */
         const bool emits = std::min(emit_hi, total_bytes) > emit_lo;
         const void *kfn = emits ? (const void *)class_seq_tile_kernel<true> : (const void *)class_seq_tile_kernel<false>;
         /* a wavefront per share of whole blocks, every pattern. As many shares as the device holds wavefronts of this kernel at
-         * once, times two (8 192 shares on 5 120 slots were 1.6 rounds: the second one 60 % full), at least 16 KiB (four tiles) each.
+         * once, times HSGPU_SEQ_ROUNDS (8 192 shares on 5 120 slots were 1.6 rounds: the second one 60 % full), at least 16 KiB (four tiles) each.
          * (The device's answers are kept: asking on every call was a visible part of a small scan.) */
         int dev = 0, n_cu = 256, per_cu = 0;
         HIP_TRY(hipGetDevice(&dev));
@@ -873,7 +877,12 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
             }
             n_cu = it->second.first, per_cu = it->second.second;
         }
-        const uint64_t slots = (uint64_t)n_cu * per_cu * (SEQ_THREADS / 64) * 2;
+#ifndef HSGPU_SEQ_ROUNDS
+#define HSGPU_SEQ_ROUNDS 4 /* shares per wavefront slot. 256 patterns, ms per GiB at 1 GiB / 4 GiB: 1 round 7.18 / --, 2 (round 4) 6.03 / 5.92, 3 5.88 / --,
+                            * 4 5.64 / 5.59, 6 6.06 / 5.40, 8 6.04 (the 16 KiB floor) / 5.43; fewer workgroups per CU than the device holds: 5 6.93, 4 6.73,
+                            * 3 10.5 (profiles/r05_wg_threads_sweep.txt) */
+#endif
+        const uint64_t slots = (uint64_t)n_cu * per_cu * (SEQ_THREADS / 64) * HSGPU_SEQ_ROUNDS;
         uint64_t share = std::max<uint64_t>(16384, (total_bytes + slots - 1) / slots);
         share = (share + 63) & ~63ull;
         t.share_bytes = share;
