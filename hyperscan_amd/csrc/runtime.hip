@@ -737,6 +737,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     while (((n_rec + (1u << args.super_shift) - 1) >> args.super_shift) > 256) args.super_shift++;
     /* consecutive regions that one record_sort_kernel workgroup places (consecutive pieces of the corpus) */
     args.group_regions = HSGPU_CONFIRM_SPLIT;
+#ifndef HSGPU_FOLD_GROUP
+#define HSGPU_FOLD_GROUP 4 /* folded pipeline: regions (consecutive sorted runs) that one gather workgroup places; tuning builds: the gather of
+                            * the headline step's 8 192 regions takes 14.3 us with groups of 2, 12.9 with 4, 13.5 with 8, 18.2 with 16, 35.0 with 32 */
+#endif
+    if (fold) args.group_regions = HSGPU_FOLD_GROUP;
     args.stats = (unsigned long long *)s->stats.p;
     args.overflow_note = s->d_note;
 
