@@ -168,6 +168,7 @@ struct hsgpu_scratch {
     unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
     uint32_t *h_note = nullptr, *d_note = nullptr; /* mapped pinned word the fused fallback sets (see HsgpuScanArgs::overflow_note) */
+    bool tune_no_skew = false;             /* ... 5: equal halves of the shares for the confirm kernel's workers (A/B of conf_skew) */
     int tune_fused = 0;                    /* hsgpu_scratch_set_tuning (tests / tuning runs) */
     int tune_solo = 0;                     /* fused_only == 3: never the single-launch path for small batches; 4: whenever the geometry allows */
     DevBuf solo_ctl;                       /* solo scans: rec_counts | rec_super | ticket, left zeroed by the scan itself */
@@ -455,6 +456,7 @@ extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsi
     s->tune_fused = fused_only == 1;
     s->tune_unfolded = fused_only == 2;
     s->tune_solo = fused_only == 3 ? 1 : fused_only == 4 ? 2 : 0;
+    s->tune_no_skew = fused_only == 5;
     s->tune_wg_threads = wg_threads;
     s->tune_wg_per_cu = wg_per_cu;
     return HSGPU_SUCCESS;
@@ -573,7 +575,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.hint_in_filter = 0;
         args.fold = 0;
         args.conf_q = args.conf_k = 1;
-        args.conf_spread = 0;
+        args.conf_spread = 0, args.conf_skew = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
         args.cand = nullptr;
         args.cand_cap = 0;
@@ -674,7 +676,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     uint32_t n_rec = n_waves * HSGPU_CONFIRM_SPLIT; /* the fused kernel uses the first n_waves of them */
     unsigned conf_grid = 0;
     args.conf_q = args.conf_k = 1;
-    args.conf_spread = 0;
+    args.conf_spread = 0, args.conf_skew = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     if (two_phase) {
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
@@ -687,6 +689,14 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         args.conf_cus = (uint32_t)std::max(1, s->n_cu);
         conf_grid = (unsigned)((workers + HSGPU_CONFIRM_THREADS / 64 - 1) / (HSGPU_CONFIRM_THREADS / 64));
         n_rec = conf_grid * (HSGPU_CONFIRM_THREADS / 64);
+#ifndef HSGPU_CONFIRM_SKEW
+#define HSGPU_CONFIRM_SKEW 3473 /* 0.053 x 2^16: the oldest of eight ranks takes 0.553 of its share, the fourth 0.508 (profiles/r05_confirm_workers.txt) */
+#endif
+        /* the headline's geometry -- every share in two parts, a part per worker, a whole even number of workgroups per CU: the halves
+         * of a share go to workers of mirrored dispatch ranks, unequal (hwlm_confirm_kernel, conf_skew) */
+        if (args.fold == 1 && !(h->flags & HSGPU_F_PAIR) && !s->tune_no_skew && q == 2 && k == 1 && (uint64_t)conf_grid * (HSGPU_CONFIRM_THREADS / 64) == (uint64_t)n_waves * 2 &&
+            s->n_cu > 0 && conf_grid % (unsigned)s->n_cu == 0 && (conf_grid / (unsigned)s->n_cu) % 2 == 0)
+            args.conf_skew = HSGPU_CONFIRM_SKEW;
         if (args.fold == 2 && !(h->flags & HSGPU_F_PAIR)) {
             /* Dense scans: parts of half a batch or a few (a dense half batch is 1 024 lookup positions, each of which may match), a
              * region per part, the parts of a worker spread over the corpus (hwlm_confirm_kernel). */

@@ -2047,18 +2047,42 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
      * per worker than with one). */
     const bool spread = DENSE && !PAIR && args.conf_spread;
     const uint32_t n_workers = gridDim.x * W;
+    /* Ordinary scans with one part per worker and two parts per share (args.conf_skew, runtime.hip: the headline's geometry): the
+     * instruction arbiter prefers the oldest wavefront of a SIMD and the resident workgroups reach a CU in index order, so with
+     * equal work the workers of the first-dispatched workgroups finish 20 % before those of the last (97 .. 121 us by the rank of a
+     * workgroup on its CU: profiles/r05_confirm_workers.txt) and the kernel's tail runs on ever fewer wavefronts. The two halves of a
+     * share therefore go to workers of MIRRORED ranks on the same CU slot -- rank k and rank R - 1 - k of the R workgroups per CU --,
+     * the older one takes the first conf_skew / 2^16 more than half of the share's batches, scaled by how far apart the two ranks
+     * are, and a record region belongs to a part, not to a worker. */
+    const bool skew = !DENSE && !PAIR && args.conf_skew && K == 1 && Q == 2;
+    uint32_t skew_part = 0, skew_num = 0; /* the part of this worker; the older worker's share of the batches in 1 / 2^16 */
+    if (skew) {
+        const uint32_t cus = max(args.conf_cus, 1u), ranks = gridDim.x / cus, wg = blockIdx.x, rank = wg / cus, slot_cu = wg - rank * cus;
+        const bool old = rank < ranks / 2;
+        const uint32_t low = old ? rank : ranks - 1u - rank; /* the older rank of the pair */
+        skew_part = 2u * ((low * cus + slot_cu) * W + wave) + (old ? 0u : 1u);
+        skew_num = 32768u + args.conf_skew * (ranks - 1u - 2u * low) / max(ranks - 1u, 1u);
+    }
+    uint32_t region_of = worker; /* the record region this worker publishes at the end */
     for (uint32_t slot = worker * K; slot < (spread ? worker * K + K : min(n_parts, worker * K + K)); slot++) {
         const uint32_t row = slot - worker * K;
-        const uint32_t part = spread ? row * n_workers + (worker + 2731u * row) % n_workers : slot;
+        const uint32_t part = spread ? row * n_workers + (worker + 2731u * row) % n_workers : skew ? skew_part : slot;
         if (part >= n_parts) continue; /* (spread: the last row is not full) */
         const uint32_t r = part / Q, q = part - r * Q;
-        if (spread) t.rec_region = args.rec_stage + (uint64_t)part * args.rec_cap;
+        if (spread || skew) t.rec_region = args.rec_stage + (uint64_t)part * args.rec_cap, region_of = part;
         const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
         /* this part's entries [base, end): the q-th of Q pieces of the share's batches of 128, consecutive pieces of the corpus */
-        /* (spread parts: pieces of whole half batches -- a dense half batch is 1 024 lookup positions) */
-        const uint32_t gshift = spread ? 6u : 7u, nb = (n + (1u << gshift) - 1u) >> gshift;
+        /* (spread and skewed parts: pieces of whole half batches -- a dense half batch is 1 024 lookup positions; a skewed cut in
+         * whole batches would move in steps of 6 % of a share) */
+        const uint32_t gshift = (spread || skew) ? 6u : 7u, nb = (n + (1u << gshift) - 1u) >> gshift;
         uint32_t base = (q * nb / Q) << gshift;
-        const uint32_t end = min(n, ((q + 1) * nb / Q) << gshift);
+        uint32_t end_b = (q + 1) * nb / Q;
+        if (skew) { /* the share's batches cut at skew_num / 2^16 */
+            const uint32_t cut = min(nb, (uint32_t)(((uint64_t)nb * skew_num + 32768u) >> 16));
+            base = (q ? cut : 0u) << gshift;
+            end_b = q ? nb : cut;
+        }
+        const uint32_t end = min(n, end_b << gshift);
         const uint32_t stride = 128u;
         uint64_t edge = 0; /* pair tables, the share's last part: the next share's first byte, when that share exists */
         if (PAIR && HAS_B) {
@@ -2245,7 +2269,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
 #endif
 #undef HSGPU_ST
     if (spread) return;
-    publish_records(t, args, lane, worker, true);
+    publish_records(t, args, lane, region_of, true);
     if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32); /* emitted out of order: "again", in dense mode */
 }
 

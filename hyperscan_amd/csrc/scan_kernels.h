@@ -64,6 +64,9 @@ struct HsgpuScanArgs {
     /* dense scans: conf_spread = 1: a record region per part (rec_regions = shares x conf_q), and the conf_k parts of a worker
      * are spread over the corpus row by row (hwlm_confirm_kernel) -- runs of dense input go round all workers */
     uint32_t conf_spread;
+    /* ordinary scans, one part per worker and two per share: the older workgroup of two mirrored dispatch ranks takes
+     * 1/2 + conf_skew / 2^16 (scaled by the ranks' distance) of a share's batches (hwlm_confirm_kernel); 0: equal halves */
+    uint32_t conf_skew;
     uint32_t conf_cus;          /* the device's CUs: workgroup index / conf_cus = the workgroup's rank among those resident on its CU */
     /* the control block of the PREVIOUS scan on this scratch (the blocks alternate): zeroed by this scan's last
      * kernel, whose workgroups read each other's words of the current block and so cannot zero that one */

@@ -147,7 +147,7 @@ class Scratch:
         # (include/hsgpu_tuning.h; the C library itself reads no environment variables)
         env = os.environ
         if env.get("HSGPU_MODE") or env.get("HSGPU_WG_THREADS") or env.get("HSGPU_WG_PER_CU"):
-            self.set_tuning({"fused": 1, "unfolded": 2}.get(env.get("HSGPU_MODE"), 0), int(env.get("HSGPU_WG_THREADS", "0")),
+            self.set_tuning({"fused": 1, "unfolded": 2, "no_skew": 5}.get(env.get("HSGPU_MODE"), 0), int(env.get("HSGPU_WG_THREADS", "0")),
                             int(env.get("HSGPU_WG_PER_CU", "0")))
 
     def set_tuning(self, fused_only=False, wg_threads=0, wg_per_cu=0):
