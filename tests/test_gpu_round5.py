@@ -302,3 +302,39 @@ def test_dense_runs_of_any_length_among_quiet_blocks_spread_parts(seed):
         a = a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
         assert np.array_equal(a, want)
         n = r.scan()
+
+
+def test_skewed_halves_of_the_shares_deliver_the_same_array_as_equal_halves():
+    """Since round 5 the confirm kernel's workers take the two halves of a candidate share in proportion to their workgroup's
+    dispatch rank, a record region belongs to a part and not to a worker (csrc/runtime.hip: conf_skew; hsgpu_scratch_set_tuning
+    5 = equal halves, worker w = part w as before). Same record array either way, element for element, in delivery order, and the
+    oracle's multiset; a corpus whose candidate density changes along its length (text, then random bytes, then text with many
+    matches) so that the shares' batch counts differ and most cuts fall inside a batch."""
+    from tests.test_gpu_round4 import Resident, _in_delivery_order
+
+    lits, _ = cp.snort_like_literals(3000, seed=9)
+    a, aoff = cp.packet_corpus(20 << 20, lits, seed=51)
+    rng = np.random.default_rng(3)
+    b = rng.integers(0, 256, 6 << 20, dtype=np.uint8)
+    boff = np.arange(0, b.size + 1, 1024, dtype=np.uint64)
+    c, coff = cp.packet_corpus(10 << 20, lits, seed=52, match_every=256)
+    corpus = np.concatenate([a, b, c])
+    off = np.concatenate([aoff, boff[1:] + np.uint64(a.size), coff[1:] + np.uint64(a.size + b.size)]).astype(np.uint64)
+    r = Resident(lits, corpus, off, cap=1 << 21)
+    got = {}
+    for name, code in (("skewed", 0), ("equal", 5), ("skewed again", 0)):
+        r.s.set_tuning(code)
+        n = r.scan()
+        assert 1000 < n <= r.cap
+        got[name] = r.records(n)
+        assert _in_delivery_order(got[name])
+    assert np.array_equal(got["skewed"], got["equal"]) and np.array_equal(got["skewed"], got["skewed again"])
+    oracle = ob.Oracle(lits)
+    want = []
+    for blk in range(off.size - 1):
+        want += [(blk, e, i) for e, i in oracle.collect(corpus[int(off[blk]):int(off[blk + 1])])]
+    want = np.array(sorted(want), dtype=np.int64)
+    g = got["skewed"]
+    have = np.stack([g[:, 0].astype(np.int64), g[:, 1].astype(np.int64), g[:, 2].astype(np.int64)], axis=1)
+    have = have[np.lexsort((have[:, 2], have[:, 1], have[:, 0]))]
+    assert np.array_equal(have, want)
