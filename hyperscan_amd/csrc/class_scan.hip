@@ -518,7 +518,8 @@ constexpr int B16_THREADS = 256;
 constexpr uint32_t B16_TABLE_BYTES = 256 * 8 * 16;
 constexpr uint32_t B16_TILE = 2048; /* bytes per wavefront tile: 32 per lane -> one dword of every class's bitmap per lane */
 
-/* (five wavefronts per SIMD = five 32 KiB workgroups per CU. A 4 KiB tile -- 64 bytes and a 64-bit word per class and lane --
+/* (registers for five wavefronts per SIMD = five 32 KiB workgroups per CU; FOUR are launched since round 5, which is faster:
+ * HSGPU_B16_WG_PER_CU below. A 4 KiB tile -- 64 bytes and a 64-bit word per class and lane --
  * needs ~110 registers and spilled a hundred dwords at 96; 32 bytes per lane need 60.) */
 __global__ __launch_bounds__(B16_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void class_bitmap16_kernel(
     const uint8_t *corpus, uint64_t total, const uint4 *lut /* [256] */, uint32_t n_classes, uint16_t *const *bitmaps) {

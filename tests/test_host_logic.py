@@ -995,3 +995,33 @@ def test_replay_batch_mt_delivers_what_the_single_threaded_walk_delivers():
         assert joined == single and nt.value == n1.value and n1.value > 5
         assert len(per) == min(threads, len(per)) and (threads == 1 or len(per) > 1)
     assert hw.hwlm_replay_count_mt(t, recs, 4) > 0
+
+
+def test_confirm_part_mappings_are_permutations():
+    """The two worker -> part mappings of round 5's confirm kernel, restated (csrc/scan_device.h, hwlm_confirm_kernel): dense scans
+    spread a worker's K parts over the corpus row by row (part = row * workers + (worker + 2731 * row) % workers, parts past the
+    end skipped); ordinary scans with two parts per share and one per worker give the halves of a share to workers of mirrored
+    dispatch ranks on the same CU slot. Either way every part must be taken exactly once -- the first build of the dense mapping
+    used a multiplier that shared a factor with the part count and visited a third of the parts three times (profiles/
+    r05_flood.txt); the GPU tests caught it, this one would have caught it here."""
+    import numpy as np
+
+    for n_parts, workers in [(18432, 6144), (8192, 4096), (36864, 5120), (34816, 5120), (20480, 5120), (7, 4), (12289, 6144), (5120, 5120), (3, 1024)]:
+        k = -(-n_parts // workers)
+        w = np.arange(workers, dtype=np.int64)
+        taken = np.concatenate([(row * workers + (w + 2731 * row) % workers) for row in range(k)])
+        taken = taken[taken < n_parts]
+        assert taken.size == n_parts and np.array_equal(np.sort(taken), np.arange(n_parts)), (n_parts, workers)
+    for ranks, cus, waves in [(8, 256, 4), (6, 256, 4), (2, 304, 4), (8, 64, 8)]:
+        wg = np.arange(ranks * cus)
+        rank, slot = wg // cus, wg % cus
+        old = rank < ranks // 2
+        low = np.where(old, rank, ranks - 1 - rank)
+        parts = []
+        for wave in range(waves):
+            parts.append(2 * ((low * cus + slot) * waves + wave) + np.where(old, 0, 1))
+        parts = np.concatenate(parts)
+        assert np.array_equal(np.sort(parts), np.arange(ranks * cus * waves)), (ranks, cus, waves)
+        # the older worker's share of the half batches: above one half, at most 1/2 + 0.053, the same for both halves of a share
+        num = 32768 + 3473 * (ranks - 1 - 2 * low) // max(ranks - 1, 1)
+        assert num.min() > 32768 and num.max() <= 32768 + 3473
