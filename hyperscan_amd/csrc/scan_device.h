@@ -1861,7 +1861,10 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
  * The grid is what the device holds at once (workgroups per CU x CUs); the 8 KiB key gate is staged once per workgroup, behind
  * the kernel's only barrier. Every wavefront is a WORKER with conf_k consecutive PARTS of the corpus -- a share (= one filter
  * wavefront's candidate region) cut into conf_q pieces of whole batches of 128 entries; runtime.hip picks the two numbers so
- * that the parts go round the workers evenly (4 096 shares x 2 = 1 per worker on the fast step's 8 192; x 3 = 2 per worker on the general step's 6 144). Its records go to ONE staging region.
+ * that the parts go round the workers evenly (4 096 shares x 2 = 1 per worker on the fast step's 8 192; x 3 = 2 per worker on the
+ * general step's 6 144). Its records go to ONE staging region -- a region per PART where a worker's parts are not neighbours in
+ * the corpus: dense scans (conf_spread: the parts of a worker spread row by row) and the two halves of a share on workers of
+ * mirrored dispatch ranks (conf_skew); both at the head of the worker's loop below.
  *   in order  (args.fold; the default) matches wait in the wavefront's LDS queue until a sync point -- more than SYNC_AT queued, or
  *             the part done: the entries with candidate bits left are confirmed first (so that no earlier position is still
  *             pending), then the queue is sorted on 64-bit keys {position, literal} by a bitonic network across the lanes,
@@ -1879,7 +1882,9 @@ __device__ __forceinline__ void scan_epilogue(const HsgpuScanArgs &args) {
  * candidate (2.67 rounds of ticket, barrier, final drain, publish, placement, copy per workgroup). Static parts per worker
  * remove the rounds; placing in the same kernel then means every worker polling the sums until everybody in front has
  * published (0.30 ms: 6 144 wavefronts on a few hundred words), so the placement went back to a kernel of its own, which for
- * sorted regions is a plain gather: 16 MiB 118 -> 49 us, 1 GiB 0.512 -> 0.491 ms, teddy64 0.320 -> 0.281 ms. */
+ * sorted regions is a plain gather: 16 MiB 118 -> 49 us, 1 GiB 0.512 -> 0.491 ms, teddy64 0.320 -> 0.281 ms. Round 5: the shape per
+ * instantiation (confirm_shape: one entry per lane at eight wavefronts per SIMD for the fast step), the tail measured worker by
+ * worker (HSGPU_CONFIRM_STAMPS, profiles/r05_confirm_workers.txt): stage 0.1665 -> 0.1445 ms. */
 constexpr uint32_t DENSE_AT = 48;    /* dense scans: candidate positions in a batch of 128 entries from which the batch goes position by position */
 constexpr uint32_t DENSE_POS = 128 * 16; /* ... the positions of a batch */
 #ifndef HSGPU_SYNC_AT
