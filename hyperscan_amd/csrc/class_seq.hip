@@ -882,7 +882,11 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
                             * 4 5.64 / 5.59, 6 6.06 / 5.40, 8 6.04 (the 16 KiB floor) / 5.43; fewer workgroups per CU than the device holds: 5 6.93, 4 6.73,
                             * 3 10.5 (profiles/r05_wg_threads_sweep.txt) */
 #endif
-        const uint64_t slots = (uint64_t)n_cu * per_cu * (SEQ_THREADS / 64) * HSGPU_SEQ_ROUNDS;
+        /* (four shares per slot up to ~1 GiB, more on larger corpora -- shares of at least ~40 KiB, at most eight per slot: the
+         * table above has 6 and 8 ahead of 4 at 4 GiB and behind it at 1 GiB) */
+        const uint64_t slots1 = (uint64_t)n_cu * per_cu * (SEQ_THREADS / 64);
+        const uint64_t rounds = std::min<uint64_t>(2 * HSGPU_SEQ_ROUNDS, std::max<uint64_t>(HSGPU_SEQ_ROUNDS, total_bytes / (slots1 * (40u << 10))));
+        const uint64_t slots = slots1 * rounds;
         uint64_t share = std::max<uint64_t>(16384, (total_bytes + slots - 1) / slots);
         share = (share + 63) & ~63ull;
         t.share_bytes = share;
