@@ -330,9 +330,9 @@ extern "C" void hsgpu_exchange_free(hsgpu_exchange_t *x) {
     if (!x) return;
     (void)hipSetDevice(x->device);
     delete x->tr;
-    if (x->send) (void)hipFree(x->send);
-    if (x->slots) (void)hipFree(x->slots);
-    if (x->d_counts) (void)hipFree(x->d_counts);
+    hsgpu_dev_free(x->send);
+    hsgpu_dev_free(x->slots);
+    hsgpu_dev_free(x->d_counts);
     if (x->h_counts) (void)hipHostFree(x->h_counts);
     delete x;
 }
@@ -354,11 +354,11 @@ extern "C" int hsgpu_exchange_create(hsgpu_exchange_t **out, const void *id, int
         hsgpu_exchange_free(x);
         return rv;
     };
-    if (hipMalloc((void **)&x->send, x->slot_bytes) != hipSuccess || hipMemset(x->send, 0, SLOT_HEADER) != hipSuccess) return fail(HSGPU_NOMEM);
-    if (x->receives() && (hipMalloc((void **)&x->slots, x->slot_bytes * (uint64_t)world) != hipSuccess ||
+    if (hsgpu_dev_alloc((void **)&x->send, x->slot_bytes) != HSGPU_SUCCESS || hipMemset(x->send, 0, SLOT_HEADER) != hipSuccess) return fail(HSGPU_NOMEM);
+    if (x->receives() && (hsgpu_dev_alloc((void **)&x->slots, x->slot_bytes * (uint64_t)world) != HSGPU_SUCCESS ||
                           hipMemset(x->slots, 0, x->slot_bytes * (uint64_t)world) != hipSuccess))
         return fail(HSGPU_NOMEM);
-    if (hipMalloc((void **)&x->d_counts, (2 * world + 1) * sizeof(unsigned long long)) != hipSuccess ||
+    if (hsgpu_dev_alloc((void **)&x->d_counts, (2 * world + 1) * sizeof(unsigned long long)) != HSGPU_SUCCESS ||
         hipHostMalloc((void **)&x->h_counts, (2 * world + 1) * sizeof(unsigned long long)) != hipSuccess)
         return fail(HSGPU_NOMEM);
     if (id && !memcmp(id, LOOP_MAGIC, sizeof(LOOP_MAGIC))) { /* virtual ranks of this process (hsgpu_exchange_loopback_id) */

@@ -28,6 +28,11 @@ int hsgpu_validate_blob(const void *buf, size_t len);
 uint32_t hsgpu_blob_checksum(const uint8_t *blob, size_t len);
 int hsgpu_table_agrees(const hsgpu_hwlm *t, const hsgpu_lit_t *lits, size_t n);
 
+/* devmem.hip: every device allocation of the library (hipMalloc, or guard-page ranges in the out-of-bounds tests) */
+int hsgpu_dev_alloc(void **p, size_t bytes);
+void hsgpu_dev_free(void *p);
+int hsgpu_dev_guard_mode();
+
 /* runtime.hip */
 void hsgpu_release_device_copies(hsgpu_hwlm *t);
 int hsgpu_host_is_pinned(const void *p);

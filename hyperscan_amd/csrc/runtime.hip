@@ -45,20 +45,18 @@ struct DevBuf {
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return HSGPU_SUCCESS;
-        if (p) (void)hipFree(p);
+        hsgpu_dev_free(p);
         p = nullptr;
         cap = 0;
-        size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            hsgpu_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-            return HSGPU_NOMEM;
-        }
+        /* guard mode (devmem.hip): exactly what was asked for, so that the buffer ends where the mapping ends */
+        size_t want = hsgpu_dev_guard_mode() ? std::max<size_t>(bytes, 16) : std::max<size_t>(bytes + bytes / 4, 4096);
+        int rv = hsgpu_dev_alloc(&p, want);
+        if (rv != HSGPU_SUCCESS) return rv;
         cap = want;
         return HSGPU_SUCCESS;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        hsgpu_dev_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -200,10 +198,11 @@ static int table_on_device(const hsgpu_hwlm *ct, int device, const uint8_t **out
         return HSGPU_SUCCESS;
     }
     void *d = nullptr;
-    HIP_TRY(hipMalloc(&d, t->blob.size()));
+    int rv = hsgpu_dev_alloc(&d, t->blob.size());
+    if (rv != HSGPU_SUCCESS) return rv;
     hipError_t e = hipMemcpy(d, t->blob.data(), t->blob.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        (void)hipFree(d);
+        hsgpu_dev_free(d);
         hsgpu_set_error("table upload failed: %s", hipGetErrorString(e));
         return HSGPU_UNKNOWN_ERROR;
     }
@@ -217,7 +216,7 @@ void hsgpu_release_device_copies(hsgpu_hwlm *t) {
     int cur = 0;
     bool have_cur = (hipGetDevice(&cur) == hipSuccess);
     for (auto &kv : t->dev_blob) {
-        if (hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second);
+        if (hipSetDevice(kv.first) == hipSuccess) hsgpu_dev_free(kv.second);
     }
     if (have_cur) (void)hipSetDevice(cur);
     t->dev_blob.clear();

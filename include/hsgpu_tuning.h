@@ -58,6 +58,28 @@ int hsgpu_scratch_get_conf_stamps(hsgpu_scratch_t *s, float *out, unsigned max_w
  * keeps most worker slots busy with every worker getting the same number of parts. Returns the workers used. Host arithmetic only. */
 unsigned hsgpu_confirm_partition(unsigned n_shares, unsigned max_workers, unsigned *q, unsigned *k);
 
+/* ---- guard pages: the out-of-bounds tests (csrc/devmem.hip, tests/test_gpu_guard_pages.py) ----------------------
+ * The reference never touches a byte outside [buf, buf + len) (zones, src/fdr/fdr.c:392-690; vectoredLoad*,
+ * src/fdr/teddy_runtime_common.h:126-391; unit/internal/fdr.cpp:496-561 scans at every alignment). hipMalloc's 2 MiB
+ * granules would hide an over-read here, so the tests place buffers against UNMAPPED pages instead:
+ *   hsgpu_debug_guard_malloc  device memory of exactly `bytes` inside a reserved address range whose neighbouring granules are
+ *                             not mapped; back == 0: the buffer starts at the first mapped byte; back != 0: it ends at the last
+ *                             one (moved down to a multiple of `align`, a power of two: with bytes % align == 0 an access one
+ *                             byte past the end faults)
+ *   hsgpu_debug_guard_mode    1 / 2: every device buffer the LIBRARY allocates from now on (scratch buffers, table images,
+ *                             exchange slots) is placed the same way, front (1) or back (2), sized exactly, without the
+ *                             growth slack; 0: hipMalloc again
+ *   hsgpu_debug_guard_probe   one byte read (or written) by a kernel at p + byte_offset, then a synchronisation: the test's proof
+ *                             that the mechanism faults on this box (run in a child process: the fault kills it)
+ * None of this is on any scan's path; with mode 0 (the default) an allocation is one hipMalloc as before. */
+int hsgpu_debug_guard_mode(int mode);
+int hsgpu_debug_guard_malloc(void **p, size_t bytes, size_t align, int back);
+void hsgpu_debug_guard_free(void *p);
+int hsgpu_debug_guard_probe(void *p, long long byte_offset, int write);
+/* synchronous hipMemcpy / hipMemset through the library's own HIP runtime (the tests fill and read guard buffers without torch) */
+int hsgpu_debug_guard_copy(void *dst, const void *src, size_t bytes, int to_device);
+int hsgpu_debug_guard_fill(void *dst, int value, size_t bytes);
+
 /* The first 32 hex digits of the sha256 over the sources this library was built from (csrc/Makefile, STAMPED): the built
  * library is not in the repository, and a test compares this with the tree it runs in. */
 const char *hsgpu_source_hash(void);

@@ -59,8 +59,7 @@ def random_sets(rng, n_sets):
 
 
 def test_forward_accel_matches_reference():
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not built")
+    ob.require_ref()
     rng = np.random.default_rng(31)
     kinds = {}
     for lits in random_sets(rng, 600):

@@ -138,8 +138,7 @@ def test_fused_block_shapes(shape):
 def test_decoders_match_reference_masks():
     """shufti / truffle masks built by the REFERENCE decode (on our side) to the class
     they were built from, and the GPU first-hit equals shuftiExec / truffleExec."""
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not shipped")
+    ob.require_ref()
     import torch
 
     R = ob.href()

@@ -193,8 +193,7 @@ def test_workload_generators_parity(scratch):
 
 
 def _ref_or_skip():
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not shipped")
+    ob.require_ref()
 
 
 def _recs_key(r):

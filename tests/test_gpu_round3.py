@@ -124,8 +124,7 @@ def test_run_accel_all_ten_cases_against_the_reference():
 
     from hyperscan_amd import accel
 
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not built")
+    ob.require_ref()
     R = ob.href(ob.ref_variants()[0])
     R.hsref_run_accel.restype = C.c_size_t
     R.hsref_run_accel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]

@@ -811,8 +811,7 @@ def test_replay_rules_equal_the_reference_under_changing_group_masks():
     from tests import oracle_binding as ob
     from tests.util import random_corpus, random_literals
 
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not built")
+    ob.require_ref()
     rng = np.random.default_rng(61)
     base = random_literals(rng, 90, 2, 8, nocase_frac=0.3)
     lits, raw = [], []
@@ -878,8 +877,7 @@ def test_replay_batch_restarts_the_rules_in_every_block_like_the_reference():
     from tests import oracle_binding as ob
     from tests.util import random_blocks, random_corpus, random_literals
 
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not built")
+    ob.require_ref()
     rng = np.random.default_rng(62)
     base = random_literals(rng, 60, 2, 8, nocase_frac=0.3)
     lits = [H.HwlmLiteral(l.s, l.nocase, i, noruns=bool(i % 4 == 0), groups=[H.HWLM_ALL_GROUPS, 0x1, 0x2][i % 3]) for i, l in enumerate(base)]

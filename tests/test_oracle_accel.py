@@ -112,8 +112,7 @@ def test_oracle_on_reference_unit_test_vectors():
 
 def test_reference_on_its_own_unit_test_vectors():
     """the compiled reference reproduces the expectations as restated (guards the restating)"""
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not built")
+    ob.require_ref()
     for case in ga.cases():
         name, kind, params, text, lo, hi, _ = case
         # the tests scan t1 + i of ONE array: keep the alignment relation (t1 16-aligned here)
@@ -173,8 +172,7 @@ def test_dverm_builders_decode_to_the_vermicelli_predicates():
 def test_double_shufti_vector_model_equals_reference():
     """oracle/hwlm_oracle.c models the reference's 16-byte-vector early exits exactly
     (hso_dshufti_ref_model) and its exact form is never earlier-than-true / later-than-reference."""
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not built")
+    ob.require_ref()
     L, R = ob.hso(), ob.href()
     rng = np.random.default_rng(17)
     checked = early = 0
@@ -218,8 +216,7 @@ def test_double_shufti_vector_model_equals_reference():
 
 
 def test_oracle_equals_reference_on_random_accel_inputs():
-    if not ob.ref_available():
-        pytest.skip("oracle/_ref not built")
+    ob.require_ref()
     L, R = ob.hso(), ob.href()
     rng = np.random.default_rng(23)
     alpha = np.frombuffer(b"abABzZ09 \n\x00\x7f\x80\xff", dtype=np.uint8)
