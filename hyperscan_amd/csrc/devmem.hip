@@ -162,9 +162,9 @@ extern "C" void hsgpu_debug_guard_free(void *p) {
     if (p) (void)guard_free(p);
 }
 
-/* Copies and fills of guard ranges go through KERNELS and a staging buffer from hipMalloc: hipMemcpy / hipMemset on a
- * virtual-memory mapping were seen returning bytes from before a kernel's stores on this stack (the first version of the tests
- * read counts that the scan had demonstrably written), so nothing but kernels touches a guard range -- as in the product. */
+/* Copies and fills of guard ranges go through KERNELS and a staging buffer from hipMalloc, with a device synchronisation on
+ * both sides: the tests' reads and writes reach a guard range the way the product's do, and a test never has to reason about
+ * stream order. (hipMemcpy* / hipMemset* on such ranges behave like on hipMalloc memory: tools/experiments/vmm_semantics.hip.) */
 namespace {
 __global__ void guard_copy_kernel(unsigned char *dst, const unsigned char *src, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];

@@ -1539,7 +1539,16 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     if (FUSED) {
         if (lane < qcount) drain_entry<HAS_A, HAS_B, HAS_C, S2, PAIR>(t, t.wl->cand[lane]);
         /* pair tables: the late-keyed literals ending at this share's last byte (the next share's first lookup would find them) */
-        if (PAIR && HAS_B && lane == 0 && n_own && tile0 + n_own < n_full) pair_edge_probe<false>(t, (tile0 + n_own) << 10);
+        /* ... and the corpus' last byte: the lookup position behind it does not exist. (Round 6, found by the guard-page tests: a
+         * 3-byte literal keyed late and ending at byte total - 1 was never reported; nor was one ending at the last byte of the
+         * last whole tile when the partial tile behind it belonged to the next wavefront.) The wavefront with the partial tile
+         * asks at `total` when that is a lookup position, every other one at the first byte behind its tiles. */
+        if (PAIR && HAS_B && lane == 0) {
+            const bool holds_tail = (total & 1023) && wave_global == (per_wave ? min((uint64_t)n_waves - 1, n_full / per_wave) : 0);
+            /* (the lookups sit on even positions: behind an odd total there is none to stand in for -- the end at total - 1 is even) */
+            const uint64_t edge = holds_tail ? ((total & 1) ? 0 : total) : n_own ? (tile0 + n_own) << 10 : 0;
+            if (edge) pair_edge_probe<false>(t, edge);
+        }
         publish_records(t, args, lane, wave_global);
         if (args.solo) solo_tail(args, lds, n_waves);
     } else if (lane == 0) {
@@ -2097,7 +2106,10 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             /* (the part that holds the share's last entries -- the ends in question sort among its records; a share without
              * entries: its last part) */
             const bool owner = n ? (base < end && end == n) : q == Q - 1;
-            if (owner && next < n_full && next > (t.share_start >> 10)) edge = next << 10;
+            /* the share with the corpus' partial last tile asks at `total` (no lookup position exists there), every other one at the
+             * first byte behind its tiles -- the next share's first lookup, or `total` itself (hwlm_filter_kernel has the same rule) */
+            const bool holds_tail = (args.total & 1023) && r == (per ? min((uint64_t)n_shares - 1, n_full / per) : 0);
+            if (owner) edge = holds_tail ? ((args.total & 1) ? 0 : args.total) : next > (t.share_start >> 10) ? next << 10 : 0;
             t.late_skip = ~0ull;
         }
         HSGPU_ST(st_entries += end > base ? end - base : 0;)

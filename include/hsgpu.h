@@ -185,8 +185,10 @@ int hsgpu_scratch_get_stats(hsgpu_scratch_t *s, uint64_t *cand_entries, int *ove
  * copy of chunk i + 1 runs beside the scan of chunk i, and on_chunk receives the records of every finished chunk --
  * delivery order, block indices of the whole batch, chunks in block order -- on the CALLING thread while later
  * chunks are still being copied and scanned: whatever the caller does per chunk (confirm, callbacks) hides behind
- * the bus. A non-zero return from on_chunk stops the scan (HSGPU_SCAN_TERMINATED). Nothing of the batch stays
- * resident afterwards. No reference counterpart: the reference has no device boundary
+ * the bus. A non-zero return from on_chunk stops the scan (HSGPU_SCAN_TERMINATED). Offsets that are not ascending (or a
+ * block of 4 GiB or more) are refused with HSGPU_INVALID before a byte of the batch has been read and before on_chunk has
+ * been called; a failure later on (device memory, a device error) ends the call after the chunks in front of it have been
+ * delivered. Nothing of the batch stays resident afterwards. No reference counterpart: the reference has no device boundary
  * (doc/dev-reference/performance.rst:56-61). */
 typedef int (*hsgpu_chunk_cb)(const hsgpu_match_t *recs, size_t n, void *ctx);
 int hsgpu_hwlm_exec_batch_cb(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *base, const uint64_t *off,

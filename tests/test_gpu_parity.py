@@ -87,6 +87,38 @@ def test_pair_filter_fdr10k_set_and_dense_candidates(scratch):
     assert as_set(got2) == as_set(ob.Oracle(lits2).collect_blocks(corpus2, one))
 
 
+@pytest.mark.parametrize("tune", [0, 1, 2, 3, 4])
+def test_pair_filter_short_literal_at_the_corpus_end_and_at_tile_edges(tune):
+    """Round 6 (found by tests/test_gpu_guard_pages.py): the pair filter keys a 3-byte literal whose end has the other parity
+    one byte LATE -- it is found at the lookup position behind its end. Behind the corpus' last byte there is none, and the
+    first position of the partial last tile may belong to another wavefront: such ends are asked for explicitly
+    (pair_edge_probe). Every pipeline, ends at total - 1 of both parities, at the last whole tile's last byte, one block / cut."""
+    rng = np.random.default_rng(600 + tune)
+    lits = random_literals(rng, 60, 3, 8, nocase_frac=0.3)
+    shorts = [l for l in lits if len(l.s) == 3]
+    assert len(shorts) >= 5
+    t = H.hwlm_build(lits, FORCE_PAIR)
+    s = H.Scratch(0)
+    s.set_tuning(tune)
+    oracle = ob.Oracle(lits)
+    for total in [3, 4, 16, 17, 1023, 1024, 1025, 1026, 2047, 2048, 2051, 16384, 16385, 65536, 65537, 200_000, 200_001]:
+        if tune == 4 and total > 100_000:
+            continue
+        for k, lit in enumerate(shorts[:4]):
+            corpus = random_corpus(rng, total, lits, plant_every=200)
+            b = np.frombuffer(lit.s, dtype=np.uint8)
+            corpus[total - 3:total] = b                     # ends at the corpus' last byte
+            if total > 2048:
+                e = (total >> 10 << 10) - (k & 1)           # ... at the last whole tile's last byte, and one before
+                corpus[e - 3:e] = b
+                corpus[1024 - 3 + (k & 1):1024 + (k & 1)] = b
+            for off in (np.array([0, total], dtype=np.uint64), np.array([0, total // 2, total // 2, total], dtype=np.uint64)):
+                got = hw.hwlm_exec_batch(t, s, corpus, off)
+                want = oracle.collect_blocks(corpus, off)
+                assert as_set(got) == as_set(want), (tune, total, lit.s, len(got), len(want))
+    s.close()
+
+
 @pytest.mark.parametrize("total", [1, 15, 16, 17, 1023, 1024, 16383, 16384, 16385, 49152 + 5, 3 * 16384])
 def test_sizes_around_tile_boundaries(scratch, total):
     rng = np.random.default_rng(total)

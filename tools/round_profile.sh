@@ -3,15 +3,16 @@
 # leg) under rocprofv3 (--kernel-trace --stats), then separate PMC passes of the same command: FETCH_SIZE,
 # WRITE_SIZE, and two sets of SQ counters for the filter kernels; summaries are written under
 # gpurun_out/<tag>/ for copying to profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --also teddy64,class256 --class-gib 1"
+# (serial launches only, no sustained run: the averages are those of the K timed steps' kernels)
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-overlap-probe --sustain-seconds 0 --also teddy64,class256 --class-gib 1"
 # 1. the headline workload alone (the driver's command without the other workloads and the CPU leg): kernel_stats.csv is
 #    what roofline.achieved's launch duration has to agree with
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-also > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-also --no-overlap-probe --sustain-seconds 0 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 # 2. the same with teddy64 and class256 (1 GiB) behind it: their kernels are other instantiations (kernel_stats_also.csv);
 #    flood has a trace of its own (tools/flood_prof.py), rose1000's GPU stage is teddy64's kernel, batch_sweep is 1 000 small launches
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_also -- $CMD > $OUT/bench_also_under_rocprof.json 2> $OUT/trace_also.err
@@ -44,6 +45,19 @@ for k,v in sq.items():
         for c in ("SQ_ACTIVE_INST_VALU","SQ_ACTIVE_INST_LDS","SQ_WAIT_INST_ANY","SQ_WAIT_ANY"):
             if c in v: v[c+"_share_of_wave_cycles"]=round(v[c]/v["SQ_WAVE_CYCLES"],3)
 json.dump(sq, open(out+"/filter_sq.json","w"), indent=1)
+# what size the passes ran at, on which box: bench.py shows traffic / kernel_ms_trace / issue bounds beside a run of THAT size only
+meta={}
+try:
+    line=[l for l in open(out+"/bench_under_rocprof.json") if l.startswith("{")][-1]
+    b=json.loads(line)
+    meta={"corpus_bytes": b["roofline"]["algorithmic_bytes_per_launch"], "workload": b["config"]["workload"], "ms_per_step_under_rocprof": b["ms_per_step"]}
+except Exception as e:
+    meta={"error": str(e)}
+try:
+    meta["gpu_uuid"]=[l.split(":",1)[1].strip() for l in open("$R/gpurun_out/box_info.txt") if "Uuid" in l and "GPU-" in l][0]
+except Exception:
+    pass
+json.dump(meta, open(out+"/profile_meta.json","w"), indent=1)
 print(open(out+"/kernel_stats.csv").read()[:2500])
 print(json.dumps(summ, indent=1)[:2500])
 print(json.dumps(sq, indent=1)[:3000])
