@@ -738,13 +738,13 @@ def run_workload(name, args, rank, world, dist, do_cpu):
         cpu, _ = cpu_baseline(lits, corpus, off)
         ref_parity = cpu["parity"] = reference_gate_full(lits, corpus, off, recs, name)
         del recs
-        run_steps(1)
+        run_steps(max(1, args.warmup))  # the W untimed warm-up steps again, right in front of the timed region (the device sat idle for the CPU leg's seconds)
         torch.cuda.synchronize()
     elif getattr(args, "reference_gate", False):  # also.fdr10k_8g: no CPU timing leg, but the same whole-corpus gate
         recs = job.records()
         ref_parity = reference_gate_full(lits, corpus, off, recs, name)
         del recs
-        run_steps(1)
+        run_steps(max(1, args.warmup))
         torch.cuda.synchronize()
 
     # timed region: barrier + sync on both sides, exactly K steps
@@ -1525,11 +1525,14 @@ def compact_cpu(c):
 def compact_also(name, r):
     if "error" in r:
         return r
-    if name == "sustained":  # {"headline": .., "shard": ..}: numbers only
-        return {k: {kk: vv for kk, vv in v.items() if kk != "workload"} for k, v in r.items()}
+    if name == "sustained":  # {"headline": .., "shard": ..}: numbers only (GB/s = bytes / ms_per_step; the details file has all of it)
+        def smi(x):
+            return {k: x[k] for k in ("sclk", "power_W") if k in x} if isinstance(x, dict) else x
+        return {k: {**{kk: v[kk] for kk in ("steps", "ms_per_step", "last30_filter_ms", "last30_confirm_stage_ms", "drift_last_over_first")},
+                    "GBps_whole": v["GBps"]["whole"], "smi_before": smi(v.get("smi_before")), "smi_after": smi(v.get("smi_after"))} for k, v in r.items()}
     if name == "virtual_ranks":  # (its figures are in multi_gpu.loopback; the whole object is in the details file)
         return {"n_ranks": r["n_ranks"], "scan_ms": r["scan_ms"], "in_line_as": "multi_gpu.loopback"}
-    keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "matches_per_s", "parity", "gpu_stage", "host_confirm",
+    keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "parity", "gpu_stage", "host_confirm",
             "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "GBps_one_block_per_call",
             "half_peak_batch_bytes", "ninety_percent_batch_bytes", "curve", "parity_whole_corpus", "parity_reference", "note")
     out = {"workload": _short(r.get("workload", name), 110)}
@@ -1540,11 +1543,11 @@ def compact_also(name, r):
                 v = {kk: vv for kk, vv in v.items() if kk not in ("what", "kernel", "threads")}
             out[k] = _short(v, 170)
     if "roofline" in r:  # (the other workloads' lines: the figures the judge recomputes from; the rest is in the details file)
-        keep_r = ("bound", "achieved", "peak", "unit", "frac", "kernel_frac", "traffic", "kernel", "kernel_ms_avg", "confirm_stage_ms_avg",
-                  "algorithmic_bytes_per_launch", "algorithmic_bytes_per_step")
+        keep_r = ("bound", "achieved", "frac", "kernel_frac", "traffic", "kernel", "kernel_ms_avg", "confirm_stage_ms_avg",
+                  "algorithmic_bytes_per_launch", "algorithmic_bytes_per_step")  # (peak 8000 GB/s as in the headline's)
         out["roofline"] = {k: v for k, v in compact_roofline(r["roofline"]).items() if k in keep_r}
     if "cpu_baseline" in r:
-        out["cpu_baseline"] = {k: v for k, v in compact_cpu(r["cpu_baseline"]).items() if k != "sample"}
+        out["cpu_baseline"] = {k: v for k, v in compact_cpu(r["cpu_baseline"]).items() if k not in ("sample", "cgroup_cpu_quota")}
     return out
 
 
@@ -1762,8 +1765,10 @@ def main():
         for k in ("exchange", "multi_gpu"):
             if k in main_res:
                 out[k] = main_res[k]
+        if dist is None and isinstance(out.get("multi_gpu"), dict):
+            out["multi_gpu"] = {k: v for k, v in out["multi_gpu"].items() if k != "assumes"}  # (the details file keeps it)
         if also:
-            out["also"] = {k: compact_also(k, v) for k, v in also.items()}
+            out["also"] = {k: compact_also(k, v) for k, v in also.items() if k != "virtual_ranks" or "error" in v}  # (virtual_ranks: multi_gpu.loopback)
         # the full objects: stderr and a side file
         dpath = args.details or os.path.join(ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "", "bench_details.json")
         try:
@@ -1775,14 +1780,14 @@ def main():
             out["details"] = f"not written ({e})"
         log("bench details: " + json.dumps(full))
         line = json.dumps(out)
-        if len(line) > 6000:  # the driver keeps an ~8.5 KB tail of stdout: shed what the details file holds anyway
+        if len(line) > 6800:  # the driver keeps an ~8.5 KB tail of stdout: shed what the details file holds anyway
             for k in ("curve",):
                 for v in out.get("also", {}).values():
                     v.pop(k, None)
             for v in out.get("also", {}).values():
                 v.pop("workload", None)
             line = json.dumps(out)
-        if len(line) > 5800:  # still: the prose of the other workloads (the gates ran; their wording is in the details file)
+        if len(line) > 6800:  # still: the prose of the other workloads (the gates ran; their wording is in the details file)
             for v in out.get("also", {}).values():
                 for k in ("parity", "parity_whole_corpus", "parity_reference", "matches", "note"):
                     if isinstance(v.get(k), str) and len(v[k]) > 60:
