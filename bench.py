@@ -1375,6 +1375,19 @@ def run_rose1000(args):
         tc.append(time.perf_counter() - t0)
         assert rv == 0 and cnt.value == n_ev, f"host confirm over the resident scan's hits: {cnt.value} events, hs_scan_batch {n_ev}"
     t_conf = float(np.median(tc))
+    # -- the RESIDENT form end to end (verdict, round 5): the corpus stays in HBM (hsbench loads it once), hs_scan_batch_resident = GPU
+    #    literal scan + D2H of the hits + host confirm (which reads the bytes behind every hit from the host copy) + callbacks
+    lib.hs_scan_batch_resident.restype = C.c_int
+    lib.hs_scan_batch_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p, hs.BATCH_CB, C.c_void_p]
+    tr = []
+    for _ in range(6):
+        cnt = C.c_ulonglong(0)
+        t0 = time.perf_counter()
+        rv = lib.hs_scan_batch_resident(db._h, buf.ctypes.data, offs.ctypes.data, offs.size - 1, job.d_corpus.data_ptr(), job.d_off.data_ptr(),
+                                        scratch._h, handler, C.byref(cnt))
+        tr.append(time.perf_counter() - t0)
+        assert rv == 0 and cnt.value == n_ev, f"hs_scan_batch_resident: rc {rv}, {cnt.value} events, hs_scan_batch {n_ev}"
+    t_res = float(np.median(tr[1:]))
     alg = total + REC_BYTES * n_hits
     res = {"workload": f"rose1000: 1000 literal-prefix + tail patterns, {args.rose_gib:g} GiB of packets through hs_scan_batch from pinned host "
                        "memory (H2D of the corpus + GPU literal scan + D2H of the records + host confirm + counting callback)",
@@ -1384,6 +1397,9 @@ def run_rose1000(args):
                          "what": "the database's literal table over the same corpus RESIDENT in HBM (hsgpu_hwlm_scan_dev, serial steps)"},
            "host_confirm": {"hits_per_s": round(n_hits / t_conf, 1), "ms": round(t_conf * 1e3, 2), "events": int(n_ev),
                             "threads": "the facade's own (hs_confirm_batch over the resident scan's hits)"},
+           "resident_end_to_end": {"GBps": round(total / t_res / 1e9, 1), "ms": round(t_res * 1e3, 2), "events": int(n_ev),
+                                   "what": "hs_scan_batch_resident: corpus resident in HBM (and in host memory for the confirm): GPU literal scan + D2H of "
+                                           "the hits + host confirm + counting callback; nothing of the corpus crosses the bus"},
            "pinned_h2d_GBps": round(total / (float(np.median(h2d)) / 1e3) / 1e9, 1),
            "bound": "the bus: end to end cannot exceed pinned_h2d_GBps; the GPU stage and the host confirm hide behind the copies",
            "roofline": {"bound": "hbm", "achieved": round(alg / (f_ms / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1532,7 +1548,7 @@ def compact_also(name, r):
                     "GBps_whole": v["GBps"]["whole"], "smi_before": smi(v.get("smi_before")), "smi_after": smi(v.get("smi_after"))} for k, v in r.items()}
     if name == "virtual_ranks":  # (its figures are in multi_gpu.loopback; the whole object is in the details file)
         return {"n_ranks": r["n_ranks"], "scan_ms": r["scan_ms"], "in_line_as": "multi_gpu.loopback"}
-    keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "parity", "gpu_stage", "host_confirm",
+    keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "parity", "gpu_stage", "host_confirm", "resident_end_to_end",
             "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "GBps_one_block_per_call",
             "half_peak_batch_bytes", "ninety_percent_batch_bytes", "curve", "parity_whole_corpus", "parity_reference", "note")
     out = {"workload": _short(r.get("workload", name), 110)}

@@ -19,6 +19,7 @@
  * non-decreasing `to`.
  */
 #include "../../include/hs_gpu.h"
+#include "../../include/hsgpu_tuning.h"
 
 #include <atomic>
 #include <condition_variable>
@@ -33,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <new>
 #include <set>
@@ -357,6 +359,20 @@ hs_error_t build_database(const std::vector<std::string> &exprs, const std::vect
                     return HS_COMPILER_ERROR;
                 }
         }
+        /* the patterns are final (nothing moves or copies them from here on): equal shift-and tables are shared */
+        {
+            std::map<std::vector<unsigned long long>, const unsigned long long *> seen;
+            for (Pattern &p : d->pats) {
+                if (p.reach.empty()) continue;
+                auto it = seen.find(p.reach);
+                if (it == seen.end()) {
+                    seen.emplace(p.reach, p.reach.data());
+                } else {
+                    p.reach_shared = it->second;
+                    std::vector<unsigned long long>().swap(p.reach); /* (its own copy is not needed any more) */
+                }
+            }
+        }
         /* one HWLM literal per pattern: the last <= 8 bytes of the literal prefix */
         std::vector<hsgpu_lit_t> lits(d->pats.size());
         hw_s.resize(d->pats.size());
@@ -597,7 +613,24 @@ void collect_slice(const hs_database *db, const unsigned char *data, const unsig
     size_t k = lo, c = cs_lo;
     std::vector<std::pair<unsigned, size_t>> by_pat;
     std::vector<size_t> starts;
+    /* A literal hit every few KiB of a multi-GiB batch: the hit's offsets, then its bytes, are two DEPENDENT cache misses per
+     * hit (round 6: 270 ns per hit cold against 140 warm on one core). The records say where the next hits are, so their
+     * offsets are asked for 16 records ahead and their bytes -- the line the literal ends in and the one behind it, where the
+     * tail runs -- 8 ahead, by which time the offsets have arrived. */
+    constexpr size_t PF_OFF = 16, PF_DATA = 8;
+    size_t pf = lo; /* records [lo, pf) have had their prefetches issued */
     while (k < hi || c < cs_hi) { /* both lists are sorted by (block, end): one run per block, blocks in order */
+        while (pf < hi && pf <= k) { /* keep the window [k, k + PF_OFF) primed */
+            if (pf + PF_OFF < hi) __builtin_prefetch(&off[recs[pf + PF_OFF].block]);
+            if (pf + PF_DATA < hi) {
+                const hsgpu_match_t &r = recs[pf + PF_DATA];
+                const unsigned char *p = data + off[r.block] + r.end;
+                __builtin_prefetch(p);
+                __builtin_prefetch(p + 64);
+                __builtin_prefetch(&db->pats[r.id < db->pats.size() ? r.id : 0]);
+            }
+            pf++;
+        }
         const unsigned long long b = std::min<unsigned long long>(k < hi ? recs[k].block : ~0ull, c < cs_hi ? cs[c].block : ~0ull);
         size_t e = k, ce = c;
         while (e < hi && recs[e].block == b) e++;
@@ -1123,27 +1156,50 @@ static int confirm_and_deliver(const hs_database *db, const char *data, const un
         return -1;
     }
 }
+/* The confirm is bound by the latency of the misses behind every hit (offsets, then bytes), not by arithmetic: it scales with
+ * the threads that have misses in flight. Up to 64 (round 5: 16). On the bench's host, 517 575 hits of config 5: 8 threads 15.4 ms,
+ * 16 8.3, 32 4.1, 64 1.9-2.8, 128 1.8-3.5 with outliers (profiles/r06_confirm_threads.txt). */
+static unsigned g_confirm_threads = 0;
+extern "C" void hsgpu_debug_confirm_threads(unsigned n) { g_confirm_threads = n; }
+static unsigned confirm_threads() {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return g_confirm_threads ? std::min(g_confirm_threads, 256u) : std::min(64u, hw);
+}
+
+/* tuning aid (include/hsgpu_tuning.h, hsgpu_debug_confirm_timing): the last large confirm of this process in seconds --
+ * setup (cuts, vectors), the parallel part's wall time, the slowest and the fastest slice, the delivery loop */
+static double g_confirm_timing[5];
+extern "C" void hsgpu_debug_confirm_timing(double out[5]) {
+    for (int i = 0; i < 5; i++) out[i] = g_confirm_timing[i];
+}
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static int confirm_and_deliver_impl(const hs_database *db, const char *data, const unsigned long long *off,
                                     const hsgpu_match_t *recs, size_t n, hs_batch_event_handler onEvent, void *context,
                                     const hsgpu_match_t *cs, size_t n_cs, HsConfirmPool *pool) {
+    const double t_in = now_s();
+    double t_par0 = t_in, t_par1 = t_in;
     /* host confirm: the events of different blocks are independent, so large batches are cut
      * into slices of whole blocks handled by worker threads; delivery stays on the calling
      * thread, in block order, as the callback contract requires */
     unsigned n_thr = 1;
-    if (onEvent && n + n_cs >= 8192) n_thr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
-    std::vector<std::vector<Event>> ev(n_thr);
-    std::vector<std::vector<BlockRun>> runs(n_thr);
+    if (onEvent && n + n_cs >= 8192) n_thr = confirm_threads();
+    /* more slices than threads: the threads take them as they come (round 6: with one slice per thread the slowest of 16
+     * took 7.3 ms and the fastest 2.1 for the same number of hits -- a box shares its cores, and a late thread was the call) */
+    const unsigned n_jobs = n_thr == 1 ? 1 : (unsigned)std::min<size_t>(n_thr * 4u, std::max<size_t>(n_thr, (n + n_cs) / 1024));
+    std::vector<std::vector<Event>> ev(n_jobs);
+    std::vector<std::vector<BlockRun>> runs(n_jobs);
     if (onEvent) {
         /* slices of whole blocks: cut the longer list evenly, snap to a block boundary, cut the other list at the
          * same block */
-        std::vector<size_t> cut(n_thr + 1, n), ccut(n_thr + 1, n_cs);
+        std::vector<size_t> cut(n_jobs + 1, n), ccut(n_jobs + 1, n_cs);
         cut[0] = ccut[0] = 0;
         const bool by_cs = n_cs > n;
         const hsgpu_match_t *lead = by_cs ? cs : recs, *follow = by_cs ? recs : cs;
         const size_t n_lead = by_cs ? n_cs : n, n_follow = by_cs ? n : n_cs;
         std::vector<size_t> &lcut = by_cs ? ccut : cut, &fcut = by_cs ? cut : ccut;
-        for (unsigned t = 1; t < n_thr; t++) {
-            size_t c = std::max(lcut[t - 1], n_lead * t / n_thr);
+        for (unsigned t = 1; t < n_jobs; t++) {
+            size_t c = std::max(lcut[t - 1], n_lead * t / n_jobs);
             while (c < n_lead && c > 0 && lead[c].block == lead[c - 1].block) c++; /* snap to a block boundary */
             lcut[t] = c;
             const unsigned long long b = c < n_lead ? lead[c].block : ~0ull;
@@ -1154,25 +1210,35 @@ static int confirm_and_deliver_impl(const hs_database *db, const char *data, con
             fcut[t] = std::max(f, fcut[t - 1]);
         }
         std::atomic<bool> failed{false}; /* no exception may leave a worker thread (std::terminate) or this extern "C" path */
+        std::vector<double> busy(n_jobs, 0.0);
         auto work = [&](unsigned t) {
             try {
+                const double t0 = now_s();
                 collect_slice(db, (const unsigned char *)data, off, recs, cut[t], cut[t + 1], ev[t], runs[t], cs, ccut[t], ccut[t + 1]);
+                busy[t] = now_s() - t0;
             } catch (...) {
                 failed = true;
             }
         };
+        t_par0 = now_s();
         if (n_thr == 1) {
             work(0);
         } else { /* the scratch's own threads and this one; without a scratch (hs_confirm_batch): threads for this call */
             HsConfirmPool local;
             HsConfirmPool *p = pool ? pool : &local;
             p->ensure(n_thr - 1);
-            p->run(n_thr, work);
+            p->run(n_jobs, work);
         }
         if (failed) return -1;
+        t_par1 = now_s();
+        if (n_thr > 1) {
+            g_confirm_timing[0] = t_par0 - t_in, g_confirm_timing[1] = t_par1 - t_par0;
+            g_confirm_timing[2] = *std::max_element(busy.begin(), busy.end()), g_confirm_timing[3] = *std::min_element(busy.begin(), busy.end());
+        }
     }
+    struct Done { double t0; bool on; ~Done() { if (on) g_confirm_timing[4] = now_s() - t0; } } done{now_s(), n_thr > 1};
     int any_terminated = 0;
-    for (unsigned t = 0; t < n_thr; t++)
+    for (unsigned t = 0; t < n_jobs; t++)
         for (const BlockRun &r : runs[t])
             for (size_t i = r.ev_begin; i < r.ev_end; i++) {
                 const Event &e = ev[t][i];
@@ -1304,6 +1370,27 @@ static hs_error_t scan_blocks(const hs_database_t *db, const char *data, const u
     return any_terminated ? HS_SCAN_TERMINATED : HS_SUCCESS;
 }
 
+hs_error_t hs_scan_batch_resident(const hs_database_t *db, const char *data, const unsigned long long *off,
+                                  unsigned long long nblocks, const void *d_corpus, const void *d_off, hs_scratch_t *scratch,
+                                  hs_batch_event_handler onEvent, void *context) {
+    db = resolve_db(db);
+    if (!scratch || !data || !off || !d_off) return HS_INVALID;
+    if (!db || db->magic != 0x48534744) return HS_INVALID;
+    if (db->mode != HS_MODE_BLOCK) return HS_DB_MODE_ERROR;
+    if (scratch->magic != 0x48534753 || !db->cs_seqs.empty() || off[0] != 0) return HS_INVALID;
+    if (scratch->in_use) return HS_SCRATCH_IN_USE;
+    scratch->in_use = true;
+    struct Guard { hs_scratch *s; ~Guard() { s->in_use = false; } } guard{scratch};
+    if (nblocks == 0 || !db->hwlm) return HS_SUCCESS;
+    const hsgpu_match_t *recs = nullptr;
+    size_t n = 0;
+    const int rv = hsgpu_hwlm_exec_resident(db->hwlm, scratch->gpu, d_corpus, off[nblocks], d_off, nblocks, 0, &recs, &n);
+    if (rv != HSGPU_SUCCESS) return rv == HSGPU_NOMEM ? HS_NOMEM : rv == HSGPU_INVALID ? HS_INVALID : HS_UNKNOWN_ERROR;
+    const int t = confirm_and_deliver(db, data, off, recs, n, onEvent, context, nullptr, 0, &scratch->pool);
+    if (t < 0) return HS_NOMEM;
+    return t ? HS_SCAN_TERMINATED : HS_SUCCESS;
+}
+
 /* the literal the GPU matcher holds for one branch (hs_gpu.h) */
 hs_error_t hs_database_literal(const hs_database_t *db, unsigned int index, const char **bytes, size_t *len,
                                int *nocase, unsigned int *id) {
@@ -1328,15 +1415,38 @@ hs_error_t hs_confirm_batch(const hs_database_t *db, const char *data, const uns
     db = resolve_db(db); /* a database placed by hs_deserialize_database_at */
     if (!db || db->magic != 0x48534744 || !data || !off || (n_records && !records)) return HS_INVALID;
     const hsgpu_match_t *recs = (const hsgpu_match_t *)records;
-    for (unsigned long long i = 0; i < n_records; i++) {
-        if (recs[i].block >= nblocks || recs[i].id >= db->pats.size()) return HS_INVALID;
-        if (i && (recs[i].block < recs[i - 1].block ||
-                  (recs[i].block == recs[i - 1].block && recs[i].end < recs[i - 1].end)))
-            return HS_INVALID;
-        if (recs[i].end >= off[recs[i].block + 1] - off[recs[i].block]) return HS_INVALID;
+    /* the caller's records are checked before anything follows them into the batch -- on the threads that confirm them
+     * afterwards (round 6: a serial walk was a quarter of a large call's time: every record reads two offsets) */
+    auto valid = [&](unsigned long long lo, unsigned long long hi) -> bool {
+        for (unsigned long long i = lo; i < hi; i++) {
+            if (recs[i].block >= nblocks || recs[i].id >= db->pats.size()) return false;
+            if (i && (recs[i].block < recs[i - 1].block ||
+                      (recs[i].block == recs[i - 1].block && recs[i].end < recs[i - 1].end)))
+                return false;
+            if (recs[i].end >= off[recs[i].block + 1] - off[recs[i].block]) return false;
+        }
+        return true;
+    };
+    if (n_records < 8192) {
+        if (!valid(0, n_records)) return HS_INVALID;
+        const int rv = confirm_and_deliver(db, data, off, recs, (size_t)n_records, onEvent, context);
+        return rv < 0 ? HS_NOMEM : (rv ? HS_SCAN_TERMINATED : HS_SUCCESS);
     }
-    const int rv = confirm_and_deliver(db, data, off, recs, (size_t)n_records, onEvent, context);
-    return rv < 0 ? HS_NOMEM : (rv ? HS_SCAN_TERMINATED : HS_SUCCESS);
+    try {
+        HsConfirmPool pool; /* (no scratch in this call: threads of its own, for the check and for the confirm) */
+        const unsigned n_thr = confirm_threads();
+        pool.ensure(n_thr - 1);
+        std::atomic<bool> bad{false};
+        const std::function<void(unsigned)> check = [&](unsigned t) {
+            if (!valid(n_records * t / n_thr, n_records * (t + 1) / n_thr)) bad = true;
+        };
+        pool.run(n_thr, check);
+        if (bad) return HS_INVALID;
+        const int rv = confirm_and_deliver(db, data, off, recs, (size_t)n_records, onEvent, context, nullptr, 0, &pool);
+        return rv < 0 ? HS_NOMEM : (rv ? HS_SCAN_TERMINATED : HS_SUCCESS);
+    } catch (...) {
+        return HS_NOMEM;
+    }
 }
 
 hs_error_t hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsigned int flags,

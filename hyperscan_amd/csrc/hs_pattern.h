@@ -83,6 +83,10 @@ struct Pattern {
      * reach[c] = unit i accepts byte c; star / optional unit masks */
     bool fast = false;
     std::vector<unsigned long long> reach; /* [256] */
+    /* set by the database once its patterns are final: the table of the FIRST pattern with the same one (patterns that share a
+     * tail share its 2 KiB table -- config 5's 1 000 patterns have three: the confirm's tables stay in L1 instead of 2 MB of L3) */
+    const unsigned long long *reach_shared = nullptr;
+    const unsigned long long *reach_tab() const { return reach_shared ? reach_shared : reach.data(); }
     unsigned long long star_mask = 0, opt_mask = 0;
     /* fragments with groups / alternation / long repeats, and every R1 in front of a literal:
      * position automata (see Auto). `general`: R2 forwards from the literal's end; `has_pre`: R1
@@ -149,9 +153,10 @@ struct TailNfa {
     template <class F> static void run64(const Pattern &p, const unsigned char *buf, size_t len, size_t pos, F report) {
         const unsigned long long accept = 1ull << p.tail.size();
         unsigned long long cur = closure64(1ull, p.opt_mask);
+        const unsigned long long *reach = p.reach_tab();
         if (cur & accept) { if (!report(pos)) return; }
         while (pos < len && (cur & (accept - 1))) {
-            const unsigned long long live = cur & p.reach[buf[pos++]];
+            const unsigned long long live = cur & reach[buf[pos++]];
             cur = closure64((live << 1) | (live & p.star_mask), p.opt_mask);
             if (cur & accept) { if (!report(pos)) return; }
         }
@@ -301,6 +306,7 @@ struct TailNfa {
         if (!n) return;
         const unsigned long long accept = 1ull << p.tail.size(), init = closure64(1ull, p.opt_mask);
         unsigned long long cur = 0;
+        const unsigned long long *reach = p.reach_tab();
         size_t pos = starts[0], k = 0;
         for (;;) {
             bool injected = false;
@@ -316,7 +322,7 @@ struct TailNfa {
                 pos = starts[k];
                 continue;
             }
-            const unsigned long long live = cur & p.reach[buf[pos++]];
+            const unsigned long long live = cur & reach[buf[pos++]];
             cur = closure64((live << 1) | (live & p.star_mask), p.opt_mask);
             if (cur & accept) { if (!report(pos)) return; }
         }

@@ -1602,6 +1602,47 @@ extern "C" int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t
     return hsgpu_hwlm_replay(t, recs.data(), recs.size(), cb, ctx, groups);
 }
 
+extern "C" int hsgpu_hwlm_exec_resident(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus, uint64_t total_bytes,
+                                        const void *d_off, uint64_t nblocks, uint64_t start, const hsgpu_match_t **recs, size_t *nout) {
+    if (!t || !s || !recs || !nout || !d_off || (total_bytes && !d_corpus)) return HSGPU_INVALID;
+    *recs = nullptr;
+    *nout = 0;
+    if (nblocks == 0 || total_bytes == 0) return HSGPU_SUCCESS;
+    InUse guard(s);
+    if (!guard.ok) return HSGPU_SCRATCH_IN_USE;
+    HIP_TRY(hipSetDevice(s->device));
+    int rv;
+    uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(4096, total_bytes / 1024), s->out.cap / sizeof(hsgpu_match_t));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        if ((rv = s->out.ensure(cap * sizeof(hsgpu_match_t))) != HSGPU_SUCCESS) return rv;
+        rv = hsgpu_hwlm_scan_dev(t, s, d_corpus, total_bytes, d_off, nblocks, start, s->out.p, cap, s->count.p, s->stream);
+        if (rv != HSGPU_SUCCESS) return rv;
+        HIP_TRY(hipMemcpyAsync(s->h_count, s->count.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const uint64_t n = *s->h_count;
+        if (n <= cap) {
+            if (n > s->h_recs_cap) {
+                if (s->h_recs) (void)hipHostFree(s->h_recs);
+                s->h_recs = nullptr;
+                s->h_recs_cap = 0;
+                const size_t want = (size_t)(n + n / 4 + 4096);
+                HIP_TRY(hipHostMalloc((void **)&s->h_recs, want * sizeof(hsgpu_match_t)));
+                s->h_recs_cap = want;
+            }
+            if (n) {
+                HIP_TRY(hipMemcpyAsync(s->h_recs, s->out.p, n * sizeof(hsgpu_match_t), hipMemcpyDeviceToHost, s->stream));
+                HIP_TRY(hipStreamSynchronize(s->stream));
+            }
+            *recs = s->h_recs;
+            *nout = (size_t)n;
+            return HSGPU_SUCCESS;
+        }
+        cap = std::max<uint64_t>(n + n / 4, cap * 2); /* "again": the count is exact or cap + 1; room for skew */
+    }
+    hsgpu_set_error("match buffer overflow persisted");
+    return HSGPU_UNKNOWN_ERROR;
+}
+
 extern "C" int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8_t *base,
                                      const uint64_t *off, size_t nblocks, size_t start, hsgpu_match_t *out,
                                      size_t cap, size_t *nout) {

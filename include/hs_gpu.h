@@ -233,6 +233,17 @@ hs_error_t hs_scan_batch(const hs_database_t *db, const char *data, const unsign
                          unsigned long long nblocks, unsigned int flags, hs_scratch_t *scratch,
                          hs_batch_event_handler onEvent, void *context);
 
+/* Extension: hs_scan_batch for a batch that is ALREADY on the device -- the caller keeps a corpus resident in HBM and scans it
+ * again and again (hsbench's protocol: the corpus is loaded once, tools/hsbench/main.cpp:502-528), or it arrived there by another
+ * route. d_corpus / d_off: the same bytes and offsets as data / off, in device memory, as hsgpu_hwlm_scan_dev takes them (d_corpus
+ * 16-byte aligned, d_off relative to d_corpus with d_off[0] == 0); data / off: the host copy the confirm reads the bytes behind
+ * every literal hit from (off[0] == 0). Literal scan on the device, its hits to the host, Rose-lite confirm, callbacks in
+ * block order on the calling thread: nothing of the corpus crosses the bus. HS_INVALID for a database with literal-less
+ * class-sequence patterns (their records are delivered range by range by hs_scan_batch). */
+hs_error_t hs_scan_batch_resident(const hs_database_t *db, const char *data, const unsigned long long *off,
+                                  unsigned long long nblocks, const void *d_corpus, const void *d_off, hs_scratch_t *scratch,
+                                  hs_batch_event_handler onEvent, void *context);
+
 /* Extension: only the host-side confirm of hs_scan_batch, over literal hits the caller supplies
  * (hsgpu_match_t records, include/hsgpu.h: sorted by (block, end); id = index of the branch, see
  * hs_database_literal; end = offset of the last byte of that branch's literal). Touches no

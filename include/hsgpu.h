@@ -141,6 +141,12 @@ int hsgpu_hwlm_exec_batch(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const uint8
                           const uint64_t *off, size_t nblocks, size_t start,
                           hsgpu_match_t *out, size_t cap, size_t *nout);
 
+/* The same for a batch that is already on the device (d_corpus, d_off as hsgpu_hwlm_scan_dev takes them): the scan, then its
+ * records -- in delivery order -- into page-locked host memory OWNED BY THE SCRATCH: *recs points at them until the next call on
+ * this scratch, *nout is their number. Repeats the scan itself when its record buffer was too small. */
+int hsgpu_hwlm_exec_resident(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus, uint64_t total_bytes,
+                             const void *d_off, uint64_t nblocks, uint64_t start, const hsgpu_match_t **recs, size_t *nout);
+
 /* Device-resident form (the hot path): corpus, offsets, records and counter all
  * live in HBM; asynchronous on `stream` (a hipStream_t passed as void*, NULL =
  * the scratch's own stream); no host synchronisation. d_off holds nblocks+1

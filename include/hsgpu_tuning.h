@@ -80,6 +80,12 @@ int hsgpu_debug_guard_probe(void *p, long long byte_offset, int write);
 int hsgpu_debug_guard_copy(void *dst, const void *src, size_t bytes, int to_device);
 int hsgpu_debug_guard_fill(void *dst, int value, size_t bytes);
 
+/* The host confirm's last large batch in this process (csrc/hs_facade.cpp, tools/confirm_prof.py), seconds: out[0] setup, [1] the
+ * parallel part's wall time, [2] / [3] the slowest / fastest worker's own time, [4] the delivery loop (callbacks). */
+void hsgpu_debug_confirm_timing(double out[5]);
+/* the host confirm's thread count for large batches, for sweeps (0 = the default: min(64, hardware threads)) */
+void hsgpu_debug_confirm_threads(unsigned n);
+
 /* The first 32 hex digits of the sha256 over the sources this library was built from (csrc/Makefile, STAMPED): the built
  * library is not in the repository, and a test compares this with the tree it runs in. */
 const char *hsgpu_source_hash(void);

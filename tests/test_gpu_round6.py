@@ -72,3 +72,42 @@ def test_bench_virtual_ranks_gather_equals_one_scan(scratch):
     assert all(len(out["_rows"]["to_root"][r]) == 0 for r in range(1, n_ranks))
     for m in ("all_gather", "to_root"):
         assert out[m]["step_ms"] > 0 and out[m]["pack_ms"] > 0 and out[m]["compact_ms"] > 0
+
+
+def test_hs_scan_batch_resident_equals_hs_scan_batch():
+    """hs_scan_batch_resident (include/hs_gpu.h): the batch already on the device, only the literal hits cross the bus; the same
+    events, in the same order, as hs_scan_batch on the host copy -- small batches (single-threaded confirm) and large ones."""
+    import torch
+
+    from hyperscan_amd import corpus as cp
+    from hyperscan_amd import hs
+    from tests import rose_model as RM
+
+    rng = np.random.default_rng(8)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ", dtype=np.uint8)
+    lits = sorted({bytes(rng.choice(alpha, int(rng.integers(6, 13)))) for _ in range(200)})
+    pats = [l.decode() + RM.TAILS[i % 3] for i, l in enumerate(lits)]
+    db = hs.Database.compile(pats, [0] * len(pats), list(range(len(pats))))
+    sc = hs.HsScratch(db)
+    lib = hs._lib()
+    lib.hs_scan_batch_resident.restype = C.c_int
+    lib.hs_scan_batch_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p, hs.BATCH_CB, C.c_void_p]
+
+    class L:
+        def __init__(self, s):
+            self.s = s
+    follow = [b"abc7", b"  key=", b"....END"]
+    for total, every in ((1 << 20, 4096), (48 << 20, 256)):
+        corpus, off = cp.packet_corpus(total, [L(l + follow[i % 3]) for i, l in enumerate(lits)], seed=3, match_every=every)
+        offs = np.ascontiguousarray(off, dtype=np.uint64)
+        a, b = [], []
+        cb_a = hs.BATCH_CB(lambda blk, i, f, t, _fl, _c: (a.append((int(blk), int(i), int(t))), 0)[1])
+        cb_b = hs.BATCH_CB(lambda blk, i, f, t, _fl, _c: (b.append((int(blk), int(i), int(t))), 0)[1])
+        assert lib.hs_scan_batch(db._h, corpus.ctypes.data, offs.ctypes.data, offs.size - 1, 0, sc._h, cb_a, None) == 0
+        d_corpus = torch.from_numpy(corpus).to("cuda:0")
+        d_off = torch.from_numpy(offs.view(np.int64)).to("cuda:0")
+        for _ in range(2):  # (the second call reuses the scratch's buffers)
+            b.clear()
+            assert lib.hs_scan_batch_resident(db._h, corpus.ctypes.data, offs.ctypes.data, offs.size - 1, d_corpus.data_ptr(), d_off.data_ptr(),
+                                              sc._h, cb_b, None) == 0
+            assert a == b and len(a) > 100, (total, len(a), len(b))
