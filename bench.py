@@ -1496,17 +1496,31 @@ def run_batch_sweep(args):
 
     def one_call():
         return lib.hsgpu_hwlm_exec(job.table._h, p_blk, n_blk, 0, count_cb, job.scratch._h, hw.HWLM_ALL_GROUPS)
-    for _ in range(5):
-        assert one_call() == 0
-    t0 = time.perf_counter()
-    for _ in range(500):
-        one_call()
-    us_exec = (time.perf_counter() - t0) / 500 * 1e6
+    def per_call(n=500):
+        for _ in range(5):
+            assert one_call() == 0
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one_call()
+        return (time.perf_counter() - t0) / n * 1e6
+    us_launch = per_call()  # a kernel launch per call (rounds 1-5)
+    n_launch = ncb.value
+    # ... and through the small-batch server (round 6, include/hsgpu.h): one resident workgroup, no launch per call
+    job.scratch.enable_server(True)
+    ncb.value = 0
+    us_exec = per_call(2000)
+    assert ncb.value * 505 == n_launch * 2005, "the server delivers other matches than the launch path"
+    calls, launches, _live = job.scratch.server_stats()
+    cu, su = C.c_float(), C.c_float()
+    lib.hsgpu_scratch_server_last_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
+    job.scratch.enable_server(False)
     lib.hsgpu_scratch_set_context(job.scratch._h, None)
     res = {"workload": "fdr10k table; resident scans of the first N bytes of the 1 GiB corpus, serial launches (hsgpu_hwlm_scan_dev), and one "
                        "hsgpu_hwlm_exec call per 1460-byte block from host memory",
            "value": round(peak, 1), "unit": "GB/s at the largest batch",
            "us_per_hwlm_exec_call_1460B": round(us_exec, 1), "GBps_one_block_per_call": round(1460 / us_exec / 1e3, 4),
+           "us_per_hwlm_exec_call_1460B_launch_path": round(us_launch, 1), "server": {"calls": calls, "launches": launches, "device_copy_us": round(cu.value, 2), "device_scan_us": round(su.value, 2)},
            "half_peak_batch_bytes": reach(0.5), "ninety_percent_batch_bytes": reach(0.9), "curve": curve}
     del job
     torch.cuda.empty_cache()
@@ -1549,7 +1563,7 @@ def compact_also(name, r):
     if name == "virtual_ranks":  # (its figures are in multi_gpu.loopback; the whole object is in the details file)
         return {"n_ranks": r["n_ranks"], "scan_ms": r["scan_ms"], "in_line_as": "multi_gpu.loopback"}
     keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "parity", "gpu_stage", "host_confirm", "resident_end_to_end",
-            "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "GBps_one_block_per_call",
+            "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "us_per_hwlm_exec_call_1460B_launch_path", "server", "GBps_one_block_per_call",
             "half_peak_batch_bytes", "ninety_percent_batch_bytes", "curve", "parity_whole_corpus", "parity_reference", "note")
     out = {"workload": _short(r.get("workload", name), 110)}
     for k in keep:

@@ -42,7 +42,7 @@ void hsgpu_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *hsgpu_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char *hsgpu_version(void) { return "hsgpu 0.1 (gfx950)"; }
+extern "C" const char *hsgpu_version(void) { return "hsgpu 0.6 (gfx950)"; }
 
 namespace {
 

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -172,6 +173,15 @@ struct hsgpu_scratch {
     DevBuf solo_ctl;                       /* solo scans: rec_counts | rec_super | ticket, left zeroed by the scan itself */
     const void *res_corpus = nullptr, *res_off = nullptr; /* where the batch this scratch took in last lives (reuse_resident): its device buffers, or the mapped small-batch area */
     uint8_t *h_small = nullptr, *d_small = nullptr; /* small host batches: mapped pinned {count | offsets | corpus | records}, read and written by the kernel itself */
+    /* the small-batch server (hsgpu_scratch_set_server; scan_device.h, hwlm_server_kernel): one resident workgroup that scans what the
+     * host puts into the mapped area above, without a launch per call */
+    bool srv_enabled = false, srv_live = false;
+    hipStream_t srv_stream = nullptr;
+    HsgpuServerCtl *h_srv = nullptr, *d_srv = nullptr;
+    const hsgpu_hwlm *srv_table = nullptr;
+    uint32_t srv_seq = 0;
+    unsigned srv_idle_us = 300; /* an idle server ends after this long: nothing it holds outlives a burst of calls by more */
+    uint64_t srv_calls = 0, srv_launches = 0;
     bool solo_ctl_clean = false;
     int tune_unfolded = 0;                 /* fused_only == 2: two-phase with record_sort_kernel behind the confirm kernel */
     unsigned tune_wg_threads = 0, tune_wg_per_cu = 0;
@@ -268,9 +278,11 @@ extern "C" int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device) {
     return HSGPU_SUCCESS;
 }
 
+static void server_stop(hsgpu_scratch *s);
 extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    server_stop(s);
     s->corpus.release();
     s->off.release();
     s->out.release();
@@ -300,6 +312,8 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     if (s->h_count) (void)hipHostFree(s->h_count);
     if (s->h_note) (void)hipHostFree(s->h_note);
     if (s->h_small) (void)hipHostFree(s->h_small);
+    if (s->h_srv) (void)hipHostFree(s->h_srv);
+    if (s->srv_stream) (void)hipStreamDestroy(s->srv_stream);
     if (s->h_recs) (void)hipHostFree(s->h_recs);
     for (int i = 0; i < 4; i++)
         if (s->ev_chunk[i]) (void)hipEventDestroy(s->ev_chunk[i]);
@@ -452,12 +466,37 @@ static int set_dyn_lds(const void *fn, size_t lds) {
 
 extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu) {
     if (!s || (wg_threads && (wg_threads % 64 || wg_threads < 256 || wg_threads > 1024)) || wg_per_cu > 4) return HSGPU_INVALID;
+    server_stop(s); /* (a resident server was sized for the old geometry) */
     s->tune_fused = fused_only == 1;
     s->tune_unfolded = fused_only == 2;
     s->tune_solo = fused_only == 3 ? 1 : fused_only == 4 ? 2 : 0;
     s->tune_no_skew = fused_only == 5;
     s->tune_wg_threads = wg_threads;
     s->tune_wg_per_cu = wg_per_cu;
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_scratch_enable_server(hsgpu_scratch_t *s, int enable, unsigned idle_us) {
+    if (!s) return HSGPU_INVALID;
+    HIP_TRY(hipSetDevice(s->device));
+    if (!enable) server_stop(s);
+    s->srv_enabled = enable != 0;
+    if (idle_us) s->srv_idle_us = std::min(idle_us, 1000000u);
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_scratch_server_last_us(hsgpu_scratch_t *s, float *copy_us, float *scan_us) {
+    if (!s || !s->h_srv) return HSGPU_INVALID;
+    if (copy_us) *copy_us = (float)s->h_srv->pad2[2] / 100.f; /* 100 MHz ticks */
+    if (scan_us) *scan_us = (float)s->h_srv->pad2[3] / 100.f;
+    return HSGPU_SUCCESS;
+}
+
+extern "C" int hsgpu_scratch_server_stats(hsgpu_scratch_t *s, uint64_t *calls, uint64_t *launches, int *live) {
+    if (!s) return HSGPU_INVALID;
+    if (calls) *calls = s->srv_calls;
+    if (launches) *launches = s->srv_launches;
+    if (live) *live = s->srv_live && !__atomic_load_n(&s->h_srv->exited, __ATOMIC_ACQUIRE);
     return HSGPU_SUCCESS;
 }
 
@@ -493,6 +532,92 @@ static unsigned confirm_resident_workgroups(hsgpu_scratch *s, const void *f_conf
     return (unsigned)it->second * (unsigned)std::max(1, s->n_cu);
 }
 
+/* The arguments and buffers of a SOLO scan -- the fused kernel with the placement in its last workgroup (scan_device.h, solo_tail):
+ * one launch for a small batch (launch_scan), or the body the small-batch server runs per request (server_start). `args` comes in
+ * with the table fields set; total / cap: the largest batch and record count this setup has to hold. */
+static int solo_setup(hsgpu_scratch *s, HsgpuScanArgs &args, uint64_t total, uint64_t cap, unsigned solo_grid, unsigned wg_threads,
+                      hipStream_t stream) {
+    int rv;
+    const uint32_t n_reg = solo_grid * (wg_threads / 64);
+    /* (the hints: every wavefront writes those of its own tiles in the kernel's prologue) */
+    args.n_hint = (total >> HSGPU_HINT_SHIFT) + 1;
+    if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    args.hint = (const uint32_t *)s->hint.p;
+    args.hint_in_filter = 0;
+    args.fold = 0;
+    args.conf_q = args.conf_k = 1;
+    args.conf_spread = 0, args.conf_skew = 0;
+    args.conf_cus = (uint32_t)std::max(1, s->n_cu);
+    args.cand = nullptr;
+    args.cand_cap = 0;
+    args.cand_waves = 0;
+    args.cand_counts = nullptr;
+    args.rec_regions = n_reg;
+    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (cap / n_reg + 1)));
+    if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_reg * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
+    args.rec_stage = (uint4 *)s->rec_stage.p;
+    const size_t super_ofs = ((size_t)2 * 1024 + 1) & ~(size_t)1, ticket_ofs = super_ofs + 2 * HSGPU_SUPER_WORDS;
+    const size_t ctl_words = (ticket_ofs + 4) & ~(size_t)3;
+    const size_t cap_before = s->solo_ctl.cap;
+    if ((rv = s->solo_ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
+    if (s->solo_ctl.cap != cap_before || !s->solo_ctl_clean) HIP_TRY(hipMemsetAsync(s->solo_ctl.p, 0, s->solo_ctl.cap, stream));
+    s->solo_ctl_clean = true; /* (the scan's last workgroup leaves it zeroed) */
+    args.rec_counts = (uint32_t *)s->solo_ctl.p;
+    args.rec_super = (unsigned long long *)((uint32_t *)s->solo_ctl.p + super_ofs);
+    args.solo_ticket = (uint32_t *)s->solo_ctl.p + ticket_ofs;
+    args.solo_ctl_words = (uint32_t)ctl_words;
+    args.super_shift = 5;
+    args.group_regions = 1;
+    args.ctl_other = nullptr;
+    args.ctl_other_words = 0;
+    args.stats = (unsigned long long *)s->stats.p;
+    args.overflow_note = s->d_note;
+    args.solo = 1;
+    args.tstamp = nullptr;
+    args.tstamp_next = nullptr;
+    args.wg_stamps = nullptr;
+    args.conf_stamps = nullptr;
+    return HSGPU_SUCCESS;
+}
+
+/* the table fields every kernel reads from its arguments (no dependent read of the header) */
+static void table_args(const HsgpuTableHeader *h, HsgpuScanArgs &args) {
+    args.t_flags = h->flags;
+    args.fold_shift = (h->flags & (HSGPU_F_BFOLD | HSGPU_F_PAIR)) ? 16u : 0u; /* one filter test stands for every key class */
+    args.t_hash_mask = h->hash_mask;
+    args.t_filter_log2 = h->filter_log2;
+    args.t_ht_a_log2 = h->ht_a_log2;
+    args.t_ht_b_log2 = h->ht_b_log2;
+    args.t_off_filter = h->off_filter;
+    args.t_off_c2bits = h->off_c2bits;
+    args.t_off_ht_a = h->off_ht_a;
+    args.t_off_ht_b = h->off_ht_b;
+    args.t_off_c2ref = h->off_c2ref;
+    args.t_off_lists = h->off_lists;
+    args.t_off_lits = h->off_lits;
+}
+
+/* the filter workgroup's size for a table (launch_scan's choice, also the server's) */
+static unsigned filter_wg_threads(const HsgpuTableHeader *h, const hsgpu_scratch *s, bool *small_out) {
+    const bool small = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, 512) * 3 <= s->lds_per_cu;
+    const bool light = (h->flags & HSGPU_F_STRIDE2) && !(h->flags & (HSGPU_F_K2 | HSGPU_F_HAS_C | HSGPU_F_PAIR));
+    if (small_out) *small_out = small;
+    unsigned wg_threads = small ? 512 : light ? 768 : HSGPU_WG_THREADS;
+    if (s->tune_wg_threads) wg_threads = s->tune_wg_threads; /* hsgpu_scratch_set_tuning */
+    return wg_threads;
+}
+
+/* ---- the small-batch server: host side (scan_device.h, hwlm_server_kernel) ------------------------------------------------ */
+static void server_stop(hsgpu_scratch *s) { /* ends a live server at once and waits until it has gone */
+    if (!s->srv_live) return;
+    __atomic_store_n(&s->h_srv->stop, 1u, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(s->srv_stream);
+    s->h_srv->stop = 0;
+    s->h_srv->exited = 0;
+    s->srv_live = false;
+    s->srv_table = nullptr;
+}
+
 static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArgs &a, hipStream_t stream) {
     const HsgpuTableHeader *h = t->hdr();
     const void *f_two = hsgpu_filter_kernel_for(h->flags, false);
@@ -505,6 +630,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     /* Geometry: big tables (up to 128 KiB of filter) run one 16-wavefront workgroup per
      * CU; tables of <= 40 KiB run three 8-wavefront workgroups per CU (24 wavefronts
      * hide more latency; the SGPR budget admits no second 16-wavefront workgroup). */
+    server_stop(s); /* (a resident server works in this scratch's buffers) */
     const bool small = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, 512) * 3 <= s->lds_per_cu;
     /* Stride-2 single-bit filters are light enough (~3 VALU instructions per byte) that the
      * kernel is bound by the memory side, and there 8 wavefronts per CU measured 7-13% faster
@@ -540,19 +666,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.solo = 0;
     args.solo_ctl_words = 0;
     args.solo_ticket = nullptr;
-    args.t_flags = h->flags;
-    args.fold_shift = (h->flags & (HSGPU_F_BFOLD | HSGPU_F_PAIR)) ? 16u : 0u; /* one filter test stands for every key class */
-    args.t_hash_mask = h->hash_mask;
-    args.t_filter_log2 = h->filter_log2;
-    args.t_ht_a_log2 = h->ht_a_log2;
-    args.t_ht_b_log2 = h->ht_b_log2;
-    args.t_off_filter = h->off_filter;
-    args.t_off_c2bits = h->off_c2bits;
-    args.t_off_ht_a = h->off_ht_a;
-    args.t_off_ht_b = h->off_ht_b;
-    args.t_off_c2ref = h->off_c2ref;
-    args.t_off_lists = h->off_lists;
-    args.t_off_lits = h->off_lits;
+    table_args(h, args);
     int rv;
     /* Small batches: ONE launch (the fused kernel with the placement in its last workgroup; scan_device.h, solo_tail). The
      * reference serves short blocks from dedicated small matchers (src/rose/block.c:382-391, src/runtime.c:401-413); here
@@ -566,45 +680,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     if (solo_ok && (a.total <= SOLO_BYTES || s->tune_solo == 2)) {
         /* 16 KiB (8 KiB for 512-thread workgroups) per workgroup; forced on big corpora (tests): at most 1024 regions */
         const unsigned solo_grid = (unsigned)std::min<uint64_t>(n_tiles, 1024 / (wg_threads / 64));
-        const uint32_t n_reg = solo_grid * (wg_threads / 64);
-        /* (the hints: every wavefront writes those of its own tiles in the kernel's prologue) */
-        args.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
-        if ((rv = s->hint.ensure(args.n_hint * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
-        args.hint = (const uint32_t *)s->hint.p;
-        args.hint_in_filter = 0;
-        args.fold = 0;
-        args.conf_q = args.conf_k = 1;
-        args.conf_spread = 0, args.conf_skew = 0;
-    args.conf_cus = (uint32_t)std::max(1, s->n_cu);
-        args.cand = nullptr;
-        args.cand_cap = 0;
-        args.cand_waves = 0;
-        args.cand_counts = nullptr;
-        args.rec_regions = n_reg;
-        args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_reg + 1)));
-        if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_reg * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
-        args.rec_stage = (uint4 *)s->rec_stage.p;
-        const size_t super_ofs = ((size_t)2 * 1024 + 1) & ~(size_t)1, ticket_ofs = super_ofs + 2 * HSGPU_SUPER_WORDS;
-        const size_t ctl_words = (ticket_ofs + 4) & ~(size_t)3;
-        const size_t cap_before = s->solo_ctl.cap;
-        if ((rv = s->solo_ctl.ensure(ctl_words * sizeof(uint32_t))) != HSGPU_SUCCESS) return rv;
-        if (s->solo_ctl.cap != cap_before || !s->solo_ctl_clean) HIP_TRY(hipMemsetAsync(s->solo_ctl.p, 0, s->solo_ctl.cap, stream));
-        s->solo_ctl_clean = true; /* (the scan's last workgroup leaves it zeroed) */
-        args.rec_counts = (uint32_t *)s->solo_ctl.p;
-        args.rec_super = (unsigned long long *)((uint32_t *)s->solo_ctl.p + super_ofs);
-        args.solo_ticket = (uint32_t *)s->solo_ctl.p + ticket_ofs;
-        args.solo_ctl_words = (uint32_t)ctl_words;
-        args.super_shift = 5;
-        args.group_regions = 1;
-        args.ctl_other = nullptr;
-        args.ctl_other_words = 0;
-        args.stats = (unsigned long long *)s->stats.p;
-        args.overflow_note = s->d_note;
-        args.solo = 1;
-        args.tstamp = nullptr;
-        args.tstamp_next = nullptr;
-        args.wg_stamps = nullptr;
-        args.conf_stamps = nullptr;
+        if ((rv = solo_setup(s, args, a.total, a.cap, solo_grid, wg_threads, stream)) != HSGPU_SUCCESS) return rv;
         if (s->timing) {
             const size_t slot = s->n_timed % hsgpu_scratch::kRing;
             s->ev_t = s->ev_ring[slot];
@@ -716,7 +792,9 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
         if (!s->d_note) n_rec = std::max(n_rec, n_waves); /* (the fused kernel behind the confirm kernel writes one region per filter wavefront) */
     }
     args.rec_regions = n_rec;
-    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(256, 2 * (a.cap / n_rec + 1)));
+    /* (dense mode has a region per PART -- tens of thousands of them for a 64 MiB chunk: a floor of 256 records each was 285 MiB
+     * of staging whatever the caller's cap said; advisor, round 5. A part that outgrows its region says "again" like any other.) */
+    args.rec_cap = (uint32_t)std::min<uint64_t>(1u << 30, std::max<uint64_t>(args.conf_spread ? 64 : 256, 2 * (a.cap / n_rec + 1)));
     if ((rv = s->rec_stage.ensure((uint64_t)args.rec_cap * n_rec * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
     /* Two control blocks that alternate from scan to scan, each rec_counts[2 n_rec] | cand_counts[n_waves + 1] |
      * rec_super[257] (64-bit): a scan works in one and its last kernel zeroes the other (the previous scan's), so
@@ -958,16 +1036,110 @@ static int upload_batch(hsgpu_scratch *s, const uint8_t *base, const uint64_t *o
     return HSGPU_SUCCESS;
 }
 
+constexpr size_t SMALL_BYTES = 256 << 10, SMALL_BLOCKS = 4096, SMALL_RECS = 4096;
+constexpr size_t SMALL_OFF_AT = 64, SMALL_CORPUS_AT = SMALL_OFF_AT + (SMALL_BLOCKS + 1) * 8 + 56 /* -> a multiple of 64 */,
+                 SMALL_RECS_AT = SMALL_CORPUS_AT + SMALL_BYTES + 64, SMALL_TOTAL = SMALL_RECS_AT + SMALL_RECS * sizeof(hsgpu_match_t);
+static_assert(SMALL_CORPUS_AT % 64 == 0 && SMALL_RECS_AT % 64 == 0, "aligned sections");
+
+/* one resident workgroup for this (scratch, table): its arguments are a solo scan's, with corpus, offsets, records and count
+ * in the scratch's mapped area. -> HSGPU_SUCCESS, 1: no server for this table / device (the caller launches), < 0: an error */
+static int server_start(const hsgpu_hwlm *t, hsgpu_scratch *s) {
+    const HsgpuTableHeader *h = t->hdr();
+    const void *f = hsgpu_server_kernel_for(h->flags);
+    if (!f || !s->d_small || !s->d_note) return 1;
+    const unsigned wg_threads = filter_wg_threads(h, s, nullptr);
+    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads) + 64; /* + the mailbox */
+    if (lds > s->lds_per_cu || (size_t)hsgpu_filter_words(h->flags, h->filter_log2) * 4 < 28 * 1024) return 1;
+    if (!s->h_srv) {
+        if (hipHostMalloc((void **)&s->h_srv, sizeof(HsgpuServerCtl), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&s->d_srv, s->h_srv, 0) != hipSuccess ||
+            hipStreamCreateWithFlags(&s->srv_stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            if (s->h_srv) (void)hipHostFree(s->h_srv);
+            s->h_srv = s->d_srv = nullptr;
+            return 1;
+        }
+        memset(s->h_srv, 0, sizeof(HsgpuServerCtl));
+    }
+    const uint8_t *d_blob = nullptr;
+    int rv = table_on_device(t, s->device, &d_blob);
+    if (rv != HSGPU_SUCCESS) return rv;
+    HsgpuScanArgs args;
+    memset(&args, 0, sizeof(args));
+    /* the batch is copied from the mapped area to device memory by the workgroup itself at the head of every request */
+    const uint32_t super_shift = wg_threads <= 256 ? 12 : wg_threads <= 512 ? 13 : 14;
+    if ((rv = s->corpus.ensure((1ull << super_shift) + 64)) != HSGPU_SUCCESS) return rv;
+    if ((rv = s->off.ensure((SMALL_BLOCKS + 1) * sizeof(uint64_t) + 64)) != HSGPU_SUCCESS) return rv;
+    args.corpus = (const uint8_t *)s->corpus.p;
+    args.off = (const uint64_t *)s->off.p;
+    args.blob = d_blob;
+    args.out = (hsgpu_match_t *)(s->d_small + SMALL_RECS_AT);
+    args.cap = SMALL_RECS;
+    args.count = (unsigned long long *)s->d_small;
+    table_args(h, args);
+    if ((rv = solo_setup(s, args, 1ull << super_shift, SMALL_RECS, 1, wg_threads, s->srv_stream)) != HSGPU_SUCCESS) return rv;
+    if ((rv = set_dyn_lds(f, lds)) != HSGPU_SUCCESS) return rv;
+    s->h_srv->stop = 0;
+    s->h_srv->exited = 0;
+    HsgpuServerCtl *ctl = s->d_srv;
+    unsigned long long idle_ticks = (unsigned long long)s->srv_idle_us * 100ull; /* the 100 MHz wall clock */
+    const void *src_corpus = s->d_small + SMALL_CORPUS_AT, *src_off = s->d_small + SMALL_OFF_AT;
+    void *kargs[] = {&args, &ctl, &idle_ticks, &src_corpus, &src_off};
+    HIP_TRY(hipLaunchKernel(f, dim3(1), dim3(wg_threads), kargs, lds, s->srv_stream));
+    s->srv_live = true;
+    s->srv_table = t;
+    s->srv_launches++;
+    return HSGPU_SUCCESS;
+}
+
+/* One request to the server; the batch is in the mapped area already (scan_host_small). -> 0: served (count and records are in
+ * the area), 1: not a batch for the server (or none to be had): the caller launches, < 0: an error */
+static int server_call(const hsgpu_hwlm *t, hsgpu_scratch *s, uint64_t total, size_t nblocks, size_t start) {
+    if (!s->srv_enabled || !total) return 1;
+    const HsgpuTableHeader *h = t->hdr();
+    const unsigned wg_threads = filter_wg_threads(h, s, nullptr);
+    const uint32_t super_shift = wg_threads <= 256 ? 12 : wg_threads <= 512 ? 13 : 14;
+    /* what ONE workgroup scans as a solo scan, under the conditions a solo scan has (launch_scan) */
+    if (total > (1ull << super_shift) || s->tune_fused || s->tune_unfolded || s->tune_solo == 1 || s->cand_div != 64 || (s->h_note && *s->h_note)) return 1;
+    if (s->srv_live && s->srv_table != t) server_stop(s);
+    if (s->srv_live && __atomic_load_n(&s->h_srv->exited, __ATOMIC_ACQUIRE)) { /* it went idle and ended */
+        (void)hipStreamSynchronize(s->srv_stream);
+        s->srv_live = false;
+    }
+    int rv;
+    if (!s->srv_live && (rv = server_start(t, s)) != HSGPU_SUCCESS) return rv;
+    HsgpuServerCtl *c = s->h_srv;
+    c->total = total, c->nblocks = nblocks, c->start = start;
+    const uint32_t seq = ++s->srv_seq;
+    __atomic_store_n(&c->req_seq, seq, __ATOMIC_RELEASE);
+    s->srv_calls++;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++) {
+        if (__atomic_load_n(&c->done_seq, __ATOMIC_ACQUIRE) == seq) return 0;
+        if (__atomic_load_n(&c->exited, __ATOMIC_ACQUIRE)) {
+            /* it ended (idle, as this request was being written) without having seen it: the next one starts from done_seq */
+            (void)hipStreamSynchronize(s->srv_stream);
+            s->srv_live = false;
+            if (__atomic_load_n(&c->done_seq, __ATOMIC_ACQUIRE) == seq) return 0;
+            if ((rv = server_start(t, s)) != HSGPU_SUCCESS) return rv;
+        }
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            hsgpu_set_error("the small-batch server did not answer request %u (done %u, exited %u)", seq, c->done_seq, c->exited);
+            server_stop(s);
+            return HSGPU_UNKNOWN_ERROR;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
 /* Small host batches (one packet per hwlmExec call is the reference's normal diet: src/rose/block.c:382-391,
  * tools/hsbench/engine_hyperscan.cpp:132-145): no copy commands at all. The batch is laid out in mapped pinned memory owned by
  * the scratch -- {count | offsets | corpus | records} -- and the scan kernel reads it over the bus and writes records and count
  * back into it: ONE kernel launch (a solo scan, launch_scan) and one stream synchronisation per call. Round 4: an H2D copy, a
  * synchronisation, a memset, three launches, a D2H of the count, a synchronisation and a blocking D2H of the records --
  * 68-72 us per 1 460-byte call. -> HSGPU_SUCCESS, or 1 when the batch does not fit this path (the caller takes the general one). */
-constexpr size_t SMALL_BYTES = 256 << 10, SMALL_BLOCKS = 4096, SMALL_RECS = 4096;
-constexpr size_t SMALL_OFF_AT = 64, SMALL_CORPUS_AT = SMALL_OFF_AT + (SMALL_BLOCKS + 1) * 8 + 56 /* -> a multiple of 64 */,
-                 SMALL_RECS_AT = SMALL_CORPUS_AT + SMALL_BYTES + 64, SMALL_TOTAL = SMALL_RECS_AT + SMALL_RECS * sizeof(hsgpu_match_t);
-static_assert(SMALL_CORPUS_AT % 64 == 0 && SMALL_RECS_AT % 64 == 0, "aligned sections");
 static int scan_host_small(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t *base, const uint64_t *off, size_t nblocks,
                            size_t start, std::vector<hsgpu_match_t> &recs) {
     const uint64_t lo = off[0], total = off[nblocks] - off[0];
@@ -990,7 +1162,18 @@ static int scan_host_small(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t 
     memset(s->h_small + SMALL_CORPUS_AT + total, 0, 16);
     *(volatile unsigned long long *)s->h_small = ~0ull;
     s->res_corpus = s->d_small + SMALL_CORPUS_AT, s->res_off = s->d_small + SMALL_OFF_AT;
-    int rv = hsgpu_hwlm_scan_dev(t, s, s->d_small + SMALL_CORPUS_AT, total, s->d_small + SMALL_OFF_AT, nblocks, start,
+    int rv = server_call(t, s, total, nblocks, start); /* the resident workgroup, when the scratch has one enabled and the batch is its size */
+    if (rv < 0) return rv;
+    if (rv == 0) {
+        const uint64_t n = *(volatile unsigned long long *)s->h_small;
+        if (n <= SMALL_RECS) {
+            recs.resize(n);
+            if (n) memcpy(recs.data(), s->h_small + SMALL_RECS_AT, n * sizeof(hsgpu_match_t));
+            return HSGPU_SUCCESS;
+        }
+        *(volatile unsigned long long *)s->h_small = ~0ull; /* more records than the area holds, or "again": the launch path decides */
+    }
+    rv = hsgpu_hwlm_scan_dev(t, s, s->d_small + SMALL_CORPUS_AT, total, s->d_small + SMALL_OFF_AT, nblocks, start,
                                  s->d_small + SMALL_RECS_AT, SMALL_RECS, s->d_small, s->stream);
     if (rv != HSGPU_SUCCESS) return rv;
     HIP_TRY(hipStreamSynchronize(s->stream));

@@ -1246,13 +1246,13 @@ __device__ __forceinline__ void write_block_hints_batch(const uint64_t *off, uin
 __device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *lds, uint32_t n_reg); /* below, behind sort_share */
 
 /* ---- phase 1: the streaming filter (FUSED: + in-kernel confirm) ----------- */
-template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
 #ifndef HSGPU_FILTER_MIN_WAVES
 #define HSGPU_FILTER_MIN_WAVES 1 /* tuning builds: 8 caps the kernel at 64 VGPRs so that two 16-wavefront workgroups fit a CU */
 #endif
-__global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filter_kernel(HsgpuScanArgs args) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
+/* The kernel's body as a function (round 6): hwlm_filter_kernel runs it once, hwlm_server_kernel -- a resident workgroup that
+ * serves small host batches without a launch per call -- once per request. Every `return` below ends one scan. */
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
+__device__ __forceinline__ void hwlm_filter_body(const HsgpuScanArgs &args, uint32_t *lds) {
     /* the fused kernel doubles as the overflow fallback: nothing to do unless the
      * two-phase pipeline ran out of candidate space */
     if (FUSED && args.cand_counts && !args.cand_counts[args.cand_waves]) {
@@ -1573,6 +1573,112 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
     }
 }
 
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
+__global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filter_kernel(HsgpuScanArgs args) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
+    hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, FUSED, PAIR, WIDE>(args, lds);
+}
+
+/* ---- the small-batch server (round 6) -----------------------------------------------------------------------------------
+ * hsbench block mode is one hs_scan per block (tools/hsbench/engine_hyperscan.cpp:132-145) and the reference serves a packet in
+ * about a microsecond (src/rose/block.c:382-391, src/runtime.c:401-413). A launch per call costs this engine ~25 us: the launch,
+ * the dispatch, a stream synchronisation that sleeps. The server is ONE workgroup that stays resident and polls a request word in
+ * mapped page-locked host memory: the host copies the batch (<= one 16 KiB super tile: what one workgroup scans) into the
+ * scratch's mapped area -- offsets | corpus, as for a solo scan --, writes the parameters and then the sequence number (release);
+ * the workgroup runs the solo scan's body (filter + confirm inline + placement by the one workgroup) with records and count
+ * going back to the same mapped area, fences at system scope and writes the done word, which the host spins on. No launch, no
+ * interrupt, no copy command.
+ *   idle        a server that has seen no request for idle_ticks of the 100 MHz wall clock says so (exited = 1) and ENDS: a
+ *               forgotten server cannot hold a CU (or a device synchronisation) for longer than that, and nothing can hang; the
+ *               host launches the next one when the next small call comes (runtime.hip, server_call)
+ *   stop        the host's way of ending it at once (hsgpu_scratch_free, a scan on the same scratch that needs the buffers)
+ * req / done are words of their own cache lines; the parameters are read AFTER the sequence number has been seen to change. */
+template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool PAIR = false, bool WIDE = false>
+__global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_server_kernel(HsgpuScanArgs args, HsgpuServerCtl *ctl,
+                                                                                            unsigned long long idle_ticks, const uint4 *src_corpus,
+                                                                                            const uint4 *src_off) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
+    /* the mailbox sits behind everything the body uses (runtime.hip sizes the launch: hsgpu_filter_lds_bytes + 64) */
+    const uint32_t words = (uint32_t)(hsgpu_filter_words(args.t_flags, args.t_filter_log2) + ((args.t_flags & HSGPU_F_HAS_C) ? 2048u : 0u)) +
+                           (uint32_t)((blockDim.x >> 6) * sizeof(WaveLds) / 4);
+    volatile uint32_t *mail = lds + words; /* [0] seq, [1] command (0 go, 1 end), [2..7] total, nblocks, start */
+    /* Everything around the barriers is WAVE-UNIFORM control flow (scalar branches on values made scalar with readfirstlane):
+     * wavefront 0 polls as a whole -- 64 lanes, one address, one request. (The first version polled in `if (threadIdx.x == 0)`,
+     * a thread-divergent loop in front of the barrier: the structurised code ran the loop's barriers a different number of times
+     * in wavefront 0 and in the others, and the workgroup hung one barrier apart.) */
+    const bool leader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t last = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    for (;;) {
+        if (leader) {
+            const unsigned long long t0 = wall_clock64();
+            uint32_t cmd = 0, seq = last;
+            for (;;) {
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) { /* first: nothing outranks it */
+                    cmd = 1;
+                    break;
+                }
+                seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+                if (seq != last) break;
+                if (wall_clock64() - t0 > idle_ticks) {
+                    cmd = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            uint32_t p[6] = {0, 0, 0, 0, 0, 0};
+            if (!cmd) { /* (the parameters were written before the sequence number: read after it) */
+                const unsigned long long tot = __hip_atomic_load(&ctl->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long nb = __hip_atomic_load(&ctl->nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long st = __hip_atomic_load(&ctl->start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                p[0] = (uint32_t)tot, p[1] = (uint32_t)(tot >> 32), p[2] = (uint32_t)nb, p[3] = (uint32_t)(nb >> 32), p[4] = (uint32_t)st, p[5] = (uint32_t)(st >> 32);
+            }
+            if (lane < 8) mail[lane] = lane == 0 ? seq : lane == 1 ? cmd : p[(lane - 2) % 6]; /* (every lane holds the same values) */
+        }
+        __syncthreads();
+        const uint32_t seq = __builtin_amdgcn_readfirstlane(mail[0]), cmd = __builtin_amdgcn_readfirstlane(mail[1]);
+        if (cmd) break;
+        HsgpuScanArgs a = args;
+        a.total = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mail[2]) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mail[3]) << 32;
+        a.nblocks = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mail[4]) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mail[5]) << 32;
+        a.start = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mail[6]) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mail[7]) << 32;
+        a.n_hint = (a.total >> HSGPU_HINT_SHIFT) + 1;
+        /* what the host wrote into the mapped area since the last request must not come out of this CU's caches */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const unsigned long long t_seen = wall_clock64();
+        /* The batch comes over the bus ONCE: offsets and corpus are copied from the mapped area into device memory by the whole
+         * workgroup (16 bytes per lane and pass, every request in flight at once), and the scan runs on the copy -- the block
+         * hints' two search rounds, the tiles and every match's offsets were a bus round trip each when read in place. */
+        if (src_corpus) {
+            const uint32_t n16 = (uint32_t)((a.total + 15) >> 4), o16 = (uint32_t)(((a.nblocks + 1) * 8 + 15) >> 4);
+            for (uint32_t i = threadIdx.x; i < n16 + o16; i += blockDim.x) {
+                if (i < n16) ((uint4 *)a.corpus)[i] = src_corpus[i];
+                else ((uint4 *)a.off)[i - n16] = src_off[i - n16];
+            }
+            __syncthreads(); /* (the same compute unit wrote it: the barrier's workgroup-scope release / acquire is enough) */
+        }
+        const unsigned long long t_copied = wall_clock64();
+        hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, true, PAIR, WIDE>(a, lds);
+        /* every wavefront: its records (and the count) out to host memory, at SYSTEM scope. (A workgroup-scope release in front of
+         * a relaxed done word was measured: the done word, another address and so another L2 channel, overtook the count -- the
+         * host read the count it had put there itself and sent every call down the launch path.) */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        if (leader) {
+            const unsigned long long t_end = wall_clock64();
+            if (lane == 0) { /* stamps of the request, 100 MHz ticks: copy, body (hsgpu_scratch_server_stats) */
+                __hip_atomic_store(&ctl->pad2[2], (uint32_t)(t_copied - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&ctl->pad2[3], (uint32_t)(t_end - t_copied), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(&ctl->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); /* (64 lanes, one word, one value) */
+        }
+        last = seq;
+    }
+    if (leader) __hip_atomic_store(&ctl->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* ---- phase 3 helpers: the records in delivery order -------------------------------------------
  * hwlmExec delivers callbacks in non-decreasing `end` (src/hwlm/hwlm.h:101-118) and Rose relies on it
  * (src/rose/match.c:396-476); a batch delivers block by block. The output of a scan is therefore sorted by
@@ -1731,16 +1837,22 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
 constexpr uint32_t SOLO_MAX_REGIONS = 1024;
 __device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *lds, uint32_t n_reg) {
     const uint32_t NT = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __syncthreads(); /* every wavefront of this workgroup has published (its stores have left for L2: the barrier's release) */
+    /* every wavefront releases what it staged and published at agent scope BEFORE the barrier (advisor, round 5: the barrier's own
+     * release is workgroup scope; that one thread's agent-scope ticket made the others' stores visible to another XCD too was a
+     * property of this compiler and this chip, not of the memory model) */
+    if (gridDim.x != 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads(); /* every wavefront of this workgroup has published */
     uint32_t *flagw = lds; /* [0] = last, [1] = total (low), [2] = total (high), [3] = flag, [4] = number of large regions, [5] = a region lost records */
     if (tid == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(args.solo_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        /* (one workgroup -- the small-batch server, a batch of one tile: it is the last by construction, and what it reads was
+         * written on this compute unit: no ticket, no agent-scope release / acquire, i.e. no write-back and no invalidation of L2) */
+        const uint32_t ticket = gridDim.x == 1 ? 0u : __hip_atomic_fetch_add(args.solo_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         flagw[0] = ticket == gridDim.x - 1;
         flagw[5] = 0;
     }
     __syncthreads();
     if (!flagw[0]) return; /* (uniform) */
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* every wavefront, before it reads what other workgroups wrote */
+    if (gridDim.x != 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* every wavefront, before it reads what other workgroups wrote */
     uint4 *buf = (uint4 *)(lds + 64);                       /* SORT_LDS records: 16 KiB */
     uint32_t *start = lds + 64 + SORT_LDS * 4;              /* [SOLO_MAX_REGIONS + 1] fills, then exclusive prefix */
     uint32_t *large = start + SOLO_MAX_REGIONS + 64;        /* regions of more than 64 records */

@@ -89,7 +89,19 @@ struct HsgpuScanArgs {
                                       * [worker][4]: start, fresh steps | rest steps << 16 | sorted drains << 32, entries, end */
 };
 
+/* the small-batch server's mailbox in mapped page-locked host memory (scan_device.h, hwlm_server_kernel; runtime.hip, server_call) */
+struct HsgpuServerCtl {
+    uint32_t req_seq, stop, pad0[14];             /* host -> device */
+    uint64_t total, nblocks, start, pad1[5];      /* ... the request (written before req_seq) */
+    uint32_t done_seq, exited, pad2[14];          /* device -> host */
+};
+
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
+/* the resident small-batch server with the fused kernel's body (scan_device.h, hwlm_server_kernel; nullptr: none for this table):
+ * launched with (HsgpuScanArgs, HsgpuServerCtl *, unsigned long long idle_ticks, const uint4 *src_corpus, const uint4 *src_off), ONE
+ * workgroup, hsgpu_filter_lds_bytes(fused) + 64 of LDS; src_*: where the host puts a request's batch (mapped memory) -- copied to
+ * args.corpus / args.off (device memory) at the head of every request */
+const void *hsgpu_server_kernel_for(uint32_t table_flags);
 const void *hsgpu_confirm_kernel_for(uint32_t table_flags, bool dense); /* dense: the folded pipeline's kernel for dense scans (fold == 2) */
 const void *hsgpu_hint_kernel(void);
 const void *hsgpu_record_sort_kernel(void);

@@ -16,6 +16,11 @@ const void *hsgpu_filter_kernels_r1f0k1(uint32_t flags);
 const void *hsgpu_filter_kernels_r1f1k0(uint32_t flags);
 const void *hsgpu_filter_kernels_r1f1k1(uint32_t flags);
 
+const void *hsgpu_server_kernels_r0f1k0(uint32_t flags); /* the small-batch server: the fused units */
+const void *hsgpu_server_kernels_r0f1k1(uint32_t flags);
+const void *hsgpu_server_kernels_r1f1k0(uint32_t flags);
+const void *hsgpu_server_kernels_r1f1k1(uint32_t flags);
+
 const void *hsgpu_pair_filter_kernel(uint32_t flags, bool fused); /* scan_inst_pair.hip */
 const void *hsgpu_pair_confirm_kernel(uint32_t flags);
 
@@ -26,6 +31,13 @@ const void *hsgpu_filter_kernel_for(uint32_t flags, bool fused) {
         {{hsgpu_filter_kernels_r0f0k0, hsgpu_filter_kernels_r0f0k1}, {hsgpu_filter_kernels_r0f1k0, hsgpu_filter_kernels_r0f1k1}},
         {{hsgpu_filter_kernels_r1f0k0, hsgpu_filter_kernels_r1f0k1}, {hsgpu_filter_kernels_r1f1k0, hsgpu_filter_kernels_r1f1k1}}};
     return tab[(flags & HSGPU_F_REPL) ? 1 : 0][fused ? 1 : 0][(flags & HSGPU_F_K2) ? 1 : 0](flags);
+}
+
+const void *hsgpu_server_kernel_for(uint32_t flags) {
+    if (flags & HSGPU_F_PAIR) return nullptr; /* (pair tables take the launch path) */
+    typedef const void *(*pick_t)(uint32_t);
+    static const pick_t tab[2][2] = {{hsgpu_server_kernels_r0f1k0, hsgpu_server_kernels_r0f1k1}, {hsgpu_server_kernels_r1f1k0, hsgpu_server_kernels_r1f1k1}};
+    return tab[(flags & HSGPU_F_REPL) ? 1 : 0][(flags & HSGPU_F_K2) ? 1 : 0](flags);
 }
 
 template <bool S2> static const void *pick_confirm(uint32_t flags) {

@@ -149,6 +149,27 @@ class Scratch:
         if env.get("HSGPU_MODE") or env.get("HSGPU_WG_THREADS") or env.get("HSGPU_WG_PER_CU"):
             self.set_tuning({"fused": 1, "unfolded": 2, "no_skew": 5}.get(env.get("HSGPU_MODE"), 0), int(env.get("HSGPU_WG_THREADS", "0")),
                             int(env.get("HSGPU_WG_PER_CU", "0")))
+        if env.get("HSGPU_MODE") == "server":  # every small host batch of the process through the resident workgroup (the parity suite, forced)
+            self.enable_server(True)
+
+    def enable_server(self, on=True, idle_us=0):
+        """the small-batch server (include/hsgpu.h, hsgpu_scratch_enable_server): hwlm_exec / hwlm_exec_batch calls of up to
+        16 KiB are served by one resident workgroup instead of a kernel launch per call"""
+        f = self._lib.hsgpu_scratch_enable_server
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+        rv = f(self._h, int(bool(on)), int(idle_us))
+        if rv != 0:
+            raise HsgpuError(rv, "hsgpu_scratch_enable_server")
+
+    def server_stats(self):
+        """(requests served, server launches, resident right now)"""
+        f = self._lib.hsgpu_scratch_server_stats
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        c, l, v = C.c_uint64(), C.c_uint64(), C.c_int()
+        f(self._h, C.byref(c), C.byref(l), C.byref(v))
+        return int(c.value), int(l.value), bool(v.value)
 
     def set_tuning(self, fused_only=False, wg_threads=0, wg_per_cu=0):
         self._lib.hsgpu_scratch_set_tuning.restype = C.c_int

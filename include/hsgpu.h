@@ -124,6 +124,20 @@ int hsgpu_hwlm_deserialize(const void *buf, size_t len, hsgpu_hwlm_t **out);
 int hsgpu_scratch_alloc(hsgpu_scratch_t **out, int device);
 void hsgpu_scratch_free(hsgpu_scratch_t *s);
 
+/* The small-batch server. hsbench block mode is ONE hs_scan per block (tools/hsbench/engine_hyperscan.cpp:132-145) and the
+ * reference serves a packet in about a microsecond from dedicated small matchers (src/rose/block.c:382-391,
+ * src/runtime.c:401-413); a kernel launch per call costs this engine ~25 us. With the server enabled, hsgpu_hwlm_exec /
+ * hsgpu_hwlm_exec_batch (and hs_scan through them) hand batches of up to 16 KiB to ONE resident workgroup that polls a request
+ * word in mapped page-locked memory: no launch, no copy command, no sleeping synchronisation. The workgroup ends by itself after
+ * idle_us (default 300) without a request -- it holds a compute unit no longer than that after a burst of calls, and a device
+ * synchronisation never waits longer for it -- and is started again by the next small call; any other scan on the scratch,
+ * hsgpu_scratch_free and disabling end it at once. Off by default. hsgpu_scratch_server_stats: requests served, server
+ * launches, whether one is resident right now (any pointer may be NULL). */
+int hsgpu_scratch_enable_server(hsgpu_scratch_t *s, int enable, unsigned idle_us /* 0: keep */);
+int hsgpu_scratch_server_stats(hsgpu_scratch_t *s, uint64_t *calls, uint64_t *launches, int *live);
+/* the last request's device-side times: the batch's copy over the bus, the scan itself (device wall clock, microseconds) */
+int hsgpu_scratch_server_last_us(hsgpu_scratch_t *s, float *copy_us, float *scan_us);
+
 /* hwlmExec (src/hwlm/hwlm.h:116-118, src/hwlm/hwlm.c:172-199), argument for argument: scan one host
  * block, deliver callbacks in non-decreasing `end` on the calling thread, honouring the group
  * mask returned by the callback, noruns and termination. Returns HSGPU_HWLM_*. The callback's

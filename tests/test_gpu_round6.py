@@ -111,3 +111,75 @@ def test_hs_scan_batch_resident_equals_hs_scan_batch():
             assert lib.hs_scan_batch_resident(db._h, corpus.ctypes.data, offs.ctypes.data, offs.size - 1, d_corpus.data_ptr(), d_off.data_ptr(),
                                               sc._h, cb_b, None) == 0
             assert a == b and len(a) > 100, (total, len(a), len(b))
+
+
+def test_small_batch_server_parity_lifetime_and_fallbacks():
+    """The small-batch server (include/hsgpu.h, hsgpu_scratch_enable_server; scan_device.h, hwlm_server_kernel): hwlm_exec and
+    hwlm_exec_batch calls of up to 16 KiB served by ONE resident workgroup -- the same records as the launch path and as the
+    oracle at every size up to its limit and beyond it (where the call falls back to a launch), over several table layouts; it
+    ends by itself when idle and comes back with the next call; another table, another pipeline, a large scan on the same scratch
+    and hsgpu_scratch_free all end it first."""
+    import time
+
+    from hyperscan_amd import corpus as cp
+    from tests import oracle_binding as ob
+    from tests.util import as_set, random_blocks
+
+    rng = np.random.default_rng(66)
+    sets = {"teddy64": (random_literals(rng, 64, 4, 8, nocase_frac=0.2), 0), "mixed3000": (random_literals(rng, 3000, 1, 8, nocase_frac=0.3), 0),
+            "fdr10k": (cp.snort_like_literals(10000, seed=4)[0], 0), "one": ([H.HwlmLiteral(b"needle", nocase=True, id=7)], 0)}
+    s = H.Scratch(0)
+    s.enable_server(True, idle_us=2000)
+    plain = H.Scratch(0)
+    served_before = 0
+    for name, (lits, flags) in sets.items():
+        t = H.hwlm_build(lits, flags)
+        oracle = ob.Oracle(lits)
+        for total in [1, 2, 7, 16, 17, 100, 1023, 1024, 1025, 1460, 4096, 8191, 8192, 8193, 16383, 16384, 16385, 20000, 70000]:
+            corpus = random_corpus(rng, total, lits, plant_every=97)
+            got = []
+            assert H.hwlm_exec(t, corpus, 0, lambda e, i, c: got.append((e, i)) or H.HWLM_CONTINUE_MATCHING, s) == H.HWLM_SUCCESS
+            assert sorted(got) == sorted(oracle.collect(corpus)), (name, total)
+            got2 = []
+            assert H.hwlm_exec(t, corpus, 3 if total > 3 else 0, lambda e, i, c: got2.append((e, i)) or H.HWLM_CONTINUE_MATCHING, s) == H.HWLM_SUCCESS
+            assert sorted(got2) == sorted(oracle.collect(corpus, 3 if total > 3 else 0)), (name, total, "start")
+            off = random_blocks(rng, total, mean_len=max(2, min(300, total // 3 + 1)))
+            assert as_set(hw.hwlm_exec_batch(t, s, corpus, off)) == as_set(oracle.collect_blocks(corpus, off)) == as_set(hw.hwlm_exec_batch(t, plain, corpus, off))
+        calls, launches, live = s.server_stats()
+        if name != "mixed3000":  # (a table with 1- and 2-byte literals fills the LDS to the last byte: no room for the server's mailbox, its calls are launches)
+            assert calls - served_before >= 30, (name, calls)
+        served_before = calls
+        t.close()  # (the next table: the server of this one is ended first)
+    calls, launches, live = s.server_stats()
+    assert launches <= 4 * len(sets), f"{launches} server launches for {calls} calls: it should stay resident across a burst"
+    # idle: it ends by itself, and the next call brings it back
+    lits, _ = sets["teddy64"]
+    t = H.hwlm_build(lits)
+    pkt = random_corpus(rng, 1460, lits, plant_every=97)
+    want = sorted(ob.Oracle(lits).collect(pkt))
+
+    def once():
+        g = []
+        assert H.hwlm_exec(t, pkt, 0, lambda e, i, c: g.append((e, i)) or H.HWLM_CONTINUE_MATCHING, s) == H.HWLM_SUCCESS
+        assert sorted(g) == want
+    once()
+    assert s.server_stats()[2]
+    time.sleep(0.05)
+    l0 = s.server_stats()
+    assert not l0[2], "the server did not end after its idle time"
+    once()
+    assert s.server_stats()[1] == l0[1] + 1 and s.server_stats()[2]
+    # a large scan on the same scratch (its buffers are the server's): the server is ended first, and comes back afterwards
+    big = random_corpus(rng, 3 << 20, lits, plant_every=500)
+    one = np.array([0, big.size], dtype=np.uint64)
+    assert as_set(hw.hwlm_exec_batch(t, s, big, one)) == as_set(ob.Oracle(lits).collect_blocks(big, one))
+    assert not s.server_stats()[2]
+    once()
+    # another pipeline
+    s.set_tuning(1)
+    once()
+    s.set_tuning(0)
+    once()
+    assert s.server_stats()[2]
+    s.close()  # with the server resident
+    plain.close()

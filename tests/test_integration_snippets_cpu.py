@@ -53,6 +53,8 @@ extern uint32_t start;
 extern const hsgpu_lit_t *glits;
 extern size_t n_glits;
 extern const hsgpu_class_seq_t *seqs;
+extern hs_database_t *db;
+extern hs_scratch_t *hs_scratch_of_this_thread;
 """
 
 
