@@ -454,9 +454,9 @@ def smi_snapshot():
         out = {}
         for k, v in card.items():
             kl = k.lower()
-            if "sclk" in kl and "level" in kl:
+            if "sclk" in kl and "speed" in kl:
                 out["sclk"] = v
-            elif "mclk" in kl and "level" in kl:
+            elif "mclk" in kl and "speed" in kl:
                 out["mclk"] = v
             elif "power" in kl and ("socket" in kl or "average" in kl or "current" in kl) and "power_W" not in out:
                 out["power_W"] = v

@@ -235,6 +235,20 @@ def scan_batch(db, data, off, scratch, on_event=None):
     return _lib().hs_scan_batch(db._h, buf.ctypes.data, off.ctypes.data, off.size - 1, 0, scratch._h, cb, None)
 
 
+def scan_batch_resident(db, data, off, d_corpus_ptr, d_off_ptr, scratch, on_event=None):
+    """hs_scan_batch_resident (include/hs_gpu.h): the batch is already on the device (raw device pointers to the same bytes and
+    offsets, as hsgpu_hwlm_scan_dev takes them); `data` / `off` are its host copy, which the confirm reads the bytes behind every
+    literal hit from. Only the hits cross the bus."""
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    cb = BATCH_CB(lambda b, i, f, t, _fl, _c: 1 if (on_event and on_event(b, i, f, t)) else 0)
+    lib = _lib()
+    lib.hs_scan_batch_resident.restype = C.c_int
+    lib.hs_scan_batch_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p, BATCH_CB,
+                                           C.c_void_p]
+    return lib.hs_scan_batch_resident(db._h, buf.ctypes.data, off.ctypes.data, off.size - 1, d_corpus_ptr, d_off_ptr, scratch._h, cb, None)
+
+
 def expression_info(expr, flags=0, ext=None):
     """hs_expression_ext_info -> (min_width, max_width)"""
     lib = _lib()

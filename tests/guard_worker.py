@@ -228,6 +228,15 @@ def case_host_entry():
             assert as_set(hw.hwlm_exec_batch(table, scratch, corpus, off)) == want
             assert as_set(hw.hwlm_exec_batch_pipelined(table, scratch, corpus, off, chunk_bytes=1 << 16)) == want
             scratch.close()
+            if total <= 16385:  # the small-batch server: its staging copy of the batch, hints, regions and control block in guard ranges too
+                srv = H.Scratch(0)
+                srv.enable_server(True)
+                for rep in range(2):
+                    got = []
+                    rv = H.hwlm_exec(table, corpus, 0, lambda e, i, c: got.append((e, i)) or H.HWLM_CONTINUE_MATCHING, srv)
+                    assert rv == H.HWLM_SUCCESS and sorted(got) == sorted(oracle.collect(corpus)), (name, total, "server")
+                    assert as_set(hw.hwlm_exec_batch(table, srv, corpus, off)) == want
+                srv.close()
         table.close()
 
 
