@@ -2255,6 +2255,13 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
              * the queue doubles it (flood: 64 positions, two matches each). (Dense mode used to mean record_sort_kernel: 10.4 ms for
              * the bench's 33.5 M flood records, profiles/r04_flood.txt.) */
             uint32_t dq = DENSE_POS, dP = 32, dense_base = 0, dm[2] = {0, 0}; /* the batch's next position, positions per step */
+            /* The reference's flood case proper (src/fdr/flood_runtime.h:86-335: one confirm replayed along a run of equal bytes). A
+             * dense batch whose chunks are consecutive, all made of ONE byte value (halo included), inside one block and clear of
+             * its start has the same eight-byte window at every one of its positions: position 0 is confirmed and drained the
+             * ordinary way (uni: dP = 1), and the records of the batch's other positions are the same records with `end` counted
+             * on -- written straight behind them, position-major, which IS delivery order (run_replicate below). */
+            bool uni = false;
+            uint32_t uni_f = 0, uni_pos = 0, dP_saved = 32;
             for (;;) {
 #if HSGPU_CONFIRM_ROTPRIO
                 switch ((prio_rank + prio_step++) & 3u) { /* (the argument of s_setprio is an immediate) */
@@ -2298,6 +2305,35 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                                 continue;
                             }
                             dm[0] = m0, dm[1] = m1, dense_base = base, dq = 0;
+                            if (DENSE && !PAIR && fold) { /* a run of one byte value? (all loads and tests wave-uniform in their outcome) */
+                                const uint4 *re = (const uint4 *)region;
+                                const uint4 z = make_uint4(0, 0, 0, 0);
+                                const uint4 a0 = i0 < end ? re[2ull * i0] : z, b0 = i0 < end ? re[2ull * i0 + 1] : z;
+                                const uint4 a1 = i1 < end ? re[2ull * i1] : z, b1 = i1 < end ? re[2ull * i1 + 1] : z;
+                                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a0.x), vv = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0.x);
+                                constexpr uint32_t ALL = S2 ? 0x5555u : 0xffffu; /* every lookup position of the chunk (stride 2: the even ones) a candidate */
+                                const bool ok0 = i0 >= end || (a0.x == c0 + lane && ((a0.y | a0.y >> 16) & 0xffffu) == ALL && a0.z == vv && a0.w == vv &&
+                                                               b0.x == vv && b0.y == vv && b0.z == vv && b0.w == vv);
+                                const bool ok1 = i1 >= end || (a1.x == c0 + 64u + lane && ((a1.y | a1.y >> 16) & 0xffffu) == ALL && a1.z == vv && a1.w == vv &&
+                                                               b1.x == vv && b1.y == vv && b1.z == vv && b1.w == vv);
+                                if ((vv & 0xffu) * 0x01010101u == vv && __ballot(!(ok0 && ok1)) == 0) {
+                                    const uint32_t ne = min(128u, end - base);
+                                    const uint64_t g0 = (uint64_t)c0 * CHUNK, g_last = g0 + (uint64_t)ne * CHUNK - 1;
+                                    if (!(t.cb_end && g0 >= t.cb_start && g0 < t.cb_end)) { /* the block of the run's first byte (every lane the same lookup) */
+                                        uint64_t bs;
+                                        const uint64_t b = block_of(t, g0, bs);
+                                        t.cb = rfl64(b), t.cb_start = rfl64(bs), t.cb_end = rfl64(t.off[min(b + 1, t.nblocks)]);
+                                    }
+                                    /* every window inside the block, every literal (<= 8 bytes) clear of `start` */
+                                    if (g0 >= t.cb_start && g_last < t.cb_end && g0 - t.cb_start >= 7 + t.start) {
+                                        uni = true;
+                                        uni_f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
+                                        uni_pos = ne * CHUNK;
+                                        dP_saved = dP;
+                                        dP = 1;
+                                    }
+                                }
+                            }
                             base += stride;
                             continue;
                         }
@@ -2352,6 +2388,35 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                     drain_matches_sorted<DENSE && !PAIR>(t, lane);
                     syncing = false;
                     HSGPU_ST(st_drains++;)
+                    if (DENSE && !PAIR && uni) {
+                        /* position 0 of a run has been confirmed and its records are in the region: the run's other positions.
+                         * (More than 64 literals on one window, or a wavefront that has already emitted out of order: the ordinary way.) */
+                        const uint32_t f1 = __builtin_amdgcn_readfirstlane(t.wl->nfront), nm = f1 - uni_f;
+                        const uint32_t ooo = __builtin_amdgcn_readfirstlane(t.wl->pad[0]);
+                        uni = false;
+                        dP = dP_saved;
+                        if (nm <= 64 && !ooo && dq >= 1) {
+                            /* (stride 2: lookup 0 reported the ends g0 and g0 + 1; every later lookup of the run the same pair, two further on) */
+                            constexpr uint32_t STEP = S2 ? 2u : 1u;
+                            const uint32_t total_new = (uni_pos / STEP - 1) * nm;
+                            if (nm) {
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* (the drain's stores, read back below) */
+                                const bool have = lane < nm && uni_f + lane < t.rec_cap;
+                                const uint4 br = have ? t.rec_region[uni_f + lane] : make_uint4(0, 0, 0, 0); /* lane r: record r of position 0 */
+                                const uint32_t inv = nm > 1 ? (uint32_t)(((1ull << 32) + nm - 1) / nm) : 0u; /* i / nm = mulhi(i, inv) for i * nm < 2^32 (nm = 1: 2^32 does not fit) */
+                                for (uint32_t i0r = 0; i0r < total_new; i0r += 64) { /* whole wavefronts: the shuffles read every lane */
+                                    const uint32_t i = i0r + lane, q = nm > 1 ? __umulhi(i, inv) : i, r = (i - q * nm) & 63u;
+                                    uint4 rec;
+                                    rec.x = (uint32_t)__shfl((int)br.x, (int)r), rec.y = (uint32_t)__shfl((int)br.y, (int)r) + STEP * (q + 1u);
+                                    rec.z = (uint32_t)__shfl((int)br.z, (int)r), rec.w = (uint32_t)__shfl((int)br.w, (int)r);
+                                    const uint64_t at = (uint64_t)f1 + i;
+                                    if (i < total_new && at < t.rec_cap) t.rec_region[at] = rec;
+                                }
+                                if (lane == 0) t.wl->nfront = f1 + total_new; /* (keeps counting past the capacity: the total stays exact) */
+                            }
+                            dq = DENSE_POS; /* the batch is done */
+                        }
+                    }
                     if (base >= end && dq >= DENSE_POS) break;
                     continue;
                 } else {

@@ -3,5 +3,4 @@
 #define HSGPU_INST_FUSED true
 #define HSGPU_INST_K2 false
 #define HSGPU_INST_NAME hsgpu_filter_kernels_r0f1k0
-#define HSGPU_INST_NAME_SRV hsgpu_server_kernels_r0f1k0
 #include "scan_inst.inc"

@@ -3,5 +3,4 @@
 #define HSGPU_INST_FUSED true
 #define HSGPU_INST_K2 true
 #define HSGPU_INST_NAME hsgpu_filter_kernels_r1f1k1
-#define HSGPU_INST_NAME_SRV hsgpu_server_kernels_r1f1k1
 #include "scan_inst.inc"

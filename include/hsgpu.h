@@ -164,7 +164,7 @@ int hsgpu_hwlm_exec_resident(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const vo
 /* Device-resident form (the hot path): corpus, offsets, records and counter all
  * live in HBM; asynchronous on `stream` (a hipStream_t passed as void*, NULL =
  * the scratch's own stream); no host synchronisation. d_off holds nblocks+1
- * ascending uint64 offsets with d_off[nblocks] == total_bytes. The records arrive in delivery
+ * ascending uint64 offsets with d_off[0] == 0 and d_off[nblocks] == total_bytes. The records arrive in delivery
  * order, sorted by (block, end, lit) -- hwlmExec's non-decreasing `end` (src/hwlm/hwlm.h:101-118),
  * block by block -- and *d_count receives the TOTAL number of matches. *d_count > cap means the
  * buffer was too small and nothing is delivered (what the buffer then holds is unspecified: the shares of the corpus that

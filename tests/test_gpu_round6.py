@@ -183,3 +183,51 @@ def test_small_batch_server_parity_lifetime_and_fallbacks():
     assert s.server_stats()[2]
     s.close()  # with the server resident
     plain.close()
+
+
+@pytest.mark.parametrize("short", [False, True])
+@pytest.mark.parametrize("start", [0, 5])
+def test_flood_runs_replicated_from_one_confirm(short, start):
+    """The dense kernel's run shortcut (scan_device.h, `uni`; the reference: src/fdr/flood_runtime.h:86-335): a batch of chunks
+    that are all one byte value, inside one block, is confirmed at ONE position and its other positions' records are written from
+    that one. Runs of several byte values and lengths, blocks cut inside runs at odd offsets (the shortcut must stop short of a
+    block's first bytes), literals that match only at a run's head (`xaaaa`), several literals per window, `start` > 0, stride-1
+    tables (a 3-byte literal in the set) and stride-2 ones: every record against the oracle, in delivery order."""
+    from tests import oracle_binding as ob
+    from tests.util import as_set
+
+    rng = np.random.default_rng(7 + short)
+    lits = []
+    for c in b"abz":
+        lits += [H.HwlmLiteral(bytes([c]) * 4, id=len(lits)), H.HwlmLiteral(bytes([c]) * 8, id=len(lits) + 1),
+                 H.HwlmLiteral(b"x" + bytes([c]) * 4, id=len(lits) + 2), H.HwlmLiteral(bytes([c]) * 5, nocase=True, id=len(lits) + 3)]
+    if short:
+        lits += [H.HwlmLiteral(b"aaa", id=len(lits)), H.HwlmLiteral(b"zz", id=len(lits) + 1)]
+    lits += [H.HwlmLiteral(l.s, nocase=l.nocase, id=len(lits) + i) for i, l in enumerate(random_literals(rng, 60, 4, 8))]
+    total = 3 << 20
+    corpus = random_corpus(rng, total, lits, plant_every=3000)
+    cuts = {0, total}
+    pos = 1000
+    for k in range(40):  # runs of 3 KiB .. 200 KiB of one value, some preceded by an 'x', with quiet stretches between them
+        ln = int(rng.integers(3 << 10, 200 << 10))
+        if pos + ln + 5000 > total:
+            break
+        v = b"abzAq"[k % 5]
+        corpus[pos:pos + ln] = v
+        if k % 3 == 0:
+            corpus[pos - 1] = ord("x")
+        for _ in range(int(rng.integers(0, 4))):  # block cuts inside the run, at any offset
+            cuts.add(pos + int(rng.integers(1, ln)))
+        cuts.add(pos + int(rng.integers(-20, 20)))
+        pos += ln + int(rng.integers(100, 30000))
+    off = np.array(sorted(cuts), dtype=np.uint64)
+    t = H.hwlm_build(lits)
+    s = H.Scratch(0)
+    want = ob.Oracle(lits).collect_blocks(corpus, off, start=start)
+    for rep in range(3):  # the first scan says "again" and the scratch goes dense; the following ones run dense
+        got = hw.hwlm_exec_batch(t, s, corpus, off, start=start)
+        assert len(got) == len(want), (rep, len(got), len(want))
+        assert as_set(got) == as_set(want), rep
+        key = (got["block"].astype(np.uint64) << np.uint64(32)) | got["end"].astype(np.uint64)
+        assert np.all((key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (got["lit"][1:] > got["lit"][:-1]))), "delivery order"
+    s.close()
