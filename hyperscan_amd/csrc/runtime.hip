@@ -150,7 +150,7 @@ struct hsgpu_scratch {
     DevBuf conf_stamps;
     unsigned conf_stamps_n = 0; /* confirm workers of the last stamped scan */
     double wall_clock_khz = 100000.0;
-    DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats;
+    DevBuf corpus, off, out, count, hint, cand, ctl, rec_stage, stats, run_tab;
     DevBuf pipe_corpus[2], pipe_off[2], pipe_out[2], pipe_count; /* hsgpu_hwlm_exec_batch_cb: two chunks in flight */
     hipEvent_t ev_copied[2] = {}, ev_scanned[2] = {};
     /* ... its page-locked staging: the chunk's relative offsets on their way in, its records on their way out. (Round 4 copied
@@ -167,7 +167,7 @@ struct hsgpu_scratch {
     unsigned long long stats_seen[2] = {0, 0};
     unsigned long long *h_count = nullptr; /* pinned */
     uint32_t *h_note = nullptr, *d_note = nullptr; /* mapped pinned word the fused fallback sets (see HsgpuScanArgs::overflow_note) */
-    bool tune_no_skew = false;             /* ... 5: equal halves of the shares for the confirm kernel's workers (A/B of conf_skew) */
+    bool tune_no_skew = false;             /* ... 5: equal halves of the shares for the confirm kernel's workers (A/B of conf_skew); dense scans: no run tables (A/B) */
     int tune_fused = 0;                    /* hsgpu_scratch_set_tuning (tests / tuning runs) */
     int tune_solo = 0;                     /* fused_only == 3: never the single-launch path for small batches; 4: whenever the geometry allows */
     DevBuf solo_ctl;                       /* solo scans: rec_counts | rec_super | ticket, left zeroed by the scan itself */
@@ -295,6 +295,7 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     s->wg_stamps.release();
     s->conf_stamps.release();
     s->rec_stage.release();
+    s->run_tab.release();
     s->solo_ctl.release();
     for (int i = 0; i < 2; i++) {
         s->pipe_corpus[i].release();
@@ -547,6 +548,7 @@ static int solo_setup(hsgpu_scratch *s, HsgpuScanArgs &args, uint64_t total, uin
     args.fold = 0;
     args.conf_q = args.conf_k = 1;
     args.conf_spread = 0, args.conf_skew = 0;
+    args.run_tab = nullptr;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     args.cand = nullptr;
     args.cand_cap = 0;
@@ -752,6 +754,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     unsigned conf_grid = 0;
     args.conf_q = args.conf_k = 1;
     args.conf_spread = 0, args.conf_skew = 0;
+    args.run_tab = nullptr;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     if (two_phase) {
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
@@ -787,6 +790,11 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
                 n_rec = (uint32_t)parts;
                 args.conf_q = q, args.conf_k = k;
                 args.conf_spread = 1;
+                /* the run tables (hwlm_confirm_kernel: a run of one byte value costs one confirm and a descriptor) */
+                if (!s->tune_no_skew) { /* (hsgpu_scratch_set_tuning(s, 5, ..): every record staged, the A/B) */
+                    if ((rv = s->run_tab.ensure(parts * HSGPU_RUN_STRIDE * sizeof(uint4))) != HSGPU_SUCCESS) return rv;
+                    args.run_tab = (uint4 *)s->run_tab.p;
+                }
             }
         }
         if (!s->d_note) n_rec = std::max(n_rec, n_waves); /* (the fused kernel behind the confirm kernel writes one region per filter wavefront) */

@@ -104,8 +104,12 @@ struct WaveLds {
     uint32_t nback;  /* records spilled to the back of the region (staging full mid-drain) */
     uint32_t nmq;    /* confirm kernel: queued matches (in cand[]) */
     uint32_t nrq;    /* confirm kernel: queued entries with candidate bits left */
-    uint32_t pad[11];
+    uint32_t pad[11]; /* [0] confirm kernel: a match was resolved in place (emitted out of order); dense scans with run tables (RUN_*):
+                       * [1] records of the current region that exist only as run descriptors, [2] the region's runs, [3..5] the last
+                       * run's first record / records per lookup / further lookups, [6..7] the corpus offset where it would go on,
+                       * [8] its byte value (x 0x01010101), [9] its block, [10] 1 = [3..9] describe a run that may go on */
 };
+constexpr int RUN_VIRT = 1, RUN_N = 2, RUN_PB = 3, RUN_NM = 4, RUN_REPS = 5, RUN_NEXT = 6, RUN_VV = 8, RUN_BLOCK = 9, RUN_LIVE = 10;
 static_assert(sizeof(WaveLds) == 1536, "per-wave LDS area is 1.5 KiB: 128 KiB filter + 8 KiB + 16 x 1.5 KiB = 160 KiB");
 
 __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { return __umul24(a, b); }
@@ -317,6 +321,9 @@ __device__ __forceinline__ void flush_records(const Tables &t, uint32_t lane, ui
  * to_supers: the pipeline with a sort kernel of its own (fused scans, dense mode) -- the fills of 2^super_shift consecutive
  * regions are added up here, one atomic per region, so that every sort workgroup can place its share without a scan
  * kernel in between. The folded pipeline (hwlm_confirm_kernel) adds up per SHARE instead, after its workgroup barrier. */
+/* RUNS (dense scans with run tables, args.run_tab): the region's count includes the records that exist only as run descriptors
+ * (pad[RUN_VIRT]); its run table's head is written here. */
+template <bool RUNS = false>
 __device__ __forceinline__ uint32_t publish_records(const Tables &t, const HsgpuScanArgs &args, uint32_t lane,
                                                     uint32_t region, bool to_supers = true) {
     flush_records(t, lane, 1);
@@ -324,11 +331,13 @@ __device__ __forceinline__ uint32_t publish_records(const Tables &t, const Hsgpu
     if (lane == 0) {
         const uint32_t front = t.wl->nfront,
                        back = __hip_atomic_load(&t.wl->nback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        args.rec_counts[2 * region] = front;
+        const uint32_t virt = RUNS ? t.wl->pad[RUN_VIRT] : 0u;
+        args.rec_counts[2 * region] = front + virt;
         args.rec_counts[2 * region + 1] = back;
-        const unsigned long long fill = (unsigned long long)front + back;
+        if (RUNS) args.run_tab[(uint64_t)region * HSGPU_RUN_STRIDE] = make_uint4(t.wl->pad[RUN_N], 0, 0, 0);
+        const unsigned long long staged = (unsigned long long)front + back, fill = staged + virt;
         if (to_supers && fill) atomicAdd(&args.rec_super[HSGPU_SUPER(region >> args.super_shift)], fill);
-        if (fill > args.rec_cap) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull); /* the region lost records */
+        if (staged > args.rec_cap) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull); /* the region lost records */
         fill32 = (uint32_t)min(fill, 0x7fffffffull);
     }
     return __builtin_amdgcn_readfirstlane(fill32);
@@ -1185,6 +1194,9 @@ __device__ __forceinline__ void init_wave_lds(Tables &t, WaveLds *wl, uint32_t l
         wl->nmq = z;
         wl->nrq = z;
         wl->pad[0] = z; /* "resolved a match in place" (push_match) */
+        wl->pad[RUN_VIRT] = z;
+        wl->pad[RUN_N] = z;
+        wl->pad[RUN_LIVE] = z;
     }
 }
 
@@ -1739,7 +1751,10 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
      * start inside the share */
     const uint32_t nreg = last - first; /* <= 64 */
     const uint2 my = lane < nreg ? counts[first + lane] : make_uint2(0, 0);
-    if (__ballot((unsigned long long)my.x + my.y > args.rec_cap)) return; /* (every wavefront holds the same fills: uniform) */
+    /* dense scans with run tables: a region's count includes the records its run descriptors stand for (they never fit; a region
+     * that lost staged records has raised the scan's flag, and nobody gets here) */
+    const bool runs = args.fold && args.run_tab != nullptr;
+    if (!runs && __ballot((unsigned long long)my.x + my.y > args.rec_cap)) return; /* (every wavefront holds the same fills: uniform) */
     uint32_t incl = my.x + my.y;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1759,9 +1774,33 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
         const uint32_t f = __shfl(my.x, r), at = __shfl(my_at, r), j = i - at;
         if (i < n) {
             const uint4 *region = args.rec_stage + (uint64_t)(first + r) * args.rec_cap;
-            const uint4 rec = j < f ? region[j] : region[args.rec_cap - 1 - (j - f)];
-            if (in_lds) buf[i] = rec;
-            else out[base + i] = rec;
+            if (runs) {
+                /* record j of the region: staged at j less the records that the runs in front of it stand for -- or one of those: the
+                 * run's lookup 0 has the record, `end` moves on by the run's step per lookup (position-major: delivery order) */
+                const uint4 *rt = args.run_tab + (uint64_t)(first + r) * HSGPU_RUN_STRIDE;
+                const uint32_t nr = min(rt[0].x, (uint32_t)HSGPU_RUN_MAX);
+                uint32_t at_staged = j, skipped = 0, add = 0;
+                for (uint32_t k = 1; k <= nr; k++) {
+                    const uint4 d = rt[k]; /* {first record, records per lookup, further lookups, step} */
+                    const uint32_t ls = d.x + skipped + d.y; /* the first record of the region that is not staged */
+                    if (j < ls) break;
+                    const uint32_t span = d.y * d.z, v = j - ls;
+                    if (v < span) {
+                        const uint32_t qv = v / d.y;
+                        at_staged = d.x + (v - qv * d.y) + skipped; /* (skipped comes off below) */
+                        add = d.w * (qv + 1u);
+                        break;
+                    }
+                    skipped += span;
+                }
+                uint4 rec = region[min(at_staged - skipped, args.rec_cap - 1u)];
+                rec.y += add;
+                out[base + i] = rec;
+            } else {
+                const uint4 rec = j < f ? region[j] : region[args.rec_cap - 1 - (j - f)];
+                if (in_lds) buf[i] = rec;
+                else out[base + i] = rec;
+            }
         }
     }
     if (args.fold) return; /* (uniform) */
@@ -2183,6 +2222,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
      * nothing here (on ordinary input every part end is a sync point: the 10 000-literal stage is 20 % slower with four parts
      * per worker than with one). */
     const bool spread = DENSE && !PAIR && args.conf_spread;
+    const bool runs = spread && args.run_tab != nullptr; /* a run of one byte value: one confirm and a descriptor (below) */
     const uint32_t n_workers = gridDim.x * W;
     /* Ordinary scans with one part per worker and two parts per share (args.conf_skew, runtime.hip: the headline's geometry): the
      * instruction arbiter prefers the oldest wavefront of a SIMD and the resident workgroups reach a CU in index order, so with
@@ -2326,11 +2366,39 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                                     }
                                     /* every window inside the block, every literal (<= 8 bytes) clear of `start` */
                                     if (g0 >= t.cb_start && g_last < t.cb_end && g0 - t.cb_start >= 7 + t.start) {
-                                        uni = true;
-                                        uni_f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
-                                        uni_pos = ne * CHUNK;
-                                        dP_saved = dP;
-                                        dP = 1;
+                                        const uint32_t f0 = __builtin_amdgcn_readfirstlane(t.wl->nfront);
+                                        bool goes_on = false;
+                                        if (runs) {
+                                            /* the run described last goes on here -- same byte, same block, the next byte of the corpus,
+                                             * nothing emitted since: its lookups are this batch's too, nothing to confirm at all */
+                                            uint32_t *pd = t.wl->pad;
+                                            const uint64_t nxt = (uint64_t)pd[RUN_NEXT + 1] << 32 | pd[RUN_NEXT];
+                                            goes_on = __builtin_amdgcn_readfirstlane((int)(pd[RUN_LIVE] && nxt == g0 && pd[RUN_VV] == vv && pd[RUN_BLOCK] == (uint32_t)t.cb &&
+                                                                                           f0 == pd[RUN_PB] + pd[RUN_NM])) != 0;
+                                            if (lane == 0) {
+                                                const uint64_t after = g_last + 1;
+                                                pd[RUN_NEXT] = (uint32_t)after, pd[RUN_NEXT + 1] = (uint32_t)(after >> 32);
+                                                if (goes_on) {
+                                                    constexpr uint32_t STEP = S2 ? 2u : 1u;
+                                                    const uint32_t more = ne * CHUNK / STEP, nm = pd[RUN_NM];
+                                                    pd[RUN_REPS] += more;
+                                                    pd[RUN_VIRT] += more * nm;
+                                                    if (nm) ((uint32_t *)(args.run_tab + (uint64_t)region_of * HSGPU_RUN_STRIDE + pd[RUN_N]))[2] = pd[RUN_REPS];
+                                                } else {
+                                                    pd[RUN_LIVE] = 0; /* (what the drain of position 0 finds decides: below) */
+                                                    pd[RUN_VV] = vv, pd[RUN_BLOCK] = (uint32_t)t.cb;
+                                                }
+                                            }
+                                        }
+                                        if (goes_on) {
+                                            dq = DENSE_POS; /* the batch is done */
+                                        } else {
+                                            uni = true;
+                                            uni_f = f0;
+                                            uni_pos = ne * CHUNK;
+                                            dP_saved = dP;
+                                            dP = 1;
+                                        }
                                     }
                                 }
                             }
@@ -2399,7 +2467,20 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                             /* (stride 2: lookup 0 reported the ends g0 and g0 + 1; every later lookup of the run the same pair, two further on) */
                             constexpr uint32_t STEP = S2 ? 2u : 1u;
                             const uint32_t total_new = (uni_pos / STEP - 1) * nm;
-                            if (nm) {
+                            /* with run tables: the other positions as a descriptor (record_sort_kernel writes their records where they go);
+                             * a region with HSGPU_RUN_MAX runs already, or one that has lost records: staged like everything else */
+                            const bool described = runs && f1 <= t.rec_cap && (!nm || __builtin_amdgcn_readfirstlane((int)t.wl->pad[RUN_N]) < HSGPU_RUN_MAX);
+                            if (described) {
+                                if (lane == 0) {
+                                    uint32_t *pd = t.wl->pad;
+                                    pd[RUN_PB] = uni_f, pd[RUN_NM] = nm, pd[RUN_REPS] = uni_pos / STEP - 1, pd[RUN_LIVE] = 1;
+                                    if (nm) {
+                                        const uint32_t k = ++pd[RUN_N];
+                                        pd[RUN_VIRT] += total_new;
+                                        args.run_tab[(uint64_t)region_of * HSGPU_RUN_STRIDE + k] = make_uint4(uni_f, nm, uni_pos / STEP - 1, STEP);
+                                    }
+                                }
+                            } else if (nm) {
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* (the drain's stores, read back below) */
                                 const bool have = lane < nm && uni_f + lane < t.rec_cap;
                                 const uint4 br = have ? t.rec_region[uni_f + lane] : make_uint4(0, 0, 0, 0); /* lane r: record r of position 0 */
@@ -2456,7 +2537,8 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             if (!fold) drain_matches(t, lane, 0);
         }
         if (spread) { /* this part's region is complete: published on its own, the wavefront's counters start over */
-            publish_records(t, args, lane, part, true);
+            if (DENSE && !PAIR && runs) publish_records<true>(t, args, lane, part, true);
+            else publish_records(t, args, lane, part, true);
             if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32);
             init_wave_lds(t, &wave_lds[wave], lane);
         }

@@ -21,6 +21,8 @@
 #define HSGPU_SUPER(i) ((i) << 3)
 #define HSGPU_SUPER_FLAGS HSGPU_SUPER(256)
 #define HSGPU_SUPER_WORDS (257 * 8)
+#define HSGPU_RUN_MAX 3
+#define HSGPU_RUN_STRIDE 4
 
 struct HsgpuScanArgs {
     const uint8_t *corpus;      /* all blocks, concatenated; 16-byte aligned */
@@ -64,6 +66,12 @@ struct HsgpuScanArgs {
     /* dense scans: conf_spread = 1: a record region per part (rec_regions = shares x conf_q), and the conf_k parts of a worker
      * are spread over the corpus row by row (hwlm_confirm_kernel) -- runs of dense input go round all workers */
     uint32_t conf_spread;
+    /* ... and a run table per region (round 6, the reference's flood case proper: src/fdr/flood_runtime.h:86-335 replays ONE confirm
+     * along a run of one byte value): [rec_regions][HSGPU_RUN_STRIDE], [0].x = the region's runs (<= HSGPU_RUN_MAX), [1 + k] =
+     * {index in the region of the records of the run's first lookup, records per lookup, further lookups, what a lookup adds to
+     * `end`} -- the further lookups' records exist only here; the region's count (rec_counts) counts them, record_sort_kernel
+     * writes them straight to where they go. nullptr: no run tables (every record staged) */
+    uint4 *run_tab;
     /* ordinary scans, one part per worker and two per share: the older workgroup of two mirrored dispatch ranks takes
      * 1/2 + conf_skew / 2^16 (scaled by the ranks' distance) of a share's batches (hwlm_confirm_kernel); 0: equal halves */
     uint32_t conf_skew;

@@ -38,7 +38,8 @@ extern "C" {
  * (normally the overflow fallback), fused_only == 2 the two-phase pipeline with record_sort_kernel as a kernel of its own
  * sorting behind the confirm kernel (regions in any order, sorted there; by default the confirm workers emit in delivery order and the
  * kernel behind them only gathers); fused_only == 3 / 4 switch the one-launch path of small batches off / force it at any size; fused_only == 5 gives the confirm kernel's workers equal halves of the candidate shares
- * instead of halves in proportion to their workgroup's dispatch rank (csrc/runtime.hip, conf_skew: the A/B of that choice);
+ * instead of halves in proportion to their workgroup's dispatch rank (csrc/runtime.hip, conf_skew: the A/B of that choice), and makes
+ * dense scans stage every record of a run of one byte value instead of a descriptor per run (run_tab: the A/B of that);
  * wg_threads in {0, 256, 512, 1024} and wg_per_cu in {0, 1..4} override the workgroup size / workgroups per CU the runtime would
  * choose (0 = its choice). */
 int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu);

@@ -185,12 +185,15 @@ def test_small_batch_server_parity_lifetime_and_fallbacks():
     plain.close()
 
 
+@pytest.mark.parametrize("tables", [True, False])
 @pytest.mark.parametrize("short", [False, True])
 @pytest.mark.parametrize("start", [0, 5])
-def test_flood_runs_replicated_from_one_confirm(short, start):
+def test_flood_runs_replicated_from_one_confirm(short, start, tables):
     """The dense kernel's run shortcut (scan_device.h, `uni`; the reference: src/fdr/flood_runtime.h:86-335): a batch of chunks
-    that are all one byte value, inside one block, is confirmed at ONE position and its other positions' records are written from
-    that one. Runs of several byte values and lengths, blocks cut inside runs at odd offsets (the shortcut must stop short of a
+    that are all one byte value, inside one block, is confirmed at ONE position; its other positions' records are a descriptor in
+    the region's run table, which goes on over the following batches of the same run and is expanded by record_sort_kernel
+    (`tables`; without them -- hsgpu_scratch_set_tuning(s, 5) -- the confirm kernel writes the records from that one position's).
+    Runs of several byte values and lengths, blocks cut inside runs at odd offsets (the shortcut must stop short of a
     block's first bytes), literals that match only at a run's head (`xaaaa`), several literals per window, `start` > 0, stride-1
     tables (a 3-byte literal in the set) and stride-2 ones: every record against the oracle, in delivery order."""
     from tests import oracle_binding as ob
@@ -223,9 +226,53 @@ def test_flood_runs_replicated_from_one_confirm(short, start):
     off = np.array(sorted(cuts), dtype=np.uint64)
     t = H.hwlm_build(lits)
     s = H.Scratch(0)
+    if not tables:
+        s.set_tuning(5)
     want = ob.Oracle(lits).collect_blocks(corpus, off, start=start)
     for rep in range(3):  # the first scan says "again" and the scratch goes dense; the following ones run dense
         got = hw.hwlm_exec_batch(t, s, corpus, off, start=start)
+        assert len(got) == len(want), (rep, len(got), len(want))
+        assert as_set(got) == as_set(want), rep
+        key = (got["block"].astype(np.uint64) << np.uint64(32)) | got["end"].astype(np.uint64)
+        assert np.all((key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (got["lit"][1:] > got["lit"][:-1]))), "delivery order"
+    s.close()
+
+
+def test_flood_run_tables_full():
+    """More runs in one part of the dense confirm stage than a region's run table holds (HSGPU_RUN_MAX = 3; the further ones are
+    staged record by record), runs that go on over many batches and over several parts, runs of a byte that is a candidate
+    everywhere and matches nothing: 512 MiB on the smallest launch geometry (1 024 filter wavefronts: shares of 512 KiB, parts
+    of 16 KiB), quiet but for 2 MiB of runs -- every record against the oracle, in delivery order."""
+    from tests import oracle_binding as ob
+    from tests.util import as_set
+
+    rng = np.random.default_rng(99)
+    lits = []
+    for c in b"abz":
+        lits += [H.HwlmLiteral(bytes([c]) * 4, id=len(lits)), H.HwlmLiteral(bytes([c]) * 8, id=len(lits) + 1)]
+    lits += [H.HwlmLiteral(b"qqqqqqqx", id=len(lits))]  # a run of q: candidates at every position, no match
+    lits += [H.HwlmLiteral(l.s, nocase=l.nocase, id=len(lits) + i) for i, l in enumerate(random_literals(rng, 40, 5, 8))]
+    total = 512 << 20
+    corpus = np.full(total, ord("."), dtype=np.uint8)
+    for at in rng.integers(0, total - 16, 2000):  # a few ordinary matches all over
+        l = lits[int(rng.integers(7, len(lits)))].s
+        corpus[at:at + len(l)] = np.frombuffer(l, dtype=np.uint8)
+    pos = (100 << 20) + 777
+    for k in range(96):  # 4 .. 7 KiB runs back to back, the values in turn: several runs per 16 KiB part
+        ln = int(rng.integers(4 << 10, 7 << 10))
+        corpus[pos:pos + ln] = b"abzq"[k % 4]
+        pos += ln
+    corpus[(200 << 20) + 5:(201 << 20) + 900] = ord("a")  # one run over ~64 parts
+    corpus[(300 << 20):(300 << 20) + (256 << 10)] = ord("q")
+    cuts = {0, total, (100 << 20) + 20000, (200 << 20) + 300000, (200 << 20) + 300001}
+    cuts |= {int(x) for x in rng.integers(0, total, 300)}
+    off = np.array(sorted(cuts), dtype=np.uint64)
+    t = H.hwlm_build(lits)
+    s = H.Scratch(0)
+    s.set_tuning(0, 256, 1)
+    want = ob.Oracle(lits).collect_blocks(corpus, off)
+    for rep in range(3):
+        got = hw.hwlm_exec_batch(t, s, corpus, off)
         assert len(got) == len(want), (rep, len(got), len(want))
         assert as_set(got) == as_set(want), rep
         key = (got["block"].astype(np.uint64) << np.uint64(32)) | got["end"].astype(np.uint64)
