@@ -2300,8 +2300,8 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
              * its start has the same eight-byte window at every one of its positions: position 0 is confirmed and drained the
              * ordinary way (uni: dP = 1), and the records of the batch's other positions are the same records with `end` counted
              * on -- written straight behind them, position-major, which IS delivery order (run_replicate below). */
-            bool uni = false;
-            uint32_t uni_f = 0, uni_pos = 0, dP_saved = 32;
+            bool uni = false, uni_wait = false;
+            uint32_t uni_f = 0, uni_pos = 0, uni_from = 0, dP_saved = 32;
             for (;;) {
 #if HSGPU_CONFIRM_ROTPRIO
                 switch ((prio_rank + prio_step++) & 3u) { /* (the argument of s_setprio is an immediate) */
@@ -2314,14 +2314,25 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                 uint32_t idx[CU] = {}, pend[CU] = {};
                 const uint32_t nrq = __builtin_amdgcn_readfirstlane(t.wl->nrq);
                 bool again = false; /* a step on (idx, pend) that somebody queued: the rest queue's entries, a dense batch's positions */
+                if (DENSE && !PAIR && uni_wait && dq > uni_from) dq = uni_from; /* (a step's stride went past the run's first position: nothing behind it was looked at) */
                 if (DENSE && dq < DENSE_POS && !syncing) {
+                    if (DENSE && !PAIR && uni_wait && dq >= uni_from) {
+                        /* everything in front of the run is out (a dense step ends in a drain): the run's first position, alone */
+                        uni_wait = false;
+                        uni = true;
+                        uni_f = __builtin_amdgcn_readfirstlane(t.wl->nfront);
+                        dq = uni_from;
+                        dP_saved = dP;
+                        dP = 1;
+                    }
+                    const uint32_t pos_end = (DENSE && !PAIR && uni_wait) ? uni_from : 128u * CHUNK; /* (the run's positions are not confirmed one by one) */
                     /* positions [dq, dq + dP) of the batch, one per lane slot: entry (position >> 4), its candidate bits of that position */
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const uint32_t sigma = u * 64 + lane, a = dq + sigma, k = a >> 4;
                         const uint32_t lo = (uint32_t)__shfl((int)dm[0], (int)(k & 63u)), hi = (uint32_t)__shfl((int)dm[1], (int)(k & 63u));
                         const uint32_t m_e = k < 64 ? lo : hi;
-                        pend[u] = (sigma < dP && k < 128) ? m_e & (0x10001u << (a & 15u)) : 0u;
+                        pend[u] = (sigma < dP && a < pos_end) ? m_e & (0x10001u << (a & 15u)) : 0u;
                         idx[u] = pend[u] ? dense_base + k : 0u;
                     }
                     if (__ballot((pend[0] | pend[1]) != 0) == 0) { /* nothing there: on */
@@ -2350,22 +2361,32 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                                 const uint4 z = make_uint4(0, 0, 0, 0);
                                 const uint4 a0 = i0 < end ? re[2ull * i0] : z, b0 = i0 < end ? re[2ull * i0 + 1] : z;
                                 const uint4 a1 = i1 < end ? re[2ull * i1] : z, b1 = i1 < end ? re[2ull * i1 + 1] : z;
-                                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a0.x), vv = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0.x);
+                                /* The batch's LAST chunk names the byte and the chunk numbers; the run is the batch's longest tail of consecutive
+                                 * chunks made of that byte (halo included) with every lookup position a candidate, cut to what lies inside the
+                                 * block of the last byte, 7 + `start` bytes clear of its first one (every window inside the block, every literal
+                                 * -- <= 8 bytes -- clear of `start`). The chunks in front of it (a block's first one: its halo is the block
+                                 * before) are confirmed position by position as ever (uni_from: where the run's positions begin). */
+                                const uint32_t ne = min(128u, end - base), last = ne - 1u;
+                                const uint32_t c_last = (uint32_t)__shfl((int)(last < 64 ? a0.x : a1.x), (int)(last & 63u));
+                                const uint32_t vv = (uint32_t)__shfl((int)(last < 64 ? b0.x : b1.x), (int)(last & 63u));
                                 constexpr uint32_t ALL = S2 ? 0x5555u : 0xffffu; /* every lookup position of the chunk (stride 2: the even ones) a candidate */
-                                const bool ok0 = i0 >= end || (a0.x == c0 + lane && ((a0.y | a0.y >> 16) & 0xffffu) == ALL && a0.z == vv && a0.w == vv &&
-                                                               b0.x == vv && b0.y == vv && b0.z == vv && b0.w == vv);
-                                const bool ok1 = i1 >= end || (a1.x == c0 + 64u + lane && ((a1.y | a1.y >> 16) & 0xffffu) == ALL && a1.z == vv && a1.w == vv &&
-                                                               b1.x == vv && b1.y == vv && b1.z == vv && b1.w == vv);
-                                if ((vv & 0xffu) * 0x01010101u == vv && __ballot(!(ok0 && ok1)) == 0) {
-                                    const uint32_t ne = min(128u, end - base);
-                                    const uint64_t g0 = (uint64_t)c0 * CHUNK, g_last = g0 + (uint64_t)ne * CHUNK - 1;
-                                    if (!(t.cb_end && g0 >= t.cb_start && g0 < t.cb_end)) { /* the block of the run's first byte (every lane the same lookup) */
+                                const bool ok0 = a0.x + (last - lane) == c_last && ((a0.y | a0.y >> 16) & 0xffffu) == ALL && a0.z == vv && a0.w == vv &&
+                                                 b0.x == vv && b0.y == vv && b0.z == vv && b0.w == vv;
+                                const bool ok1 = a1.x + (last - 64u - lane) == c_last && ((a1.y | a1.y >> 16) & 0xffffu) == ALL && a1.z == vv && a1.w == vv &&
+                                                 b1.x == vv && b1.y == vv && b1.z == vv && b1.w == vv;
+                                const uint64_t bad0 = __ballot(lane < ne && !ok0), bad1 = __ballot(64u + lane < ne && !ok1);
+                                const uint32_t k_val = bad1 ? 128u - (uint32_t)__builtin_clzll(bad1) : bad0 ? 64u - (uint32_t)__builtin_clzll(bad0) : 0u; /* the tail's first entry */
+                                if ((vv & 0xffu) * 0x01010101u == vv && k_val < ne) {
+                                    const uint64_t g_last = (uint64_t)c_last * CHUNK + CHUNK - 1, g_tail = (uint64_t)(c_last - (last - k_val)) * CHUNK;
+                                    if (!(t.cb_end && g_last >= t.cb_start && g_last < t.cb_end)) { /* the block of the run's last byte (every lane the same lookup) */
                                         uint64_t bs;
-                                        const uint64_t b = block_of(t, g0, bs);
+                                        const uint64_t b = block_of(t, g_last, bs);
                                         t.cb = rfl64(b), t.cb_start = rfl64(bs), t.cb_end = rfl64(t.off[min(b + 1, t.nblocks)]);
                                     }
-                                    /* every window inside the block, every literal (<= 8 bytes) clear of `start` */
-                                    if (g0 >= t.cb_start && g_last < t.cb_end && g0 - t.cb_start >= 7 + t.start) {
+                                    const uint64_t clear = (t.cb_start + 7 + t.start + (CHUNK - 1)) & ~(uint64_t)(CHUNK - 1);
+                                    const uint64_t g_run = max(g_tail, clear); /* the run's first byte */
+                                    if (g_run <= g_last) {
+                                        const uint32_t k_run = k_val + (uint32_t)((g_run - g_tail) / CHUNK), n_run = ne - k_run; /* its first entry, its chunks */
                                         const uint32_t f0 = __builtin_amdgcn_readfirstlane(t.wl->nfront);
                                         bool goes_on = false;
                                         if (runs) {
@@ -2373,8 +2394,8 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                                              * nothing emitted since: its lookups are this batch's too, nothing to confirm at all */
                                             uint32_t *pd = t.wl->pad;
                                             const uint64_t nxt = (uint64_t)pd[RUN_NEXT + 1] << 32 | pd[RUN_NEXT];
-                                            goes_on = __builtin_amdgcn_readfirstlane((int)(pd[RUN_LIVE] && nxt == g0 && pd[RUN_VV] == vv && pd[RUN_BLOCK] == (uint32_t)t.cb &&
-                                                                                           f0 == pd[RUN_PB] + pd[RUN_NM])) != 0;
+                                            goes_on = __builtin_amdgcn_readfirstlane((int)(k_run == 0 && pd[RUN_LIVE] && nxt == g_run && pd[RUN_VV] == vv &&
+                                                                                           pd[RUN_BLOCK] == (uint32_t)t.cb && f0 == pd[RUN_PB] + pd[RUN_NM])) != 0;
                                             if (lane == 0) {
                                                 const uint64_t after = g_last + 1;
                                                 pd[RUN_NEXT] = (uint32_t)after, pd[RUN_NEXT + 1] = (uint32_t)(after >> 32);
@@ -2385,7 +2406,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                                                     pd[RUN_VIRT] += more * nm;
                                                     if (nm) ((uint32_t *)(args.run_tab + (uint64_t)region_of * HSGPU_RUN_STRIDE + pd[RUN_N]))[2] = pd[RUN_REPS];
                                                 } else {
-                                                    pd[RUN_LIVE] = 0; /* (what the drain of position 0 finds decides: below) */
+                                                    pd[RUN_LIVE] = 0; /* (what the drain of the run's first position finds decides: below) */
                                                     pd[RUN_VV] = vv, pd[RUN_BLOCK] = (uint32_t)t.cb;
                                                 }
                                             }
@@ -2393,11 +2414,9 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                                         if (goes_on) {
                                             dq = DENSE_POS; /* the batch is done */
                                         } else {
-                                            uni = true;
-                                            uni_f = f0;
-                                            uni_pos = ne * CHUNK;
-                                            dP_saved = dP;
-                                            dP = 1;
+                                            uni_pos = n_run * CHUNK;
+                                            uni_from = k_run * CHUNK;
+                                            uni_wait = true; /* (the dense step below starts the run when it gets to its first position) */
                                         }
                                     }
                                 }
@@ -2463,7 +2482,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
                         const uint32_t ooo = __builtin_amdgcn_readfirstlane(t.wl->pad[0]);
                         uni = false;
                         dP = dP_saved;
-                        if (nm <= 64 && !ooo && dq >= 1) {
+                        if (nm <= 64 && !ooo && dq >= uni_from + 1) {
                             /* (stride 2: lookup 0 reported the ends g0 and g0 + 1; every later lookup of the run the same pair, two further on) */
                             constexpr uint32_t STEP = S2 ? 2u : 1u;
                             const uint32_t total_new = (uni_pos / STEP - 1) * nm;
