@@ -1506,13 +1506,21 @@ def run_batch_sweep(args):
     us_launch = per_call()  # a kernel launch per call (rounds 1-5)
     n_launch = ncb.value
     # ... and through the small-batch server (round 6, include/hsgpu.h): one resident workgroup, no launch per call
+    # (enable 2: the requests through mapped host memory -- the only way on a device without a large PCIe BAR -- as the A/B of 1:
+    # requests written straight into device memory)
+    job.scratch.enable_server(2)
+    ncb.value = 0
+    us_host_mailbox = per_call(2000)
+    assert ncb.value * 505 == n_launch * 2005, "the server (mailbox in host memory) delivers other matches than the launch path"
+    cu, su = C.c_float(), C.c_float()
+    lib.hsgpu_scratch_server_last_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
+    su_host = su.value
     job.scratch.enable_server(True)
     ncb.value = 0
     us_exec = per_call(2000)
     assert ncb.value * 505 == n_launch * 2005, "the server delivers other matches than the launch path"
     calls, launches, _live = job.scratch.server_stats()
-    cu, su = C.c_float(), C.c_float()
-    lib.hsgpu_scratch_server_last_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
     job.scratch.enable_server(False)
     lib.hsgpu_scratch_set_context(job.scratch._h, None)
@@ -1520,7 +1528,8 @@ def run_batch_sweep(args):
                        "hsgpu_hwlm_exec call per 1460-byte block from host memory",
            "value": round(peak, 1), "unit": "GB/s at the largest batch",
            "us_per_hwlm_exec_call_1460B": round(us_exec, 1), "GBps_one_block_per_call": round(1460 / us_exec / 1e3, 4),
-           "us_per_hwlm_exec_call_1460B_launch_path": round(us_launch, 1), "server": {"calls": calls, "launches": launches, "device_copy_us": round(cu.value, 2), "device_scan_us": round(su.value, 2)},
+           "us_per_hwlm_exec_call_1460B_launch_path": round(us_launch, 1), "server": {"calls": calls, "launches": launches, "device_copy_us": round(cu.value, 2), "device_scan_us": round(su.value, 2),
+                                                                                     "us_per_call_mailbox_in_host_memory": round(us_host_mailbox, 1), "device_scan_us_mailbox_in_host_memory": round(su_host, 2)},
            "half_peak_batch_bytes": reach(0.5), "ninety_percent_batch_bytes": reach(0.9), "curve": curve}
     del job
     torch.cuda.empty_cache()

@@ -178,6 +178,14 @@ struct hsgpu_scratch {
     bool srv_enabled = false, srv_live = false;
     hipStream_t srv_stream = nullptr;
     HsgpuServerCtl *h_srv = nullptr, *d_srv = nullptr;
+    /* the request side of the mailbox in DEVICE memory that the host writes through the PCIe BAR (fine-grained; devices with a
+     * large BAR only): {request lines of an HsgpuServerCtl | offsets | corpus}, laid out like the mapped area. The workgroup then
+     * polls and reads its batch locally -- a 1.5 KB request's round trip is 4.4 us instead of 10.5 (profiles/r06_bar_mailbox.txt) */
+    uint8_t *bar_small = nullptr;
+    HsgpuServerCtl *bar_ctl = nullptr; /* ... its request lines (behind offsets and corpus) */
+    int bar_state = 0;          /* 0 not tried, 1 in use, -1 none (no large BAR, guard-page mode, or asked for: enable == 2) */
+    bool srv_req_bar = false;   /* the live server reads its requests from bar_small */
+    bool srv_host_mailbox = false; /* hsgpu_scratch_enable_server(s, 2, ..): the A/B */
     const hsgpu_hwlm *srv_table = nullptr;
     uint32_t srv_seq = 0;
     unsigned srv_idle_us = 300; /* an idle server ends after this long: nothing it holds outlives a burst of calls by more */
@@ -314,6 +322,7 @@ extern "C" void hsgpu_scratch_free(hsgpu_scratch_t *s) {
     if (s->h_note) (void)hipHostFree(s->h_note);
     if (s->h_small) (void)hipHostFree(s->h_small);
     if (s->h_srv) (void)hipHostFree(s->h_srv);
+    if (s->bar_small) (void)hipFree(s->bar_small);
     if (s->srv_stream) (void)hipStreamDestroy(s->srv_stream);
     if (s->h_recs) (void)hipHostFree(s->h_recs);
     for (int i = 0; i < 4; i++)
@@ -480,8 +489,9 @@ extern "C" int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsi
 extern "C" int hsgpu_scratch_enable_server(hsgpu_scratch_t *s, int enable, unsigned idle_us) {
     if (!s) return HSGPU_INVALID;
     HIP_TRY(hipSetDevice(s->device));
-    if (!enable) server_stop(s);
+    if (!enable || (enable == 2) != s->srv_host_mailbox) server_stop(s);
     s->srv_enabled = enable != 0;
+    s->srv_host_mailbox = enable == 2;
     if (idle_us) s->srv_idle_us = std::min(idle_us, 1000000u);
     return HSGPU_SUCCESS;
 }
@@ -549,6 +559,7 @@ static int solo_setup(hsgpu_scratch *s, HsgpuScanArgs &args, uint64_t total, uin
     args.conf_q = args.conf_k = 1;
     args.conf_spread = 0, args.conf_skew = 0;
     args.run_tab = nullptr;
+    args.img_keep_words = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     args.cand = nullptr;
     args.cand_cap = 0;
@@ -610,11 +621,20 @@ static unsigned filter_wg_threads(const HsgpuTableHeader *h, const hsgpu_scratch
 }
 
 /* ---- the small-batch server: host side (scan_device.h, hwlm_server_kernel) ------------------------------------------------ */
+/* the request lines of the mailbox as the host writes them: in the BAR area when the live server reads them there */
+static inline HsgpuServerCtl *server_req(hsgpu_scratch *s) { return s->srv_req_bar ? s->bar_ctl : s->h_srv; }
+static inline void bar_flush() {
+#if defined(__x86_64__)
+    __builtin_ia32_sfence(); /* (device memory through the BAR is write-combining: without it a store sits in the CPU's buffers) */
+#endif
+}
 static void server_stop(hsgpu_scratch *s) { /* ends a live server at once and waits until it has gone */
     if (!s->srv_live) return;
-    __atomic_store_n(&s->h_srv->stop, 1u, __ATOMIC_RELEASE);
+    __atomic_store_n(&server_req(s)->stop, 1u, __ATOMIC_RELEASE);
+    bar_flush();
     (void)hipStreamSynchronize(s->srv_stream);
-    s->h_srv->stop = 0;
+    server_req(s)->stop = 0;
+    bar_flush();
     s->h_srv->exited = 0;
     s->srv_live = false;
     s->srv_table = nullptr;
@@ -755,6 +775,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.conf_q = args.conf_k = 1;
     args.conf_spread = 0, args.conf_skew = 0;
     args.run_tab = nullptr;
+    args.img_keep_words = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     if (two_phase) {
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
@@ -1048,6 +1069,31 @@ constexpr size_t SMALL_BYTES = 256 << 10, SMALL_BLOCKS = 4096, SMALL_RECS = 4096
 constexpr size_t SMALL_OFF_AT = 64, SMALL_CORPUS_AT = SMALL_OFF_AT + (SMALL_BLOCKS + 1) * 8 + 56 /* -> a multiple of 64 */,
                  SMALL_RECS_AT = SMALL_CORPUS_AT + SMALL_BYTES + 64, SMALL_TOTAL = SMALL_RECS_AT + SMALL_RECS * sizeof(hsgpu_match_t);
 static_assert(SMALL_CORPUS_AT % 64 == 0 && SMALL_RECS_AT % 64 == 0, "aligned sections");
+/* the request side in device memory (bar_area): offsets and corpus where the mapped area has them, the request lines of the mailbox behind them */
+constexpr size_t BAR_CTL_AT = SMALL_RECS_AT, BAR_TOTAL = BAR_CTL_AT + sizeof(HsgpuServerCtl);
+
+/* The request side of the server's mailbox in device memory (hsgpu_scratch::bar_small), once per scratch. */
+static bool bar_area(hsgpu_scratch *s) {
+    if (s->srv_host_mailbox || hsgpu_dev_guard_mode()) return false; /* (guard-page runs keep to the buffers the guard allocator made) */
+    if (s->bar_state) return s->bar_state > 0;
+    s->bar_state = -1;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, s->device) != hipSuccess || !pr.isLargeBar) {
+        (void)hipGetLastError();
+        return false;
+    }
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, BAR_TOTAL, hipDeviceMallocFinegrained) != hipSuccess || hipMemsetAsync(p, 0, BAR_TOTAL, s->stream) != hipSuccess ||
+        hipStreamSynchronize(s->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        if (p) (void)hipFree(p);
+        return false;
+    }
+    s->bar_small = (uint8_t *)p;
+    s->bar_ctl = (HsgpuServerCtl *)(s->bar_small + BAR_CTL_AT);
+    s->bar_state = 1;
+    return true;
+}
 
 /* one resident workgroup for this (scratch, table): its arguments are a solo scan's, with corpus, offsets, records and count
  * in the scratch's mapped area. -> HSGPU_SUCCESS, 1: no server for this table / device (the caller launches), < 0: an error */
@@ -1087,12 +1133,20 @@ static int server_start(const hsgpu_hwlm *t, hsgpu_scratch *s) {
     table_args(h, args);
     if ((rv = solo_setup(s, args, 1ull << super_shift, SMALL_RECS, 1, wg_threads, s->srv_stream)) != HSGPU_SUCCESS) return rv;
     if ((rv = set_dyn_lds(f, lds)) != HSGPU_SUCCESS) return rv;
-    s->h_srv->stop = 0;
+    s->srv_req_bar = bar_area(s);
+    if (s->srv_req_bar) { /* (a request written for a server that went idle before it saw it is served by this one: same words) */
+        HsgpuServerCtl *q = (HsgpuServerCtl *)(s->bar_small + BAR_CTL_AT);
+        q->req_seq = s->h_srv->req_seq;
+        q->total = s->h_srv->total, q->nblocks = s->h_srv->nblocks, q->start = s->h_srv->start;
+    }
+    server_req(s)->stop = 0;
+    bar_flush();
     s->h_srv->exited = 0;
-    HsgpuServerCtl *ctl = s->d_srv;
+    HsgpuServerCtl *ctl = s->d_srv, *req = s->srv_req_bar ? (HsgpuServerCtl *)(s->bar_small + BAR_CTL_AT) : s->d_srv;
     unsigned long long idle_ticks = (unsigned long long)s->srv_idle_us * 100ull; /* the 100 MHz wall clock */
-    const void *src_corpus = s->d_small + SMALL_CORPUS_AT, *src_off = s->d_small + SMALL_OFF_AT;
-    void *kargs[] = {&args, &ctl, &idle_ticks, &src_corpus, &src_off};
+    uint8_t *const area = s->srv_req_bar ? s->bar_small : s->d_small;
+    const void *src_corpus = area + SMALL_CORPUS_AT, *src_off = area + SMALL_OFF_AT;
+    void *kargs[] = {&args, &ctl, &req, &idle_ticks, &src_corpus, &src_off};
     HIP_TRY(hipLaunchKernel(f, dim3(1), dim3(wg_threads), kargs, lds, s->srv_stream));
     s->srv_live = true;
     s->srv_table = t;
@@ -1100,26 +1154,39 @@ static int server_start(const hsgpu_hwlm *t, hsgpu_scratch *s) {
     return HSGPU_SUCCESS;
 }
 
-/* One request to the server; the batch is in the mapped area already (scan_host_small). -> 0: served (count and records are in
- * the area), 1: not a batch for the server (or none to be had): the caller launches, < 0: an error */
-static int server_call(const hsgpu_hwlm *t, hsgpu_scratch *s, uint64_t total, size_t nblocks, size_t start) {
-    if (!s->srv_enabled || !total) return 1;
+/* a batch the resident workgroup could serve on this scratch as it is set up */
+static bool server_takes(const hsgpu_hwlm *t, hsgpu_scratch *s, uint64_t total) {
+    if (!s->srv_enabled || !total) return false;
     const HsgpuTableHeader *h = t->hdr();
     const unsigned wg_threads = filter_wg_threads(h, s, nullptr);
     const uint32_t super_shift = wg_threads <= 256 ? 12 : wg_threads <= 512 ? 13 : 14;
     /* what ONE workgroup scans as a solo scan, under the conditions a solo scan has (launch_scan) */
-    if (total > (1ull << super_shift) || s->tune_fused || s->tune_unfolded || s->tune_solo == 1 || s->cand_div != 64 || (s->h_note && *s->h_note)) return 1;
+    return !(total > (1ull << super_shift) || s->tune_fused || s->tune_unfolded || s->tune_solo == 1 || s->cand_div != 64 || (s->h_note && *s->h_note));
+}
+
+/* A server for this table and a batch of this size, resident (started when there is none): -> 0, where it reads its requests is
+ * s->srv_req_bar; 1: none to be had: the caller launches; < 0: an error. BEFORE the batch is laid out: it goes where the server reads. */
+static int server_ready(const hsgpu_hwlm *t, hsgpu_scratch *s, uint64_t total) {
+    if (!server_takes(t, s, total)) return 1;
     if (s->srv_live && s->srv_table != t) server_stop(s);
     if (s->srv_live && __atomic_load_n(&s->h_srv->exited, __ATOMIC_ACQUIRE)) { /* it went idle and ended */
         (void)hipStreamSynchronize(s->srv_stream);
         s->srv_live = false;
     }
+    return s->srv_live ? 0 : server_start(t, s);
+}
+
+/* One request to the resident server (server_ready said 0; the batch is laid out where it reads). -> 0: served (count and records
+ * are in the mapped area), < 0: an error */
+static int server_call(const hsgpu_hwlm *t, hsgpu_scratch *s, uint64_t total, size_t nblocks, size_t start) {
     int rv;
-    if (!s->srv_live && (rv = server_start(t, s)) != HSGPU_SUCCESS) return rv;
-    HsgpuServerCtl *c = s->h_srv;
-    c->total = total, c->nblocks = nblocks, c->start = start;
+    HsgpuServerCtl *c = s->h_srv, *q = server_req(s);
     const uint32_t seq = ++s->srv_seq;
-    __atomic_store_n(&c->req_seq, seq, __ATOMIC_RELEASE);
+    if (q != c) c->total = total, c->nblocks = nblocks, c->start = start, c->req_seq = seq; /* (what a restarted server is told: server_start) */
+    q->total = total, q->nblocks = nblocks, q->start = start;
+    bar_flush(); /* the batch (scan_host_small) and the parameters are out before the sequence number */
+    __atomic_store_n(&q->req_seq, seq, __ATOMIC_RELEASE);
+    bar_flush();
     s->srv_calls++;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0;; spin++) {
@@ -1164,15 +1231,23 @@ static int scan_host_small(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t 
             return 1;
         }
     }
-    uint64_t *h_off = (uint64_t *)(s->h_small + SMALL_OFF_AT);
-    for (size_t i = 0; i <= nblocks; i++) h_off[i] = off[i] - lo;
-    memcpy(s->h_small + SMALL_CORPUS_AT, base + lo, total);
-    memset(s->h_small + SMALL_CORPUS_AT + total, 0, 16);
-    *(volatile unsigned long long *)s->h_small = ~0ull;
-    s->res_corpus = s->d_small + SMALL_CORPUS_AT, s->res_off = s->d_small + SMALL_OFF_AT;
-    int rv = server_call(t, s, total, nblocks, start); /* the resident workgroup, when the scratch has one enabled and the batch is its size */
+    /* the batch into the area the scan reads it from: the mapped one -- or, for the resident workgroup on a device whose memory the
+     * host can write (bar_area), device memory */
+    auto put = [&](uint8_t *area) {
+        uint64_t *a_off = (uint64_t *)(area + SMALL_OFF_AT);
+        for (size_t i = 0; i <= nblocks; i++) a_off[i] = off[i] - lo;
+        memcpy(area + SMALL_CORPUS_AT, base + lo, total);
+        memset(area + SMALL_CORPUS_AT + total, 0, 16);
+    };
+    int rv = server_ready(t, s, total); /* the resident workgroup, when the scratch has one enabled and the batch is its size */
     if (rv < 0) return rv;
-    if (rv == 0) {
+    const bool served = rv == 0, to_bar = served && s->srv_req_bar;
+    put(to_bar ? s->bar_small : s->h_small);
+    *(volatile unsigned long long *)s->h_small = ~0ull;
+    uint8_t *const d_area = to_bar ? s->bar_small : s->d_small;
+    s->res_corpus = d_area + SMALL_CORPUS_AT, s->res_off = d_area + SMALL_OFF_AT;
+    if (served && (rv = server_call(t, s, total, nblocks, start)) < 0) return rv;
+    if (served) {
         const uint64_t n = *(volatile unsigned long long *)s->h_small;
         if (n <= SMALL_RECS) {
             recs.resize(n);
@@ -1180,6 +1255,10 @@ static int scan_host_small(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t 
             return HSGPU_SUCCESS;
         }
         *(volatile unsigned long long *)s->h_small = ~0ull; /* more records than the area holds, or "again": the launch path decides */
+    }
+    if (to_bar) { /* (rare: the launch path reads the mapped area) */
+        put(s->h_small);
+        s->res_corpus = s->d_small + SMALL_CORPUS_AT, s->res_off = s->d_small + SMALL_OFF_AT;
     }
     rv = hsgpu_hwlm_scan_dev(t, s, s->d_small + SMALL_CORPUS_AT, total, s->d_small + SMALL_OFF_AT, nblocks, start,
                                  s->d_small + SMALL_RECS_AT, SMALL_RECS, s->d_small, s->stream);

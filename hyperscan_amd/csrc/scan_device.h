@@ -109,6 +109,7 @@ struct WaveLds {
                        * run's first record / records per lookup / further lookups, [6..7] the corpus offset where it would go on,
                        * [8] its byte value (x 0x01010101), [9] its block, [10] 1 = [3..9] describe a run that may go on */
 };
+constexpr uint32_t SOLO_LDS_WORDS = 28 * 1024 / 4; /* what solo_tail uses of the (dead) filter image as scratch: flags, sort buffer, prefix array, list of large regions */
 constexpr int RUN_VIRT = 1, RUN_N = 2, RUN_PB = 3, RUN_NM = 4, RUN_REPS = 5, RUN_NEXT = 6, RUN_VV = 8, RUN_BLOCK = 9, RUN_LIVE = 10;
 static_assert(sizeof(WaveLds) == 1536, "per-wave LDS area is 1.5 KiB: 128 KiB filter + 8 KiB + 16 x 1.5 KiB = 160 KiB");
 
@@ -1350,11 +1351,15 @@ __device__ __forceinline__ void hwlm_filter_body(const HsgpuScanArgs &args, uint
 #endif
     constexpr int IMG = HSGPU_PROLOGUE_IMG; /* 16-byte pieces of the image per thread in the first batch: 128 KiB / 1024 threads */
     const uint4 *img_src = (const uint4 *)(args.blob + args.t_off_filter);
+    /* (the small-batch server from its second request on: the image is in LDS but for its head, which the placement of the request
+     * before used as scratch -- solo_tail) */
+    const bool img_kept = FUSED && args.img_keep_words != 0;
+    const uint32_t nw_load = img_kept ? min(nw, args.img_keep_words) : nw;
     uint4 img[IMG];
 #pragma unroll
     for (int u = 0; u < IMG; u++) {
         const uint32_t i = threadIdx.x + u * blockDim.x;
-        img[u] = i < nw / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
+        img[u] = i < nw_load / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
     }
 #ifndef HSGPU_HINTS_LATE
 #define HSGPU_HINTS_LATE 1 /* the block hints are written after the wavefront's share, not in front of it (0: in the prologue, as in
@@ -1404,10 +1409,10 @@ __device__ __forceinline__ void hwlm_filter_body(const HsgpuScanArgs &args, uint
 #pragma unroll
     for (int u = 0; u < IMG; u++) {
         const uint32_t i = threadIdx.x + u * blockDim.x;
-        if (i < nw / 4) ((uint4 *)filter)[i] = img[u];
+        if (i < nw_load / 4) ((uint4 *)filter)[i] = img[u];
     }
-    for (uint32_t i = threadIdx.x + IMG * blockDim.x; i < nw / 4; i += blockDim.x) ((uint4 *)filter)[i] = img_src[i];
-    if (HAS_C) {
+    for (uint32_t i = threadIdx.x + IMG * blockDim.x; i < nw_load / 4; i += blockDim.x) ((uint4 *)filter)[i] = img_src[i];
+    if (HAS_C && !img_kept) {
         const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
         for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
     }
@@ -1611,9 +1616,13 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
  *               forgotten server cannot hold a CU (or a device synchronisation) for longer than that, and nothing can hang; the
  *               host launches the next one when the next small call comes (runtime.hip, server_call)
  *   stop        the host's way of ending it at once (hsgpu_scratch_free, a scan on the same scratch that needs the buffers)
- * req / done are words of their own cache lines; the parameters are read AFTER the sequence number has been seen to change. */
+ * req / done are words of their own cache lines; the parameters are read AFTER the sequence number has been seen to change.
+ * `req` (the request lines: stop, req_seq, total, nblocks, start) and src_* may be DEVICE memory that the host writes through the
+ * PCIe BAR (runtime.hip, bar_area): the poll and the batch's tiles are then local reads -- a 1.5 KB request's round trip through
+ * one wavefront is 4.4 us instead of 10.5 (tools/experiments/bar_mailbox.hip) --, `ctl` (done_seq, exited, stamps), records and
+ * count stay in mapped host memory, which the host polls and reads at memory speed. */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool PAIR = false, bool WIDE = false>
-__global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_server_kernel(HsgpuScanArgs args, HsgpuServerCtl *ctl,
+__global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_server_kernel(HsgpuScanArgs args, HsgpuServerCtl *ctl, HsgpuServerCtl *req,
                                                                                             unsigned long long idle_ticks, const uint4 *src_corpus,
                                                                                             const uint4 *src_off) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1629,16 +1638,17 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
     const bool leader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t last = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    uint32_t img_keep = 0; /* words at the head of the table image to load again (0: the whole image) */
     for (;;) {
         if (leader) {
             const unsigned long long t0 = wall_clock64();
             uint32_t cmd = 0, seq = last;
             for (;;) {
-                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) { /* first: nothing outranks it */
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&req->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) { /* first: nothing outranks it */
                     cmd = 1;
                     break;
                 }
-                seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+                seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&req->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
                 if (seq != last) break;
                 if (wall_clock64() - t0 > idle_ticks) {
                     cmd = 1;
@@ -1648,9 +1658,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
             }
             uint32_t p[6] = {0, 0, 0, 0, 0, 0};
             if (!cmd) { /* (the parameters were written before the sequence number: read after it) */
-                const unsigned long long tot = __hip_atomic_load(&ctl->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned long long nb = __hip_atomic_load(&ctl->nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned long long st = __hip_atomic_load(&ctl->start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long tot = __hip_atomic_load(&req->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long nb = __hip_atomic_load(&req->nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long st = __hip_atomic_load(&req->start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 p[0] = (uint32_t)tot, p[1] = (uint32_t)(tot >> 32), p[2] = (uint32_t)nb, p[3] = (uint32_t)(nb >> 32), p[4] = (uint32_t)st, p[5] = (uint32_t)(st >> 32);
             }
             if (lane < 8) mail[lane] = lane == 0 ? seq : lane == 1 ? cmd : p[(lane - 2) % 6]; /* (every lane holds the same values) */
@@ -1683,7 +1693,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
             __syncthreads(); /* (the same compute unit wrote it: the barrier's workgroup-scope release / acquire is enough) */
         }
         const unsigned long long t_copied = wall_clock64();
+        a.img_keep_words = img_keep;
         hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, true, PAIR, WIDE>(a, lds);
+        img_keep = SOLO_LDS_WORDS; /* the table image stays in LDS between requests; solo_tail's scratch is its head */
         /* every wavefront: its records (and the count) out to host memory, at SYSTEM scope. (A workgroup-scope release in front of
          * a relaxed done word was measured: the done word, another address and so another L2 channel, overtook the count -- the
          * host read the count it had put there itself and sent every call down the launch path.) */
@@ -1906,6 +1918,7 @@ __device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *l
     uint4 *buf = (uint4 *)(lds + 64);                       /* SORT_LDS records: 16 KiB */
     uint32_t *start = lds + 64 + SORT_LDS * 4;              /* [SOLO_MAX_REGIONS + 1] fills, then exclusive prefix */
     uint32_t *large = start + SOLO_MAX_REGIONS + 64;        /* regions of more than 64 records */
+    static_assert(64 + SORT_LDS * 4 + 2 * (SOLO_MAX_REGIONS + 64) <= SOLO_LDS_WORDS, "solo_tail's scratch is the head of the filter image that the server loads again");
     const uint2 *counts = (const uint2 *)args.rec_counts;
     uint32_t over = 0;
     for (uint32_t i = tid; i < SOLO_MAX_REGIONS; i += NT) {
@@ -2241,13 +2254,20 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
         skew_num = 32768u + args.conf_skew * (ranks - 1u - 2u * low) / max(ranks - 1u, 1u);
     }
     uint32_t region_of = worker; /* the record region this worker publishes at the end */
+    uint32_t fills64 = 0; /* spread: lane j holds the fill of the share of this worker's part of row (row & ~63) + j */
     for (uint32_t slot = worker * K; slot < (spread ? worker * K + K : min(n_parts, worker * K + K)); slot++) {
         const uint32_t row = slot - worker * K;
         const uint32_t part = spread ? row * n_workers + (worker + 2731u * row) % n_workers : skew ? skew_part : slot;
+        if (spread && (row & 63u) == 0) {
+            /* the fills of the next 64 rows' shares in ONE round trip (most parts of a flood corpus are empty: a dependent load per
+             * part was most of what they cost) */
+            const uint32_t rj = row + lane, pj = rj * n_workers + (worker + 2731u * rj) % n_workers;
+            fills64 = (rj < K && pj < n_parts) ? args.cand_counts[pj / Q] : 0u;
+        }
         if (part >= n_parts) continue; /* (spread: the last row is not full) */
         const uint32_t r = part / Q, q = part - r * Q;
         if (spread || skew) t.rec_region = args.rec_stage + (uint64_t)part * args.rec_cap, region_of = part;
-        const uint32_t n = min(args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
+        const uint32_t n = min(spread ? (uint32_t)__shfl((int)fills64, (int)(row & 63u)) : args.cand_counts[r], args.cand_cap); /* never past the region, whatever the counter says */
         /* this part's entries [base, end): the q-th of Q pieces of the share's batches of 128, consecutive pieces of the corpus */
         /* (spread and skewed parts: pieces of whole half batches -- a dense half batch is 1 024 lookup positions; a skewed cut in
          * whole batches would move in steps of 6 % of a share) */
@@ -2260,6 +2280,7 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             end_b = q ? nb : cut;
         }
         const uint32_t end = min(n, end_b << gshift);
+        const bool any_entries = base < end;
         const uint32_t stride = 128u;
         uint64_t edge = 0; /* pair tables, the share's last part: the next share's first byte, when that share exists */
         if (PAIR && HAS_B) {
@@ -2555,7 +2576,8 @@ void hwlm_confirm_kernel(HsgpuScanArgs args) {
             }
             if (!fold) drain_matches(t, lane, 0);
         }
-        if (spread) { /* this part's region is complete: published on its own, the wavefront's counters start over */
+        if (spread && any_entries) { /* this part's region is complete: published on its own, the wavefront's counters start over
+                                     * (a part without entries: its words of the control block are zero as they are, nobody reads its run table) */
             if (DENSE && !PAIR && runs) publish_records<true>(t, args, lane, part, true);
             else publish_records(t, args, lane, part, true);
             if (fold && lane == 0 && t.wl->pad[0]) atomicAdd(&args.rec_super[HSGPU_SUPER_FLAGS], 1ull << 32);

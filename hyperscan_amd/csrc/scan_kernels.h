@@ -91,6 +91,7 @@ struct HsgpuScanArgs {
     uint32_t solo;
     uint32_t solo_ctl_words;    /* words of the control block that starts at rec_counts (rec_counts | rec_super | ticket) */
     uint32_t *solo_ticket;
+    uint32_t img_keep_words;    /* fused kernel's body inside the small-batch server: the table image is in LDS already but for its first img_keep_words words (0: load all of it) */
     unsigned long long *wg_stamps;   /* tuning (hsgpu_scratch_enable_timing(s, 2)): [filter grid][4] device wall clock per
                                       * workgroup: start, image staged / hints written, wavefront 0's share done, end */
     unsigned long long *conf_stamps; /* the same for the confirm kernel's workers (tuning builds, HSGPU_CONFIRM_STAMPS=1):
@@ -106,7 +107,7 @@ struct HsgpuServerCtl {
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
 /* the resident small-batch server with the fused kernel's body (scan_device.h, hwlm_server_kernel; nullptr: none for this table):
- * launched with (HsgpuScanArgs, HsgpuServerCtl *, unsigned long long idle_ticks, const uint4 *src_corpus, const uint4 *src_off), ONE
+ * launched with (HsgpuScanArgs, HsgpuServerCtl *ctl, HsgpuServerCtl *req, unsigned long long idle_ticks, const uint4 *src_corpus, const uint4 *src_off), ONE
  * workgroup, hsgpu_filter_lds_bytes(fused) + 64 of LDS; src_*: where the host puts a request's batch (mapped memory) -- copied to
  * args.corpus / args.off (device memory) at the head of every request */
 const void *hsgpu_server_kernel_for(uint32_t table_flags);

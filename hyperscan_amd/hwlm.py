@@ -149,16 +149,17 @@ class Scratch:
         if env.get("HSGPU_MODE") or env.get("HSGPU_WG_THREADS") or env.get("HSGPU_WG_PER_CU"):
             self.set_tuning({"fused": 1, "unfolded": 2, "no_skew": 5}.get(env.get("HSGPU_MODE"), 0), int(env.get("HSGPU_WG_THREADS", "0")),
                             int(env.get("HSGPU_WG_PER_CU", "0")))
-        if env.get("HSGPU_MODE") == "server":  # every small host batch of the process through the resident workgroup (the parity suite, forced)
-            self.enable_server(True)
+        if env.get("HSGPU_MODE") in ("server", "server_host"):  # every small host batch of the process through the resident workgroup (the parity suite, forced)
+            self.enable_server(2 if env.get("HSGPU_MODE") == "server_host" else True)
 
     def enable_server(self, on=True, idle_us=0):
         """the small-batch server (include/hsgpu.h, hsgpu_scratch_enable_server): hwlm_exec / hwlm_exec_batch calls of up to
-        16 KiB are served by one resident workgroup instead of a kernel launch per call"""
+        16 KiB are served by one resident workgroup instead of a kernel launch per call (on = 2: the requests through mapped host
+        memory even where the host can write device memory)"""
         f = self._lib.hsgpu_scratch_enable_server
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, C.c_int, C.c_uint]
-        rv = f(self._h, int(bool(on)), int(idle_us))
+        rv = f(self._h, 2 if on == 2 else int(bool(on)), int(idle_us))
         if rv != 0:
             raise HsgpuError(rv, "hsgpu_scratch_enable_server")
 

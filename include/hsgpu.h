@@ -131,8 +131,12 @@ void hsgpu_scratch_free(hsgpu_scratch_t *s);
  * word in mapped page-locked memory: no launch, no copy command, no sleeping synchronisation. The workgroup ends by itself after
  * idle_us (default 300) without a request -- it holds a compute unit no longer than that after a burst of calls, and a device
  * synchronisation never waits longer for it -- and is started again by the next small call; any other scan on the scratch,
- * hsgpu_scratch_free and disabling end it at once. Off by default. hsgpu_scratch_server_stats: requests served, server
- * launches, whether one is resident right now (any pointer may be NULL). */
+ * hsgpu_scratch_free and disabling end it at once. Off by default. On a device whose memory the host can write (a large PCIe
+ * BAR: hipDeviceProp_t::isLargeBar) the request -- sequence number, parameters, offsets, bytes -- is written straight into device
+ * memory, so that the workgroup polls and reads locally; records, count and the done word come back through page-locked host
+ * memory either way. enable == 2 keeps the request in mapped host memory on every device (what a device without a large BAR
+ * does; the A/B). hsgpu_scratch_server_stats: requests served, server launches, whether one is resident right now (any pointer
+ * may be NULL). */
 int hsgpu_scratch_enable_server(hsgpu_scratch_t *s, int enable, unsigned idle_us /* 0: keep */);
 int hsgpu_scratch_server_stats(hsgpu_scratch_t *s, uint64_t *calls, uint64_t *launches, int *live);
 /* the last request's device-side times: the batch's copy over the bus, the scan itself (device wall clock, microseconds) */

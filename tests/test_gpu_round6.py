@@ -113,8 +113,11 @@ def test_hs_scan_batch_resident_equals_hs_scan_batch():
             assert a == b and len(a) > 100, (total, len(a), len(b))
 
 
-def test_small_batch_server_parity_lifetime_and_fallbacks():
-    """The small-batch server (include/hsgpu.h, hsgpu_scratch_enable_server; scan_device.h, hwlm_server_kernel): hwlm_exec and
+@pytest.mark.parametrize("mailbox", [1, 2])
+def test_small_batch_server_parity_lifetime_and_fallbacks(mailbox):
+    """(mailbox 1: the requests written into device memory through the PCIe BAR where the device has a large one; 2: through
+    mapped host memory.)
+    The small-batch server (include/hsgpu.h, hsgpu_scratch_enable_server; scan_device.h, hwlm_server_kernel): hwlm_exec and
     hwlm_exec_batch calls of up to 16 KiB served by ONE resident workgroup -- the same records as the launch path and as the
     oracle at every size up to its limit and beyond it (where the call falls back to a launch), over several table layouts; it
     ends by itself when idle and comes back with the next call; another table, another pipeline, a large scan on the same scratch
@@ -129,7 +132,7 @@ def test_small_batch_server_parity_lifetime_and_fallbacks():
     sets = {"teddy64": (random_literals(rng, 64, 4, 8, nocase_frac=0.2), 0), "mixed3000": (random_literals(rng, 3000, 1, 8, nocase_frac=0.3), 0),
             "fdr10k": (cp.snort_like_literals(10000, seed=4)[0], 0), "one": ([H.HwlmLiteral(b"needle", nocase=True, id=7)], 0)}
     s = H.Scratch(0)
-    s.enable_server(True, idle_us=2000)
+    s.enable_server(mailbox, idle_us=2000)
     plain = H.Scratch(0)
     served_before = 0
     for name, (lits, flags) in sets.items():
@@ -278,3 +281,32 @@ def test_flood_run_tables_full():
         key = (got["block"].astype(np.uint64) << np.uint64(32)) | got["end"].astype(np.uint64)
         assert np.all((key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (got["lit"][1:] > got["lit"][:-1]))), "delivery order"
     s.close()
+
+
+def test_small_batch_server_mailbox_switches():
+    """One scratch, the request mailbox switched between device memory (through the BAR) and mapped host memory and back with calls
+    in between, and across an idle exit: no request is lost, none is served twice (the sequence numbers of the two mailboxes are
+    brought together when a server starts: runtime.hip, server_start)."""
+    import time
+
+    from tests import oracle_binding as ob
+
+    rng = np.random.default_rng(5)
+    lits = random_literals(rng, 200, 4, 8)
+    t = H.hwlm_build(lits)
+    s = H.Scratch(0)
+    oracle = ob.Oracle(lits)
+    served = 0
+    for rnd, kind in enumerate([1, 2, 1, 1, 2, 2, 1]):
+        s.enable_server(kind, idle_us=400)
+        for k in range(7):
+            pkt = random_corpus(rng, int(rng.integers(16, 4000)), lits, plant_every=61)  # (a workgroup of 256 threads serves up to 4 KiB)
+            g = []
+            assert H.hwlm_exec(t, pkt, 0, lambda e, i, c: g.append((e, i)) or H.HWLM_CONTINUE_MATCHING, s) == H.HWLM_SUCCESS
+            assert sorted(g) == sorted(oracle.collect(pkt)), (rnd, kind, k)
+            served += 1
+            if k == 3 and rnd % 2:
+                time.sleep(0.01)  # the server ends by itself; the next call starts another
+        assert s.server_stats()[0] == served
+    s.close()
+    t.close()
