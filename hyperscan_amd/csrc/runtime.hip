@@ -503,6 +503,13 @@ extern "C" int hsgpu_scratch_server_last_us(hsgpu_scratch_t *s, float *copy_us, 
     return HSGPU_SUCCESS;
 }
 
+extern "C" int hsgpu_debug_server_stamps(hsgpu_scratch_t *s, float *us) {
+    if (!s || !s->h_srv || !us) return HSGPU_INVALID;
+    const volatile unsigned long long *st = (const volatile unsigned long long *)&s->h_srv->pad2[4];
+    for (int i = 0; i < 3; i++) us[i] = (float)(long long)(st[i + 1] - st[i]) / 100.f; /* 100 MHz ticks */
+    return HSGPU_SUCCESS;
+}
+
 extern "C" int hsgpu_scratch_server_stats(hsgpu_scratch_t *s, uint64_t *calls, uint64_t *launches, int *live) {
     if (!s) return HSGPU_INVALID;
     if (calls) *calls = s->srv_calls;

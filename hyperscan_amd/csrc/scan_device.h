@@ -1266,20 +1266,77 @@ __device__ __forceinline__ void solo_tail(const HsgpuScanArgs &args, uint32_t *l
 #ifndef HSGPU_FILTER_MIN_WAVES
 #define HSGPU_FILTER_MIN_WAVES 1 /* tuning builds: 8 caps the kernel at 64 VGPRs so that two 16-wavefront workgroups fit a CU */
 #endif
+__device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (block, end, literal index) */
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    return a.w < b.w;
+}
+
+/* Workgroup-convergent. A solo scan of ONE workgroup whose wavefronts still hold every record they found in their LDS staging
+ * (nothing flushed to a region, nothing spilled: the usual packet): the records ranked inside their wavefront's handful (a
+ * wavefront's records are those of one piece of the corpus) and written to where they go -- the wavefronts in front + the rank --
+ * and the count: one barrier, LDS reads, one store per record. false (uniform): somebody has flushed; the caller takes solo_tail.
+ * (solo_tail reads fills, regions and records back from memory: four dependent round trips of the 12 us a 1 460-byte request took.) */
+__device__ __forceinline__ bool solo_place_lds(const HsgpuScanArgs &args, WaveLds *wls, uint32_t W) {
+    __syncthreads(); /* every wavefront has confirmed its share */
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    /* every wavefront looks at all of them (<= 16; the same LDS words for every lane group: broadcasts) */
+    uint32_t my_n = 0, dirty = 0;
+    if (lane < W) {
+        const WaveLds *w = wls + lane;
+        my_n = __hip_atomic_load(&w->nrec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        dirty = (w->nfront | __hip_atomic_load(&w->nback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0 || my_n > (uint32_t)OCAP;
+    }
+    if (__ballot(dirty)) return false;
+    uint32_t incl = my_n;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += v;
+    }
+    const uint32_t all = __shfl(incl, (int)W - 1);
+    if (all > args.cap) return false; /* (solo_tail says "again" the way record_sort_kernel does) */
+    uint4 *out = (uint4 *)args.out;
+    /* a thread per staging slot: wavefront tid / 32, record tid % 32 (OCAP <= 32; the workgroup has 64 threads per wavefront) */
+    static_assert(OCAP <= 32, "a staging slot per half wavefront");
+    const uint32_t w = min(tid >> 5, W - 1u), j = tid & 31u;
+    const uint32_t n = __shfl(my_n, (int)w), at = __shfl(incl, (int)w) - n; /* (every wavefront holds every fill in its lanes 0 .. W - 1) */
+    if (tid < W * 32u && j < n) {
+        const uint4 rec = wls[w].rec[j];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; q++) {
+            const uint4 o = wls[w].rec[q];
+            rank += (rec_less(o, rec) || (q < j && !rec_less(rec, o))) ? 1u : 0u;
+        }
+        out[at + rank] = rec;
+    }
+    if (tid == 0) {
+        *args.count = all;
+        if (args.tstamp) { /* as solo_tail: one kernel, every stage ends here */
+            const unsigned long long now = wall_clock64();
+            args.tstamp[1] = now, args.tstamp[2] = now, args.tstamp[3] = now;
+            if (args.tstamp_next) args.tstamp_next[0] = ~0ull, args.tstamp_next[1] = 0, args.tstamp_next[2] = 0, args.tstamp_next[3] = 0;
+        }
+    }
+    return true;
+}
+
 /* The kernel's body as a function (round 6): hwlm_filter_kernel runs it once, hwlm_server_kernel -- a resident workgroup that
  * serves small host batches without a launch per call -- once per request. Every `return` below ends one scan. */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
-__device__ __forceinline__ void hwlm_filter_body(const HsgpuScanArgs &args, uint32_t *lds) {
+__device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint32_t *lds) {
+    /* -> true (uniform): solo_tail has used the head of the table image in LDS as its scratch (the server loads it again) */
     /* the fused kernel doubles as the overflow fallback: nothing to do unless the
      * two-phase pipeline ran out of candidate space */
     if (FUSED && args.cand_counts && !args.cand_counts[args.cand_waves]) {
         /* it runs right behind the confirm kernel: its start is the end of the confirm stage */
         if (args.tstamp && blockIdx.x == 0 && threadIdx.x == 0) args.tstamp[2] = wall_clock64();
-        return;
+        return false;
     }
+    bool image_used = false;
     if (FUSED && args.cand_counts && args.overflow_note && blockIdx.x == 0 && threadIdx.x == 0) *args.overflow_note = 1u;
     if ((!FUSED || args.solo) && args.tstamp && threadIdx.x == 0) atomicMin(&args.tstamp[0], (unsigned long long)wall_clock64());
-    if (!FUSED && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x] = wall_clock64();
+    if ((!FUSED || args.solo) && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x] = wall_clock64();
 
     const uint32_t flog2 = args.t_filter_log2;
     const uint32_t nw = (PAIR || WIDE) ? (2u << flog2) : REPL ? (32u << flog2) : (1u << flog2);
@@ -1431,7 +1488,7 @@ __device__ __forceinline__ void hwlm_filter_body(const HsgpuScanArgs &args, uint
     }
 #endif
     __syncthreads();
-    if (!FUSED && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x + 1] = wall_clock64();
+    if ((!FUSED || args.solo) && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x + 1] = wall_clock64();
 
     Tables t;
     uint32_t qcount = 0;
@@ -1572,8 +1629,14 @@ __device__ __forceinline__ void hwlm_filter_body(const HsgpuScanArgs &args, uint
             const uint64_t edge = holds_tail ? ((total & 1) ? 0 : total) : n_own ? (tile0 + n_own) << 10 : 0;
             if (edge) pair_edge_probe<false>(t, edge);
         }
-        publish_records(t, args, lane, wave_global);
-        if (args.solo) solo_tail(args, lds, n_waves);
+        if (args.solo && args.wg_stamps && wave == 0 && lane == 0) args.wg_stamps[4 * blockIdx.x + 2] = wall_clock64(); /* (wavefront 0's share confirmed) */
+        /* ONE workgroup (the small-batch server; a solo scan of one super tile) whose wavefronts have staged everything they found
+         * in LDS: placed from there (solo_place_lds) -- no region, no count and no control word goes through memory */
+        if (!(args.solo && gridDim.x == 1 && solo_place_lds(args, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)), WAVES))) {
+            publish_records(t, args, lane, wave_global);
+            if (args.solo) solo_tail(args, lds, n_waves), image_used = true;
+        }
+        if (args.solo && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x + 3] = wall_clock64();
     } else if (lane == 0) {
         args.cand_counts[wave_global] = sp.written;
         if (sp.overflow) args.cand_counts[n_waves] = 1;
@@ -1594,6 +1657,7 @@ __device__ __forceinline__ void hwlm_filter_body(const HsgpuScanArgs &args, uint
             if (args.wg_stamps) args.wg_stamps[4 * blockIdx.x + 3] = now;
         }
     }
+    return image_used;
 }
 
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
@@ -1694,8 +1758,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
         }
         const unsigned long long t_copied = wall_clock64();
         a.img_keep_words = img_keep;
-        hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, true, PAIR, WIDE>(a, lds);
-        img_keep = SOLO_LDS_WORDS; /* the table image stays in LDS between requests; solo_tail's scratch is its head */
+        a.wg_stamps = (unsigned long long *)&ctl->pad2[4]; /* the request's stages: start, image staged, wavefront 0 confirmed, placed (hsgpu_debug_server_stamps) */
+        const bool image_used = hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, true, PAIR, WIDE>(a, lds);
+        img_keep = image_used ? SOLO_LDS_WORDS : 1u; /* the table image stays in LDS between requests; solo_tail's scratch was its head (1: nothing to load) */
         /* every wavefront: its records (and the count) out to host memory, at SYSTEM scope. (A workgroup-scope release in front of
          * a relaxed done word was measured: the done word, another address and so another L2 channel, overtook the count -- the
          * host read the count it had put there itself and sent every call down the launch path.) */
@@ -1725,11 +1790,6 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
 constexpr uint32_t SORT_LDS = 1024; /* largest share sorted in LDS (16 KiB of records) */
 constexpr uint32_t SORT_THREADS = 256;
 
-__device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (block, end, literal index) */
-    if (a.x != b.x) return a.x < b.x;
-    if (a.y != b.y) return a.y < b.y;
-    return a.w < b.w;
-}
 
 /* normalized bitonic network (every comparator ascending) over n records at x; positions from n up to the
  * next power of two stand for records greater than all: a comparator that touches one is a no-op. One workgroup. */

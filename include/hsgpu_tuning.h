@@ -44,6 +44,11 @@ extern "C" {
  * choose (0 = its choice). */
 int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_threads, unsigned wg_per_cu);
 
+/* The small-batch server's last request on this scratch, stage by stage on the device (microseconds): us[0] request taken ->
+ * table image and first tiles in place, us[1] -> wavefront 0 has filtered and confirmed its share, us[2] -> records placed and count
+ * written. (hsgpu_scratch_server_last_us, include/hsgpu.h: the request as a whole.) */
+int hsgpu_debug_server_stamps(hsgpu_scratch_t *s, float *us /* [3] */);
+
 /* hsgpu_scratch_enable_timing(s, 2) also stamps every workgroup of the filter kernel (device wall clock); this returns the last
  * scan's stamps in milliseconds from the earliest start: out[4 w + {0 start, 1 image staged and hints written, 2 wavefront 0's
  * share streamed, 3 end}], w < min(*n_wgs, max_wgs). Synchronises the device. */
