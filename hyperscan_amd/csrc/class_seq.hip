@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -800,20 +801,32 @@ static int class_seq_scan(const hsgpu_class_seq_t *seqs, unsigned n_seqs, const 
         /* the header goes up from page-locked memory, a ring of four staging areas each with an event: a copy out of one is
          * awaited (that copy alone) before the area is written again. Round 4 kept a host copy per work-area pointer in a static
          * map -- never erased, and a changed header meant hipDeviceSynchronize(): a device-wide stall on a no-wait path (advisor). */
+        /* (round 6, advisor: the ring's one mutex was held across hipEventSynchronize -- with more than four scans in flight one
+         * caller's wait for another stream's copy held up every other caller. The ring's mutex now only hands out the next area;
+         * an area has its own, held from the wait to the record, so that a caller waits for the users of ITS area alone.) */
         struct Stage {
+            std::mutex m;
             uint8_t *p = nullptr;
             hipEvent_t ev = nullptr;
             bool used = false;
         };
+        struct Ring {
+            Stage st[4];
+            unsigned next = 0;
+        };
         static std::mutex mu;
-        static std::map<int, std::vector<Stage>> rings; /* per device */
-        static std::map<int, unsigned> next;
+        static std::map<int, std::unique_ptr<Ring>> rings; /* per device; process lifetime, like the device's context */
         int dev_now = 0;
         HIP_TRY(hipGetDevice(&dev_now));
-        std::lock_guard<std::mutex> lock(mu);
-        std::vector<Stage> &ring = rings[dev_now];
-        if (ring.empty()) ring.resize(4);
-        Stage &sg = ring[next[dev_now]++ % ring.size()];
+        Stage *sgp;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            std::unique_ptr<Ring> &ring = rings[dev_now];
+            if (!ring) ring.reset(new Ring());
+            sgp = &ring->st[ring->next++ % 4];
+        }
+        Stage &sg = *sgp;
+        std::lock_guard<std::mutex> area(sg.m);
         if (!sg.p) {
             HIP_TRY(hipHostMalloc((void **)&sg.p, SEQ_HEADER));
             HIP_TRY(hipEventCreateWithFlags(&sg.ev, hipEventDisableTiming));

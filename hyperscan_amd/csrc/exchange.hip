@@ -121,6 +121,7 @@ struct Transport {
     virtual int group_end() = 0;
     virtual int all_gather(const void *mine, void *all, size_t bytes, hipStream_t st) = 0; /* in place: mine == all + rank * bytes */
     virtual int before_use(hipStream_t) { return 0; } /* called before a rank touches its buffers again */
+    virtual int unmet_receives() { return 0; }         /* loopback: receives of this rank whose sender has not come by yet */
     virtual const char *name() const = 0;
 };
 
@@ -201,21 +202,28 @@ struct LoopTransport : Transport {
                                 is_send ? "sends" : "expects", bytes, peer, is_send ? "expects" : "sends", o.bytes);
                 return HSGPU_INVALID;
             }
-            if ((e = hipStreamWaitEvent(st, o.ready, 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
-            (void)hipEventDestroy(o.ready); /* (released once the wait has gone through) */
+            e = hipStreamWaitEvent(st, o.ready, 0);
+            (void)hipEventDestroy(o.ready); /* (the half has been taken off the queue: released on every path, once the wait has been queued) */
+            if (e != hipSuccess) return fail(e, "hipStreamWaitEvent");
             void *dst = is_send ? (void *)o.ptr : (void *)p;
             const void *src = is_send ? p : o.ptr;
             if ((e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e, "hipMemcpyAsync");
             hipEvent_t done;
             if ((e = hipEventCreateWithFlags(&done, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-            if ((e = hipEventRecord(done, st)) != hipSuccess) return fail(e, "hipEventRecord");
+            if ((e = hipEventRecord(done, st)) != hipSuccess) {
+                (void)hipEventDestroy(done);
+                return fail(e, "hipEventRecord");
+            }
             o.owner->wait_for.push_back(done);
             return 0;
         }
         LoopHub::Half h{is_send, p, bytes, nullptr, this};
         hipError_t e;
         if ((e = hipEventCreateWithFlags(&h.ready, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-        if ((e = hipEventRecord(h.ready, st)) != hipSuccess) return fail(e, "hipEventRecord");
+        if ((e = hipEventRecord(h.ready, st)) != hipSuccess) {
+            (void)hipEventDestroy(h.ready);
+            return fail(e, "hipEventRecord");
+        }
         q.push_back(h);
         return 0;
     }
@@ -238,11 +246,23 @@ struct LoopTransport : Transport {
             std::lock_guard<std::mutex> g(hub->mu);
             evs.swap(wait_for);
         }
+        int rv = 0;
         for (hipEvent_t e : evs) {
-            (void)hipStreamWaitEvent(st, e, 0);
+            const hipError_t err = hipStreamWaitEvent(st, e, 0);
+            if (err != hipSuccess && !rv) rv = fail(err, "hipStreamWaitEvent"); /* (the buffers may be in use by a copy nobody waits for: the caller must not go on) */
             (void)hipEventDestroy(e);
         }
-        return 0;
+        return rv;
+    }
+    /* Over RCCL a rank that gathers before its peers have sent BLOCKS; here nothing blocks, and a rank that compacted before
+     * every peer had called step() would read the previous step's slots. Its own receives still in the queue say so. */
+    int unmet_receives() override {
+        std::lock_guard<std::mutex> g(hub->mu);
+        int n = 0;
+        for (auto &kv : hub->pending)
+            if (kv.first.second == rank)
+                for (const auto &h : kv.second) n += (!h.is_send && h.owner == this) ? 1 : 0;
+        return n;
     }
     const char *name() const override { return "loopback"; }
 };
@@ -435,7 +455,8 @@ extern "C" int hsgpu_exchange_step(hsgpu_exchange_t *x, const void *d_records, u
     if (!x || !d_records || !d_count) return HSGPU_INVALID;
     HIP_TRY(hipSetDevice(x->device));
     hipStream_t st = (hipStream_t)stream;
-    if (x->tr) x->tr->before_use(st); /* loopback: copies other ranks posted on their streams out of / into this rank's buffers */
+    int rv;
+    if (x->tr && (rv = x->tr->before_use(st)) != HSGPU_SUCCESS) return rv; /* loopback: copies other ranks posted on their streams out of / into this rank's buffers */
     /* packed straight into its place where this rank also receives */
     uint8_t *mine = x->receives() ? x->slots + (uint64_t)x->rank * x->slot_bytes : x->send;
     const uint64_t my_rows = x->agreed.empty() ? x->rows : x->agreed[x->rank];
@@ -452,7 +473,7 @@ extern "C" int hsgpu_exchange_step(hsgpu_exchange_t *x, const void *d_records, u
     }
     /* point to point, all transfers of the step in one group: to the root, or (exact sizes) everybody to everybody. An error
      * inside the group still closes it: an open RCCL group would swallow the next call's transfers. */
-    int rv = T->group_start();
+    rv = T->group_start();
     if (rv) return rv;
     for (int r = 0; r < x->world && !rv; r++) {
         if (r == x->rank) continue;
@@ -471,7 +492,16 @@ extern "C" int hsgpu_exchange_compact(hsgpu_exchange_t *x, void *d_out, uint64_t
     if (!x->receives()) return HSGPU_SUCCESS; /* nothing arrives here: the root has it */
     HIP_TRY(hipSetDevice(x->device));
     hipStream_t st = (hipStream_t)stream;
-    if (x->tr) x->tr->before_use(st);
+    if (x->tr) {
+        const int unmet = x->tr->unmet_receives();
+        if (unmet) {
+            hsgpu_set_error("hsgpu_exchange_compact on rank %d before %d of its peers have called hsgpu_exchange_step: their slots hold the step before (over RCCL this call would block)",
+                            x->rank, unmet);
+            return HSGPU_INVALID;
+        }
+        const int rvb = x->tr->before_use(st);
+        if (rvb != HSGPU_SUCCESS) return rvb;
+    }
     hipLaunchKernelGGL(exchange_compact_kernel, dim3(256), dim3(256), 0, st, x->slots, x->slot_bytes, (uint32_t)x->world, (hsgpu_wire_t *)d_out, cap,
                        x->d_counts);
     HIP_TRY(hipGetLastError());

@@ -197,3 +197,26 @@ def test_sharded_scans_through_the_loopback_exchange_equal_one_scan(world):
     assert np.all(k[1:] >= k[:-1]), "rank order must be corpus order"
     for rk in ranks:
         rk[7].close()
+
+
+def test_loopback_compact_before_the_peers_have_stepped_is_an_error():
+    """Over RCCL a rank that gathers before its peers have sent blocks; the loopback transport blocks nobody, and a rank that
+    compacted early would read the slots of the step before (advisor, round 5). Its own receives still waiting for their senders say
+    so: hsgpu_exchange_compact refuses, and works once everybody has stepped."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    lid = hd.NativeExchange.loopback_id()
+    xs = [hd.NativeExchange(None, 3, r, dev, 500, 100 * r, mode=TO_ROOT, id_bytes=lid) for r in range(3)]
+    rng = np.random.default_rng(3)
+    data = [_fake_records(rng, 40 + r, 50, 508) for r in range(3)]
+    xs[0].step(data[0][0], data[0][1])  # the root: its receives are posted, nobody has sent
+    xs[1].step(data[1][0], data[1][1])
+    with pytest.raises(RuntimeError, match="before 1 of its peers"):
+        xs[0].compact()
+    xs[2].step(data[2][0], data[2][1])
+    out, got = xs[0].compact()
+    torch.cuda.synchronize()
+    assert got == [40, 41, 42] and out.shape[0] == 123
+    for x in xs:
+        x.close()
