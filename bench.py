@@ -1496,13 +1496,22 @@ def run_batch_sweep(args):
 
     def one_call():
         return lib.hsgpu_hwlm_exec(job.table._h, p_blk, n_blk, 0, count_cb, job.scratch._h, hw.HWLM_ALL_GROUPS)
+    lib.hsgpu_debug_exec_repeat.restype = C.c_int
+    lib.hsgpu_debug_exec_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, hw.HWLM_CB, C.c_void_p, C.c_uint64, C.c_uint, C.POINTER(C.c_double)]
+    ctypes_us = []
+
     def per_call(n=500):
+        """microseconds per hsgpu_hwlm_exec call from a NATIVE loop (include/hsgpu_tuning.h, hsgpu_debug_exec_repeat: hsbench's loop is
+        C++ too); the same through ctypes -- ~1 us more, the binding's own -- goes to ctypes_us"""
         for _ in range(5):
             assert one_call() == 0
         t0 = time.perf_counter()
         for _ in range(n):
             one_call()
-        return (time.perf_counter() - t0) / n * 1e6
+        ctypes_us.append(round((time.perf_counter() - t0) / n * 1e6, 1))
+        us = C.c_double(0)
+        assert lib.hsgpu_debug_exec_repeat(job.table._h, p_blk, n_blk, 0, count_cb, job.scratch._h, hw.HWLM_ALL_GROUPS, n, C.byref(us)) == 0
+        return us.value
     us_launch = per_call()  # a kernel launch per call (rounds 1-5)
     n_launch = ncb.value
     # ... and through the small-batch server (round 6, include/hsgpu.h): one resident workgroup, no launch per call
@@ -1511,7 +1520,7 @@ def run_batch_sweep(args):
     job.scratch.enable_server(2)
     ncb.value = 0
     us_host_mailbox = per_call(2000)
-    assert ncb.value * 505 == n_launch * 2005, "the server (mailbox in host memory) delivers other matches than the launch path"
+    assert ncb.value * 1005 == n_launch * 4005, "the server (mailbox in host memory) delivers other matches than the launch path"
     cu, su = C.c_float(), C.c_float()
     lib.hsgpu_scratch_server_last_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
@@ -1519,7 +1528,7 @@ def run_batch_sweep(args):
     job.scratch.enable_server(True)
     ncb.value = 0
     us_exec = per_call(2000)
-    assert ncb.value * 505 == n_launch * 2005, "the server delivers other matches than the launch path"
+    assert ncb.value * 1005 == n_launch * 4005, "the server delivers other matches than the launch path"
     calls, launches, _live = job.scratch.server_stats()
     lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
     job.scratch.enable_server(False)
@@ -1529,7 +1538,9 @@ def run_batch_sweep(args):
            "value": round(peak, 1), "unit": "GB/s at the largest batch",
            "us_per_hwlm_exec_call_1460B": round(us_exec, 1), "GBps_one_block_per_call": round(1460 / us_exec / 1e3, 4),
            "us_per_hwlm_exec_call_1460B_launch_path": round(us_launch, 1), "server": {"calls": calls, "launches": launches, "device_copy_us": round(cu.value, 2), "device_scan_us": round(su.value, 2),
-                                                                                     "us_per_call_mailbox_in_host_memory": round(us_host_mailbox, 1), "device_scan_us_mailbox_in_host_memory": round(su_host, 2)},
+                                                                                     "us_per_call_mailbox_in_host_memory": round(us_host_mailbox, 1), "device_scan_us_mailbox_in_host_memory": round(su_host, 2),
+                                                                                     "us_per_call_through_ctypes": {"launch": ctypes_us[0], "mailbox_in_host_memory": ctypes_us[1], "server": ctypes_us[2]},
+                                                                                     "measured": "a native loop of hsgpu_hwlm_exec calls (hsgpu_debug_exec_repeat), as hsbench's; through ctypes ~1 us more per call"},
            "half_peak_batch_bytes": reach(0.5), "ninety_percent_batch_bytes": reach(0.9), "curve": curve}
     del job
     torch.cuda.empty_cache()

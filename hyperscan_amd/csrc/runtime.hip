@@ -14,6 +14,8 @@
  * kernel launch per <= 2^36-byte corpus, fully asynchronous.
  */
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1096,6 +1098,18 @@ static bool bar_area(hsgpu_scratch *s) {
         if (p) (void)hipFree(p);
         return false;
     }
+    /* isLargeBar says the host can reach device memory; that THIS range is writable from here is asked of the kernel, without a
+     * signal handler: read(2) from /dev/zero into it fails with EFAULT where a store would fault */
+    bool writable = false;
+    const int zfd = open("/dev/zero", O_RDONLY | O_CLOEXEC);
+    if (zfd >= 0) {
+        writable = read(zfd, p, 64) == 64 && read(zfd, (uint8_t *)p + BAR_TOTAL - 64, 64) == 64;
+        (void)close(zfd);
+    }
+    if (!writable) {
+        (void)hipFree(p);
+        return false;
+    }
     s->bar_small = (uint8_t *)p;
     s->bar_ctl = (HsgpuServerCtl *)(s->bar_small + BAR_CTL_AT);
     s->bar_state = 1;
@@ -1877,6 +1891,20 @@ extern "C" int hsgpu_hwlm_exec(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t
     std::vector<hsgpu_match_t> recs;
     if (scan_host(t, s, buf, off, 1, start, recs) != HSGPU_SUCCESS) return HSGPU_HWLM_ERROR_UNKNOWN;
     return hsgpu_hwlm_replay(t, recs.data(), recs.size(), cb, ctx, groups);
+}
+
+/* hsgpu_hwlm_exec `calls` times from native code, the way hsbench walks its blocks (tools/hsbench/engine_hyperscan.cpp:132-145):
+ * what a C caller pays per call (a ctypes call costs ~1 us by itself). */
+extern "C" int hsgpu_debug_exec_repeat(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t len, size_t start, hsgpu_hwlm_cb cb, hsgpu_scratch_t *s,
+                                       uint64_t groups, unsigned calls, double *us_per_call) {
+    if (!calls || !us_per_call) return HSGPU_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned i = 0; i < calls; i++) {
+        const int rv = hsgpu_hwlm_exec(t, buf, len, start, cb, s, groups);
+        if (rv != HSGPU_HWLM_SUCCESS) return rv;
+    }
+    *us_per_call = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
+    return HSGPU_SUCCESS;
 }
 
 extern "C" int hsgpu_hwlm_exec_resident(const hsgpu_hwlm_t *t, hsgpu_scratch_t *s, const void *d_corpus, uint64_t total_bytes,

@@ -48,6 +48,11 @@ int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_thr
  * table image and first tiles in place, us[1] -> wavefront 0 has filtered and confirmed its share, us[2] -> records placed and count
  * written. (hsgpu_scratch_server_last_us, include/hsgpu.h: the request as a whole.) */
 int hsgpu_debug_server_stamps(hsgpu_scratch_t *s, float *us /* [3] */);
+/* hsgpu_hwlm_exec `calls` times in a row from native code, as hsbench walks its blocks (tools/hsbench/engine_hyperscan.cpp:132-145);
+ * *us_per_call = the mean: what a C caller pays per call (a Python ctypes call costs ~1 us by itself). Stops at the first call
+ * that does not return HSGPU_HWLM_SUCCESS and returns its code. */
+int hsgpu_debug_exec_repeat(const hsgpu_hwlm_t *t, const uint8_t *buf, size_t len, size_t start, hsgpu_hwlm_cb cb, hsgpu_scratch_t *s,
+                            uint64_t groups, unsigned calls, double *us_per_call);
 
 /* hsgpu_scratch_enable_timing(s, 2) also stamps every workgroup of the filter kernel (device wall clock); this returns the last
  * scan's stamps in milliseconds from the earliest start: out[4 w + {0 start, 1 image staged and hints written, 2 wavefront 0's
