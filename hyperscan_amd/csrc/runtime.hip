@@ -500,14 +500,14 @@ extern "C" int hsgpu_scratch_enable_server(hsgpu_scratch_t *s, int enable, unsig
 
 extern "C" int hsgpu_scratch_server_last_us(hsgpu_scratch_t *s, float *copy_us, float *scan_us) {
     if (!s || !s->h_srv) return HSGPU_INVALID;
-    if (copy_us) *copy_us = (float)s->h_srv->pad2[2] / 100.f; /* 100 MHz ticks */
-    if (scan_us) *scan_us = (float)s->h_srv->pad2[3] / 100.f;
+    if (copy_us) *copy_us = (float)s->h_srv->done_copy_ticks / 100.f; /* 100 MHz ticks */
+    if (scan_us) *scan_us = (float)s->h_srv->done_body_ticks / 100.f;
     return HSGPU_SUCCESS;
 }
 
 extern "C" int hsgpu_debug_server_stamps(hsgpu_scratch_t *s, float *us) {
     if (!s || !s->h_srv || !us) return HSGPU_INVALID;
-    const volatile unsigned long long *st = (const volatile unsigned long long *)&s->h_srv->pad2[4];
+    const volatile unsigned long long *st = (const volatile unsigned long long *)s->h_srv->stamps;
     for (int i = 0; i < 3; i++) us[i] = (float)(long long)(st[i + 1] - st[i]) / 100.f; /* 100 MHz ticks */
     return HSGPU_SUCCESS;
 }
@@ -569,6 +569,7 @@ static int solo_setup(hsgpu_scratch *s, HsgpuScanArgs &args, uint64_t total, uin
     args.conf_spread = 0, args.conf_skew = 0;
     args.run_tab = nullptr;
     args.img_keep_words = 0;
+    args.srv_inline_at = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     args.cand = nullptr;
     args.cand_cap = 0;
@@ -785,6 +786,7 @@ static int launch_scan(const hsgpu_hwlm *t, hsgpu_scratch *s, const HsgpuScanArg
     args.conf_spread = 0, args.conf_skew = 0;
     args.run_tab = nullptr;
     args.img_keep_words = 0;
+    args.srv_inline_at = 0;
     args.conf_cus = (uint32_t)std::max(1, s->n_cu);
     if (two_phase) {
         /* The confirm kernel's partition: share = one filter wavefront's candidates, cut into Q parts, K consecutive parts per
@@ -1123,7 +1125,7 @@ static int server_start(const hsgpu_hwlm *t, hsgpu_scratch *s) {
     const void *f = hsgpu_server_kernel_for(h->flags);
     if (!f || !s->d_small || !s->d_note) return 1;
     const unsigned wg_threads = filter_wg_threads(h, s, nullptr);
-    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads) + 64; /* + the mailbox */
+    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads) + 128; /* + the mailbox and the answer line */
     if (lds > s->lds_per_cu || (size_t)hsgpu_filter_words(h->flags, h->filter_log2) * 4 < 28 * 1024) return 1;
     if (!s->h_srv) {
         if (hipHostMalloc((void **)&s->h_srv, sizeof(HsgpuServerCtl), hipHostMallocMapped) != hipSuccess ||
@@ -1269,6 +1271,13 @@ static int scan_host_small(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t 
     s->res_corpus = d_area + SMALL_CORPUS_AT, s->res_off = d_area + SMALL_OFF_AT;
     if (served && (rv = server_call(t, s, total, nblocks, start)) < 0) return rv;
     if (served) {
+        /* the answer line (HsgpuServerCtl): up to three records came with the sequence number; ~0: count and records are in the mapped area */
+        const uint32_t n_line = *(volatile uint32_t *)&s->h_srv->done_count;
+        if (n_line <= HSGPU_SRV_INLINE_RECS) {
+            recs.resize(n_line);
+            if (n_line) memcpy(recs.data(), (const void *)s->h_srv->done_rec, n_line * sizeof(hsgpu_match_t));
+            return HSGPU_SUCCESS;
+        }
         const uint64_t n = *(volatile unsigned long long *)s->h_small;
         if (n <= SMALL_RECS) {
             recs.resize(n);

@@ -1277,7 +1277,7 @@ __device__ __forceinline__ bool rec_less(const uint4 a, const uint4 b) { /* (blo
  * wavefront's records are those of one piece of the corpus) and written to where they go -- the wavefronts in front + the rank --
  * and the count: one barrier, LDS reads, one store per record. false (uniform): somebody has flushed; the caller takes solo_tail.
  * (solo_tail reads fills, regions and records back from memory: four dependent round trips of the 12 us a 1 460-byte request took.) */
-__device__ __forceinline__ bool solo_place_lds(const HsgpuScanArgs &args, WaveLds *wls, uint32_t W) {
+__device__ __forceinline__ bool solo_place_lds(const HsgpuScanArgs &args, WaveLds *wls, uint32_t W, uint32_t *inl = nullptr) {
     __syncthreads(); /* every wavefront has confirmed its share */
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     /* every wavefront looks at all of them (<= 16; the same LDS words for every lane group: broadcasts) */
@@ -1296,6 +1296,9 @@ __device__ __forceinline__ bool solo_place_lds(const HsgpuScanArgs &args, WaveLd
     }
     const uint32_t all = __shfl(incl, (int)W - 1);
     if (all > args.cap) return false; /* (solo_tail says "again" the way record_sort_kernel does) */
+    /* the small-batch server's answer line (HsgpuServerCtl, scan_kernels.h): <= HSGPU_SRV_INLINE_RECS records stay in LDS, where the
+     * server's wavefront 0 picks them up and sends records, count and sequence number in ONE store */
+    const bool to_line = inl != nullptr && all <= (uint32_t)HSGPU_SRV_INLINE_RECS;
     uint4 *out = (uint4 *)args.out;
     /* a thread per staging slot: wavefront tid / 32, record tid % 32 (OCAP <= 32; the workgroup has 64 threads per wavefront) */
     static_assert(OCAP <= 32, "a staging slot per half wavefront");
@@ -1308,10 +1311,12 @@ __device__ __forceinline__ bool solo_place_lds(const HsgpuScanArgs &args, WaveLd
             const uint4 o = wls[w].rec[q];
             rank += (rec_less(o, rec) || (q < j && !rec_less(rec, o))) ? 1u : 0u;
         }
-        out[at + rank] = rec;
+        if (to_line) ((uint4 *)inl)[at + rank] = rec;
+        else out[at + rank] = rec;
     }
     if (tid == 0) {
-        *args.count = all;
+        if (to_line) inl[12] = all, inl[15] = 1u;
+        else *args.count = all;
         if (args.tstamp) { /* as solo_tail: one kernel, every stage ends here */
             const unsigned long long now = wall_clock64();
             args.tstamp[1] = now, args.tstamp[2] = now, args.tstamp[3] = now;
@@ -1632,7 +1637,7 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
         if (args.solo && args.wg_stamps && wave == 0 && lane == 0) args.wg_stamps[4 * blockIdx.x + 2] = wall_clock64(); /* (wavefront 0's share confirmed) */
         /* ONE workgroup (the small-batch server; a solo scan of one super tile) whose wavefronts have staged everything they found
          * in LDS: placed from there (solo_place_lds) -- no region, no count and no control word goes through memory */
-        if (!(args.solo && gridDim.x == 1 && solo_place_lds(args, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)), WAVES))) {
+        if (!(args.solo && gridDim.x == 1 && solo_place_lds(args, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)), WAVES, args.srv_inline_at ? lds + args.srv_inline_at : nullptr))) {
             publish_records(t, args, lane, wave_global);
             if (args.solo) solo_tail(args, lds, n_waves), image_used = true;
         }
@@ -1691,14 +1696,14 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
                                                                                             const uint4 *src_off) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
-    /* the mailbox sits behind everything the body uses (runtime.hip sizes the launch: hsgpu_filter_lds_bytes + 64) */
+    /* the mailbox sits behind everything the body uses (runtime.hip sizes the launch: hsgpu_filter_lds_bytes + 128) */
     const uint32_t words = (uint32_t)(hsgpu_filter_words(args.t_flags, args.t_filter_log2) + ((args.t_flags & HSGPU_F_HAS_C) ? 2048u : 0u)) +
                            (uint32_t)((blockDim.x >> 6) * sizeof(WaveLds) / 4);
-    volatile uint32_t *mail = lds + words; /* [0] seq, [1] command (0 go, 1 end), [2..7] total, nblocks, start */
+    volatile uint32_t *mail = lds + words; /* [0] seq, [1] command (0 go, 1 end), [2..7] total, nblocks, start; [16..31] the answer line */
     /* Everything around the barriers is WAVE-UNIFORM control flow (scalar branches on values made scalar with readfirstlane):
-     * wavefront 0 polls as a whole -- 64 lanes, one address, one request. (The first version polled in `if (threadIdx.x == 0)`,
-     * a thread-divergent loop in front of the barrier: the structurised code ran the loop's barriers a different number of times
-     * in wavefront 0 and in the others, and the workgroup hung one barrier apart.) */
+     * wavefront 0 polls as a whole. (The first version polled in `if (threadIdx.x == 0)`, a thread-divergent loop in front of
+     * the barrier: the structurised code ran the loop's barriers a different number of times in wavefront 0 and in the others,
+     * and the workgroup hung one barrier apart.) */
     const bool leader = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t last = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
@@ -1706,28 +1711,26 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
     for (;;) {
         if (leader) {
             const unsigned long long t0 = wall_clock64();
-            uint32_t cmd = 0, seq = last;
+            uint32_t cmd = 0, seq = last, line;
             for (;;) {
-                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&req->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) { /* first: nothing outranks it */
+                /* ONE read per poll: the request line, a dword per lane (16 lanes, one 64-byte request): stop, the sequence number
+                 * and the parameters, which the host wrote BEFORE the number -- a read that brings the new number brings them */
+                line = __hip_atomic_load((uint32_t *)req + (lane & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (__builtin_amdgcn_readlane(line, 1)) { /* stop first: nothing outranks it */
                     cmd = 1;
                     break;
                 }
-                seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&req->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+                seq = __builtin_amdgcn_readlane(line, 0);
                 if (seq != last) break;
                 if (wall_clock64() - t0 > idle_ticks) {
                     cmd = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
             }
-            uint32_t p[6] = {0, 0, 0, 0, 0, 0};
-            if (!cmd) { /* (the parameters were written before the sequence number: read after it) */
-                const unsigned long long tot = __hip_atomic_load(&req->total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned long long nb = __hip_atomic_load(&req->nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned long long st = __hip_atomic_load(&req->start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                p[0] = (uint32_t)tot, p[1] = (uint32_t)(tot >> 32), p[2] = (uint32_t)nb, p[3] = (uint32_t)(nb >> 32), p[4] = (uint32_t)st, p[5] = (uint32_t)(st >> 32);
-            }
-            if (lane < 8) mail[lane] = lane == 0 ? seq : lane == 1 ? cmd : p[(lane - 2) % 6]; /* (every lane holds the same values) */
+            /* (HsgpuServerCtl: dwords 2 .. 7 = total, nblocks, start) */
+            if (lane < 8) mail[lane] = lane == 0 ? seq : lane == 1 ? cmd : cmd ? 0u : line;
+            if (lane == 31) mail[lane] = 0; /* the answer line's "records inside" flag (solo_place_lds) */
         }
         __syncthreads();
         const uint32_t seq = __builtin_amdgcn_readfirstlane(mail[0]), cmd = __builtin_amdgcn_readfirstlane(mail[1]);
@@ -1758,21 +1761,36 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
         }
         const unsigned long long t_copied = wall_clock64();
         a.img_keep_words = img_keep;
-        a.wg_stamps = (unsigned long long *)&ctl->pad2[4]; /* the request's stages: start, image staged, wavefront 0 confirmed, placed (hsgpu_debug_server_stamps) */
+        a.srv_inline_at = words + 16;
+        a.wg_stamps = ctl->stamps; /* the request's stages: start, image staged, wavefront 0 confirmed, placed (hsgpu_debug_server_stamps) */
         const bool image_used = hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, true, PAIR, WIDE>(a, lds);
         img_keep = image_used ? SOLO_LDS_WORDS : 1u; /* the table image stays in LDS between requests; solo_tail's scratch was its head (1: nothing to load) */
-        /* every wavefront: its records (and the count) out to host memory, at SYSTEM scope. (A workgroup-scope release in front of
-         * a relaxed done word was measured: the done word, another address and so another L2 channel, overtook the count -- the
-         * host read the count it had put there itself and sent every call down the launch path.) */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __syncthreads();
+        const uint32_t inlined = __builtin_amdgcn_readfirstlane(mail[31]);
+        if (!inlined) {
+            /* records and count went to the mapped area: every wavefront's out at SYSTEM scope before the answer line. (A
+             * workgroup-scope release in front of a relaxed done word was measured: the done word, another address and so another
+             * L2 channel, overtook the count -- the host read the count it had put there itself and sent every call down the
+             * launch path.) */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __syncthreads();
+        }
         if (leader) {
+            /* the answer: records (from LDS, <= 3), count (~0: in the mapped area), the request's stamps (100 MHz ticks: copy,
+             * body) and the sequence number, the line's LAST dword: four lanes x 16 bytes, one store instruction, one 64-byte
+             * write -- the 2.4 us of write-back and wait that a release in front of a separate done word cost are gone */
             const unsigned long long t_end = wall_clock64();
-            if (lane == 0) { /* stamps of the request, 100 MHz ticks: copy, body (hsgpu_scratch_server_stats) */
-                __hip_atomic_store(&ctl->pad2[2], (uint32_t)(t_copied - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&ctl->pad2[3], (uint32_t)(t_end - t_copied), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v;
+            if (lane < 3) {
+                v[0] = mail[16 + 4 * lane], v[1] = mail[17 + 4 * lane], v[2] = mail[18 + 4 * lane], v[3] = mail[19 + 4 * lane];
+            } else {
+                v[0] = inlined ? mail[28] : ~0u, v[1] = (uint32_t)(t_copied - t_seen), v[2] = (uint32_t)(t_end - t_copied), v[3] = seq;
             }
-            __hip_atomic_store(&ctl->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); /* (64 lanes, one word, one value) */
+            if (lane < 4) {
+                u32x4 *dst = (u32x4 *)ctl->done_rec + lane;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            }
         }
         last = seq;
     }

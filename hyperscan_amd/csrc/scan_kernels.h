@@ -91,6 +91,7 @@ struct HsgpuScanArgs {
     uint32_t solo;
     uint32_t solo_ctl_words;    /* words of the control block that starts at rec_counts (rec_counts | rec_super | ticket) */
     uint32_t *solo_ticket;
+    uint32_t srv_inline_at;     /* ... inside the small-batch server: LDS word index of the 16-word answer line a scan with <= HSGPU_SRV_INLINE_RECS records leaves its records and count in (0: none) */
     uint32_t img_keep_words;    /* fused kernel's body inside the small-batch server: the table image is in LDS already but for its first img_keep_words words (0: load all of it) */
     unsigned long long *wg_stamps;   /* tuning (hsgpu_scratch_enable_timing(s, 2)): [filter grid][4] device wall clock per
                                       * workgroup: start, image staged / hints written, wavefront 0's share done, end */
@@ -98,17 +99,34 @@ struct HsgpuScanArgs {
                                       * [worker][4]: start, fresh steps | rest steps << 16 | sorted drains << 32, entries, end */
 };
 
-/* the small-batch server's mailbox in mapped page-locked host memory (scan_device.h, hwlm_server_kernel; runtime.hip, server_call) */
+/* the small-batch server's mailbox (scan_device.h, hwlm_server_kernel; runtime.hip, server_call): four 64-byte lines.
+ *   line 0  host -> device, the WHOLE request: the workgroup's poll is ONE 64-byte read (a dword per lane) that brings the
+ *           parameters with the sequence number (the host writes them first: a read that sees the new number sees them)
+ *   line 2  device -> host, the WHOLE answer of a request with <= HSGPU_SRV_INLINE_RECS records: records, count, stamps and the
+ *           sequence number LAST, written by ONE store instruction (four lanes x 16 bytes = one 64-byte write over the bus, whose
+ *           bytes land in address order) -- nothing else has to be ordered in front of it. done_count = ~0: count and records
+ *           are in the scratch's mapped area as before (released at system scope in front of this line)
+ *   line 3  exited and the debug stamps */
+#define HSGPU_SRV_INLINE_RECS 3
 struct HsgpuServerCtl {
-    uint32_t req_seq, stop, pad0[14];             /* host -> device */
-    uint64_t total, nblocks, start, pad1[5];      /* ... the request (written before req_seq) */
-    uint32_t done_seq, exited, pad2[14];          /* device -> host */
+    uint32_t req_seq, stop;                       /* host -> device */
+    uint64_t total, nblocks, start;               /* ... the request (written before req_seq) */
+    uint32_t pad0[8];
+    uint64_t pad1[8];
+    uint32_t done_rec[4 * HSGPU_SRV_INLINE_RECS]; /* device -> host: hsgpu_match_t x 3 */
+    uint32_t done_count, done_copy_ticks, done_body_ticks, done_seq;
+    uint32_t exited, pad3;
+    unsigned long long stamps[4];                 /* hsgpu_debug_server_stamps */
+    uint32_t pad4[6];
 };
+static_assert(sizeof(HsgpuServerCtl) == 256 && offsetof(HsgpuServerCtl, done_rec) == 128 && offsetof(HsgpuServerCtl, done_seq) == 188 &&
+                  offsetof(HsgpuServerCtl, exited) == 192,
+              "the request is line 0, the answer line 2 with its sequence number last");
 
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
 /* the resident small-batch server with the fused kernel's body (scan_device.h, hwlm_server_kernel; nullptr: none for this table):
  * launched with (HsgpuScanArgs, HsgpuServerCtl *ctl, HsgpuServerCtl *req, unsigned long long idle_ticks, const uint4 *src_corpus, const uint4 *src_off), ONE
- * workgroup, hsgpu_filter_lds_bytes(fused) + 64 of LDS; src_*: where the host puts a request's batch (mapped memory) -- copied to
+ * workgroup, hsgpu_filter_lds_bytes(fused) + 128 of LDS; src_*: where the host puts a request's batch (mapped memory) -- copied to
  * args.corpus / args.off (device memory) at the head of every request */
 const void *hsgpu_server_kernel_for(uint32_t table_flags);
 const void *hsgpu_confirm_kernel_for(uint32_t table_flags, bool dense); /* dense: the folded pipeline's kernel for dense scans (fold == 2) */
