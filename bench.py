@@ -1523,14 +1523,24 @@ def run_batch_sweep(args):
     assert ncb.value * 1005 == n_launch * 4005, "the server (mailbox in host memory) delivers other matches than the launch path"
     cu, su = C.c_float(), C.c_float()
     lib.hsgpu_scratch_server_last_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
+    lib.hsgpu_debug_server_stamping.argtypes = [C.c_void_p, C.c_int]
+
+    def device_times():
+        """the request's device-side times: taken only while stamping is on (a stamp is a clock read the workgroup waits for), so a
+        few calls of their own behind the timed ones"""
+        lib.hsgpu_debug_server_stamping(job.scratch._h, 1)
+        for _ in range(20):
+            assert one_call() == 0
+        lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
+        lib.hsgpu_debug_server_stamping(job.scratch._h, 0)
+    device_times()
     su_host = su.value
     job.scratch.enable_server(True)
     ncb.value = 0
     us_exec = per_call(2000)
     assert ncb.value * 1005 == n_launch * 4005, "the server delivers other matches than the launch path"
     calls, launches, _live = job.scratch.server_stats()
-    lib.hsgpu_scratch_server_last_us(job.scratch._h, C.byref(cu), C.byref(su))
+    device_times()
     job.scratch.enable_server(False)
     lib.hsgpu_scratch_set_context(job.scratch._h, None)
     res = {"workload": "fdr10k table; resident scans of the first N bytes of the 1 GiB corpus, serial launches (hsgpu_hwlm_scan_dev), and one "

@@ -188,6 +188,7 @@ struct hsgpu_scratch {
     int bar_state = 0;          /* 0 not tried, 1 in use, -1 none (no large BAR, guard-page mode, or asked for: enable == 2) */
     bool srv_req_bar = false;   /* the live server reads its requests from bar_small */
     bool srv_host_mailbox = false; /* hsgpu_scratch_enable_server(s, 2, ..): the A/B */
+    bool srv_debug = false;        /* hsgpu_debug_server_stamping: the requests ask for their stage stamps */
     const hsgpu_hwlm *srv_table = nullptr;
     uint32_t srv_seq = 0;
     unsigned srv_idle_us = 300; /* an idle server ends after this long: nothing it holds outlives a burst of calls by more */
@@ -505,10 +506,25 @@ extern "C" int hsgpu_scratch_server_last_us(hsgpu_scratch_t *s, float *copy_us, 
     return HSGPU_SUCCESS;
 }
 
+extern "C" int hsgpu_debug_server_stamping(hsgpu_scratch_t *s, int on) {
+    if (!s) return HSGPU_INVALID;
+    s->srv_debug = on != 0;
+    return HSGPU_SUCCESS;
+}
+
 extern "C" int hsgpu_debug_server_stamps(hsgpu_scratch_t *s, float *us) {
     if (!s || !s->h_srv || !us) return HSGPU_INVALID;
     const volatile unsigned long long *st = (const volatile unsigned long long *)s->h_srv->stamps;
     for (int i = 0; i < 3; i++) us[i] = (float)(long long)(st[i + 1] - st[i]) / 100.f; /* 100 MHz ticks */
+    return HSGPU_SUCCESS;
+}
+
+/* ... and, from the body's start: us[0] -> the first loads are out, us[1] -> the wavefront stands in front of the body's first barrier */
+extern "C" int hsgpu_debug_server_head_stamps(hsgpu_scratch_t *s, float *us) {
+    if (!s || !s->h_srv || !us) return HSGPU_INVALID;
+    const volatile unsigned long long *st = (const volatile unsigned long long *)s->h_srv->stamps;
+    us[0] = (float)(long long)(st[4] - st[0]) / 100.f;
+    us[1] = (float)(long long)(st[5] - st[0]) / 100.f;
     return HSGPU_SUCCESS;
 }
 
@@ -1125,7 +1141,7 @@ static int server_start(const hsgpu_hwlm *t, hsgpu_scratch *s) {
     const void *f = hsgpu_server_kernel_for(h->flags);
     if (!f || !s->d_small || !s->d_note) return 1;
     const unsigned wg_threads = filter_wg_threads(h, s, nullptr);
-    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads) + 128; /* + the mailbox and the answer line */
+    const size_t lds = hsgpu_filter_lds_bytes(h->flags, h->filter_log2, true, wg_threads) + 192; /* + the mailbox, the answer line and the stage stamps */
     if (lds > s->lds_per_cu || (size_t)hsgpu_filter_words(h->flags, h->filter_log2) * 4 < 28 * 1024) return 1;
     if (!s->h_srv) {
         if (hipHostMalloc((void **)&s->h_srv, sizeof(HsgpuServerCtl), hipHostMallocMapped) != hipSuccess ||
@@ -1160,7 +1176,7 @@ static int server_start(const hsgpu_hwlm *t, hsgpu_scratch *s) {
     if (s->srv_req_bar) { /* (a request written for a server that went idle before it saw it is served by this one: same words) */
         HsgpuServerCtl *q = (HsgpuServerCtl *)(s->bar_small + BAR_CTL_AT);
         q->req_seq = s->h_srv->req_seq;
-        q->total = s->h_srv->total, q->nblocks = s->h_srv->nblocks, q->start = s->h_srv->start;
+        q->total = s->h_srv->total, q->nblocks = s->h_srv->nblocks, q->start = s->h_srv->start, q->debug = s->h_srv->debug;
     }
     server_req(s)->stop = 0;
     bar_flush();
@@ -1205,8 +1221,8 @@ static int server_call(const hsgpu_hwlm *t, hsgpu_scratch *s, uint64_t total, si
     int rv;
     HsgpuServerCtl *c = s->h_srv, *q = server_req(s);
     const uint32_t seq = ++s->srv_seq;
-    if (q != c) c->total = total, c->nblocks = nblocks, c->start = start, c->req_seq = seq; /* (what a restarted server is told: server_start) */
-    q->total = total, q->nblocks = nblocks, q->start = start;
+    if (q != c) c->total = total, c->nblocks = nblocks, c->start = start, c->debug = s->srv_debug, c->req_seq = seq; /* (what a restarted server is told: server_start) */
+    q->total = total, q->nblocks = nblocks, q->start = start, q->debug = s->srv_debug;
     bar_flush(); /* the batch (scan_host_small) and the parameters are out before the sequence number */
     __atomic_store_n(&q->req_seq, seq, __ATOMIC_RELEASE);
     bar_flush();

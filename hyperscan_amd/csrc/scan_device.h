@@ -1329,7 +1329,11 @@ __device__ __forceinline__ bool solo_place_lds(const HsgpuScanArgs &args, WaveLd
 /* The kernel's body as a function (round 6): hwlm_filter_kernel runs it once, hwlm_server_kernel -- a resident workgroup that
  * serves small host batches without a launch per call -- once per request. Every `return` below ends one scan. */
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool FUSED, bool PAIR = false, bool WIDE = false>
-__device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint32_t *lds) {
+__device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint32_t *lds, const uint32_t bdim, const uint32_t gdim) {
+    /* bdim / gdim: bdim / gdim, handed in. (They are loads -- of the dispatch packet or the hidden kernel arguments, both
+     * in HOST memory -- that the compiler repeats rather than keeps: inside the small-batch server's loop, behind the request's
+     * acquire, that was a read over the bus in front of the first tile's loads, ~1.5 us of every request. The server reads them
+     * once, in front of its loop.) */
     /* -> true (uniform): solo_tail has used the head of the table image in LDS as its scratch (the server loads it again) */
     /* the fused kernel doubles as the overflow fallback: nothing to do unless the
      * two-phase pipeline ran out of candidate space */
@@ -1350,8 +1354,8 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t WAVES = blockDim.x >> 6;           /* 16 or 8 */
-    const uint32_t n_waves = gridDim.x * WAVES;
+    const uint32_t WAVES = bdim >> 6;           /* 16 or 8 */
+    const uint32_t n_waves = gdim * WAVES;
     const uint32_t wave_global = blockIdx.x * WAVES + wave;
 
     const uint8_t *corpus = args.corpus;
@@ -1361,7 +1365,11 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
      * records found in a wavefront's candidates are then the records of one corpus range: delivery order
      * costs one small sort per share instead of a global one (phase 3). */
     const uint64_t n_full = total >> 10; /* 1 KiB tiles with every load in bounds */
-    const uint64_t per_wave = (n_full + n_waves - 1) / n_waves;
+    /* (the fused body -- solo scans, the small-batch server -- in 32-bit arithmetic: a corpus has at most 2^26 tiles, and the two
+     * 64-bit divisions were ~1.3 us of dependent instructions in front of the first load of a 6.5 us request) */
+    const uint64_t per_wave = FUSED ? (uint64_t)(((uint32_t)n_full + n_waves - 1) / n_waves) : (n_full + n_waves - 1) / n_waves;
+    /* the wavefront whose share would hold tile n_full, the partial last one (the last wavefront when the shares come out even) */
+    const uint64_t tail_wave = !per_wave ? 0 : FUSED ? (uint64_t)min(n_waves - 1, (uint32_t)n_full / (uint32_t)per_wave) : min((uint64_t)n_waves - 1, n_full / per_wave);
     /* The share as wave-uniform SCALARS: its first tile (64-bit) and the number of tiles in it (32-bit; a share of
      * 2^32 tiles would be 4 TiB). The 64-bit division above leaves its result in vector registers; with `tile` and
      * `tile_end` taken from there every stage of the loop below paid three 64-bit vector compares and two 64-bit moves
@@ -1420,7 +1428,7 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
     uint4 img[IMG];
 #pragma unroll
     for (int u = 0; u < IMG; u++) {
-        const uint32_t i = threadIdx.x + u * blockDim.x;
+        const uint32_t i = threadIdx.x + u * bdim;
         img[u] = i < nw_load / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
     }
 #ifndef HSGPU_HINTS_LATE
@@ -1451,12 +1459,28 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
         c5 = issue(5), c6 = issue(6);
 #endif
     }
+    /* The small-batch server (its batch ends in 16 zero bytes wherever it lies: runtime.hip, scan_host_small): the partial last tile
+     * is asked for HERE, beside the first tiles, with whole 16-byte loads -- behind the streaming loop it was a memory round trip of
+     * its own plus a byte-wise loop for the lane that holds the corpus' end (1.3 us of a 6.5 us request: the other wavefronts
+     * waited for this one at the placement's barrier). */
+    Chunk ct;
+    ct.d = make_uint4(0, 0, 0, 0);
+    ct.h = make_uint2(0, 0);
+    const bool tail_early = FUSED && args.srv_inline_at != 0;
+    if (tail_early && (total & 1023) && wave_global == tail_wave) {
+        const uint64_t coff = (n_full << 10) + lane_off;
+        if (coff < total) {
+            ct.d = *(const uint4 *)(corpus + coff);
+            if (coff) ct.h = *(const uint2 *)(corpus + coff - 8);
+        }
+    }
+    if (FUSED && args.srv_inline_at && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4] = wall_clock64(); /* (server: the loads are out) */
     if (FUSED && args.solo) {
         /* solo scans: no kernel ran in front of this one, so every wavefront writes the block hints of its OWN tiles (and of the
          * boundary behind them: block_of reads hint[tile] and hint[tile + 1]) before it needs them -- a wave-wide search each, two
          * dependent rounds, behind the image and corpus loads already in flight. (Resolving matches by plain bisection was 11
          * dependent loads per match: a 1 MiB solo scan took 61 us against the three kernels' 33.) */
-        const bool owns_tail = (total & 1023) && wave_global == (per_wave ? min((uint64_t)n_waves - 1, n_full / per_wave) : 0);
+        const bool owns_tail = (total & 1023) && wave_global == tail_wave;
         if (n_own || owns_tail) {
             const uint64_t t_last = min(tile0 + n_own, args.n_hint - 1);
             for (uint64_t tt = tile0; tt <= t_last; tt++) {
@@ -1470,13 +1494,13 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
     /* the filter image into LDS: once per workgroup */
 #pragma unroll
     for (int u = 0; u < IMG; u++) {
-        const uint32_t i = threadIdx.x + u * blockDim.x;
+        const uint32_t i = threadIdx.x + u * bdim;
         if (i < nw_load / 4) ((uint4 *)filter)[i] = img[u];
     }
-    for (uint32_t i = threadIdx.x + IMG * blockDim.x; i < nw_load / 4; i += blockDim.x) ((uint4 *)filter)[i] = img_src[i];
+    for (uint32_t i = threadIdx.x + IMG * bdim; i < nw_load / 4; i += bdim) ((uint4 *)filter)[i] = img_src[i];
     if (HAS_C && !img_kept) {
         const uint4 *src2 = (const uint4 *)(args.blob + args.t_off_c2bits);
-        for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) ((uint4 *)c2bits)[i] = src2[i];
+        for (uint32_t i = threadIdx.x; i < 512; i += bdim) ((uint4 *)c2bits)[i] = src2[i];
     }
     /* (two-phase: 64 bytes behind the tables hold the workgroup's progress sum, hsgpu_filter_lds_bytes) */
     uint32_t *wg_done = lds + nw + (HAS_C ? 2048 : 0);
@@ -1492,6 +1516,7 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
             write_block_hints_batch<HK>(args.off, args.nblocks, (uint32_t *)args.hint, args.n_hint, w0 * (64 * HK), lane);
     }
 #endif
+    if (FUSED && args.srv_inline_at && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[5] = wall_clock64(); /* (server: in front of the barrier) */
     __syncthreads();
     if ((!FUSED || args.solo) && args.wg_stamps && threadIdx.x == 0) args.wg_stamps[4 * blockIdx.x + 1] = wall_clock64();
 
@@ -1596,12 +1621,14 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
     /* the partial last tile: guarded, byte-wise where needed; the wavefront whose share would hold tile n_full
      * (the last one when the shares come out even). Bytes at/after the end of the corpus read as zero and
      * their lookup positions are masked off. */
-    if ((total & 1023) && wave_global == (per_wave ? min((uint64_t)n_waves - 1, n_full / per_wave) : 0)) {
+    if ((total & 1023) && wave_global == tail_wave) {
         const uint64_t coff = (n_full << 10) + lane_off;
         Chunk c;
         c.d = make_uint4(0, 0, 0, 0);
         c.h = make_uint2(0, 0);
-        if (coff < total) {
+        if (tail_early) {
+            c = ct;
+        } else if (coff < total) {
             if (coff + CHUNK <= total) {
                 c.d = *(const uint4 *)(corpus + coff);
             } else {
@@ -1629,7 +1656,7 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
          * last whole tile when the partial tile behind it belonged to the next wavefront.) The wavefront with the partial tile
          * asks at `total` when that is a lookup position, every other one at the first byte behind its tiles. */
         if (PAIR && HAS_B && lane == 0) {
-            const bool holds_tail = (total & 1023) && wave_global == (per_wave ? min((uint64_t)n_waves - 1, n_full / per_wave) : 0);
+            const bool holds_tail = (total & 1023) && wave_global == tail_wave;
             /* (the lookups sit on even positions: behind an odd total there is none to stand in for -- the end at total - 1 is even) */
             const uint64_t edge = holds_tail ? ((total & 1) ? 0 : total) : n_own ? (tile0 + n_own) << 10 : 0;
             if (edge) pair_edge_probe<false>(t, edge);
@@ -1637,7 +1664,7 @@ __device__ __forceinline__ bool hwlm_filter_body(const HsgpuScanArgs &args, uint
         if (args.solo && args.wg_stamps && wave == 0 && lane == 0) args.wg_stamps[4 * blockIdx.x + 2] = wall_clock64(); /* (wavefront 0's share confirmed) */
         /* ONE workgroup (the small-batch server; a solo scan of one super tile) whose wavefronts have staged everything they found
          * in LDS: placed from there (solo_place_lds) -- no region, no count and no control word goes through memory */
-        if (!(args.solo && gridDim.x == 1 && solo_place_lds(args, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)), WAVES, args.srv_inline_at ? lds + args.srv_inline_at : nullptr))) {
+        if (!(args.solo && gdim == 1 && solo_place_lds(args, (WaveLds *)(lds + nw + (HAS_C ? 2048 : 0)), WAVES, args.srv_inline_at ? lds + args.srv_inline_at : nullptr))) {
             publish_records(t, args, lane, wave_global);
             if (args.solo) solo_tail(args, lds, n_waves), image_used = true;
         }
@@ -1669,7 +1696,7 @@ template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool 
 __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filter_kernel(HsgpuScanArgs args) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
-    hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, FUSED, PAIR, WIDE>(args, lds);
+    hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, FUSED, PAIR, WIDE>(args, lds, blockDim.x, gridDim.x);
 }
 
 /* ---- the small-batch server (round 6) -----------------------------------------------------------------------------------
@@ -1696,10 +1723,16 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
                                                                                             const uint4 *src_off) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0) __builtin_trap();
-    /* the mailbox sits behind everything the body uses (runtime.hip sizes the launch: hsgpu_filter_lds_bytes + 128) */
+    /* the mailbox sits behind everything the body uses (runtime.hip sizes the launch: hsgpu_filter_lds_bytes + 192) */
+    uint32_t bdim = __builtin_amdgcn_readfirstlane(blockDim.x); /* read ONCE (hwlm_filter_body): opaque to the compiler, so kept, not loaded again per request */
+    asm volatile("" : "+s"(bdim));
     const uint32_t words = (uint32_t)(hsgpu_filter_words(args.t_flags, args.t_filter_log2) + ((args.t_flags & HSGPU_F_HAS_C) ? 2048u : 0u)) +
-                           (uint32_t)((blockDim.x >> 6) * sizeof(WaveLds) / 4);
-    volatile uint32_t *mail = lds + words; /* [0] seq, [1] command (0 go, 1 end), [2..7] total, nblocks, start; [16..31] the answer line */
+                           (uint32_t)((bdim >> 6) * sizeof(WaveLds) / 4);
+    /* (an LDS pointer by TYPE and not volatile: a volatile generic pointer compiled to flat loads at system scope, each with a wait
+     * of its own -- the request's nine words alone were ~0.6 us of serialised round trips behind the barrier; the barriers order
+     * every access below) */
+    typedef __attribute__((address_space(3))) uint32_t lds_rw_u32_t;
+    lds_rw_u32_t *mail = (lds_rw_u32_t *)(lds + words); /* [0] seq, [1] command (0 go, 1 end), [2..7] total, nblocks, start, [8] debug; [16..31] the answer line; [32..43] the stage stamps */
     /* Everything around the barriers is WAVE-UNIFORM control flow (scalar branches on values made scalar with readfirstlane):
      * wavefront 0 polls as a whole. (The first version polled in `if (threadIdx.x == 0)`, a thread-divergent loop in front of
      * the barrier: the structurised code ran the loop's barriers a different number of times in wavefront 0 and in the others,
@@ -1729,7 +1762,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
                 __builtin_amdgcn_s_sleep(2);
             }
             /* (HsgpuServerCtl: dwords 2 .. 7 = total, nblocks, start) */
-            if (lane < 8) mail[lane] = lane == 0 ? seq : lane == 1 ? cmd : cmd ? 0u : line;
+            if (lane < 9) mail[lane] = lane == 0 ? seq : lane == 1 ? cmd : cmd ? 0u : line; /* ([8]: the request's debug flag) */
             if (lane == 31) mail[lane] = 0; /* the answer line's "records inside" flag (solo_place_lds) */
         }
         __syncthreads();
@@ -1747,23 +1780,27 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
         if (!stage) a.corpus = (const uint8_t *)src_corpus, a.off = (const uint64_t *)src_off;
         /* what the host wrote into the mapped area since the last request must not come out of this CU's caches */
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        const unsigned long long t_seen = wall_clock64();
+        const bool dbg = __builtin_amdgcn_readfirstlane(mail[8]) != 0; /* stamps only when asked for: a clock read is a scalar memory operation the wavefront waits for */
+        const unsigned long long t_seen = dbg ? wall_clock64() : 0;
         /* The batch comes over the bus ONCE: offsets and corpus are copied from the mapped area into device memory by the whole
          * workgroup (16 bytes per lane and pass, every request in flight at once), and the scan runs on the copy -- the block
          * hints' two search rounds, the tiles and every match's offsets were a bus round trip each when read in place. */
         if (stage) {
             const uint32_t n16 = (uint32_t)((a.total + 15) >> 4), o16 = (uint32_t)(((a.nblocks + 1) * 8 + 15) >> 4);
-            for (uint32_t i = threadIdx.x; i < n16 + o16; i += blockDim.x) {
+            for (uint32_t i = threadIdx.x; i < n16 + o16; i += bdim) {
                 if (i < n16) ((uint4 *)a.corpus)[i] = src_corpus[i];
                 else ((uint4 *)a.off)[i - n16] = src_off[i - n16];
             }
             __syncthreads(); /* (the same compute unit wrote it: the barrier's workgroup-scope release / acquire is enough) */
         }
-        const unsigned long long t_copied = wall_clock64();
+        const unsigned long long t_copied = dbg ? wall_clock64() : 0;
         a.img_keep_words = img_keep;
         a.srv_inline_at = words + 16;
-        a.wg_stamps = ctl->stamps; /* the request's stages: start, image staged, wavefront 0 confirmed, placed (hsgpu_debug_server_stamps) */
-        const bool image_used = hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, true, PAIR, WIDE>(a, lds);
+        /* the request's stages: start, image staged, wavefront 0 confirmed, placed (hsgpu_debug_server_stamps) -- stamped into LDS
+         * (a generic pointer) and sent with the answer: a store to host memory in the body is a bus write that the next barrier's
+         * wait for outstanding memory operations sits behind */
+        a.wg_stamps = dbg ? (unsigned long long *)(lds + words + 32) : nullptr;
+        const bool image_used = hwlm_filter_body<HAS_A, HAS_B, HAS_C, REPL, K2, S2, BLIND, true, PAIR, WIDE>(a, lds, bdim, 1u);
         img_keep = image_used ? SOLO_LDS_WORDS : 1u; /* the table image stays in LDS between requests; solo_tail's scratch was its head (1: nothing to load) */
         __syncthreads();
         const uint32_t inlined = __builtin_amdgcn_readfirstlane(mail[31]);
@@ -1779,7 +1816,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
             /* the answer: records (from LDS, <= 3), count (~0: in the mapped area), the request's stamps (100 MHz ticks: copy,
              * body) and the sequence number, the line's LAST dword: four lanes x 16 bytes, one store instruction, one 64-byte
              * write -- the 2.4 us of write-back and wait that a release in front of a separate done word cost are gone */
-            const unsigned long long t_end = wall_clock64();
+            const unsigned long long t_end = dbg ? wall_clock64() : 0;
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             u32x4 v;
             if (lane < 3) {
@@ -1787,8 +1824,9 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
             } else {
                 v[0] = inlined ? mail[28] : ~0u, v[1] = (uint32_t)(t_copied - t_seen), v[2] = (uint32_t)(t_end - t_copied), v[3] = seq;
             }
-            if (lane < 4) {
-                u32x4 *dst = (u32x4 *)ctl->done_rec + lane;
+            if (lane >= 4 && lane < 7) v[0] = mail[32 + 4 * (lane - 4)], v[1] = mail[33 + 4 * (lane - 4)], v[2] = mail[34 + 4 * (lane - 4)], v[3] = mail[35 + 4 * (lane - 4)];
+            if (lane < (dbg ? 7u : 4u)) { /* (lanes 4 .. 6: the six stage stamps, a line of their own -- debug, ordered with nothing) */
+                u32x4 *dst = lane < 4 ? (u32x4 *)ctl->done_rec + lane : (u32x4 *)ctl->stamps + (lane - 4);
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
             }
         }

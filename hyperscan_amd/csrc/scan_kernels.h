@@ -111,13 +111,13 @@ struct HsgpuScanArgs {
 struct HsgpuServerCtl {
     uint32_t req_seq, stop;                       /* host -> device */
     uint64_t total, nblocks, start;               /* ... the request (written before req_seq) */
-    uint32_t pad0[8];
+    uint32_t debug, pad0[7];                      /* debug: stamp the request's stages (hsgpu_debug_server_stamping; each stamp is a clock read the wavefront waits for) */
     uint64_t pad1[8];
     uint32_t done_rec[4 * HSGPU_SRV_INLINE_RECS]; /* device -> host: hsgpu_match_t x 3 */
     uint32_t done_count, done_copy_ticks, done_body_ticks, done_seq;
     uint32_t exited, pad3;
-    unsigned long long stamps[4];                 /* hsgpu_debug_server_stamps */
-    uint32_t pad4[6];
+    unsigned long long stamps[6];                 /* hsgpu_debug_server_stamps: the body's four stages; [4] first loads out, [5] in front of the first barrier */
+    uint32_t pad4[2];
 };
 static_assert(sizeof(HsgpuServerCtl) == 256 && offsetof(HsgpuServerCtl, done_rec) == 128 && offsetof(HsgpuServerCtl, done_seq) == 188 &&
                   offsetof(HsgpuServerCtl, exited) == 192,
@@ -126,7 +126,7 @@ static_assert(sizeof(HsgpuServerCtl) == 256 && offsetof(HsgpuServerCtl, done_rec
 const void *hsgpu_filter_kernel_for(uint32_t table_flags, bool fused);
 /* the resident small-batch server with the fused kernel's body (scan_device.h, hwlm_server_kernel; nullptr: none for this table):
  * launched with (HsgpuScanArgs, HsgpuServerCtl *ctl, HsgpuServerCtl *req, unsigned long long idle_ticks, const uint4 *src_corpus, const uint4 *src_off), ONE
- * workgroup, hsgpu_filter_lds_bytes(fused) + 128 of LDS; src_*: where the host puts a request's batch (mapped memory) -- copied to
+ * workgroup, hsgpu_filter_lds_bytes(fused) + 192 of LDS; src_*: where the host puts a request's batch (mapped memory) -- copied to
  * args.corpus / args.off (device memory) at the head of every request */
 const void *hsgpu_server_kernel_for(uint32_t table_flags);
 const void *hsgpu_confirm_kernel_for(uint32_t table_flags, bool dense); /* dense: the folded pipeline's kernel for dense scans (fold == 2) */

@@ -139,7 +139,8 @@ void hsgpu_scratch_free(hsgpu_scratch_t *s);
  * may be NULL). */
 int hsgpu_scratch_enable_server(hsgpu_scratch_t *s, int enable, unsigned idle_us /* 0: keep */);
 int hsgpu_scratch_server_stats(hsgpu_scratch_t *s, uint64_t *calls, uint64_t *launches, int *live);
-/* the last request's device-side times: the batch's copy over the bus, the scan itself (device wall clock, microseconds) */
+/* the last request's device-side times: the batch's copy over the bus, the scan itself (device wall clock, microseconds); taken
+ * for requests made while hsgpu_debug_server_stamping (include/hsgpu_tuning.h) is on, zero otherwise */
 int hsgpu_scratch_server_last_us(hsgpu_scratch_t *s, float *copy_us, float *scan_us);
 
 /* hwlmExec (src/hwlm/hwlm.h:116-118, src/hwlm/hwlm.c:172-199), argument for argument: scan one host

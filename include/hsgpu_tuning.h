@@ -48,6 +48,12 @@ int hsgpu_scratch_set_tuning(hsgpu_scratch_t *s, int fused_only, unsigned wg_thr
  * table image and first tiles in place, us[1] -> wavefront 0 has filtered and confirmed its share, us[2] -> records placed and count
  * written. (hsgpu_scratch_server_last_us, include/hsgpu.h: the request as a whole.) */
 int hsgpu_debug_server_stamps(hsgpu_scratch_t *s, float *us /* [3] */);
+/* The stamps (and hsgpu_scratch_server_last_us's times) are taken only for requests made while stamping is on (off by default:
+ * every stamp is a clock read the wavefront waits for, ~0.1 us each of a ~5 us request). */
+int hsgpu_debug_server_stamping(hsgpu_scratch_t *s, int on);
+/* ... and inside the first stage, from the body's start: us[0] -> the first tiles' (and the partial last tile's) loads are issued,
+ * us[1] -> wavefront 0 stands in front of the body's first barrier (the rest of the stage is the wait for the loads). */
+int hsgpu_debug_server_head_stamps(hsgpu_scratch_t *s, float *us /* [2] */);
 /* hsgpu_hwlm_exec `calls` times in a row from native code, as hsbench walks its blocks (tools/hsbench/engine_hyperscan.cpp:132-145);
  * *us_per_call = the mean: what a C caller pays per call (a Python ctypes call costs ~1 us by itself). Stops at the first call
  * that does not return HSGPU_HWLM_SUCCESS and returns its code. */

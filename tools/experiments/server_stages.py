@@ -26,6 +26,8 @@ ncb = C.c_uint64(0)
 count_cb = C.cast(lib.hsgpu_hwlm_count_cb, hw.HWLM_CB)
 lib.hsgpu_scratch_set_context(s._h, C.addressof(ncb))
 lib.hsgpu_debug_server_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+lib.hsgpu_debug_server_head_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+lib.hsgpu_debug_server_stamping.argtypes = [C.c_void_p, C.c_int]
 lib.hsgpu_scratch_server_last_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
 p, n = pkt.ctypes.data, pkt.size
 
@@ -44,11 +46,17 @@ for kind in (2, 1, 2, 1):
     s.enable_server(kind)
     ncb.value = 0
     us = per_call()
+    lib.hsgpu_debug_server_stamping(s._h, 1)  # (the stamps cost: taken on a few calls of their own)
+    us_stamped = per_call(300)
+    lib.hsgpu_debug_server_stamping(s._h, 0)
     st = (C.c_float * 3)()
     lib.hsgpu_debug_server_stamps(s._h, st)
     cu, su = C.c_float(), C.c_float()
     lib.hsgpu_scratch_server_last_us(s._h, C.byref(cu), C.byref(su))
-    print(f"server, mailbox {'in device memory (BAR)' if kind == 1 else 'in mapped host memory'}: {us:.2f} us per call ({ncb.value / 3020:.1f} matches); on the device "
+    hd = (C.c_float * 2)()
+    lib.hsgpu_debug_server_head_stamps(s._h, hd)
+    print(f"  head: loads out at {hd[0]:.2f} us, in front of the barrier at {hd[1]:.2f} us")
+    print(f"server, mailbox {'in device memory (BAR)' if kind == 1 else 'in mapped host memory'}: {us:.2f} us per call ({us_stamped:.2f} with stamps; {ncb.value / 3340:.1f} matches); on the device "
           f"{su.value:.2f} us: image + first tiles {st[0]:.2f}, filter + confirm {st[1]:.2f}, placement {st[2]:.2f}; stats {s.server_stats()}")
 s.enable_server(False)
 s.close()
