@@ -648,6 +648,7 @@ static unsigned filter_wg_threads(const HsgpuTableHeader *h, const hsgpu_scratch
 
 /* ---- the small-batch server: host side (scan_device.h, hwlm_server_kernel) ------------------------------------------------ */
 /* the request lines of the mailbox as the host writes them: in the BAR area when the live server reads them there */
+constexpr uint32_t SRV_POISON_COUNT = ~0u - 1u;
 static inline HsgpuServerCtl *server_req(hsgpu_scratch *s) { return s->srv_req_bar ? s->bar_ctl : s->h_srv; }
 static inline void bar_flush() {
 #if defined(__x86_64__)
@@ -1221,6 +1222,10 @@ static int server_call(const hsgpu_hwlm *t, hsgpu_scratch *s, uint64_t total, si
     int rv;
     HsgpuServerCtl *c = s->h_srv, *q = server_req(s);
     const uint32_t seq = ++s->srv_seq;
+    /* the answer line poisoned: should its 64 bytes ever arrive in pieces (they are one store, one bus write), a piece that is not
+     * there yet shows -- no literal has index ~0, no count is ~0 - 1 -- and scan_host_small waits for it */
+    c->done_count = SRV_POISON_COUNT;
+    for (int i = 0; i < HSGPU_SRV_INLINE_RECS; i++) c->done_rec[4 * i + 3] = ~0u;
     if (q != c) c->total = total, c->nblocks = nblocks, c->start = start, c->debug = s->srv_debug, c->req_seq = seq; /* (what a restarted server is told: server_start) */
     q->total = total, q->nblocks = nblocks, q->start = start, q->debug = s->srv_debug;
     bar_flush(); /* the batch (scan_host_small) and the parameters are out before the sequence number */
@@ -1288,7 +1293,19 @@ static int scan_host_small(const hsgpu_hwlm *t, hsgpu_scratch *s, const uint8_t 
     if (served && (rv = server_call(t, s, total, nblocks, start)) < 0) return rv;
     if (served) {
         /* the answer line (HsgpuServerCtl): up to three records came with the sequence number; ~0: count and records are in the mapped area */
-        const uint32_t n_line = *(volatile uint32_t *)&s->h_srv->done_count;
+        uint32_t n_line;
+        for (unsigned spin = 0;; spin++) { /* (see server_call: whole on the first look unless the line came in pieces) */
+            n_line = __atomic_load_n(&s->h_srv->done_count, __ATOMIC_ACQUIRE);
+            bool whole = n_line != SRV_POISON_COUNT;
+            for (uint32_t i = 0; whole && n_line <= HSGPU_SRV_INLINE_RECS && i < n_line; i++) /* (~0: count and records are in the mapped area) */
+                whole = __atomic_load_n(&s->h_srv->done_rec[4 * i + 3], __ATOMIC_ACQUIRE) != ~0u;
+            if (whole) break;
+            if (spin > 100000000u) {
+                hsgpu_set_error("the small-batch server's answer line stayed incomplete");
+                server_stop(s);
+                return HSGPU_UNKNOWN_ERROR;
+            }
+        }
         if (n_line <= HSGPU_SRV_INLINE_RECS) {
             recs.resize(n_line);
             if (n_line) memcpy(recs.data(), (const void *)s->h_srv->done_rec, n_line * sizeof(hsgpu_match_t));

@@ -310,3 +310,53 @@ def test_small_batch_server_mailbox_switches():
         assert s.server_stats()[0] == served
     s.close()
     t.close()
+
+
+@pytest.mark.parametrize("mailbox", [1, 2])
+def test_small_batch_server_answer_line(mailbox):
+    """The server's answer line (scan_kernels.h, HsgpuServerCtl): a request with up to three records gets them back WITH its
+    sequence number in one 64-byte store; four and more go through the mapped area. Packets with exactly 0 .. 6 matches, several
+    hundred requests in a row with every packet new (a stale or torn line would deliver the records of the request before), one
+    block per call and a few blocks per call, `start` > 0, and the stage stamps switched on and off in between -- each against the
+    oracle, ends and ids in delivery order."""
+    from tests import oracle_binding as ob
+
+    rng = np.random.default_rng(77 + mailbox)
+    lits = [H.HwlmLiteral(b"needle", id=11), H.HwlmLiteral(b"HayStack", nocase=True, id=12), H.HwlmLiteral(b"zq7", id=13)]
+    lits += random_literals(rng, 300, 5, 8)
+    t = H.hwlm_build(lits)
+    oracle = ob.Oracle(lits)
+    s = H.Scratch(0)
+    s.enable_server(mailbox, idle_us=2000)
+    lib = t._lib
+    lib.hsgpu_debug_server_stamping.argtypes = [C.c_void_p, C.c_int]
+    alphabet = np.frombuffer(b"0123456789 .,;:-_", dtype=np.uint8)
+    plant = [b"needle", b"haystack", b"zq7", b"HAYSTACK", b"needle"]
+    seen = {k: 0 for k in range(7)}
+    for rnd in range(420):
+        if rnd % 70 == 0:
+            lib.hsgpu_debug_server_stamping(s._h, (rnd // 70) & 1)
+        n = int(rng.integers(40, 1500))
+        pkt = rng.choice(alphabet, n).astype(np.uint8)
+        k = int(rng.integers(0, 7))
+        for j in range(k):  # k planted literals on slots of their own (one may still be cut by the packet's end: counted below)
+            p = (n // max(k, 1)) * j
+            w = np.frombuffer(plant[(rnd + j) % len(plant)], dtype=np.uint8)
+            if p + w.size <= n:
+                pkt[p:p + w.size] = w
+        start = int(rng.integers(0, 9)) if rnd % 5 == 0 else 0
+        want = oracle.collect(pkt, start)
+        got = []
+        assert H.hwlm_exec(t, pkt, start, lambda e, i, c: got.append((e, i)) or H.HWLM_CONTINUE_MATCHING, s) == H.HWLM_SUCCESS
+        assert [e for e, _ in got] == sorted(e for e, _ in got), (rnd, "delivery order")
+        assert sorted(got) == sorted(want), (rnd, k, n, start)
+        seen[min(len(want), 6)] += 1
+        if rnd % 9 == 0:  # a few blocks per call: the staged path, the same answer line
+            from tests.util import as_set, random_blocks
+            off = random_blocks(rng, n, mean_len=max(2, n // 3))
+            assert as_set(hw.hwlm_exec_batch(t, s, pkt, off)) == as_set(oracle.collect_blocks(pkt, off)), (rnd, "batch")
+    calls, launches, _live = s.server_stats()
+    assert calls >= 420 and launches <= 8, (calls, launches)
+    assert all(seen[k] >= 10 for k in range(5)), seen  # (both sides of the line's three records)
+    s.close()
+    t.close()
