@@ -1717,6 +1717,12 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_filte
  * PCIe BAR (runtime.hip, bar_area): the poll and the batch's tiles are then local reads -- a 1.5 KB request's round trip through
  * one wavefront is 4.4 us instead of 10.5 (tools/experiments/bar_mailbox.hip) --, `ctl` (done_seq, exited, stamps), records and
  * count stay in mapped host memory, which the host polls and reads at memory speed. */
+#ifndef HSGPU_SRV_ACQUIRE_SCOPE
+#define HSGPU_SRV_ACQUIRE_SCOPE "" /* system (tuning builds: "agent" -- the vector L1 alone) */
+#endif
+#ifndef HSGPU_SRV_POLL_SLEEP
+#define HSGPU_SRV_POLL_SLEEP 2
+#endif
 template <bool HAS_A, bool HAS_B, bool HAS_C, bool REPL, bool K2, bool S2, bool BLIND, bool PAIR = false, bool WIDE = false>
 __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_server_kernel(HsgpuScanArgs args, HsgpuServerCtl *ctl, HsgpuServerCtl *req,
                                                                                             unsigned long long idle_ticks, const uint4 *src_corpus,
@@ -1759,7 +1765,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
                     cmd = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(HSGPU_SRV_POLL_SLEEP);
             }
             /* (HsgpuServerCtl: dwords 2 .. 7 = total, nblocks, start) */
             if (lane < 9) mail[lane] = lane == 0 ? seq : lane == 1 ? cmd : cmd ? 0u : line; /* ([8]: the request's debug flag) */
@@ -1779,7 +1785,7 @@ __global__ __launch_bounds__(WG_THREADS, HSGPU_FILTER_MIN_WAVES) void hwlm_serve
         const bool stage = a.nblocks != 1;
         if (!stage) a.corpus = (const uint8_t *)src_corpus, a.off = (const uint64_t *)src_off;
         /* what the host wrote into the mapped area since the last request must not come out of this CU's caches */
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, HSGPU_SRV_ACQUIRE_SCOPE);
         const bool dbg = __builtin_amdgcn_readfirstlane(mail[8]) != 0; /* stamps only when asked for: a clock read is a scalar memory operation the wavefront waits for */
         const unsigned long long t_seen = dbg ? wall_clock64() : 0;
         /* The batch comes over the bus ONCE: offsets and corpus are copied from the mapped area into device memory by the whole
