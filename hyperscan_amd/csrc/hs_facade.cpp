@@ -1140,6 +1140,23 @@ hs_error_t hs_free_scratch(hs_scratch_t *scratch) {
     return HS_SUCCESS;
 }
 
+/* include/hs_gpu.h: the small-batch server of the scratch's device side (csrc/runtime.hip, hsgpu_scratch_enable_server) */
+hs_error_t hs_scratch_enable_small_batch_server(hs_scratch_t *scratch, int enable, unsigned int idle_us) {
+    if (!scratch || scratch->magic != 0x48534753 || enable < 0 || enable > 2) return HS_INVALID;
+    if (scratch->in_use) return HS_SCRATCH_IN_USE;
+    const int rv = hsgpu_scratch_enable_server(scratch->gpu, enable, idle_us);
+    return rv == HSGPU_SUCCESS ? HS_SUCCESS : rv == HSGPU_NOMEM ? HS_NOMEM : HS_UNKNOWN_ERROR;
+}
+
+hs_error_t hs_scratch_small_batch_server_stats(hs_scratch_t *scratch, unsigned long long *calls, unsigned long long *launches) {
+    if (!scratch || scratch->magic != 0x48534753) return HS_INVALID;
+    uint64_t c = 0, l = 0;
+    if (hsgpu_scratch_server_stats(scratch->gpu, &c, &l, nullptr) != HSGPU_SUCCESS) return HS_UNKNOWN_ERROR;
+    if (calls) *calls = c;
+    if (launches) *launches = l;
+    return HS_SUCCESS;
+}
+
 /* The host confirm of a batch ("Rose-lite"): literal hits -> events, delivered in block order
  * on the calling thread. recs: sorted by (block, end), id = pattern index, as the literal
  * engine emits them. Returns 1 if some callback asked to stop (its block only), 0 if none did, -1

@@ -201,6 +201,27 @@ class HsScratch:
             _lib().hs_free_scratch(self._h)
             self._h = None
 
+    def enable_server(self, on=True, idle_us=0):
+        """hs_scratch_enable_small_batch_server (include/hs_gpu.h): hs_scan / hs_scan_batch calls of up to 16 KiB served by one
+        resident workgroup instead of a kernel launch per call (on = 2: the requests through mapped host memory)"""
+        f = _lib().hs_scratch_enable_small_batch_server
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+        rv = f(self._h, 2 if on == 2 else int(bool(on)), int(idle_us))
+        if rv != 0:
+            raise HsError(rv, "hs_scratch_enable_small_batch_server")
+
+    def server_stats(self):
+        """(calls served, server launches)"""
+        f = _lib().hs_scratch_small_batch_server_stats
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+        c, l = C.c_ulonglong(0), C.c_ulonglong(0)
+        rv = f(self._h, C.byref(c), C.byref(l))
+        if rv != 0:
+            raise HsError(rv, "hs_scratch_small_batch_server_stats")
+        return c.value, l.value
+
     def __del__(self):
         try:
             self.close()

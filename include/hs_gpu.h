@@ -244,6 +244,16 @@ hs_error_t hs_scan_batch_resident(const hs_database_t *db, const char *data, con
                                   unsigned long long nblocks, const void *d_corpus, const void *d_off, hs_scratch_t *scratch,
                                   hs_batch_event_handler onEvent, void *context);
 
+/* Extension: one hs_scan per block is hsbench's block mode (tools/hsbench/engine_hyperscan.cpp:132-145) and the reference serves a
+ * packet in about a microsecond; a kernel launch per call costs this engine ~20. With the small-batch server enabled on a scratch
+ * (include/hsgpu.h, hsgpu_scratch_enable_server: enable 1 -- requests through the PCIe BAR where the device has a large one --, 2
+ * -- through mapped host memory --, 0 off; idle_us: 0 keeps the default of 300) hs_scan / hs_scan_batch calls of up to 16 KiB are
+ * served by ONE resident workgroup without a launch: ~8 us per 1 460-byte call. The workgroup ends by itself when no call has come
+ * for idle_us and comes back with the next one; hs_free_scratch ends it. *_stats: calls served so far, server launches (either
+ * pointer may be NULL). HS_SCRATCH_IN_USE inside a callback. */
+hs_error_t hs_scratch_enable_small_batch_server(hs_scratch_t *scratch, int enable, unsigned int idle_us);
+hs_error_t hs_scratch_small_batch_server_stats(hs_scratch_t *scratch, unsigned long long *calls, unsigned long long *launches);
+
 /* Extension: only the host-side confirm of hs_scan_batch, over literal hits the caller supplies
  * (hsgpu_match_t records, include/hsgpu.h: sorted by (block, end); id = index of the branch, see
  * hs_database_literal; end = offset of the last byte of that branch's literal). Touches no

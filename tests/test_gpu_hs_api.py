@@ -234,3 +234,57 @@ def test_deserialize_database_at_places_a_header_the_api_follows():
     assert placed.serialize() == blob and placed.size() == db.size()
     placed.close()  # hs_free_database: releases the database proper, leaves the caller's buffer alone
     assert mem[0] & 0xffffffff == 0
+
+
+@pytest.mark.parametrize("mailbox", [1, 2])
+def test_hs_scan_per_packet_through_the_small_batch_server(mailbox):
+    """hs_scratch_enable_small_batch_server (include/hs_gpu.h): one hs_scan per packet -- hsbench's block mode,
+    tools/hsbench/engine_hyperscan.cpp:132-145 -- served by the scratch's resident workgroup: the same events as without it and as
+    one hs_scan_batch over all packets (literals, literal + regex tail, caseless, SOM), termination by the callback, packets above
+    the server's 16 KiB (a launch), arguments checked, hs_free_scratch with a server live."""
+    rng = np.random.default_rng(404 + mailbox)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789 ._-", dtype=np.uint8)
+    pats = [b"needle", b"hay[a-z]{2}ack", b"foo\\d+bar", b"zq7x", b"GET /[a-z]+", b"abc"]
+    flags = [0, hs.HS_FLAG_CASELESS, 0, hs.HS_FLAG_SOM_LEFTMOST, hs.HS_FLAG_CASELESS, hs.HS_FLAG_SINGLEMATCH]
+    ids = [10, 11, 12, 13, 14, 15]
+    plants = [b"needle", b"HAYstACK", b"foo123bar", b"zq7x", b"get /index", b"abcabc", b"hayzzack"]
+    db = hs.Database.compile(pats, flags, ids)
+    plain, served = hs.HsScratch(db), hs.HsScratch(db)
+    served.enable_server(mailbox, idle_us=2000)
+    packets = []
+    for k in range(160):
+        n = int(rng.integers(20, 1500)) if k % 40 else 20000  # (every 40th is too large for the server: a launch)
+        p = bytearray(rng.choice(alpha, n).tobytes())
+        for j in range(int(rng.integers(0, 5))):
+            w = plants[int(rng.integers(0, len(plants)))]
+            at = int(rng.integers(0, n - len(w)))
+            p[at:at + len(w)] = w
+        packets.append(bytes(p))
+    total_events = 0
+    for k, p in enumerate(packets):
+        a, b = collect(db, p, plain), collect(db, p, served)
+        assert a == b, (k, len(p))
+        total_events += len(a)
+    assert total_events > 100
+    calls, launches = served.server_stats()
+    assert calls >= 150 and launches <= 6, (calls, launches)
+    # ... and as one batch
+    off = np.concatenate([[0], np.cumsum([len(p) for p in packets])]).astype(np.uint64)
+    got = []
+    assert hs.scan_batch(db, b"".join(packets), off, plain, lambda blk, i, f, t: got.append((blk, i, f, t)) and False) == hs.HS_SUCCESS
+    per_call = [(k, i, f, t) for k, p in enumerate(packets) for i, f, t in collect(db, p, served)]
+    assert sorted(got) == sorted(per_call)
+    # termination: the callback's stop ends the scan (src/runtime.c:177-185)
+    hit = next(p for p in packets if len(collect(db, p, plain)) >= 2 and len(p) < 4000)
+    seen = []
+    assert hs.scan(db, hit, served, lambda i, f, t: seen.append(i) or True) == hs.HS_SCAN_TERMINATED
+    assert len(seen) == 1
+    lib = hs._lib()
+    assert lib.hs_scratch_enable_small_batch_server(None, 1, 0) == hs.HS_INVALID
+    assert lib.hs_scratch_enable_small_batch_server(served._h, 3, 0) == hs.HS_INVALID
+    served.enable_server(False)
+    assert collect(db, packets[1], served) == collect(db, packets[1], plain)
+    served.enable_server(mailbox)
+    assert collect(db, packets[2], served) == collect(db, packets[2], plain)
+    served.close()  # (a server is live: hs_free_scratch ends it)
+    plain.close()

@@ -62,7 +62,9 @@ def test_hsbench_end_to_end(tmp_path):
         blk = bytes(data[int(off[b]):int(off[b + 1])])
         want += len(re.findall(b"(?=needle)", blk)) + len(re.findall(b"(?i)(?=hay)", blk)) + len(re.findall(b"(?=stack)", blk))
     env = dict(os.environ, PYTHONPATH=ROOT)
-    for extra in ([], ["--literal-on"], ["--literal-on", "--resident"]):
+    # (the last two: the reference's own loop -- one hs_scan per block -- with a launch per call and through the small-batch server)
+    for extra in ([], ["--literal-on"], ["--literal-on", "--resident"], ["--one-scan-per-block"], ["--one-scan-per-block", "--server", "1"],
+                  ["--literal-on", "--one-scan-per-block", "--server", "2"]):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hsbench.py"), "-e", str(pats), "-c", corpus_db,
                               "-N", "-n", "3"] + extra, capture_output=True, text=True, env=env, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
@@ -75,3 +77,6 @@ def test_hsbench_end_to_end(tmp_path):
         assert int(m.group(1)) == want, (extra, out.stdout)
         assert f"({off.size - 1} blocks)" in out.stdout
         assert "INCONSISTENT" not in out.stdout
+        if "--server" in extra:
+            m = re.search(r"Small-batch server:\s+(\d+) calls served, (\d+) server launches", out.stdout)
+            assert m and int(m.group(1)) >= 3 * (off.size - 1) and int(m.group(2)) <= 3, out.stdout

@@ -18,7 +18,8 @@ output lines as the reference's benchmarker (tools/hsbench/main.cpp), block mode
 What is timed: the default is the whole hs_scan_batch call per repeat (H2D of the corpus,
 GPU literal scan, D2H of records, host confirm, counting callback). `--resident` keeps the
 corpus in HBM and times the device pipeline alone (pure-literal pattern sets only) -- the
-figure bench.py reports. Also: `--make-corpus KIND -o FILE --mib M` writes a synthetic corpus
+figure bench.py reports. `--one-scan-per-block` is the reference's own loop (one hs_scan per block), `--server 1|2` with the
+scratch's small-batch server (include/hs_gpu.h) serving those calls without a launch each. Also: `--make-corpus KIND -o FILE --mib M` writes a synthetic corpus
 in the same SQLite format (packets | lines), usable by the reference's hsbench as well."""
 import argparse
 import ctypes as C
@@ -145,6 +146,10 @@ def main(argv=None):
     ap.add_argument("--per-scan", action="store_true")
     ap.add_argument("--echo-matches", action="store_true")
     ap.add_argument("--resident", action="store_true", help="corpus resident in HBM, device pipeline only")
+    ap.add_argument("--one-scan-per-block", action="store_true",
+                    help="the reference's own call pattern in block mode: one hs_scan per block (engine_hyperscan.cpp:132-145) instead of one hs_scan_batch per repeat")
+    ap.add_argument("--server", type=int, default=0, choices=[0, 1, 2],
+                    help="hs_scratch_enable_small_batch_server on the scratch (1: requests through the PCIe BAR, 2: through mapped host memory)")
     ap.add_argument("--make-corpus", choices=["packets", "lines"])
     ap.add_argument("-o", dest="out")
     ap.add_argument("--mib", type=float, default=64.0)
@@ -246,6 +251,34 @@ def main(argv=None):
             one()
             torch.cuda.synchronize()
             results.append((time.perf_counter() - t0, int(d_count.item())))
+    elif a.one_scan_per_block:
+        # the reference's loop (engine_hyperscan.cpp:132-145): hs_scan per block, a counting callback. (Driven from Python:
+        # ~1.5 us of ctypes per call on top of the call itself.)
+        if a.server:
+            scratch.enable_server(a.server)
+        cnt = [0]
+
+        def on_match(_id, _from, _to, _flags, _ctx):
+            cnt[0] += 1
+            return 0
+        cb = hs.MATCH_CB(on_match)
+        base = corpus.ctypes.data
+        starts = [base + int(o) for o in off[:-1]]
+        lens = [int(n) for n in np.diff(off.astype(np.int64))]
+        scan = lib.hs_scan
+        scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, hs.MATCH_CB, C.c_void_p]
+        for _ in range(a.repeats):
+            cnt[0] = 0
+            t0 = time.perf_counter()
+            for p, n in zip(starts, lens):
+                rv = scan(db._h, p, n, 0, scratch._h, cb, None)
+                if rv != 0:
+                    print(f"Fatal error: hs_scan returned error {rv}")
+                    return 1
+            results.append((time.perf_counter() - t0, cnt[0]))
+        if a.server:
+            calls, launches = scratch.server_stats()
+            print(f"Small-batch server:        {calls} calls served, {launches} server launches")
     else:
         handler = C.cast(lib.hs_batch_count_handler, hs.BATCH_CB)
         echo = None
