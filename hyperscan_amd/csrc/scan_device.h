@@ -1900,6 +1900,13 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
     if (!n) return;
     /* folded pipeline: the regions are consecutive sorted runs of the corpus -- gathered straight into place */
     const bool in_lds = !args.fold && n <= SORT_LDS;
+    if (runs) {
+        /* the share's run tables into LDS, once (buf is free in the folded pipeline): read from memory per RECORD -- the count, then
+         * descriptor after descriptor, then the record: a chain of dependent round trips in front of every store -- the flood
+         * corpus' gather took 0.21 ms for 537 MB, twice what the writes take (uniform: every wavefront holds the same fills) */
+        for (uint32_t k = tid; k < nreg * HSGPU_RUN_STRIDE; k += NT) buf[k] = args.run_tab[(uint64_t)first * HSGPU_RUN_STRIDE + k];
+        __syncthreads();
+    }
     /* gather: every lane walks the share's records: which region, which slot (front records, then the ones
      * spilled to the back) */
     for (uint32_t i = tid; i < n + ((64 - n % 64) % 64); i += NT) { /* whole wavefronts: shuffles below */
@@ -1911,7 +1918,7 @@ __device__ __forceinline__ void sort_share(const HsgpuScanArgs &args, uint4 *buf
             if (runs) {
                 /* record j of the region: staged at j less the records that the runs in front of it stand for -- or one of those: the
                  * run's lookup 0 has the record, `end` moves on by the run's step per lookup (position-major: delivery order) */
-                const uint4 *rt = args.run_tab + (uint64_t)(first + r) * HSGPU_RUN_STRIDE;
+                const uint4 *rt = buf + r * HSGPU_RUN_STRIDE;
                 const uint32_t nr = min(rt[0].x, (uint32_t)HSGPU_RUN_MAX);
                 uint32_t at_staged = j, skipped = 0, add = 0;
                 for (uint32_t k = 1; k <= nr; k++) {
