@@ -1251,7 +1251,7 @@ def run_flood(args):
            "matches_per_step": int(n), "matches_per_s": round(n / dt, 1), "record_bytes_per_step": int(n) * REC_BYTES,
            "candidate_overflow_scans": int(over), "record_capacity": int(cap),
            "stages_ms": {"filter": round(f_ms, 3), "confirm_place_copy": round(c_ms, 3), "pipeline": round(p_ms, 3),
-                         "gaps": round(dt * 1e3 - p_ms, 3)},
+                         "gather_and_gaps": round(dt * 1e3 - p_ms, 3)},  # (pipeline = filter start -> the gather's start: the rest of a step is record_sort_kernel expanding the runs, ~6 us of gaps)
            "pipeline": "folded, dense: every chunk has a candidate entry; dense batches confirmed position by position, emitted in order",
            "parity": f"count exact ({n}); (end, id) of block 0 ({len(want)} matches) identical to the reference, delivery order checked",
            "table": job.table.info()}
