@@ -24,7 +24,10 @@ import ctypes as C
 lib = t._lib
 cu, su = C.c_float(), C.c_float()
 lib.hsgpu_scratch_server_last_us.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-os.environ["HSGPU_SERVER_DEBUG"] = "1"
+lib.hsgpu_debug_server_stamping.argtypes = [C.c_void_p, C.c_int]
+lib.hsgpu_debug_server_stamping(s._h, 1)  # (the device-side times are taken only for requests made while stamping is on)
+H.hwlm_exec(t, pkt, 0, lambda e, i, c: H.HWLM_CONTINUE_MATCHING, s)
+lib.hsgpu_debug_server_stamping(s._h, 0)
 lib.hsgpu_scratch_server_last_us(s._h, C.byref(cu), C.byref(su))
 print("device copy us", cu.value, "scan us", su.value, flush=True)
 print("closing", flush=True)
