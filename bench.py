@@ -1554,6 +1554,44 @@ def run_batch_sweep(args):
            "half_peak_batch_bytes": reach(0.5), "ninety_percent_batch_bytes": reach(0.9), "curve": curve}
     del job
     torch.cuda.empty_cache()
+    # ... and the same packet through the PUBLIC API: hs_scan per call (literal scan + host confirm + callback), the scratch's
+    # small-batch server off and on (include/hs_gpu.h, hs_scratch_enable_small_batch_server); a ctypes loop (~1 us of its own per
+    # call). Beside the figures above, never one of them; a failure here is reported, not raised.
+    try:
+        from hyperscan_amd import hs
+
+        db = hs.Database.compile_lit([l.s for l in lits], [hs.HS_FLAG_CASELESS if l.nocase else 0 for l in lits], list(range(len(lits))))
+        sc = hs.HsScratch(db)
+        n_ev = [0]
+
+        def on_ev(_i, _f, _t, _fl, _c):
+            n_ev[0] += 1
+            return 0
+        cb = hs.MATCH_CB(on_ev)
+        hlib = hs._lib()
+        hlib.hs_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, hs.MATCH_CB, C.c_void_p]
+
+        def hs_per_call(n):
+            for _ in range(20):
+                assert hlib.hs_scan(db._h, p_blk, n_blk, 0, sc._h, cb, None) == 0
+            n_ev[0] = 0
+            t0 = time.perf_counter()
+            for _ in range(n):
+                hlib.hs_scan(db._h, p_blk, n_blk, 0, sc._h, cb, None)
+            return (time.perf_counter() - t0) / n * 1e6, n_ev[0] / n
+        us_hs_launch, ev_launch = hs_per_call(300)
+        sc.enable_server(True)
+        us_hs_server, ev_server = hs_per_call(2000)
+        hs_calls, hs_launches = sc.server_stats()
+        sc.close()
+        assert ev_launch == ev_server, "hs_scan through the server delivers other events than with a launch per call"
+        res["hs_scan_per_call_1460B"] = {"us_launch_per_call": round(us_hs_launch, 1), "us_server": round(us_hs_server, 1), "events_per_call": ev_server,
+                                         "server_calls": hs_calls, "server_launches": hs_launches,
+                                         "what": "hs_scan (public API: literal scan + host confirm + callback) on the same packet, a ctypes loop"}
+    except AssertionError:
+        raise
+    except Exception as e:  # noqa: BLE001
+        res["hs_scan_per_call_1460B"] = {"error": f"{type(e).__name__}: {e}"}
     return res
 
 
@@ -1593,7 +1631,7 @@ def compact_also(name, r):
     if name == "virtual_ranks":  # (its figures are in multi_gpu.loopback; the whole object is in the details file)
         return {"n_ranks": r["n_ranks"], "scan_ms": r["scan_ms"], "in_line_as": "multi_gpu.loopback"}
     keep = ("value", "unit", "ms_per_step", "ms", "matches_per_step", "matches", "parity", "gpu_stage", "host_confirm", "resident_end_to_end",
-            "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "us_per_hwlm_exec_call_1460B_launch_path", "server", "GBps_one_block_per_call",
+            "pinned_h2d_GBps", "class_stage", "sequence_stage", "stages_ms", "us_per_hwlm_exec_call_1460B", "us_per_hwlm_exec_call_1460B_launch_path", "server", "hs_scan_per_call_1460B", "GBps_one_block_per_call",
             "half_peak_batch_bytes", "ninety_percent_batch_bytes", "curve", "parity_whole_corpus", "parity_reference", "note")
     out = {"workload": _short(r.get("workload", name), 110)}
     for k in keep:
